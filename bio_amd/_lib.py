@@ -1,0 +1,84 @@
+"""ctypes loader for libbiosketch.so (include/biosketch.h).
+
+The shared object is built in-tree by ``__graft_entry__.build()`` /
+``make -C bio_amd/csrc``.  There is no Python or CPU implementation behind it:
+if the library is missing or no gfx950 device is visible every compute entry
+raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libbiosketch.so")
+
+# bsk_err (include/biosketch.h) -- the first eleven are the reference's sentinel errors
+OK = 0
+ERR_INVALID_K, ERR_EMPTY_SEQ, ERR_SHORT_SEQ, ERR_ILLEGAL_BASE, ERR_K_TOO_LARGE = 1, 2, 3, 4, 5
+ERR_INVALID_M, ERR_INVALID_SCALE, ERR_INVALID_S, ERR_INVALID_W, ERR_BUF_NIL, ERR_BUF_NOT_EMPTY = 6, 7, 8, 9, 10, 11
+ERR_ARG, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED, ERR_NO_DEVICE = 64, 65, 66, 67, 68
+
+KMER, NTHASH, SIMHASH, MINIMIZER, SYNCMER, PROT_HASH, PROT_MINIMIZER = 1, 2, 3, 4, 5, 6, 7
+ALPHA_DNA, ALPHA_PROTEIN = 0, 1
+
+ST_OK, ST_SHORT, ST_ILLEGAL, ST_CODE_MASK = 0x00, 0x01, 0x02, 0x0F
+ST_FIRST_WINDOW_TIE, ST_HAS_NON_ACGT = 0x10, 0x20
+POS_STRAND_BIT, POS_MASK = 0x80000000, 0x7FFFFFFF
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("kind", "k", "w", "s", "m", "scale", "canonical", "circular", "codon_table", "frame")]
+
+
+# every symbol include/biosketch.h declares: (name, restype, argtypes)
+_vp = C.c_void_p
+_pp = C.POINTER(C.c_void_p)
+_u64p = C.POINTER(C.c_uint64)
+SYMBOLS = [
+    ("bsk_abi_version", C.c_int, []),
+    ("bsk_device_count", C.c_int, [C.POINTER(C.c_int)]),
+    ("bsk_ctx_create", C.c_int, [C.c_int, _pp]),
+    ("bsk_ctx_destroy", None, [_vp]),
+    ("bsk_ctx_sync", C.c_int, [_vp]),
+    ("bsk_last_error", C.c_char_p, [_vp]),
+    ("bsk_err_name", C.c_char_p, [C.c_int]),
+    ("bsk_batch_from_ascii", C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_int, _pp]),
+    ("bsk_batch_from_packed", C.c_int, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, _pp]),
+    ("bsk_batch_synth", C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint32, C.c_uint64, _pp]),
+    ("bsk_batch_info", C.c_int, [_vp, _u64p, _u64p, _u64p, _u64p]),
+    ("bsk_batch_fetch_ascii", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, _vp]),
+    ("bsk_batch_destroy", None, [_vp]),
+    ("bsk_sketch", C.c_int, [_vp, _vp, C.POINTER(Params), _pp]),
+    ("bsk_sketch_timed", C.c_int, [_vp, _vp, C.POINTER(Params), _pp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    ("bsk_result_info", C.c_int, [_vp, _u64p, _u64p, C.POINTER(C.c_int)]),
+    ("bsk_result_fetch", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp, C.c_uint64]),
+    ("bsk_result_device", C.c_int, [_vp, _pp, _pp, _pp, _pp]),
+    ("bsk_result_digest", C.c_int, [_vp, _vp, _u64p, _u64p, _u64p]),
+    ("bsk_result_release", None, [_vp]),
+]
+
+_lib = None
+
+
+class BiosketchUnavailable(RuntimeError):
+    pass
+
+
+def load():
+    """Load libbiosketch.so and bind every ABI symbol.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise BiosketchUnavailable(
+            f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(SO_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,980 @@
+// biosketch.hip -- C ABI (include/biosketch.h) of the MI355X k-mer sketching engine.
+// Host side: contexts, batches (device-resident 2-bit packed reads), results
+// (device-resident CSR tuples) and the kernel dispatch.  gfx950 only; there is no
+// CPU implementation behind this ABI: without a device every compute entry fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "biosketch.h"
+#include "kernels_generic.hpp"
+#include "kernels_fast.hpp"
+
+using namespace bsk;
+
+// ------------------------------------------------------------------------------------
+struct bsk_ctx {
+    int device = 0;
+    int cus = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // per-launch synchronisation scratch
+    u32 *d_ticket = nullptr;    // [2]
+    u64 *d_total = nullptr;     // [1]
+    u64 *d_lookback = nullptr;  // [lookback_cap]
+    size_t lookback_cap = 0;
+    u64 *d_ring_h = nullptr;  // runtime-w ring scratch
+    u32 *d_ring_p = nullptr;
+    size_t ring_cap = 0;  // entries
+    u64 *h_pinned = nullptr;  // [8] pinned host words for small read-backs
+};
+
+struct bsk_batch {
+    bsk_ctx *ctx = nullptr;
+    int alphabet = BSK_ALPHA_DNA;
+    u64 n = 0, n_bases = 0, n_words = 0, n_nonacgt = 0;
+    u32 maxlen = 0;
+    u32 uniform_len = 0;  // != 0: every read has this length (synthetic batches)
+    u32 *words = nullptr;
+    u64 *desc = nullptr;
+    u8 *rflags = nullptr;
+    u8 *ascii = nullptr;  // DNA: kept only when some read has a non-ACGT byte; protein: always
+    u64 *aoff = nullptr;
+    u64 device_bytes = 0;
+};
+
+struct bsk_result {
+    bsk_ctx *ctx = nullptr;
+    u64 n = 0, cap = 0, n_tuples = 0;
+    int kind = 0, has_pos = 0;
+    u64 *offsets = nullptr;
+    u8 *status = nullptr;
+    u64 *hash = nullptr;
+    u32 *pos = nullptr;
+};
+
+static int fail_hip(bsk_ctx *ctx, hipError_t e, const char *what) {
+    if (ctx) {
+        char buf[512];
+        snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+        ctx->err = buf;
+    }
+    (void)hipGetLastError();
+    return e == hipErrorOutOfMemory ? BSK_ERR_NOMEM : BSK_ERR_DEVICE;
+}
+static int fail_arg(bsk_ctx *ctx, const char *what) {
+    if (ctx) ctx->err = what;
+    return BSK_ERR_ARG;
+}
+#define HIPCHK(ctx, call)                                        \
+    do {                                                         \
+        hipError_t e__ = (call);                                 \
+        if (e__ != hipSuccess) return fail_hip(ctx, e__, #call); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------
+// utility kernels
+// ------------------------------------------------------------------------------------
+__global__ void k_synth_dna(u32 *words, u64 *desc, u8 *rflags, u64 n, u32 len, u32 wpr, u64 seed) {
+    const u64 total = n * wpr;
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (u64)gridDim.x * blockDim.x) {
+        const u64 r = g / wpr;
+        const u32 j = (u32)(g - r * wpr);
+        u32 v = (u32)splitmix64(seed + g);
+        const u32 valid = len - j * 16u;
+        if (valid < 16u) v &= (1u << (2 * valid)) - 1u;
+        words[g] = v;
+        if (j == 0) {
+            desc[r] = ((r * wpr) << 24) | len;
+            rflags[r] = 0;
+        }
+    }
+}
+__global__ void k_synth_protein(u8 *ascii, u64 *aoff, u64 n, u32 len, u64 seed) {
+    const u64 total = n * len;
+    const char *aa = "ACDEFGHIKLMNPQRSTVWY";
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (u64)gridDim.x * blockDim.x) {
+        ascii[g] = (u8)aa[splitmix64(seed + g) % 20u];
+        if (g <= n) aoff[g] = g * len;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && total < n + 1) {
+        for (u64 g = total; g <= n; ++g) aoff[g] = g * len;
+    }
+}
+// ASCII -> 2-bit words.  One thread per output word; the owning read is found by a
+// binary search over desc[] (first_word is monotone).  Not on the hot path.
+__global__ void k_pack(const u8 *ascii, const u64 *aoff, const u64 *desc, u64 n, u64 n_words, u32 *words, u8 *rflags,
+                       u32 *nonacgt_reads) {
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < n_words; g += (u64)gridDim.x * blockDim.x) {
+        u64 lo = 0, hi = n - 1;  // largest r with first_word[r] <= g  (reads with 0 words share a first_word: take the last)
+        while (lo < hi) {
+            u64 mid = (lo + hi + 1) >> 1;
+            if ((desc[mid] >> 24) <= g) lo = mid;
+            else hi = mid - 1;
+        }
+        const u64 d = desc[lo];
+        const u64 L = d & 0xffffffULL;
+        const u64 j = g - (d >> 24);
+        const u8 *src = ascii + aoff[lo] + j * 16;
+        const u64 nb = L > j * 16 ? (L - j * 16 < 16 ? L - j * 16 : 16) : 0;
+        u32 v = 0;
+        bool bad = false;
+        for (u64 b = 0; b < nb; ++b) {
+            unsigned c = acgt_code(src[b]);
+            if (c > 3) {
+                bad = true;
+                c = 0;
+            }
+            v |= c << (2 * b);
+        }
+        words[g] = v;
+        if (bad) {
+            if (rflags[lo] == 0) atomicAdd(nonacgt_reads, 1u);  // approximate under races; recounted on host
+            rflags[lo] = BSK_ST_HAS_NON_ACGT;
+        }
+    }
+}
+__global__ void k_count_flags(const u8 *rflags, u64 n, u32 *count) {
+    u32 c = 0;
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (u64)gridDim.x * blockDim.x)
+        c += rflags[g] != 0;
+    for (int d = 32; d; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+// circular: read r' = read r + its first k-1 bases (iterator.go:642-646).  One thread per output word.
+__global__ void k_extend_packed(const u32 *words, const u64 *desc, const u64 *ndesc, u64 n, u64 n_words_new, u32 *out) {
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < n_words_new; g += (u64)gridDim.x * blockDim.x) {
+        u64 lo = 0, hi = n - 1;
+        while (lo < hi) {
+            u64 mid = (lo + hi + 1) >> 1;
+            if ((ndesc[mid] >> 24) <= g) lo = mid;
+            else hi = mid - 1;
+        }
+        const u64 L = desc[lo] & 0xffffffULL, L2 = ndesc[lo] & 0xffffffULL;
+        const u32 *src = words + (desc[lo] >> 24);
+        const u64 j0 = (g - (ndesc[lo] >> 24)) * 16;
+        u32 v = 0;
+        for (u64 b = 0; b < 16 && j0 + b < L2; ++b) {
+            u64 p = j0 + b;
+            if (p >= L) p -= L;
+            v |= ((src[p >> 4] >> ((p & 15) * 2)) & 3u) << (2 * b);
+        }
+        out[g] = v;
+    }
+}
+__global__ void k_extend_ascii(const u8 *ascii, const u64 *aoff, const u64 *naoff, u64 n, u8 *out) {
+    // one wave per read
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 r = wave; r < n; r += nw) {
+        const u64 L = aoff[r + 1] - aoff[r], L2 = naoff[r + 1] - naoff[r];
+        for (u64 p = threadIdx.x & 63; p < L2; p += 64) out[naoff[r] + p] = ascii[aoff[r] + (p < L ? p : p - L)];
+    }
+}
+
+// digest: checksum = sum hash*(2*pos+1); tuple kinds: thread per tuple; stream kinds: thread per read
+__global__ void k_digest_tuples(const u64 *hash, const u32 *pos, u64 T, u64 *out) {
+    u64 s = 0;
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < T; g += (u64)gridDim.x * blockDim.x)
+        s += hash[g] * (2ULL * (pos[g] & BSK_POS_MASK) + 1ULL);
+    s = wave_sum_u64(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+__global__ void k_digest_stream(const u64 *hash, const u64 *offsets, u64 n, u64 *out) {
+    u64 s = 0;
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) {
+        const u64 b = offsets[r], e = offsets[r + 1];
+        for (u64 t = b; t < e; ++t) s += hash[t] * (2ULL * (t - b) + 1ULL);
+    }
+    s = wave_sum_u64(s);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+__global__ void k_digest_status(const u8 *status, u64 n, u64 *out4) {
+    u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (u64)gridDim.x * blockDim.x) {
+        const u8 s = status[g];
+        c0 += (s & BSK_ST_CODE_MASK) == BSK_ST_SHORT;
+        c1 += (s & BSK_ST_CODE_MASK) == BSK_ST_ILLEGAL;
+        c2 += (s & BSK_ST_FIRST_WINDOW_TIE) != 0;
+        c3 += (s & BSK_ST_HAS_NON_ACGT) != 0;
+    }
+    c0 = wave_sum_u64(c0);
+    c1 = wave_sum_u64(c1);
+    c2 = wave_sum_u64(c2);
+    c3 = wave_sum_u64(c3);
+    if ((threadIdx.x & 63) == 0) {
+        if (c0) atomicAdd(&out4[0], c0);
+        if (c1) atomicAdd(&out4[1], c1);
+        if (c2) atomicAdd(&out4[2], c2);
+        if (c3) atomicAdd(&out4[3], c3);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------
+extern "C" int bsk_abi_version(void) { return BSK_ABI_VERSION; }
+
+extern "C" const char *bsk_err_name(int e) {
+    switch (e) {
+        case BSK_OK: return "ok";
+        case BSK_ERR_INVALID_K: return "ErrInvalidK";
+        case BSK_ERR_EMPTY_SEQ: return "ErrEmptySeq";
+        case BSK_ERR_SHORT_SEQ: return "ErrShortSeq";
+        case BSK_ERR_ILLEGAL_BASE: return "ErrIllegalBase";
+        case BSK_ERR_K_TOO_LARGE: return "ErrKTooLarge";
+        case BSK_ERR_INVALID_M: return "ErrInvalidM";
+        case BSK_ERR_INVALID_SCALE: return "ErrInvalidScale";
+        case BSK_ERR_INVALID_S: return "ErrInvalidS";
+        case BSK_ERR_INVALID_W: return "ErrInvalidW";
+        case BSK_ERR_BUF_NIL: return "ErrBufNil";
+        case BSK_ERR_BUF_NOT_EMPTY: return "ErrBufNotEmpty";
+        case BSK_ERR_ARG: return "bad argument";
+        case BSK_ERR_NOMEM: return "out of memory";
+        case BSK_ERR_DEVICE: return "device error";
+        case BSK_ERR_UNSUPPORTED: return "unsupported";
+        case BSK_ERR_NO_DEVICE: return "no gfx950 device";
+        default: return "unknown";
+    }
+}
+
+extern "C" int bsk_device_count(int *n) {
+    if (!n) return BSK_ERR_ARG;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    *n = c;
+    return BSK_OK;
+}
+
+extern "C" int bsk_ctx_create(int device, bsk_ctx **out) {
+    if (!out) return BSK_ERR_ARG;
+    *out = nullptr;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) {
+        (void)hipGetLastError();
+        return BSK_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= c) return BSK_ERR_ARG;
+    bsk_ctx *ctx = new (std::nothrow) bsk_ctx();
+    if (!ctx) return BSK_ERR_NOMEM;
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        delete ctx;
+        return BSK_ERR_DEVICE;
+    }
+    ctx->cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&ctx->d_ticket, 2 * sizeof(u32)) != hipSuccess || hipMalloc(&ctx->d_total, 8 * sizeof(u64)) != hipSuccess ||
+        hipHostMalloc(&ctx->h_pinned, 8 * sizeof(u64)) != hipSuccess) {
+        bsk_ctx_destroy(ctx);
+        return BSK_ERR_DEVICE;
+    }
+    *out = ctx;
+    return BSK_OK;
+}
+
+extern "C" void bsk_ctx_destroy(bsk_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->d_ticket);
+    (void)hipFree(ctx->d_total);
+    (void)hipFree(ctx->d_lookback);
+    (void)hipFree(ctx->d_ring_h);
+    (void)hipFree(ctx->d_ring_p);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int bsk_ctx_sync(bsk_ctx *ctx) {
+    if (!ctx) return BSK_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return BSK_OK;
+}
+
+extern "C" const char *bsk_last_error(const bsk_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+// ------------------------------------------------------------------------------------
+// batches
+// ------------------------------------------------------------------------------------
+static int grid_for(bsk_ctx *ctx, u64 items, int block) {
+    u64 g = (items + block - 1) / block;
+    u64 cap = (u64)ctx->cus * 16;
+    return (int)std::max<u64>(1, std::min(g, cap));
+}
+
+extern "C" void bsk_batch_destroy(bsk_batch *b) {
+    if (!b) return;
+    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    (void)hipFree(b->words);
+    (void)hipFree(b->desc);
+    (void)hipFree(b->rflags);
+    (void)hipFree(b->ascii);
+    (void)hipFree(b->aoff);
+    delete b;
+}
+
+static u64 pad_words(u32 maxlen) { return (u64)maxlen / 16 + 8; }
+
+extern "C" int bsk_batch_from_ascii(bsk_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet,
+                                    bsk_batch **out) {
+    if (!ctx || !out || (!offsets && n) || (n && !bytes && offsets[n] > 0)) return fail_arg(ctx, "bsk_batch_from_ascii: null argument");
+    if (alphabet != BSK_ALPHA_DNA && alphabet != BSK_ALPHA_PROTEIN) return fail_arg(ctx, "bad alphabet");
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    bsk_batch *b = new (std::nothrow) bsk_batch();
+    if (!b) return BSK_ERR_NOMEM;
+    b->ctx = ctx;
+    b->alphabet = alphabet;
+    b->n = n;
+    const u64 nbytes = n ? offsets[n] : 0;
+    b->n_bases = nbytes;
+    u32 maxlen = 0;
+    for (u64 r = 0; r < n; ++r) {
+        if (offsets[r + 1] < offsets[r]) {
+            delete b;
+            return fail_arg(ctx, "offsets not monotone");
+        }
+        u64 L = offsets[r + 1] - offsets[r];
+        if (L >= (1ULL << 24)) {
+            delete b;
+            ctx->err = "reads of 2^24 bases or more are not supported yet (tile long sequences on the host)";
+            return BSK_ERR_UNSUPPORTED;
+        }
+        maxlen = std::max<u32>(maxlen, (u32)L);
+    }
+    b->maxlen = maxlen;
+    int rc = BSK_OK;
+    auto bail = [&](int code) {
+        bsk_batch_destroy(b);
+        return code;
+    };
+#define BCHK(call)                                                  \
+    do {                                                            \
+        hipError_t e__ = (call);                                    \
+        if (e__ != hipSuccess) return bail(fail_hip(ctx, e__, #call)); \
+    } while (0)
+    // ascii + offsets to the device
+    BCHK(hipMalloc(&b->ascii, nbytes + 64));
+    BCHK(hipMalloc(&b->aoff, (n + 1) * sizeof(u64)));
+    if (nbytes) BCHK(hipMemcpyAsync(b->ascii, bytes, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    if (n) BCHK(hipMemcpyAsync(b->aoff, offsets, (n + 1) * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    else {
+        u64 z = 0;
+        BCHK(hipMemcpyAsync(b->aoff, &z, sizeof z, hipMemcpyHostToDevice, ctx->stream));
+    }
+    b->device_bytes = nbytes + 64 + (n + 1) * 8;
+    if (alphabet == BSK_ALPHA_DNA) {
+        std::vector<u64> desc(n ? n : 1);
+        u64 w = 0;
+        for (u64 r = 0; r < n; ++r) {
+            u64 L = offsets[r + 1] - offsets[r];
+            desc[r] = (w << 24) | L;
+            w += (L + 15) / 16;
+        }
+        b->n_words = w;
+        const u64 alloc_words = w + pad_words(maxlen);
+        BCHK(hipMalloc(&b->words, alloc_words * sizeof(u32)));
+        BCHK(hipMalloc(&b->desc, (n ? n : 1) * sizeof(u64)));
+        BCHK(hipMalloc(&b->rflags, n ? n : 1));
+        BCHK(hipMemsetAsync(b->words, 0, alloc_words * sizeof(u32), ctx->stream));
+        BCHK(hipMemsetAsync(b->rflags, 0, n ? n : 1, ctx->stream));
+        if (n) BCHK(hipMemcpyAsync(b->desc, desc.data(), n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        BCHK(hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream));
+        if (n && w) {
+            hipLaunchKernelGGL(k_pack, dim3(grid_for(ctx, w, 256)), dim3(256), 0, ctx->stream, b->ascii, b->aoff, b->desc, n, w,
+                               b->words, b->rflags, ctx->d_ticket);
+            hipLaunchKernelGGL(k_count_flags, dim3(grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, b->rflags, n,
+                               ctx->d_ticket + 1);
+        }
+        BCHK(hipMemcpyAsync(ctx->h_pinned, ctx->d_ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+        BCHK(hipStreamSynchronize(ctx->stream));  // also: desc (host vector) no longer needed after this
+        BCHK(hipGetLastError());
+        b->n_nonacgt = ((u32 *)ctx->h_pinned)[1];
+        b->device_bytes += alloc_words * 4 + n * 9;
+        if (b->n_nonacgt == 0) {  // pure ACGT: the 2-bit stream is all the kernels need
+            (void)hipFree(b->ascii);
+            (void)hipFree(b->aoff);
+            b->ascii = nullptr;
+            b->aoff = nullptr;
+            b->device_bytes -= nbytes + 64 + (n + 1) * 8;
+        }
+    } else {
+        BCHK(hipStreamSynchronize(ctx->stream));
+    }
+#undef BCHK
+    *out = b;
+    return rc;
+}
+
+extern "C" int bsk_batch_from_packed(bsk_ctx *ctx, const uint32_t *words, uint64_t n_words, const uint64_t *desc, uint64_t n,
+                                     bsk_batch **out) {
+    if (!ctx || !out || (n && !desc) || (n_words && !words)) return fail_arg(ctx, "bsk_batch_from_packed: null argument");
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    u32 maxlen = 0;
+    u64 nb = 0;
+    for (u64 r = 0; r < n; ++r) {
+        u64 L = desc[r] & 0xffffffULL, w0 = desc[r] >> 24;
+        if (w0 + (L + 15) / 16 > n_words) return fail_arg(ctx, "desc points outside words[]");
+        maxlen = std::max<u32>(maxlen, (u32)L);
+        nb += L;
+    }
+    bsk_batch *b = new (std::nothrow) bsk_batch();
+    if (!b) return BSK_ERR_NOMEM;
+    b->ctx = ctx;
+    b->alphabet = BSK_ALPHA_DNA;
+    b->n = n;
+    b->n_bases = nb;
+    b->n_words = n_words;
+    b->maxlen = maxlen;
+    const u64 alloc_words = n_words + pad_words(maxlen);
+    hipError_t e;
+    if ((e = hipMalloc(&b->words, alloc_words * 4)) != hipSuccess || (e = hipMalloc(&b->desc, (n ? n : 1) * 8)) != hipSuccess ||
+        (e = hipMalloc(&b->rflags, n ? n : 1)) != hipSuccess ||
+        (e = hipMemsetAsync(b->words, 0, alloc_words * 4, ctx->stream)) != hipSuccess ||
+        (e = hipMemsetAsync(b->rflags, 0, n ? n : 1, ctx->stream)) != hipSuccess ||
+        (n_words && (e = hipMemcpyAsync(b->words, words, n_words * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) ||
+        (n && (e = hipMemcpyAsync(b->desc, desc, n * 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) ||
+        (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) {
+        bsk_batch_destroy(b);
+        return fail_hip(ctx, e, "bsk_batch_from_packed");
+    }
+    b->device_bytes = alloc_words * 4 + n * 9;
+    *out = b;
+    return BSK_OK;
+}
+
+extern "C" int bsk_batch_synth(bsk_ctx *ctx, int alphabet, uint64_t n, uint32_t len, uint64_t seed, bsk_batch **out) {
+    if (!ctx || !out) return fail_arg(ctx, "bsk_batch_synth: null argument");
+    if (len == 0 || len >= (1u << 24) || n == 0) return fail_arg(ctx, "bsk_batch_synth: bad n/len");
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    bsk_batch *b = new (std::nothrow) bsk_batch();
+    if (!b) return BSK_ERR_NOMEM;
+    b->ctx = ctx;
+    b->alphabet = alphabet;
+    b->n = n;
+    b->n_bases = n * len;
+    b->maxlen = len;
+    b->uniform_len = len;
+    hipError_t e = hipSuccess;
+    if (alphabet == BSK_ALPHA_DNA) {
+        const u32 wpr = (len + 15) / 16;
+        b->n_words = n * wpr;
+        const u64 alloc_words = b->n_words + pad_words(len);
+        if ((e = hipMalloc(&b->words, alloc_words * 4)) == hipSuccess && (e = hipMalloc(&b->desc, n * 8)) == hipSuccess &&
+            (e = hipMalloc(&b->rflags, n)) == hipSuccess &&
+            (e = hipMemsetAsync(b->words + b->n_words, 0, pad_words(len) * 4, ctx->stream)) == hipSuccess) {
+            hipLaunchKernelGGL(k_synth_dna, dim3(grid_for(ctx, b->n_words, 256)), dim3(256), 0, ctx->stream, b->words, b->desc,
+                               b->rflags, n, len, wpr, seed);
+            e = hipGetLastError();
+        }
+        b->device_bytes = alloc_words * 4 + n * 9;
+    } else if (alphabet == BSK_ALPHA_PROTEIN) {
+        if ((e = hipMalloc(&b->ascii, n * len + 64)) == hipSuccess && (e = hipMalloc(&b->aoff, (n + 1) * 8)) == hipSuccess) {
+            hipLaunchKernelGGL(k_synth_protein, dim3(grid_for(ctx, n * len, 256)), dim3(256), 0, ctx->stream, b->ascii, b->aoff, n,
+                               len, seed);
+            e = hipGetLastError();
+        }
+        b->device_bytes = n * len + 64 + (n + 1) * 8;
+    } else {
+        delete b;
+        return fail_arg(ctx, "bad alphabet");
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        bsk_batch_destroy(b);
+        return fail_hip(ctx, e, "bsk_batch_synth");
+    }
+    *out = b;
+    return BSK_OK;
+}
+
+extern "C" int bsk_batch_info(const bsk_batch *b, uint64_t *n_reads, uint64_t *n_bases, uint64_t *device_bytes,
+                              uint64_t *n_non_acgt_reads) {
+    if (!b) return BSK_ERR_ARG;
+    if (n_reads) *n_reads = b->n;
+    if (n_bases) *n_bases = b->n_bases;
+    if (device_bytes) *device_bytes = b->device_bytes;
+    if (n_non_acgt_reads) *n_non_acgt_reads = b->n_nonacgt;
+    return BSK_OK;
+}
+
+extern "C" int bsk_batch_fetch_ascii(bsk_ctx *ctx, const bsk_batch *b, uint64_t first, uint64_t count, uint8_t *bytes,
+                                     uint64_t bytes_cap, uint64_t *offsets) {
+    if (!ctx || !b || !offsets || (!bytes && bytes_cap)) return fail_arg(ctx, "bsk_batch_fetch_ascii: null argument");
+    if (first + count > b->n) return fail_arg(ctx, "bsk_batch_fetch_ascii: range outside batch");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    offsets[0] = 0;
+    if (count == 0) return BSK_OK;
+    if (b->ascii) {  // exact original bytes
+        std::vector<u64> ao(count + 1);
+        HIPCHK(ctx, hipMemcpy(ao.data(), b->aoff + first, (count + 1) * 8, hipMemcpyDeviceToHost));
+        const u64 nb = ao[count] - ao[0];
+        if (nb > bytes_cap) return fail_arg(ctx, "bsk_batch_fetch_ascii: bytes_cap too small");
+        if (nb) HIPCHK(ctx, hipMemcpy(bytes, b->ascii + ao[0], nb, hipMemcpyDeviceToHost));
+        for (u64 i = 0; i <= count; ++i) offsets[i] = ao[i] - ao[0];
+        return BSK_OK;
+    }
+    std::vector<u64> d(count);
+    HIPCHK(ctx, hipMemcpy(d.data(), b->desc + first, count * 8, hipMemcpyDeviceToHost));
+    const u64 w0 = d[0] >> 24;
+    const u64 w1 = (d[count - 1] >> 24) + ((d[count - 1] & 0xffffffULL) + 15) / 16;
+    std::vector<u32> w(w1 - w0 + 1);
+    if (w1 > w0) HIPCHK(ctx, hipMemcpy(w.data(), b->words + w0, (w1 - w0) * 4, hipMemcpyDeviceToHost));
+    u64 o = 0;
+    for (u64 i = 0; i < count; ++i) {
+        const u64 L = d[i] & 0xffffffULL, base = (d[i] >> 24) - w0;
+        if (o + L > bytes_cap) return fail_arg(ctx, "bsk_batch_fetch_ascii: bytes_cap too small");
+        for (u64 p = 0; p < L; ++p) bytes[o + p] = "ACGT"[(w[base + (p >> 4)] >> ((p & 15) * 2)) & 3];
+        o += L;
+        offsets[i + 1] = o;
+    }
+    return BSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// results
+// ------------------------------------------------------------------------------------
+extern "C" void bsk_result_release(bsk_result *r) {
+    if (!r) return;
+    if (r->ctx) (void)hipSetDevice(r->ctx->device);
+    (void)hipFree(r->offsets);
+    (void)hipFree(r->status);
+    (void)hipFree(r->hash);
+    (void)hipFree(r->pos);
+    delete r;
+}
+
+static bool kind_has_pos(int kind) { return kind == BSK_MINIMIZER || kind == BSK_SYNCMER || kind == BSK_PROT_MINIMIZER; }
+
+static int result_prepare(bsk_ctx *ctx, bsk_result **res, u64 n, int kind, u64 cap) {
+    bsk_result *r = *res;
+    const int hp = kind_has_pos(kind) ? 1 : 0;
+    if (r && (r->ctx != ctx || r->n != n || r->has_pos != hp)) {  // shape changed: start over
+        bsk_result_release(r);
+        r = nullptr;
+        *res = nullptr;
+    }
+    if (!r) {
+        r = new (std::nothrow) bsk_result();
+        if (!r) return BSK_ERR_NOMEM;
+        r->ctx = ctx;
+        r->n = n;
+        r->has_pos = hp;
+        hipError_t e;
+        if ((e = hipMalloc(&r->offsets, (n + 1) * 8)) != hipSuccess || (e = hipMalloc(&r->status, n ? n : 1)) != hipSuccess) {
+            bsk_result_release(r);
+            return fail_hip(ctx, e, "result alloc");
+        }
+        *res = r;
+    }
+    r->kind = kind;
+    if (r->cap < cap) {
+        (void)hipFree(r->hash);
+        (void)hipFree(r->pos);
+        r->hash = nullptr;
+        r->pos = nullptr;
+        r->cap = 0;
+        hipError_t e;
+        if ((e = hipMalloc(&r->hash, (cap + 2) * 8)) != hipSuccess) return fail_hip(ctx, e, "result hash alloc");
+        if (hp && (e = hipMalloc(&r->pos, (cap + 2) * 4)) != hipSuccess) return fail_hip(ctx, e, "result pos alloc");
+        r->cap = cap;
+    }
+    return BSK_OK;
+}
+
+extern "C" int bsk_result_info(const bsk_result *r, uint64_t *n_reads, uint64_t *n_tuples, int *has_pos) {
+    if (!r) return BSK_ERR_ARG;
+    if (n_reads) *n_reads = r->n;
+    if (n_tuples) *n_tuples = r->n_tuples;
+    if (has_pos) *has_pos = r->has_pos;
+    return BSK_OK;
+}
+
+extern "C" int bsk_result_device(const bsk_result *r, const uint64_t **offsets, const uint8_t **status, const uint64_t **hash,
+                                 const uint32_t **pos) {
+    if (!r) return BSK_ERR_ARG;
+    if (offsets) *offsets = (const uint64_t *)r->offsets;
+    if (status) *status = r->status;
+    if (hash) *hash = (const uint64_t *)r->hash;
+    if (pos) *pos = r->pos;
+    return BSK_OK;
+}
+
+extern "C" int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t first, uint64_t count, uint64_t *offsets,
+                                uint8_t *status, uint64_t *hash, uint32_t *pos, uint64_t tuple_cap) {
+    if (!ctx || !r || !offsets) return fail_arg(ctx, "bsk_result_fetch: null argument");
+    if (first + count > r->n) return fail_arg(ctx, "bsk_result_fetch: range outside result");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpy(offsets, r->offsets + first, (count + 1) * 8, hipMemcpyDeviceToHost));
+    const u64 t0 = offsets[0], t1 = offsets[count];
+    for (u64 i = 0; i <= count; ++i) offsets[i] -= t0;
+    if (status && count) HIPCHK(ctx, hipMemcpy(status, r->status + first, count, hipMemcpyDeviceToHost));
+    if ((hash || pos) && t1 - t0 > tuple_cap) return fail_arg(ctx, "bsk_result_fetch: tuple_cap too small");
+    if (hash && t1 > t0) HIPCHK(ctx, hipMemcpy(hash, r->hash + t0, (t1 - t0) * 8, hipMemcpyDeviceToHost));
+    if (pos && t1 > t0) {
+        if (!r->pos) return fail_arg(ctx, "bsk_result_fetch: this kind has implicit positions");
+        HIPCHK(ctx, hipMemcpy(pos, r->pos + t0, (t1 - t0) * 4, hipMemcpyDeviceToHost));
+    }
+    return BSK_OK;
+}
+
+extern "C" int bsk_result_digest(bsk_ctx *ctx, const bsk_result *r, uint64_t *checksum, uint64_t *n_tuples,
+                                 uint64_t status_counts[4]) {
+    if (!ctx || !r) return fail_arg(ctx, "bsk_result_digest: null argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, 8 * sizeof(u64), ctx->stream));
+    if (r->n_tuples) {
+        if (r->has_pos)
+            hipLaunchKernelGGL(k_digest_tuples, dim3(grid_for(ctx, r->n_tuples, 256)), dim3(256), 0, ctx->stream, r->hash, r->pos,
+                               r->n_tuples, ctx->d_total + 1);
+        else
+            hipLaunchKernelGGL(k_digest_stream, dim3(grid_for(ctx, r->n, 256)), dim3(256), 0, ctx->stream, r->hash, r->offsets,
+                               r->n, ctx->d_total + 1);
+    }
+    if (r->n)
+        hipLaunchKernelGGL(k_digest_status, dim3(grid_for(ctx, r->n, 256)), dim3(256), 0, ctx->stream, r->status, r->n,
+                           ctx->d_total + 2);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_total, 8 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (checksum) *checksum = ctx->h_pinned[1];
+    if (n_tuples) *n_tuples = r->n_tuples;
+    if (status_counts)
+        for (int i = 0; i < 4; ++i) status_counts[i] = ctx->h_pinned[2 + i];
+    return BSK_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// dispatch
+// ------------------------------------------------------------------------------------
+static int validate(const bsk_params *p, int alphabet) {
+    switch (p->kind) {
+        case BSK_NTHASH:  // NewHashIterator iterator.go:616
+            if (p->k < 1) return BSK_ERR_INVALID_K;
+            break;
+        case BSK_KMER:  // NewKmerIterator iterator.go:669 ; kmers.Encode rejects k > 32 at the first NextKmer
+            if (p->k < 1) return BSK_ERR_INVALID_K;
+            if (p->k > 32) return BSK_ERR_K_TOO_LARGE;
+            break;
+        case BSK_SIMHASH:  // NewSimHashIterator iterator.go:114-126
+            if (p->k < 1) return BSK_ERR_INVALID_K;
+            if (p->k >= 65535) return BSK_ERR_K_TOO_LARGE;
+            if (p->m < 4 || p->m > p->k) return BSK_ERR_INVALID_M;
+            if (p->scale < 1 || p->scale > p->k - p->m + 1) return BSK_ERR_INVALID_SCALE;
+            break;
+        case BSK_MINIMIZER:  // NewMinimizerSketch sketch.go:86-91
+            if (p->k < 1) return BSK_ERR_INVALID_K;
+            if (p->w < 1) return BSK_ERR_INVALID_W;
+            break;
+        case BSK_SYNCMER:  // NewSyncmerSketch sketch.go:143-148
+            if (p->k < 1) return BSK_ERR_INVALID_K;
+            if (p->s > p->k || p->s <= 0) return BSK_ERR_INVALID_S;
+            break;
+        case BSK_PROT_HASH:  // NewProteinIterator iterator-protein.go:47
+            if (p->k < 1) return BSK_ERR_INVALID_K;
+            break;
+        case BSK_PROT_MINIMIZER:  // NewProteinMinimizerSketch sketch-protein.go:63-72
+            if (p->k < 1) return BSK_ERR_INVALID_K;
+            if (p->w < 1) return BSK_ERR_INVALID_W;
+            break;
+        default: return BSK_ERR_ARG;
+    }
+    const bool prot = p->kind == BSK_PROT_HASH || p->kind == BSK_PROT_MINIMIZER;
+    if (prot != (alphabet == BSK_ALPHA_PROTEIN)) return BSK_ERR_UNSUPPORTED;  // DNA->protein translation: DESIGN.md "next"
+    return BSK_OK;
+}
+
+static int ensure_scratch(bsk_ctx *ctx, size_t nunits, size_t ring_entries) {
+    if (ctx->lookback_cap < nunits) {
+        (void)hipFree(ctx->d_lookback);
+        ctx->d_lookback = nullptr;
+        ctx->lookback_cap = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_lookback, nunits * sizeof(u64)));
+        ctx->lookback_cap = nunits;
+    }
+    if (ctx->ring_cap < ring_entries) {
+        (void)hipFree(ctx->d_ring_h);
+        (void)hipFree(ctx->d_ring_p);
+        ctx->d_ring_h = nullptr;
+        ctx->d_ring_p = nullptr;
+        ctx->ring_cap = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->d_ring_h, ring_entries * sizeof(u64)));
+        HIPCHK(ctx, hipMalloc(&ctx->d_ring_p, ring_entries * sizeof(u32)));
+        ctx->ring_cap = ring_entries;
+    }
+    return BSK_OK;
+}
+
+template <class K>
+static int blocks_per_cu(K kernel) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 64, 0) != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        nb = 1;
+    }
+    return nb;
+}
+
+// One launch of the kernel for (batch, params) into res.  ev0/ev1 (optional) bracket the kernel itself.
+static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_result *res, int circ_ext, hipEvent_t ev0,
+                  hipEvent_t ev1) {
+    KArgs a;
+    memset(&a, 0, sizeof a);
+    a.words = b->words;
+    a.desc = b->desc;
+    a.ascii = b->ascii;
+    a.aoff = b->aoff;
+    a.rflags = b->rflags;
+    a.n = b->n;
+    a.nunits = (u32)((b->n + 63) / 64);
+    a.kind = p->kind;
+    a.k = p->k;
+    a.w = p->w;
+    a.s = p->s;
+    a.m = p->m;
+    a.scale = p->scale;
+    a.canonical = p->canonical ? 1 : 0;
+    a.circ_ext = circ_ext;
+    a.offsets = res->offsets;
+    a.status = res->status;
+    a.hash = res->hash;
+    a.pos = res->pos;
+    a.cap = res->cap;
+    a.ticket = ctx->d_ticket;
+    a.total = ctx->d_total;
+    const bool use_ascii = b->alphabet == BSK_ALPHA_DNA && b->n_nonacgt > 0;
+    if (a.nunits == 0) return BSK_OK;
+
+    int grid = 1;
+    size_t ring_entries = 0;
+    enum { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST } which;
+    int fast_w = 0;
+    if (p->kind == BSK_MINIMIZER) {
+        if (!use_ascii && fast_minimizer_supported(p->w) && !getenv("BSK_FORCE_GENERIC")) {
+            which = K_MIN_FAST;
+            fast_w = p->w;
+            grid = ctx->cus * fast_minimizer_blocks_per_cu(p->w);
+        } else {
+            which = use_ascii ? K_MIN_GEN_A : K_MIN_GEN_P;
+            grid = ctx->cus * (use_ascii ? blocks_per_cu(k_minimizer_generic<1>) : blocks_per_cu(k_minimizer_generic<0>));
+        }
+    } else if (p->kind == BSK_NTHASH) {
+        which = use_ascii ? K_NT_A : K_NT_P;
+        grid = ctx->cus * (use_ascii ? blocks_per_cu(k_nthash_stream<1>) : blocks_per_cu(k_nthash_stream<0>));
+    } else {
+        ctx->err = "kind not implemented yet";
+        return BSK_ERR_UNSUPPORTED;
+    }
+    grid = (int)std::min<u64>((u64)grid, a.nunits);
+    if (which == K_MIN_GEN_A || which == K_MIN_GEN_P) {
+        a.ring_w = (u32)p->w;
+        ring_entries = (size_t)grid * a.ring_w * 64;
+    }
+    int rc = ensure_scratch(ctx, a.nunits, ring_entries);
+    if (rc != BSK_OK) return rc;
+    a.lookback = ctx->d_lookback;
+    a.ring_h = ctx->d_ring_h;
+    a.ring_p = ctx->d_ring_p;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, sizeof(u64), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_lookback, 0, (size_t)a.nunits * sizeof(u64), ctx->stream));
+    if (ev0) HIPCHK(ctx, hipEventRecord(ev0, ctx->stream));
+    switch (which) {
+        case K_MIN_GEN_P: hipLaunchKernelGGL(k_minimizer_generic<0>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
+        case K_MIN_GEN_A: hipLaunchKernelGGL(k_minimizer_generic<1>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
+        case K_NT_P: hipLaunchKernelGGL(k_nthash_stream<0>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
+        case K_NT_A: hipLaunchKernelGGL(k_nthash_stream<1>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
+        case K_MIN_FAST: fast_minimizer_launch(fast_w, grid, ctx->stream, a); break;
+    }
+    if (ev1) HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    return BSK_OK;
+}
+
+// capacity guess (tuples); an undershoot is detected on device and the call re-runs with the exact size
+static u64 estimate_cap(const bsk_batch *b, const bsk_params *p, int circ_ext) {
+    const u64 bases = b->n_bases + b->n * (u64)circ_ext;
+    switch (p->kind) {
+        case BSK_MINIMIZER:
+        case BSK_PROT_MINIMIZER: {
+            if (p->w <= 1) return bases + 64;
+            double d = 2.6 / (p->w + 1.0);
+            if (d > 1.0) d = 1.0;
+            return (u64)(bases * d) + b->n + 1024;
+        }
+        case BSK_SYNCMER: {
+            if (p->s == p->k) return bases + 64;
+            double d = 2.6 / (p->k - p->s + 1.0);
+            if (d > 1.0) d = 1.0;
+            return (u64)(bases * d) + b->n + 1024;
+        }
+        case BSK_KMER: return (p->canonical ? 1 : 2) * bases + 64;
+        default: return bases + 64;
+    }
+}
+
+static int make_circular(bsk_ctx *ctx, const bsk_batch *b, int k, bsk_batch **out);
+
+static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, bsk_result **result, int warmup, int iters,
+                       float *kernel_ms) {
+    if (!ctx || !batch || !p || !result) return fail_arg(ctx, "bsk_sketch: null argument");
+    if (batch->ctx != ctx) return fail_arg(ctx, "bsk_sketch: batch belongs to another context");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = validate(p, batch->alphabet);
+    if (rc != BSK_OK) {
+        ctx->err = bsk_err_name(rc);
+        return rc;
+    }
+    const bsk_batch *b = batch;
+    bsk_batch *tmp = nullptr;
+    int circ_ext = 0;
+    if (p->circular && p->k > 1 && batch->alphabet == BSK_ALPHA_DNA) {
+        rc = make_circular(ctx, batch, p->k, &tmp);
+        if (rc != BSK_OK) return rc;
+        b = tmp;
+        circ_ext = p->k - 1;
+    }
+    u64 cap = estimate_cap(b, p, circ_ext);
+    if (*result && (*result)->cap > cap) cap = (*result)->cap;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (kernel_ms) {
+        (void)hipEventCreate(&ev0);
+        (void)hipEventCreate(&ev1);
+    }
+    auto cleanup = [&](int code) {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (tmp) bsk_batch_destroy(tmp);
+        return code;
+    };
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        rc = result_prepare(ctx, result, b->n, p->kind, cap);
+        if (rc != BSK_OK) return cleanup(rc);
+        bsk_result *res = *result;
+        rc = launch(ctx, b, p, res, circ_ext, nullptr, nullptr);
+        if (rc != BSK_OK) return cleanup(rc);
+        hipError_t e = hipMemcpyAsync(ctx->h_pinned, ctx->d_total, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_pinned + 1, ctx->d_ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return cleanup(fail_hip(ctx, e, "bsk_sketch run"));
+        const u64 total = ctx->h_pinned[0];
+        const u32 ovf = ((u32 *)(ctx->h_pinned + 1))[1];
+        res->n_tuples = total;
+        if (!ovf) break;
+        if (attempt == 1) {
+            ctx->err = "result capacity overflow after exact re-size";
+            return cleanup(BSK_ERR_DEVICE);
+        }
+        cap = total + 64;  // exact size known now: re-run once
+    }
+    // timed repetitions (same result buffers; capacity is now known to be sufficient)
+    for (int it = 0; it < warmup + iters; ++it) {
+        const bool timed = it >= warmup && kernel_ms;
+        rc = launch(ctx, b, p, *result, circ_ext, timed ? ev0 : nullptr, timed ? ev1 : nullptr);
+        if (rc != BSK_OK) return cleanup(rc);
+        if (timed) {
+            hipError_t e = hipEventSynchronize(ev1);
+            float ms = 0;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
+            if (e != hipSuccess) return cleanup(fail_hip(ctx, e, "event timing"));
+            kernel_ms[it - warmup] = ms;
+        }
+    }
+    if (warmup + iters > 0) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return cleanup(fail_hip(ctx, e, "bsk_sketch_timed sync"));
+    }
+    return cleanup(BSK_OK);
+}
+
+extern "C" int bsk_sketch(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, bsk_result **result) {
+    return sketch_impl(ctx, batch, p, result, 0, 0, nullptr);
+}
+
+extern "C" int bsk_sketch_timed(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, bsk_result **result, int warmup,
+                                int iters, float *kernel_ms) {
+    if (warmup < 0 || iters < 0) return fail_arg(ctx, "bsk_sketch_timed: negative counts");
+    return sketch_impl(ctx, batch, p, result, warmup, iters, kernel_ms);
+}
+
+// circular=true: build a temporary batch whose reads carry their first k-1 bases appended
+// (iterator.go:642-646, sketch.go:106-110,163-167).
+static int make_circular(bsk_ctx *ctx, const bsk_batch *b, int k, bsk_batch **out) {
+    *out = nullptr;
+    const u64 n = b->n;
+    std::vector<u64> desc(n ? n : 1), nd(n ? n : 1);
+    if (n) HIPCHK(ctx, hipMemcpy(desc.data(), b->desc, n * 8, hipMemcpyDeviceToHost));
+    bsk_batch *t = new (std::nothrow) bsk_batch();
+    if (!t) return BSK_ERR_NOMEM;
+    t->ctx = ctx;
+    t->alphabet = b->alphabet;
+    t->n = n;
+    u64 w = 0, nb = 0;
+    u32 maxlen = 0;
+    std::vector<u64> nao(n + 1);
+    for (u64 r = 0; r < n; ++r) {
+        const u64 L = desc[r] & 0xffffffULL;
+        const u64 ext = std::min<u64>(L, (u64)(k - 1));  // reads shorter than k-1 are ErrShortSeq anyway
+        const u64 L2 = L + ext;
+        if (L2 >= (1ULL << 24)) {
+            delete t;
+            ctx->err = "circular read too long";
+            return BSK_ERR_UNSUPPORTED;
+        }
+        nd[r] = (w << 24) | L2;
+        nao[r] = nb;
+        w += (L2 + 15) / 16;
+        nb += L2;
+        maxlen = std::max<u32>(maxlen, (u32)L2);
+    }
+    nao[n] = nb;
+    t->n_bases = nb;
+    t->n_words = w;
+    t->maxlen = maxlen;
+    t->n_nonacgt = b->n_nonacgt;
+    const u64 alloc_words = w + pad_words(maxlen);
+    hipError_t e;
+    if ((e = hipMalloc(&t->words, alloc_words * 4)) != hipSuccess || (e = hipMalloc(&t->desc, (n ? n : 1) * 8)) != hipSuccess ||
+        (e = hipMalloc(&t->rflags, n ? n : 1)) != hipSuccess ||
+        (e = hipMemsetAsync(t->words, 0, alloc_words * 4, ctx->stream)) != hipSuccess ||
+        (n && (e = hipMemcpyAsync(t->desc, nd.data(), n * 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) ||
+        (n && (e = hipMemcpyAsync(t->rflags, b->rflags, n, hipMemcpyDeviceToDevice, ctx->stream)) != hipSuccess)) {
+        bsk_batch_destroy(t);
+        return fail_hip(ctx, e, "make_circular alloc");
+    }
+    if (n && w)
+        hipLaunchKernelGGL(k_extend_packed, dim3(grid_for(ctx, w, 256)), dim3(256), 0, ctx->stream, b->words, b->desc, t->desc, n, w,
+                           t->words);
+    if (b->ascii && n) {  // batches with non-ACGT bytes are hashed from ASCII: extend that too
+        if ((e = hipMalloc(&t->ascii, nb + 64)) != hipSuccess || (e = hipMalloc(&t->aoff, (n + 1) * 8)) != hipSuccess ||
+            (e = hipMemcpyAsync(t->aoff, nao.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) {
+            bsk_batch_destroy(t);
+            return fail_hip(ctx, e, "make_circular ascii alloc");
+        }
+        hipLaunchKernelGGL(k_extend_ascii, dim3(grid_for(ctx, n * 64, 256)), dim3(256), 0, ctx->stream, b->ascii, b->aoff, t->aoff,
+                           n, t->ascii);
+    }
+    e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        bsk_batch_destroy(t);
+        return fail_hip(ctx, e, "make_circular");
+    }
+    *out = t;
+    return BSK_OK;
+}

@@ -1,0 +1,172 @@
+// device_common.hpp -- gfx950 device helpers shared by the biosketch kernels.
+// wave = 64 lanes; every kernel here is launched with 64-thread workgroups
+// (one wavefront per workgroup) so "wave" and "block" coincide and
+// __syncthreads() is a single-wave barrier + LDS fence.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+typedef unsigned short u16;
+typedef unsigned char u8;
+
+#define WAVE 64
+
+// ntHash-1 seeds (github.com/will-rowe/nthash v0.4.0 as called from
+// sketches/iterator.go:649,659 and sketches/sketch.go:120,179,184; values pinned by
+// sketches/sketch_test.go:67-72).  Index = 2-bit code A0 C1 G2 T3 (sketches/kmers.go:23-40).
+#define SEED_A 0x3c8bfbb395c60474ULL
+#define SEED_C 0x3193c18562a02b4cULL
+#define SEED_G 0x20323ed082572324ULL
+#define SEED_T 0x295549f54be24456ULL
+
+__host__ __device__ __forceinline__ u64 rol64(u64 v, unsigned n) {
+    n &= 63u;
+    return n ? (v << n) | (v >> (64u - n)) : v;
+}
+__host__ __device__ __forceinline__ u64 ror64(u64 v, unsigned n) {
+    n &= 63u;
+    return n ? (v >> n) | (v << (64u - n)) : v;
+}
+__device__ __forceinline__ u64 rol1(u64 v) { return (v << 1) | (v >> 63); }
+__device__ __forceinline__ u64 ror1(u64 v) { return (v >> 1) | (v << 63); }
+
+__host__ __device__ __forceinline__ u64 seed_fwd_code(unsigned c) {
+    return c == 0 ? SEED_A : c == 1 ? SEED_C : c == 2 ? SEED_G : SEED_T;
+}
+__host__ __device__ __forceinline__ u64 seed_rev_code(unsigned c) {  // seed of the complement base
+    return c == 0 ? SEED_T : c == 1 ? SEED_G : c == 2 ? SEED_C : SEED_A;
+}
+// full byte tables of ntHash-1 (forward: ACGTU + lower case, else 0; reverse: table[b & 7])
+__host__ __device__ __forceinline__ u64 seed_fwd_byte(unsigned b) {
+    switch (b) {
+        case 'A': case 'a': return SEED_A;
+        case 'C': case 'c': return SEED_C;
+        case 'G': case 'g': return SEED_G;
+        case 'T': case 't': case 'U': case 'u': return SEED_T;
+        default: return 0;
+    }
+}
+__host__ __device__ __forceinline__ u64 seed_rev_byte(unsigned b) {
+    switch (b & 7u) {
+        case 1: return SEED_T;
+        case 3: return SEED_G;
+        case 4: case 5: return SEED_A;
+        case 7: return SEED_C;
+        default: return 0;
+    }
+}
+__host__ __device__ __forceinline__ unsigned acgt_code(unsigned b) {  // 0..3, or 4 if not ACGTacgt
+    switch (b) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        default: return 4;
+    }
+}
+
+// ---- wave primitives ---------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ u32 wave_incl_scan_u32(u32 v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u64 t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+#pragma unroll
+    for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {
+#pragma unroll
+    for (int d = 32; d; d >>= 1) {
+        u32 t = __shfl_xor(v, d, 64);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ u32 wave_bcast_u32(u32 v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ u64 wave_bcast_u64(u64 v, int src) { return __shfl(v, src, 64); }
+
+// ---- work distribution: persistent waves pull units (64 reads) from a ticket ----
+// Tickets are handed out in program order of the atomic, so every unit with a
+// smaller ticket is already running or done: the look-back below cannot deadlock,
+// whatever the workgroup -> CU/XCD placement.
+__device__ __forceinline__ u32 next_ticket(u32 *ticket, int lane) {
+    u32 t = 0;
+    if (lane == 0) t = atomicAdd(ticket, 1u);
+    return (u32)__builtin_amdgcn_readfirstlane((int)t);
+}
+
+// ---- decoupled look-back: exclusive prefix of per-unit tuple totals ---------------
+// One 8-byte granule per unit: bits 63..62 state (0 empty, 1 aggregate, 2 inclusive),
+// bits 61..0 value.  Granules are written/read with relaxed agent-scope atomics
+// (sc1 stores/loads: they bypass the non-coherent per-XCD L2s); the granule IS the
+// payload, so no fence is needed (MI355X guide, G16 R2).
+#define LB_AGG (1ULL << 62)
+#define LB_INC (2ULL << 62)
+#define LB_VAL ((1ULL << 62) - 1)
+
+__device__ __forceinline__ void lb_store(u64 *p, u64 v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 lb_load(u64 *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ u64 lookback_exclusive(u64 *st, u32 unit, u64 total, int lane) {
+    if (unit == 0) {
+        if (lane == 0) lb_store(&st[0], LB_INC | total);
+        return 0;
+    }
+    if (lane == 0) lb_store(&st[unit], LB_AGG | total);
+    u64 excl = 0;
+    long long end = (long long)unit - 1;
+    for (;;) {
+        long long idx = end - lane;
+        u64 s = idx >= 0 ? lb_load(&st[idx]) : LB_INC;  // virtual unit -1: inclusive 0
+        u32 state = (u32)(s >> 62);
+        u64 inc_mask = __ballot(state == 2);
+        u64 empty_mask = __ballot(state == 0);
+        if (inc_mask) {
+            int first = __builtin_ctzll(inc_mask);
+            u64 needed = first == 63 ? ~0ULL : ((2ULL << first) - 1);
+            if (empty_mask & needed) {
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            excl += wave_sum_u64(lane <= first ? (s & LB_VAL) : 0ULL);
+            break;
+        }
+        if (empty_mask) {
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        excl += wave_sum_u64(s & LB_VAL);
+        end -= 64;
+    }
+    if (lane == 0) lb_store(&st[unit], LB_INC | (excl + total));
+    return excl;
+}
+
+// splitmix64: counter-based generator for bsk_batch_synth
+__host__ __device__ __forceinline__ u64 splitmix64(u64 x) {
+    x += 0x9E3779B97F4A7C15ULL;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+    return x ^ (x >> 31);
+}

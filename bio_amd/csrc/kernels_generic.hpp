@@ -1,0 +1,455 @@
+// kernels_generic.hpp -- the general ("any k, any w, any byte") biosketch kernels.
+//
+// Mapping: ONE READ PER LANE.  A wavefront owns a *unit* of 64 consecutive reads
+// and walks all of them in lock-step, one k-mer per step, with a true rolling
+// ntHash per lane (the reference's own recurrence, iterator.go:658-665 ->
+// nthash.Next).  All loop counters are wave-uniform (SGPRs); only data differs
+// per lane.  Selected tuples are staged per lane in LDS and written out as one
+// contiguous, position-ordered block per unit (CSR), whose global offset comes
+// from a decoupled look-back over the unit totals.
+//
+// These kernels are the correctness baseline on the device and the fall-back for
+// parameters the specialised kernels (kernels_fast.hpp) do not cover.
+#pragma once
+#include "device_common.hpp"
+#include "biosketch.h"
+
+namespace bsk {
+
+struct KArgs {
+    // input batch
+    const u32 *words;   // packed DNA (16 bases / word)
+    const u64 *desc;    // (first_word << 24) | n_bases
+    const u8 *ascii;    // ASCII DNA or protein residues
+    const u64 *aoff;    // ascii offsets [n+1]
+    const u8 *rflags;   // per-read input flags (BSK_ST_HAS_NON_ACGT) or NULL
+    u64 n;
+    u32 nunits;
+    // parameters
+    int kind, k, w, s, canonical, circ_ext, m, scale;
+    // output
+    u64 *offsets;
+    u8 *status;
+    u64 *hash;
+    u32 *pos;
+    u64 cap;  // capacity of hash[]/pos[] in tuples
+    // synchronisation / scratch
+    u32 *ticket;    // [0] unit ticket, [1] overflow flag
+    u64 *lookback;  // [nunits]
+    u64 *total;     // [1]
+    u64 *ring_h;    // runtime-w ring: per workgroup ring_w*64 entries
+    u32 *ring_p;
+    u32 ring_w;
+};
+
+// X table: one 16-byte entry per (outgoing code 0..4, incoming code 0..3);
+//   .x/.y = rol(seedF[out], k) ^ seedF[in]          (forward strand update)
+//   .z/.w = ror(seedR[out], 1) ^ rol(seedR[in], k-1) (reverse strand update)
+// outgoing code 4 = "nothing leaves" (warm-up of the first k-1 bases).
+__device__ __forceinline__ void build_xtab(uint4 *xt, int k, int tid) {
+    if (tid < 20) {
+        unsigned out = tid >> 2, in = tid & 3;
+        u64 f = seed_fwd_code(in);
+        u64 r = rol64(seed_rev_code(in), (unsigned)(k - 1));
+        if (out < 4) {
+            f ^= rol64(seed_fwd_code(out), (unsigned)k);
+            r ^= ror64(seed_rev_code(out), 1);
+        }
+        xt[tid] = make_uint4((u32)f, (u32)(f >> 32), (u32)r, (u32)(r >> 32));
+    }
+}
+// byte tables for the ASCII path: tin[b] = {seedF[b], rol(seedR[b],k-1)}, tout[b] = {rol(seedF[b],k), ror(seedR[b],1)}
+__device__ __forceinline__ void build_bytetabs(uint4 *tin, uint4 *tout, int k, int tid) {
+    for (int b = tid; b < 256; b += WAVE) {
+        u64 f = seed_fwd_byte(b), r = seed_rev_byte(b);
+        u64 fi = f, ri = rol64(r, (unsigned)(k - 1));
+        u64 fo = rol64(f, (unsigned)k), ro = ror64(r, 1);
+        tin[b] = make_uint4((u32)fi, (u32)(fi >> 32), (u32)ri, (u32)(ri >> 32));
+        tout[b] = make_uint4((u32)fo, (u32)(fo >> 32), (u32)ro, (u32)(ro >> 32));
+    }
+}
+__device__ __forceinline__ u64 u64_of(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+
+// ---------------------------------------------------------------------------------
+// Hash sources.  step(i) returns the hash of k-mer i; i is wave-uniform and is
+// called for i = 0,1,2,... in order.  `rev` = 1 iff the reverse-strand hash won.
+// ---------------------------------------------------------------------------------
+struct NtPacked {  // 2-bit packed input, ACGT only
+    const u32 *w;  // this lane's first word
+    const uint4 *xt;
+    u64 fh, rh;
+    u32 win, wout;
+    int k, canonical;
+    __device__ __forceinline__ void init(const u32 *words, u64 first_word, int k_, int canon, const uint4 *xt_) {
+        w = words + first_word;
+        xt = xt_;
+        k = k_;
+        canonical = canon;
+        fh = rh = 0;
+        win = wout = 0;
+        for (int t = 0; t < k - 1; ++t) {  // warm-up: bases 0..k-2 enter, nothing leaves
+            if ((t & 15) == 0) win = w[t >> 4];
+            uint4 x = xt[16 + ((win >> ((t & 15) * 2)) & 3)];
+            fh = rol1(fh) ^ u64_of(x.x, x.y);
+            rh = ror1(rh) ^ u64_of(x.z, x.w);
+        }
+    }
+    __device__ __forceinline__ void step(u32 i, u64 &h, u32 &rev) {
+        u32 t = i + (u32)k - 1;
+        if ((t & 15) == 0) win = w[t >> 4];
+        u32 cin = (win >> ((t & 15) * 2)) & 3;
+        u32 idx = 16 + cin;
+        if (i) {
+            u32 p = i - 1;
+            if ((p & 15) == 0) wout = w[p >> 4];
+            idx = (((wout >> ((p & 15) * 2)) & 3) << 2) | cin;
+        }
+        uint4 x = xt[idx];
+        fh = rol1(fh) ^ u64_of(x.x, x.y);
+        rh = ror1(rh) ^ u64_of(x.z, x.w);
+        rev = (canonical && rh < fh) ? 1u : 0u;
+        h = rev ? rh : fh;
+    }
+};
+
+struct NtAscii {  // raw bytes, full ntHash-1 seed tables (any byte)
+    const u8 *a;
+    const uint4 *tin, *tout;
+    u64 fh, rh;
+    int k, canonical;
+    u64 L;  // bytes available (reads are clamped so out-of-range lanes stay in bounds)
+    __device__ __forceinline__ void init(const u8 *ascii, u64 off, u64 len, int k_, int canon, const uint4 *tin_,
+                                         const uint4 *tout_) {
+        a = ascii + off;
+        L = len;
+        tin = tin_;
+        tout = tout_;
+        k = k_;
+        canonical = canon;
+        fh = rh = 0;
+        for (int t = 0; t < k - 1; ++t) {
+            uint4 x = tin[(u64)t < L ? a[t] : 0];
+            fh = rol1(fh) ^ u64_of(x.x, x.y);
+            rh = ror1(rh) ^ u64_of(x.z, x.w);
+        }
+    }
+    __device__ __forceinline__ void step(u32 i, u64 &h, u32 &rev) {
+        u64 t = (u64)i + (u64)k - 1;
+        uint4 x = tin[t < L ? a[t] : 0];
+        fh = rol1(fh) ^ u64_of(x.x, x.y);
+        rh = ror1(rh) ^ u64_of(x.z, x.w);
+        if (i) {
+            uint4 y = tout[(u64)(i - 1) < L ? a[i - 1] : 0];
+            fh ^= u64_of(y.x, y.y);
+            rh ^= u64_of(y.z, y.w);
+        }
+        rev = (canonical && rh < fh) ? 1u : 0u;
+        h = rev ? rh : fh;
+    }
+};
+
+// ---------------------------------------------------------------------------------
+// Per-lane LDS staging of selected tuples.  Slot of tuple e of lane l:
+//   e*64 + ((l + e) & 63)
+// -> writes (many lanes, similar e) and the copy-out reads (one lane's run of
+//    consecutive e) are both bank-conflict free.
+// ---------------------------------------------------------------------------------
+template <int CAP>
+struct Stage {
+    u64 *sh;    // [CAP*64]
+    u32 *sp;    // [CAP*64]
+    u16 *smap;  // [CAP*64] wave-relative output index -> slot
+    __device__ __forceinline__ static u32 slot(u32 e, int lane) { return e * 64u + ((u32)(lane + e) & 63u); }
+};
+
+// Window minimizer over a hash source: the closed form of NextMinimizer
+// (sketch.go:205-309; oracle/bio_oracle.c orc_minimizer_closed): per window of W
+// consecutive k-mers the LEFTMOST minimum, emitted when its position changes.
+// Sliding minimum by the two-pass block decomposition: blocks of W k-mers; P =
+// running prefix minimum of the current block, ring[] = suffix minima of the
+// previous block; window min = min(ring[o+1], P) with the older element winning ties.
+// The ring lives in global scratch (layout [slot][lane], so every access is one
+// coalesced 512-byte line per wave) because W is a run-time value here.
+template <class Src, int CAP, bool DIRECT>
+__device__ __forceinline__ void window_pass(Src &src, u32 nk, u32 nk_max, int W, u64 *ring_h, u32 *ring_p, int lane,
+                                            Stage<CAP> st, u32 &cnt, u32 &tie, u64 *ghash, u32 *gpos, u64 gbase) {
+    u64 Ph = 0;
+    u32 Pp = 0, prev = 0xffffffffu;
+    int o = 0;
+    bool first = true;
+    for (u32 i = 0; i < nk_max; ++i) {
+        u64 h;
+        u32 rev;
+        src.step(i, h, rev);
+        const u32 ps = i | (rev << 31);
+        const bool act = i < nk;
+        if (o == 0 || h < Ph) {
+            Ph = h;
+            Pp = ps;
+        }
+        if (!first || o == W - 1) {
+            u64 mh = Ph;
+            u32 mp = Pp;
+            if (o != W - 1) {
+                u64 Sh = ring_h[(o + 1) * 64 + lane];
+                u32 Sp = ring_p[(o + 1) * 64 + lane];
+                if (!(Ph < Sh)) {
+                    mh = Sh;
+                    mp = Sp;
+                }
+            }
+            const bool emit = act && mp != prev;
+            prev = mp;
+            if (emit) {
+                if (!DIRECT) {
+                    if (cnt < (u32)CAP) {
+                        u32 sl = Stage<CAP>::slot(cnt, lane);
+                        st.sh[sl] = mh;
+                        st.sp[sl] = mp;
+                    }
+                } else {
+                    ghash[gbase + cnt] = mh;
+                    gpos[gbase + cnt] = mp;
+                }
+                cnt++;
+            }
+        }
+        ring_h[o * 64 + lane] = h;
+        ring_p[o * 64 + lane] = ps;
+        if (o == W - 1) {
+            if (first && !DIRECT) {  // BSK_ST_FIRST_WINDOW_TIE: any two equal hashes among the first W
+                for (int a = 0; a + 1 < W; ++a) {
+                    u64 ha = ring_h[a * 64 + lane];
+                    for (int b = a + 1; b < W; ++b) tie |= (ring_h[b * 64 + lane] == ha) ? 1u : 0u;
+                }
+            }
+            u64 nh = h;
+            u32 np = ps;
+            for (int q = W - 2; q >= 0; --q) {  // ring[q] = min(ring[q..W-1]), leftmost on ties
+                u64 ah = ring_h[q * 64 + lane];
+                u32 ap = ring_p[q * 64 + lane];
+                if (nh < ah) {
+                    ring_h[q * 64 + lane] = nh;
+                    ring_p[q * 64 + lane] = np;
+                } else {
+                    nh = ah;
+                    np = ap;
+                }
+            }
+            o = 0;
+            first = false;
+        } else {
+            ++o;
+        }
+    }
+}
+
+// Unit epilogue shared by every tuple-producing kernel: wave scan of the per-lane
+// counts, look-back for the unit's global base, LDS -> HBM copy-out in read order,
+// CSR offsets, status bytes.  Returns the unit's global base and whether the
+// result buffer is too small (then nothing is written, only offsets/total).
+template <int CAP>
+__device__ __forceinline__ u64 unit_epilogue(const KArgs &a, u32 unit, int lane, u64 r, u32 c, Stage<CAP> st,
+                                             u32 &excl_out, bool &ovf_out) {
+    const u32 incl = wave_incl_scan_u32(c, lane);
+    const u32 excl = incl - c;
+    const u32 T = wave_bcast_u32(incl, 63);
+    const u64 base = lookback_exclusive(a.lookback, unit, (u64)T, lane);
+    const bool ovf = base + T > a.cap;
+    // A lane that selected more than CAP tuples could not stage them all: then the whole unit is
+    // written by the DIRECT re-run instead (rare; the caller checks the same ballot).
+    const bool any_over = __ballot(c > (u32)CAP) != 0;
+    if (!ovf && !any_over) {
+        // smap: wave-relative output index -> LDS slot
+        const u32 cmax = wave_max_u32(c);
+        for (u32 e = 0; e < cmax; ++e)
+            if (e < c) st.smap[excl + e] = (u16)Stage<CAP>::slot(e, lane);
+        __syncthreads();
+        for (u32 t = lane; t < T; t += 64) {
+            const u32 sl = st.smap[t];
+            a.hash[base + t] = st.sh[sl];
+            if (a.pos) a.pos[base + t] = st.sp[sl];
+        }
+        __syncthreads();
+    } else if (!ovf) {
+        // nothing: DIRECT pass follows
+    } else if (lane == 0) {
+        atomicOr(&a.ticket[1], 1u);
+    }
+    if (r < a.n) a.offsets[r + 1] = base + incl;
+    if (unit == 0 && lane == 0) a.offsets[0] = 0;
+    if (unit == a.nunits - 1 && lane == 63) *a.total = base + incl;
+    excl_out = excl;
+    ovf_out = ovf;
+    return base;
+}
+
+#define BSK_GEN_CAP 32
+
+// ---- MINIMIZER, generic (kind BSK_MINIMIZER; any k, any w; packed or ASCII) ----
+template <int ENC>  // 0 packed, 1 ascii
+__global__ __launch_bounds__(64) void k_minimizer_generic(KArgs a) {
+    constexpr int CAP = BSK_GEN_CAP;
+    __shared__ uint4 s_tab[ENC ? 512 : 32];
+    __shared__ u64 s_h[CAP * 64];
+    __shared__ u32 s_p[CAP * 64];
+    __shared__ u16 s_m[CAP * 64];
+    const int lane = lane_id();
+    if (ENC) build_bytetabs(s_tab, s_tab + 256, a.k, lane);
+    else build_xtab(s_tab, a.k, lane);
+    __syncthreads();
+    Stage<CAP> st{s_h, s_p, s_m};
+    u64 *ring_h = a.ring_h + (u64)blockIdx.x * a.ring_w * 64;
+    u32 *ring_p = a.ring_p + (u64)blockIdx.x * a.ring_w * 64;
+    const int W = a.w;
+    for (;;) {
+        const u32 unit = next_ticket(a.ticket, lane);
+        if (unit >= a.nunits) break;
+        const u64 r = (u64)unit * 64 + lane;
+        u64 off = 0, L = 0;
+        if (r < a.n) {
+            if (ENC) {
+                off = a.aoff[r];
+                L = a.aoff[r + 1] - off;
+            } else {
+                u64 d = a.desc[r];
+                off = d >> 24;
+                L = d & 0xffffffULL;
+            }
+        }
+        // NewMinimizerSketch sketch.go:92: len(S.Seq) < k+w-1 -> ErrShortSeq (on the un-extended length)
+        const bool ok = r < a.n && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W && L >= (u64)a.circ_ext;
+        const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
+        const u32 nk_max = wave_max_u32(nk);
+        u32 cnt = 0, tie = 0;
+        if (nk_max) {
+            if (ENC) {
+                NtAscii src;
+                src.init(a.ascii, off, L, a.k, 1, s_tab, s_tab + 256);
+                window_pass<NtAscii, CAP, false>(src, nk, nk_max, W, ring_h, ring_p, lane, st, cnt, tie, a.hash, a.pos, 0);
+            } else {
+                NtPacked src;
+                src.init(a.words, off, a.k, 1, s_tab);
+                window_pass<NtPacked, CAP, false>(src, nk, nk_max, W, ring_h, ring_p, lane, st, cnt, tie, a.hash, a.pos, 0);
+            }
+        }
+        u32 excl;
+        bool ovf;
+        const u64 base = unit_epilogue<CAP>(a, unit, lane, r, cnt, st, excl, ovf);
+        if (!ovf && __ballot(cnt > (u32)CAP)) {  // rare: a lane selected more than CAP tuples -> recompute, write straight to HBM
+            u32 cnt2 = 0, tie2 = 0;
+            if (ENC) {
+                NtAscii src;
+                src.init(a.ascii, off, L, a.k, 1, s_tab, s_tab + 256);
+                window_pass<NtAscii, CAP, true>(src, nk, nk_max, W, ring_h, ring_p, lane, st, cnt2, tie2, a.hash, a.pos, base + excl);
+            } else {
+                NtPacked src;
+                src.init(a.words, off, a.k, 1, s_tab);
+                window_pass<NtPacked, CAP, true>(src, nk, nk_max, W, ring_h, ring_p, lane, st, cnt2, tie2, a.hash, a.pos, base + excl);
+            }
+        }
+        if (r < a.n) {
+            u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
+            if (tie) sbyte |= BSK_ST_FIRST_WINDOW_TIE;
+            if (ok && a.rflags) sbyte |= a.rflags[r];
+            a.status[r] = sbyte;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// "Every position" kinds: value i of read r goes to out[offsets[r] + i].  Counts are
+// known from the lengths alone, so the look-back runs BEFORE the hashing and values
+// stream out through a 64x16 LDS transpose tile (row = read): each flush writes
+// 128 contiguous bytes per read with 16-byte stores.
+// ---------------------------------------------------------------------------------
+#define TILE_LD 18  // u64 per row: 16 + 2 pad (16-byte aligned rows)
+struct __attribute__((aligned(8))) u64x2_a8 {
+    u64 a, b;
+};
+
+template <int ENC>
+__global__ __launch_bounds__(64) void k_nthash_stream(KArgs a) {
+    __shared__ uint4 s_tab[ENC ? 512 : 32];
+    __shared__ u64 s_tile[64 * TILE_LD];
+    __shared__ u64 s_off[64];
+    __shared__ u32 s_nk[64];
+    const int lane = lane_id();
+    if (ENC) build_bytetabs(s_tab, s_tab + 256, a.k, lane);
+    else build_xtab(s_tab, a.k, lane);
+    __syncthreads();
+    for (;;) {
+        const u32 unit = next_ticket(a.ticket, lane);
+        if (unit >= a.nunits) break;
+        const u64 r = (u64)unit * 64 + lane;
+        u64 off = 0, L = 0;
+        if (r < a.n) {
+            if (ENC) {
+                off = a.aoff[r];
+                L = a.aoff[r + 1] - off;
+            } else {
+                u64 d = a.desc[r];
+                off = d >> 24;
+                L = d & 0xffffffULL;
+            }
+        }
+        // NewHashIterator iterator.go:619: len(s.Seq) < k -> ErrShortSeq
+        const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) >= (u64)a.k;
+        const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
+        const u32 nk_max = wave_max_u32(nk);
+        const u64 incl = wave_incl_scan_u64((u64)nk, lane);
+        const u64 T = wave_bcast_u64(incl, 63);
+        const u64 base = lookback_exclusive(a.lookback, unit, T, lane);
+        const bool ovf = base + T > a.cap;
+        if (ovf && lane == 0) atomicOr(&a.ticket[1], 1u);
+        if (r < a.n) a.offsets[r + 1] = base + incl;
+        if (unit == 0 && lane == 0) a.offsets[0] = 0;
+        if (unit == a.nunits - 1 && lane == 63) *a.total = base + incl;
+        if (r < a.n) {
+            u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
+            if (ok && a.rflags) sbyte |= a.rflags[r];
+            a.status[r] = sbyte;
+        }
+        if (ovf || nk_max == 0) continue;
+        s_off[lane] = base + incl - nk;
+        s_nk[lane] = nk;
+        NtPacked sp;
+        NtAscii sa;
+        if (ENC) sa.init(a.ascii, off, L, a.k, a.canonical, s_tab, s_tab + 256);
+        else sp.init(a.words, off, a.k, a.canonical, s_tab);
+        __syncthreads();
+        for (u32 i = 0; i < nk_max; ++i) {
+            u64 h;
+            u32 rev;
+            if (ENC) sa.step(i, h, rev);
+            else sp.step(i, h, rev);
+            s_tile[lane * TILE_LD + (i & 15)] = h;
+            if ((i & 15) == 15 || i == nk_max - 1) {
+                __syncthreads();
+                const u32 c0 = i & ~15u;
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int row = rr * 8 + (lane >> 3);
+                    const u32 col = (u32)(lane & 7) * 2;
+                    const u32 ia = c0 + col;
+                    const u32 nkr = s_nk[row];
+                    u64 *dst = a.hash + s_off[row] + ia;
+                    const u64 v0 = s_tile[row * TILE_LD + col], v1 = s_tile[row * TILE_LD + col + 1];
+                    if (ia + 1 < nkr) {
+                        // two u64 = one 16-byte store (dst is only 8-byte aligned: dword alignment is
+                        // enough for global_store_dwordx4)
+                        u64x2_a8 vv;
+                        vv.a = v0;
+                        vv.b = v1;
+                        *reinterpret_cast<u64x2_a8 *>(dst) = vv;
+                    } else if (ia < nkr) {
+                        dst[0] = v0;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+}  // namespace bsk

@@ -1,0 +1,418 @@
+"""Host-side mirror of the reference ``sketches`` package over the C ABI.
+
+Same names, argument order and error behaviour as shenwei356/bio ``sketches``
+(file:line relative to the reference root):
+
+    NewHashIterator(s, k, canonical, circular)      iterator.go:615   -> Iterator.NextHash()   :658
+    NewKmerIterator(s, k, canonical, circular)      iterator.go:668   -> Iterator.NextKmer()   :708
+    NewSimHashIterator(s, k, m, scale, canon, circ) iterator.go:113   -> Iterator.NextSimHash():191
+    NewMinimizerSketch(S, k, w, circular)           sketch.go:85      -> Sketch.NextMinimizer():205
+    NewSyncmerSketch(S, k, s, circular)             sketch.go:142     -> Sketch.NextSyncmer()  :312
+    NewProteinIterator(s, k, codonTable, frame)     iterator-protein.go:46 -> ProteinIterator.Next() :76
+    NewProteinMinimizerSketch(S, k, table, frame, w) sketch-protein.go:62  -> ProteinMinimizerSketch.Next() :106
+    Index() on all four types                       iterator.go:776, sketch.go:488, ...
+
+Constructors return ``(obj, err)`` Go-style; ``err`` is one of the sentinel
+objects below (compare with ``is``).  The device works on batches: the fast path
+is ``Engine.batch(...)`` + ``Engine.run(...)`` whose ``BatchResult.iterator(i)``
+hands out the same cursor types; the single-sequence constructors run a batch of
+one on the GPU so that code written against the reference keeps working.
+
+Everything computes on the MI355X through libbiosketch.so -- there is no Python
+or CPU implementation here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+
+# ---- sentinel errors (iterator.go:34-53, sketch.go:32-42) ------------------------------------
+class SketchError(Exception):
+    def __init__(self, code: int, msg: str):
+        super().__init__(msg)
+        self.code = code
+
+
+ErrInvalidK = SketchError(L.ERR_INVALID_K, "sketches: invalid k-mer size")
+ErrEmptySeq = SketchError(L.ERR_EMPTY_SEQ, "sketches: empty sequence")
+ErrShortSeq = SketchError(L.ERR_SHORT_SEQ, "sketches: sequence too short")
+ErrIllegalBase = SketchError(L.ERR_ILLEGAL_BASE, "sketches: illegal base")
+ErrKTooLarge = SketchError(L.ERR_K_TOO_LARGE, "sketches: k-mer size is too large")
+ErrInvalidM = SketchError(L.ERR_INVALID_M, "sketches: invalid m-mer size, should be in range of [4, k]")
+ErrInvalidScale = SketchError(L.ERR_INVALID_SCALE, "sketches: invalid scale, should be in range of [1, k-m+1]")
+ErrInvalidS = SketchError(L.ERR_INVALID_S, "kmers: invalid s-mer size")
+ErrInvalidW = SketchError(L.ERR_INVALID_W, "kmers: invalid minimimzer window")
+ErrBufNil = SketchError(L.ERR_BUF_NIL, "kmers: buffer slice is nil")
+ErrBufNotEmpty = SketchError(L.ERR_BUF_NOT_EMPTY, "kmers: buffer has elements")
+_SENTINELS = {e.code: e for e in (ErrInvalidK, ErrEmptySeq, ErrShortSeq, ErrIllegalBase, ErrKTooLarge, ErrInvalidM,
+                                  ErrInvalidScale, ErrInvalidS, ErrInvalidW, ErrBufNil, ErrBufNotEmpty)}
+
+
+class DeviceError(RuntimeError):
+    """Non-sentinel failure of the engine (device, memory, unsupported)."""
+
+
+# ---- seq.Seq stand-in (seq/seq.go:29-34): only Alphabet identity and the byte slice cross the boundary
+class Alphabet:
+    def __init__(self, name):
+        self.name = name
+
+    def __repr__(self):
+        return self.name
+
+
+DNA = Alphabet("DNA")
+DNAredundant = Alphabet("DNAredundant")
+RNA = Alphabet("RNA")
+Protein = Alphabet("Protein")
+
+
+class Seq:
+    def __init__(self, alphabet: Alphabet, seq):
+        self.Alphabet = alphabet
+        self.Seq = seq.encode() if isinstance(seq, str) else bytes(seq)
+
+
+def NewSeq(alphabet: Alphabet, seq) -> Tuple[Seq, None]:
+    return Seq(alphabet, seq), None
+
+
+# ---- engine ---------------------------------------------------------------------------------------
+class Batch:
+    def __init__(self, eng: "Engine", handle):
+        self.eng, self.h = eng, handle
+
+    def info(self):
+        v = [C.c_uint64() for _ in range(4)]
+        self.eng._chk(self.eng.lib.bsk_batch_info(self.h, *[C.byref(x) for x in v]))
+        return dict(n_reads=v[0].value, n_bases=v[1].value, device_bytes=v[2].value, n_non_acgt_reads=v[3].value)
+
+    def fetch_ascii(self, first: int, count: int) -> Tuple[np.ndarray, np.ndarray]:
+        inf = self.info()
+        cap = inf["n_bases"] if count == inf["n_reads"] else None
+        offs = np.zeros(count + 1, np.uint64)
+        if cap is None:  # two-step: sizes first via a generous bound
+            cap = inf["n_bases"]
+        buf = np.zeros(max(int(cap), 1), np.uint8)
+        self.eng._chk(self.eng.lib.bsk_batch_fetch_ascii(self.eng.ctx, self.h, first, count, buf.ctypes.data, buf.size,
+                                                         offs.ctypes.data))
+        return buf[: int(offs[-1])].copy(), offs
+
+    def close(self):
+        if self.h:
+            self.eng.lib.bsk_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BatchResult:
+    """Device-resident CSR result of one bsk_sketch call."""
+
+    def __init__(self, eng: "Engine", handle, params: L.Params):
+        self.eng, self.h, self.params = eng, handle, params
+        self._host = None
+
+    def info(self):
+        n, t, hp = C.c_uint64(), C.c_uint64(), C.c_int()
+        self.eng._chk(self.eng.lib.bsk_result_info(self.h, C.byref(n), C.byref(t), C.byref(hp)))
+        return dict(n_reads=n.value, n_tuples=t.value, has_pos=bool(hp.value))
+
+    def fetch(self, first: int = 0, count: Optional[int] = None):
+        """-> (offsets[count+1] rebased, status[count], hash[T], pos[T] or None)"""
+        inf = self.info()
+        if count is None:
+            count = inf["n_reads"] - first
+        offs = np.zeros(count + 1, np.uint64)
+        status = np.zeros(max(count, 1), np.uint8)
+        self.eng._chk(self.eng.lib.bsk_result_fetch(self.eng.ctx, self.h, first, count, offs.ctypes.data,
+                                                    status.ctypes.data, None, None, 0))
+        T = int(offs[-1])
+        hash_ = np.zeros(max(T, 1), np.uint64)
+        pos = np.zeros(max(T, 1), np.uint32) if inf["has_pos"] else None
+        self.eng._chk(self.eng.lib.bsk_result_fetch(self.eng.ctx, self.h, first, count, offs.ctypes.data,
+                                                    status.ctypes.data, hash_.ctypes.data,
+                                                    pos.ctypes.data if pos is not None else None, max(T, 1)))
+        return offs, status[:count], hash_[:T], (pos[:T] if pos is not None else None)
+
+    def digest(self):
+        ck, nt = C.c_uint64(), C.c_uint64()
+        sc = (C.c_uint64 * 4)()
+        self.eng._chk(self.eng.lib.bsk_result_digest(self.eng.ctx, self.h, C.byref(ck), C.byref(nt), sc))
+        return dict(checksum=ck.value, n_tuples=nt.value, short=sc[0], illegal=sc[1], first_window_tie=sc[2],
+                    has_non_acgt=sc[3])
+
+    def _cache(self):
+        if self._host is None:
+            self._host = self.fetch()
+        return self._host
+
+    def read(self, i: int):
+        """(status, hash[], pos[] or None) of read i -- what the reference iterator over read i yields."""
+        offs, status, h, p = self._cache()
+        a, b = int(offs[i]), int(offs[i + 1])
+        return int(status[i]), h[a:b], (p[a:b] if p is not None else None)
+
+    def close(self):
+        if self.h:
+            self.eng.lib.bsk_result_release(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One GPU context (bsk_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = L.load()
+        h = C.c_void_p()
+        rc = self.lib.bsk_ctx_create(device, C.byref(h))
+        if rc != L.OK:
+            raise DeviceError(f"bsk_ctx_create({device}) failed: {self.lib.bsk_err_name(rc).decode()}")
+        self.ctx = h
+
+    def _chk(self, rc: int):
+        if rc == L.OK:
+            return
+        if rc in _SENTINELS:
+            raise _SENTINELS[rc]
+        raise DeviceError(f"{self.lib.bsk_err_name(rc).decode()}: {self.lib.bsk_last_error(self.ctx).decode()}")
+
+    # -- batches
+    def batch(self, seqs: Sequence, alphabet: int = L.ALPHA_DNA) -> Batch:
+        bs = [s.Seq if isinstance(s, Seq) else (s.encode() if isinstance(s, str) else bytes(s)) for s in seqs]
+        offs = np.zeros(len(bs) + 1, np.uint64)
+        if bs:
+            offs[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+        data = np.frombuffer(b"".join(bs), np.uint8) if offs[-1] else np.zeros(1, np.uint8)
+        return self.batch_from_arrays(data, offs, alphabet)
+
+    def batch_from_arrays(self, data: np.ndarray, offsets: np.ndarray, alphabet: int = L.ALPHA_DNA) -> Batch:
+        data = np.ascontiguousarray(data, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        h = C.c_void_p()
+        self._chk(self.lib.bsk_batch_from_ascii(self.ctx, data.ctypes.data, offsets.ctypes.data, len(offsets) - 1,
+                                                alphabet, C.byref(h)))
+        return Batch(self, h)
+
+    def batch_from_packed(self, words: np.ndarray, desc: np.ndarray) -> Batch:
+        words = np.ascontiguousarray(words, np.uint32)
+        desc = np.ascontiguousarray(desc, np.uint64)
+        h = C.c_void_p()
+        self._chk(self.lib.bsk_batch_from_packed(self.ctx, words.ctypes.data, len(words), desc.ctypes.data, len(desc),
+                                                 C.byref(h)))
+        return Batch(self, h)
+
+    def synth(self, alphabet: int, n: int, length: int, seed: int) -> Batch:
+        h = C.c_void_p()
+        self._chk(self.lib.bsk_batch_synth(self.ctx, alphabet, n, length, seed, C.byref(h)))
+        return Batch(self, h)
+
+    # -- compute
+    @staticmethod
+    def params(kind, k, w=0, s=0, m=0, scale=0, canonical=True, circular=False, codon_table=1, frame=1) -> L.Params:
+        return L.Params(kind, k, w, s, m, scale, int(bool(canonical)), int(bool(circular)), codon_table, frame)
+
+    def run(self, batch: Batch, p: L.Params, reuse: Optional[BatchResult] = None) -> BatchResult:
+        h = reuse.h if reuse is not None else C.c_void_p()
+        self._chk(self.lib.bsk_sketch(self.ctx, batch.h, C.byref(p), C.byref(h)))
+        if reuse is not None:
+            reuse.h, reuse.params, reuse._host = h, p, None
+            return reuse
+        return BatchResult(self, h, p)
+
+    def run_timed(self, batch: Batch, p: L.Params, warmup: int, iters: int, reuse: Optional[BatchResult] = None):
+        h = reuse.h if reuse is not None else C.c_void_p()
+        ms = (C.c_float * max(iters, 1))()
+        self._chk(self.lib.bsk_sketch_timed(self.ctx, batch.h, C.byref(p), C.byref(h), warmup, iters, ms))
+        res = reuse if reuse is not None else BatchResult(self, h, p)
+        res.h, res.params, res._host = h, p, None
+        return res, [ms[i] for i in range(iters)]
+
+    def sync(self):
+        self._chk(self.lib.bsk_ctx_sync(self.ctx))
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.bsk_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_engine: Optional[Engine] = None
+
+
+def default_engine() -> Engine:
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = Engine(0)
+    return _default_engine
+
+
+# ---- cursors: the reference's iterator types over one read's slice of a BatchResult -----------------
+class _Cursor:
+    def __init__(self, status: int, codes: np.ndarray, pos: Optional[np.ndarray]):
+        self._status, self._codes, self._pos = status, codes, pos
+        self._i = 0
+        self._idx = -1
+
+    def _next(self):
+        if self._i >= len(self._codes):
+            return 0, False
+        c = int(self._codes[self._i])
+        self._idx = int(self._pos[self._i] & L.POS_MASK) if self._pos is not None else self._i
+        self._strand = int(self._pos[self._i] >> 31) if self._pos is not None else 0
+        self._i += 1
+        return c, True
+
+    def Index(self) -> int:
+        return self._idx
+
+    def flags(self) -> int:
+        """engine extension: the read's BSK_ST_* status byte"""
+        return self._status
+
+
+class Iterator(_Cursor):
+    """k-mer code / ntHash / SimHash iterator (iterator.go:60-106)."""
+
+    def __init__(self, status, codes, kind, n_per_strand=None):
+        super().__init__(status, codes, None)
+        self._kind = kind
+        self._nps = n_per_strand
+
+    def NextHash(self):  # iterator.go:658
+        return self._next()
+
+    def NextSimHash(self):  # iterator.go:191
+        return self._next()
+
+    def NextKmer(self):  # iterator.go:708 -> (code, ok, err)
+        c, ok = self._next()
+        if not ok and (self._status & L.ST_CODE_MASK) == L.ST_ILLEGAL:
+            return 0, False, ErrIllegalBase
+        if ok and self._nps:  # non-canonical: Index() restarts at 0 on the reverse strand (iterator.go:720)
+            self._idx = self._idx % self._nps
+        return c, ok, None
+
+    def Next(self):  # iterator.go:762
+        if self._kind == L.KMER:
+            return self.NextKmer()
+        c, ok = self._next()
+        return c, ok, None
+
+
+class Sketch(_Cursor):
+    """minimizer / syncmer sketch iterator (sketch.go:45-77)."""
+
+    def NextMinimizer(self):  # sketch.go:205
+        return self._next()
+
+    def NextSyncmer(self):  # sketch.go:312
+        return self._next()
+
+    def Next(self):  # sketch.go:480
+        return self._next()
+
+    def Strand(self) -> int:
+        """engine extension: 1 iff the reverse-strand hash was the canonical one for the last tuple"""
+        return self._strand
+
+
+class ProteinIterator(_Cursor):
+    def Next(self):  # iterator-protein.go:76
+        return self._next()
+
+
+class ProteinMinimizerSketch(_Cursor):
+    def Next(self):  # sketch-protein.go:106
+        return self._next()
+
+
+def _single(seq: Seq, p: L.Params, alphabet: int, eng: Optional[Engine]):
+    eng = eng or default_engine()
+    b = eng.batch([seq], alphabet)
+    try:
+        res = eng.run(b, p)
+    except SketchError as e:
+        b.close()
+        return None, None, e
+    status, codes, pos = res.read(0)
+    res.close()
+    b.close()
+    if (status & L.ST_CODE_MASK) == L.ST_SHORT:
+        return None, None, ErrShortSeq
+    return (status, codes, pos), None, None
+
+
+def NewHashIterator(s: Seq, k: int, canonical: bool, circular: bool, engine: Optional[Engine] = None):
+    got, _, err = _single(s, Engine.params(L.NTHASH, k, canonical=canonical, circular=circular), L.ALPHA_DNA, engine)
+    if err is not None:
+        return None, err
+    return Iterator(got[0], got[1], L.NTHASH), None
+
+
+def NewKmerIterator(s: Seq, k: int, canonical: bool, circular: bool, engine: Optional[Engine] = None):
+    got, _, err = _single(s, Engine.params(L.KMER, k, canonical=canonical, circular=circular), L.ALPHA_DNA, engine)
+    if err is not None:
+        return None, err
+    nps = None if canonical else (len(s.Seq) + (k - 1 if circular else 0) - k + 1)
+    return Iterator(got[0], got[1], L.KMER, nps), None
+
+
+def NewSimHashIterator(s: Seq, k: int, m: int, scale: int, canonical: bool, circular: bool,
+                       engine: Optional[Engine] = None):
+    got, _, err = _single(s, Engine.params(L.SIMHASH, k, m=m, scale=scale, canonical=canonical, circular=circular),
+                          L.ALPHA_DNA, engine)
+    if err is not None:
+        return None, err
+    return Iterator(got[0], got[1], L.SIMHASH), None
+
+
+def NewMinimizerSketch(S: Seq, k: int, w: int, circular: bool, engine: Optional[Engine] = None):
+    got, _, err = _single(S, Engine.params(L.MINIMIZER, k, w=w, circular=circular), L.ALPHA_DNA, engine)
+    if err is not None:
+        return None, err
+    return Sketch(*got), None
+
+
+def NewSyncmerSketch(S: Seq, k: int, s: int, circular: bool, engine: Optional[Engine] = None):
+    got, _, err = _single(S, Engine.params(L.SYNCMER, k, s=s, circular=circular), L.ALPHA_DNA, engine)
+    if err is not None:
+        return None, err
+    return Sketch(*got), None
+
+
+def NewProteinIterator(s: Seq, k: int, codonTable: int, frame: int, engine: Optional[Engine] = None):
+    alpha = L.ALPHA_PROTEIN if s.Alphabet is Protein else L.ALPHA_DNA
+    got, _, err = _single(s, Engine.params(L.PROT_HASH, k, codon_table=codonTable, frame=frame), alpha, engine)
+    if err is not None:
+        return None, err
+    return ProteinIterator(got[0], got[1], None), None
+
+
+def NewProteinMinimizerSketch(S: Seq, k: int, codonTable: int, frame: int, w: int, engine: Optional[Engine] = None):
+    alpha = L.ALPHA_PROTEIN if S.Alphabet is Protein else L.ALPHA_DNA
+    got, _, err = _single(S, Engine.params(L.PROT_MINIMIZER, k, w=w, codon_table=codonTable, frame=frame), alpha, engine)
+    if err is not None:
+        return None, err
+    return ProteinMinimizerSketch(*got), None

@@ -1,0 +1,185 @@
+/*
+ * biosketch.h -- C ABI of libbiosketch.so, the MI355X (gfx950) k-mer sketching engine.
+ *
+ * This is the drop-in boundary for the `sketches/` package of shenwei356/bio
+ * (reference v0.13.8; file:line below are relative to the reference root).  The
+ * reference exposes per-sequence pull iterators; a device cannot be driven one
+ * value at a time, so the boundary is "batch in -> all tuples out", and the
+ * reference's iterator types become cursors over one read's slice of a result
+ * (bindings/go/sketches, bio_amd/csrc/sketches.hpp, bio_amd/sketches.py).
+ *
+ *   reference constructor / pull method                     ->  bsk_params.kind
+ *   NewKmerIterator / NextKmer        iterator.go:668,708   ->  BSK_KMER
+ *   NewHashIterator / NextHash        iterator.go:615,658   ->  BSK_NTHASH
+ *   NewSimHashIterator / NextSimHash  iterator.go:113,191   ->  BSK_SIMHASH
+ *   NewMinimizerSketch / NextMinimizer sketch.go:85,205     ->  BSK_MINIMIZER
+ *   NewSyncmerSketch / NextSyncmer    sketch.go:142,312     ->  BSK_SYNCMER
+ *   NewProteinIterator / Next         iterator-protein.go:46,76      -> BSK_PROT_HASH
+ *   NewProteinMinimizerSketch / Next  sketch-protein.go:62,106       -> BSK_PROT_MINIMIZER
+ *   Index()  iterator.go:776 sketch.go:488 iterator-protein.go:93 sketch-protein.go:213
+ *                                                           ->  bsk_result pos[] (bit 31 = strand)
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  All functions return
+ * BSK_OK (0) or a bsk_err; nothing aborts or throws across the boundary.  Host
+ * pointers passed in are never retained after the call returns (cgo rule).
+ * One bsk_ctx = one GPU + one HIP stream; contexts are independent and may be
+ * used from different threads concurrently; a single context is not re-entrant.
+ */
+#ifndef BIOSKETCH_H
+#define BIOSKETCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BSK_ABI_VERSION 1
+
+/* Call-level errors.  1..11 are the reference's sentinel errors, returned when a
+ * constructor argument is invalid for EVERY read of the batch
+ * (iterator.go:34-53, sketch.go:32-42). */
+typedef enum bsk_err {
+    BSK_OK = 0,
+    BSK_ERR_INVALID_K = 1,     /* ErrInvalidK      iterator.go:34  k < 1 */
+    BSK_ERR_EMPTY_SEQ = 2,     /* ErrEmptySeq      iterator.go:37  (declared, never returned upstream) */
+    BSK_ERR_SHORT_SEQ = 3,     /* ErrShortSeq      iterator.go:40  (per read: see BSK_ST_SHORT) */
+    BSK_ERR_ILLEGAL_BASE = 4,  /* ErrIllegalBase   iterator.go:43  (per read: see BSK_ST_ILLEGAL) */
+    BSK_ERR_K_TOO_LARGE = 5,   /* ErrKTooLarge     iterator.go:46 */
+    BSK_ERR_INVALID_M = 6,     /* ErrInvalidM      iterator.go:49 */
+    BSK_ERR_INVALID_SCALE = 7, /* ErrInvalidScale  iterator.go:52 */
+    BSK_ERR_INVALID_S = 8,     /* ErrInvalidS      sketch.go:32 */
+    BSK_ERR_INVALID_W = 9,     /* ErrInvalidW      sketch.go:35 */
+    BSK_ERR_BUF_NIL = 10,      /* ErrBufNil        sketch.go:38 (declared, never returned upstream) */
+    BSK_ERR_BUF_NOT_EMPTY = 11,/* ErrBufNotEmpty   sketch.go:41 (declared, never returned upstream) */
+    BSK_ERR_ARG = 64,          /* NULL pointer / inconsistent sizes */
+    BSK_ERR_NOMEM = 65,        /* host or device allocation failed */
+    BSK_ERR_DEVICE = 66,       /* HIP runtime error; text in bsk_last_error() */
+    BSK_ERR_UNSUPPORTED = 67,  /* valid upstream, not implemented here (see DESIGN.md scope) */
+    BSK_ERR_NO_DEVICE = 68     /* no gfx950 device visible: there is NO CPU fallback */
+} bsk_err;
+
+typedef enum bsk_kind {
+    BSK_KMER = 1,
+    BSK_NTHASH = 2,
+    BSK_SIMHASH = 3,
+    BSK_MINIMIZER = 4,
+    BSK_SYNCMER = 5,
+    BSK_PROT_HASH = 6,
+    BSK_PROT_MINIMIZER = 7
+} bsk_kind;
+
+typedef enum bsk_alphabet {
+    BSK_ALPHA_DNA = 0,    /* seq.DNA / DNAredundant / RNA*: hashed with ntHash, 2-bit packed on device */
+    BSK_ALPHA_PROTEIN = 1 /* seq.Protein: one byte per residue (the `S.Alphabet == seq.Protein`
+                             branch of iterator-protein.go:62 / sketch-protein.go:83) */
+} bsk_alphabet;
+
+/* Per-read status byte (bsk_result status[]).  Low nibble = what the reference
+ * constructor / iterator would have reported for that read; high nibble = flags. */
+#define BSK_ST_OK 0x00
+#define BSK_ST_SHORT 0x01             /* constructor would return ErrShortSeq; 0 tuples */
+#define BSK_ST_ILLEGAL 0x02           /* NextKmer hit ErrIllegalBase (iterator.go:731,746); tuples before it kept */
+#define BSK_ST_CODE_MASK 0x0f
+#define BSK_ST_FIRST_WINDOW_TIE 0x10  /* two equal hashes in the first sorted window: upstream's unstable
+                                         sorts.Quicksort (sketch.go:236,351) may order them differently;
+                                         this engine returns the leftmost.  Bit-exactness vs Go is claimed
+                                         for reads WITHOUT this flag. */
+#define BSK_ST_HAS_NON_ACGT 0x20      /* a byte outside ACGTacgt was hashed (ntHash seed table for such
+                                         bytes is unpinned upstream) */
+
+#define BSK_POS_STRAND_BIT 0x80000000u /* pos[] bit 31: 1 iff the reverse-strand hash was the canonical one */
+#define BSK_POS_MASK 0x7fffffffu
+
+/* Mirrors the reference constructor arguments 1:1. */
+typedef struct bsk_params {
+    int32_t kind;       /* bsk_kind */
+    int32_t k;          /* k-mer size (all kinds) */
+    int32_t w;          /* MINIMIZER / PROT_MINIMIZER: window, sketch.go:85 `w`, sketch-protein.go:62 `w` */
+    int32_t s;          /* SYNCMER: s-mer size, sketch.go:142 `s` */
+    int32_t m;          /* SIMHASH: m-mer size, iterator.go:113 `m` */
+    int32_t scale;      /* SIMHASH: FracMinHash scale, iterator.go:113 `scale` */
+    int32_t canonical;  /* KMER / NTHASH / SIMHASH: `canonical` argument (sketches are always canonical) */
+    int32_t circular;   /* `circular` argument: first k-1 bases appended (iterator.go:642-646) */
+    int32_t codon_table;/* PROT_*: only used for DNA input (not implemented: BSK_ERR_UNSUPPORTED) */
+    int32_t frame;      /* PROT_*: idem */
+} bsk_params;
+
+typedef struct bsk_ctx bsk_ctx;
+typedef struct bsk_batch bsk_batch;
+typedef struct bsk_result bsk_result;
+
+/* ---- context ---------------------------------------------------------------- */
+int bsk_abi_version(void);
+int bsk_device_count(int *n);                      /* number of visible gfx950 devices */
+int bsk_ctx_create(int device, bsk_ctx **ctx);     /* hipSetDevice + one stream */
+void bsk_ctx_destroy(bsk_ctx *ctx);
+int bsk_ctx_sync(bsk_ctx *ctx);                    /* wait for the context's stream */
+const char *bsk_last_error(const bsk_ctx *ctx);    /* text of the last BSK_ERR_DEVICE/ARG on this ctx */
+const char *bsk_err_name(int err);                 /* "ErrShortSeq", ... (the reference's names) */
+
+/* ---- batches: what a Go caller collects from fastx.Record.Seq.Seq ---------------
+ * seqio/fastx/reader.go:229-232 reuses the record buffer, so the shim copies each
+ * record's bytes into one contiguous `bytes` array with `offsets[n+1]`.  The call
+ * copies to the device and (DNA) packs to 2 bits/base there; host memory is not
+ * referenced after return. */
+int bsk_batch_from_ascii(bsk_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, uint64_t n,
+                         int alphabet, bsk_batch **out);
+/* Pre-packed DNA: words[] holds 16 bases per uint32 (base i of a read in bits
+ * [2*(i%16), 2*(i%16)+2) of word i/16, A0 C1 G2 T3); each read starts on a word
+ * boundary; desc[r] = (first_word << 24) | n_bases.  n_words = total words. */
+int bsk_batch_from_packed(bsk_ctx *ctx, const uint32_t *words, uint64_t n_words,
+                          const uint64_t *desc, uint64_t n, bsk_batch **out);
+/* Synthetic i.i.d. uniform reads generated ON DEVICE (bench / full-size tests):
+ * DNA over ACGT (packed) or protein over ACDEFGHIKLMNPQRSTVWY; counter-based
+ * splitmix64(seed, index), so any shard is reproducible. */
+int bsk_batch_synth(bsk_ctx *ctx, int alphabet, uint64_t n, uint32_t len, uint64_t seed,
+                    bsk_batch **out);
+int bsk_batch_info(const bsk_batch *b, uint64_t *n_reads, uint64_t *n_bases, uint64_t *device_bytes,
+                   uint64_t *n_non_acgt_reads);
+/* Decode reads [first, first+count) back to ASCII on the host (tests: feed the oracle
+ * the exact bytes the device hashed).  bytes_cap = capacity of bytes[]; offsets[count+1]. */
+int bsk_batch_fetch_ascii(bsk_ctx *ctx, const bsk_batch *b, uint64_t first, uint64_t count,
+                          uint8_t *bytes, uint64_t bytes_cap, uint64_t *offsets);
+void bsk_batch_destroy(bsk_batch *b);
+
+/* ---- compute -------------------------------------------------------------------
+ * Runs the iterator/sketch named by p->kind over every read of the batch.
+ * *result == NULL: a result is allocated; otherwise it is reused (bench loops).
+ * Output layout (device, SoA, CSR by read, deterministic):
+ *   offsets[n+1] u64 ; status[n] u8 ; hash[T] u64 ; pos[T] u32 (bit 31 strand)
+ * read r owns tuples [offsets[r], offsets[r+1]) in position order -- exactly the
+ * sequence of (Next*() value, Index()) pairs the reference iterator yields.
+ * KMER / NTHASH / SIMHASH / PROT_HASH emit every position, so pos[] is implicit
+ * (NULL): tuple j of read r is position j. */
+int bsk_sketch(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, bsk_result **result);
+
+/* Same, repeated: `warmup` untimed runs then `iters` runs, each bracketed by HIP
+ * events on the context's stream.  kernel_ms[iters] (may be NULL) receives the
+ * per-run duration of the sketch kernel; the call returns after the last run
+ * completed.  Used by bench.py (roofline leg). */
+int bsk_sketch_timed(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, bsk_result **result,
+                     int warmup, int iters, float *kernel_ms);
+
+int bsk_result_info(const bsk_result *r, uint64_t *n_reads, uint64_t *n_tuples, int *has_pos);
+/* Copy reads [first, first+count) to the host.  offsets[count+1] are rebased to 0;
+ * hash/pos may be NULL; tuple_cap = capacity (in tuples) of hash[]/pos[]. */
+int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t first, uint64_t count,
+                     uint64_t *offsets, uint8_t *status, uint64_t *hash, uint32_t *pos,
+                     uint64_t tuple_cap);
+/* Device pointers (valid until release / next bsk_sketch on this result). */
+int bsk_result_device(const bsk_result *r, const uint64_t **offsets, const uint8_t **status,
+                      const uint64_t **hash, const uint32_t **pos);
+/* Order-independent digest computed on device over the whole result:
+ *   checksum = sum over tuples of hash * (2*position + 1)   (mod 2^64)
+ *   status_counts[k] = number of reads whose status byte has bit pattern k set, for
+ *   k in {SHORT, ILLEGAL, FIRST_WINDOW_TIE, HAS_NON_ACGT} (4 entries). */
+int bsk_result_digest(bsk_ctx *ctx, const bsk_result *r, uint64_t *checksum, uint64_t *n_tuples,
+                      uint64_t status_counts[4]);
+void bsk_result_release(bsk_result *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIOSKETCH_H */

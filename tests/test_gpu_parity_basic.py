@@ -1,0 +1,124 @@
+"""GPU parity: HIP kernels (through the C ABI) vs the CPU oracle, bit-exact."""
+import random
+
+import numpy as np
+import pytest
+
+from bio_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_dna(rng, n, alpha="ACGT"):
+    return "".join(rng.choice(alpha) for _ in range(n))
+
+
+def check_minimizer(engine, oracle, seqs, k, w, circular=False):
+    b = engine.batch(seqs)
+    res = engine.run(b, engine.params(L.MINIMIZER, k, w=w, circular=circular))
+    for i, s in enumerate(seqs):
+        st, h, p = res.read(i)
+        try:
+            eh, ep, es, fl = oracle.minimizer(s, k, w, circular, closed=True)
+        except oracle.OracleError as e:
+            assert e.name == "ErrShortSeq"
+            assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0, (i, s, k, w)
+            continue
+        assert (st & L.ST_CODE_MASK) == L.ST_OK, (i, s, st)
+        assert np.array_equal(h, eh), (i, s, k, w, h, eh)
+        assert np.array_equal(p & L.POS_MASK, ep), (i, s, k, w)
+        assert np.array_equal(p >> 31, es), (i, s, k, w)
+        assert (st & 0xF0) == fl, (i, s, k, w, st, fl)
+    res.close()
+    b.close()
+
+
+def test_reference_known_answer(engine):
+    # sketches/sketch_test.go:33-76 TestMinimizer
+    from bio_amd import sketches as S
+    seq, _ = S.NewSeq(S.DNA, "GGCAAGTTCGTCA")
+    sk, err = S.NewMinimizerSketch(seq, 5, 3, False, engine)
+    assert err is None
+    codes, idxs = [], []
+    while True:
+        code, ok = sk.NextMinimizer()
+        if not ok:
+            break
+        codes.append(code)
+        idxs.append(sk.Index())
+    assert codes == [973456138564179607, 2645801399420473919, 1099502864234245338, 6763474888237448943,
+                     2737971715116251183]
+    assert idxs == [0, 1, 4, 7, 8]
+
+
+@pytest.mark.parametrize("k,w", [(21, 11), (5, 3), (31, 15), (15, 10), (1, 1), (7, 1), (3, 2), (33, 5), (64, 4), (70, 3),
+                                 (21, 40)])
+def test_minimizer_random(engine, oracle, k, w):
+    rng = random.Random(k * 1000 + w)
+    seqs = [rand_dna(rng, rng.choice([150, 150, 150, rng.randint(1, 300)])) for _ in range(300)]
+    check_minimizer(engine, oracle, seqs, k, w)
+
+
+def test_minimizer_adversarial(engine, oracle):
+    rng = random.Random(5)
+    seqs = ["A" * 150, "AC" * 75, "ACG" * 50, "ACGT" * 40, "T" * 31, "", "A", "ACGTTGCA" * 20,
+            "GAATTC" * 30, rand_dna(rng, 150, "AC"), rand_dna(rng, 150, "AAAC")]
+    for L_ in (20, 21, 30, 31, 32, 33):
+        seqs.append(rand_dna(rng, L_))
+    for k, w in [(21, 11), (5, 3), (11, 11), (4, 16)]:
+        check_minimizer(engine, oracle, seqs, k, w)
+
+
+def test_minimizer_non_acgt_and_lowercase(engine, oracle):
+    rng = random.Random(7)
+    seqs = [rand_dna(rng, 150, "ACGTN"), rand_dna(rng, 150, "acgtACGT"), rand_dna(rng, 200, "ACGTRYKMSWN"),
+            rand_dna(rng, 150), "N" * 150, rand_dna(rng, 150, "ACGTU")]
+    check_minimizer(engine, oracle, seqs, 21, 11)
+    check_minimizer(engine, oracle, seqs, 5, 3)
+
+
+def test_minimizer_circular(engine, oracle):
+    rng = random.Random(9)
+    seqs = [rand_dna(rng, n) for n in (150, 31, 40, 500, 29, 10)] + [rand_dna(rng, 100, "ACGTN")]
+    check_minimizer(engine, oracle, seqs, 21, 11, circular=True)
+    check_minimizer(engine, oracle, seqs, 7, 4, circular=True)
+
+
+def test_minimizer_overflow_of_lds_staging(engine, oracle):
+    # strictly "decreasing" runs force > 32 selections per read -> exercises the direct re-run path
+    rng = random.Random(11)
+    seqs = [rand_dna(rng, 400) for _ in range(70)]
+    check_minimizer(engine, oracle, seqs, 9, 2)
+    check_minimizer(engine, oracle, seqs, 15, 1)
+
+
+@pytest.mark.parametrize("k,canonical,circular", [(21, True, False), (21, False, False), (10, True, True), (1, True, False),
+                                                  (31, True, False), (65, True, False), (100, False, True)])
+def test_nthash_stream(engine, oracle, k, canonical, circular):
+    rng = random.Random(k)
+    seqs = [rand_dna(rng, rng.choice([150, 150, rng.randint(1, 400)])) for _ in range(200)]
+    seqs += ["", "A" * 200, rand_dna(rng, 150, "ACGTN")]
+    b = engine.batch(seqs)
+    res = engine.run(b, engine.params(L.NTHASH, k, canonical=canonical, circular=circular))
+    for i, s in enumerate(seqs):
+        st, h, _ = res.read(i)
+        try:
+            eh, _es = oracle.nthash(s, k, canonical, circular)
+        except oracle.OracleError as e:
+            assert e.name == "ErrShortSeq" and (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0
+            continue
+        assert np.array_equal(h, eh), (i, s, k)
+
+
+def test_synth_batch_roundtrip_and_digest(engine, oracle):
+    b = engine.synth(L.ALPHA_DNA, 5000, 150, 0x5EED0003)
+    data, offs = b.fetch_ascii(0, 5000)
+    assert len(data) == 5000 * 150 and set(np.unique(data).tolist()) <= set(b"ACGT")
+    res = engine.run(b, engine.params(L.MINIMIZER, 21, w=11))
+    nt, ck = oracle.batch_run(4, data, offs, 21, 11, threads=2)
+    d = res.digest()
+    assert d["n_tuples"] == nt and d["checksum"] == ck, (d, nt, ck)
+    res2 = engine.run(b, engine.params(L.NTHASH, 21))
+    nt2, ck2 = oracle.batch_run(2, data, offs, 21, 0, threads=2)
+    d2 = res2.digest()
+    assert d2["n_tuples"] == nt2 == 5000 * 130 and d2["checksum"] == ck2
