@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the sketches/ hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on):
+    100M x 150 bp synthetic reads, minimizer sketch k=21 w=11, canonical ntHash.
+One "step" = one pass of the minimizer kernel over the whole device-resident batch
+(2-bit packed reads in HBM -> (hash, pos|strand) tuples + per-read index in HBM).
+Reads shard by record: with N GPUs every rank owns its own 100M-read batch (weak
+scaling, no data-path collective); the only collective is one RCCL all_gather of the
+per-rank counters at the end.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+
+WORKLOADS = {
+    # name: (kind, n_reads, read_len, k, w_or_s, description)
+    "minimizer": ("min", 100_000_000, 150, 21, 11, "100M x 150 bp reads, minimizer sketch k=21 w=11 (BASELINE configs[2])"),
+    "nthash": ("nt", 10_000_000, 150, 21, 0, "10M x 150 bp reads, canonical ntHash stream k=21 (BASELINE configs[1])"),
+}
+
+
+def cpu_baseline(kind: str, k: int, x: int, read_len: int, seed: int):
+    """Oracle (a CPU restatement of the reference algorithm, NOT the Go binary) on the host cores.
+
+    Bounded sample of the same synthetic workload; the reference's per-read iterator
+    state machine (sorted buffer, binary-search insert), one iterator per read, OpenMP over reads.
+    """
+    import numpy as np
+    from oracle import oracle as O
+    cores = len(os.sched_getaffinity(0))
+    rng = np.random.default_rng(seed)
+    okind = {"min": 4, "nt": 2}[kind]
+
+    def run(n, threads):
+        data = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n * read_len)]
+        offs = (np.arange(n + 1, dtype=np.uint64) * read_len)
+        O.batch_run(okind, data[: 1000 * read_len], offs[:1001], k, x, threads=threads)  # warm
+        t = time.perf_counter()
+        O.batch_run(okind, data, offs, k, x, threads=threads)
+        return n * read_len / (time.perf_counter() - t) / 1e9
+
+    v1 = run(200_000, 1)
+    n_all = min(4_000_000, 400_000 * cores)
+    vall = run(n_all, cores)
+    return {
+        "value": round(vall, 4), "unit": "Gbases/s", "cores": cores, "kind": "port",
+        "value_1thread": round(v1, 4),
+        "sample": f"{n_all} synthetic {read_len}-bp reads on {cores} threads (and 200000 reads on 1 thread); "
+                  "C restatement of the reference state machine (oracle/bio_oracle.c), not the Go binary",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="minimizer", choices=sorted(WORKLOADS))
+    ap.add_argument("--reads", type=float, default=0, help="override reads per GPU (dev)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the sketch engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from bio_amd import _lib as L
+    from bio_amd import sketches as S
+
+    kind, n_reads, read_len, k, x, desc = WORKLOADS[args.workload]
+    if args.reads:
+        n_reads = int(args.reads)
+    seed = 0x5EED0000 + 3 + 0x1000000 * rank  # each rank hashes its own shard of the synthetic stream
+    eng = S.Engine(local_rank)
+    batch = eng.synth(L.ALPHA_DNA, n_reads, read_len, seed)
+    p = eng.params(L.MINIMIZER, k, w=x) if kind == "min" else eng.params(L.NTHASH, k)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed: first run sizes the result buffers; W warm-up steps
+    res, _ = eng.run_timed(batch, p, args.warmup, 0)
+    barrier()
+    t0 = time.perf_counter()
+    res, kernel_ms = eng.run_timed(batch, p, 0, args.steps, reuse=res)  # exactly K steps, HIP events around each kernel
+    barrier()
+    dt = time.perf_counter() - t0
+
+    info = res.info()
+    tuples = info["n_tuples"]
+    # whole-job numbers: MAX time over ranks, SUM of units over ranks (one RCCL all_gather of counters)
+    if world > 1:
+        mine = torch.tensor([dt, float(n_reads * read_len), float(tuples)], dtype=torch.float64, device=dev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        dt_max = max(float(v[0]) for v in allv)
+        bases_total = sum(float(v[1]) for v in allv)
+        tuples_total = sum(float(v[2]) for v in allv)
+    else:
+        dt_max, bases_total, tuples_total = dt, float(n_reads * read_len), float(tuples)
+
+    if rank == 0:
+        ms_per_step = dt_max / args.steps * 1e3
+        value = bases_total * args.steps / dt_max / 1e9
+        # algorithmic bytes per launch on THIS rank: packed bases + one u64 descriptor in,
+        # 12 B per tuple (u64 hash + u32 pos|strand) + one u64 index word per read out.
+        if kind == "min":
+            alg_bytes = n_reads * ((read_len + 3) // 4 + 8) + 12 * tuples + 8 * n_reads
+        else:
+            alg_bytes = n_reads * ((read_len + 3) // 4 + 8) + 8 * tuples + 8 * n_reads
+        k_ms = sum(kernel_ms) / len(kernel_ms)
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Gbases/s hashed (k=21 ntHash + minimizer)" if kind == "min" else "Gbases/s hashed (k=21 ntHash stream)",
+            "value": round(value, 2), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": desc, "reads_per_gpu": n_reads, "read_len": read_len, "k": k,
+                       ("w" if kind == "min" else "canonical"): (x if kind == "min" else True),
+                       "tuples_per_gpu": int(tuples), "tuples_total": int(tuples_total),
+                       "parallelism": f"reads sharded by record over {world} GPU(s), no data-path collective",
+                       "input": "2-bit packed reads resident in HBM", "output": "hash u64 + pos|strand u32 + u64 index per read, in HBM"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "k_minimizer_fast<11,32>" if kind == "min" else "k_nthash_stream<0>",
+                         "kernel_ms_avg": round(k_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "note": "integer-VALU bound, not HBM bound (DESIGN.md); frac is vs the 8 TB/s spec peak"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(kind, k, x, read_len, 12345)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libbiosketch.so")
+SO_PATH = os.environ.get("BSK_LIB") or os.path.join(_HERE, "csrc", "libbiosketch.so")  # BSK_LIB: dev A/B builds
 
 # bsk_err (include/biosketch.h) -- the first eleven are the reference's sentinel errors
 OK = 0

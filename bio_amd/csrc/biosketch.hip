@@ -757,6 +757,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     a.cap = res->cap;
     a.ticket = ctx->d_ticket;
     a.total = ctx->d_total;
+    a.debug = getenv("BSK_DEBUG") ? (u32)atoi(getenv("BSK_DEBUG")) : 0u;
     const bool use_ascii = b->alphabet == BSK_ALPHA_DNA && b->n_nonacgt > 0;
     if (a.nunits == 0) return BSK_OK;
 

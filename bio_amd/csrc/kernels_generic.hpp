@@ -40,6 +40,7 @@ struct KArgs {
     u64 *ring_h;    // runtime-w ring: per workgroup ring_w*64 entries
     u32 *ring_p;
     u32 ring_w;
+    u32 debug;  // dev experiments (BSK_DEBUG env): bit0 no look-back (slab bases), bit1 no copy-out
 };
 
 // X table: one 16-byte entry per (outgoing code 0..4, incoming code 0..3);
@@ -163,7 +164,7 @@ struct Stage {
 };
 
 // Window minimizer over a hash source: the closed form of NextMinimizer
-// (sketch.go:205-309; oracle/bio_oracle.c orc_minimizer_closed): per window of W
+// (sketch.go:205-309; DESIGN.md "closed form"): per window of W
 // consecutive k-mers the LEFTMOST minimum, emitted when its position changes.
 // Sliding minimum by the two-pass block decomposition: blocks of W k-mers; P =
 // running prefix minimum of the current block, ring[] = suffix minima of the

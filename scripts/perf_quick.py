@@ -1,0 +1,24 @@
+"""dev helper: time one kind on a synthetic batch; prints Gbases/s + digest."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bio_amd import sketches as S, _lib as L
+
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
+kind = sys.argv[2] if len(sys.argv) > 2 else "min"
+k = int(sys.argv[3]) if len(sys.argv) > 3 else 21
+x = int(sys.argv[4]) if len(sys.argv) > 4 else 11
+iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
+eng = S.Engine(0)
+t = time.time()
+b = eng.synth(L.ALPHA_DNA, n, 150, 0x5EED0003)
+print("synth", time.time() - t, b.info())
+p = {"min": eng.params(L.MINIMIZER, k, w=x), "nt": eng.params(L.NTHASH, k), "syn": eng.params(L.SYNCMER, k, s=x)}[kind]
+t = time.time()
+res, ms = eng.run_timed(b, p, 1, iters)
+wall = time.time() - t
+inf = res.info()
+best = min(ms)
+print(f"kind={kind} k={k} x={x} n={n} tuples={inf['n_tuples']} per_read={inf['n_tuples']/n:.2f}")
+print("kernel ms:", [round(m, 3) for m in ms], "wall", round(wall, 3))
+print(f"Gbases/s best={n*150/best/1e6:.1f} avg={n*150/(sum(ms)/len(ms))/1e6:.1f}")
+print(res.digest())

@@ -1,0 +1,162 @@
+"""CPU: the oracle against the reference's known-answer test and the committed golden vectors."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "sketches_golden.json")))
+
+
+def test_reference_known_answer_pins_nthash(oracle):
+    # sketches/sketch_test.go:33-76: the only value-checking test of the reference on this path
+    kat = GOLD["ref_kat"]
+    h, p, st, fl = oracle.minimizer(kat["seq"], kat["k"], kat["w"])
+    assert h.tolist() == kat["codes"]
+    assert p.tolist() == [0, 1, 4, 7, 8]
+    # the same five values fall out of the plain hash stream at those positions
+    hs, _ = oracle.nthash(kat["seq"], kat["k"])
+    assert [int(hs[i]) for i in (0, 1, 4, 7, 8)] == kat["codes"]
+    # closed form == state machine
+    h2, p2, st2, fl2 = oracle.minimizer(kat["seq"], kat["k"], kat["w"], closed=True)
+    assert h2.tolist() == kat["codes"] and p2.tolist() == p.tolist()
+
+
+def test_reference_count_assertions(oracle):
+    # iterator_test.go:63,100 ; iterator-protein_test.go is DNA-input (out of scope)
+    s = "AAGTTTGAATCATTCAACTATCTAGTTTTCAGAGAACAATGTTCTCTAAAGAATAGAAAAGAGTCATTGTGCGGTGATGATGGCGGGAAGGATCCACCTG"
+    assert len(oracle.kmer_codes(s, 10)) == len(s) - 10 + 1
+    assert len(oracle.nthash(s, 10)[0]) == len(s) - 10 + 1
+    for t in ("GAACAATGTTCTCTAAAATTG", "GcACAATGTTCTCTAAAATTG"):  # iterator_test.go:141
+        assert len(oracle.simhash(t, 21, 5, 5)) == len(t) - 21 + 1
+    # sketch_test.go:111 (commented-out expectation): 5 syncmers for k=5 s=2
+    h, p, _, _ = oracle.syncmer("GGCAAGTTCGTCATCGATC", 5, 2)
+    assert len(h) == 5
+
+
+def _run(oracle, c):
+    fn = c["fn"]
+    s = c["seq"]
+    try:
+        if fn == "minimizer":
+            r = oracle.minimizer(s, c["k"], c["w"])
+        elif fn == "syncmer":
+            r = oracle.syncmer(s, c["k"], c["s"])
+        elif fn == "nthash":
+            r = oracle.nthash(s, c["k"], c["canonical"], c["circular"])
+        elif fn == "kmer":
+            r = oracle.kmer_codes(s, c["k"], c["canonical"])
+        elif fn == "simhash":
+            r = oracle.simhash(s, c["k"], c["m"], c["scale"])
+        elif fn == "protein_minimizer":
+            r = oracle.protein_minimizer(s, c["k"], c["w"])
+        elif fn == "protein_hashes":
+            r = oracle.protein_hashes(s, c["k"])
+        else:
+            raise AssertionError(fn)
+    except oracle.OracleError as e:
+        return {"error": e.name}
+    if isinstance(r, tuple):
+        return [[int(v) for v in x] if hasattr(x, "__len__") else int(x) for x in r]
+    return [int(v) for v in r]
+
+
+def test_golden_vectors(oracle):
+    assert len(GOLD["cases"]) > 200
+    for c in GOLD["cases"]:
+        assert _run(oracle, c) == c["out"], (c["name"], c["fn"], c.get("k"))
+
+
+def test_state_machine_equals_closed_form(oracle):
+    """sketch.go:205-477 restated line by line == leftmost-argmin closed form (what the kernels compute)."""
+    rng = random.Random(7)
+    for _ in range(4000):
+        L = rng.randint(1, 220)
+        s = "".join(rng.choice(rng.choice(["ACGT", "AC", "A", "ACGTN", "AAAC"])) for _ in range(L))
+        k = rng.choice([1, 2, 3, 5, 7, 11, 21, 31, 33, 64, 70])
+        w = rng.choice([1, 2, 3, 5, 11, 15, 20])
+        circ = rng.random() < 0.2
+        for fn, x in ((oracle.minimizer, w), (oracle.syncmer, rng.randint(1, k) if rng.random() < 0.9 else rng.choice([0, k + 1]))):
+            res = []
+            for closed in (False, True):
+                try:
+                    res.append(fn(s, k, x, circ, closed=closed))
+                except oracle.OracleError as e:
+                    res.append(e.name)
+            a, b = res
+            if isinstance(a, str) or isinstance(b, str):
+                assert a == b, (s, k, x, circ)
+            else:
+                assert all(np.array_equal(a[i], b[i]) for i in range(3)) and a[3] == b[3], (s, k, x, circ)
+
+
+def test_protein_state_machine_equals_closed_form(oracle):
+    rng = random.Random(3)
+    for _ in range(1500):
+        L = rng.randint(1, 120)
+        aa = "".join(rng.choice("ACDEFGHIKLMNPQRSTVWY"[: rng.choice([2, 20])]) for _ in range(L))
+        k, w = rng.choice([1, 2, 3, 5, 9, 10]), rng.choice([1, 2, 3, 5, 7])
+        res = []
+        for closed in (False, True):
+            try:
+                res.append(oracle.protein_minimizer(aa, k, w, closed=closed))
+            except oracle.OracleError as e:
+                res.append(e.name)
+        a, b = res
+        if isinstance(a, str) or isinstance(b, str):
+            assert a == b
+        else:
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+
+
+def test_nthash_is_the_published_formula(oracle):
+    """rolling recurrence == from-scratch definition, incl. k > 64 (rotations mod 64)."""
+    rng = random.Random(5)
+    seed = {'A': 0x3c8bfbb395c60474, 'C': 0x3193c18562a02b4c, 'G': 0x20323ed082572324, 'T': 0x295549f54be24456}
+    comp = {'A': 'T', 'C': 'G', 'G': 'C', 'T': 'A'}
+
+    def rol(v, n):
+        n %= 64
+        return ((v << n) | (v >> (64 - n))) & (2 ** 64 - 1) if n else v
+    x = "".join(rng.choice("ACGT") for _ in range(120))
+    for k in (1, 5, 21, 31, 64, 65, 100):
+        hs, st = oracle.nthash(x, k)
+        for i in range(len(x) - k + 1):
+            f = r = 0
+            for j in range(k):
+                f ^= rol(seed[x[i + j]], k - 1 - j)
+                r ^= rol(seed[comp[x[i + j]]], j)
+            assert int(hs[i]) == min(f, r) and int(st[i]) == (1 if r < f else 0)
+
+
+def test_error_surface(oracle):
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.minimizer("ACGT", 0, 3)
+    assert e.value.name == "ErrInvalidK"
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.minimizer("ACGT", 3, 0)
+    assert e.value.name == "ErrInvalidW"
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.minimizer("ACGTACG", 5, 4)  # len 7 < k+w-1 = 8
+    assert e.value.name == "ErrShortSeq"
+    assert len(oracle.minimizer("ACGTACGT", 5, 4)[0]) >= 1
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.syncmer("ACGTACGTAC", 5, 6)
+    assert e.value.name == "ErrInvalidS"
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.syncmer("ACGTACGTAC", 5, 0)
+    assert e.value.name == "ErrInvalidS"
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.simhash("ACGTACGTACGT", 8, 3, 1)
+    assert e.value.name == "ErrInvalidM"
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.simhash("ACGTACGTACGT", 8, 5, 5)
+    assert e.value.name == "ErrInvalidScale"
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.kmer_codes("ACGTXACGT", 4)  # N maps to A in kmers.go:23-40; X is illegal
+    assert e.value.name == "ErrIllegalBase"
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.protein_minimizer("ACDEFGHIKLMNPQRSTVWY", 7, 3)  # len 20 < 3k
+    assert e.value.name == "ErrShortSeq"
