@@ -52,8 +52,9 @@ struct bsk_batch {
 struct bsk_result {
     bsk_ctx *ctx = nullptr;
     u64 n = 0, cap = 0, n_tuples = 0;
+    u64 ovf_cap = 0;  // slab kernels: tuples reserved (inside cap) for units that outgrow their slab
     int kind = 0, has_pos = 0;
-    u64 *offsets = nullptr;
+    u64 *refs = nullptr;  // per read: (first_tuple << 24) | n_tuples
     u8 *status = nullptr;
     u64 *hash = nullptr;
     u32 *pos = nullptr;
@@ -177,22 +178,37 @@ __global__ void k_extend_ascii(const u8 *ascii, const u64 *aoff, const u64 *naof
     }
 }
 
-// digest: checksum = sum hash*(2*pos+1); tuple kinds: thread per tuple; stream kinds: thread per read
-__global__ void k_digest_tuples(const u64 *hash, const u32 *pos, u64 T, u64 *out) {
-    u64 s = 0;
-    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < T; g += (u64)gridDim.x * blockDim.x)
-        s += hash[g] * (2ULL * (pos[g] & BSK_POS_MASK) + 1ULL);
-    s = wave_sum_u64(s);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
-}
-__global__ void k_digest_stream(const u64 *hash, const u64 *offsets, u64 n, u64 *out) {
-    u64 s = 0;
+// digest: checksum = sum over tuples of hash*(2*position+1); one thread per read walks its tuples
+__global__ void k_digest(const u64 *hash, const u32 *pos, const u64 *refs, u64 n, u64 *out /*[0] checksum [1] tuples*/) {
+    u64 s = 0, c = 0;
     for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) {
-        const u64 b = offsets[r], e = offsets[r + 1];
-        for (u64 t = b; t < e; ++t) s += hash[t] * (2ULL * (t - b) + 1ULL);
+        const u64 ref = refs[r], b = ref >> 24, cnt = ref & 0xffffffULL;
+        for (u64 t = 0; t < cnt; ++t) s += hash[b + t] * (2ULL * (pos ? (u64)(pos[b + t] & BSK_POS_MASK) : t) + 1ULL);
+        c += cnt;
     }
     s = wave_sum_u64(s);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+    c = wave_sum_u64(c);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], s);
+        atomicAdd(&out[1], c);
+    }
+}
+__global__ void k_sum_counts(const u64 *refs, u64 n, u64 *out) {
+    u64 c = 0;
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) c += refs[r] & 0xffffffULL;
+    c = wave_sum_u64(c);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+// fetch: pack the tuples of reads [first, first+count) densely (dst offsets computed on the host); one wave per read
+__global__ void k_gather(const u64 *hash, const u32 *pos, const u64 *refs, const u64 *dstoff, u64 count, u64 *ohash, u32 *opos) {
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 r = wave; r < count; r += nw) {
+        const u64 ref = refs[r], b = ref >> 24, cnt = ref & 0xffffffULL, d = dstoff[r];
+        for (u64 t = threadIdx.x & 63; t < cnt; t += 64) {
+            if (ohash) ohash[d + t] = hash[b + t];
+            if (opos) opos[d + t] = pos[b + t];
+        }
+    }
 }
 __global__ void k_digest_status(const u8 *status, u64 n, u64 *out4) {
     u64 c0 = 0, c1 = 0, c2 = 0, c3 = 0;
@@ -552,7 +568,7 @@ extern "C" int bsk_batch_fetch_ascii(bsk_ctx *ctx, const bsk_batch *b, uint64_t 
 extern "C" void bsk_result_release(bsk_result *r) {
     if (!r) return;
     if (r->ctx) (void)hipSetDevice(r->ctx->device);
-    (void)hipFree(r->offsets);
+    (void)hipFree(r->refs);
     (void)hipFree(r->status);
     (void)hipFree(r->hash);
     (void)hipFree(r->pos);
@@ -576,7 +592,7 @@ static int result_prepare(bsk_ctx *ctx, bsk_result **res, u64 n, int kind, u64 c
         r->n = n;
         r->has_pos = hp;
         hipError_t e;
-        if ((e = hipMalloc(&r->offsets, (n + 1) * 8)) != hipSuccess || (e = hipMalloc(&r->status, n ? n : 1)) != hipSuccess) {
+        if ((e = hipMalloc(&r->refs, (n ? n : 1) * 8)) != hipSuccess || (e = hipMalloc(&r->status, n ? n : 1)) != hipSuccess) {
             bsk_result_release(r);
             return fail_hip(ctx, e, "result alloc");
         }
@@ -605,10 +621,10 @@ extern "C" int bsk_result_info(const bsk_result *r, uint64_t *n_reads, uint64_t 
     return BSK_OK;
 }
 
-extern "C" int bsk_result_device(const bsk_result *r, const uint64_t **offsets, const uint8_t **status, const uint64_t **hash,
+extern "C" int bsk_result_device(const bsk_result *r, const uint64_t **refs, const uint8_t **status, const uint64_t **hash,
                                  const uint32_t **pos) {
     if (!r) return BSK_ERR_ARG;
-    if (offsets) *offsets = (const uint64_t *)r->offsets;
+    if (refs) *refs = (const uint64_t *)r->refs;
     if (status) *status = r->status;
     if (hash) *hash = (const uint64_t *)r->hash;
     if (pos) *pos = r->pos;
@@ -619,17 +635,36 @@ extern "C" int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t firs
                                 uint8_t *status, uint64_t *hash, uint32_t *pos, uint64_t tuple_cap) {
     if (!ctx || !r || !offsets) return fail_arg(ctx, "bsk_result_fetch: null argument");
     if (first + count > r->n) return fail_arg(ctx, "bsk_result_fetch: range outside result");
+    if (pos && !r->pos) return fail_arg(ctx, "bsk_result_fetch: this kind has implicit positions");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemcpy(offsets, r->offsets + first, (count + 1) * 8, hipMemcpyDeviceToHost));
-    const u64 t0 = offsets[0], t1 = offsets[count];
-    for (u64 i = 0; i <= count; ++i) offsets[i] -= t0;
+    std::vector<u64> refs(count ? count : 1);
+    if (count) HIPCHK(ctx, hipMemcpy(refs.data(), r->refs + first, count * 8, hipMemcpyDeviceToHost));
+    offsets[0] = 0;
+    for (u64 i = 0; i < count; ++i) offsets[i + 1] = offsets[i] + (refs[i] & 0xffffffULL);
+    const u64 T = offsets[count];
     if (status && count) HIPCHK(ctx, hipMemcpy(status, r->status + first, count, hipMemcpyDeviceToHost));
-    if ((hash || pos) && t1 - t0 > tuple_cap) return fail_arg(ctx, "bsk_result_fetch: tuple_cap too small");
-    if (hash && t1 > t0) HIPCHK(ctx, hipMemcpy(hash, r->hash + t0, (t1 - t0) * 8, hipMemcpyDeviceToHost));
-    if (pos && t1 > t0) {
-        if (!r->pos) return fail_arg(ctx, "bsk_result_fetch: this kind has implicit positions");
-        HIPCHK(ctx, hipMemcpy(pos, r->pos + t0, (t1 - t0) * 4, hipMemcpyDeviceToHost));
+    if (!hash && !pos) return BSK_OK;
+    if (T > tuple_cap) return fail_arg(ctx, "bsk_result_fetch: tuple_cap too small");
+    if (T == 0) return BSK_OK;
+    // pack on the device (the tuple arrays are slab-organised), then one D2H copy per array
+    u64 *d_off = nullptr, *d_h = nullptr;
+    u32 *d_p = nullptr;
+    hipError_t e = hipMalloc(&d_off, count * 8);
+    if (e == hipSuccess && hash) e = hipMalloc(&d_h, T * 8);
+    if (e == hipSuccess && pos) e = hipMalloc(&d_p, T * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, offsets, count * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_gather, dim3(grid_for(ctx, count * 64, 256)), dim3(256), 0, ctx->stream, r->hash, r->pos, r->refs + first,
+                           d_off, count, d_h, d_p);
+        e = hipGetLastError();
     }
+    if (e == hipSuccess && hash) e = hipMemcpyAsync(hash, d_h, T * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && pos) e = hipMemcpyAsync(pos, d_p, T * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_off);
+    (void)hipFree(d_h);
+    (void)hipFree(d_p);
+    if (e != hipSuccess) return fail_hip(ctx, e, "bsk_result_fetch");
     return BSK_OK;
 }
 
@@ -638,22 +673,17 @@ extern "C" int bsk_result_digest(bsk_ctx *ctx, const bsk_result *r, uint64_t *ch
     if (!ctx || !r) return fail_arg(ctx, "bsk_result_digest: null argument");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, 8 * sizeof(u64), ctx->stream));
-    if (r->n_tuples) {
-        if (r->has_pos)
-            hipLaunchKernelGGL(k_digest_tuples, dim3(grid_for(ctx, r->n_tuples, 256)), dim3(256), 0, ctx->stream, r->hash, r->pos,
-                               r->n_tuples, ctx->d_total + 1);
-        else
-            hipLaunchKernelGGL(k_digest_stream, dim3(grid_for(ctx, r->n, 256)), dim3(256), 0, ctx->stream, r->hash, r->offsets,
-                               r->n, ctx->d_total + 1);
-    }
-    if (r->n)
+    if (r->n) {
+        hipLaunchKernelGGL(k_digest, dim3(grid_for(ctx, r->n, 256)), dim3(256), 0, ctx->stream, r->hash, r->pos, r->refs, r->n,
+                           ctx->d_total);
         hipLaunchKernelGGL(k_digest_status, dim3(grid_for(ctx, r->n, 256)), dim3(256), 0, ctx->stream, r->status, r->n,
                            ctx->d_total + 2);
+    }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->d_total, 8 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (checksum) *checksum = ctx->h_pinned[1];
-    if (n_tuples) *n_tuples = r->n_tuples;
+    if (checksum) *checksum = ctx->h_pinned[0];
+    if (n_tuples) *n_tuples = ctx->h_pinned[1];
     if (status_counts)
         for (int i = 0; i < 4; ++i) status_counts[i] = ctx->h_pinned[2 + i];
     return BSK_OK;
@@ -730,9 +760,54 @@ static int blocks_per_cu(K kernel) {
     return nb;
 }
 
-// One launch of the kernel for (batch, params) into res.  ev0/ev1 (optional) bracket the kernel itself.
-static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_result *res, int circ_ext, hipEvent_t ev0,
-                  hipEvent_t ev1) {
+// Which kernel runs a (batch, params) pair, on how many workgroups, and how the tuple arrays are organised.
+enum Which { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST };
+struct Plan {
+    Which which = K_MIN_GEN_P;
+    int grid = 1;
+    int fast_w = 0;
+    bool slab = false;     // true: unit u owns tuples [u*slab_unit, (u+1)*slab_unit) (+ overflow region); no look-back
+    u64 slab_unit = 0;     // tuples per unit slab
+    u64 slab_total = 0;    // nunits * slab_unit
+    u32 nunits = 0;
+    u32 ring_w = 0;
+    size_t ring_entries = 0;
+};
+
+static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan &pl) {
+    pl.nunits = (u32)((b->n + 63) / 64);
+    const bool use_ascii = b->alphabet == BSK_ALPHA_DNA && b->n_nonacgt > 0;
+    int per_cu = 1;
+    if (p->kind == BSK_MINIMIZER) {
+        // fast path: 2-bit input, a window size with a compiled specialisation, positions that fit 15 bits
+        if (!use_ascii && fast_minimizer_supported(p->w) && b->maxlen < 32768u && !getenv("BSK_FORCE_GENERIC")) {
+            pl.which = K_MIN_FAST;
+            pl.fast_w = p->w;
+            pl.slab = true;
+            pl.slab_unit = (u64)64 * BSK_FAST_CAP;
+            pl.slab_total = (u64)pl.nunits * pl.slab_unit;
+            per_cu = fast_minimizer_blocks_per_cu(p->w);
+        } else {
+            pl.which = use_ascii ? K_MIN_GEN_A : K_MIN_GEN_P;
+            per_cu = use_ascii ? blocks_per_cu(k_minimizer_generic<1>) : blocks_per_cu(k_minimizer_generic<0>);
+            pl.ring_w = (u32)p->w;
+        }
+    } else if (p->kind == BSK_NTHASH) {
+        pl.which = use_ascii ? K_NT_A : K_NT_P;
+        per_cu = use_ascii ? blocks_per_cu(k_nthash_stream<1>) : blocks_per_cu(k_nthash_stream<0>);
+    } else {
+        ctx->err = "kind not implemented yet";
+        return BSK_ERR_UNSUPPORTED;
+    }
+    pl.grid = (int)std::max<u64>(1, std::min<u64>((u64)ctx->cus * per_cu, pl.nunits));
+    pl.ring_entries = (size_t)pl.grid * pl.ring_w * 64;
+    return BSK_OK;
+}
+
+// One launch of the planned kernel into res.  ev0/ev1 (optional) bracket the kernel itself.
+static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_result *res, int circ_ext, const Plan &pl,
+                  hipEvent_t ev0, hipEvent_t ev1) {
+    if (pl.nunits == 0) return BSK_OK;
     KArgs a;
     memset(&a, 0, sizeof a);
     a.words = b->words;
@@ -741,7 +816,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     a.aoff = b->aoff;
     a.rflags = b->rflags;
     a.n = b->n;
-    a.nunits = (u32)((b->n + 63) / 64);
+    a.nunits = pl.nunits;
     a.kind = p->kind;
     a.k = p->k;
     a.w = p->w;
@@ -750,64 +825,39 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     a.scale = p->scale;
     a.canonical = p->canonical ? 1 : 0;
     a.circ_ext = circ_ext;
-    a.offsets = res->offsets;
+    a.refs = res->refs;
     a.status = res->status;
     a.hash = res->hash;
     a.pos = res->pos;
     a.cap = res->cap;
+    a.ovf_base = pl.slab_total;
+    a.ovf_cap = res->ovf_cap;
     a.ticket = ctx->d_ticket;
     a.total = ctx->d_total;
-    a.debug = getenv("BSK_DEBUG") ? (u32)atoi(getenv("BSK_DEBUG")) : 0u;
-    const bool use_ascii = b->alphabet == BSK_ALPHA_DNA && b->n_nonacgt > 0;
-    if (a.nunits == 0) return BSK_OK;
-
-    int grid = 1;
-    size_t ring_entries = 0;
-    enum { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST } which;
-    int fast_w = 0;
-    if (p->kind == BSK_MINIMIZER) {
-        if (!use_ascii && fast_minimizer_supported(p->w) && !getenv("BSK_FORCE_GENERIC")) {
-            which = K_MIN_FAST;
-            fast_w = p->w;
-            grid = ctx->cus * fast_minimizer_blocks_per_cu(p->w);
-        } else {
-            which = use_ascii ? K_MIN_GEN_A : K_MIN_GEN_P;
-            grid = ctx->cus * (use_ascii ? blocks_per_cu(k_minimizer_generic<1>) : blocks_per_cu(k_minimizer_generic<0>));
-        }
-    } else if (p->kind == BSK_NTHASH) {
-        which = use_ascii ? K_NT_A : K_NT_P;
-        grid = ctx->cus * (use_ascii ? blocks_per_cu(k_nthash_stream<1>) : blocks_per_cu(k_nthash_stream<0>));
-    } else {
-        ctx->err = "kind not implemented yet";
-        return BSK_ERR_UNSUPPORTED;
-    }
-    grid = (int)std::min<u64>((u64)grid, a.nunits);
-    if (which == K_MIN_GEN_A || which == K_MIN_GEN_P) {
-        a.ring_w = (u32)p->w;
-        ring_entries = (size_t)grid * a.ring_w * 64;
-    }
-    int rc = ensure_scratch(ctx, a.nunits, ring_entries);
+    a.ring_w = pl.ring_w;
+    int rc = ensure_scratch(ctx, pl.slab ? 1 : pl.nunits, pl.ring_entries);
     if (rc != BSK_OK) return rc;
     a.lookback = ctx->d_lookback;
     a.ring_h = ctx->d_ring_h;
     a.ring_p = ctx->d_ring_p;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, sizeof(u64), ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_lookback, 0, (size_t)a.nunits * sizeof(u64), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, 2 * sizeof(u64), ctx->stream));
+    if (!pl.slab) HIPCHK(ctx, hipMemsetAsync(ctx->d_lookback, 0, (size_t)pl.nunits * sizeof(u64), ctx->stream));
     if (ev0) HIPCHK(ctx, hipEventRecord(ev0, ctx->stream));
-    switch (which) {
-        case K_MIN_GEN_P: hipLaunchKernelGGL(k_minimizer_generic<0>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
-        case K_MIN_GEN_A: hipLaunchKernelGGL(k_minimizer_generic<1>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
-        case K_NT_P: hipLaunchKernelGGL(k_nthash_stream<0>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
-        case K_NT_A: hipLaunchKernelGGL(k_nthash_stream<1>, dim3(grid), dim3(64), 0, ctx->stream, a); break;
-        case K_MIN_FAST: fast_minimizer_launch(fast_w, grid, ctx->stream, a); break;
+    switch (pl.which) {
+        case K_MIN_GEN_P: hipLaunchKernelGGL(k_minimizer_generic<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
+        case K_MIN_GEN_A: hipLaunchKernelGGL(k_minimizer_generic<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
+        case K_NT_P: hipLaunchKernelGGL(k_nthash_stream<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
+        case K_NT_A: hipLaunchKernelGGL(k_nthash_stream<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
+        case K_MIN_FAST: fast_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
     }
     if (ev1) HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
     HIPCHK(ctx, hipGetLastError());
     return BSK_OK;
 }
 
-// capacity guess (tuples); an undershoot is detected on device and the call re-runs with the exact size
+// capacity guess (tuples) for the dense kernels; an undershoot is detected on device and the call re-runs
+// with the exact size
 static u64 estimate_cap(const bsk_batch *b, const bsk_params *p, int circ_ext) {
     const u64 bases = b->n_bases + b->n * (u64)circ_ext;
     switch (p->kind) {
@@ -850,54 +900,83 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
         b = tmp;
         circ_ext = p->k - 1;
     }
-    u64 cap = estimate_cap(b, p, circ_ext);
-    if (*result && (*result)->cap > cap) cap = (*result)->cap;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (kernel_ms) {
-        (void)hipEventCreate(&ev0);
-        (void)hipEventCreate(&ev1);
-    }
     auto cleanup = [&](int code) {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (tmp) bsk_batch_destroy(tmp);
         return code;
     };
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    Plan pl;
+    rc = make_plan(ctx, b, p, pl);
+    if (rc != BSK_OK) return cleanup(rc);
+    u64 ovf_cap = pl.slab ? std::max<u64>(65536, pl.slab_total / 50) : 0;
+    if (pl.slab && *result && (*result)->ovf_cap > ovf_cap) ovf_cap = (*result)->ovf_cap;
+    u64 cap = pl.slab ? pl.slab_total + ovf_cap : estimate_cap(b, p, circ_ext);
+    if (*result && (*result)->cap > cap) cap = (*result)->cap;
+    // bsk_sketch always runs (and sizes) once; bsk_sketch_timed on an existing result only repeats the launch
+    const bool sizing = *result == nullptr || warmup + iters == 0;
+    for (int attempt = 0; sizing && attempt < 2; ++attempt) {
         rc = result_prepare(ctx, result, b->n, p->kind, cap);
         if (rc != BSK_OK) return cleanup(rc);
         bsk_result *res = *result;
-        rc = launch(ctx, b, p, res, circ_ext, nullptr, nullptr);
+        res->ovf_cap = pl.slab ? res->cap - pl.slab_total : 0;
+        rc = launch(ctx, b, p, res, circ_ext, pl, nullptr, nullptr);
         if (rc != BSK_OK) return cleanup(rc);
-        hipError_t e = hipMemcpyAsync(ctx->h_pinned, ctx->d_total, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_pinned + 1, ctx->d_ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e = hipMemcpyAsync(ctx->h_pinned, ctx->d_total, 2 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_pinned + 2, ctx->d_ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) return cleanup(fail_hip(ctx, e, "bsk_sketch run"));
-        const u64 total = ctx->h_pinned[0];
-        const u32 ovf = ((u32 *)(ctx->h_pinned + 1))[1];
+        const u64 total = ctx->h_pinned[0], ovf_used = ctx->h_pinned[1];
+        const u32 ovf = ((u32 *)(ctx->h_pinned + 2))[1];
         res->n_tuples = total;
         if (!ovf) break;
         if (attempt == 1) {
             ctx->err = "result capacity overflow after exact re-size";
             return cleanup(BSK_ERR_DEVICE);
         }
-        cap = total + 64;  // exact size known now: re-run once
+        cap = pl.slab ? pl.slab_total + ovf_used + ovf_used / 4 + 65536 : total + 64;  // size known now: re-run once
     }
-    // timed repetitions (same result buffers; capacity is now known to be sufficient)
+    if (sizing && pl.slab && b->n) {  // slab kernels keep no running total: sum the per-read counts once
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, sizeof(u64), ctx->stream));
+        hipLaunchKernelGGL(k_sum_counts, dim3(grid_for(ctx, b->n, 256)), dim3(256), 0, ctx->stream, (*result)->refs, b->n, ctx->d_total);
+        hipError_t e = hipMemcpyAsync(ctx->h_pinned, ctx->d_total, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return cleanup(fail_hip(ctx, e, "bsk_sketch count"));
+        (*result)->n_tuples = ctx->h_pinned[0];
+    }
+    // timed repetitions (same result buffers; capacity is now known to be sufficient).  All launches are queued
+    // back to back; the per-kernel HIP events are read after one final stream synchronisation.
+    std::vector<hipEvent_t> evs;
+    if (kernel_ms)
+        for (int i = 0; i < 2 * iters; ++i) {
+            hipEvent_t e = nullptr;
+            (void)hipEventCreate(&e);
+            evs.push_back(e);
+        }
+    auto drop_events = [&]() {
+        for (hipEvent_t e : evs)
+            if (e) (void)hipEventDestroy(e);
+    };
     for (int it = 0; it < warmup + iters; ++it) {
         const bool timed = it >= warmup && kernel_ms;
-        rc = launch(ctx, b, p, *result, circ_ext, timed ? ev0 : nullptr, timed ? ev1 : nullptr);
-        if (rc != BSK_OK) return cleanup(rc);
-        if (timed) {
-            hipError_t e = hipEventSynchronize(ev1);
-            float ms = 0;
-            if (e == hipSuccess) e = hipEventElapsedTime(&ms, ev0, ev1);
-            if (e != hipSuccess) return cleanup(fail_hip(ctx, e, "event timing"));
-            kernel_ms[it - warmup] = ms;
+        rc = launch(ctx, b, p, *result, circ_ext, pl, timed ? evs[2 * (it - warmup)] : nullptr,
+                    timed ? evs[2 * (it - warmup) + 1] : nullptr);
+        if (rc != BSK_OK) {
+            drop_events();
+            return cleanup(rc);
         }
     }
     if (warmup + iters > 0) {
-        hipError_t e = hipStreamSynchronize(ctx->stream);
+        hipError_t e = hipMemcpyAsync(ctx->h_pinned + 2, ctx->d_ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess && ((u32 *)(ctx->h_pinned + 2))[1]) {
+            drop_events();
+            ctx->err = "result too small for this batch: call bsk_sketch first";
+            return cleanup(BSK_ERR_ARG);
+        }
+        for (int i = 0; e == hipSuccess && kernel_ms && i < iters; ++i) e = hipEventElapsedTime(&kernel_ms[i], evs[2 * i], evs[2 * i + 1]);
+        drop_events();
         if (e != hipSuccess) return cleanup(fail_hip(ctx, e, "bsk_sketch_timed sync"));
     }
     return cleanup(BSK_OK);

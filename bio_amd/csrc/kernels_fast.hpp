@@ -1,72 +1,93 @@
 // kernels_fast.hpp -- minimizer kernel specialised on the window size W (compile time).
 //
-// Same mapping as kernels_generic.hpp (one read per lane, 64 reads per wavefront,
-// wave-uniform loop counters) but the k-mer loop is unrolled by W so that
-//   * the sliding-window state (suffix minima of the previous block of W k-mers,
-//     running prefix minimum of the current block) lives entirely in VGPRs with
-//     static indices -- no LDS/HBM traffic for the window at all;
-//   * the 2-bit codes of the W incoming and W outgoing bases of a block are cut
-//     out of the packed stream once per block (one v_alignbit each) and then
-//     addressed with immediate shifts; the packed words of the NEXT block are
-//     requested while the current block is being hashed;
-//   * per k-mer the only memory read is ONE 16-byte LDS fetch of the
-//     (outgoing, incoming) -> (forward, reverse) update table, and all W of them
-//     are issued at the top of the block, ahead of the dependent hash chain;
-//   * the block body is branch-free: a selected tuple is stored to the lane's next
-//     LDS staging slot, a non-selected one to a per-lane dummy slot.
+// Mapping (same as kernels_generic.hpp): one read per lane, 64 reads ("unit") per
+// wavefront, wave-uniform loop counters, true rolling ntHash per lane.  What is
+// specialised here:
+//   * the k-mer loop is unrolled by W: the sliding-window state (suffix minima of the
+//     previous block of W k-mers, running prefix minimum of the current block) lives
+//     in VGPRs with static indices -- no LDS/HBM traffic for the window;
+//   * the 2-bit codes of the W incoming / W outgoing bases of a block are cut out of
+//     the packed stream once per block (one v_alignbit each); the packed words of the
+//     NEXT block are requested while the current block is hashed;
+//   * per k-mer the only memory read is ONE 16-byte LDS fetch of the (outgoing,
+//     incoming) -> (forward, reverse) update table; all W of them are issued at the top
+//     of the block, ahead of the dependent hash chain;
+//   * no inter-wavefront synchronisation at all: unit u owns the fixed slab
+//     [u*64*CAP, (u+1)*64*CAP) of the tuple arrays, so its tuples go out with nothing to
+//     wait for (a look-back chain over the ~1500 resident units cost 37 % of the run
+//     time in the first version of this kernel);
+//   * instruction selection follows the measured gfx950 integer issue rates
+//     (scripts/ubench): and/or/xor/lshr/add are full rate, everything VOP3 is half
+//     rate, and a VOP2 v_cndmask reading VCC costs ~5 half-rate slots -- so every
+//     select is forced to the VOP3 form with an SGPR-pair mask.
 // HBM traffic is the packed bases in and the selected (hash, pos|strand) tuples
-// out; tuples leave LDS as whole 512-/256-byte rows.
+// plus one 8-byte reference per read out; tuples leave LDS as whole 512-/256-byte rows.
 #pragma once
 #include "kernels_generic.hpp"
 
 namespace bsk {
 
-// LDS staging for the fast kernels: slot(e, lane) = e*65 + lane (row stride 65: a lane's
-// consecutive tuples rotate through the banks; lanes at equal e are consecutive).
-// Row CAP is the dummy row (slot CAP*65 + lane) that absorbs non-selected stores.
-template <int CAP>
-struct FStage {
-    u64 *sh;  // [(CAP+1)*65]
-    u32 *sp;  // [(CAP+1)*65]
-    u16 *smap;
-    static constexpr int SLOTS = (CAP + 1) * 65;
-};
+typedef u64 lmask;  // one bit per lane, lives in an SGPR pair
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
-struct H64 {
-    u32 lo, hi;
-};
-__device__ __forceinline__ u64 to64(H64 v) { return ((u64)v.hi << 32) | v.lo; }
-__device__ __forceinline__ H64 hrol1(H64 v) {
-    H64 r;
-    r.lo = __builtin_amdgcn_alignbit(v.lo, v.hi, 31);
-    r.hi = __builtin_amdgcn_alignbit(v.hi, v.lo, 31);
-    return r;
+// VOP3 compare -> SGPR pair, VOP3 select <- SGPR pair.  (v_cmp -> v_cndmask through an
+// SGPR needs no software wait states on gfx9; the asm only pins the encoding.)
+__device__ __forceinline__ lmask lt64(u32 alo, u32 ahi, u32 blo, u32 bhi) {
+    return __builtin_amdgcn_ballot_w64((((u64)ahi << 32) | alo) < (((u64)bhi << 32) | blo));
 }
-__device__ __forceinline__ H64 hror1(H64 v) {
-    H64 r;
-    r.lo = __builtin_amdgcn_alignbit(v.hi, v.lo, 1);
-    r.hi = __builtin_amdgcn_alignbit(v.lo, v.hi, 1);
+__device__ __forceinline__ u32 sel(lmask m, u32 t, u32 f) {  // m ? t : f
+    u32 r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(t), "s"(m));
     return r;
 }
 
-template <int W, int CAP, bool DIRECT>
+struct HV {  // hash (lo, hi) + pos|strand
+    u32 lo, hi, p;
+};
+__device__ __forceinline__ HV selv(lmask m, HV t, HV f) {
+    HV r;
+    r.lo = sel(m, t.lo, f.lo);
+    r.hi = sel(m, t.hi, f.hi);
+    r.p = sel(m, t.p, f.p);
+    return r;
+}
+
+// LDS plan of one wavefront (bytes).  7 wavefronts per CU fit in the 160 KB.
+#define LDSQ __attribute__((address_space(3)))
+template <int CAP, bool POS16>
+struct FLds {
+    static constexpr int ROW = 65;  // slot(e, lane) = e*65 + lane: bank-conflict free for the per-lane
+                                    // stores (equal e -> consecutive lanes) and for the copy-out reads
+                                    // (one lane's consecutive e rotate through the banks).
+                                    // Row CAP is a dummy row: it absorbs the stores of non-selected steps.
+    static constexpr int PB = POS16 ? 2 : 4;
+    static constexpr int TAB = 0;                                           // 20 x uint4 update table
+    static constexpr int SH = 512;                                          // u64 [(CAP+1)*65]
+    static constexpr int SP = SH + (CAP + 1) * ROW * 8;                     // u16|u32 [(CAP+1)*65]
+    static constexpr int EXCL = SP + (((CAP + 1) * ROW * PB + 15) & ~15);   // u32 [64]
+    static constexpr int HEADS = EXCL + 256;  // u64 [CAP+1]: bit j of word c: a lane's run starts at output 64c+j
+    static constexpr int NZ = HEADS + (CAP + 1) * 8;  // u8 [64]: rank among non-empty lanes -> lane
+    static constexpr int TOTAL = NZ + 64;
+};
+
+template <int W, int CAP, bool POS16, bool DIRECT>
 struct FastMin {
+    typedef FLds<CAP, POS16> LY;
+    static constexpr u32 SBIT = POS16 ? 0x8000u : 0x80000000u;  // strand bit inside the staged pos word
     const u32 *__restrict__ w;
-    const uint4 *__restrict__ xt;
+    LDSQ char *lds;
     int k, lane;
     u32 nk;
-    FStage<CAP> st;
     u64 *__restrict__ ghash;
     u32 *__restrict__ gpos;
     u64 gbase;
     // rolling state
-    H64 fh, rh;
-    u64 bh[W];
-    u32 bp[W];
-    u64 Ph;
-    u32 Pp, prev, cnt, tie;
-    // packed words of the current block: (in_lo,in_hi) from base t0, (out_lo,out_hi) from base i0-1
-    u32 in_lo, in_hi, out_lo, out_hi;
+    u32 fl, fh_, rl, rh_;  // forward / reverse hash halves
+    HV S[W];               // suffix minima of the previous block (then raw values of the current one)
+    HV P;                  // running prefix minimum of the current block
+    u32 prev, cnt, tie;
+    u32 slot;                          // byte offset (from SH) of this lane's next staging slot = (cnt*65 + lane)*8
+    u32 in_lo, in_hi, out_lo, out_hi;  // packed words of the current block
 
     __device__ __forceinline__ void load_block_words(u32 i0) {
         const u32 t0 = i0 + (u32)k - 1;
@@ -76,126 +97,130 @@ struct FastMin {
         out_lo = w[p0 >> 4];
         out_hi = w[(p0 >> 4) + 1];
     }
-
-    __device__ __forceinline__ void select(bool e, u64 mh, u32 mp) {
-        if (!DIRECT) {
-            const bool keep = e && cnt < (u32)CAP;
-            const u32 sl = (keep ? cnt : (u32)CAP) * 65u + (u32)lane;
-            st.sh[sl] = mh;
-            st.sp[sl] = mp;
-        } else if (e) {
-            ghash[gbase + cnt] = mh;
-            gpos[gbase + cnt] = mp;
-        }
-        cnt += e ? 1u : 0u;
+    __device__ __forceinline__ void roll(u32x4 x) {
+        const u32 a = __builtin_amdgcn_alignbit(fl, fh_, 31), b = __builtin_amdgcn_alignbit(fh_, fl, 31);
+        const u32 c = __builtin_amdgcn_alignbit(rh_, rl, 1), d = __builtin_amdgcn_alignbit(rl, rh_, 1);
+        fl = a ^ x.x;
+        fh_ = b ^ x.y;
+        rl = c ^ x.z;
+        rh_ = d ^ x.w;
     }
 
-    template <bool FIRST>
+    // UNI: every lane of the wave has the same number of k-mers (no per-lane bound check)
+    // GUARD: some lane may reach CAP staged tuples inside this block (store must be bounded)
+    template <bool FIRST, bool UNI, bool GUARD>
     __device__ __forceinline__ void block(u32 i0) {
         const u32 t0 = i0 + (u32)k - 1;
-        const u32 cinb = __builtin_amdgcn_alignbit(in_hi, in_lo, (t0 & 15) * 2);
+        const u32 cinb = __builtin_amdgcn_alignbit(in_hi, in_lo, (t0 & 15) * 2);  // code of slot o at bits [2o, 2o+2)
         u32 coutb;
         if (FIRST) coutb = out_lo << 2;  // slot 0: nothing leaves; slot o >= 1 sees base o-1
         else coutb = __builtin_amdgcn_alignbit(out_hi, out_lo, ((i0 - 1) & 15) * 2);
-        // all W table fetches first: they do not depend on the hash chain
-        uint4 xs[W];
+        u32x4 xs[W];
 #pragma unroll
-        for (int o = 0; o < W; ++o) {
-            const u32 cin = (cinb >> (2 * o)) & 3;
-            u32 idx = (((coutb >> (2 * o)) & 3) << 2) | cin;
-            if (FIRST && o == 0) idx = 16 + cin;
-            xs[o] = xt[idx];
+        for (int o = 0; o < W; ++o) {  // byte offset into the table = out*64 + in*16 ; row "nothing leaves" = 256 + in*16
+            const u32 a = (o >= 2 ? (cinb >> (2 * o - 4)) : (cinb << (4 - 2 * o))) & 0x30u;
+            const u32 b = (FIRST && o == 0) ? 0x100u : ((o >= 3 ? (coutb >> (2 * o - 6)) : (coutb << (6 - 2 * o))) & 0xC0u);
+            xs[o] = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB + (a | b));
         }
         load_block_words(i0 + W);  // next block's words: in flight while this block is hashed
+        u32 vi = i0;               // k-mer index as a VGPR (selects need VGPR operands)
+        const u32 dummy = (u32)(CAP * LY::ROW + lane) * 8u;
 #pragma unroll
         for (int o = 0; o < W; ++o) {
-            const u32 i = i0 + o;
-            fh = hrol1(fh);
-            rh = hror1(rh);
-            fh.lo ^= xs[o].x;
-            fh.hi ^= xs[o].y;
-            rh.lo ^= xs[o].z;
-            rh.hi ^= xs[o].w;
-            const u64 f64 = to64(fh), r64 = to64(rh);
-            const bool rev = r64 < f64;
-            const u64 h = rev ? r64 : f64;
-            const u32 ps = rev ? (i | 0x80000000u) : i;
+            roll(xs[o]);
+            const lmask rev = lt64(rl, rh_, fl, fh_);
+            HV v;
+            v.lo = sel(rev, rl, fl);
+            v.hi = sel(rev, rh_, fh_);
+            v.p = sel(rev, vi | SBIT, vi);
             if (o == 0) {
-                Ph = h;
-                Pp = ps;
-            } else if (h < Ph) {
-                Ph = h;
-                Pp = ps;
+                P = v;
+            } else {
+                P = selv(lt64(v.lo, v.hi, P.lo, P.hi), v, P);
             }
             if (!FIRST || o == W - 1) {
-                u64 mh = Ph;
-                u32 mp = Pp;
-                if (o != W - 1) {
-                    const bool takeS = !(Ph < bh[o + 1]);
-                    mh = takeS ? bh[o + 1] : Ph;
-                    mp = takeS ? bp[o + 1] : Pp;
+                HV m = P;
+                if (o != W - 1) m = selv(lt64(P.lo, P.hi, S[o + 1].lo, S[o + 1].hi), P, S[o + 1]);
+                lmask e = __builtin_amdgcn_ballot_w64(m.p != prev);
+                if (!UNI) e &= __builtin_amdgcn_ballot_w64(vi < nk);
+                prev = m.p;
+                if (!DIRECT) {
+                    // branch-free: a selected tuple goes to the lane's next slot, anything else to the dummy row
+                    lmask st = e;
+                    if (GUARD) st &= __builtin_amdgcn_ballot_w64(slot < dummy);
+                    const u32 addr = sel(st, slot, dummy);
+                    *reinterpret_cast<LDSQ u64 *>(lds + LY::SH + addr) = ((u64)m.hi << 32) | m.lo;
+                    if (POS16) *reinterpret_cast<LDSQ u16 *>(lds + LY::SP + (addr >> 2)) = (u16)m.p;
+                    else *reinterpret_cast<LDSQ u32 *>(lds + LY::SP + (addr >> 1)) = m.p;
+                    slot = sel(e, slot + (u32)(LY::ROW * 8), slot);
+                } else {
+                    if ((e >> lane) & 1) {
+                        const u32 c = (slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);
+                        ghash[gbase + c] = ((u64)m.hi << 32) | m.lo;
+                        gpos[gbase + c] = POS16 ? ((m.p & 0x7fffu) | ((m.p & 0x8000u) << 16)) : m.p;
+                        slot += (u32)(LY::ROW * 8);
+                    }
                 }
-                const bool e = (i < nk) & (mp != prev);
-                prev = mp;
-                select(e, mh, mp);
             }
-            bh[o] = h;
-            bp[o] = ps;
+            S[o] = v;
+            vi += 1;
         }
-        if (FIRST && !DIRECT) {
+        if (FIRST && !DIRECT) {  // BSK_ST_FIRST_WINDOW_TIE: two equal hashes among the first W
+            lmask tm = 0;
 #pragma unroll
             for (int a = 0; a + 1 < W; ++a)
 #pragma unroll
-                for (int b = a + 1; b < W; ++b) tie |= (bh[a] == bh[b]) ? 1u : 0u;
+                for (int b = a + 1; b < W; ++b)
+                    tm |= __builtin_amdgcn_ballot_w64((((u64)S[a].hi << 32) | S[a].lo) == (((u64)S[b].hi << 32) | S[b].lo));
+            tie = (u32)((tm >> lane) & 1);
         }
 #pragma unroll
-        for (int q = W - 2; q >= 0; --q) {
-            const bool t = bh[q + 1] < bh[q];
-            bh[q] = t ? bh[q + 1] : bh[q];
-            bp[q] = t ? bp[q + 1] : bp[q];
-        }
+        for (int q = W - 2; q >= 0; --q)  // S[q] = min(S[q..W-1]), the older (left) element wins ties
+            S[q] = selv(lt64(S[q + 1].lo, S[q + 1].hi, S[q].lo, S[q].hi), S[q + 1], S[q]);
     }
 
+    template <bool UNI>
     __device__ __forceinline__ void run(u32 nk_max) {
-        fh.lo = fh.hi = rh.lo = rh.hi = 0;
-        Ph = 0;
-        Pp = 0;
+        fl = fh_ = rl = rh_ = 0;
         prev = 0xffffffffu;
-        cnt = 0;
         tie = 0;
+        slot = (u32)lane * 8u;
         // warm-up: bases 0..k-2 enter, nothing leaves (table rows 16..19)
         for (int t0 = 0; t0 < k - 1; t0 += 16) {
             const u32 word = w[t0 >> 4];
             const int nb = (k - 1 - t0) < 16 ? (k - 1 - t0) : 16;
-            for (int j = 0; j < nb; ++j) {
-                const uint4 x = xt[16 + ((word >> (2 * j)) & 3)];
-                fh = hrol1(fh);
-                rh = hror1(rh);
-                fh.lo ^= x.x;
-                fh.hi ^= x.y;
-                rh.lo ^= x.z;
-                rh.hi ^= x.w;
-            }
+            for (int j = 0; j < nb; ++j)
+                roll(*reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB + 256 + (((word >> (2 * j)) & 3) << 4)));
         }
         load_block_words(0);
-        block<true>(0);
-        for (u32 i0 = W; i0 < nk_max; i0 += W) block<false>(i0);
+        block<true, UNI, false>(0);
+        const u32 guard_from = (u32)((CAP - W) * LY::ROW + lane) * 8u;  // slot value from which a block could overrun row CAP-1
+        for (u32 i0 = W; i0 < nk_max; i0 += W) {
+            // a lane stages at most W tuples per block: the bounded store is only needed near the cap
+            const bool guard = !DIRECT && __builtin_amdgcn_ballot_w64(slot > guard_from) != 0;
+            if (i0 + W > nk_max) {  // partial last block: per-lane bound check even when the wave is uniform
+                if (guard) block<false, false, true>(i0);
+                else block<false, false, false>(i0);
+            } else if (guard) {
+                block<false, UNI, true>(i0);
+            } else {
+                block<false, UNI, false>(i0);
+            }
+        }
+        cnt = (slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);
     }
 };
 
-template <int W, int CAP>
+template <int W, int CAP, bool POS16>
 __global__ __launch_bounds__(64) void k_minimizer_fast(KArgs a) {
-    __shared__ uint4 s_tab[32];
-    __shared__ u64 s_h[FStage<CAP>::SLOTS];
-    __shared__ u32 s_p[FStage<CAP>::SLOTS];
-    __shared__ u16 s_m[CAP * 64];
+    typedef FLds<CAP, POS16> LY;
+    __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
+    LDSQ char *const ldsq = (LDSQ char *)lds;
     const int lane = lane_id();
-    build_xtab(s_tab, a.k, lane);
+    build_xtab(reinterpret_cast<uint4 *>(lds + LY::TAB), a.k, lane);
     __syncthreads();
-    FStage<CAP> st{s_h, s_p, s_m};
-    for (;;) {
-        const u32 unit = next_ticket(a.ticket, lane);
-        if (unit >= a.nunits) break;
+    const u64 slab = (u64)64 * CAP;
+    for (u32 unit = blockIdx.x; unit < a.nunits; unit += gridDim.x) {
         const u64 r = (u64)unit * 64 + lane;
         u64 off = 0, L = 0;
         if (r < a.n) {
@@ -206,80 +231,118 @@ __global__ __launch_bounds__(64) void k_minimizer_fast(KArgs a) {
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
         const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
         const u32 nk_max = wave_max_u32(nk);
+        const bool uni = __builtin_amdgcn_ballot_w64(nk != nk_max) == 0;
         u32 cnt = 0, tie = 0;
         if (nk_max) {
-            FastMin<W, CAP, false> fm;
+            FastMin<W, CAP, POS16, false> fm;
             fm.w = a.words + off;
-            fm.xt = s_tab;
+            fm.lds = ldsq;
             fm.k = a.k;
             fm.lane = lane;
             fm.nk = nk;
-            fm.st = st;
-            fm.ghash = a.hash;
-            fm.gpos = a.pos;
-            fm.gbase = 0;
-            fm.run(nk_max);
+            if (uni) fm.template run<true>(nk_max);
+            else fm.template run<false>(nk_max);
             cnt = fm.cnt;
             tie = fm.tie;
         }
-        // ---- unit epilogue: scan, look-back, LDS -> HBM copy-out, CSR offsets ----
+        // ---- unit epilogue: LDS -> HBM in read order into the unit's slab ----
         const u32 incl = wave_incl_scan_u32(cnt, lane);
         const u32 excl = incl - cnt;
         const u32 T = wave_bcast_u32(incl, 63);
-        const u64 base = (a.debug & 1) ? (u64)unit * (64 * CAP) : lookback_exclusive(a.lookback, unit, (u64)T, lane);
-        const bool ovf = base + T > a.cap;
-        const bool any_over = __ballot(cnt > (u32)CAP) != 0;
-        if (a.debug & 2) {
-        } else if (!ovf && !any_over) {
-            const u32 cmax = wave_max_u32(cnt);
-            for (u32 e = 0; e < cmax; ++e)
-                if (e < cnt) st.smap[excl + e] = (u16)(e * 65u + (u32)lane);
+        const bool any_over = __builtin_amdgcn_ballot_w64(cnt > (u32)CAP) != 0;
+        u64 base = (u64)unit * slab;
+        if (!any_over) {
+            // owner of output t = lane whose run [excl, excl+cnt) holds t.  One head bit per non-empty lane,
+            // popcount below the bit -> rank among non-empty lanes -> lane (no per-output map in LDS).
+            u32 *s_excl = reinterpret_cast<u32 *>(lds + LY::EXCL);
+            u64 *s_heads = reinterpret_cast<u64 *>(lds + LY::HEADS);
+            u8 *s_nz = reinterpret_cast<u8 *>(lds + LY::NZ);
+            const u64 nzmask = __builtin_amdgcn_ballot_w64(cnt > 0);
+            s_excl[lane] = excl;
+            if (lane <= CAP) s_heads[lane] = 0;
             __syncthreads();
-            for (u32 t = lane; t < T; t += 64) {
-                const u32 sl = st.smap[t];
-                a.hash[base + t] = st.sh[sl];
-                a.pos[base + t] = st.sp[sl];
+            if (cnt > 0) {
+                s_nz[__builtin_amdgcn_mbcnt_hi((u32)(nzmask >> 32), __builtin_amdgcn_mbcnt_lo((u32)nzmask, 0))] = (u8)lane;
+                atomicOr(&s_heads[excl >> 6], 1ULL << (excl & 63));
             }
             __syncthreads();
-        } else if (!ovf) {  // rare: some lane selected more than CAP tuples -> recompute, store straight to HBM
-            FastMin<W, CAP, true> fm;
-            fm.w = a.words + off;
-            fm.xt = s_tab;
-            fm.k = a.k;
-            fm.lane = lane;
-            fm.nk = nk;
-            fm.st = st;
-            fm.ghash = a.hash;
-            fm.gpos = a.pos;
-            fm.gbase = base + excl;
-            fm.run(nk_max);
-        } else if (lane == 0) {
-            atomicOr(&a.ticket[1], 1u);
+            u32 heads_before = 0;
+            const u64 *sh = reinterpret_cast<const u64 *>(lds + LY::SH);
+            for (u32 t0 = 0; t0 < T; t0 += 64) {
+                const u64 M = s_heads[t0 >> 6];
+                const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(M >> 32), __builtin_amdgcn_mbcnt_lo((u32)M, 0));
+                const u32 upto = below + (u32)((M >> lane) & 1);
+                const u32 t = t0 + lane;
+                if (t < T) {
+                    const u32 owner = s_nz[heads_before + upto - 1];
+                    const u32 sl = (t - s_excl[owner]) * LY::ROW + owner;
+                    a.hash[base + t] = sh[sl];
+                    u32 p;
+                    if (POS16) {
+                        p = *reinterpret_cast<const u16 *>(lds + LY::SP + sl * 2);
+                        p = (p & 0x7fffu) | ((p & 0x8000u) << 16);
+                    } else {
+                        p = *reinterpret_cast<const u32 *>(lds + LY::SP + sl * 4);
+                    }
+                    a.pos[base + t] = p;
+                }
+                heads_before += (u32)__builtin_popcountll(M);
+            }
+            __syncthreads();
+        } else {
+            // rare (0.6 % of units at k=21 w=11 CAP=32): a lane selected more than CAP tuples.  The unit may not
+            // fit its slab: take T tuples from the overflow region and recompute, storing straight to HBM.
+            u64 ob = 0;
+            if (lane == 0) ob = atomicAdd(a.total + 1, (u64)T);
+            ob = wave_bcast_u64(ob, 0);
+            if (ob + T <= a.ovf_cap) {
+                base = a.ovf_base + ob;
+                FastMin<W, CAP, POS16, true> fm;
+                fm.w = a.words + off;
+                fm.lds = ldsq;
+                fm.k = a.k;
+                fm.lane = lane;
+                fm.nk = nk;
+                fm.ghash = a.hash;
+                fm.gpos = a.pos;
+                fm.gbase = base + excl;
+                fm.template run<false>(nk_max);
+            } else {
+                cnt = 0;  // result buffers too small: flagged, the host re-runs with a larger overflow region
+                if (lane == 0) atomicOr(&a.ticket[1], 1u);
+            }
         }
         if (r < a.n) {
-            a.offsets[r + 1] = base + incl;
+            a.refs[r] = ((base + excl) << 24) | cnt;
             u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
             if (tie) sbyte |= BSK_ST_FIRST_WINDOW_TIE;
             if (ok && a.rflags) sbyte |= a.rflags[r];
             a.status[r] = sbyte;
         }
-        if (unit == 0 && lane == 0) a.offsets[0] = 0;
-        if (unit == a.nunits - 1 && lane == 63) *a.total = base + incl;
     }
 }
 
 // ---- dispatch table --------------------------------------------------------------------
 #define BSK_FAST_CAP 32
-#define BSK_FAST_WS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#define BSK_FAST_WS(X) X(4) X(5) X(8) X(10) X(11) X(12) X(15) X(16)
 
-static inline bool fast_minimizer_supported(int w) { return w >= 2 && w <= 16; }
+static inline bool fast_minimizer_supported(int w) {
+    switch (w) {
+#define X(WW) case WW:
+        BSK_FAST_WS(X)
+#undef X
+        return true;
+        default: return false;
+    }
+}
 
-static inline int fast_minimizer_blocks_per_cu(int w) {
+template <bool POS16>
+static inline int fast_minimizer_blocks_per_cu_t(int w) {
     int nb = 0;
     hipError_t e = hipErrorInvalidValue;
     switch (w) {
 #define X(WW) \
-    case WW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_minimizer_fast<WW, BSK_FAST_CAP>, 64, 0); break;
+    case WW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_minimizer_fast<WW, BSK_FAST_CAP, POS16>, 64, 0); break;
         BSK_FAST_WS(X)
 #undef X
         default: break;
@@ -290,11 +353,13 @@ static inline int fast_minimizer_blocks_per_cu(int w) {
     }
     return nb;
 }
+static inline int fast_minimizer_blocks_per_cu(int w) { return fast_minimizer_blocks_per_cu_t<true>(w); }
 
+// staged positions are 15 bit + strand: the fast path takes reads shorter than 32768 bases (longer: generic kernel)
 static inline void fast_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a) {
     switch (w) {
 #define X(WW) \
-    case WW: hipLaunchKernelGGL((k_minimizer_fast<WW, BSK_FAST_CAP>), dim3(grid), dim3(64), 0, stream, a); break;
+    case WW: hipLaunchKernelGGL((k_minimizer_fast<WW, BSK_FAST_CAP, true>), dim3(grid), dim3(64), 0, stream, a); break;
         BSK_FAST_WS(X)
 #undef X
         default: break;

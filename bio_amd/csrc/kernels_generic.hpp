@@ -28,7 +28,7 @@ struct KArgs {
     // parameters
     int kind, k, w, s, canonical, circ_ext, m, scale;
     // output
-    u64 *offsets;
+    u64 *refs;     // per read: (first_tuple << 24) | n_tuples
     u8 *status;
     u64 *hash;
     u32 *pos;
@@ -36,11 +36,12 @@ struct KArgs {
     // synchronisation / scratch
     u32 *ticket;    // [0] unit ticket, [1] overflow flag
     u64 *lookback;  // [nunits]
-    u64 *total;     // [1]
+    u64 *total;     // [0] tuples written by the dense (look-back) kernels, [1] overflow-region cursor (slab kernels)
     u64 *ring_h;    // runtime-w ring: per workgroup ring_w*64 entries
     u32 *ring_p;
     u32 ring_w;
-    u32 debug;  // dev experiments (BSK_DEBUG env): bit0 no look-back (slab bases), bit1 no copy-out
+    u64 ovf_base;   // slab kernels: first tuple index of the overflow region, and its size
+    u64 ovf_cap;
 };
 
 // X table: one 16-byte entry per (outgoing code 0..4, incoming code 0..3);
@@ -247,8 +248,8 @@ __device__ __forceinline__ void window_pass(Src &src, u32 nk, u32 nk_max, int W,
 
 // Unit epilogue shared by every tuple-producing kernel: wave scan of the per-lane
 // counts, look-back for the unit's global base, LDS -> HBM copy-out in read order,
-// CSR offsets, status bytes.  Returns the unit's global base and whether the
-// result buffer is too small (then nothing is written, only offsets/total).
+// per-read references, status bytes.  Returns the unit's global base and whether the
+// result buffer is too small (then nothing is written, only refs/total).
 template <int CAP>
 __device__ __forceinline__ u64 unit_epilogue(const KArgs &a, u32 unit, int lane, u64 r, u32 c, Stage<CAP> st,
                                              u32 &excl_out, bool &ovf_out) {
@@ -277,8 +278,7 @@ __device__ __forceinline__ u64 unit_epilogue(const KArgs &a, u32 unit, int lane,
     } else if (lane == 0) {
         atomicOr(&a.ticket[1], 1u);
     }
-    if (r < a.n) a.offsets[r + 1] = base + incl;
-    if (unit == 0 && lane == 0) a.offsets[0] = 0;
+    if (r < a.n) a.refs[r] = ((base + excl) << 24) | c;
     if (unit == a.nunits - 1 && lane == 63) *a.total = base + incl;
     excl_out = excl;
     ovf_out = ovf;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64) void k_minimizer_generic(KArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
-// "Every position" kinds: value i of read r goes to out[offsets[r] + i].  Counts are
+// "Every position" kinds: value i of read r goes to out[first_tuple(r) + i].  Counts are
 // known from the lengths alone, so the look-back runs BEFORE the hashing and values
 // stream out through a 64x16 LDS transpose tile (row = read): each flush writes
 // 128 contiguous bytes per read with 16-byte stores.
@@ -403,8 +403,7 @@ __global__ __launch_bounds__(64) void k_nthash_stream(KArgs a) {
         const u64 base = lookback_exclusive(a.lookback, unit, T, lane);
         const bool ovf = base + T > a.cap;
         if (ovf && lane == 0) atomicOr(&a.ticket[1], 1u);
-        if (r < a.n) a.offsets[r + 1] = base + incl;
-        if (unit == 0 && lane == 0) a.offsets[0] = 0;
+        if (r < a.n) a.refs[r] = ((base + incl - nk) << 24) | nk;
         if (unit == a.nunits - 1 && lane == 63) *a.total = base + incl;
         if (r < a.n) {
             u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
