@@ -59,7 +59,8 @@ struct FLds {
     static constexpr int ROW = 65;  // slot(e, lane) = e*65 + lane: bank-conflict free for the per-lane
                                     // stores (equal e -> consecutive lanes) and for the copy-out reads
                                     // (one lane's consecutive e rotate through the banks).
-                                    // Row CAP is a dummy row: it absorbs the stores of non-selected steps.
+                                    // Row CAP is a spare row: every step stores to the lane's NEXT slot (a non-selected
+                                    // candidate is simply overwritten later), so a full lane scribbles on row CAP.
     static constexpr int PB = POS16 ? 2 : 4;
     static constexpr int TAB = 0;                                           // 20 x uint4 update table
     static constexpr int SH = 512;                                          // u64 [(CAP+1)*65]
@@ -124,7 +125,7 @@ struct FastMin {
         }
         load_block_words(i0 + W);  // next block's words: in flight while this block is hashed
         u32 vi = i0;               // k-mer index as a VGPR (selects need VGPR operands)
-        const u32 dummy = (u32)(CAP * LY::ROW + lane) * 8u;
+        const u32 spare = (u32)(CAP * LY::ROW + lane) * 8u;
 #pragma unroll
         for (int o = 0; o < W; ++o) {
             roll(xs[o]);
@@ -145,10 +146,10 @@ struct FastMin {
                 if (!UNI) e &= __builtin_amdgcn_ballot_w64(vi < nk);
                 prev = m.p;
                 if (!DIRECT) {
-                    // branch-free: a selected tuple goes to the lane's next slot, anything else to the dummy row
-                    lmask st = e;
-                    if (GUARD) st &= __builtin_amdgcn_ballot_w64(slot < dummy);
-                    const u32 addr = sel(st, slot, dummy);
+                    // branch-free: every candidate is stored to the lane's next slot; the slot only advances when the
+                    // candidate is a new selection, so anything else is overwritten (or left beyond the count)
+                    u32 addr = slot;
+                    if (GUARD) addr = sel(__builtin_amdgcn_ballot_w64(slot < spare), slot, spare);
                     *reinterpret_cast<LDSQ u64 *>(lds + LY::SH + addr) = ((u64)m.hi << 32) | m.lo;
                     if (POS16) *reinterpret_cast<LDSQ u16 *>(lds + LY::SP + (addr >> 2)) = (u16)m.p;
                     else *reinterpret_cast<LDSQ u32 *>(lds + LY::SP + (addr >> 1)) = m.p;
@@ -220,7 +221,13 @@ __global__ __launch_bounds__(64) void k_minimizer_fast(KArgs a) {
     build_xtab(reinterpret_cast<uint4 *>(lds + LY::TAB), a.k, lane);
     __syncthreads();
     const u64 slab = (u64)64 * CAP;
-    for (u32 unit = blockIdx.x; unit < a.nunits; unit += gridDim.x) {
+    // work distribution: a wave takes 8 consecutive units per ticket (one atomic per 512 reads)
+    for (u32 unit = next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; unit < a.nunits; ++unit, ({
+             if (unit == uend) {
+                 unit = next_ticket(a.ticket, lane) * 8u;
+                 uend = unit + 8u;
+             }
+         })) {
         const u64 r = (u64)unit * 64 + lane;
         u64 off = 0, L = 0;
         if (r < a.n) {
