@@ -761,7 +761,7 @@ static int blocks_per_cu(K kernel) {
 }
 
 // Which kernel runs a (batch, params) pair, on how many workgroups, and how the tuple arrays are organised.
-enum Which { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST };
+enum Which { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST, K_NT_FAST };
 struct Plan {
     Which which = K_MIN_GEN_P;
     int grid = 1;
@@ -793,12 +793,18 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
             pl.ring_w = (u32)p->w;
         }
     } else if (p->kind == BSK_NTHASH) {
-        pl.which = use_ascii ? K_NT_A : K_NT_P;
-        per_cu = use_ascii ? blocks_per_cu(k_nthash_stream<1>) : blocks_per_cu(k_nthash_stream<0>);
+        if (!use_ascii && !getenv("BSK_FORCE_GENERIC")) {
+            pl.which = K_NT_FAST;
+            per_cu = p->canonical ? blocks_per_cu(k_nthash_fast<true>) : blocks_per_cu(k_nthash_fast<false>);
+        } else {
+            pl.which = use_ascii ? K_NT_A : K_NT_P;
+            per_cu = use_ascii ? blocks_per_cu(k_nthash_stream<1>) : blocks_per_cu(k_nthash_stream<0>);
+        }
     } else {
         ctx->err = "kind not implemented yet";
         return BSK_ERR_UNSUPPORTED;
     }
+    if (getenv("BSK_WAVES_PER_CU")) per_cu = std::max(1, atoi(getenv("BSK_WAVES_PER_CU")));  // dev: occupancy experiments
     pl.grid = (int)std::max<u64>(1, std::min<u64>((u64)ctx->cus * per_cu, pl.nunits));
     pl.ring_entries = (size_t)pl.grid * pl.ring_w * 64;
     return BSK_OK;
@@ -825,6 +831,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     a.scale = p->scale;
     a.canonical = p->canonical ? 1 : 0;
     a.circ_ext = circ_ext;
+    a.uniform_len = b->uniform_len;
     a.refs = res->refs;
     a.status = res->status;
     a.hash = res->hash;
@@ -850,6 +857,10 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_NT_P: hipLaunchKernelGGL(k_nthash_stream<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_NT_A: hipLaunchKernelGGL(k_nthash_stream<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_MIN_FAST: fast_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
+        case K_NT_FAST:
+            if (a.canonical) hipLaunchKernelGGL(k_nthash_fast<true>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
+            else hipLaunchKernelGGL(k_nthash_fast<false>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
+            break;
     }
     if (ev1) HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
     HIPCHK(ctx, hipGetLastError());
@@ -1027,6 +1038,7 @@ static int make_circular(bsk_ctx *ctx, const bsk_batch *b, int k, bsk_batch **ou
     t->n_words = w;
     t->maxlen = maxlen;
     t->n_nonacgt = b->n_nonacgt;
+    t->uniform_len = (b->uniform_len && b->uniform_len >= (u32)(k - 1)) ? b->uniform_len + (u32)(k - 1) : 0;
     const u64 alloc_words = w + pad_words(maxlen);
     hipError_t e;
     if ((e = hipMalloc(&t->words, alloc_words * 4)) != hipSuccess || (e = hipMalloc(&t->desc, (n ? n : 1) * 8)) != hipSuccess ||

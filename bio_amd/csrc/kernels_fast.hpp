@@ -329,6 +329,131 @@ __global__ __launch_bounds__(64) void k_minimizer_fast(KArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// ntHash stream (kind BSK_NTHASH), 2-bit input: value i of read r -> hash[first(r) + i].
+// Same rolling core as above, unrolled by 16 (one packed word of bases per block); the 16
+// hashes of a block go through a 64x16 LDS tile (row = read) so that they leave as 128
+// contiguous bytes per read, 16 bytes per lane and store.  For fixed-length batches the
+// output offset of every read is a closed form, otherwise it comes from the look-back.
+// ---------------------------------------------------------------------------------------
+template <bool CANON>
+__global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
+    constexpr int TL = 18;  // u64 per tile row (16 + 2 pad: 144-byte rows keep 16-byte alignment, 2-way conflicts at most)
+    __shared__ __attribute__((aligned(16))) char lds[512 + 64 * TL * 8];
+    __shared__ u64 s_off[64];
+    __shared__ u32 s_nk[64];
+    LDSQ char *const lq = (LDSQ char *)lds;
+    const int lane = lane_id();
+    build_xtab(reinterpret_cast<uint4 *>(lds), a.k, lane);
+    __syncthreads();
+    const int k = a.k;
+    for (u32 unit = next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; unit < a.nunits; ++unit, ({
+             if (unit == uend) {
+                 unit = next_ticket(a.ticket, lane) * 8u;
+                 uend = unit + 8u;
+             }
+         })) {
+        const u64 r = (u64)unit * 64 + lane;
+        u64 off = 0, L = 0;
+        if (r < a.n) {
+            const u64 d = a.desc[r];
+            off = d >> 24;
+            L = d & 0xffffffULL;
+        }
+        const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) >= (u64)k;  // iterator.go:619
+        const u32 nk = ok ? (u32)(L - k + 1) : 0u;
+        const u32 nk_max = wave_max_u32(nk);
+        const u64 incl = wave_incl_scan_u64((u64)nk, lane);
+        const u64 T = wave_bcast_u64(incl, 63);
+        const u64 base = a.uniform_len ? (u64)unit * 64 * nk_max : lookback_exclusive(a.lookback, unit, T, lane);
+        const bool ovf = base + T > a.cap;
+        if (ovf && lane == 0) atomicOr(&a.ticket[1], 1u);
+        if (r < a.n) {
+            a.refs[r] = ((base + incl - nk) << 24) | nk;
+            u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
+            if (ok && a.rflags) sbyte |= a.rflags[r];
+            a.status[r] = sbyte;
+        }
+        if (unit == a.nunits - 1 && lane == 63) *a.total = base + incl;
+        if (ovf || nk_max == 0) continue;
+        s_off[lane] = base + incl - nk;
+        s_nk[lane] = nk;
+        __syncthreads();
+        // the 8 rows this lane serves during a flush: row = rr*8 + lane/8, two values at column (lane%8)*2
+        u64 roff[8];
+        u32 rnk[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            roff[rr] = s_off[rr * 8 + (lane >> 3)] + (u32)(lane & 7) * 2;
+            rnk[rr] = s_nk[rr * 8 + (lane >> 3)];
+        }
+        const u32 *__restrict__ w = a.words + off;
+        u32 fl = 0, fh_ = 0, rl = 0, rh_ = 0;
+        auto roll = [&](u32x4 x) {
+            const u32 p = __builtin_amdgcn_alignbit(fl, fh_, 31), q = __builtin_amdgcn_alignbit(fh_, fl, 31);
+            const u32 c = __builtin_amdgcn_alignbit(rh_, rl, 1), d = __builtin_amdgcn_alignbit(rl, rh_, 1);
+            fl = p ^ x.x;
+            fh_ = q ^ x.y;
+            rl = c ^ x.z;
+            rh_ = d ^ x.w;
+        };
+        for (int t0 = 0; t0 < k - 1; t0 += 16) {
+            const u32 word = w[t0 >> 4];
+            const int nb = (k - 1 - t0) < 16 ? (k - 1 - t0) : 16;
+            for (int j = 0; j < nb; ++j) roll(*reinterpret_cast<LDSQ const u32x4 *>(lq + 256 + (((word >> (2 * j)) & 3) << 4)));
+        }
+        u32 in_lo = w[(k - 1) >> 4], in_hi = w[((k - 1) >> 4) + 1], out_lo = w[0], out_hi = w[1];
+        LDSQ char *const myrow = lq + 512 + lane * (TL * 8);
+        for (u32 i0 = 0; i0 < nk_max; i0 += 16) {
+            const u32 t0 = i0 + (u32)k - 1;
+            const u32 cinb = __builtin_amdgcn_alignbit(in_hi, in_lo, (t0 & 15) * 2);
+            const u32 coutb = i0 ? __builtin_amdgcn_alignbit(out_hi, out_lo, ((i0 - 1) & 15) * 2) : (out_lo << 2);
+            u32x4 xs[16];
+#pragma unroll
+            for (int o = 0; o < 16; ++o) {
+                const u32 ia = (o >= 2 ? (cinb >> (2 * o - 4)) : (cinb << (4 - 2 * o))) & 0x30u;
+                u32 ib = (o >= 3 ? (coutb >> (2 * o - 6)) : (coutb << (6 - 2 * o))) & 0xC0u;
+                if (o == 0) ib = i0 ? ib : 0x100u;  // very first k-mer: nothing leaves
+                xs[o] = *reinterpret_cast<LDSQ const u32x4 *>(lq + (ia | ib));
+            }
+            {  // next block's words
+                const u32 t1 = t0 + 16, p1 = i0 + 15;
+                in_lo = w[t1 >> 4];
+                in_hi = w[(t1 >> 4) + 1];
+                out_lo = w[p1 >> 4];
+                out_hi = w[(p1 >> 4) + 1];
+            }
+#pragma unroll
+            for (int o = 0; o < 16; ++o) {
+                roll(xs[o]);
+                u32 hl = fl, hh = fh_;
+                if (CANON) {
+                    const lmask rev = lt64(rl, rh_, fl, fh_);
+                    hl = sel(rev, rl, fl);
+                    hh = sel(rev, rh_, fh_);
+                }
+                *reinterpret_cast<LDSQ u64 *>(myrow + o * 8) = ((u64)hh << 32) | hl;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const u32 ia = i0 + (u32)(lane & 7) * 2;
+                const u32x4 v = *reinterpret_cast<LDSQ const u32x4 *>(lq + 512 + (rr * 8 + (lane >> 3)) * (TL * 8) + (lane & 7) * 16);
+                u64 *dst = a.hash + roff[rr] + i0;
+                if (ia + 1 < rnk[rr]) {
+                    u64x2_a8 vv;
+                    vv.a = ((u64)v.y << 32) | v.x;
+                    vv.b = ((u64)v.w << 32) | v.z;
+                    *reinterpret_cast<u64x2_a8 *>(dst) = vv;
+                } else if (ia < rnk[rr]) {
+                    dst[0] = ((u64)v.y << 32) | v.x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ---- dispatch table --------------------------------------------------------------------
 #define BSK_FAST_CAP 32
 #define BSK_FAST_WS(X) X(4) X(5) X(8) X(10) X(11) X(12) X(15) X(16)

@@ -40,6 +40,7 @@ struct KArgs {
     u64 *ring_h;    // runtime-w ring: per workgroup ring_w*64 entries
     u32 *ring_p;
     u32 ring_w;
+    u32 uniform_len;  // != 0: every read has exactly this many bases (synthetic / fixed-length batches)
     u64 ovf_base;   // slab kernels: first tuple index of the overflow region, and its size
     u64 ovf_cap;
 };
@@ -400,7 +401,8 @@ __global__ __launch_bounds__(64) void k_nthash_stream(KArgs a) {
         const u32 nk_max = wave_max_u32(nk);
         const u64 incl = wave_incl_scan_u64((u64)nk, lane);
         const u64 T = wave_bcast_u64(incl, 63);
-        const u64 base = lookback_exclusive(a.lookback, unit, T, lane);
+        // fixed-length batch: every earlier unit holds exactly 64*nk values, no prefix chain needed
+        const u64 base = a.uniform_len ? (u64)unit * 64 * nk_max : lookback_exclusive(a.lookback, unit, T, lane);
         const bool ovf = base + T > a.cap;
         if (ovf && lane == 0) atomicOr(&a.ticket[1], 1u);
         if (r < a.n) a.refs[r] = ((base + incl - nk) << 24) | nk;
