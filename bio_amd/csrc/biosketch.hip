@@ -15,6 +15,7 @@
 #include "biosketch.h"
 #include "kernels_generic.hpp"
 #include "kernels_fast.hpp"
+#include "kernels_more.hpp"
 
 using namespace bsk;
 
@@ -706,6 +707,7 @@ static int validate(const bsk_params *p, int alphabet) {
             if (p->k >= 65535) return BSK_ERR_K_TOO_LARGE;
             if (p->m < 4 || p->m > p->k) return BSK_ERR_INVALID_M;
             if (p->scale < 1 || p->scale > p->k - p->m + 1) return BSK_ERR_INVALID_SCALE;
+            if (p->k - p->m + 1 > 32767) return BSK_ERR_UNSUPPORTED;  // the reference's int16 counters would wrap
             break;
         case BSK_MINIMIZER:  // NewMinimizerSketch sketch.go:86-91
             if (p->k < 1) return BSK_ERR_INVALID_K;
@@ -761,7 +763,8 @@ static int blocks_per_cu(K kernel) {
 }
 
 // Which kernel runs a (batch, params) pair, on how many workgroups, and how the tuple arrays are organised.
-enum Which { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST, K_NT_FAST };
+enum Which { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST, K_NT_FAST, K_SYN_P, K_SYN_A, K_KMER_P, K_KMER_A, K_SIM_P, K_SIM_A,
+             K_PROT_HASH, K_PROT_MIN };
 struct Plan {
     Which which = K_MIN_GEN_P;
     int grid = 1;
@@ -802,9 +805,27 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
             pl.which = use_ascii ? K_NT_A : K_NT_P;
             per_cu = use_ascii ? blocks_per_cu(k_nthash_stream<1>) : blocks_per_cu(k_nthash_stream<0>);
         }
+    } else if (p->kind == BSK_SYNCMER) {
+        pl.which = use_ascii ? K_SYN_A : K_SYN_P;
+        per_cu = use_ascii ? blocks_per_cu(k_syncmer<1>) : blocks_per_cu(k_syncmer<0>);
+        pl.ring_w = (u32)std::max(1, 2 * (p->k - p->s));
+    } else if (p->kind == BSK_KMER) {
+        pl.which = use_ascii ? K_KMER_A : K_KMER_P;
+        per_cu = use_ascii ? blocks_per_cu(k_kmer<1>) : blocks_per_cu(k_kmer<0>);
+    } else if (p->kind == BSK_SIMHASH) {
+        pl.which = use_ascii ? K_SIM_A : K_SIM_P;
+        per_cu = use_ascii ? blocks_per_cu(k_simhash<1>) : blocks_per_cu(k_simhash<0>);
+        pl.ring_w = (u32)(p->k - p->m + 1);
+    } else if (p->kind == BSK_PROT_HASH) {
+        pl.which = K_PROT_HASH;
+        per_cu = blocks_per_cu(k_prot_hash);
+    } else if (p->kind == BSK_PROT_MINIMIZER) {
+        pl.which = K_PROT_MIN;
+        per_cu = blocks_per_cu(k_prot_minimizer);
+        pl.ring_w = (u32)p->w;
     } else {
-        ctx->err = "kind not implemented yet";
-        return BSK_ERR_UNSUPPORTED;
+        ctx->err = "unknown kind";
+        return BSK_ERR_ARG;
     }
     if (getenv("BSK_WAVES_PER_CU")) per_cu = std::max(1, atoi(getenv("BSK_WAVES_PER_CU")));  // dev: occupancy experiments
     pl.grid = (int)std::max<u64>(1, std::min<u64>((u64)ctx->cus * per_cu, pl.nunits));
@@ -859,6 +880,14 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_NT_P: hipLaunchKernelGGL(k_nthash_stream<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_NT_A: hipLaunchKernelGGL(k_nthash_stream<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_MIN_FAST: fast_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
+        case K_SYN_P: hipLaunchKernelGGL(k_syncmer<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
+        case K_SYN_A: hipLaunchKernelGGL(k_syncmer<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
+        case K_KMER_P: hipLaunchKernelGGL(k_kmer<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
+        case K_KMER_A: hipLaunchKernelGGL(k_kmer<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
+        case K_SIM_P: hipLaunchKernelGGL(k_simhash<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
+        case K_SIM_A: hipLaunchKernelGGL(k_simhash<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
+        case K_PROT_HASH: hipLaunchKernelGGL(k_prot_hash, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
+        case K_PROT_MIN: hipLaunchKernelGGL(k_prot_minimizer, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_NT_FAST:
             if (a.canonical) hipLaunchKernelGGL(k_nthash_fast<true>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             else hipLaunchKernelGGL(k_nthash_fast<false>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
