@@ -1,0 +1,190 @@
+//go:build biosketch
+
+package sketches
+
+/*
+#cgo LDFLAGS: -lbiosketch
+#include <stdlib.h>
+#include "biosketch.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"fmt"
+	"runtime"
+	"unsafe"
+
+	"github.com/shenwei356/bio/seq"
+	"github.com/shenwei356/bio/seqio/fastx"
+)
+
+// sentinel errors: the SAME variables as the reference (iterator.go:34-53, sketch.go:32-42),
+// so callers that compare by identity keep working.
+var errByCode = map[C.int]error{
+	C.BSK_ERR_INVALID_K:     ErrInvalidK,
+	C.BSK_ERR_EMPTY_SEQ:     ErrEmptySeq,
+	C.BSK_ERR_SHORT_SEQ:     ErrShortSeq,
+	C.BSK_ERR_ILLEGAL_BASE:  ErrIllegalBase,
+	C.BSK_ERR_K_TOO_LARGE:   ErrKTooLarge,
+	C.BSK_ERR_INVALID_M:     ErrInvalidM,
+	C.BSK_ERR_INVALID_SCALE: ErrInvalidScale,
+	C.BSK_ERR_INVALID_S:     ErrInvalidS,
+	C.BSK_ERR_INVALID_W:     ErrInvalidW,
+	C.BSK_ERR_BUF_NIL:       ErrBufNil,
+	C.BSK_ERR_BUF_NOT_EMPTY: ErrBufNotEmpty,
+}
+
+// Engine is one GPU context (bsk_ctx).  Use one per goroutine that drives a GPU.
+type Engine struct{ ctx *C.bsk_ctx }
+
+func NewEngine(device int) (*Engine, error) {
+	e := &Engine{}
+	if rc := C.bsk_ctx_create(C.int(device), &e.ctx); rc != C.BSK_OK {
+		return nil, fmt.Errorf("biosketch: %s", C.GoString(C.bsk_err_name(rc)))
+	}
+	runtime.SetFinalizer(e, func(e *Engine) { C.bsk_ctx_destroy(e.ctx) })
+	return e, nil
+}
+
+func (e *Engine) err(rc C.int) error {
+	if rc == C.BSK_OK {
+		return nil
+	}
+	if s, ok := errByCode[rc]; ok {
+		return s
+	}
+	return errors.New("biosketch: " + C.GoString(C.bsk_err_name(rc)) + ": " + C.GoString(C.bsk_last_error(e.ctx)))
+}
+
+// Batch is a device-resident set of sequences (2-bit packed for DNA).
+type Batch struct {
+	eng     *Engine
+	h       *C.bsk_batch
+	n       int
+	protein bool
+}
+
+// NewBatch copies the sequence bytes of the records into one C buffer (the fastx reader
+// reuses its record buffer, seqio/fastx/reader.go:229-232) and hands it to the device.
+// No Go pointer is retained by C after the call returns.
+func (e *Engine) NewBatch(records []*fastx.Record) (*Batch, error) {
+	seqs := make([]*seq.Seq, len(records))
+	for i, r := range records {
+		seqs[i] = r.Seq
+	}
+	return e.NewBatchFromSeqs(seqs)
+}
+
+func (e *Engine) NewBatchFromSeqs(seqs []*seq.Seq) (*Batch, error) {
+	n := len(seqs)
+	total := 0
+	protein := n > 0 && seqs[0].Alphabet == seq.Protein // same pointer test as iterator-protein.go:62
+	for _, s := range seqs {
+		total += len(s.Seq)
+	}
+	bytes := (*[1 << 40]byte)(C.malloc(C.size_t(total + 1)))[: total+1 : total+1]
+	offs := (*[1 << 37]C.uint64_t)(C.malloc(C.size_t(8 * (n + 1))))[: n+1 : n+1]
+	defer C.free(unsafe.Pointer(&bytes[0]))
+	defer C.free(unsafe.Pointer(&offs[0]))
+	o := 0
+	for i, s := range seqs {
+		offs[i] = C.uint64_t(o)
+		o += copy(bytes[o:], s.Seq)
+	}
+	offs[n] = C.uint64_t(o)
+	alpha := C.int(C.BSK_ALPHA_DNA)
+	if protein {
+		alpha = C.BSK_ALPHA_PROTEIN
+	}
+	b := &Batch{eng: e, n: n, protein: protein}
+	rc := C.bsk_batch_from_ascii(e.ctx, (*C.uint8_t)(unsafe.Pointer(&bytes[0])), &offs[0], C.uint64_t(n), alpha, &b.h)
+	if err := e.err(rc); err != nil {
+		return nil, err
+	}
+	runtime.SetFinalizer(b, func(b *Batch) { C.bsk_batch_destroy(b.h) })
+	return b, nil
+}
+
+// Result holds the tuples of one launch on the host (CSR by record).
+type Result struct {
+	kind    C.int
+	offsets []uint64
+	status  []uint8
+	hash    []uint64
+	pos     []uint32 // nil for the "every position" kinds
+	seqLen  []int
+	k       int
+}
+
+func (b *Batch) run(p C.bsk_params) (*Result, error) {
+	var r *C.bsk_result
+	if err := b.eng.err(C.bsk_sketch(b.eng.ctx, b.h, &p, &r)); err != nil {
+		return nil, err
+	}
+	defer C.bsk_result_release(r)
+	var nReads, nTuples C.uint64_t
+	var hasPos C.int
+	C.bsk_result_info(r, &nReads, &nTuples, &hasPos)
+	res := &Result{kind: C.int(p.kind), k: int(p.k)}
+	res.offsets = make([]uint64, int(nReads)+1)
+	res.status = make([]uint8, int(nReads)+1)
+	res.hash = make([]uint64, int(nTuples)+1)
+	var posPtr *C.uint32_t
+	if hasPos != 0 {
+		res.pos = make([]uint32, int(nTuples)+1)
+		posPtr = (*C.uint32_t)(unsafe.Pointer(&res.pos[0]))
+	}
+	// Go memory is only written during this call (cgo pointer rules)
+	rc := C.bsk_result_fetch(b.eng.ctx, r, 0, nReads, (*C.uint64_t)(unsafe.Pointer(&res.offsets[0])),
+		(*C.uint8_t)(unsafe.Pointer(&res.status[0])), (*C.uint64_t)(unsafe.Pointer(&res.hash[0])), posPtr, nTuples+1)
+	if err := b.eng.err(rc); err != nil {
+		return nil, err
+	}
+	return res, nil
+}
+
+func b2i(b bool) C.int32_t {
+	if b {
+		return 1
+	}
+	return 0
+}
+
+// one launch per constructor of the reference
+func (b *Batch) HashIterators(k int, canonical, circular bool) (*Result, error) {
+	return b.run(C.bsk_params{kind: C.BSK_NTHASH, k: C.int32_t(k), canonical: b2i(canonical), circular: b2i(circular)})
+}
+func (b *Batch) KmerIterators(k int, canonical, circular bool) (*Result, error) {
+	return b.run(C.bsk_params{kind: C.BSK_KMER, k: C.int32_t(k), canonical: b2i(canonical), circular: b2i(circular)})
+}
+func (b *Batch) SimHashIterators(k, m, scale int, canonical, circular bool) (*Result, error) {
+	return b.run(C.bsk_params{kind: C.BSK_SIMHASH, k: C.int32_t(k), m: C.int32_t(m), scale: C.int32_t(scale),
+		canonical: b2i(canonical), circular: b2i(circular)})
+}
+func (b *Batch) MinimizerSketches(k, w int, circular bool) (*Result, error) {
+	return b.run(C.bsk_params{kind: C.BSK_MINIMIZER, k: C.int32_t(k), w: C.int32_t(w), canonical: 1, circular: b2i(circular)})
+}
+func (b *Batch) SyncmerSketches(k, s int, circular bool) (*Result, error) {
+	return b.run(C.bsk_params{kind: C.BSK_SYNCMER, k: C.int32_t(k), s: C.int32_t(s), canonical: 1, circular: b2i(circular)})
+}
+func (b *Batch) ProteinIterators(k, codonTable, frame int) (*Result, error) {
+	return b.run(C.bsk_params{kind: C.BSK_PROT_HASH, k: C.int32_t(k), codon_table: C.int32_t(codonTable), frame: C.int32_t(frame)})
+}
+func (b *Batch) ProteinMinimizerSketches(k, codonTable, frame, w int) (*Result, error) {
+	return b.run(C.bsk_params{kind: C.BSK_PROT_MINIMIZER, k: C.int32_t(k), w: C.int32_t(w), codon_table: C.int32_t(codonTable),
+		frame: C.int32_t(frame)})
+}
+
+func (r *Result) slice(i int) (codes []uint64, pos []uint32, status uint8, err error) {
+	a, e := r.offsets[i], r.offsets[i+1]
+	status = r.status[i]
+	if status&C.BSK_ST_CODE_MASK == C.BSK_ST_SHORT {
+		return nil, nil, status, ErrShortSeq // what the reference constructor returns for this record
+	}
+	codes = r.hash[a:e]
+	if r.pos != nil {
+		pos = r.pos[a:e]
+	}
+	return
+}

@@ -1,0 +1,92 @@
+// C++ mirror of the reference's sketches/sketch_test.go + iterator_test.go, driven through
+// bio_amd/csrc/sketches.hpp -> C ABI -> GPU.  Built by __graft_entry__.build(), run by tests/test_gpu_cpp_mirror.py.
+#include <cstdio>
+#include <vector>
+
+#include "sketches.hpp"
+using namespace sketches;
+
+static int fails = 0;
+#define CHECK(c)                                                    \
+    do {                                                            \
+        if (!(c)) {                                                 \
+            std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); \
+            ++fails;                                                \
+        }                                                           \
+    } while (0)
+
+int main() {
+    int err = 0;
+    {  // TestMinimizer sketch_test.go:33-76
+        Seq s{false, "GGCAAGTTCGTCA"};
+        auto sk = NewMinimizerSketch(s, 5, 3, false, &err);
+        CHECK(sk && err == 0);
+        std::vector<uint64_t> codes;
+        std::vector<long> idx;
+        uint64_t c;
+        while (sk && sk->NextMinimizer(c)) {
+            codes.push_back(c);
+            idx.push_back(sk->Index());
+        }
+        const std::vector<uint64_t> want = {973456138564179607ULL, 2645801399420473919ULL, 1099502864234245338ULL,
+                                            6763474888237448943ULL, 2737971715116251183ULL};
+        CHECK(codes == want);
+        CHECK((idx == std::vector<long>{0, 1, 4, 7, 8}));
+    }
+    {  // TestSyncmer sketch_test.go:78-117 (the reference asserts nothing; the commented-out expectation is 5 codes)
+        Seq s{false, "GGCAAGTTCGTCATCGATC"};
+        auto sk = NewSyncmerSketch(s, 5, 2, false, &err);
+        CHECK(sk && err == 0);
+        int n = 0;
+        uint64_t c;
+        while (sk && sk->NextSyncmer(c)) ++n;
+        CHECK(n == 5);
+    }
+    const std::string s100 =
+        "AAGTTTGAATCATTCAACTATCTAGTTTTCAGAGAACAATGTTCTCTAAAGAATAGAAAAGAGTCATTGTGCGGTGATGATGGCGGGAAGGATCCACCTG";
+    {  // TestKmerIterator / TestHashIterator iterator_test.go:31-103
+        Seq s{false, s100};
+        auto it = NewKmerIterator(s, 10, true, false, &err);
+        CHECK(it && err == 0);
+        size_t n = 0;
+        uint64_t c;
+        int e2 = 0;
+        while (it && it->NextKmer(c, &e2)) ++n;
+        CHECK(e2 == 0 && n == s100.size() - 10 + 1);
+        auto ih = NewHashIterator(s, 10, true, false, &err);
+        CHECK(ih && err == 0);
+        n = 0;
+        while (ih && ih->NextHash(c)) ++n;
+        CHECK(n == s100.size() - 10 + 1);
+    }
+    for (const char *q : {"GAACAATGTTCTCTAAAATTG", "GcACAATGTTCTCTAAAATTG"}) {  // TestSimHashIterator iterator_test.go:105-145
+        Seq s{false, q};
+        auto it = NewSimHashIterator(s, 21, 5, 5, true, false, &err);
+        CHECK(it && err == 0);
+        size_t n = 0;
+        uint64_t c;
+        while (it && it->NextSimHash(c)) ++n;
+        CHECK(n == 1);
+    }
+    {  // error surface: constructors return the reference's sentinels
+        Seq s{false, "ACGTACG"};
+        CHECK(!NewMinimizerSketch(s, 5, 4, false, &err) && err == ErrShortSeq);
+        CHECK(!NewMinimizerSketch(s, 0, 4, false, &err) && err == ErrInvalidK);
+        CHECK(!NewMinimizerSketch(s, 5, 0, false, &err) && err == ErrInvalidW);
+        CHECK(!NewSyncmerSketch(s, 5, 6, false, &err) && err == ErrInvalidS);
+        CHECK(!NewKmerIterator(s, 33, true, false, &err) && err == ErrKTooLarge);
+    }
+    {  // protein (amino-acid input)
+        Seq s{true, "ACDEFGHIKLMNPQRSTVWYACDEFGHIKLMNPQRSTVWY"};
+        auto it = NewProteinIterator(s, 9, 1, 1, &err);
+        CHECK(it && err == 0);
+        size_t n = 0;
+        uint64_t c;
+        while (it && it->Next(c)) ++n;
+        CHECK(n == 40 - 9 + 1);
+        auto sk = NewProteinMinimizerSketch(s, 9, 1, 1, 5, &err);
+        CHECK(sk && err == 0);
+    }
+    std::printf(fails ? "FAILED %d checks\n" : "all C++ mirror checks passed\n", fails);
+    return fails ? 1 : 0;
+}
