@@ -147,10 +147,12 @@ void bsk_batch_destroy(bsk_batch *b);
 /* ---- compute -------------------------------------------------------------------
  * Runs the iterator/sketch named by p->kind over every read of the batch.
  * *result == NULL: a result is allocated; otherwise it is reused (bench loops).
- * Output layout (device, SoA, CSR by read, deterministic):
- *   offsets[n+1] u64 ; status[n] u8 ; hash[T] u64 ; pos[T] u32 (bit 31 strand)
- * read r owns tuples [offsets[r], offsets[r+1]) in position order -- exactly the
- * sequence of (Next*() value, Index()) pairs the reference iterator yields.
+ * Output layout (device, SoA, deterministic):
+ *   refs[n] u64 = (first_tuple << 24) | n_tuples ; status[n] u8 ; hash[] u64 ; pos[] u32 (bit 31 strand)
+ * read r owns tuples [first_tuple, first_tuple + n_tuples) in position order -- exactly
+ * the sequence of (Next*() value, Index()) pairs the reference iterator yields.
+ * (The tuple arrays may contain gaps between reads of different 64-read units; use
+ * bsk_result_fetch for a dense, rebased CSR copy on the host.)
  * KMER / NTHASH / SIMHASH / PROT_HASH emit every position, so pos[] is implicit
  * (NULL): tuple j of read r is position j. */
 int bsk_sketch(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, bsk_result **result);
@@ -158,7 +160,9 @@ int bsk_sketch(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, bsk_re
 /* Same, repeated: `warmup` untimed runs then `iters` runs, each bracketed by HIP
  * events on the context's stream.  kernel_ms[iters] (may be NULL) receives the
  * per-run duration of the sketch kernel; the call returns after the last run
- * completed.  Used by bench.py (roofline leg). */
+ * completed.  With *result == NULL one untimed sizing run is done first; with an
+ * existing result (from bsk_sketch on the same batch and params) only the
+ * warmup + iters launches run.  Used by bench.py (roofline leg). */
 int bsk_sketch_timed(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, bsk_result **result,
                      int warmup, int iters, float *kernel_ms);
 
@@ -168,8 +172,8 @@ int bsk_result_info(const bsk_result *r, uint64_t *n_reads, uint64_t *n_tuples, 
 int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t first, uint64_t count,
                      uint64_t *offsets, uint8_t *status, uint64_t *hash, uint32_t *pos,
                      uint64_t tuple_cap);
-/* Device pointers (valid until release / next bsk_sketch on this result). */
-int bsk_result_device(const bsk_result *r, const uint64_t **offsets, const uint8_t **status,
+/* Device pointers (valid until release / next bsk_sketch on this result); refs[] as described above. */
+int bsk_result_device(const bsk_result *r, const uint64_t **refs, const uint8_t **status,
                       const uint64_t **hash, const uint32_t **pos);
 /* Order-independent digest computed on device over the whole result:
  *   checksum = sum over tuples of hash * (2*position + 1)   (mod 2^64)
