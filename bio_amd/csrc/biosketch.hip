@@ -16,6 +16,7 @@
 #include "kernels_generic.hpp"
 #include "kernels_fast.hpp"
 #include "kernels_more.hpp"
+#include "kernels_syncmer.hpp"
 
 using namespace bsk;
 
@@ -764,7 +765,7 @@ static int blocks_per_cu(K kernel) {
 
 // Which kernel runs a (batch, params) pair, on how many workgroups, and how the tuple arrays are organised.
 enum Which { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST, K_NT_FAST, K_SYN_P, K_SYN_A, K_KMER_P, K_KMER_A, K_SIM_P, K_SIM_A,
-             K_PROT_HASH, K_PROT_MIN };
+             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST };
 struct Plan {
     Which which = K_MIN_GEN_P;
     int grid = 1;
@@ -806,9 +807,18 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
             per_cu = use_ascii ? blocks_per_cu(k_nthash_stream<1>) : blocks_per_cu(k_nthash_stream<0>);
         }
     } else if (p->kind == BSK_SYNCMER) {
-        pl.which = use_ascii ? K_SYN_A : K_SYN_P;
-        per_cu = use_ascii ? blocks_per_cu(k_syncmer<1>) : blocks_per_cu(k_syncmer<0>);
-        pl.ring_w = (u32)std::max(1, 2 * (p->k - p->s));
+        if (!use_ascii && fast_syncmer_supported(p->k, p->s) && b->maxlen < 32768u && !getenv("BSK_FORCE_GENERIC")) {
+            pl.which = K_SYN_FAST;
+            pl.fast_w = p->k - p->s;
+            pl.slab = true;
+            pl.slab_unit = (u64)64 * BSK_SYN_CAP;
+            pl.slab_total = (u64)pl.nunits * pl.slab_unit;
+            per_cu = fast_syncmer_blocks_per_cu(pl.fast_w);
+        } else {
+            pl.which = use_ascii ? K_SYN_A : K_SYN_P;
+            per_cu = use_ascii ? blocks_per_cu(k_syncmer<1>) : blocks_per_cu(k_syncmer<0>);
+            pl.ring_w = (u32)std::max(1, 2 * (p->k - p->s));
+        }
     } else if (p->kind == BSK_KMER) {
         pl.which = use_ascii ? K_KMER_A : K_KMER_P;
         per_cu = use_ascii ? blocks_per_cu(k_kmer<1>) : blocks_per_cu(k_kmer<0>);
@@ -888,6 +898,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_SIM_A: hipLaunchKernelGGL(k_simhash<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_PROT_HASH: hipLaunchKernelGGL(k_prot_hash, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_PROT_MIN: hipLaunchKernelGGL(k_prot_minimizer, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
+        case K_SYN_FAST: fast_syncmer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_NT_FAST:
             if (a.canonical) hipLaunchKernelGGL(k_nthash_fast<true>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             else hipLaunchKernelGGL(k_nthash_fast<false>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);

@@ -212,6 +212,48 @@ struct FastMin {
     }
 };
 
+// LDS -> HBM copy-out of one unit's staged tuples in read order (shared by the fast kernels).
+// owner of output t = lane whose run [excl, excl+cnt) holds t: one head bit per non-empty lane,
+// popcount below the bit -> rank among non-empty lanes -> lane (no per-output map in LDS).
+template <class LY, bool POS16, int CAP>
+__device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 excl, u32 T, u64 base, const KArgs &a) {
+    u32 *s_excl = reinterpret_cast<u32 *>(lds + LY::EXCL);
+    u64 *s_heads = reinterpret_cast<u64 *>(lds + LY::HEADS);
+    u8 *s_nz = reinterpret_cast<u8 *>(lds + LY::NZ);
+    const u64 nzmask = __builtin_amdgcn_ballot_w64(cnt > 0);
+    s_excl[lane] = excl;
+    if (lane <= CAP) s_heads[lane] = 0;
+    __syncthreads();
+    if (cnt > 0) {
+        s_nz[__builtin_amdgcn_mbcnt_hi((u32)(nzmask >> 32), __builtin_amdgcn_mbcnt_lo((u32)nzmask, 0))] = (u8)lane;
+        atomicOr(&s_heads[excl >> 6], 1ULL << (excl & 63));
+    }
+    __syncthreads();
+    u32 heads_before = 0;
+    const u64 *sh = reinterpret_cast<const u64 *>(lds + LY::SH);
+    for (u32 t0 = 0; t0 < T; t0 += 64) {
+        const u64 M = s_heads[t0 >> 6];
+        const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(M >> 32), __builtin_amdgcn_mbcnt_lo((u32)M, 0));
+        const u32 upto = below + (u32)((M >> lane) & 1);
+        const u32 t = t0 + lane;
+        if (t < T) {
+            const u32 owner = s_nz[heads_before + upto - 1];
+            const u32 sl = (t - s_excl[owner]) * LY::ROW + owner;
+            a.hash[base + t] = sh[sl];
+            u32 p;
+            if (POS16) {
+                p = *reinterpret_cast<const u16 *>(lds + LY::SP + sl * 2);
+                p = (p & 0x7fffu) | ((p & 0x8000u) << 16);
+            } else {
+                p = *reinterpret_cast<const u32 *>(lds + LY::SP + sl * 4);
+            }
+            a.pos[base + t] = p;
+        }
+        heads_before += (u32)__builtin_popcountll(M);
+    }
+    __syncthreads();
+}
+
 template <int W, int CAP, bool POS16>
 __global__ __launch_bounds__(64) void k_minimizer_fast(KArgs a) {
     typedef FLds<CAP, POS16> LY;
@@ -259,43 +301,7 @@ __global__ __launch_bounds__(64) void k_minimizer_fast(KArgs a) {
         const bool any_over = __builtin_amdgcn_ballot_w64(cnt > (u32)CAP) != 0;
         u64 base = (u64)unit * slab;
         if (!any_over) {
-            // owner of output t = lane whose run [excl, excl+cnt) holds t.  One head bit per non-empty lane,
-            // popcount below the bit -> rank among non-empty lanes -> lane (no per-output map in LDS).
-            u32 *s_excl = reinterpret_cast<u32 *>(lds + LY::EXCL);
-            u64 *s_heads = reinterpret_cast<u64 *>(lds + LY::HEADS);
-            u8 *s_nz = reinterpret_cast<u8 *>(lds + LY::NZ);
-            const u64 nzmask = __builtin_amdgcn_ballot_w64(cnt > 0);
-            s_excl[lane] = excl;
-            if (lane <= CAP) s_heads[lane] = 0;
-            __syncthreads();
-            if (cnt > 0) {
-                s_nz[__builtin_amdgcn_mbcnt_hi((u32)(nzmask >> 32), __builtin_amdgcn_mbcnt_lo((u32)nzmask, 0))] = (u8)lane;
-                atomicOr(&s_heads[excl >> 6], 1ULL << (excl & 63));
-            }
-            __syncthreads();
-            u32 heads_before = 0;
-            const u64 *sh = reinterpret_cast<const u64 *>(lds + LY::SH);
-            for (u32 t0 = 0; t0 < T; t0 += 64) {
-                const u64 M = s_heads[t0 >> 6];
-                const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(M >> 32), __builtin_amdgcn_mbcnt_lo((u32)M, 0));
-                const u32 upto = below + (u32)((M >> lane) & 1);
-                const u32 t = t0 + lane;
-                if (t < T) {
-                    const u32 owner = s_nz[heads_before + upto - 1];
-                    const u32 sl = (t - s_excl[owner]) * LY::ROW + owner;
-                    a.hash[base + t] = sh[sl];
-                    u32 p;
-                    if (POS16) {
-                        p = *reinterpret_cast<const u16 *>(lds + LY::SP + sl * 2);
-                        p = (p & 0x7fffu) | ((p & 0x8000u) << 16);
-                    } else {
-                        p = *reinterpret_cast<const u32 *>(lds + LY::SP + sl * 4);
-                    }
-                    a.pos[base + t] = p;
-                }
-                heads_before += (u32)__builtin_popcountll(M);
-            }
-            __syncthreads();
+            fast_copyout<LY, POS16, CAP>(lds, lane, cnt, excl, T, base, a);
         } else {
             // rare (0.6 % of units at k=21 w=11 CAP=32): a lane selected more than CAP tuples.  The unit may not
             // fit its slab: take T tuples from the overflow region and recompute, storing straight to HBM.

@@ -1,0 +1,350 @@
+// kernels_syncmer.hpp -- the reference's window-bounded closed syncmer (sketch.go:312-477),
+// specialised on W = k - s (compile time), 2-bit input, one read per lane.
+//
+// Closed form: for idx in [0, end], end = L-2k+s+1, let mI be the leftmost
+// argmin of the canonical s-mer hashes at s-mer positions [idx, idx+2W-1];
+// b = mI if mI-idx < W else mI-W; every distinct b <= end is emitted once, in increasing
+// order, as the canonical k-mer hash at b.
+//
+// ONE fused pass per read:
+//   * the s-mer stream runs 2W-1 positions ahead of idx; its sliding minimum over W s-mers
+//     (block decomposition in VGPRs, exactly as in kernels_fast.hpp) gives M[j] = leftmost
+//     min of s-mers [j, j+W-1]; the 2W window of idx is min(M[idx], M[idx+W]) with the left
+//     half winning ties, and "left half" / "right half" is exactly the prefix / suffix rule;
+//     M[idx] was produced W steps earlier at the same block offset, so it sits in D[o];
+//   * the selected position b lies in [idx, idx+W-1]: bit (b-idx) of a per-lane pending
+//     mask is set; the mask shifts right once per step, so bit 0 says "position idx is
+//     selected" exactly when the k-mer stream (which runs AT idx) has that k-mer's hash --
+//     this is the reference's "emit when idx reaches it" queue (sketch.go:424-475) without a
+//     queue, de-duplication is the OR, and selections beyond `end` never reach bit 0;
+//   * the (hash, idx|strand) of every step is stored to the lane's next LDS staging slot and
+//     the slot advances only on a selection (branch-free); copy-out as in kernels_fast.hpp.
+#pragma once
+#include "kernels_fast.hpp"
+
+namespace bsk {
+
+template <int W, int CAP>
+struct SynLds {
+    static constexpr int ROW = 65;
+    static constexpr int TABK = 0;    // k-mer update table (20 x 16 B)
+    static constexpr int TABS = 512;  // s-mer update table
+    static constexpr int SH = 1024;   // u64 [(CAP+1)*65]
+    static constexpr int SP = SH + (CAP + 1) * ROW * 8;  // u16 [(CAP+1)*65]
+    static constexpr int EXCL = SP + (((CAP + 1) * ROW * 2 + 15) & ~15);
+    static constexpr int HEADS = EXCL + 256;
+    static constexpr int NZ = HEADS + (CAP + 1) * 8;
+    static constexpr int TOTAL = NZ + 64;
+};
+
+// 32 consecutive 2-bit codes starting at base position p0 (p0 >= 0): lo = codes 0..15, hi = codes 16..31
+struct Codes32 {
+    u32 lo, hi;
+    __device__ __forceinline__ void load(const u32 *__restrict__ w, u32 p0) {
+        const u32 wi = p0 >> 4, sh = (p0 & 15) * 2;
+        const u32 w0 = w[wi], w1 = w[wi + 1], w2 = w[wi + 2];
+        lo = __builtin_amdgcn_alignbit(w1, w0, sh);
+        hi = __builtin_amdgcn_alignbit(w2, w1, sh);
+    }
+    template <int O>
+    __device__ __forceinline__ u32 in_off() const {  // code O as table byte offset (<< 4)
+        constexpr int o = O & 15;
+        const u32 v = O < 16 ? lo : hi;
+        return (o >= 2 ? (v >> (2 * o - 4)) : (v << (4 - 2 * o))) & 0x30u;
+    }
+    template <int O>
+    __device__ __forceinline__ u32 out_off() const {  // code O as table byte offset (<< 6)
+        constexpr int o = O & 15;
+        const u32 v = O < 16 ? lo : hi;
+        return (o >= 3 ? (v >> (2 * o - 6)) : (v << (6 - 2 * o))) & 0xC0u;
+    }
+};
+
+template <int W, int CAP, bool DIRECT>
+struct FastSyn {
+    typedef SynLds<W, CAP> LY;
+    const u32 *__restrict__ w;
+    LDSQ char *lds;
+    int k, s, lane;
+    u32 end_plus1;  // number of windows of this lane (end + 1), 0 if the read is short
+    u64 *__restrict__ ghash;
+    u32 *__restrict__ gpos;
+    u64 gbase;
+    // state
+    u32 kfl, kfh, krl, krh, sfl, sfh, srl, srh;
+    HV S[W], D[W], P;
+    u32 R0l[W], R0h[W];  // raw s-mer hashes of block 0 (first-window tie flag)
+    u32 pend, slot, tie, cnt;
+    lmask tm;
+
+    __device__ __forceinline__ void rollk(u32x4 x) {
+        const u32 a = __builtin_amdgcn_alignbit(kfl, kfh, 31), b = __builtin_amdgcn_alignbit(kfh, kfl, 31);
+        const u32 c = __builtin_amdgcn_alignbit(krh, krl, 1), d = __builtin_amdgcn_alignbit(krl, krh, 1);
+        kfl = a ^ x.x;
+        kfh = b ^ x.y;
+        krl = c ^ x.z;
+        krh = d ^ x.w;
+    }
+    __device__ __forceinline__ void rolls(u32x4 x) {
+        const u32 a = __builtin_amdgcn_alignbit(sfl, sfh, 31), b = __builtin_amdgcn_alignbit(sfh, sfl, 31);
+        const u32 c = __builtin_amdgcn_alignbit(srh, srl, 1), d = __builtin_amdgcn_alignbit(srl, srh, 1);
+        sfl = a ^ x.x;
+        sfh = b ^ x.y;
+        srl = c ^ x.z;
+        srh = d ^ x.w;
+    }
+    __device__ __forceinline__ u32x4 tabk(u32 off) const { return *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TABK + off); }
+    __device__ __forceinline__ u32x4 tabs(u32 off) const { return *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TABS + off); }
+
+    // MODE 0: s-mer block 0 (priming). MODE 1: block 1 (first 2W window completes at its last offset).
+    // MODE 2: steady state (every offset is a fused step).
+    template <int MODE, int O>
+    __device__ __forceinline__ void step(u32 i0, const Codes32 &sin, const Codes32 &sout, const Codes32 &kin, const Codes32 &kout) {
+        // ---- s-mer i_s = i0 + O ----
+        const u32 so = (MODE == 0 && O == 0) ? 0x100u : sout.template out_off<O>();
+        rolls(tabs(sin.template in_off<O>() | so));
+        const lmask srev = lt64(srl, srh, sfl, sfh);
+        HV v;
+        v.lo = sel(srev, srl, sfl);
+        v.hi = sel(srev, srh, sfh);
+        v.p = i0 + O;  // s-mer position (wave-uniform value in a VGPR)
+        if (O == 0) P = v;
+        else P = selv(lt64(v.lo, v.hi, P.lo, P.hi), v, P);
+        if (MODE >= 1 || O == W - 1) {
+            HV M = P;  // leftmost min of s-mers [i_s-W+1, i_s]
+            if (MODE >= 1 && O != W - 1) M = selv(lt64(P.lo, P.hi, S[O + 1].lo, S[O + 1].hi), P, S[O + 1]);
+            if (MODE == 2 || (MODE == 1 && O == W - 1)) {
+                // ---- fused step: idx = i_s - 2W + 1 ----
+                const u32 idx = i0 + O - (2 * W - 1);
+                const lmask right = lt64(M.lo, M.hi, D[O].lo, D[O].hi);  // strict: the left half wins ties
+                const u32 b = sel(right, M.p - (u32)W, D[O].p);          // sketch.go:413-420
+                pend |= 1u << (b - idx);
+                // k-mer at idx
+                const u32 ko = (MODE == 1) ? 0x100u : kout.template out_off<O>();
+                rollk(tabk(kin.template in_off<O>() | ko));
+                const lmask krev = lt64(krl, krh, kfl, kfh);
+                const u32 hl = sel(krev, krl, kfl), hh = sel(krev, krh, kfh);
+                const u32 ps = sel(krev, idx | 0x8000u, idx);
+                lmask e = __builtin_amdgcn_ballot_w64((pend & 1u) != 0) & __builtin_amdgcn_ballot_w64(idx < end_plus1);
+                pend >>= 1;
+                if (!DIRECT) {
+                    const u32 spare = (u32)(CAP * LY::ROW + lane) * 8u;
+                    const u32 addr = slot < spare ? slot : spare;  // a full lane scribbles on the spare row
+                    *reinterpret_cast<LDSQ u64 *>(lds + LY::SH + addr) = ((u64)hh << 32) | hl;
+                    *reinterpret_cast<LDSQ u16 *>(lds + LY::SP + (addr >> 2)) = (u16)ps;
+                    slot = sel(e, slot + (u32)(LY::ROW * 8), slot);
+                } else if ((e >> lane) & 1) {
+                    const u32 c = (slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);
+                    ghash[gbase + c] = ((u64)hh << 32) | hl;
+                    gpos[gbase + c] = (ps & 0x7fffu) | ((ps & 0x8000u) << 16);
+                    slot += (u32)(LY::ROW * 8);
+                }
+            }
+            D[O] = M;
+        }
+        if (!DIRECT && MODE == 1) {  // first-window tie flag: compare with every earlier s-mer of blocks 0 and 1
+#pragma unroll
+            for (int j = 0; j < W; ++j)
+                tm |= __builtin_amdgcn_ballot_w64((((u64)R0h[j] << 32) | R0l[j]) == (((u64)v.hi << 32) | v.lo));
+#pragma unroll
+            for (int j = 0; j < O; ++j)
+                tm |= __builtin_amdgcn_ballot_w64((((u64)S[j].hi << 32) | S[j].lo) == (((u64)v.hi << 32) | v.lo));
+        }
+        S[O] = v;
+    }
+
+    template <int MODE, int O>
+    __device__ __forceinline__ void steps(u32 i0, const Codes32 &sin, const Codes32 &sout, const Codes32 &kin, const Codes32 &kout) {
+        if constexpr (O < W) {
+            step<MODE, O>(i0, sin, sout, kin, kout);
+            steps<MODE, O + 1>(i0, sin, sout, kin, kout);
+        }
+    }
+
+    template <int MODE>
+    __device__ __forceinline__ void block(u32 i0) {
+        Codes32 sin, sout, kin, kout;
+        sin.load(w, i0 + (u32)s - 1);
+        sout.load(w, i0 ? i0 - 1 : 0);
+        if (MODE == 0) {  // block 0: offset o >= 1 sees base o-1 (offset 0 takes the "nothing leaves" row)
+            const u64 v = (((u64)sout.hi << 32) | sout.lo) << 2;
+            sout.lo = (u32)v;
+            sout.hi = (u32)(v >> 32);
+        }
+        const u32 idx0 = i0 - (2 * W - 1);  // idx of offset 0 (meaningful for MODE 2; MODE 1 only uses offset W-1)
+        if (MODE == 2) {
+            kin.load(w, idx0 + (u32)k - 1);
+            kout.load(w, idx0 - 1);
+        } else if (MODE == 1) {
+            // only offset W-1 is a fused step: idx = 0, incoming base k-1; place it at code index W-1
+            kin.load(w, (u32)k - 1);
+            // shift so that code 0 of the load appears at index W-1
+            const u64 v = (((u64)kin.hi << 32) | kin.lo) << (2 * (W - 1));
+            kin.lo = (u32)v;
+            kin.hi = (u32)(v >> 32);
+            kout.lo = kout.hi = 0;
+        } else {
+            kin.lo = kin.hi = kout.lo = kout.hi = 0;
+        }
+        steps<MODE, 0>(i0, sin, sout, kin, kout);
+        if (MODE == 0 && !DIRECT) {
+#pragma unroll
+            for (int a = 0; a < W; ++a) {
+                R0l[a] = S[a].lo;
+                R0h[a] = S[a].hi;
+            }
+#pragma unroll
+            for (int a = 0; a + 1 < W; ++a)
+#pragma unroll
+                for (int b = a + 1; b < W; ++b)
+                    tm |= __builtin_amdgcn_ballot_w64((((u64)S[a].hi << 32) | S[a].lo) == (((u64)S[b].hi << 32) | S[b].lo));
+        }
+#pragma unroll
+        for (int q = W - 2; q >= 0; --q) S[q] = selv(lt64(S[q + 1].lo, S[q + 1].hi, S[q].lo, S[q].hi), S[q + 1], S[q]);
+    }
+
+    // ns_max: wave maximum of the number of s-mers (L - s + 1)
+    __device__ __forceinline__ void run(u32 ns_max) {
+        kfl = kfh = krl = krh = sfl = sfh = srl = srh = 0;
+        pend = 0;
+        tie = 0;
+        tm = 0;
+        slot = (u32)lane * 8u;
+        for (int t0 = 0; t0 < s - 1; t0 += 16) {  // s-mer warm-up
+            const u32 word = w[t0 >> 4];
+            const int nb = (s - 1 - t0) < 16 ? (s - 1 - t0) : 16;
+            for (int j = 0; j < nb; ++j) rolls(tabs(256 + (((word >> (2 * j)) & 3) << 4)));
+        }
+        for (int t0 = 0; t0 < k - 1; t0 += 16) {  // k-mer warm-up
+            const u32 word = w[t0 >> 4];
+            const int nb = (k - 1 - t0) < 16 ? (k - 1 - t0) : 16;
+            for (int j = 0; j < nb; ++j) rollk(tabk(256 + (((word >> (2 * j)) & 3) << 4)));
+        }
+        block<0>(0);
+        if (ns_max > (u32)W) block<1>(W);
+        for (u32 i0 = 2 * W; i0 < ns_max; i0 += W) block<2>(i0);
+        tie = (u32)((tm >> lane) & 1);
+        cnt = (slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);
+    }
+};
+
+#define BSK_SYN_CAP 16
+
+template <int W>
+__global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves per SIMD: at most 256 VGPRs
+    constexpr int CAP = BSK_SYN_CAP;
+    typedef SynLds<W, CAP> LY;
+    __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
+    LDSQ char *const ldsq = (LDSQ char *)lds;
+    const int lane = lane_id();
+    build_xtab(reinterpret_cast<uint4 *>(lds + LY::TABK), a.k, lane);
+    build_xtab(reinterpret_cast<uint4 *>(lds + LY::TABS), a.s, lane);
+    __syncthreads();
+    const u64 slab = (u64)64 * CAP;
+    for (u32 unit = next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; unit < a.nunits; ++unit, ({
+             if (unit == uend) {
+                 unit = next_ticket(a.ticket, lane) * 8u;
+                 uend = unit + 8u;
+             }
+         })) {
+        const u64 r = (u64)unit * 64 + lane;
+        u64 off = 0, L = 0;
+        if (r < a.n) {
+            const u64 d = a.desc[r];
+            off = d >> 24;
+            L = d & 0xffffffULL;
+        }
+        const long long Lorig = (long long)L - a.circ_ext;
+        const bool ok = r < a.n && Lorig >= 0 && Lorig >= 2LL * a.k - a.s - 1 && L >= (u64)a.k;  // sketch.go:149
+        const u32 nwin = ok ? (u32)(L - 2 * (u64)a.k + a.s + 2) : 0u;                             // end + 1
+        const u32 ns = ok ? (u32)(L - a.s + 1) : 0u;
+        const u32 ns_max = wave_max_u32(ns);
+        u32 cnt = 0, tie = 0;
+        if (ns_max) {
+            FastSyn<W, CAP, false> fs;
+            fs.w = a.words + off;
+            fs.lds = ldsq;
+            fs.k = a.k;
+            fs.s = a.s;
+            fs.lane = lane;
+            fs.end_plus1 = nwin;
+            fs.run(ns_max);
+            cnt = fs.cnt;
+            tie = ok ? fs.tie : 0;
+        }
+        const u32 incl = wave_incl_scan_u32(cnt, lane);
+        const u32 excl = incl - cnt;
+        const u32 T = wave_bcast_u32(incl, 63);
+        const bool any_over = __builtin_amdgcn_ballot_w64(cnt > (u32)CAP) != 0;
+        u64 base = (u64)unit * slab;
+        if (!any_over) {
+            fast_copyout<LY, true, CAP>(lds, lane, cnt, excl, T, base, a);
+        } else {
+            u64 ob = 0;
+            if (lane == 0) ob = atomicAdd(a.total + 1, (u64)T);
+            ob = wave_bcast_u64(ob, 0);
+            if (ob + T <= a.ovf_cap) {
+                base = a.ovf_base + ob;
+                FastSyn<W, CAP, true> fs;
+                fs.w = a.words + off;
+                fs.lds = ldsq;
+                fs.k = a.k;
+                fs.s = a.s;
+                fs.lane = lane;
+                fs.end_plus1 = nwin;
+                fs.ghash = a.hash;
+                fs.gpos = a.pos;
+                fs.gbase = base + excl;
+                fs.run(ns_max);
+            } else {
+                cnt = 0;
+                if (lane == 0) atomicOr(&a.ticket[1], 1u);
+            }
+        }
+        if (r < a.n) {
+            a.refs[r] = ((base + excl) << 24) | cnt;
+            u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
+            if (tie) sbyte |= BSK_ST_FIRST_WINDOW_TIE;
+            if (ok && a.rflags) sbyte |= a.rflags[r];
+            a.status[r] = sbyte;
+        }
+    }
+}
+
+#define BSK_SYN_WS(X) X(5) X(10) X(15) X(16) X(20)
+static inline bool fast_syncmer_supported(int k, int s) {
+    switch (k - s) {
+#define X(WW) case WW:
+        BSK_SYN_WS(X)
+#undef X
+        return true;
+        default: return false;
+    }
+}
+static inline int fast_syncmer_blocks_per_cu(int w) {
+    int nb = 0;
+    hipError_t e = hipErrorInvalidValue;
+    switch (w) {
+#define X(WW) \
+    case WW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_syncmer_fast<WW>, 64, 0); break;
+        BSK_SYN_WS(X)
+#undef X
+        default: break;
+    }
+    if (e != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        nb = 1;
+    }
+    return nb;
+}
+static inline void fast_syncmer_launch(int w, int grid, hipStream_t stream, const KArgs &a) {
+    switch (w) {
+#define X(WW) \
+    case WW: hipLaunchKernelGGL((k_syncmer_fast<WW>), dim3(grid), dim3(64), 0, stream, a); break;
+        BSK_SYN_WS(X)
+#undef X
+        default: break;
+    }
+}
+
+}  // namespace bsk

@@ -10,9 +10,11 @@ x = int(sys.argv[4]) if len(sys.argv) > 4 else 11
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 5
 eng = S.Engine(0)
 t = time.time()
-b = eng.synth(L.ALPHA_DNA, n, 150, 0x5EED0003)
+prot = kind.startswith("p")
+b = eng.synth(L.ALPHA_PROTEIN, n, 300, 0x5EED0005) if prot else eng.synth(L.ALPHA_DNA, n, 150, 0x5EED0003)
 print("synth", time.time() - t, b.info())
-p = {"min": eng.params(L.MINIMIZER, k, w=x), "nt": eng.params(L.NTHASH, k), "syn": eng.params(L.SYNCMER, k, s=x)}[kind]
+p = {"min": eng.params(L.MINIMIZER, k, w=x), "nt": eng.params(L.NTHASH, k), "syn": eng.params(L.SYNCMER, k, s=x), "pmin": eng.params(L.PROT_MINIMIZER, k, w=x), "phash": eng.params(L.PROT_HASH, k),
+     "kmer": eng.params(L.KMER, k), "sim": eng.params(L.SIMHASH, k, m=5, scale=5)}[kind]
 t = time.time()
 res, ms = eng.run_timed(b, p, 1, iters)
 wall = time.time() - t
@@ -20,5 +22,6 @@ inf = res.info()
 best = min(ms)
 print(f"kind={kind} k={k} x={x} n={n} tuples={inf['n_tuples']} per_read={inf['n_tuples']/n:.2f}")
 print("kernel ms:", [round(m, 3) for m in ms], "wall", round(wall, 3))
-print(f"Gbases/s best={n*150/best/1e6:.1f} avg={n*150/(sum(ms)/len(ms))/1e6:.1f}")
+LL = 300 if prot else 150
+print(f"Gbases/s best={n*LL/best/1e6:.1f} avg={n*LL/(sum(ms)/len(ms))/1e6:.1f}")
 print(res.digest())
