@@ -17,6 +17,7 @@
 #include "kernels_fast.hpp"
 #include "kernels_more.hpp"
 #include "kernels_syncmer.hpp"
+#include "kernels_protein.hpp"
 
 using namespace bsk;
 
@@ -35,6 +36,7 @@ struct bsk_ctx {
     u32 *d_ring_p = nullptr;
     size_t ring_cap = 0;  // entries
     u64 *h_pinned = nullptr;  // [8] pinned host words for small read-backs
+    bool no_prot_fast = false;  // set while a call falls back from the per-sequence-slab protein kernel
 };
 
 struct bsk_batch {
@@ -765,7 +767,7 @@ static int blocks_per_cu(K kernel) {
 
 // Which kernel runs a (batch, params) pair, on how many workgroups, and how the tuple arrays are organised.
 enum Which { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST, K_NT_FAST, K_SYN_P, K_SYN_A, K_KMER_P, K_KMER_A, K_SIM_P, K_SIM_A,
-             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST };
+             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST };
 struct Plan {
     Which which = K_MIN_GEN_P;
     int grid = 1;
@@ -776,6 +778,8 @@ struct Plan {
     u32 nunits = 0;
     u32 ring_w = 0;
     size_t ring_entries = 0;
+    u64 slab_read = 0;     // per-sequence slabs (protein fast path)
+    int fast_k = 0;
 };
 
 static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan &pl) {
@@ -830,9 +834,23 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
         pl.which = K_PROT_HASH;
         per_cu = blocks_per_cu(k_prot_hash);
     } else if (p->kind == BSK_PROT_MINIMIZER) {
-        pl.which = K_PROT_MIN;
-        per_cu = blocks_per_cu(k_prot_minimizer);
-        pl.ring_w = (u32)p->w;
+        if (fast_prot_supported(p->w, p->k) && b->maxlen < 65536u && b->maxlen >= (u32)(p->k + p->w) && !getenv("BSK_FORCE_GENERIC") &&
+            !ctx->no_prot_fast) {
+            pl.which = K_PROT_MIN_FAST;
+            pl.fast_w = p->w;
+            pl.fast_k = p->k;
+            pl.slab = true;
+            const u64 nwin = (u64)b->maxlen - p->k - p->w + 2;
+            pl.slab_read = std::min<u64>(nwin, (u64)(nwin * 2.6 / (p->w + 1.0)) + 8);  // mean 2/(w+1) of the windows, +30 %
+            pl.slab_read = (pl.slab_read + 15) & ~(u64)15;  // whole 128-byte lines of hashes per sequence
+            pl.slab_unit = 64 * pl.slab_read;
+            pl.slab_total = (u64)pl.nunits * pl.slab_unit;
+            per_cu = fast_prot_blocks_per_cu(p->w, p->k);
+        } else {
+            pl.which = K_PROT_MIN;
+            per_cu = blocks_per_cu(k_prot_minimizer);
+            pl.ring_w = (u32)p->w;
+        }
     } else {
         ctx->err = "unknown kind";
         return BSK_ERR_ARG;
@@ -871,6 +889,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     a.pos = res->pos;
     a.cap = res->cap;
     a.ovf_base = pl.slab_total;
+    a.slab_read = pl.slab_read;
     a.ovf_cap = res->ovf_cap;
     a.ticket = ctx->d_ticket;
     a.total = ctx->d_total;
@@ -899,6 +918,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_PROT_HASH: hipLaunchKernelGGL(k_prot_hash, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_PROT_MIN: hipLaunchKernelGGL(k_prot_minimizer, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_SYN_FAST: fast_syncmer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
+        case K_PROT_MIN_FAST: fast_prot_launch(pl.fast_w, pl.fast_k, pl.grid, ctx->stream, a); break;
         case K_NT_FAST:
             if (a.canonical) hipLaunchKernelGGL(k_nthash_fast<true>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             else hipLaunchKernelGGL(k_nthash_fast<false>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
@@ -969,7 +989,7 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
     if (*result && (*result)->cap > cap) cap = (*result)->cap;
     // bsk_sketch always runs (and sizes) once; bsk_sketch_timed on an existing result only repeats the launch
     const bool sizing = *result == nullptr || warmup + iters == 0;
-    for (int attempt = 0; sizing && attempt < 2; ++attempt) {
+    for (int attempt = 0; sizing && attempt < 3; ++attempt) {
         rc = result_prepare(ctx, result, b->n, p->kind, cap);
         if (rc != BSK_OK) return cleanup(rc);
         bsk_result *res = *result;
@@ -984,9 +1004,17 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
         const u32 ovf = ((u32 *)(ctx->h_pinned + 2))[1];
         res->n_tuples = total;
         if (!ovf) break;
-        if (attempt == 1) {
+        if (attempt == 2) {
             ctx->err = "result capacity overflow after exact re-size";
             return cleanup(BSK_ERR_DEVICE);
+        }
+        if (pl.which == K_PROT_MIN_FAST) {  // a sequence outgrew its slab (unusual density): use the dense general kernel
+            ctx->no_prot_fast = true;
+            rc = make_plan(ctx, b, p, pl);
+            ctx->no_prot_fast = false;
+            if (rc != BSK_OK) return cleanup(rc);
+            cap = estimate_cap(b, p, circ_ext);
+            continue;
         }
         cap = pl.slab ? pl.slab_total + ovf_used + ovf_used / 4 + 65536 : total + 64;  // size known now: re-run once
     }

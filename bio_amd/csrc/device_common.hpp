@@ -68,6 +68,17 @@ __host__ __device__ __forceinline__ unsigned acgt_code(unsigned b) {  // 0..3, o
 }
 
 // ---- wave primitives ---------------------------------------------------------
+// LDS hand-off between lanes of ONE wavefront (every kernel here runs one wavefront per workgroup).
+// The LDS unit performs a wave's DS instructions in issue order, so a ds_read issued after another lane's
+// ds_write sees it; what is needed is only that the COMPILER keeps the order.  __syncthreads() would also
+// emit s_waitcnt vmcnt(0): every hand-off would wait for all outstanding global stores of the wave
+// (measured: the tuple copy-out and the stream flushes were store-latency bound because of it).
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ u32 wave_incl_scan_u32(u32 v, int lane) {

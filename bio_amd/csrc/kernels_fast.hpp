@@ -223,12 +223,12 @@ __device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 e
     const u64 nzmask = __builtin_amdgcn_ballot_w64(cnt > 0);
     s_excl[lane] = excl;
     if (lane <= CAP) s_heads[lane] = 0;
-    __syncthreads();
+    wave_sync_lds();
     if (cnt > 0) {
         s_nz[__builtin_amdgcn_mbcnt_hi((u32)(nzmask >> 32), __builtin_amdgcn_mbcnt_lo((u32)nzmask, 0))] = (u8)lane;
         atomicOr(&s_heads[excl >> 6], 1ULL << (excl & 63));
     }
-    __syncthreads();
+    wave_sync_lds();
     u32 heads_before = 0;
     const u64 *sh = reinterpret_cast<const u64 *>(lds + LY::SH);
     for (u32 t0 = 0; t0 < T; t0 += 64) {
@@ -251,7 +251,7 @@ __device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 e
         }
         heads_before += (u32)__builtin_popcountll(M);
     }
-    __syncthreads();
+    wave_sync_lds();
 }
 
 template <int W, int CAP, bool POS16>
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
         if (ovf || nk_max == 0) continue;
         s_off[lane] = base + incl - nk;
         s_nk[lane] = nk;
-        __syncthreads();
+        wave_sync_lds();
         // the 8 rows this lane serves during a flush: row = rr*8 + lane/8, two values at column (lane%8)*2
         u64 roff[8];
         u32 rnk[8];
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
                 }
                 *reinterpret_cast<LDSQ u64 *>(myrow + o * 8) = ((u64)hh << 32) | hl;
             }
-            __syncthreads();
+            wave_sync_lds();
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
                 const u32 ia = i0 + (u32)(lane & 7) * 2;
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
                     dst[0] = ((u64)v.y << 32) | v.x;
                 }
             }
-            __syncthreads();
+            wave_sync_lds();
         }
     }
 }

@@ -41,6 +41,7 @@ struct KArgs {
     u32 *ring_p;
     u32 ring_w;
     u32 uniform_len;  // != 0: every read has exactly this many bases (synthetic / fixed-length batches)
+    u64 slab_read;  // per-sequence slab kernels (protein): tuples reserved per sequence
     u64 ovf_base;   // slab kernels: first tuple index of the overflow region, and its size
     u64 ovf_cap;
 };
@@ -267,13 +268,13 @@ __device__ __forceinline__ u64 unit_epilogue(const KArgs &a, u32 unit, int lane,
         const u32 cmax = wave_max_u32(c);
         for (u32 e = 0; e < cmax; ++e)
             if (e < c) st.smap[excl + e] = (u16)Stage<CAP>::slot(e, lane);
-        __syncthreads();
+        wave_sync_lds();
         for (u32 t = lane; t < T; t += 64) {
             const u32 sl = st.smap[t];
             a.hash[base + t] = st.sh[sl];
             if (a.pos) a.pos[base + t] = st.sp[sl];
         }
-        __syncthreads();
+        wave_sync_lds();
     } else if (!ovf) {
         // nothing: DIRECT pass follows
     } else if (lane == 0) {
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(64) void k_nthash_stream(KArgs a) {
         NtAscii sa;
         if (ENC) sa.init(a.ascii, off, L, a.k, a.canonical, s_tab, s_tab + 256);
         else sp.init(a.words, off, a.k, a.canonical, s_tab);
-        __syncthreads();
+        wave_sync_lds();
         for (u32 i = 0; i < nk_max; ++i) {
             u64 h;
             u32 rev;
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(64) void k_nthash_stream(KArgs a) {
             else sp.step(i, h, rev);
             s_tile[lane * TILE_LD + (i & 15)] = h;
             if ((i & 15) == 15 || i == nk_max - 1) {
-                __syncthreads();
+                wave_sync_lds();
                 const u32 c0 = i & ~15u;
 #pragma unroll
                 for (int rr = 0; rr < 8; ++rr) {
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(64) void k_nthash_stream(KArgs a) {
                         dst[0] = v0;
                     }
                 }
-                __syncthreads();
+                wave_sync_lds();
             }
         }
     }

@@ -129,7 +129,7 @@ __device__ __forceinline__ void stream_values(Src &src, const KArgs &a, u32 nk_m
         src.step(i, h, rev);
         s_tile[lane * TILE_LD + (i & 15)] = h;
         if ((i & 15) == 15 || i == nk_max - 1) {
-            __syncthreads();
+            wave_sync_lds();
             const u32 c0 = i & ~15u;
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
@@ -141,7 +141,7 @@ __device__ __forceinline__ void stream_values(Src &src, const KArgs &a, u32 nk_m
                 if (ia < nkr) dst[0] = s_tile[row * TILE_LD + col];
                 if (ia + 1 < nkr) dst[1] = s_tile[row * TILE_LD + col + 1];
             }
-            __syncthreads();
+            wave_sync_lds();
         }
     }
 }
@@ -163,7 +163,7 @@ __device__ __forceinline__ bool stream_prologue(const KArgs &a, u32 unit, int la
     if (ovf || nk_max == 0) return false;
     s_off[lane] = base + incl - nk;
     s_nk[lane] = nk;
-    __syncthreads();
+    wave_sync_lds();
     return true;
 }
 
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(64) void k_kmer(KArgs a) {
             s_tile[lane * TILE_LD + (i & 15)] = h;
             s_tile2[lane * TILE_LD + 15 - (i & 15)] = src.rc2;  // reverse strand is emitted in reverse position order
             if ((i & 15) == 15 || i == nk_max - 1) {
-                __syncthreads();
+                wave_sync_lds();
                 const u32 c0 = i & ~15u;
                 for (int rr = 0; rr < 8; ++rr) {
                     const int row = rr * 8 + (lane >> 3);
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(64) void k_kmer(KArgs a) {
                         }
                     }
                 }
-                __syncthreads();
+                wave_sync_lds();
             }
         }
     }
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(64) void k_simhash(KArgs a) {
             }
             s_tile[lane * TILE_LD + (i & 15)] = code;
             if ((i & 15) == 15 || i == nk_max - 1) {
-                __syncthreads();
+                wave_sync_lds();
                 const u32 c0 = i & ~15u;
                 for (int rr = 0; rr < 8; ++rr) {
                     const int row = rr * 8 + (lane >> 3);
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(64) void k_simhash(KArgs a) {
                     if (ia < nkr) dst[0] = s_tile[row * TILE_LD + col];
                     if (ia + 1 < nkr) dst[1] = s_tile[row * TILE_LD + col + 1];
                 }
-                __syncthreads();
+                wave_sync_lds();
             }
         }
     }

@@ -1,0 +1,305 @@
+// kernels_protein.hpp -- protein minimizer (NewProteinMinimizerSketch / Next,
+// sketch-protein.go:62-210) specialised on the window W and the k-mer size K (9..16).
+//
+// One sequence per lane.  wyhash (seed 1) of every K residues is computed from scratch
+// per position as the reference does (sketch-protein.go:117), but entirely in registers:
+// the lane keeps the next 20 residues in five dwords; at sub-step j the K bytes start at
+// byte j, so r32(p), r32(p+4) and the tail are three v_alignbit with an immediate shift;
+// the two 64x64->128 "mum" products are four v_mad_u64_u32 each.  The leftmost-argmin
+// window machine is the one of kernels_fast.hpp.
+//
+// Output: a 300-residue sequence selects ~97 positions, far more than can be staged per
+// lane for a whole sequence, so every sequence owns a fixed slab of `slab_read` tuples in
+// the tuple arrays and the wavefront flushes its LDS staging every MB = lcm(W,4) steps
+// (each lane appends its new tuples to its own slab; runs leave LDS in lane order).
+#pragma once
+#include "kernels_fast.hpp"
+#include "kernels_more.hpp"
+
+namespace bsk {
+
+constexpr int ilcm4(int w) { return (w % 4 == 0) ? w : (w % 2 == 0 ? 2 * w : 4 * w); }
+
+template <int MB>
+struct ProtLds {
+    static constexpr int ROW = 65;
+    static constexpr int ROWS = MB + 16;                      // up to 15 leftover tuples + MB new ones + 1 spare row
+    static constexpr int SH = 0;                              // u64 [ROWS*65]
+    static constexpr int SP = SH + ROWS * ROW * 8;            // u16 [ROWS*65]
+    static constexpr int EXCL = SP + ((ROWS * ROW * 2 + 15) & ~15);
+    static constexpr int HEADS = EXCL + 256;                  // u64 [ROWS]
+    static constexpr int NZ = HEADS + ROWS * 8;
+    static constexpr int DST = NZ + 64;                       // u32 [64]: lane's next free tuple index inside the unit's region
+    static constexpr int TOTAL = DST + 256;
+};
+
+__device__ __forceinline__ u64 mum64(u32 a0, u32 a1, u32 b0, u32 b1) {  // hi64(a*b) ^ lo64(a*b)
+    const u64 t0 = (u64)a0 * b0;
+    const u64 t1 = (u64)a1 * b0 + (t0 >> 32);
+    const u64 t2 = (u64)a0 * b1 + (u32)t1;
+    const u64 hi = (u64)a1 * b1 + (t1 >> 32) + (t2 >> 32);
+    const u64 lo = (t2 << 32) | (u32)t0;
+    return hi ^ lo;
+}
+
+template <int W, int K>
+struct FastProt {
+    static_assert(K >= 9 && K <= 16, "register wyhash covers 9..16 residues");
+    static constexpr int MB = ilcm4(W);  // steps per macro block: a whole number of windows-blocks and of dwords
+    typedef ProtLds<MB> LY;
+    LDSQ char *lds;
+    int lane;
+    u32 nk;
+    HV S[W], P;
+    u32 prev, slot;
+    u32 R[5 + MB / 4];  // residues: R[0..4] = the 20 bytes at the macro block's first position, R[5..] = the following ones
+    lmask tm;
+
+    // wyhash (published v1) of the K bytes starting at byte j of (A,B,C,D,E)
+    template <int J>
+    __device__ __forceinline__ u64 hashK(u32 A, u32 B, u32 C, u32 D, u32 E) const {
+        const u32 h0 = J ? __builtin_amdgcn_alignbit(B, A, 8 * J) : A;  // r32(p)
+        const u32 h1 = J ? __builtin_amdgcn_alignbit(C, B, 8 * J) : B;  // r32(p+4)
+        const u32 t0 = J ? __builtin_amdgcn_alignbit(D, C, 8 * J) : C;  // bytes 8..11
+        const u32 t1 = (K > 12) ? (J ? __builtin_amdgcn_alignbit(E, D, 8 * J) : D) : 0u;  // bytes 12..15
+        constexpr int r = K - 8;
+        u64 tail;
+        if (r == 1) tail = t0 & 0xffu;
+        else if (r == 2) tail = t0 & 0xffffu;
+        else if (r == 3) tail = ((t0 & 0xffffu) << 8) | ((t0 >> 16) & 0xffu);
+        else if (r == 4) tail = t0;
+        else if (r == 5) tail = ((u64)t0 << 8) | (t1 & 0xffu);
+        else if (r == 6) tail = ((u64)t0 << 16) | (t1 & 0xffffu);
+        else if (r == 7) tail = ((u64)t0 << 24) | ((u64)(t1 & 0xffffu) << 8) | ((t1 >> 16) & 0xffu);
+        else tail = ((u64)t0 << 32) | t1;
+        constexpr u64 seed0 = 1ULL ^ WYP0;                  // seed ^= p0
+        const u64 a = (((u64)h0 << 32) | h1) ^ seed0;       // wyr64s(p) ^ seed
+        const u64 b = tail ^ WYP2;
+        const u64 s1 = mum64((u32)a, (u32)(a >> 32), (u32)b, (u32)(b >> 32));
+        constexpr u64 fin = (u64)K ^ WYP5;
+        return mum64((u32)s1, (u32)(s1 >> 32), (u32)fin, (u32)(fin >> 32));
+    }
+
+    // one macro block of MB steps starting at k-mer position i0 (FIRSTMB: i0 == 0)
+    template <bool FIRSTMB>
+    __device__ __forceinline__ void macro(u32 i0) {
+        u32 vi = i0;
+#pragma unroll
+        for (int t = 0; t < MB; ++t) {
+            const int g = t >> 2;
+            u64 h;
+            switch (t & 3) {
+                case 0: h = hashK<0>(R[g], R[g + 1], R[g + 2], R[g + 3], R[g + 4]); break;
+                case 1: h = hashK<1>(R[g], R[g + 1], R[g + 2], R[g + 3], R[g + 4]); break;
+                case 2: h = hashK<2>(R[g], R[g + 1], R[g + 2], R[g + 3], R[g + 4]); break;
+                default: h = hashK<3>(R[g], R[g + 1], R[g + 2], R[g + 3], R[g + 4]); break;
+            }
+            const int o = t % W;
+            const bool first = FIRSTMB && t < W;  // the very first window block of the sequence
+            HV v;
+            v.lo = (u32)h;
+            v.hi = (u32)(h >> 32);
+            v.p = vi;
+            if (o == 0) P = v;
+            else P = selv(lt64(v.lo, v.hi, P.lo, P.hi), v, P);
+            if (!first || o == W - 1) {
+                HV m = P;
+                if (o != W - 1) m = selv(lt64(P.lo, P.hi, S[o + 1].lo, S[o + 1].hi), P, S[o + 1]);
+                const lmask e = __builtin_amdgcn_ballot_w64(m.p != prev) & __builtin_amdgcn_ballot_w64(vi < nk);
+                prev = m.p;
+                *reinterpret_cast<LDSQ u64 *>(lds + LY::SH + slot) = ((u64)m.hi << 32) | m.lo;
+                *reinterpret_cast<LDSQ u16 *>(lds + LY::SP + (slot >> 2)) = (u16)m.p;
+                slot = sel(e, slot + (u32)(LY::ROW * 8), slot);
+            }
+            S[o] = v;
+            vi += 1;
+            if (o == W - 1) {
+                if (first) {  // BSK_ST_FIRST_WINDOW_TIE
+#pragma unroll
+                    for (int x = 0; x + 1 < W; ++x)
+#pragma unroll
+                        for (int y = x + 1; y < W; ++y)
+                            tm |= __builtin_amdgcn_ballot_w64((((u64)S[x].hi << 32) | S[x].lo) == (((u64)S[y].hi << 32) | S[y].lo));
+                }
+#pragma unroll
+                for (int q = W - 2; q >= 0; --q) S[q] = selv(lt64(S[q + 1].lo, S[q + 1].hi, S[q].lo, S[q].hi), S[q + 1], S[q]);
+            }
+        }
+    }
+};
+
+// Flush staged tuples to the per-sequence slabs.  Regular rounds move only whole groups of 16 tuples per lane
+// (a full, aligned 128-byte line of hashes and 64 bytes of positions: no partial-line writes; measured 2.2x
+// faster than flushing every tuple of every round); the final round moves what is left.
+template <class LY>
+__device__ __forceinline__ void flush_rows(char *lds, int lane, u32 cnt, bool last, u32 done, u64 slab_read, u64 ubase,
+                                           const KArgs &a) {
+    u32 *s_excl = reinterpret_cast<u32 *>(lds + LY::EXCL);
+    u64 *s_heads = reinterpret_cast<u64 *>(lds + LY::HEADS);
+    u8 *s_nz = reinterpret_cast<u8 *>(lds + LY::NZ);
+    u32 *s_dst = reinterpret_cast<u32 *>(lds + LY::DST);
+    // unit of work: a group of 16 tuples (regular round) or a single tuple (final round)
+    const u32 units = last ? cnt : (cnt >> 4);
+    const u32 ushift = last ? 0u : 4u;
+    const u32 incl = wave_incl_scan_u32(units, lane);
+    const u32 excl = incl - units;
+    const u32 U = wave_bcast_u32(incl, 63);
+    if (U == 0) return;
+    const u64 nzmask = __builtin_amdgcn_ballot_w64(units > 0);
+    const bool fits = (u64)done + ((u64)units << ushift) <= slab_read;
+    if (__builtin_amdgcn_ballot_w64(!fits) && lane == 0) atomicOr(&a.ticket[1], 1u);  // slab too small: host falls back
+    s_excl[lane] = excl;
+    s_dst[lane] = fits ? (u32)(lane * slab_read + done) : 0xffffffffu;
+    if (lane < LY::ROWS) s_heads[lane] = 0;
+    wave_sync_lds();
+    if (units > 0) {
+        s_nz[__builtin_amdgcn_mbcnt_hi((u32)(nzmask >> 32), __builtin_amdgcn_mbcnt_lo((u32)nzmask, 0))] = (u8)lane;
+        atomicOr(&s_heads[excl >> 6], 1ULL << (excl & 63));
+    }
+    wave_sync_lds();
+    const u32 T = U << ushift;  // tuples to move
+    u32 heads_before = 0, word = 0xffffffffu;
+    u64 M = 0;
+    for (u32 t0 = 0; t0 < T; t0 += 64) {
+        const u32 t = t0 + lane;
+        const u32 ui = t >> ushift;  // work-unit index of this lane's tuple
+        if ((t0 >> ushift >> 6) != word) {  // next 64 work units: next head word (wave-uniform)
+            heads_before += (u32)__builtin_popcountll(M);
+            word = t0 >> ushift >> 6;
+            M = s_heads[word];
+        }
+        if (t < T) {
+            const u32 bit = ui & 63;
+            const u32 upto = (u32)__builtin_popcountll(M & (bit == 63 ? ~0ULL : ((2ULL << bit) - 1)));
+            const u32 owner = s_nz[heads_before + upto - 1];
+            const u32 e = ((ui - s_excl[owner]) << ushift) | (t & ((1u << ushift) - 1));
+            const u32 sl = e * LY::ROW + owner;
+            const u32 d = s_dst[owner];
+#ifdef PROT_EXP_NOSTORE  // dev experiment: everything but the global stores
+            if (d == 0xfffffff0u) a.pos[e] = sl;
+#else
+            if (d != 0xffffffffu) {
+                a.hash[ubase + d + e] = *reinterpret_cast<const u64 *>(lds + LY::SH + sl * 8);
+                a.pos[ubase + d + e] = *reinterpret_cast<const u16 *>(lds + LY::SP + sl * 2);
+            }
+#endif
+        }
+    }
+    wave_sync_lds();
+}
+
+template <int W, int K>
+__global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
+    typedef FastProt<W, K> FP;
+    constexpr int MB = FP::MB;
+    typedef ProtLds<MB> LY;
+    __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
+    LDSQ char *const ldsq = (LDSQ char *)lds;
+    const int lane = lane_id();
+    const u64 slab_read = a.slab_read;  // tuples reserved per sequence
+    for (u32 unit = next_ticket(a.ticket, lane) * 4u, uend = unit + 4u; unit < a.nunits; ++unit, ({
+             if (unit == uend) {
+                 unit = next_ticket(a.ticket, lane) * 4u;
+                 uend = unit + 4u;
+             }
+         })) {
+        const u64 r = (u64)unit * 64 + lane;
+        u64 off = 0, L = 0;
+        if (r < a.n) {
+            off = a.aoff[r];
+            L = a.aoff[r + 1] - off;
+        }
+        const bool ok = r < a.n && L >= (u64)K * 3 + (u64)W - 1;  // sketch-protein.go:66,73
+        const u32 nk = ok ? (u32)(L - K + 1) : 0u;
+        const u32 nk_max = wave_max_u32(nk);
+        u32 done = 0;  // tuples of this lane already in HBM
+        u32 tie = 0;
+        const u64 ubase = (u64)unit * 64 * slab_read;
+        if (nk_max) {
+            FP fp;
+            fp.lds = ldsq;
+            fp.lane = lane;
+            fp.nk = nk;
+            fp.prev = 0xffffffffu;
+            fp.tm = 0;
+            // residues are bytes at an arbitrary address: read aligned dwords and realign by (address & 3) bytes
+            const u8 *p0 = a.ascii + off;
+            const u32 bsh = (u32)((size_t)p0 & 3) * 8;
+            const u32 *wp = reinterpret_cast<const u32 *>((size_t)p0 & ~(size_t)3);
+            u32 wprev = wp[0];
+            const u32 jmax = (u32)((L + bsh / 8 + 3) / 4);  // last aligned dword that holds a byte of this sequence
+            auto next_dword = [&](u32 j) {  // dword j of the sequence (bytes 4j..4j+3), realigned
+                const u32 wn = wp[j + 1 < jmax ? j + 1 : jmax];
+                const u32 v = __builtin_amdgcn_alignbit(wn, wprev, bsh);
+                wprev = wn;
+                return v;
+            };
+            u32 dj = 0;
+            fp.slot = (u32)lane * 8u;  // staging persists across macro blocks (leftovers of fewer than 16 tuples stay in LDS)
+#pragma unroll
+            for (int g = 0; g < 5; ++g) fp.R[g] = next_dword(dj++);
+            for (u32 i0 = 0; i0 < nk_max; i0 += MB) {
+#pragma unroll
+                for (int g = 0; g < MB / 4; ++g) fp.R[5 + g] = next_dword(dj++);
+                if (i0 == 0) fp.template macro<true>(i0);
+                else fp.template macro<false>(i0);
+#pragma unroll
+                for (int g = 0; g < 5; ++g) fp.R[g] = fp.R[g + MB / 4];
+                // ---- flush whole 16-tuple groups (= full 128-byte lines of hashes) of every lane to its slab ----
+                const u32 cnt = (fp.slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);  // staged, leftovers included
+                const bool last = i0 + MB >= nk_max;                              // final round: flush everything
+                flush_rows<LY>(lds, lane, cnt, last, done, slab_read, ubase, a);
+                const u32 nfl = last ? cnt : (cnt & ~15u);
+                if (!last) {  // move the leftover (< 16 tuples) down to row 0
+                    const u32 left = cnt - nfl;
+                    if (__builtin_amdgcn_ballot_w64(nfl != 0)) {
+                        for (u32 e = 0; e < 15; ++e) {
+                            if (nfl && e < left) {
+                                const u32 src = (nfl + e) * LY::ROW + lane, dst = e * LY::ROW + lane;
+                                *reinterpret_cast<u64 *>(lds + LY::SH + dst * 8) = *reinterpret_cast<const u64 *>(lds + LY::SH + src * 8);
+                                *reinterpret_cast<u16 *>(lds + LY::SP + dst * 2) = *reinterpret_cast<const u16 *>(lds + LY::SP + src * 2);
+                            }
+                        }
+                    }
+                    fp.slot = (left * LY::ROW + (u32)lane) * 8u;
+                }
+                done += nfl;
+            }
+            tie = (u32)((fp.tm >> lane) & 1);
+        }
+        if (r < a.n) {
+            a.refs[r] = ((ubase + (u64)lane * slab_read) << 24) | done;
+            a.status[r] = (u8)((ok ? BSK_ST_OK : BSK_ST_SHORT) | ((ok && tie) ? BSK_ST_FIRST_WINDOW_TIE : 0));
+        }
+    }
+}
+
+#define BSK_PROT_KW(X) X(5, 9) X(5, 10) X(3, 10) X(4, 12)
+static inline bool fast_prot_supported(int w, int k) {
+#define X(WW, KK) \
+    if (w == WW && k == KK) return true;
+    BSK_PROT_KW(X)
+#undef X
+    return false;
+}
+static inline int fast_prot_blocks_per_cu(int w, int k) {
+    int nb = 0;
+    hipError_t e = hipErrorInvalidValue;
+#define X(WW, KK) \
+    if (w == WW && k == KK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_prot_minimizer_fast<WW, KK>, 64, 0);
+    BSK_PROT_KW(X)
+#undef X
+    if (e != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        nb = 1;
+    }
+    return nb;
+}
+static inline void fast_prot_launch(int w, int k, int grid, hipStream_t stream, const KArgs &a) {
+#define X(WW, KK) \
+    if (w == WW && k == KK) hipLaunchKernelGGL((k_prot_minimizer_fast<WW, KK>), dim3(grid), dim3(64), 0, stream, a);
+    BSK_PROT_KW(X)
+#undef X
+}
+
+}  // namespace bsk
