@@ -801,11 +801,11 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
             pl.ring_w = (u32)p->w;
         }
     } else if (p->kind == BSK_NTHASH) {
-        if (!use_ascii && !getenv("BSK_FORCE_GENERIC")) {
+        if (!use_ascii && b->maxlen + (u32)(p->circular ? p->k : 0) <= 16u * (BSK_NT_FAST_WORDS - 2) && !getenv("BSK_FORCE_GENERIC")) {
             pl.which = K_NT_FAST;
             // write-bound kernel: measured fastest at 4 waves/CU (more concurrent 128-byte write streams per XCD
             // thrash the L2 write-combining: 3.65 ms vs 5.27 ms at 15 waves/CU for 10M reads)
-            per_cu = std::min(4, p->canonical ? blocks_per_cu(k_nthash_fast<true>) : blocks_per_cu(k_nthash_fast<false>));
+            per_cu = p->canonical ? blocks_per_cu(k_nthash_fast<true>) : blocks_per_cu(k_nthash_fast<false>);
         } else {
             pl.which = use_ascii ? K_NT_A : K_NT_P;
             per_cu = use_ascii ? blocks_per_cu(k_nthash_stream<1>) : blocks_per_cu(k_nthash_stream<0>);
@@ -948,6 +948,7 @@ static u64 estimate_cap(const bsk_batch *b, const bsk_params *p, int circ_ext) {
             return (u64)(bases * d) + b->n + 1024;
         }
         case BSK_KMER: return (p->canonical ? 1 : 2) * bases + 64;
+        case BSK_NTHASH: return bases + 16 * b->n + 64;  // runs are padded to whole 128-byte lines
         default: return bases + 64;
     }
 }
@@ -1018,7 +1019,7 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
         }
         cap = pl.slab ? pl.slab_total + ovf_used + ovf_used / 4 + 65536 : total + 64;  // size known now: re-run once
     }
-    if (sizing && pl.slab && b->n) {  // slab kernels keep no running total: sum the per-read counts once
+    if (sizing && (pl.slab || pl.which == K_NT_FAST) && b->n) {  // slab / line-padded kernels: sum the per-read counts once
         HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, sizeof(u64), ctx->stream));
         hipLaunchKernelGGL(k_sum_counts, dim3(grid_for(ctx, b->n, 256)), dim3(256), 0, ctx->stream, (*result)->refs, b->n, ctx->d_total);
         hipError_t e = hipMemcpyAsync(ctx->h_pinned, ctx->d_total, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);

@@ -237,14 +237,18 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
             u32 dj = 0;
             fp.slot = (u32)lane * 8u;  // staging persists across macro blocks (leftovers of fewer than 16 tuples stay in LDS)
 #pragma unroll
-            for (int g = 0; g < 5; ++g) fp.R[g] = next_dword(dj++);
+            for (int g = 0; g < 5 + MB / 4; ++g) fp.R[g] = next_dword(dj++);
             for (u32 i0 = 0; i0 < nk_max; i0 += MB) {
-#pragma unroll
-                for (int g = 0; g < MB / 4; ++g) fp.R[5 + g] = next_dword(dj++);
                 if (i0 == 0) fp.template macro<true>(i0);
                 else fp.template macro<false>(i0);
 #pragma unroll
                 for (int g = 0; g < 5; ++g) fp.R[g] = fp.R[g + MB / 4];
+                // residues of the NEXT macro block: requested and waited for BEFORE this round's flush stores are
+                // issued (vmcnt is in-order: a load issued after the stores could only be waited for together with them)
+#pragma unroll
+                for (int g = 0; g < MB / 4; ++g) fp.R[5 + g] = next_dword(dj++);
+#pragma unroll
+                for (int g = 0; g < MB / 4; ++g) asm volatile("" ::"v"(fp.R[5 + g]));
                 // ---- flush whole 16-tuple groups (= full 128-byte lines of hashes) of every lane to its slab ----
                 const u32 cnt = (fp.slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);  // staged, leftovers included
                 const bool last = i0 + MB >= nk_max;                              // final round: flush everything
