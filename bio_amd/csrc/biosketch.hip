@@ -805,7 +805,7 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
             pl.which = K_NT_FAST;
             // write-bound kernel: measured fastest at 4 waves/CU (more concurrent 128-byte write streams per XCD
             // thrash the L2 write-combining: 3.65 ms vs 5.27 ms at 15 waves/CU for 10M reads)
-            per_cu = p->canonical ? blocks_per_cu(k_nthash_fast<true>) : blocks_per_cu(k_nthash_fast<false>);
+            per_cu = p->canonical ? blocks_per_cu(k_nthash_fast<1>) : blocks_per_cu(k_nthash_fast<0>);
         } else {
             pl.which = use_ascii ? K_NT_A : K_NT_P;
             per_cu = use_ascii ? blocks_per_cu(k_nthash_stream<1>) : blocks_per_cu(k_nthash_stream<0>);
@@ -824,8 +824,14 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
             pl.ring_w = (u32)std::max(1, 2 * (p->k - p->s));
         }
     } else if (p->kind == BSK_KMER) {
-        pl.which = use_ascii ? K_KMER_A : K_KMER_P;
-        per_cu = use_ascii ? blocks_per_cu(k_kmer<1>) : blocks_per_cu(k_kmer<0>);
+        if (!use_ascii && p->canonical && b->maxlen + (u32)(p->circular ? p->k : 0) <= 16u * (BSK_NT_FAST_WORDS - 2) &&
+            !getenv("BSK_FORCE_GENERIC")) {
+            pl.which = K_NT_FAST;  // same streaming kernel, MODE 2
+            per_cu = blocks_per_cu(k_nthash_fast<2>);
+        } else {
+            pl.which = use_ascii ? K_KMER_A : K_KMER_P;
+            per_cu = use_ascii ? blocks_per_cu(k_kmer<1>) : blocks_per_cu(k_kmer<0>);
+        }
     } else if (p->kind == BSK_SIMHASH) {
         pl.which = use_ascii ? K_SIM_A : K_SIM_P;
         per_cu = use_ascii ? blocks_per_cu(k_simhash<1>) : blocks_per_cu(k_simhash<0>);
@@ -920,8 +926,9 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_SYN_FAST: fast_syncmer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_PROT_MIN_FAST: fast_prot_launch(pl.fast_w, pl.fast_k, pl.grid, ctx->stream, a); break;
         case K_NT_FAST:
-            if (a.canonical) hipLaunchKernelGGL(k_nthash_fast<true>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
-            else hipLaunchKernelGGL(k_nthash_fast<false>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
+            if (a.kind == BSK_KMER) hipLaunchKernelGGL(k_nthash_fast<2>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
+            else if (a.canonical) hipLaunchKernelGGL(k_nthash_fast<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
+            else hipLaunchKernelGGL(k_nthash_fast<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             break;
     }
     if (ev1) HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
@@ -947,8 +954,8 @@ static u64 estimate_cap(const bsk_batch *b, const bsk_params *p, int circ_ext) {
             if (d > 1.0) d = 1.0;
             return (u64)(bases * d) + b->n + 1024;
         }
-        case BSK_KMER: return (p->canonical ? 1 : 2) * bases + 64;
         case BSK_NTHASH: return bases + 16 * b->n + 64;  // runs are padded to whole 128-byte lines
+        case BSK_KMER: return (p->canonical ? 1 : 2) * bases + 16 * b->n + 64;
         default: return bases + 64;
     }
 }

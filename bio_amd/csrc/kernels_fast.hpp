@@ -343,7 +343,8 @@ __global__ __launch_bounds__(64) void k_minimizer_fast(KArgs a) {
 // output offset of every read is a closed form, otherwise it comes from the look-back.
 // ---------------------------------------------------------------------------------------
 #define BSK_NT_FAST_WORDS 34  // reads of up to 32*16 = 512 bases (+2 words of look-ahead)
-template <bool CANON>
+// MODE 0: ntHash forward strand, 1: canonical ntHash, 2: canonical 2-bit k-mer code (NextKmer, iterator.go:708-759, k <= 32)
+template <int MODE>
 __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
     constexpr int TL = 18;  // u64 per tile row (16 + 2 pad: 144-byte rows keep 16-byte alignment, 2-way conflicts at most)
     constexpr int NWL = BSK_NT_FAST_WORDS;          // packed words of a read staged in LDS
@@ -416,10 +417,21 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
             rl = c ^ x.z;
             rh_ = d ^ x.w;
         };
+        u64 code = 0, rc = 0;  // MODE 2: forward / reverse-complement code, first base in the most significant pair
+        const u64 cmask = k >= 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
+        const unsigned sh2 = 2u * (unsigned)(k - 1);
         for (int t0 = 0; t0 < k - 1; t0 += 16) {
             const u32 word = sw[(t0 >> 4) * 64 + lane];
             const int nb = (k - 1 - t0) < 16 ? (k - 1 - t0) : 16;
-            for (int j = 0; j < nb; ++j) roll(*reinterpret_cast<LDSQ const u32x4 *>(lq + 256 + (((word >> (2 * j)) & 3) << 4)));
+            for (int j = 0; j < nb; ++j) {
+                const u32 b = (word >> (2 * j)) & 3;
+                if (MODE == 2) {
+                    code = (code << 2) | b;
+                    rc = (rc >> 2) | ((u64)(b ^ 3u) << sh2);
+                } else {
+                    roll(*reinterpret_cast<LDSQ const u32x4 *>(lq + 256 + (b << 4)));
+                }
+            }
         }
         LDSQ char *const myrow = lq + 512 + lane * (TL * 8);
         for (u32 i0 = 0; i0 < nk_max; i0 += 16) {
@@ -428,21 +440,34 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
             const u32 olo = sw[(p0 >> 4) * 64 + lane], ohi = sw[((p0 >> 4) + 1) * 64 + lane];
             const u32 coutb = i0 ? __builtin_amdgcn_alignbit(ohi, olo, (p0 & 15) * 2) : (olo << 2);
             u32x4 xs[16];
+            if (MODE != 2) {
 #pragma unroll
-            for (int o = 0; o < 16; ++o) {
-                const u32 ia = (o >= 2 ? (cinb >> (2 * o - 4)) : (cinb << (4 - 2 * o))) & 0x30u;
-                u32 ib = (o >= 3 ? (coutb >> (2 * o - 6)) : (coutb << (6 - 2 * o))) & 0xC0u;
-                if (o == 0) ib = i0 ? ib : 0x100u;  // very first k-mer: nothing leaves
-                xs[o] = *reinterpret_cast<LDSQ const u32x4 *>(lq + (ia | ib));
+                for (int o = 0; o < 16; ++o) {
+                    const u32 ia = (o >= 2 ? (cinb >> (2 * o - 4)) : (cinb << (4 - 2 * o))) & 0x30u;
+                    u32 ib = (o >= 3 ? (coutb >> (2 * o - 6)) : (coutb << (6 - 2 * o))) & 0xC0u;
+                    if (o == 0) ib = i0 ? ib : 0x100u;  // very first k-mer: nothing leaves
+                    xs[o] = *reinterpret_cast<LDSQ const u32x4 *>(lq + (ia | ib));
+                }
             }
 #pragma unroll
             for (int o = 0; o < 16; ++o) {
-                roll(xs[o]);
-                u32 hl = fl, hh = fh_;
-                if (CANON) {
-                    const lmask rev = lt64(rl, rh_, fl, fh_);
-                    hl = sel(rev, rl, fl);
-                    hh = sel(rev, rh_, fh_);
+                u32 hl, hh;
+                if (MODE == 2) {
+                    const u32 b = (cinb >> (2 * o)) & 3;
+                    code = ((code << 2) | b) & cmask;                   // iterator.go:736
+                    rc = (rc >> 2) | ((u64)(b ^ 3u) << sh2);            // iterator.go:740
+                    const lmask rev = lt64((u32)rc, (u32)(rc >> 32), (u32)code, (u32)(code >> 32));  // iterator.go:754
+                    hl = sel(rev, (u32)rc, (u32)code);
+                    hh = sel(rev, (u32)(rc >> 32), (u32)(code >> 32));
+                } else {
+                    roll(xs[o]);
+                    hl = fl;
+                    hh = fh_;
+                    if (MODE == 1) {
+                        const lmask rev = lt64(rl, rh_, fl, fh_);
+                        hl = sel(rev, rl, fl);
+                        hh = sel(rev, rh_, fh_);
+                    }
                 }
                 *reinterpret_cast<LDSQ u64 *>(myrow + o * 8) = ((u64)hh << 32) | hl;
             }

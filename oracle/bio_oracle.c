@@ -972,6 +972,14 @@ int orc_batch_run(int kind, const uint8_t *seqs, const uint64_t *offsets, uint32
             long long c = orc_protein_minimizer_all(s, len, k, w_or_s, hb, pb, CAP, NULL);
             for (long long i = 0; i < c; i++) sum += hb[i] * (2 * (uint64_t)pb[i] + 1);
             if (c > 0) tot += (uint64_t)c;
+        } else if (kind == 1 || kind == 3 || kind == 6) { /* every-position kinds: k-mer codes, SimHash (m=5, scale=5), protein hash */
+            enum { CAP2 = 8192 };
+            uint64_t hb[CAP2];
+            long long c = kind == 1 ? orc_kmer_all(s, len, k, 1, 0, hb, CAP2)
+                        : kind == 3 ? orc_simhash_all(s, len, k, 5, 5, 1, 0, hb, CAP2)
+                                    : orc_protein_hash_all(s, len, k, hb, CAP2);
+            for (long long i = 0; i < c; i++) sum += hb[i] * (2 * (uint64_t)i + 1);
+            if (c > 0) tot += (uint64_t)c;
         } else {
             err = 1;
         }
