@@ -387,7 +387,7 @@ extern "C" int bsk_batch_from_ascii(bsk_ctx *ctx, const uint8_t *bytes, const ui
         if (e__ != hipSuccess) return bail(fail_hip(ctx, e__, #call)); \
     } while (0)
     // ascii + offsets to the device
-    BCHK(hipMalloc(&b->ascii, nbytes + 64));
+    BCHK(hipMalloc(&b->ascii, nbytes + BSK_ASCII_PAD));
     BCHK(hipMalloc(&b->aoff, (n + 1) * sizeof(u64)));
     if (nbytes) BCHK(hipMemcpyAsync(b->ascii, bytes, nbytes, hipMemcpyHostToDevice, ctx->stream));
     if (n) BCHK(hipMemcpyAsync(b->aoff, offsets, (n + 1) * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
@@ -504,7 +504,7 @@ extern "C" int bsk_batch_synth(bsk_ctx *ctx, int alphabet, uint64_t n, uint32_t 
         }
         b->device_bytes = alloc_words * 4 + n * 9;
     } else if (alphabet == BSK_ALPHA_PROTEIN) {
-        if ((e = hipMalloc(&b->ascii, n * len + 64)) == hipSuccess && (e = hipMalloc(&b->aoff, (n + 1) * 8)) == hipSuccess) {
+        if ((e = hipMalloc(&b->ascii, n * len + BSK_ASCII_PAD)) == hipSuccess && (e = hipMalloc(&b->aoff, (n + 1) * 8)) == hipSuccess) {
             hipLaunchKernelGGL(k_synth_protein, dim3(grid_for(ctx, n * len, 256)), dim3(256), 0, ctx->stream, b->ascii, b->aoff, n,
                                len, seed);
             e = hipGetLastError();
@@ -767,7 +767,7 @@ static int blocks_per_cu(K kernel) {
 
 // Which kernel runs a (batch, params) pair, on how many workgroups, and how the tuple arrays are organised.
 enum Which { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST, K_NT_FAST, K_SYN_P, K_SYN_A, K_KMER_P, K_KMER_A, K_SIM_P, K_SIM_A,
-             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST };
+             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST };
 struct Plan {
     Which which = K_MIN_GEN_P;
     int grid = 1;
@@ -837,8 +837,14 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
         per_cu = use_ascii ? blocks_per_cu(k_simhash<1>) : blocks_per_cu(k_simhash<0>);
         pl.ring_w = (u32)(p->k - p->m + 1);
     } else if (p->kind == BSK_PROT_HASH) {
-        pl.which = K_PROT_HASH;
-        per_cu = blocks_per_cu(k_prot_hash);
+        if (fast_prot_hash_supported(p->k) && !getenv("BSK_FORCE_GENERIC")) {
+            pl.which = K_PROT_HASH_FAST;
+            pl.fast_k = p->k;
+            per_cu = fast_prot_hash_blocks_per_cu(p->k);
+        } else {
+            pl.which = K_PROT_HASH;
+            per_cu = blocks_per_cu(k_prot_hash);
+        }
     } else if (p->kind == BSK_PROT_MINIMIZER) {
         if (fast_prot_supported(p->w, p->k) && b->maxlen < 65536u && b->maxlen >= (u32)(p->k + p->w) && !getenv("BSK_FORCE_GENERIC") &&
             !ctx->no_prot_fast) {
@@ -925,6 +931,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_PROT_MIN: hipLaunchKernelGGL(k_prot_minimizer, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_SYN_FAST: fast_syncmer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_PROT_MIN_FAST: fast_prot_launch(pl.fast_w, pl.fast_k, pl.grid, ctx->stream, a); break;
+        case K_PROT_HASH_FAST: fast_prot_hash_launch(pl.fast_k, pl.grid, ctx->stream, a); break;
         case K_NT_FAST:
             if (a.kind == BSK_KMER) hipLaunchKernelGGL(k_nthash_fast<2>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             else if (a.canonical) hipLaunchKernelGGL(k_nthash_fast<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
@@ -956,6 +963,7 @@ static u64 estimate_cap(const bsk_batch *b, const bsk_params *p, int circ_ext) {
         }
         case BSK_NTHASH: return bases + 16 * b->n + 64;  // runs are padded to whole 128-byte lines
         case BSK_KMER: return (p->canonical ? 1 : 2) * bases + 16 * b->n + 64;
+        case BSK_PROT_HASH: return bases + 16 * b->n + 64;
         default: return bases + 64;
     }
 }
@@ -1026,7 +1034,7 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
         }
         cap = pl.slab ? pl.slab_total + ovf_used + ovf_used / 4 + 65536 : total + 64;  // size known now: re-run once
     }
-    if (sizing && (pl.slab || pl.which == K_NT_FAST) && b->n) {  // slab / line-padded kernels: sum the per-read counts once
+    if (sizing && (pl.slab || pl.which == K_NT_FAST || pl.which == K_PROT_HASH_FAST) && b->n) {  // slab / line-padded kernels: sum the per-read counts once
         HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, sizeof(u64), ctx->stream));
         hipLaunchKernelGGL(k_sum_counts, dim3(grid_for(ctx, b->n, 256)), dim3(256), 0, ctx->stream, (*result)->refs, b->n, ctx->d_total);
         hipError_t e = hipMemcpyAsync(ctx->h_pinned, ctx->d_total, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
@@ -1131,7 +1139,7 @@ static int make_circular(bsk_ctx *ctx, const bsk_batch *b, int k, bsk_batch **ou
         hipLaunchKernelGGL(k_extend_packed, dim3(grid_for(ctx, w, 256)), dim3(256), 0, ctx->stream, b->words, b->desc, t->desc, n, w,
                            t->words);
     if (b->ascii && n) {  // batches with non-ACGT bytes are hashed from ASCII: extend that too
-        if ((e = hipMalloc(&t->ascii, nb + 64)) != hipSuccess || (e = hipMalloc(&t->aoff, (n + 1) * 8)) != hipSuccess ||
+        if ((e = hipMalloc(&t->ascii, nb + BSK_ASCII_PAD)) != hipSuccess || (e = hipMalloc(&t->aoff, (n + 1) * 8)) != hipSuccess ||
             (e = hipMemcpyAsync(t->aoff, nao.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) {
             bsk_batch_destroy(t);
             return fail_hip(ctx, e, "make_circular ascii alloc");

@@ -229,7 +229,11 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
             u32 wprev = wp[0];
             const u32 jmax = (u32)((L + bsh / 8 + 3) / 4);  // last aligned dword that holds a byte of this sequence
             auto next_dword = [&](u32 j) {  // dword j of the sequence (bytes 4j..4j+3), realigned
+#ifdef PROT_EXP_FAKEIN  // dev experiment: no residue loads
+                const u32 wn = (j * 0x9E3779B9u) ^ (u32)lane;
+#else
                 const u32 wn = wp[j + 1 < jmax ? j + 1 : jmax];
+#endif
                 const u32 v = __builtin_amdgcn_alignbit(wn, wprev, bsh);
                 wprev = wn;
                 return v;
@@ -303,6 +307,170 @@ static inline void fast_prot_launch(int w, int k, int grid, hipStream_t stream, 
 #define X(WW, KK) \
     if (w == WW && k == KK) hipLaunchKernelGGL((k_prot_minimizer_fast<WW, KK>), dim3(grid), dim3(64), 0, stream, a);
     BSK_PROT_KW(X)
+#undef X
+}
+
+// ---------------------------------------------------------------------------------------
+// Protein k-mer hashes (kind BSK_PROT_HASH; ProteinIterator.Next, iterator-protein.go:86-117)
+// for K = 9..16: value i of sequence r -> hash[first(r) + i].  One sequence per lane; the
+// residues of a 512-position chunk are realigned and staged in LDS ([dword][lane]) so that
+// the hashing loop has no global loads (see k_nthash_fast: loads and stores in one loop make
+// every block wait for the previous flush); 16 hashes per lane go through the 64x16 tile and
+// leave as one aligned 128-byte line per sequence.  Runs are padded to 16 values.
+// ---------------------------------------------------------------------------------------
+#ifndef BSK_PH_CHUNK
+#define BSK_PH_CHUNK 256
+#endif
+#define BSK_ASCII_PAD 1024  // slack behind the residue buffer: the staging below reads whole 16-byte pieces past a chunk's end
+
+// Cooperative staging of one residue chunk per sequence: for every source lane s in `want`, the wavefront copies
+// np16 16-byte pieces starting at that lane's (byte-aligned) address A into the lane's LDS region (RS dwords apart,
+// RS = 4*odd: regions are 16-byte aligned and ds_read_b128 of 64 different regions is 2-way conflicted at most).
+// One global_load_dwordx4 per source touches ~np16/8 lines (a per-lane walk touches 64 lines per instruction and
+// measured 2x slower end to end: the 64 KB of lines that 8 waves walk do not stay in the 32 KB L1).
+#define GLBQ __attribute__((address_space(1)))
+typedef u32x4 u32x4_u __attribute__((aligned(1)));  // byte-aligned 16-byte global load (unaligned access mode of the HSA ABI)
+#ifndef BSK_PH_UNR
+#define BSK_PH_UNR 16
+#endif
+// Branch-free on purpose: UNR loads are issued back to back and every lane takes part (lanes past the last piece
+// repeat it) -- with a branch around each load the compiler waits for vmcnt(0) between them and the 64 loads of a
+// chunk run one memory latency after the other.
+template <int RS, int NP>
+__device__ __forceinline__ void stage_chunks(LDSQ char *reg0, const u8 *A, u64 want, int lane) {
+    const u32 alo = (u32)(size_t)A, ahi = (u32)((size_t)A >> 32);
+    const u32 lo16 = (u32)(lane < NP ? lane : NP - 1) * 16u;
+#pragma unroll 1
+    for (int s0 = 0; s0 < 64; s0 += BSK_PH_UNR) {
+        if (((want >> s0) & ((1ULL << BSK_PH_UNR) - 1)) == 0) continue;  // wave-uniform
+        u32x4 v[BSK_PH_UNR];
+#pragma unroll
+        for (int q = 0; q < BSK_PH_UNR; ++q) {
+            const u64 as = ((u64)(u32)__builtin_amdgcn_readlane((int)ahi, s0 + q) << 32) | (u32)__builtin_amdgcn_readlane((int)alo, s0 + q);
+            v[q] = *reinterpret_cast<const GLBQ u32x4_u *>(as + lo16);
+        }
+        if (lane < NP) {
+#pragma unroll
+            for (int q = 0; q < BSK_PH_UNR; ++q) *reinterpret_cast<LDSQ u32x4 *>(reg0 + (s0 + q) * (RS * 4) + 16 * lane) = v[q];
+        }
+    }
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void k_prot_hash_fast(KArgs a) {
+    typedef FastProt<1, K> FP;
+    constexpr int TL = 18;
+    constexpr int RS = BSK_PH_CHUNK / 4 + 4;  // dwords per staged region: 16 positions look at 8 dwords
+    static_assert((RS % 4) == 0 && ((RS / 4) & 1), "region stride must be 4*odd dwords");
+    constexpr int SW_OFF = 64 * TL * 8;
+    __shared__ __attribute__((aligned(16))) char lds[SW_OFF + RS * 64 * 4];
+    LDSQ char *const lq = (LDSQ char *)lds;
+    LDSQ char *const reg0 = lq + SW_OFF;
+    u64 *const s_off = reinterpret_cast<u64 *>(lds);        // unit prologue only: aliases the tile
+    u32 *const s_nk = reinterpret_cast<u32 *>(lds + 512);
+    const int lane = lane_id();
+    FP fp;  // only hashK() is used
+    for (u32 unit = next_ticket(a.ticket, lane) * 4u, uend = unit + 4u; unit < a.nunits; ++unit, ({
+             if (unit == uend) {
+                 unit = next_ticket(a.ticket, lane) * 4u;
+                 uend = unit + 4u;
+             }
+         })) {
+        const u64 r = (u64)unit * 64 + lane;
+        u64 off = 0, L = 0;
+        if (r < a.n) {
+            off = a.aoff[r];
+            L = a.aoff[r + 1] - off;
+        }
+        const bool ok = r < a.n && L >= (u64)K * 3;  // iterator-protein.go:50 (checked on the input length)
+        const u32 nk = ok ? (u32)(L - K + 1) : 0u;
+        const u32 nk_max = wave_max_u32(nk);
+        const u32 pk = (nk + 15u) & ~15u;
+        const u64 incl = wave_incl_scan_u64((u64)pk, lane);
+        const u64 T = wave_bcast_u64(incl, 63);
+        const u64 base = a.uniform_len ? (u64)unit * 64 * ((nk_max + 15u) & ~15u) : lookback_exclusive(a.lookback, unit, T, lane);
+        const bool ovf = base + T > a.cap;
+        if (ovf && lane == 0) atomicOr(&a.ticket[1], 1u);
+        if (r < a.n) {
+            a.refs[r] = ((base + incl - pk) << 24) | nk;
+            a.status[r] = ok ? BSK_ST_OK : BSK_ST_SHORT;
+        }
+        if (unit == a.nunits - 1 && lane == 63) *a.total = base + incl;
+        if (ovf || nk_max == 0) continue;
+        s_off[lane] = base + incl - pk;
+        s_nk[lane] = pk;
+        wave_sync_lds();
+        u64 roff[8];
+        u32 rnk[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            roff[rr] = s_off[rr * 8 + (lane >> 3)] + (u32)(lane & 7) * 2;
+            rnk[rr] = s_nk[rr * 8 + (lane >> 3)];
+        }
+        wave_sync_lds();
+        const u8 *p0 = a.ascii + off;
+        LDSQ char *const myrow = lq + lane * (TL * 8);
+        LDSQ char *const myreg = reg0 + lane * (RS * 4);
+        for (u32 c0 = 0; c0 < nk_max; c0 += BSK_PH_CHUNK) {
+            const u32 cend = (c0 + BSK_PH_CHUNK < nk_max) ? c0 + BSK_PH_CHUNK : nk_max;
+            // every lane's source stays inside its own sequence (+ the buffer's slack), whatever the other lanes' lengths
+            stage_chunks<RS, RS / 4>(reg0, p0 + ((u64)c0 < L ? (u64)c0 : L), __builtin_amdgcn_ballot_w64(c0 < pk), lane);
+            wave_sync_lds();
+            for (u32 i0 = c0; i0 < cend; i0 += 16) {
+                const u32x4 ra = *reinterpret_cast<LDSQ const u32x4 *>(myreg + (i0 - c0));
+                const u32x4 rb = *reinterpret_cast<LDSQ const u32x4 *>(myreg + (i0 - c0) + 16);
+                const u32 R[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int g = t >> 2;
+                    u64 h;
+                    switch (t & 3) {
+                        case 0: h = fp.template hashK<0>(R[g], R[g + 1], R[g + 2], R[g + 3], R[g + 4]); break;
+                        case 1: h = fp.template hashK<1>(R[g], R[g + 1], R[g + 2], R[g + 3], R[g + 4]); break;
+                        case 2: h = fp.template hashK<2>(R[g], R[g + 1], R[g + 2], R[g + 3], R[g + 4]); break;
+                        default: h = fp.template hashK<3>(R[g], R[g + 1], R[g + 2], R[g + 3], R[g + 4]); break;
+                    }
+                    *reinterpret_cast<LDSQ u64 *>(myrow + t * 8) = h;
+                }
+                wave_sync_lds();
+                u32x4 tv[8];
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr)
+                    tv[rr] = *reinterpret_cast<LDSQ const u32x4 *>(lq + (rr * 8 + (lane >> 3)) * (TL * 8) + (lane & 7) * 16);
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    if (i0 + (u32)(lane & 7) * 2 < rnk[rr]) {
+                        u64x2_a8 vv;
+                        vv.a = ((u64)tv[rr].y << 32) | tv[rr].x;
+                        vv.b = ((u64)tv[rr].w << 32) | tv[rr].z;
+                        *reinterpret_cast<u64x2_a8 *>(a.hash + roff[rr] + i0) = vv;
+                    }
+                }
+                wave_sync_lds();
+            }
+        }
+    }
+}
+
+#define BSK_PH_KS(X) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+static inline bool fast_prot_hash_supported(int k) { return k >= 9 && k <= 16; }
+static inline int fast_prot_hash_blocks_per_cu(int k) {
+    int nb = 0;
+    hipError_t e = hipErrorInvalidValue;
+#define X(KK) \
+    if (k == KK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_prot_hash_fast<KK>, 64, 0);
+    BSK_PH_KS(X)
+#undef X
+    if (e != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        nb = 1;
+    }
+    return nb;
+}
+static inline void fast_prot_hash_launch(int k, int grid, hipStream_t stream, const KArgs &a) {
+#define X(KK) \
+    if (k == KK) hipLaunchKernelGGL((k_prot_hash_fast<KK>), dim3(grid), dim3(64), 0, stream, a);
+    BSK_PH_KS(X)
 #undef X
 }
 
