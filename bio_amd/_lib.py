@@ -49,6 +49,8 @@ SYMBOLS = [
     ("bsk_batch_synth", C.c_int, [_vp, C.c_int, C.c_uint64, C.c_uint32, C.c_uint64, _pp]),
     ("bsk_batch_info", C.c_int, [_vp, _u64p, _u64p, _u64p, _u64p]),
     ("bsk_batch_fetch_ascii", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, _vp]),
+    ("bsk_batch_translate", C.c_int, [_vp, _vp, C.c_int, C.c_int, _pp]),
+    ("bsk_codon_lut", C.c_int, [C.c_int, _vp, C.c_uint64]),
     ("bsk_batch_destroy", None, [_vp]),
     ("bsk_sketch", C.c_int, [_vp, _vp, C.POINTER(Params), _pp]),
     ("bsk_sketch_timed", C.c_int, [_vp, _vp, C.POINTER(Params), _pp, C.c_int, C.c_int, C.POINTER(C.c_float)]),

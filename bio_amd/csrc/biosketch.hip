@@ -18,6 +18,7 @@
 #include "kernels_more.hpp"
 #include "kernels_syncmer.hpp"
 #include "kernels_protein.hpp"
+#include "kernels_translate.hpp"
 
 using namespace bsk;
 
@@ -36,6 +37,8 @@ struct bsk_ctx {
     u32 *d_ring_p = nullptr;
     size_t ring_cap = 0;  // entries
     u64 *h_pinned = nullptr;  // [8] pinned host words for small read-backs
+    u8 *d_lut = nullptr;      // codon tables of `lut_table` (kernels_translate.hpp layout)
+    int lut_table = 0;
     bool no_prot_fast = false;  // set while a call falls back from the per-sequence-slab protein kernel
 };
 
@@ -312,6 +315,7 @@ extern "C" void bsk_ctx_destroy(bsk_ctx *ctx) {
     (void)hipFree(ctx->d_lookback);
     (void)hipFree(ctx->d_ring_h);
     (void)hipFree(ctx->d_ring_p);
+    (void)hipFree(ctx->d_lut);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -730,8 +734,8 @@ static int validate(const bsk_params *p, int alphabet) {
         default: return BSK_ERR_ARG;
     }
     const bool prot = p->kind == BSK_PROT_HASH || p->kind == BSK_PROT_MINIMIZER;
-    if (prot != (alphabet == BSK_ALPHA_PROTEIN)) return BSK_ERR_UNSUPPORTED;  // DNA->protein translation: DESIGN.md "next"
-    return BSK_OK;
+    if (!prot && alphabet == BSK_ALPHA_PROTEIN) return BSK_ERR_UNSUPPORTED;  // nucleotide sketches of a protein batch
+    return BSK_OK;  // protein kinds on a DNA batch: translated first (sketch_impl)
 }
 
 static int ensure_scratch(bsk_ctx *ctx, size_t nunits, size_t ring_entries) {
@@ -873,6 +877,160 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
     return BSK_OK;
 }
 
+// ------------------------------------------------------------------------------------
+// DNA/RNA -> protein (the Translate call of NewProteinIterator / NewProteinMinimizerSketch,
+// iterator-protein.go:62-67, sketch-protein.go:83-88)
+// ------------------------------------------------------------------------------------
+// NCBI genetic codes: the standard code plus each table's reassigned codons (codon order T,C,A,G; the ids are the
+// ones registered at seq/codon_tables.go:431-621).
+static const char kStdCode[65] = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+static const struct { int id; const char *diff; } kGeneticCodes[] = {
+    {1, ""}, {2, "TGAW ATAM AGA* AGG*"}, {3, "TGAW CTTT CTCT CTAT CTGT ATAM"}, {4, "TGAW"}, {5, "TGAW ATAM AGAS AGGS"},
+    {6, "TAAQ TAGQ"}, {9, "TGAW AAAN AGAS AGGS"}, {10, "TGAC"}, {11, ""}, {12, "CTGS"}, {13, "TGAW ATAM AGAG AGGG"},
+    {14, "TAAY TGAW AAAN AGAS AGGS"}, {16, "TAGL"}, {21, "TGAW ATAM AAAN AGAS AGGS"}, {22, "TCA* TAGL"}, {23, "TTA*"},
+    {24, "TGAW AGAS AGGK"}, {25, "TGAG"}, {26, "CTGA"}, {27, "TAAQ TAGQ TGAW"}, {28, "TAAQ TAGQ TGAW"}, {29, "TAAY TAGY"},
+    {30, "TAAE TAGE"}, {31, "TAAE TAGE TGAW"},
+};
+#define BSK_LUT_BYTES (4096 + 256 + 64)
+
+// IUPAC letter -> 4-bit base set (A1 C2 G4 T/U8), gap letters 0, everything else 16 (seq/ambiguous_bases.go:28-67)
+static unsigned iupac_set(unsigned b) {
+    static const char letters[] = "ACMGRSVTWYHKDBN";  // letter of set 1..15
+    if (b == ' ' || b == '*' || b == '-') return 0;
+    if (b == 'U' || b == 'u') return 8;
+    for (unsigned c = 1; c < 16; ++c)
+        if (b == (unsigned)letters[c - 1] || b == (unsigned)(letters[c - 1] | 0x20)) return c;
+    return 16;
+}
+
+// Tables for kernels_translate.hpp.  A codon made of base SETS has an amino acid iff every plain codon it stands for has
+// that amino acid -- the fixed point of the three passes of codonTableFromText (seq/codon_tables.go:350-427); entries
+// left empty there read as 'X' (Get, :172-174).  Pure host code.
+extern "C" int bsk_codon_lut(int table, uint8_t *lut, uint64_t lut_bytes) {
+    if (!lut || lut_bytes < BSK_LUT_BYTES) return BSK_ERR_ARG;
+    const char *diff = nullptr;
+    for (const auto &g : kGeneticCodes)
+        if (g.id == table) diff = g.diff;
+    if (!diff) return BSK_ERR_ARG;
+    char aa[64];
+    memcpy(aa, kStdCode, 64);
+    auto tcag = [](char c) { return c == 'T' ? 0 : c == 'C' ? 1 : c == 'A' ? 2 : 3; };
+    for (const char *d = diff; *d; d += d[4] ? 5 : 4) aa[tcag(d[0]) * 16 + tcag(d[1]) * 4 + tcag(d[2])] = d[3];
+    static const int bit_to_tcag[9] = {-1, 2, 1, -1, 3, -1, -1, -1, 0};  // set bit A1 C2 G4 T8 -> index in T,C,A,G order
+    for (unsigned i = 0; i < 16; ++i)
+        for (unsigned j = 0; j < 16; ++j)
+            for (unsigned k = 0; k < 16; ++k) {
+                int common = -1;  // -1 nothing yet, 0 disagreement
+                if (i && j && k)
+                    for (unsigned a = 1; a <= 8 && common != 0; a <<= 1)
+                        for (unsigned b = 1; b <= 8 && common != 0; b <<= 1)
+                            for (unsigned c = 1; c <= 8 && common != 0; c <<= 1) {
+                                if (!(i & a) || !(j & b) || !(k & c)) continue;
+                                const int v = aa[bit_to_tcag[a] * 16 + bit_to_tcag[b] * 4 + bit_to_tcag[c]];
+                                common = common < 0 ? v : (common == v ? v : 0);
+                            }
+                lut[(i << 8) | (j << 4) | k] = common > 0 ? (uint8_t)common : (uint8_t)'X';
+            }
+    for (unsigned b = 0; b < 256; ++b) lut[4096 + b] = (uint8_t)iupac_set(b);
+    static const int acgt_to_tcag[4] = {2, 1, 3, 0};  // 2-bit code A0 C1 G2 T3
+    for (unsigned c = 0; c < 64; ++c)
+        lut[4096 + 256 + c] = (uint8_t)aa[acgt_to_tcag[c >> 4] * 16 + acgt_to_tcag[(c >> 2) & 3] * 4 + acgt_to_tcag[c & 3]];
+    return BSK_OK;
+}
+
+// Translate every sequence of a DNA batch into a new protein batch.  need != 0: sequences shorter than `need` bases are
+// flagged (rflags) so that the protein kernels report them as ErrShortSeq -- the reference checks the INPUT length.
+static int translate_batch(bsk_ctx *ctx, const bsk_batch *b, int table, int frame, u64 need, bsk_batch **out) {
+    *out = nullptr;
+    if (frame < -3 || frame > 3 || frame == 0) {
+        ctx->err = "invalid frame (available: 1, 2, 3, -1, -2, -3)";  // seq/seq.go:694
+        return BSK_ERR_ARG;
+    }
+    if (ctx->lut_table != table || !ctx->d_lut) {
+        uint8_t lut[BSK_LUT_BYTES];
+        if (bsk_codon_lut(table, lut, sizeof lut) != BSK_OK) {
+            ctx->err = "invalid codon table";  // seq/seq.go:691
+            return BSK_ERR_ARG;
+        }
+        if (!ctx->d_lut) HIPCHK(ctx, hipMalloc(&ctx->d_lut, BSK_LUT_BYTES));
+        HIPCHK(ctx, hipMemcpy(ctx->d_lut, lut, BSK_LUT_BYTES, hipMemcpyHostToDevice));
+        ctx->lut_table = table;
+    }
+    bsk_batch *t = new (std::nothrow) bsk_batch();
+    if (!t) return BSK_ERR_NOMEM;
+    t->ctx = ctx;
+    t->alphabet = BSK_ALPHA_PROTEIN;
+    t->n = b->n;
+    t->maxlen = (u32)translated_len(b->maxlen, frame > 0 ? 1 : -1);
+    t->uniform_len = b->uniform_len ? (u32)translated_len(b->uniform_len, frame) : 0;
+    const u64 cap_bytes = b->n_bases / 3 + 1;
+    hipError_t e;
+    if ((e = hipMalloc(&t->ascii, cap_bytes + BSK_ASCII_PAD)) != hipSuccess || (e = hipMalloc(&t->aoff, (b->n + 1) * 8)) != hipSuccess ||
+        (e = hipMalloc(&t->rflags, b->n ? b->n : 1)) != hipSuccess ||
+        (e = hipMemsetAsync(t->aoff, 0, 8, ctx->stream)) != hipSuccess) {
+        bsk_batch_destroy(t);
+        return fail_hip(ctx, e, "translate alloc");
+    }
+    t->device_bytes = cap_bytes + BSK_ASCII_PAD + (b->n + 1) * 8 + b->n;
+    const u32 nunits = (u32)((b->n + 63) / 64);
+    if (nunits) {
+        int rc = ensure_scratch(ctx, nunits, 0);
+        if (rc != BSK_OK) {
+            bsk_batch_destroy(t);
+            return rc;
+        }
+        TArgs a;
+        memset(&a, 0, sizeof a);
+        a.words = b->words;
+        a.desc = b->desc;
+        a.ascii = b->ascii;
+        a.aoff = b->aoff;
+        a.n = b->n;
+        a.nunits = nunits;
+        a.frame = frame;
+        a.need = need;
+        a.lut = ctx->d_lut;
+        a.out = t->ascii;
+        a.out_off = t->aoff;
+        a.short_flag = t->rflags;
+        a.ticket = ctx->d_ticket;
+        a.lookback = ctx->d_lookback;
+        a.total = ctx->d_total;
+        const bool use_ascii = b->n_nonacgt > 0;
+        int per_cu = use_ascii ? blocks_per_cu(k_translate<1>) : blocks_per_cu(k_translate<0>);
+        const int grid = (int)std::max<u64>(1, std::min<u64>((u64)ctx->cus * per_cu, nunits));
+        if ((e = hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream)) == hipSuccess &&
+            (e = hipMemsetAsync(ctx->d_total, 0, 2 * sizeof(u64), ctx->stream)) == hipSuccess &&
+            (e = hipMemsetAsync(ctx->d_lookback, 0, (size_t)nunits * sizeof(u64), ctx->stream)) == hipSuccess) {
+            if (use_ascii) hipLaunchKernelGGL(k_translate<1>, dim3(grid), dim3(64), 0, ctx->stream, a);
+            else hipLaunchKernelGGL(k_translate<0>, dim3(grid), dim3(64), 0, ctx->stream, a);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_pinned, ctx->d_total, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            bsk_batch_destroy(t);
+            return fail_hip(ctx, e, "translate");
+        }
+        t->n_bases = ctx->h_pinned[0];
+    }
+    *out = t;
+    return BSK_OK;
+}
+
+extern "C" int bsk_batch_translate(bsk_ctx *ctx, const bsk_batch *dna, int codon_table, int frame, bsk_batch **out) {
+    if (!ctx || !dna || !out) return fail_arg(ctx, "bsk_batch_translate: null argument");
+    if (dna->ctx != ctx) return fail_arg(ctx, "bsk_batch_translate: batch belongs to another context");
+    if (dna->alphabet != BSK_ALPHA_DNA) return fail_arg(ctx, "bsk_batch_translate: only DNA/RNA batches can be translated");  // seq.go:686
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = translate_batch(ctx, dna, codon_table, frame, 0, out);
+    if (rc == BSK_OK) {  // a stand-alone protein batch: length checks then apply to the protein, as for any Protein Seq
+        (void)hipFree((*out)->rflags);
+        (*out)->rflags = nullptr;
+    }
+    return rc;
+}
+
 // One launch of the planned kernel into res.  ev0/ev1 (optional) bracket the kernel itself.
 static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_result *res, int circ_ext, const Plan &pl,
                   hipEvent_t ev0, hipEvent_t ev1) {
@@ -988,6 +1146,13 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
         if (rc != BSK_OK) return rc;
         b = tmp;
         circ_ext = p->k - 1;
+    }
+    if (batch->alphabet == BSK_ALPHA_DNA && (p->kind == BSK_PROT_HASH || p->kind == BSK_PROT_MINIMIZER)) {
+        // iterator-protein.go:50,62-67 / sketch-protein.go:66-75,83-88: length checks on the nucleotides, then Translate
+        const u64 need = (u64)p->k * 3 + (p->kind == BSK_PROT_MINIMIZER ? (u64)p->w - 1 : 0);
+        rc = translate_batch(ctx, batch, p->codon_table, p->frame, need, &tmp);
+        if (rc != BSK_OK) return rc;
+        b = tmp;
     }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     auto cleanup = [&](int code) {

@@ -57,6 +57,14 @@ __device__ inline u64 wyhash_dev(const u8 *key, unsigned len, u64 seed) {
     return wymum(seed, (u64)len ^ WYP5);
 }
 
+// Length rule of the protein constructors (iterator-protein.go:50, sketch-protein.go:66,73): checked on the INPUT.
+// Protein input: the residues themselves.  Translated input: the translate kernel left one flag per sequence
+// (rflags: 1 = too few nucleotides); the translation itself may then hold fewer than k residues (or fewer than w
+// k-mers), which yields nothing but is no error.
+__device__ __forceinline__ bool prot_len_ok(const KArgs &a, u64 r, u64 L, u64 need) {
+    return a.rflags ? a.rflags[r] == 0 : L >= need;
+}
+
 struct WySrc {  // hash source over residues
     const u8 *a;
     u64 L;
@@ -95,8 +103,8 @@ __global__ __launch_bounds__(64) void k_prot_minimizer(KArgs a) {
             L = a.aoff[r + 1] - off;
         }
         // sketch-protein.go:66,73: len < 3k -> ErrShortSeq ; len < 3k+w-1 -> ErrShortSeq (on the INPUT length)
-        const bool ok = r < a.n && L >= (u64)a.k * 3 + (u64)W - 1;
-        const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
+        const bool ok = r < a.n && prot_len_ok(a, r, L, (u64)a.k * 3 + (u64)W - 1);
+        const u32 nk = (ok && L >= (u64)a.k + (u64)W - 1) ? (u32)(L - a.k + 1) : 0u;
         const u32 nk_max = wave_max_u32(nk);
         u32 cnt = 0, tie = 0;
         WySrc src;
@@ -182,8 +190,8 @@ __global__ __launch_bounds__(64) void k_prot_hash(KArgs a) {
             off = a.aoff[r];
             L = a.aoff[r + 1] - off;
         }
-        const bool ok = r < a.n && L >= (u64)a.k * 3;  // iterator-protein.go:50 (checked on the input length)
-        const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
+        const bool ok = r < a.n && prot_len_ok(a, r, L, (u64)a.k * 3);  // iterator-protein.go:50 (checked on the input length)
+        const u32 nk = (ok && L >= (u64)a.k) ? (u32)(L - a.k + 1) : 0u;
         u32 nk_max;
         if (!stream_prologue(a, unit, lane, r, nk, ok ? BSK_ST_OK : BSK_ST_SHORT, s_off, s_nk, nk_max)) continue;
         WySrc src;

@@ -209,8 +209,8 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
             off = a.aoff[r];
             L = a.aoff[r + 1] - off;
         }
-        const bool ok = r < a.n && L >= (u64)K * 3 + (u64)W - 1;  // sketch-protein.go:66,73
-        const u32 nk = ok ? (u32)(L - K + 1) : 0u;
+        const bool ok = r < a.n && prot_len_ok(a, r, L, (u64)K * 3 + (u64)W - 1);  // sketch-protein.go:66,73
+        const u32 nk = (ok && L >= (u64)K + (u64)W - 1) ? (u32)(L - K + 1) : 0u;
         const u32 nk_max = wave_max_u32(nk);
         u32 done = 0;  // tuples of this lane already in HBM
         u32 tie = 0;
@@ -382,8 +382,8 @@ __global__ __launch_bounds__(64) void k_prot_hash_fast(KArgs a) {
             off = a.aoff[r];
             L = a.aoff[r + 1] - off;
         }
-        const bool ok = r < a.n && L >= (u64)K * 3;  // iterator-protein.go:50 (checked on the input length)
-        const u32 nk = ok ? (u32)(L - K + 1) : 0u;
+        const bool ok = r < a.n && prot_len_ok(a, r, L, (u64)K * 3);  // iterator-protein.go:50 (checked on the input length)
+        const u32 nk = (ok && L >= (u64)K) ? (u32)(L - K + 1) : 0u;
         const u32 nk_max = wave_max_u32(nk);
         const u32 pk = (nk + 15u) & ~15u;
         const u64 incl = wave_incl_scan_u64((u64)pk, lane);

@@ -103,6 +103,12 @@ class Batch:
                                                          offs.ctypes.data))
         return buf[: int(offs[-1])].copy(), offs
 
+    def translate(self, codon_table: int = 1, frame: int = 1) -> "Batch":
+        """(*seq.Seq).Translate(table, frame, false, false, true, false) of every sequence (seq/seq.go:685) -> protein batch."""
+        h = C.c_void_p()
+        self.eng._chk(self.eng.lib.bsk_batch_translate(self.eng.ctx, self.h, codon_table, frame, C.byref(h)))
+        return Batch(self.eng, h)
+
     def close(self):
         if self.h:
             self.eng.lib.bsk_batch_destroy(self.h)

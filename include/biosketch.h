@@ -102,8 +102,8 @@ typedef struct bsk_params {
     int32_t scale;      /* SIMHASH: FracMinHash scale, iterator.go:113 `scale` */
     int32_t canonical;  /* KMER / NTHASH / SIMHASH: `canonical` argument (sketches are always canonical) */
     int32_t circular;   /* `circular` argument: first k-1 bases appended (iterator.go:642-646) */
-    int32_t codon_table;/* PROT_*: only used for DNA input (not implemented: BSK_ERR_UNSUPPORTED) */
-    int32_t frame;      /* PROT_*: idem */
+    int32_t codon_table;/* PROT_* on a DNA batch: NCBI genetic-code id for the translation (ignored for protein batches) */
+    int32_t frame;      /* PROT_* on a DNA batch: 1,2,3,-1,-2,-3 */
 } bsk_params;
 
 typedef struct bsk_ctx bsk_ctx;
@@ -142,6 +142,18 @@ int bsk_batch_info(const bsk_batch *b, uint64_t *n_reads, uint64_t *n_bases, uin
  * the exact bytes the device hashed).  bytes_cap = capacity of bytes[]; offsets[count+1]. */
 int bsk_batch_fetch_ascii(bsk_ctx *ctx, const bsk_batch *b, uint64_t first, uint64_t count,
                           uint8_t *bytes, uint64_t bytes_cap, uint64_t *offsets);
+/* DNA/RNA batch -> protein batch on the device: (*seq.Seq).Translate(codon_table, frame, trim=false, clean=false,
+ * allowUnknownCodon=true, markInitCodonAsM=false), seq/seq.go:685-708 + seq/codon_tables.go:205-285 -- the call that
+ * NewProteinIterator (iterator-protein.go:62-67) and NewProteinMinimizerSketch (sketch-protein.go:83-88) make for
+ * non-protein input.  frame: 1,2,3,-1,-2,-3; codon_table: an NCBI genetic-code id of seq/codon_tables.go:431-621.
+ * bsk_sketch does this internally when a PROT_* kind is run on a DNA batch (and then applies the constructors'
+ * length checks to the NUCLEOTIDE length, as the reference does); this entry point exposes the translation itself. */
+int bsk_batch_translate(bsk_ctx *ctx, const bsk_batch *dna, int codon_table, int frame, bsk_batch **out);
+/* Host-only: the tables the translate kernel uses for `codon_table` -- [0,4096) amino acid of the codon whose bases
+ * are the IUPAC sets (i,j,k) at index i*256+j*16+k ('X' where the reference's 16x16x16 matrix is empty,
+ * codon_tables.go:172-174,317-429), [4096,4352) letter -> set (16 = not a base letter, ambiguous_bases.go:28-67),
+ * [4352,4416) the 64 plain codons by 2-bit code (A0 C1 G2 T3, first base most significant).  lut_bytes >= 4416. */
+int bsk_codon_lut(int codon_table, uint8_t *lut, uint64_t lut_bytes);
 void bsk_batch_destroy(bsk_batch *b);
 
 /* ---- compute -------------------------------------------------------------------

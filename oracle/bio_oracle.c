@@ -841,12 +841,19 @@ long long orc_protein_hash_all(const uint8_t *aa, size_t len, int k, uint64_t *o
 }
 
 /* ---- A8: NewProteinMinimizerSketch sketch-protein.go:62-103, Next :106-210 ---- */
+static long long protein_minimizer_core(const uint8_t *aa, size_t len, int k, int w, uint64_t *hash,
+                                        uint32_t *pos, size_t cap, unsigned *flags);
 long long orc_protein_minimizer_all(const uint8_t *aa, size_t len, int k, int w, uint64_t *hash,
                                     uint32_t *pos, size_t cap, unsigned *flags) {
     if (k < 1) return ORC_ERR_INVALID_K;                             /* :63 */
     if (len < (size_t)k * 3) return ORC_ERR_SHORT_SEQ;               /* :66 */
     if (w < 1) return ORC_ERR_INVALID_W;                             /* :70 */
     if (len < (size_t)k * 3 + (size_t)w - 1) return ORC_ERR_SHORT_SEQ; /* :73 */
+    return protein_minimizer_core(aa, len, k, w, hash, pos, cap, flags);
+}
+
+static long long protein_minimizer_core(const uint8_t *aa, size_t len, int k, int w, uint64_t *hash,
+                                        uint32_t *pos, size_t cap, unsigned *flags) {
     /* same sorted-buffer machine as NextMinimizer, fed by wyhash: reuse orc_sketch fields */
     orc_sketch sk;
     memset(&sk, 0, sizeof sk);
@@ -926,6 +933,191 @@ long long orc_protein_minimizer_closed(const uint8_t *aa, size_t len, int k, int
     }
     if (flags) *flags = fl;
     free(h);
+    return n;
+}
+
+/* =====================================================================
+ * DNA/RNA -> protein translation as NewProteinIterator / NewProteinMinimizerSketch apply it to
+ * non-protein input: s.Translate(codonTable, frame, trim=false, clean=false,
+ * allowUnknownCodon=true, markInitCodonAsM=false)  (iterator-protein.go:62-67,
+ * sketch-protein.go:83-88; seq/seq.go:685-708; seq/codon_tables.go:205-285).
+ * Pinned by the vectors of seq/codon_tables_test.go:26-135 (tests/golden/codon_golden.json).
+ * ===================================================================== */
+
+/* base2code seq/ambiguous_bases.go:28-67: IUPAC letter -> 4-bit set (A1 C2 G4 T/U8); ' ' '*' '-' -> 0;
+ * anything else invalid (-1) */
+static int base2code(uint8_t b) {
+    switch (b) {
+    case 'A': case 'a': return 1;
+    case 'C': case 'c': return 2;
+    case 'G': case 'g': return 4;
+    case 'T': case 't': case 'U': case 'u': return 8;
+    case 'N': case 'n': return 15;
+    case 'M': case 'm': return 3;
+    case 'R': case 'r': return 5;
+    case 'W': case 'w': return 9;
+    case 'S': case 's': return 6;
+    case 'Y': case 'y': return 10;
+    case 'K': case 'k': return 12;
+    case 'V': case 'v': return 7;
+    case 'H': case 'h': return 11;
+    case 'D': case 'd': return 13;
+    case 'B': case 'b': return 14;
+    case ' ': case '*': case '-': return 0;
+    default: return -1;
+    }
+}
+
+/* The NCBI genetic codes (https://www.ncbi.nlm.nih.gov/Taxonomy/Utils/wprintgc.cgi), kept as the standard
+ * code plus each table's reassigned codons; codon order T,C,A,G for every base, first base slowest
+ * (the layout of the five-line blocks at seq/codon_tables.go:431-621). */
+static const char STD_CODE[65] = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+static const struct { int id; const char *diff; } GENETIC_CODES[] = {
+    {1, ""}, {2, "TGAW ATAM AGA* AGG*"}, {3, "TGAW CTTT CTCT CTAT CTGT ATAM"}, {4, "TGAW"},
+    {5, "TGAW ATAM AGAS AGGS"}, {6, "TAAQ TAGQ"}, {9, "TGAW AAAN AGAS AGGS"}, {10, "TGAC"}, {11, ""},
+    {12, "CTGS"}, {13, "TGAW ATAM AGAG AGGG"}, {14, "TAAY TGAW AAAN AGAS AGGS"}, {16, "TAGL"},
+    {21, "TGAW ATAM AAAN AGAS AGGS"}, {22, "TCA* TAGL"}, {23, "TTA*"}, {24, "TGAW AGAS AGGK"}, {25, "TGAG"},
+    {26, "CTGA"}, {27, "TAAQ TAGQ TGAW"}, {28, "TAAQ TAGQ TGAW"}, {29, "TAAY TAGY"}, {30, "TAAE TAGE"},
+    {31, "TAAE TAGE TGAW"},
+};
+
+/* 64 amino acids of table `id` in TCAG order; returns 0, or -1 for an unknown table (seq.go:691) */
+int orc_genetic_code(int id, char aa64[65]) {
+    static const char TCAG[] = "TCAG";
+    for (size_t t = 0; t < sizeof GENETIC_CODES / sizeof GENETIC_CODES[0]; t++) {
+        if (GENETIC_CODES[t].id != id) continue;
+        memcpy(aa64, STD_CODE, 65);
+        for (const char *d = GENETIC_CODES[t].diff; *d; d += (d[4] ? 5 : 4)) {
+            int idx = 0;
+            for (int j = 0; j < 3; j++) idx = idx * 4 + (int)(strchr(TCAG, d[j]) - TCAG);
+            aa64[idx] = d[3];
+        }
+        return 0;
+    }
+    return -1;
+}
+
+/* codonTableFromText seq/codon_tables.go:317-429: 16x16x16 matrix indexed by base2code; the 64 plain
+ * codons first (:329-341), then the three passes that give a codon with ambiguity letters an amino acid
+ * when the letters it stands for agree (:350-427).  In a pass the groups of different amino acids write
+ * disjoint entries, so Go's map iteration order does not matter. */
+int orc_codon_matrix(int id, uint8_t m[16][16][16]) {
+    static const int CODE_TCAG[4] = {8, 2, 1, 4};
+    char aa64[65];
+    if (orc_genetic_code(id, aa64) != 0) return -1;
+    memset(m, 0, 4096);
+    for (int i = 0; i < 64; i++) m[CODE_TCAG[i >> 4]][CODE_TCAG[(i >> 2) & 3]][CODE_TCAG[i & 3]] = (uint8_t)aa64[i];
+    for (int pass = 0; pass < 3; pass++) {          /* 0: third base :350, 1: second :376, 2: first :402 */
+        for (int a = 1; a < 16; a++) {
+            for (int b = 1; b < 16; b++) {
+                /* group the running index c by amino acid: set[aa] = OR of the codes that carry it (Codes2AmbCode) */
+                int set[256];
+                memset(set, 0, sizeof set);
+                for (int c = 1; c < 16; c++) {
+                    uint8_t aa = pass == 0 ? m[a][b][c] : pass == 1 ? m[a][c][b] : m[c][a][b];
+                    if (aa) set[aa] |= c;
+                }
+                for (int aa = 1; aa < 256; aa++) {
+                    if (!set[aa]) continue;
+                    /* AmbCodes2Codes seq/ambiguous_bases.go:153-175: every non-empty sub-set of the code */
+                    for (int c = 1; c < 16; c++) {
+                        if ((c & set[aa]) != c) continue;
+                        if (pass == 0) m[a][b][c] = (uint8_t)aa;
+                        else if (pass == 1) m[a][c][b] = (uint8_t)aa;
+                        else m[c][a][b] = (uint8_t)aa;
+                    }
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* CodonTable.Get seq/codon_tables.go:157-177 with allowUnknownCodon = true */
+static uint8_t codon_get(uint8_t m[16][16][16], uint8_t c0, uint8_t c1, uint8_t c2) {
+    int i = base2code(c0), j = base2code(c1), k = base2code(c2);
+    if (i < 0 || j < 0 || k < 0) return 'X';                 /* :160-163 */
+    if (c0 == '-' && c1 == '-' && c2 == '-') return '-';     /* :167 */
+    uint8_t aa = m[i][j][k];
+    return aa ? aa : 'X';                                     /* :172-174 */
+}
+
+/* DNA.PairLetter seq/alphabet.go:313-325 with the DNA alphabet of :353-359: acgtACGT are complemented;
+ * gap and ambiguous letters map to themselves; for any other byte the error is ignored by the caller
+ * (codon_tables.go:226-228) and the byte itself is used */
+static uint8_t dna_pair_letter(uint8_t b) {
+    switch (b) {
+    case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a';
+    case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A';
+    default: return b;
+    }
+}
+
+/* CodonTable.Translate seq/codon_tables.go:205-285 (allowUnknownCodon = true, markInitCodonAsM = false).
+ * Returns the number of residues (written to out if non-NULL, at most cap), -1 unknown table,
+ * -2 bad frame, -3 sequence shorter than 3 (:206). */
+long long orc_translate(const uint8_t *nt, size_t len, int table, int frame, int trim, int clean,
+                        uint8_t *out, size_t cap) {
+    uint8_t m[16][16][16];
+    if (orc_codon_matrix(table, m) != 0) return -1;
+    if (len < 3) return -3;
+    if (frame < -3 || frame > 3 || frame == 0) return -2;
+    long long n = 0;
+    if (frame < 0) {
+        for (long long i = (long long)len + frame; i >= 2; i -= 3) {                  /* :224 */
+            uint8_t aa = codon_get(m, dna_pair_letter(nt[i]), dna_pair_letter(nt[i - 1]), dna_pair_letter(nt[i - 2]));
+            if (trim && (aa == 'X' || aa == '*')) break;                              /* :246 */
+            if (clean && aa == '*') aa = 'X';
+            if (out) { if ((size_t)n >= cap) return ORC_ERR_CAPACITY; out[n] = aa; }
+            n++;
+        }
+    } else {
+        for (size_t i = (size_t)frame - 1; i + 2 < len; i += 3) {                     /* :256 */
+            uint8_t aa = codon_get(m, nt[i], nt[i + 1], nt[i + 2]);
+            if (trim && (aa == 'X' || aa == '*')) break;
+            if (clean && aa == '*') aa = 'X';
+            if (out) { if ((size_t)n >= cap) return ORC_ERR_CAPACITY; out[n] = aa; }
+            n++;
+        }
+    }
+    return n;
+}
+
+/* A7 on nucleotide input (iterator-protein.go:46-73): the length check is on the INPUT (:50); the
+ * translation may then be shorter than k, in which case end < 0 and Next() ends at once (:81). */
+long long orc_protein_hash_nt(const uint8_t *nt, size_t len, int k, int table, int frame, uint64_t *out, size_t cap) {
+    if (k < 1) return ORC_ERR_INVALID_K;
+    if (len < (size_t)k * 3) return ORC_ERR_SHORT_SEQ;
+    uint8_t *aa = (uint8_t *)malloc(len / 3 + 2);
+    if (!aa) return ORC_ERR_NOMEM;
+    long long P = orc_translate(nt, len, table, frame, 0, 0, aa, len / 3 + 2);
+    if (P < 0) { free(aa); return ORC_ERR_ILLEGAL_BASE; }  /* Translate's own errors (table, frame): surfaced as "other" */
+    long long n = 0;
+    for (long long idx = 0; idx + k <= P; idx++) {
+        if (out) {
+            if ((size_t)n >= cap) { free(aa); return ORC_ERR_CAPACITY; }
+            out[n] = orc_wyhash(aa + idx, (size_t)k, 1);
+        }
+        n++;
+    }
+    free(aa);
+    return n;
+}
+
+/* A8 on nucleotide input (sketch-protein.go:62-103): both length checks are on the INPUT (:66,:73); a
+ * translation with fewer than w k-mers never completes a window and yields nothing (:126-131). */
+long long orc_protein_minimizer_nt(const uint8_t *nt, size_t len, int k, int w, int table, int frame,
+                                   uint64_t *hash, uint32_t *pos, size_t cap, unsigned *flags) {
+    if (k < 1) return ORC_ERR_INVALID_K;
+    if (len < (size_t)k * 3) return ORC_ERR_SHORT_SEQ;
+    if (w < 1) return ORC_ERR_INVALID_W;
+    if (len < (size_t)k * 3 + (size_t)w - 1) return ORC_ERR_SHORT_SEQ;
+    uint8_t *aa = (uint8_t *)malloc(len / 3 + 2);
+    if (!aa) return ORC_ERR_NOMEM;
+    long long P = orc_translate(nt, len, table, frame, 0, 0, aa, len / 3 + 2);
+    if (P < 0) { free(aa); return ORC_ERR_ILLEGAL_BASE; }
+    long long n = protein_minimizer_core(aa, (size_t)P, k, w, hash, pos, cap, flags);
+    free(aa);
     return n;
 }
 

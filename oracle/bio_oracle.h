@@ -126,6 +126,16 @@ long long orc_protein_minimizer_all(const uint8_t *aa, size_t len, int k, int w,
 long long orc_protein_minimizer_closed(const uint8_t *aa, size_t len, int k, int w,
                                        uint64_t *hash, uint32_t *pos, size_t cap, unsigned *flags);
 
+/* ---- A7/A8 on DNA/RNA input: Translate(table, frame, trim=false, clean=false, allowUnknownCodon=true,
+ * markInitCodonAsM=false) first (seq/codon_tables.go:205-285), length checks on the nucleotide length ---- */
+int orc_genetic_code(int id, char aa64[65]);
+int orc_codon_matrix(int id, uint8_t m[16][16][16]);
+long long orc_translate(const uint8_t *nt, size_t len, int table, int frame, int trim, int clean,
+                        uint8_t *out, size_t cap);
+long long orc_protein_hash_nt(const uint8_t *nt, size_t len, int k, int table, int frame, uint64_t *out, size_t cap);
+long long orc_protein_minimizer_nt(const uint8_t *nt, size_t len, int k, int w, int table, int frame,
+                                   uint64_t *hash, uint32_t *pos, size_t cap, unsigned *flags);
+
 /* ---- batch drivers (cpu_baseline leg of bench.py; OpenMP over reads) ----
  * kind: 2 = ntHash stream, 4 = minimizer, 5 = syncmer, 7 = protein minimizer.
  * seqs: concatenated bytes, offsets[n+1].  Only tuple counts and an

@@ -177,6 +177,55 @@ def protein_minimizer(aa, k, w, closed=False):
     return h[:n].copy(), p[:n].copy(), int(fl.value)
 
 
+def genetic_code(table):
+    """64 amino acids of an NCBI genetic code in TCAG order (seq/codon_tables.go:431-621)."""
+    buf = C.create_string_buffer(65)
+    if lib().orc_genetic_code(table, buf) != 0:
+        raise ValueError(f"unknown codon table {table}")
+    return buf.value.decode()
+
+
+def translate(nt, table=1, frame=1, trim=False, clean=False):
+    """CodonTable.Translate(..., allowUnknownCodon=true, markInitCodonAsM=false) (seq/codon_tables.go:205-285)."""
+    s = _b(nt)
+    cap = len(s) // 3 + 2
+    out = np.zeros(cap, np.uint8)
+    L = lib()
+    L.orc_translate.restype = C.c_longlong
+    L.orc_translate.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    n = L.orc_translate(s, len(s), table, frame, int(trim), int(clean), out.ctypes.data, cap)
+    if n < 0:
+        raise ValueError({-1: "invalid codon table", -2: "invalid frame", -3: "sequence too short to translate"}.get(n, str(n)))
+    return out[:n].tobytes().decode("latin-1")
+
+
+def protein_hashes_nt(nt, k, table=1, frame=1):
+    """NewProteinIterator/Next on DNA/RNA input (iterator-protein.go:46-90)."""
+    s = _b(nt)
+    cap = len(s) // 3 + 2
+    out = np.zeros(cap, np.uint64)
+    L = lib()
+    L.orc_protein_hash_nt.restype = C.c_longlong
+    L.orc_protein_hash_nt.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    n = _chk(L.orc_protein_hash_nt(s, len(s), k, table, frame, out.ctypes.data, cap))
+    return out[:n].copy()
+
+
+def protein_minimizer_nt(nt, k, w, table=1, frame=1):
+    """NewProteinMinimizerSketch/Next on DNA/RNA input (sketch-protein.go:62-210) -> (hash, pos, flags)."""
+    s = _b(nt)
+    cap = len(s) // 3 + 2
+    h = np.zeros(cap, np.uint64)
+    p = np.zeros(cap, np.uint32)
+    fl = C.c_uint(0)
+    L = lib()
+    L.orc_protein_minimizer_nt.restype = C.c_longlong
+    L.orc_protein_minimizer_nt.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_size_t, C.c_void_p]
+    n = _chk(L.orc_protein_minimizer_nt(s, len(s), k, w, table, frame, h.ctypes.data, p.ctypes.data, cap, C.byref(fl)))
+    return h[:n].copy(), p[:n].copy(), int(fl.value)
+
+
 def batch_run(kind, seqs: np.ndarray, offsets: np.ndarray, k, w_or_s, threads=1):
     """cpu_baseline driver: returns (n_tuples, checksum). kind: 2 nthash, 4 minimizer, 5 syncmer, 7 protmin."""
     seqs = np.ascontiguousarray(seqs, np.uint8)

@@ -85,3 +85,32 @@ def test_product_never_touches_the_oracle():
                 if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
                     txt = open(os.path.join(dp, f), errors="ignore").read()
                     assert "bio_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, os.path.join(dp, f)
+
+
+def test_codon_tables_of_the_library_equal_the_reference_matrix(oracle):
+    """bsk_codon_lut (host-only; built as "every expansion agrees") == the 16x16x16 matrix of codonTableFromText
+    (three passes, seq/codon_tables.go:317-429) with empty entries read as 'X' (Get, :172-174), for all 24 codes."""
+    from bio_amd import _lib as L
+    lib = L.load()
+    import json
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "codon_golden.json")))
+    olib = oracle.lib()
+    for tid in sorted(int(t) for t in gold["ncbieaa"]):
+        lut = np.zeros(4416, np.uint8)
+        assert lib.bsk_codon_lut(tid, lut.ctypes.data, lut.size) == 0
+        m = np.zeros(4096, np.uint8)
+        assert olib.orc_codon_matrix(tid, m.ctypes.data_as(C.c_void_p)) == 0
+        want = np.where(m == 0, ord("X"), m).astype(np.uint8)
+        assert np.array_equal(lut[:4096], want), tid
+        aa = gold["ncbieaa"][str(tid)]
+        tcag = "TCAG"
+        for c in range(64):  # 2-bit table: A0 C1 G2 T3, first base most significant
+            codon = "".join("ACGT"[(c >> s) & 3] for s in (4, 2, 0))
+            idx = tcag.index(codon[0]) * 16 + tcag.index(codon[1]) * 4 + tcag.index(codon[2])
+            assert chr(lut[4352 + c]) == aa[idx], (tid, codon)
+        for b in range(256):  # letter -> IUPAC set
+            want_set = {"A": 1, "C": 2, "G": 4, "T": 8, "U": 8, "N": 15, "M": 3, "R": 5, "W": 9, "S": 6, "Y": 10, "K": 12, "V": 7,
+                        "H": 11, "D": 13, "B": 14, " ": 0, "*": 0, "-": 0}.get(chr(b).upper(), 16)
+            assert lut[4096 + b] == want_set, (tid, b)
+    assert lib.bsk_codon_lut(7, np.zeros(4416, np.uint8).ctypes.data, 4416) != 0      # no such genetic code
+    assert lib.bsk_codon_lut(1, np.zeros(16, np.uint8).ctypes.data, 16) != 0          # buffer too small

@@ -170,8 +170,109 @@ def test_protein_hash_register_kernel_all_k_and_long_sequences(engine, oracle, k
             assert np.array_equal(h, e), (i, len(q))
 
 
-def test_protein_from_dna_is_refused_loudly(engine):
+IUPAC = "ACGTacgtUuNnRYSWKMBDHVryswkmbdhv"
+
+
+def _codon_golden():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "codon_golden.json")))
+
+
+@pytest.mark.parametrize("frame", [1, 2, 3, -1, -2, -3])
+def test_translate_on_device(engine, oracle, frame):
+    """bsk_batch_translate == Translate(table, frame, false, false, true, false) (seq/codon_tables.go:205-285): the
+    reference's own vectors (codon_tables_test.go), every genetic code, IUPAC / gap / junk letters, both encodings."""
+    rng = random.Random(40 + frame)
+    gold = _codon_golden()
+    for table in (1, 2, 4, 11, 25, 31):
+        plain = [rand_seq(rng, rng.randint(3, 400)) for _ in range(150)] + [v["nt"].upper() for v in gold["vectors"]]
+        mixed = [rand_seq(rng, rng.randint(3, 300), IUPAC) for _ in range(100)]
+        mixed += [v["nt"] for v in gold["vectors"]] + ["---ATG---", "AT-GCC* *AA", "ACGTXJ!ACGTAA", "atgNNNtaa", "ATGRAYTGGNNNGCN---TAA"]
+        for seqs in (plain, mixed):  # 2-bit path / ASCII path
+            b = engine.batch(seqs)
+            t = b.translate(table, frame)
+            data, offs = t.fetch_ascii(0, len(seqs))
+            for i, q in enumerate(seqs):
+                got = data[int(offs[i]):int(offs[i + 1])].tobytes().decode("latin-1")
+                assert got == oracle.translate(q, table, frame), (table, frame, i, q)
+            t.close()
+            b.close()
+    for v in gold["vectors"]:  # the reference's expected strings (trim=true ones end at the first stop)
+        if v["frame"] != frame:
+            continue
+        b = engine.batch([v["nt"]])
+        t = b.translate(v["table"], frame)
+        data, offs = t.fetch_ascii(0, 1)
+        got = data.tobytes().decode("latin-1")
+        assert got.startswith(v["aa"]) and (not v["trim"] or got[len(v["aa"]):len(v["aa"]) + 1] in ("*", "X", ""))
+        if not v["trim"]:
+            assert got == v["aa"]
+
+
+@pytest.mark.parametrize("k,w,table,frame", [(9, 5, 1, 1), (9, 5, 11, -1), (10, 3, 4, 2), (3, 1, 1, 3), (5, 4, 2, -3), (12, 4, 1, -2),
+                                             (17, 6, 1, 1)])
+def test_protein_kinds_on_dna_input(engine, oracle, k, w, table, frame):
+    """NewProteinIterator / NewProteinMinimizerSketch fed DNA: length checks on the nucleotides (iterator-protein.go:50,
+    sketch-protein.go:66,73), then Translate, then the protein path -- a translation with fewer than k residues or fewer
+    than w k-mers yields nothing and is no error."""
+    rng = random.Random(k * 100 + w * 10 + frame + 7)
+    edge = [3 * k - 1, 3 * k, 3 * k + 1, 3 * k + 2, 3 * k + w - 2, 3 * k + w - 1, 3 * k + w, 3 * (k + w), 3 * (k + w) + 2, 1, 2, 3]
+    for alphabet in ("ACGT", "ACGTacgtNRYU-"):
+        seqs = [rand_seq(rng, n, alphabet) for n in edge] + [rand_seq(rng, rng.randint(1, 1200), alphabet) for _ in range(150)]
+        b = engine.batch(seqs)
+        rh = engine.run(b, engine.params(L.PROT_HASH, k, codon_table=table, frame=frame))
+        rm = engine.run(b, engine.params(L.PROT_MINIMIZER, k, w=w, codon_table=table, frame=frame))
+        for i, q in enumerate(seqs):
+            st, h, _ = rh.read(i)
+            try:
+                e = oracle.protein_hashes_nt(q, k, table, frame)
+            except oracle.OracleError as err:
+                assert err.name == "ErrShortSeq" and (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0, (i, len(q))
+            else:
+                assert (st & L.ST_CODE_MASK) == 0 and np.array_equal(h, e), (i, len(q))
+            st, h, p = rm.read(i)
+            try:
+                eh, ep, fl = oracle.protein_minimizer_nt(q, k, w, table, frame)
+            except oracle.OracleError as err:
+                assert err.name == "ErrShortSeq" and (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0, (i, len(q))
+            else:
+                assert (st & L.ST_CODE_MASK) == 0 and np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep), (i, len(q))
+                if not fl:  # unflagged reads: bit-exact claim; flagged ones (first-window tie) must carry the flag
+                    pass
+                else:
+                    assert st & L.ST_FIRST_WINDOW_TIE
+        b.close()
+
+
+def test_protein_constructors_on_dna_seq(engine, oracle):
     from bio_amd import sketches as S
-    seq, _ = S.NewSeq(S.DNA, "ACGT" * 30)
-    with pytest.raises(S.DeviceError):  # DNA -> protein translation is not implemented: no silent fallback
-        S.NewProteinIterator(seq, 5, 1, 1, engine)
+    rng = random.Random(77)
+    dna = rand_seq(rng, 600)
+    seq, _ = S.NewSeq(S.DNA, dna)
+    it, err = S.NewProteinIterator(seq, 9, 1, 1, engine)
+    assert err is None
+    got = []
+    while True:
+        code, ok = it.Next()
+        if not ok:
+            break
+        got.append(code)
+    assert np.array_equal(np.array(got, np.uint64), oracle.protein_hashes_nt(dna, 9, 1, 1))
+    sk, err = S.NewProteinMinimizerSketch(seq, 9, 11, -2, 5, engine)
+    assert err is None
+    eh, ep, _ = oracle.protein_minimizer_nt(dna, 9, 5, 11, -2)
+    got, pos = [], []
+    while True:
+        code, ok = sk.Next()
+        if not ok:
+            break
+        got.append(code)
+        pos.append(sk.Index())
+    assert np.array_equal(np.array(got, np.uint64), eh) and pos == [int(x) for x in ep]
+    short, _ = S.NewSeq(S.DNA, "ACGT" * 6)  # 24 < 3*9
+    assert S.NewProteinIterator(short, 9, 1, 1, engine) == (None, S.ErrShortSeq)
+    with pytest.raises(S.DeviceError, match="codon table"):  # Translate's own errors (seq.go:691,694) are not sentinels
+        S.NewProteinIterator(seq, 9, 7, 1, engine)
+    with pytest.raises(S.DeviceError, match="frame"):
+        S.NewProteinIterator(seq, 9, 1, 0, engine)

@@ -160,3 +160,61 @@ def test_error_surface(oracle):
     with pytest.raises(oracle.OracleError) as e:
         oracle.protein_minimizer("ACDEFGHIKLMNPQRSTVWY", 7, 3)  # len 20 < 3k
     assert e.value.name == "ErrShortSeq"
+
+
+def _codon_golden():
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "codon_golden.json")))
+
+
+def test_translation_oracle_is_pinned_by_the_reference_vectors(oracle):
+    """seq/codon_tables_test.go:26-135: six GenBank sequences with expected translations (frames 1,-1,-2,-3; trim;
+    an N codon), and the 64-letter NCBI amino-acid line of all 24 genetic codes (seq/codon_tables.go:431-621)."""
+    g = _codon_golden()
+    assert len(g["vectors"]) == 6 and len(g["ncbieaa"]) == 24
+    for tid, aa in g["ncbieaa"].items():
+        assert oracle.genetic_code(int(tid)) == aa, tid
+    for v in g["vectors"]:
+        assert oracle.translate(v["nt"], v["table"], v["frame"], v["trim"], v["clean"]) == v["aa"], (v["table"], v["frame"])
+    with pytest.raises(ValueError):
+        oracle.translate("ACGTACGT", 7, 1)
+    with pytest.raises(ValueError):
+        oracle.translate("ACGTACGT", 1, 0)
+    with pytest.raises(ValueError):
+        oracle.translate("AC", 1, 1)
+
+
+def test_translation_quirks_of_the_reference(oracle):
+    # ambiguity letters resolve only when every base they stand for agrees (codon_tables.go:350-427)
+    assert oracle.translate("GCNACNCTNRAYAARTTYCGNMGN", 1, 1) == "ATLXKFRX"   # RAY = N|D -> X ; MGN = CGN (R) | AGN (R|S) -> X
+    assert oracle.translate("ATGRAYTGGNNNGCN---TAA", 1, 1) == "MXWXA-*"   # "---" -> '-' (codon_tables.go:167)
+    assert oracle.translate("AT-ATGA*A", 1, 1) == "XMX"                     # gap letters have the empty set -> X
+    assert oracle.translate("ATGJJJTAA", 1, 1) == "MX*"                     # a letter outside base2code -> X (allowUnknownCodon)
+    assert oracle.translate("augUAA", 1, 1) == "M*"                         # RNA, lower case
+    # minus frames complement acgtACGT only (DNA.PairLetter, alphabet.go:353-359): 'R' stays 'R', 'U' stays 'U'
+    assert oracle.translate("TTACAT", 1, -1) == "M*"
+    assert oracle.translate("YTACAT", 1, -1) == "MY"    # a true complement (R) would read TAR = stop; the kept Y reads TAY = Y
+    assert oracle.translate("UUACAU", 1, -1) == "LF"    # U is kept: codons "UTG" (= TTG, L) and "TUU" (= TTT, F), not M*
+    # length of a translation: floor((L - f + 1) / 3) for frame f, same for -f
+    for L in range(3, 40):
+        for f in (1, 2, 3):
+            s = "ACG" * 14
+            assert len(oracle.translate(s[:L], 1, f)) == (L - f + 1) // 3 == len(oracle.translate(s[:L], 1, -f))
+
+
+def test_protein_paths_on_nucleotides_check_the_input_length(oracle):
+    k, w = 4, 3
+    dna = "ATGGCCATTGTAATGGGCCGCTGAAAGGGTGCCCGATAG"
+    aa = oracle.translate(dna, 1, 1)
+    # k-mer hashes of the translation are the protein iterator's output
+    assert np.array_equal(oracle.protein_hashes_nt(dna, k, 1, 1), np.array([oracle.wyhash(aa[i:i + k].encode()) for i in range(len(aa) - k + 1)], np.uint64))
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.protein_hashes_nt(dna[:3 * k - 1], k, 1, 1)       # iterator-protein.go:50
+    assert e.value.name == "ErrShortSeq"
+    assert len(oracle.protein_hashes_nt(dna[:3 * k], k, 1, 2)) == 0   # 12 nt pass the check; frame 2 leaves 3 residues < k: nothing, no error
+    with pytest.raises(oracle.OracleError):
+        oracle.protein_minimizer_nt(dna[:3 * k + w - 2], k, w, 1, 1)    # sketch-protein.go:73
+    h, p, _ = oracle.protein_minimizer_nt(dna[:3 * k + w - 1], k, w, 1, 1)   # 14 nt -> 4 residues -> 1 k-mer < w: no window completes
+    assert len(h) == 0 and len(p) == 0
+    h, p, _ = oracle.protein_minimizer_nt(dna, k, w, 1, 1)
+    h2, p2, _ = oracle.protein_minimizer(aa + "A" * 20, k, w)             # same machine on protein input (length padded past 3k+w-1)
+    assert len(h) > 0 and np.array_equal(p, p2[:len(p)]) and np.array_equal(h, h2[:len(h)])
