@@ -87,6 +87,24 @@ int main() {
         auto sk = NewProteinMinimizerSketch(s, 9, 1, 1, 5, &err);
         CHECK(sk && err == 0);
     }
+    {  // TestProteinIterator iterator-protein_test.go:29-63 / TestProteinMinimizer sketch-protein_test.go:29-58: DNA input
+        const std::string dna = "AAGTTTGAATCATTCAACTATCTAGTTTTCAGAGAACAATGTTCTCTAAAGAATAGAAAAGAGTCATTGTGCGGTGATGATGGCGGGAAGGATCCACCTG";
+        Seq s{false, dna};
+        const int k = 10;
+        auto it = NewProteinIterator(s, k, 1, 1, &err);
+        CHECK(it && err == 0);
+        size_t n = 0;
+        uint64_t c;
+        while (it && it->Next(c)) ++n;
+        CHECK(n == dna.size() / 3 - k + 1);  // iterator-protein_test.go:59
+        auto sk = NewProteinMinimizerSketch(s, k, 1, 1, 3, &err);
+        CHECK(sk && err == 0);
+        size_t m = 0;
+        while (sk && sk->Next(c)) ++m;
+        CHECK(m >= 1 && m <= n);
+        Seq tiny{false, dna.substr(0, 3 * k - 1)};
+        CHECK(!NewProteinIterator(tiny, k, 1, 1, &err) && err == ErrShortSeq);  // iterator-protein.go:50
+    }
     std::printf(fails ? "FAILED %d checks\n" : "all C++ mirror checks passed\n", fails);
     return fails ? 1 : 0;
 }

@@ -218,3 +218,13 @@ def test_protein_paths_on_nucleotides_check_the_input_length(oracle):
     h, p, _ = oracle.protein_minimizer_nt(dna, k, w, 1, 1)
     h2, p2, _ = oracle.protein_minimizer(aa + "A" * 20, k, w)             # same machine on protein input (length padded past 3k+w-1)
     assert len(h) > 0 and np.array_equal(p, p2[:len(p)]) and np.array_equal(h, h2[:len(h)])
+
+
+def test_reference_protein_tests_feed_dna(oracle):
+    """TestProteinIterator (iterator-protein_test.go:29-63) and TestProteinMinimizer (sketch-protein_test.go:29-58) build
+    the iterators from a DNA Seq; the only assertion is the count len/3 - k + 1."""
+    dna = "AAGTTTGAATCATTCAACTATCTAGTTTTCAGAGAACAATGTTCTCTAAAGAATAGAAAAGAGTCATTGTGCGGTGATGATGGCGGGAAGGATCCACCTG"
+    k = 10
+    assert len(oracle.protein_hashes_nt(dna, k, 1, 1)) == len(dna) // 3 - k + 1
+    h, p, _ = oracle.protein_minimizer_nt(dna, k, 3, 1, 1)
+    assert 1 <= len(h) <= len(dna) // 3 - k + 1 and list(p) == sorted(set(int(x) for x in p))
