@@ -19,6 +19,7 @@
 #include "kernels_syncmer.hpp"
 #include "kernels_protein.hpp"
 #include "kernels_translate.hpp"
+#include "kernels_tile.hpp"
 
 using namespace bsk;
 
@@ -49,7 +50,11 @@ struct bsk_batch {
     u32 maxlen = 0;
     u32 uniform_len = 0;  // != 0: every read has this length (synthetic batches)
     u32 *words = nullptr;
-    u64 *desc = nullptr;
+    u64 *desc = nullptr;   // NULL when a sequence has 2^24 bases or more: fw + llen then locate the sequences (tiled runs only)
+    u64 *fw = nullptr;     // [n] first word
+    u64 *llen = nullptr;   // [n] bases
+    u64 *adesc = nullptr;  // tile batches over ASCII: (first_byte << 24) | n_bases per tile
+    bool alias = false;    // words / ascii belong to another batch (tile batches)
     u8 *rflags = nullptr;
     u8 *ascii = nullptr;  // DNA: kept only when some read has a non-ACGT byte; protein: always
     u64 *aoff = nullptr;
@@ -61,7 +66,8 @@ struct bsk_result {
     u64 n = 0, cap = 0, n_tuples = 0;
     u64 ovf_cap = 0;  // slab kernels: tuples reserved (inside cap) for units that outgrow their slab
     int kind = 0, has_pos = 0;
-    u64 *refs = nullptr;  // per read: (first_tuple << 24) | n_tuples
+    u64 *refs = nullptr;  // per read: (first_tuple << 24) | n_tuples ; NULL for wide results
+    u64 *wfirst = nullptr, *wcount = nullptr;  // wide results (tiled long sequences): first tuple and tuple count per sequence
     u8 *status = nullptr;
     u64 *hash = nullptr;
     u32 *pos = nullptr;
@@ -117,18 +123,17 @@ __global__ void k_synth_protein(u8 *ascii, u64 *aoff, u64 n, u32 len, u64 seed) 
 }
 // ASCII -> 2-bit words.  One thread per output word; the owning read is found by a
 // binary search over desc[] (first_word is monotone).  Not on the hot path.
-__global__ void k_pack(const u8 *ascii, const u64 *aoff, const u64 *desc, u64 n, u64 n_words, u32 *words, u8 *rflags,
+__global__ void k_pack(const u8 *ascii, const u64 *aoff, const u64 *desc, const u64 *fw, u64 n, u64 n_words, u32 *words, u8 *rflags,
                        u32 *nonacgt_reads) {
     for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < n_words; g += (u64)gridDim.x * blockDim.x) {
         u64 lo = 0, hi = n - 1;  // largest r with first_word[r] <= g  (reads with 0 words share a first_word: take the last)
         while (lo < hi) {
             u64 mid = (lo + hi + 1) >> 1;
-            if ((desc[mid] >> 24) <= g) lo = mid;
+            if ((desc ? desc[mid] >> 24 : fw[mid]) <= g) lo = mid;
             else hi = mid - 1;
         }
-        const u64 d = desc[lo];
-        const u64 L = d & 0xffffffULL;
-        const u64 j = g - (d >> 24);
+        const u64 L = aoff[lo + 1] - aoff[lo];
+        const u64 j = g - (desc ? desc[lo] >> 24 : fw[lo]);
         const u8 *src = ascii + aoff[lo] + j * 16;
         const u64 nb = L > j * 16 ? (L - j * 16 < 16 ? L - j * 16 : 16) : 0;
         u32 v = 0;
@@ -186,10 +191,11 @@ __global__ void k_extend_ascii(const u8 *ascii, const u64 *aoff, const u64 *naof
 }
 
 // digest: checksum = sum over tuples of hash*(2*position+1); one thread per read walks its tuples
-__global__ void k_digest(const u64 *hash, const u32 *pos, const u64 *refs, u64 n, u64 *out /*[0] checksum [1] tuples*/) {
+__global__ void k_digest(const u64 *hash, const u32 *pos, const u64 *refs, const u64 *wfirst, const u64 *wcount, u64 n,
+                         u64 *out /*[0] checksum [1] tuples*/) {
     u64 s = 0, c = 0;
     for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) {
-        const u64 ref = refs[r], b = ref >> 24, cnt = ref & 0xffffffULL;
+        const u64 b = refs ? refs[r] >> 24 : wfirst[r], cnt = refs ? refs[r] & 0xffffffULL : wcount[r];
         for (u64 t = 0; t < cnt; ++t) s += hash[b + t] * (2ULL * (pos ? (u64)(pos[b + t] & BSK_POS_MASK) : t) + 1ULL);
         c += cnt;
     }
@@ -207,10 +213,11 @@ __global__ void k_sum_counts(const u64 *refs, u64 n, u64 *out) {
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 // fetch: pack the tuples of reads [first, first+count) densely (dst offsets computed on the host); one wave per read
-__global__ void k_gather(const u64 *hash, const u32 *pos, const u64 *refs, const u64 *dstoff, u64 count, u64 *ohash, u32 *opos) {
+__global__ void k_gather(const u64 *hash, const u32 *pos, const u64 *refs, const u64 *wfirst, const u64 *wcount, const u64 *dstoff,
+                         u64 count, u64 *ohash, u32 *opos) {
     const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
     for (u64 r = wave; r < count; r += nw) {
-        const u64 ref = refs[r], b = ref >> 24, cnt = ref & 0xffffffULL, d = dstoff[r];
+        const u64 b = refs ? refs[r] >> 24 : wfirst[r], cnt = refs ? refs[r] & 0xffffffULL : wcount[r], d = dstoff[r];
         for (u64 t = threadIdx.x & 63; t < cnt; t += 64) {
             if (ohash) ohash[d + t] = hash[b + t];
             if (opos) opos[d + t] = pos[b + t];
@@ -342,10 +349,15 @@ static int grid_for(bsk_ctx *ctx, u64 items, int block) {
 extern "C" void bsk_batch_destroy(bsk_batch *b) {
     if (!b) return;
     if (b->ctx) (void)hipSetDevice(b->ctx->device);
-    (void)hipFree(b->words);
+    if (!b->alias) {
+        (void)hipFree(b->words);
+        (void)hipFree(b->ascii);
+    }
     (void)hipFree(b->desc);
+    (void)hipFree(b->fw);
+    (void)hipFree(b->llen);
+    (void)hipFree(b->adesc);
     (void)hipFree(b->rflags);
-    (void)hipFree(b->ascii);
     (void)hipFree(b->aoff);
     delete b;
 }
@@ -372,9 +384,9 @@ extern "C" int bsk_batch_from_ascii(bsk_ctx *ctx, const uint8_t *bytes, const ui
             return fail_arg(ctx, "offsets not monotone");
         }
         u64 L = offsets[r + 1] - offsets[r];
-        if (L >= (1ULL << 24)) {
+        if (L >= (1ULL << 31) || (L >= (1ULL << 24) && alphabet != BSK_ALPHA_DNA)) {
             delete b;
-            ctx->err = "reads of 2^24 bases or more are not supported yet (tile long sequences on the host)";
+            ctx->err = "sequence too long (DNA: 2^31 bases, positions carry the strand in bit 31; protein: 2^24 residues)";
             return BSK_ERR_UNSUPPORTED;
         }
         maxlen = std::max<u32>(maxlen, (u32)L);
@@ -401,24 +413,30 @@ extern "C" int bsk_batch_from_ascii(bsk_ctx *ctx, const uint8_t *bytes, const ui
     }
     b->device_bytes = nbytes + 64 + (n + 1) * 8;
     if (alphabet == BSK_ALPHA_DNA) {
-        std::vector<u64> desc(n ? n : 1);
+        const bool wide = maxlen >= (1u << 24);  // desc cannot hold such a length: sequences are located by fw + llen
+        std::vector<u64> desc(n ? n : 1), llen(wide ? n : 0);
         u64 w = 0;
         for (u64 r = 0; r < n; ++r) {
             u64 L = offsets[r + 1] - offsets[r];
-            desc[r] = (w << 24) | L;
+            desc[r] = wide ? w : ((w << 24) | L);
+            if (wide) llen[r] = L;
             w += (L + 15) / 16;
         }
         b->n_words = w;
         const u64 alloc_words = w + pad_words(maxlen);
         BCHK(hipMalloc(&b->words, alloc_words * sizeof(u32)));
-        BCHK(hipMalloc(&b->desc, (n ? n : 1) * sizeof(u64)));
+        BCHK(hipMalloc(wide ? &b->fw : &b->desc, (n ? n : 1) * sizeof(u64)));
+        if (wide) {
+            BCHK(hipMalloc(&b->llen, n * sizeof(u64)));
+            BCHK(hipMemcpyAsync(b->llen, llen.data(), n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        }
         BCHK(hipMalloc(&b->rflags, n ? n : 1));
         BCHK(hipMemsetAsync(b->words, 0, alloc_words * sizeof(u32), ctx->stream));
         BCHK(hipMemsetAsync(b->rflags, 0, n ? n : 1, ctx->stream));
-        if (n) BCHK(hipMemcpyAsync(b->desc, desc.data(), n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        if (n) BCHK(hipMemcpyAsync(wide ? b->fw : b->desc, desc.data(), n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
         BCHK(hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream));
         if (n && w) {
-            hipLaunchKernelGGL(k_pack, dim3(grid_for(ctx, w, 256)), dim3(256), 0, ctx->stream, b->ascii, b->aoff, b->desc, n, w,
+            hipLaunchKernelGGL(k_pack, dim3(grid_for(ctx, w, 256)), dim3(256), 0, ctx->stream, b->ascii, b->aoff, b->desc, b->fw, n, w,
                                b->words, b->rflags, ctx->d_ticket);
             hipLaunchKernelGGL(k_count_flags, dim3(grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, b->rflags, n,
                                ctx->d_ticket + 1);
@@ -553,15 +571,24 @@ extern "C" int bsk_batch_fetch_ascii(bsk_ctx *ctx, const bsk_batch *b, uint64_t 
         for (u64 i = 0; i <= count; ++i) offsets[i] = ao[i] - ao[0];
         return BSK_OK;
     }
-    std::vector<u64> d(count);
-    HIPCHK(ctx, hipMemcpy(d.data(), b->desc + first, count * 8, hipMemcpyDeviceToHost));
-    const u64 w0 = d[0] >> 24;
-    const u64 w1 = (d[count - 1] >> 24) + ((d[count - 1] & 0xffffffULL) + 15) / 16;
+    std::vector<u64> d(count), fwv(count);
+    if (b->desc) {
+        HIPCHK(ctx, hipMemcpy(d.data(), b->desc + first, count * 8, hipMemcpyDeviceToHost));
+        for (u64 i = 0; i < count; ++i) {
+            fwv[i] = d[i] >> 24;
+            d[i] &= 0xffffffULL;
+        }
+    } else {
+        HIPCHK(ctx, hipMemcpy(fwv.data(), b->fw + first, count * 8, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(d.data(), b->llen + first, count * 8, hipMemcpyDeviceToHost));
+    }
+    const u64 w0 = fwv[0];
+    const u64 w1 = fwv[count - 1] + (d[count - 1] + 15) / 16;
     std::vector<u32> w(w1 - w0 + 1);
     if (w1 > w0) HIPCHK(ctx, hipMemcpy(w.data(), b->words + w0, (w1 - w0) * 4, hipMemcpyDeviceToHost));
     u64 o = 0;
     for (u64 i = 0; i < count; ++i) {
-        const u64 L = d[i] & 0xffffffULL, base = (d[i] >> 24) - w0;
+        const u64 L = d[i], base = fwv[i] - w0;
         if (o + L > bytes_cap) return fail_arg(ctx, "bsk_batch_fetch_ascii: bytes_cap too small");
         for (u64 p = 0; p < L; ++p) bytes[o + p] = "ACGT"[(w[base + (p >> 4)] >> ((p & 15) * 2)) & 3];
         o += L;
@@ -577,6 +604,8 @@ extern "C" void bsk_result_release(bsk_result *r) {
     if (!r) return;
     if (r->ctx) (void)hipSetDevice(r->ctx->device);
     (void)hipFree(r->refs);
+    (void)hipFree(r->wfirst);
+    (void)hipFree(r->wcount);
     (void)hipFree(r->status);
     (void)hipFree(r->hash);
     (void)hipFree(r->pos);
@@ -588,7 +617,7 @@ static bool kind_has_pos(int kind) { return kind == BSK_MINIMIZER || kind == BSK
 static int result_prepare(bsk_ctx *ctx, bsk_result **res, u64 n, int kind, u64 cap) {
     bsk_result *r = *res;
     const int hp = kind_has_pos(kind) ? 1 : 0;
-    if (r && (r->ctx != ctx || r->n != n || r->has_pos != hp)) {  // shape changed: start over
+    if (r && (r->ctx != ctx || r->n != n || r->has_pos != hp || !r->refs)) {  // shape changed: start over
         bsk_result_release(r);
         r = nullptr;
         *res = nullptr;
@@ -632,10 +661,17 @@ extern "C" int bsk_result_info(const bsk_result *r, uint64_t *n_reads, uint64_t 
 extern "C" int bsk_result_device(const bsk_result *r, const uint64_t **refs, const uint8_t **status, const uint64_t **hash,
                                  const uint32_t **pos) {
     if (!r) return BSK_ERR_ARG;
-    if (refs) *refs = (const uint64_t *)r->refs;
+    if (refs) *refs = (const uint64_t *)r->refs;  // NULL for wide results: bsk_result_device_wide
     if (status) *status = r->status;
     if (hash) *hash = (const uint64_t *)r->hash;
     if (pos) *pos = r->pos;
+    return BSK_OK;
+}
+
+extern "C" int bsk_result_device_wide(const bsk_result *r, const uint64_t **first, const uint64_t **count) {
+    if (!r) return BSK_ERR_ARG;
+    if (first) *first = (const uint64_t *)r->wfirst;
+    if (count) *count = (const uint64_t *)r->wcount;
     return BSK_OK;
 }
 
@@ -646,9 +682,9 @@ extern "C" int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t firs
     if (pos && !r->pos) return fail_arg(ctx, "bsk_result_fetch: this kind has implicit positions");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     std::vector<u64> refs(count ? count : 1);
-    if (count) HIPCHK(ctx, hipMemcpy(refs.data(), r->refs + first, count * 8, hipMemcpyDeviceToHost));
+    if (count) HIPCHK(ctx, hipMemcpy(refs.data(), (r->refs ? r->refs : r->wcount) + first, count * 8, hipMemcpyDeviceToHost));
     offsets[0] = 0;
-    for (u64 i = 0; i < count; ++i) offsets[i + 1] = offsets[i] + (refs[i] & 0xffffffULL);
+    for (u64 i = 0; i < count; ++i) offsets[i + 1] = offsets[i] + (r->refs ? (refs[i] & 0xffffffULL) : refs[i]);
     const u64 T = offsets[count];
     if (status && count) HIPCHK(ctx, hipMemcpy(status, r->status + first, count, hipMemcpyDeviceToHost));
     if (!hash && !pos) return BSK_OK;
@@ -662,8 +698,9 @@ extern "C" int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t firs
     if (e == hipSuccess && pos) e = hipMalloc(&d_p, T * 4);
     if (e == hipSuccess) e = hipMemcpyAsync(d_off, offsets, count * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_gather, dim3(grid_for(ctx, count * 64, 256)), dim3(256), 0, ctx->stream, r->hash, r->pos, r->refs + first,
-                           d_off, count, d_h, d_p);
+        hipLaunchKernelGGL(k_gather, dim3(grid_for(ctx, count * 64, 256)), dim3(256), 0, ctx->stream, r->hash, r->pos,
+                           r->refs ? r->refs + first : nullptr, r->refs ? nullptr : r->wfirst + first,
+                           r->refs ? nullptr : r->wcount + first, d_off, count, d_h, d_p);
         e = hipGetLastError();
     }
     if (e == hipSuccess && hash) e = hipMemcpyAsync(hash, d_h, T * 8, hipMemcpyDeviceToHost, ctx->stream);
@@ -682,8 +719,8 @@ extern "C" int bsk_result_digest(bsk_ctx *ctx, const bsk_result *r, uint64_t *ch
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, 8 * sizeof(u64), ctx->stream));
     if (r->n) {
-        hipLaunchKernelGGL(k_digest, dim3(grid_for(ctx, r->n, 256)), dim3(256), 0, ctx->stream, r->hash, r->pos, r->refs, r->n,
-                           ctx->d_total);
+        hipLaunchKernelGGL(k_digest, dim3(grid_for(ctx, r->n, 256)), dim3(256), 0, ctx->stream, r->hash, r->pos, r->refs, r->wfirst,
+                           r->wcount, r->n, ctx->d_total);
         hipLaunchKernelGGL(k_digest_status, dim3(grid_for(ctx, r->n, 256)), dim3(256), 0, ctx->stream, r->status, r->n,
                            ctx->d_total + 2);
     }
@@ -942,6 +979,10 @@ extern "C" int bsk_codon_lut(int table, uint8_t *lut, uint64_t lut_bytes) {
 // flagged (rflags) so that the protein kernels report them as ErrShortSeq -- the reference checks the INPUT length.
 static int translate_batch(bsk_ctx *ctx, const bsk_batch *b, int table, int frame, u64 need, bsk_batch **out) {
     *out = nullptr;
+    if (!b->desc) {
+        ctx->err = "translate: sequences of 2^24 bases or more are not supported";
+        return BSK_ERR_UNSUPPORTED;
+    }
     if (frame < -3 || frame > 3 || frame == 0) {
         ctx->err = "invalid frame (available: 1, 2, 3, -1, -2, -3)";  // seq/seq.go:694
         return BSK_ERR_ARG;
@@ -1041,6 +1082,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     a.desc = b->desc;
     a.ascii = b->ascii;
     a.aoff = b->aoff;
+    a.adesc = b->adesc;
     a.rflags = b->rflags;
     a.n = b->n;
     a.nunits = pl.nunits;
@@ -1128,37 +1170,18 @@ static u64 estimate_cap(const bsk_batch *b, const bsk_params *p, int circ_ext) {
 
 static int make_circular(bsk_ctx *ctx, const bsk_batch *b, int k, bsk_batch **out);
 
-static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, bsk_result **result, int warmup, int iters,
+// Plan, size, launch (and optionally time) the kernel of p->kind over a prepared batch.
+static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, int circ_ext, bsk_result **result, int warmup, int iters,
                        float *kernel_ms) {
-    if (!ctx || !batch || !p || !result) return fail_arg(ctx, "bsk_sketch: null argument");
-    if (batch->ctx != ctx) return fail_arg(ctx, "bsk_sketch: batch belongs to another context");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    int rc = validate(p, batch->alphabet);
-    if (rc != BSK_OK) {
-        ctx->err = bsk_err_name(rc);
-        return rc;
-    }
-    const bsk_batch *b = batch;
-    bsk_batch *tmp = nullptr;
-    int circ_ext = 0;
-    if (p->circular && p->k > 1 && batch->alphabet == BSK_ALPHA_DNA) {
-        rc = make_circular(ctx, batch, p->k, &tmp);
-        if (rc != BSK_OK) return rc;
-        b = tmp;
-        circ_ext = p->k - 1;
-    }
-    if (batch->alphabet == BSK_ALPHA_DNA && (p->kind == BSK_PROT_HASH || p->kind == BSK_PROT_MINIMIZER)) {
-        // iterator-protein.go:50,62-67 / sketch-protein.go:66-75,83-88: length checks on the nucleotides, then Translate
-        const u64 need = (u64)p->k * 3 + (p->kind == BSK_PROT_MINIMIZER ? (u64)p->w - 1 : 0);
-        rc = translate_batch(ctx, batch, p->codon_table, p->frame, need, &tmp);
-        if (rc != BSK_OK) return rc;
-        b = tmp;
+    int rc = BSK_OK;
+    if (!b->desc && b->alphabet == BSK_ALPHA_DNA) {
+        ctx->err = "sequences of 2^24 bases or more are only supported by the kinds that tile (not: two-strand k-mer codes, s == k syncmers)";
+        return BSK_ERR_UNSUPPORTED;
     }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     auto cleanup = [&](int code) {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
-        if (tmp) bsk_batch_destroy(tmp);
         return code;
     };
     Plan pl;
@@ -1244,6 +1267,238 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
     return cleanup(BSK_OK);
 }
 
+// ------------------------------------------------------------------------------------
+// long sequences: tile, run the ordinary kernels over the tiles, stitch (kernels_tile.hpp)
+// ------------------------------------------------------------------------------------
+static u32 env_u32(const char *name, u32 dflt) {
+    const char *v = getenv(name);
+    return v && *v ? (u32)strtoul(v, nullptr, 10) : dflt;
+}
+
+static bool kind_tiles(const bsk_params *p) {
+    switch (p->kind) {
+        case BSK_NTHASH:
+        case BSK_SIMHASH:
+        case BSK_MINIMIZER: return true;
+        case BSK_KMER: return p->canonical != 0;  // the two-strand mode walks the reverse strand backwards (iterator.go:713-723)
+        case BSK_SYNCMER: return p->s < p->k;     // s == k emits every k-mer with its own end rule (sketch.go:328-331)
+        default: return false;
+    }
+}
+
+// positions one tile owns: about 22 tuples per tile (the kernels stage 32 per lane; 16 for syncmers), a multiple of 16
+static u32 tile_positions(const bsk_params *p) {
+    u32 tp;
+    if (p->kind == BSK_MINIMIZER) tp = 16u * std::max<u32>(2, (u32)(22.0 * (p->w + 1.0) / 2.0 / 16.0));
+    else if (p->kind == BSK_SYNCMER) tp = 16u * std::max<u32>(2, (u32)(11.0 * (p->k - p->s + 1.0) / 2.0 / 16.0));
+    else tp = 256;
+    tp = std::min<u32>(tp, 8192);
+    const u32 forced = env_u32("BSK_TILE_POS", 0);  // tests: exercise the tile seams
+    if (forced) tp = std::max<u32>(16, (forced + 15) & ~15u);
+    return tp;
+}
+
+static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, int circ_ext, bsk_result **result, int warmup, int iters,
+                        float *kernel_ms) {
+    const u64 n = b->n;
+    TileGeo geo;
+    geo.kind = p->kind;
+    geo.k = p->k;
+    geo.w = p->kind == BSK_SYNCMER ? p->k - p->s : p->w;
+    geo.s = p->s;
+    geo.tp = tile_positions(p);
+    geo.circ_ext = circ_ext;
+    const bool stream = !kind_has_pos(p->kind);
+    SeqTab seq{b->desc, b->fw, b->llen, b->aoff, n};
+    u64 *tstart = nullptr, *oexcl = nullptr, *sbad = nullptr;
+    u32 *sflags = nullptr;
+    TileTab tt{nullptr, nullptr, nullptr, nullptr, nullptr};
+    bsk_batch *tb = nullptr;
+    bsk_result *tres = nullptr, *fin = nullptr;
+    auto done = [&](int code) {
+        (void)hipFree(tstart);
+        (void)hipFree(oexcl);
+        (void)hipFree(sbad);
+        (void)hipFree(sflags);
+        (void)hipFree(tt.seq);
+        (void)hipFree(tt.shift);
+        (void)hipFree(tt.keep);
+        if (tb) bsk_batch_destroy(tb);  // owns tt.desc / tt.adesc
+        else {
+            (void)hipFree(tt.desc);
+            (void)hipFree(tt.adesc);
+        }
+        if (tres) bsk_result_release(tres);
+        if (code != BSK_OK && fin) bsk_result_release(fin);
+        return code;
+    };
+#define TCHK(call)                                                  \
+    do {                                                            \
+        hipError_t e__ = (call);                                    \
+        if (e__ != hipSuccess) return done(fail_hip(ctx, e__, #call)); \
+    } while (0)
+    if (*result) {  // a tiled result is rebuilt from scratch
+        bsk_result_release(*result);
+        *result = nullptr;
+    }
+    // 1. tiles per sequence -> first tile of every sequence
+    const u32 nunits = (u32)((n + 63) / 64);
+    int rc = ensure_scratch(ctx, std::max<u32>(nunits, 1), 0);
+    if (rc != BSK_OK) return done(rc);
+    TCHK(hipMalloc(&tstart, (n + 1) * 8));
+    TCHK(hipMemsetAsync(tstart, 0, (n + 1) * 8, ctx->stream));
+    u64 nt = 0;
+    if (n) {
+        TCHK(hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream));
+        TCHK(hipMemsetAsync(ctx->d_lookback, 0, (size_t)nunits * 8, ctx->stream));
+        TileArgs ta{seq, geo, nunits, tstart, ctx->d_ticket, ctx->d_lookback};
+        hipLaunchKernelGGL(k_tile_count, dim3(std::min<u32>(nunits, (u32)ctx->cus * 8)), dim3(64), 0, ctx->stream, ta);
+        TCHK(hipGetLastError());
+        TCHK(hipMemcpyAsync(ctx->h_pinned, tstart + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+        TCHK(hipStreamSynchronize(ctx->stream));
+        nt = ctx->h_pinned[0];
+    }
+    // 2. tile table + a batch whose "reads" are the tiles (aliases the words / bytes of b)
+    const bool use_ascii = b->n_nonacgt > 0;
+    const size_t nta = nt ? nt : 1;
+    TCHK(hipMalloc(&tt.desc, nta * 8));
+    if (use_ascii) TCHK(hipMalloc(&tt.adesc, nta * 8));
+    TCHK(hipMalloc(&tt.seq, nta * 4));
+    TCHK(hipMalloc(&tt.shift, nta * 8));
+    TCHK(hipMalloc(&tt.keep, nta * 8));
+    if (nt) {
+        hipLaunchKernelGGL(k_tile_build, dim3(grid_for(ctx, nt, 256)), dim3(256), 0, ctx->stream, seq, geo, tstart, nt, tt);
+        TCHK(hipGetLastError());
+    }
+    tb = new (std::nothrow) bsk_batch();
+    if (!tb) return done(BSK_ERR_NOMEM);
+    tb->ctx = ctx;
+    tb->alphabet = BSK_ALPHA_DNA;
+    tb->alias = true;
+    tb->n = nt;
+    tb->words = b->words;
+    tb->ascii = b->ascii;
+    tb->desc = tt.desc;
+    tb->adesc = tt.adesc;
+    tb->n_nonacgt = b->n_nonacgt;
+    const u64 over = p->kind == BSK_MINIMIZER ? 2ULL * p->w + p->k + 16 : p->kind == BSK_SYNCMER ? 3ULL * p->k + 16 : (u64)p->k;
+    tb->maxlen = (u32)std::min<u64>((u64)geo.tp + over, (u64)b->maxlen);
+    tb->n_bases = nt * tb->maxlen;  // upper bound: sizes the first capacity guess
+    tb->n_words = b->n_words;
+    bsk_params p2 = *p;
+    p2.circular = 0;
+    // 3. the ordinary kernels over the tiles
+    rc = run_planned(ctx, tb, &p2, 0, &tres, warmup, iters, kernel_ms);
+    if (rc != BSK_OK) return done(rc);
+    // 4. per-sequence flags
+    TCHK(hipMalloc(&sflags, (n ? n : 1) * 4));
+    TCHK(hipMalloc(&sbad, (n ? n : 1) * 8));
+    TCHK(hipMemsetAsync(sflags, 0, (n ? n : 1) * 4, ctx->stream));
+    TCHK(hipMemsetAsync(sbad, 0xff, (n ? n : 1) * 8, ctx->stream));
+    if (nt) {
+        hipLaunchKernelGGL(k_tile_flags, dim3(grid_for(ctx, nt, 256)), dim3(256), 0, ctx->stream, tres->status, tt.seq, tstart, nt, sflags,
+                           sbad);
+        TCHK(hipGetLastError());
+    }
+    // 5. the final, per-sequence result
+    fin = new (std::nothrow) bsk_result();
+    if (!fin) return done(BSK_ERR_NOMEM);
+    fin->ctx = ctx;
+    fin->n = n;
+    fin->kind = p->kind;
+    fin->has_pos = stream ? 0 : 1;
+    TCHK(hipMalloc(&fin->status, n ? n : 1));
+    TCHK(hipMalloc(&fin->wfirst, (n ? n : 1) * 8));
+    TCHK(hipMalloc(&fin->wcount, (n ? n : 1) * 8));
+    if (stream) {  // the tile runs are adjacent: the tile result's value array IS the sequence result
+        fin->hash = tres->hash;
+        fin->cap = tres->cap;
+        tres->hash = nullptr;
+        tres->cap = 0;
+    } else {
+        const u64 cap = tres->n_tuples + 64;  // the stitch keeps a subset of the tile tuples
+        TCHK(hipMalloc(&fin->hash, cap * 8));
+        TCHK(hipMalloc(&fin->pos, cap * 4));
+        fin->cap = cap;
+        TCHK(hipMalloc(&oexcl, (nt + 1) * 8));
+        TCHK(hipMemsetAsync(oexcl, 0, (nt + 1) * 8, ctx->stream));
+        if (nt) {
+            const u32 tunits = (u32)((nt + 63) / 64);
+            rc = ensure_scratch(ctx, tunits, 0);
+            if (rc != BSK_OK) return done(rc);
+            TCHK(hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream));
+            TCHK(hipMemsetAsync(ctx->d_lookback, 0, (size_t)tunits * 8, ctx->stream));
+            StitchArgs sa;
+            sa.nt = nt;
+            sa.nunits = tunits;
+            sa.trefs = tres->refs;
+            sa.thash = tres->hash;
+            sa.tpos = tres->pos;
+            sa.shift = tt.shift;
+            sa.keep = tt.keep;
+            sa.oexcl = oexcl;
+            sa.ohash = fin->hash;
+            sa.opos = fin->pos;
+            sa.cap = cap;
+            sa.ticket = ctx->d_ticket;
+            sa.lookback = ctx->d_lookback;
+            hipLaunchKernelGGL(k_tile_stitch, dim3(std::min<u32>(tunits, (u32)ctx->cus * 8)), dim3(64), 0, ctx->stream, sa);
+            TCHK(hipGetLastError());
+        }
+    }
+    TCHK(hipMemsetAsync(ctx->d_total, 0, 2 * sizeof(u64), ctx->stream));
+    if (n) {
+        hipLaunchKernelGGL(k_tile_finish, dim3(grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, seq, geo, tstart, stream ? nullptr : oexcl,
+                           tres->refs, b->rflags, sflags, sbad, fin->wfirst, fin->wcount, fin->status, ctx->d_total);
+        TCHK(hipGetLastError());
+    }
+    TCHK(hipMemcpyAsync(ctx->h_pinned, ctx->d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    TCHK(hipMemcpyAsync(ctx->h_pinned + 2, ctx->d_ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+    TCHK(hipStreamSynchronize(ctx->stream));
+    if (!stream && nt && ((u32 *)(ctx->h_pinned + 2))[1]) {
+        ctx->err = "tile stitch overflow";
+        return done(BSK_ERR_DEVICE);
+    }
+    fin->n_tuples = ctx->h_pinned[0];
+#undef TCHK
+    *result = fin;
+    return done(BSK_OK);
+}
+
+static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, bsk_result **result, int warmup, int iters,
+                       float *kernel_ms) {
+    if (!ctx || !batch || !p || !result) return fail_arg(ctx, "bsk_sketch: null argument");
+    if (batch->ctx != ctx) return fail_arg(ctx, "bsk_sketch: batch belongs to another context");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = validate(p, batch->alphabet);
+    if (rc != BSK_OK) {
+        ctx->err = bsk_err_name(rc);
+        return rc;
+    }
+    const bsk_batch *b = batch;
+    bsk_batch *tmp = nullptr;
+    int circ_ext = 0;
+    const bool prot_kind = p->kind == BSK_PROT_HASH || p->kind == BSK_PROT_MINIMIZER;
+    if (batch->alphabet == BSK_ALPHA_DNA && prot_kind) {
+        // iterator-protein.go:50,62-67 / sketch-protein.go:66-75,83-88: length checks on the nucleotides, then Translate
+        const u64 need = (u64)p->k * 3 + (p->kind == BSK_PROT_MINIMIZER ? (u64)p->w - 1 : 0);
+        rc = translate_batch(ctx, batch, p->codon_table, p->frame, need, &tmp);
+        if (rc != BSK_OK) return rc;
+        b = tmp;
+    } else if (p->circular && p->k > 1 && batch->alphabet == BSK_ALPHA_DNA) {
+        rc = make_circular(ctx, batch, p->k, &tmp);
+        if (rc != BSK_OK) return rc;
+        b = tmp;
+        circ_ext = p->k - 1;
+    }
+    const bool tiled = b->alphabet == BSK_ALPHA_DNA && kind_tiles(p) && !getenv("BSK_NO_TILES") &&
+                       (!b->desc || b->maxlen > env_u32("BSK_TILE_MIN", 4096));
+    rc = tiled ? sketch_tiled(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms)
+               : run_planned(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms);
+    if (tmp) bsk_batch_destroy(tmp);
+    return rc;
+}
+
 extern "C" int bsk_sketch(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, bsk_result **result) {
     return sketch_impl(ctx, batch, p, result, 0, 0, nullptr);
 }
@@ -1258,6 +1513,10 @@ extern "C" int bsk_sketch_timed(bsk_ctx *ctx, const bsk_batch *batch, const bsk_
 // (iterator.go:642-646, sketch.go:106-110,163-167).
 static int make_circular(bsk_ctx *ctx, const bsk_batch *b, int k, bsk_batch **out) {
     *out = nullptr;
+    if (!b->desc) {
+        ctx->err = "circular: sequences of 2^24 bases or more are not supported";
+        return BSK_ERR_UNSUPPORTED;
+    }
     const u64 n = b->n;
     std::vector<u64> desc(n ? n : 1), nd(n ? n : 1);
     if (n) HIPCHK(ctx, hipMemcpy(desc.data(), b->desc, n * 8, hipMemcpyDeviceToHost));

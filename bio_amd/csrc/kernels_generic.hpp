@@ -22,6 +22,7 @@ struct KArgs {
     const u64 *desc;    // (first_word << 24) | n_bases
     const u8 *ascii;    // ASCII DNA or protein residues
     const u64 *aoff;    // ascii offsets [n+1]
+    const u64 *adesc;   // tiles of long ASCII sequences: (first_byte << 24) | n_bases; replaces aoff when set
     const u8 *rflags;   // per-read input flags (BSK_ST_HAS_NON_ACGT) or NULL
     u64 n;
     u32 nunits;
@@ -45,6 +46,18 @@ struct KArgs {
     u64 ovf_base;   // slab kernels: first tuple index of the overflow region, and its size
     u64 ovf_cap;
 };
+
+// byte range of read r in the ASCII buffer
+__device__ __forceinline__ void ascii_span(const KArgs &a, u64 r, u64 &off, u64 &L) {
+    if (a.adesc) {
+        const u64 d = a.adesc[r];
+        off = d >> 24;
+        L = d & 0xffffffULL;
+    } else {
+        off = a.aoff[r];
+        L = a.aoff[r + 1] - off;
+    }
+}
 
 // X table: one 16-byte entry per (outgoing code 0..4, incoming code 0..3);
 //   .x/.y = rol(seedF[out], k) ^ seedF[in]          (forward strand update)
@@ -312,8 +325,7 @@ __global__ __launch_bounds__(64) void k_minimizer_generic(KArgs a) {
         u64 off = 0, L = 0;
         if (r < a.n) {
             if (ENC) {
-                off = a.aoff[r];
-                L = a.aoff[r + 1] - off;
+                ascii_span(a, r, off, L);
             } else {
                 u64 d = a.desc[r];
                 off = d >> 24;
@@ -388,8 +400,7 @@ __global__ __launch_bounds__(64) void k_nthash_stream(KArgs a) {
         u64 off = 0, L = 0;
         if (r < a.n) {
             if (ENC) {
-                off = a.aoff[r];
-                L = a.aoff[r + 1] - off;
+                ascii_span(a, r, off, L);
             } else {
                 u64 d = a.desc[r];
                 off = d >> 24;

@@ -302,8 +302,7 @@ __global__ __launch_bounds__(64) void k_kmer(KArgs a) {
         u64 off = 0, L = 0;
         if (r < a.n) {
             if (ENC) {
-                off = a.aoff[r];
-                L = a.aoff[r + 1] - off;
+                ascii_span(a, r, off, L);
             } else {
                 const u64 d = a.desc[r];
                 off = d >> 24;
@@ -394,8 +393,7 @@ __global__ __launch_bounds__(64) void k_simhash(KArgs a) {
         u64 off = 0, L = 0;
         if (r < a.n) {
             if (ENC) {
-                off = a.aoff[r];
-                L = a.aoff[r + 1] - off;
+                ascii_span(a, r, off, L);
             } else {
                 const u64 d = a.desc[r];
                 off = d >> 24;
@@ -581,8 +579,7 @@ __global__ __launch_bounds__(64) void k_syncmer(KArgs a) {
         u64 off = 0, L = 0;
         if (r < a.n) {
             if (ENC) {
-                off = a.aoff[r];
-                L = a.aoff[r + 1] - off;
+                ascii_span(a, r, off, L);
             } else {
                 const u64 d = a.desc[r];
                 off = d >> 24;

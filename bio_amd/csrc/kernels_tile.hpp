@@ -1,0 +1,224 @@
+// kernels_tile.hpp -- long sequences (contigs, chromosomes) as overlapping tiles.
+//
+// The sketch kernels give one sequence to one lane; that is the right shape for reads, not for a 100-Mbp chromosome.
+// A long sequence is therefore cut into tiles that the same kernels process as ordinary short "reads" of one batch
+// (zero copy: a tile is a descriptor into the sequence's 2-bit words / ASCII bytes), and a stitch pass turns the tile
+// results back into one result per sequence.  Exactness rests on the closed forms (note V):
+//   * stream kinds (ntHash, k-mer code, SimHash): value i depends on bases [i, i+k-1] only.  Tile j owns values
+//     [j*TP, (j+1)*TP) and reads TP+k-1 bases; TP is a multiple of 16, so tile starts are word aligned and the
+//     line-padded runs of consecutive tiles are adjacent in the output: no copy at all.
+//   * minimizer: the emitted tuples are the distinct values of p_j = leftmost argmin of window j, and p_j is in
+//     [j, j+w-1].  Tile j owns POSITIONS [P0,P1): it evaluates windows max(0,P0-w+1) .. min(P1-1, nwin-1), which is every
+//     window that can select a position of its range, and the stitch keeps the tuples whose position is in [P0,P1).
+//   * syncmer (s < k): the emitted positions are the distinct b(idx) <= end, with b(idx) in [idx, idx+w-1], w = k-s.
+//     Tile j evaluates idx = max(0,P0-w+1) .. P1-1; its own "end" rule drops b > P1-1, which belong to the next tile,
+//     and in the last tile P1-1 = end is the reference's bound (sketch.go:170,314).
+// A tile starts at a multiple of 16 bases (a0); positions are shifted back by a0 when stitching.
+#pragma once
+#include "biosketch.h"
+#include "device_common.hpp"
+
+namespace bsk {
+
+struct TileGeo {
+    int kind, k, w, s;  // w: minimizer window, or k - s for the syncmer
+    u32 tp;             // positions owned by one tile (multiple of 16)
+    int circ_ext;       // bases the circular copy appended (length checks look at L - circ_ext)
+};
+
+struct SeqTab {  // where the sequences of a DNA batch are: desc (reads shorter than 2^24) or fw + llen
+    const u64 *desc, *fw, *llen, *aoff;
+    u64 n;
+};
+__device__ __forceinline__ u64 seq_first_word(const SeqTab &t, u64 r) { return t.desc ? t.desc[r] >> 24 : t.fw[r]; }
+__device__ __forceinline__ u64 seq_len(const SeqTab &t, u64 r) { return t.desc ? t.desc[r] & 0xffffffULL : t.llen[r]; }
+
+// positions (values, or selectable k-mer starts) of a sequence of L bases; 0: the constructor returns ErrShortSeq
+__host__ __device__ __forceinline__ u64 tile_npos(const TileGeo &g, u64 L) {
+    if (L < (u64)g.circ_ext) return 0;
+    const u64 L0 = L - (u64)g.circ_ext;
+    switch (g.kind) {
+        case BSK_MINIMIZER: return (L0 + 1 >= (u64)g.k + (u64)g.w) ? L - (u64)g.k + 1 : 0;  // sketch.go:92
+        case BSK_SYNCMER: return (L0 + 1 + (u64)g.s >= 2ULL * g.k && L >= (u64)g.k) ? L + (u64)g.s + 2 - 2ULL * g.k : 0;  // sketch.go:149,170
+        default: return L0 >= (u64)g.k ? L - (u64)g.k + 1 : 0;  // iterator.go:619,672,128
+    }
+}
+__host__ __device__ __forceinline__ u64 tile_count(const TileGeo &g, u64 L) { return (tile_npos(g, L) + g.tp - 1) / g.tp; }
+
+struct TileArgs {
+    SeqTab seq;
+    TileGeo geo;
+    u32 nunits;       // ceil(n / 64)
+    u64 *tstart;      // [n+1] first tile of every sequence
+    u32 *ticket;
+    u64 *lookback;
+};
+
+// first tile of every sequence: exclusive prefix of the tile counts (one wavefront per 64 sequences + look-back)
+__global__ __launch_bounds__(64) void k_tile_count(TileArgs a) {
+    const int lane = lane_id();
+    for (;;) {
+        const u32 unit = next_ticket(a.ticket, lane);
+        if (unit >= a.nunits) break;
+        const u64 r = (u64)unit * 64 + lane;
+        const u64 c = r < a.seq.n ? tile_count(a.geo, seq_len(a.seq, r)) : 0;
+        const u64 incl = wave_incl_scan_u64(c, lane);
+        const u64 base = lookback_exclusive(a.lookback, unit, wave_bcast_u64(incl, 63), lane);
+        if (r < a.seq.n) a.tstart[r] = base + incl - c;
+        if (unit == a.nunits - 1 && lane == 63) a.tstart[a.seq.n] = base + incl;
+    }
+}
+
+struct TileTab {
+    u64 *desc;    // [nt] (first_word << 24) | n_bases         (2-bit kernels)
+    u64 *adesc;   // [nt] (first_byte << 24) | n_bases or NULL (ASCII kernels)
+    u32 *seq;     // [nt] owning sequence
+    u64 *shift;   // [nt] a0: tile-local position + a0 = position in the sequence
+    u64 *keep;    // [nt] lo | hi << 32: tile-local positions [lo, hi) belong to this tile
+};
+
+__global__ void k_tile_build(SeqTab seq, TileGeo g, const u64 *tstart, u64 nt, TileTab t) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += (u64)gridDim.x * blockDim.x) {
+        u64 lo = 0, hi = seq.n - 1;  // largest r with tstart[r] <= i (sequences without tiles share their successor's start)
+        while (lo < hi) {
+            const u64 mid = (lo + hi + 1) >> 1;
+            if (tstart[mid] <= i) lo = mid;
+            else hi = mid - 1;
+        }
+        const u64 r = lo, L = seq_len(seq, r), np = tile_npos(g, L);
+        const u64 P0 = (i - tstart[r]) * g.tp, P1 = (P0 + g.tp < np) ? P0 + g.tp : np;
+        u64 a0, Lt;
+        if (g.kind == BSK_MINIMIZER) {
+            const u64 nwin = np - (u64)g.w + 1;
+            const u64 jlo = P0 + 1 > (u64)g.w ? P0 + 1 - (u64)g.w : 0;
+            const u64 jhi = P1 - 1 < nwin - 1 ? P1 - 1 : nwin - 1;
+            a0 = jlo & ~15ULL;
+            Lt = jhi + (u64)g.w + (u64)g.k - 1 - a0;
+        } else if (g.kind == BSK_SYNCMER) {
+            const u64 ilo = P0 + 1 > (u64)g.w ? P0 + 1 - (u64)g.w : 0;
+            a0 = ilo & ~15ULL;
+            Lt = (P1 - 1) + 2ULL * g.k - (u64)g.s - 1 - a0;
+        } else {
+            a0 = P0;
+            Lt = (P1 - P0) + (u64)g.k - 1;
+        }
+        t.desc[i] = ((seq_first_word(seq, r) + (a0 >> 4)) << 24) | Lt;
+        if (t.adesc) t.adesc[i] = ((seq.aoff[r] + a0) << 24) | Lt;
+        t.seq[i] = (u32)r;
+        t.shift[i] = a0;
+        t.keep[i] = (P0 - a0) | ((P1 - a0) << 32);
+    }
+}
+
+// per-tile flags -> per-sequence accumulators: first-window tie (first tile only), first tile that met an illegal base
+__global__ void k_tile_flags(const u8 *tstatus, const u32 *tseq, const u64 *tstart, u64 nt, u32 *sflags, u64 *sbad) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += (u64)gridDim.x * blockDim.x) {
+        const u8 st = tstatus[i];
+        const u32 r = tseq[i];
+        if ((st & BSK_ST_FIRST_WINDOW_TIE) && tstart[r] == i) atomicOr(&sflags[r], (u32)BSK_ST_FIRST_WINDOW_TIE);
+        if ((st & BSK_ST_CODE_MASK) == BSK_ST_ILLEGAL) atomicMin((unsigned long long *)&sbad[r], (unsigned long long)i);
+    }
+}
+
+struct StitchArgs {
+    u64 nt;
+    u32 nunits;          // ceil(nt / 64)
+    const u64 *trefs;    // tile results
+    const u64 *thash;
+    const u32 *tpos;
+    const u64 *shift, *keep;
+    u64 *oexcl;          // [nt+1] first output tuple of every tile
+    u64 *ohash;          // stitched tuples
+    u32 *opos;
+    u64 cap;             // capacity of ohash / opos
+    u32 *ticket;         // [1] = overflow flag
+    u64 *lookback;
+};
+
+// minimizer / syncmer: keep the tuples a tile owns, shift their positions, pack them in tile order
+__global__ __launch_bounds__(64) void k_tile_stitch(StitchArgs a) {
+    __shared__ u64 s_src[64], s_dst[64], s_shift[64];
+    __shared__ u32 s_cnt[64];
+    const int lane = lane_id();
+    for (;;) {
+        const u32 unit = next_ticket(a.ticket, lane);
+        if (unit >= a.nunits) break;
+        const u64 t = (u64)unit * 64 + lane;
+        u64 src = 0, sh = 0;
+        u32 kept = 0;
+        if (t < a.nt) {
+            const u64 ref = a.trefs[t], b = ref >> 24, cnt = ref & 0xffffffULL, kp = a.keep[t];
+            const u32 lo = (u32)kp, hi = (u32)(kp >> 32);
+            u64 s = 0, e = 0;  // positions ascend inside a tile: the owned tuples are one run [s, e)
+            for (u64 i = 0; i < cnt; ++i) {
+                const u32 p = a.tpos[b + i] & BSK_POS_MASK;
+                s += p < lo;
+                e += p < hi;
+            }
+            src = b + s;
+            kept = (u32)(e - s);
+            sh = a.shift[t];
+        }
+        const u64 incl = wave_incl_scan_u64((u64)kept, lane);
+        const u64 base = lookback_exclusive(a.lookback, unit, wave_bcast_u64(incl, 63), lane);
+        const u64 dst = base + incl - kept;
+        if (t < a.nt) a.oexcl[t] = dst;
+        if (unit == a.nunits - 1 && lane == 63) a.oexcl[a.nt] = base + incl;
+        const bool ovf = base + wave_bcast_u64(incl, 63) > a.cap;
+        if (ovf) {
+            if (lane == 0) atomicOr(&a.ticket[1], 1u);
+            continue;
+        }
+        s_src[lane] = src;
+        s_dst[lane] = dst;
+        s_shift[lane] = sh;
+        s_cnt[lane] = kept;
+        wave_sync_lds();
+        for (int q = 0; q < 64; ++q) {
+            const u32 c = s_cnt[q];
+            const u64 sb = s_src[q], db = s_dst[q], shq = s_shift[q];
+            for (u32 i = (u32)lane; i < c; i += 64) {
+                a.ohash[db + i] = a.thash[sb + i];
+                const u32 p = a.tpos[sb + i];
+                a.opos[db + i] = (p & BSK_POS_STRAND_BIT) | (u32)((p & BSK_POS_MASK) + shq);
+            }
+        }
+        wave_sync_lds();
+    }
+}
+
+// per sequence: first tuple, tuple count, status.  stream = 1: the tile runs already are the sequence's run.
+__global__ void k_tile_finish(SeqTab seq, TileGeo g, const u64 *tstart, const u64 *oexcl /*stitched kinds*/, const u64 *trefs /*stream kinds*/,
+                              const u8 *rflags, const u32 *sflags, const u64 *sbad, u64 *wfirst, u64 *wcount, u8 *status, u64 *total) {
+    u64 sum = 0;
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < seq.n; r += (u64)gridDim.x * blockDim.x) {
+        const u64 t0 = tstart[r], t1 = tstart[r + 1];
+        u64 first = 0, cnt = 0;
+        u8 st = BSK_ST_SHORT;
+        if (t1 > t0) {
+            st = BSK_ST_OK;
+            if (oexcl) {
+                first = oexcl[t0];
+                cnt = oexcl[t1] - first;
+            } else {
+                first = trefs[t0] >> 24;
+                cnt = tile_npos(g, seq_len(seq, r));
+                const u64 bad = sbad[r];
+                if (bad != ~0ULL) {  // NextKmer stopped at the first k-mer with an illegal base (iterator.go:746)
+                    cnt = (bad - t0) * g.tp + (trefs[bad] & 0xffffffULL);
+                    st = BSK_ST_ILLEGAL;
+                }
+            }
+            st |= (u8)sflags[r];
+            if (rflags) st |= rflags[r];
+        }
+        wfirst[r] = first;
+        wcount[r] = cnt;
+        status[r] = st;
+        sum += cnt;
+    }
+    sum = wave_sum_u64(sum);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd((unsigned long long *)total, (unsigned long long)sum);
+}
+
+}  // namespace bsk

@@ -184,9 +184,17 @@ int bsk_result_info(const bsk_result *r, uint64_t *n_reads, uint64_t *n_tuples, 
 int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t first, uint64_t count,
                      uint64_t *offsets, uint8_t *status, uint64_t *hash, uint32_t *pos,
                      uint64_t tuple_cap);
-/* Device pointers (valid until release / next bsk_sketch on this result); refs[] as described above. */
+/* Device pointers (valid until release / next bsk_sketch on this result); refs[] as described above.
+ * Long sequences: when a DNA batch holds a sequence longer than the tile threshold (4096 bases; always from 2^24
+ * bases on) the engine cuts the sequences into overlapping tiles, runs the same kernels over the tiles and stitches
+ * the tile results back (exactly the tuples of the un-tiled iterator).  Such a result is
+ * "wide": a sequence can own more than 2^24 tuples, so *refs is NULL and bsk_result_device_wide returns
+ * first[n] / count[n] instead (u64 each).  bsk_result_fetch / bsk_result_digest work for both layouts.
+ * Not tiled (sequences of 2^24 bases or more are refused with BSK_ERR_UNSUPPORTED): the two-strand k-mer mode
+ * (KMER with canonical = 0), syncmers with s == k, circular = 1, translation. */
 int bsk_result_device(const bsk_result *r, const uint64_t **refs, const uint8_t **status,
                       const uint64_t **hash, const uint32_t **pos);
+int bsk_result_device_wide(const bsk_result *r, const uint64_t **first, const uint64_t **count);
 /* Order-independent digest computed on device over the whole result:
  *   checksum = sum over tuples of hash * (2*position + 1)   (mod 2^64)
  *   status_counts[k] = number of reads whose status byte has bit pattern k set, for

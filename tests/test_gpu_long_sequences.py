@@ -1,0 +1,218 @@
+"""Long sequences: tiled runs must reproduce the un-tiled iterator exactly (kernels_tile.hpp).
+
+BSK_TILE_MIN / BSK_TILE_POS (read by the library at every call) shrink the tile threshold and the tile size so that
+ordinary test sequences cross many tile seams, for every kind that tiles; then genuinely long sequences, including
+one above 2^24 bases, run with the defaults.
+"""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from bio_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_seq(rng, n, alpha="ACGT"):
+    return "".join(rng.choice(alpha) for _ in range(n))
+
+
+@pytest.fixture
+def tiny_tiles():
+    saved = {k: os.environ.get(k) for k in ("BSK_TILE_MIN", "BSK_TILE_POS")}
+
+    def set_(tile_min, tile_pos):
+        os.environ["BSK_TILE_MIN"] = str(tile_min)
+        if tile_pos:
+            os.environ["BSK_TILE_POS"] = str(tile_pos)
+        else:
+            os.environ.pop("BSK_TILE_POS", None)
+
+    yield set_
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def seq_set(rng, alpha, k_hint):
+    lens = [1, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 100, 127, 128, 129, 150, 255, 256, 257, 300, 511, 512, 513, 777, 1023, 1024, 1025,
+            2000, 3333, k_hint - 1, k_hint, k_hint + 1, 2 * k_hint, 2 * k_hint + 1]
+    seqs = [rand_seq(rng, n, alpha) for n in lens if n > 0] + [rand_seq(rng, rng.randint(1, 2500), alpha) for _ in range(60)]
+    seqs += ["", "A" * 700, "AC" * 400, "ACGTTGCAACGT" * 70]  # ties everywhere: leftmost-wins must survive the seams
+    return seqs
+
+
+def check_sketch(engine, oracle, seqs, kind, fn, **pk):
+    b = engine.batch(seqs)
+    res = engine.run(b, engine.params(kind, **pk))
+    for i, q in enumerate(seqs):
+        st, h, p = res.read(i)
+        try:
+            eh, ep, es, fl = fn(q)
+        except oracle.OracleError as e:
+            assert e.name == "ErrShortSeq" and (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0, (i, len(q), e.name, st)
+            continue
+        assert (st & L.ST_CODE_MASK) == L.ST_OK, (i, len(q), st)
+        assert len(h) == len(eh), (i, len(q), len(h), len(eh))
+        assert np.array_equal(h, eh), (i, len(q))
+        assert np.array_equal(p & L.POS_MASK, ep) and np.array_equal(p >> 31, es), (i, len(q))
+        assert (st & 0xF0) == fl, (i, len(q), st, fl)
+    res.close()
+    b.close()
+
+
+@pytest.mark.parametrize("tile_pos", [16, 48, 0])
+@pytest.mark.parametrize("k,w", [(21, 11), (31, 15), (5, 3), (7, 1), (21, 7), (64, 33), (15, 4)])
+def test_minimizer_tiled(engine, oracle, tiny_tiles, k, w, tile_pos):
+    tiny_tiles(40, tile_pos)
+    rng = random.Random(k * 100 + w + tile_pos)
+    for alpha in ("ACGT", "ACGTN"):
+        seqs = seq_set(rng, alpha, k + w - 1)
+        check_sketch(engine, oracle, seqs, L.MINIMIZER, lambda q: oracle.minimizer(q, k, w, False, closed=True), k=k, w=w)
+
+
+@pytest.mark.parametrize("tile_pos", [16, 64, 0])
+@pytest.mark.parametrize("k,s", [(31, 11), (31, 16), (5, 2), (15, 14), (21, 1), (64, 33), (11, 6)])
+def test_syncmer_tiled(engine, oracle, tiny_tiles, k, s, tile_pos):
+    tiny_tiles(40, tile_pos)
+    rng = random.Random(k * 100 + s + tile_pos)
+    for alpha in ("ACGT", "ACGTRYN"):
+        seqs = seq_set(rng, alpha, 2 * k - s - 1)
+        check_sketch(engine, oracle, seqs, L.SYNCMER, lambda q: oracle.syncmer(q, k, s, False, closed=True), k=k, s=s)
+
+
+@pytest.mark.parametrize("tile_pos", [16, 0])
+def test_streams_tiled(engine, oracle, tiny_tiles, tile_pos):
+    tiny_tiles(40, tile_pos)
+    rng = random.Random(5 + tile_pos)
+    for alpha in ("ACGT", "ACGTNacgt"):
+        for k, canonical in ((21, True), (21, False), (5, True), (32, True), (300, True)):
+            seqs = seq_set(rng, alpha, k)
+            b = engine.batch(seqs)
+            rn = engine.run(b, engine.params(L.NTHASH, k, canonical=canonical))
+            for i, q in enumerate(seqs):
+                st, h, _ = rn.read(i)
+                try:
+                    e = oracle.nthash(q, k, canonical)[0]
+                except oracle.OracleError:
+                    assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0
+                    continue
+                assert np.array_equal(h, e), ("nthash", k, canonical, i, len(q))
+            rn.close()
+            if k <= 32 and canonical:
+                rk = engine.run(b, engine.params(L.KMER, k, canonical=True))
+                for i, q in enumerate(seqs):
+                    st, h, _ = rk.read(i)
+                    try:
+                        e = oracle.kmer_codes(q, k, True, False)
+                    except oracle.OracleError as err:
+                        assert err.name == "ErrShortSeq" and (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0
+                        continue
+                    assert np.array_equal(h, e), ("kmer", k, i, len(q))
+                rk.close()
+            b.close()
+    seqs = seq_set(rng, "ACGT", 21)[:40]
+    b = engine.batch(seqs)
+    rs = engine.run(b, engine.params(L.SIMHASH, 21, m=5, scale=5))
+    for i, q in enumerate(seqs):
+        st, h, _ = rs.read(i)
+        try:
+            e = oracle.simhash(q, 21, 5, 5, True)
+        except oracle.OracleError:
+            assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0
+            continue
+        assert np.array_equal(h, e), ("simhash", i, len(q))
+
+
+def test_kmer_illegal_base_stops_the_tiled_iterator_where_the_reference_stops(engine, oracle, tiny_tiles):
+    tiny_tiles(40, 16)
+    rng = random.Random(3)
+    k = 11
+    for badpos in (0, 5, 15, 16, 17, 40, 200, 777, 1499):
+        q = list(rand_seq(rng, 1500))
+        q[badpos] = "X"
+        q = "".join(q)
+        b = engine.batch([q, rand_seq(rng, 900)])
+        res = engine.run(b, engine.params(L.KMER, k, canonical=True))
+        st, h, _ = res.read(0)
+        good = max(0, badpos - k + 1)
+        assert (st & L.ST_CODE_MASK) == L.ST_ILLEGAL and len(h) == good, (badpos, st, len(h), good)
+        if good:
+            assert np.array_equal(h, oracle.kmer_codes(q[:badpos], k, True, False)[:good])
+        st1, h1, _ = res.read(1)
+        assert (st1 & L.ST_CODE_MASK) == L.ST_OK and len(h1) == 900 - k + 1
+
+
+def test_circular_long_and_refusals(engine, oracle, tiny_tiles):
+    tiny_tiles(40, 32)
+    rng = random.Random(8)
+    seqs = [rand_seq(rng, n) for n in (50, 333, 1000, 2049)]
+    check_sketch(engine, oracle, seqs, L.MINIMIZER, lambda q: oracle.minimizer(q, 11, 5, True, closed=True), k=11, w=5, circular=True)
+    b = engine.batch(seqs)
+    rn = engine.run(b, engine.params(L.NTHASH, 9, circular=True))
+    for i, q in enumerate(seqs):
+        _, h, _ = rn.read(i)
+        assert np.array_equal(h, oracle.nthash(q, 9, True, True)[0])
+
+
+def test_long_sequences_with_default_tiles(engine, oracle):
+    """1 Mbp (BASELINE configs[0]) and mixed contig lengths with the default tile size."""
+    rng = np.random.default_rng(11)
+    lens = [1_000_000, 5000, 4097, 4096, 150, 123_457, 20]
+    seqs = ["".join(np.array(list("ACGT"))[rng.integers(0, 4, n)]) for n in lens]
+    seqs[5] = seqs[5][:60_000] + "N" * 100 + seqs[5][60_100:]  # a gap: the whole batch runs on the ASCII kernels
+    for batch_seqs in (seqs[:5], seqs):
+        b = engine.batch(batch_seqs)
+        rn = engine.run(b, engine.params(L.NTHASH, 21))
+        rm = engine.run(b, engine.params(L.MINIMIZER, 21, w=11))
+        rs = engine.run(b, engine.params(L.SYNCMER, 31, s=11))
+        for i, q in enumerate(batch_seqs):
+            st, h, _ = rn.read(i)
+            if len(q) < 21:
+                assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0
+            else:
+                assert np.array_equal(h, oracle.nthash(q, 21, True)[0]), ("nthash", i)
+            st, h, p = rm.read(i)
+            try:
+                eh, ep, es, fl = oracle.minimizer(q, 21, 11, False, closed=True)
+            except oracle.OracleError:
+                assert (st & L.ST_CODE_MASK) == L.ST_SHORT
+            else:
+                assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep) and np.array_equal(p >> 31, es), ("min", i)
+            st, h, p = rs.read(i)
+            try:
+                eh, ep, es, fl = oracle.syncmer(q, 31, 11, False, closed=True)
+            except oracle.OracleError:
+                assert (st & L.ST_CODE_MASK) == L.ST_SHORT
+            else:
+                assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep), ("syn", i)
+        assert rm.digest()["n_tuples"] == rm.info()["n_tuples"]
+        b.close()
+
+
+def test_sequence_longer_than_2_pow_24(engine, oracle):
+    n = (1 << 24) + 12345
+    rng = np.random.default_rng(2)
+    big = np.array(list(b"ACGT"), np.uint8)[rng.integers(0, 4, n)]
+    small = np.frombuffer(b"ACGTTGCATGCATGCAAACCGGTTACGT", np.uint8)
+    data = np.concatenate([small, big, small])
+    offs = np.array([0, len(small), len(small) + n, len(small) * 2 + n], np.uint64)
+    b = engine.batch_from_arrays(data, offs)
+    q = big.tobytes().decode()
+    rm = engine.run(b, engine.params(L.MINIMIZER, 21, w=11))
+    st, h, p = rm.read(1)
+    eh, ep, es, fl = oracle.minimizer(q, 21, 11, False, closed=True)
+    assert len(h) == len(eh) and np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep) and np.array_equal(p >> 31, es)
+    assert rm.info()["n_tuples"] == len(eh)  # the 28-base neighbours are too short for k = 21, w = 11
+    rn = engine.run(b, engine.params(L.NTHASH, 31))
+    st, h, _ = rn.read(1)
+    assert len(h) == n - 30 and np.array_equal(h, oracle.nthash(q, 31, True)[0])
+    from bio_amd import sketches as S
+    with pytest.raises(S.DeviceError, match="2\\^24"):
+        engine.run(b, engine.params(L.KMER, 21, canonical=False))
+    with pytest.raises(S.DeviceError):
+        engine.run(b, engine.params(L.NTHASH, 21, circular=True))
