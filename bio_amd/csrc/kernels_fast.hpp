@@ -357,12 +357,32 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
     build_xtab(reinterpret_cast<uint4 *>(lds), a.k, lane);
     __syncthreads();
     const int k = a.k;
-    for (u32 unit = next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; unit < a.nunits; ++unit, ({
-             if (unit == uend) {
-                 unit = next_ticket(a.ticket, lane) * 8u;
-                 uend = unit + 8u;
-             }
-         })) {
+    __shared__ u64 s_base[8];
+    for (;;) {
+      const u32 u0 = next_ticket(a.ticket, lane) * 8u;
+      if (u0 >= a.nunits) break;
+      const u32 u1 = u0 + 8u < a.nunits ? u0 + 8u : a.nunits;
+      if (!a.uniform_len) {
+          // ragged batch: the output offsets of ALL units of this ticket are resolved (and published) before any of them
+          // is processed -- a wave that published unit u only after processing units u0..u-1 serialised the whole grid
+          // behind the look-back chain (measured: 200 Mbases of 277-base tiles took 210 ms instead of 2)
+          // (the scan element of the look-back chain is the TICKET: one aggregate for its 8 units, published at once)
+          u64 run = 0;
+          for (u32 unit = u0; unit < u1; ++unit) {
+              const u64 r = (u64)unit * 64 + lane;
+              u64 L = 0;
+              if (r < a.n) L = a.desc[r] & 0xffffffULL;
+              const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) >= (u64)k;
+              const u32 pk = ok ? ((u32)(L - k + 1) + 15u) & ~15u : 0u;
+              if (lane == 0) s_base[unit - u0] = run;
+              run += wave_sum_u64((u64)pk);
+          }
+          const u64 tbase = lookback_exclusive(a.lookback, u0 >> 3, run, lane);
+          wave_sync_lds();
+          if (lane < 8) s_base[lane] += tbase;
+          wave_sync_lds();
+      }
+      for (u32 unit = u0; unit < u1; ++unit) {
         const u64 r = (u64)unit * 64 + lane;
         u64 off = 0, L = 0;
         if (r < a.n) {
@@ -378,7 +398,7 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
         const u32 pk = (nk + 15u) & ~15u;
         const u64 incl = wave_incl_scan_u64((u64)pk, lane);
         const u64 T = wave_bcast_u64(incl, 63);
-        const u64 base = a.uniform_len ? (u64)unit * 64 * ((nk_max + 15u) & ~15u) : lookback_exclusive(a.lookback, unit, T, lane);
+        const u64 base = a.uniform_len ? (u64)unit * 64 * ((nk_max + 15u) & ~15u) : s_base[unit - u0];
         const bool ovf = base + T > a.cap;
         if (ovf && lane == 0) atomicOr(&a.ticket[1], 1u);
         if (r < a.n) {
@@ -489,6 +509,7 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
             }
             wave_sync_lds();
         }
+      }
     }
 }
 

@@ -370,12 +370,28 @@ __global__ __launch_bounds__(64) void k_prot_hash_fast(KArgs a) {
     u32 *const s_nk = reinterpret_cast<u32 *>(lds + 512);
     const int lane = lane_id();
     FP fp;  // only hashK() is used
-    for (u32 unit = next_ticket(a.ticket, lane) * 4u, uend = unit + 4u; unit < a.nunits; ++unit, ({
-             if (unit == uend) {
-                 unit = next_ticket(a.ticket, lane) * 4u;
-                 uend = unit + 4u;
-             }
-         })) {
+    __shared__ u64 s_base[4];
+    for (;;) {
+      const u32 u0 = next_ticket(a.ticket, lane) * 4u;
+      if (u0 >= a.nunits) break;
+      const u32 u1 = u0 + 4u < a.nunits ? u0 + 4u : a.nunits;
+      if (!a.uniform_len) {  // ragged batch: resolve and publish the offsets of every unit of the ticket first (see k_nthash_fast)
+          u64 run = 0;
+          for (u32 unit = u0; unit < u1; ++unit) {
+              const u64 r = (u64)unit * 64 + lane;
+              u64 L = 0;
+              if (r < a.n) L = a.aoff[r + 1] - a.aoff[r];
+              const bool ok = r < a.n && prot_len_ok(a, r, L, (u64)K * 3);
+              const u32 pk = (ok && L >= (u64)K) ? ((u32)(L - K + 1) + 15u) & ~15u : 0u;
+              if (lane == 0) s_base[unit - u0] = run;
+              run += wave_sum_u64((u64)pk);
+          }
+          const u64 tbase = lookback_exclusive(a.lookback, u0 >> 2, run, lane);
+          wave_sync_lds();
+          if (lane < 4) s_base[lane] += tbase;
+          wave_sync_lds();
+      }
+      for (u32 unit = u0; unit < u1; ++unit) {
         const u64 r = (u64)unit * 64 + lane;
         u64 off = 0, L = 0;
         if (r < a.n) {
@@ -388,7 +404,7 @@ __global__ __launch_bounds__(64) void k_prot_hash_fast(KArgs a) {
         const u32 pk = (nk + 15u) & ~15u;
         const u64 incl = wave_incl_scan_u64((u64)pk, lane);
         const u64 T = wave_bcast_u64(incl, 63);
-        const u64 base = a.uniform_len ? (u64)unit * 64 * ((nk_max + 15u) & ~15u) : lookback_exclusive(a.lookback, unit, T, lane);
+        const u64 base = a.uniform_len ? (u64)unit * 64 * ((nk_max + 15u) & ~15u) : s_base[unit - u0];
         const bool ovf = base + T > a.cap;
         if (ovf && lane == 0) atomicOr(&a.ticket[1], 1u);
         if (r < a.n) {
@@ -449,6 +465,7 @@ __global__ __launch_bounds__(64) void k_prot_hash_fast(KArgs a) {
                 wave_sync_lds();
             }
         }
+      }
     }
 }
 
