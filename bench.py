@@ -33,7 +33,24 @@ WORKLOADS = {
     # name: (kind, n_reads, read_len, k, w_or_s, description)
     "minimizer": ("min", 100_000_000, 150, 21, 11, "100M x 150 bp reads, minimizer sketch k=21 w=11 (BASELINE configs[2])"),
     "nthash": ("nt", 10_000_000, 150, 21, 0, "10M x 150 bp reads, canonical ntHash stream k=21 (BASELINE configs[1])"),
+    "syncmer": ("syn", 125_000_000, 150, 31, 11, "125M x 150 bp reads per GPU (1B over 8), syncmer sketch k=31 s=11 (BASELINE configs[3])"),
+    "protmin": ("pmin", 50_000_000, 300, 9, 5, "50M x 300 aa, protein minimizer sketch k=9 w=5 (BASELINE configs[4])"),
+    "kmer": ("kmer", 10_000_000, 150, 21, 0, "10M x 150 bp reads, canonical 2-bit k-mer codes k=21"),
+    "prothash": ("phash", 20_000_000, 300, 9, 0, "20M x 300 aa, protein k-mer hashes k=9"),
 }
+KERNELS = {"min": "k_minimizer_fast<11,32,true>", "nt": "k_nthash_fast<1>", "syn": "k_syncmer_fast<20>", "pmin": "k_prot_minimizer_fast<5,9>",
+           "kmer": "k_nthash_fast<2>", "phash": "k_prot_hash_fast<9>"}
+NOTES = {
+    "min": "integer-VALU bound, not HBM bound (DESIGN.md 3.1); frac is vs the 8 TB/s spec peak",
+    "nt": "HBM-write bound (DESIGN.md 3.2); a plain 16 B/lane fill kernel reaches 5.2-5.9 TB/s on this part",
+    "syn": "integer-VALU bound (two rolling hashes + a 2(k-s) window per base; DESIGN.md 3.3)",
+    "pmin": "integer-VALU bound (wyhash from scratch per residue: 8 v_mad_u64_u32; DESIGN.md 3.4)",
+    "kmer": "HBM-write bound, same streaming kernel as ntHash (DESIGN.md 3.2)",
+    "phash": "HBM-write bound (DESIGN.md 3.4)",
+}
+ORACLE_KIND = {"min": 4, "nt": 2, "syn": 5, "pmin": 7, "kmer": 1, "phash": 6}
+PROTEIN = ("pmin", "phash")
+STREAM = ("nt", "kmer", "phash")
 
 
 def cpu_baseline(kind: str, k: int, x: int, read_len: int, seed: int):
@@ -46,23 +63,25 @@ def cpu_baseline(kind: str, k: int, x: int, read_len: int, seed: int):
     from oracle import oracle as O
     cores = len(os.sched_getaffinity(0))
     rng = np.random.default_rng(seed)
-    okind = {"min": 4, "nt": 2}[kind]
+    okind = ORACLE_KIND[kind]
+    letters = b"ACDEFGHIKLMNPQRSTVWY" if kind in PROTEIN else b"ACGT"
 
     def run(n, threads):
-        data = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n * read_len)]
+        data = np.frombuffer(letters, np.uint8)[rng.integers(0, len(letters), n * read_len)]
         offs = (np.arange(n + 1, dtype=np.uint64) * read_len)
         O.batch_run(okind, data[: 1000 * read_len], offs[:1001], k, x, threads=threads)  # warm
         t = time.perf_counter()
         O.batch_run(okind, data, offs, k, x, threads=threads)
         return n * read_len / (time.perf_counter() - t) / 1e9
 
-    v1 = run(200_000, 1)
-    n_all = min(4_000_000, 400_000 * cores)
+    scale = 150.0 / read_len
+    v1 = run(int(200_000 * scale), 1)
+    n_all = int(min(4_000_000, 400_000 * cores) * scale)
     vall = run(n_all, cores)
     return {
         "value": round(vall, 4), "unit": "Gbases/s", "cores": cores, "kind": "port",
         "value_1thread": round(v1, 4),
-        "sample": f"{n_all} synthetic {read_len}-bp reads on {cores} threads (and 200000 reads on 1 thread); "
+        "sample": f"{n_all} synthetic {read_len}-letter sequences on {cores} threads (and {int(200_000 * scale)} on 1 thread); "
                   "C restatement of the reference state machine (oracle/bio_oracle.c), not the Go binary",
     }
 
@@ -118,8 +137,10 @@ def main():
         n_reads = int(args.reads)
     seed = 0x5EED0000 + 3 + 0x1000000 * rank  # each rank hashes its own shard of the synthetic stream
     eng = S.Engine(local_rank)
-    batch = eng.synth(L.ALPHA_DNA, n_reads, read_len, seed)
-    p = eng.params(L.MINIMIZER, k, w=x) if kind == "min" else eng.params(L.NTHASH, k)
+    batch = eng.synth(L.ALPHA_PROTEIN if kind in PROTEIN else L.ALPHA_DNA, n_reads, read_len, seed)
+    p = {"min": lambda: eng.params(L.MINIMIZER, k, w=x), "nt": lambda: eng.params(L.NTHASH, k), "syn": lambda: eng.params(L.SYNCMER, k, s=x),
+         "pmin": lambda: eng.params(L.PROT_MINIMIZER, k, w=x), "kmer": lambda: eng.params(L.KMER, k),
+         "phash": lambda: eng.params(L.PROT_HASH, k)}[kind]()
 
     def barrier():
         if world > 1:
@@ -147,28 +168,34 @@ def main():
         value = bases_total * args.steps / dt_max / 1e9
         # algorithmic bytes per launch on THIS rank: packed bases + one u64 descriptor in,
         # 12 B per tuple (u64 hash + u32 pos|strand) + one u64 index word per read out.
-        if kind == "min":
-            alg_bytes = n_reads * ((read_len + 3) // 4 + 8) + 12 * tuples + 8 * n_reads
+        in_bytes = n_reads * ((read_len + 8) if kind in PROTEIN else ((read_len + 3) // 4 + 8))  # residues are bytes, bases 2 bits
+        if kind in STREAM:
+            alg_bytes = in_bytes + 8 * tuples  # positions and offsets implicit
         else:
-            alg_bytes = n_reads * ((read_len + 3) // 4 + 8) + 8 * tuples  # positions and offsets implicit
+            alg_bytes = in_bytes + 12 * tuples + 8 * n_reads
         k_ms = sum(kernel_ms) / len(kernel_ms)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        unit = "Gresidues/s" if kind in PROTEIN else "Gbases/s"
+        metric = {"min": "Gbases/s hashed (k=21 ntHash + minimizer)", "nt": "Gbases/s hashed (k=21 ntHash stream)",
+                  "syn": "Gbases/s hashed (k=31 s=11 syncmer)", "pmin": "Gresidues/s hashed (k=9 w=5 protein minimizer)",
+                  "kmer": "Gbases/s encoded (k=21 canonical k-mer codes)", "phash": "Gresidues/s hashed (k=9 wyhash)"}[kind]
+        par = {"min": ("w", x), "syn": ("s", x), "pmin": ("w", x)}.get(kind, ("canonical", True))
         out = {
-            "metric": "Gbases/s hashed (k=21 ntHash + minimizer)" if kind == "min" else "Gbases/s hashed (k=21 ntHash stream)",
-            "value": round(value, 2), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": metric,
+            "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": desc, "reads_per_gpu": n_reads, "read_len": read_len, "k": k,
-                       ("w" if kind == "min" else "canonical"): (x if kind == "min" else True),
+            "config": {"workload": desc, "reads_per_gpu": n_reads, "read_len": read_len, "k": k, par[0]: par[1],
                        "tuples_per_gpu": int(tuples), "tuples_total": int(tuples_total),
                        "parallelism": f"reads sharded by record over {world} GPU(s), no data-path collective",
-                       "input": "2-bit packed reads resident in HBM", "output": "hash u64 + pos|strand u32 + u64 index per read, in HBM"},
+                       "input": ("residues (1 B each)" if kind in PROTEIN else "2-bit packed reads") + " resident in HBM",
+                       "output": ("hash u64 per position" if kind in STREAM else "hash u64 + pos|strand u32") + " + u64 index per read, in HBM"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, n_reads),
-                         "kernel": "k_minimizer_fast<11,32,true>" if kind == "min" else "k_nthash_fast<true>",
+                         "kernel": KERNELS[kind],
                          "kernel_ms_avg": round(k_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "note": ("integer-VALU bound, not HBM bound (DESIGN.md 3.1); frac is vs the 8 TB/s spec peak" if kind == "min" else
-                                  "HBM-write bound (DESIGN.md 3.2); a plain 16 B/lane fill kernel reaches 5.2-5.9 TB/s on this part")},
+                         "read_only_frac": round(in_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "note": NOTES[kind] + "; read_only_frac = input bytes alone over the same peak (north_star's 'HBM-read roofline')"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, k, x, read_len, 12345)

@@ -1,0 +1,46 @@
+"""Turn the rocprofv3 CSVs of scripts/profile_round.sh into traffic.json (HBM bytes per launch of the bench kernel).
+
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-byte read requests at 64 bytes and is doubled
+(MI355X_MICROARCH.md, HBM / rocprofv3 section).  Only the dispatches of the workload's sketch kernel are averaged.
+"""
+import csv
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (WORKLOADS / KERNELS tables)
+
+out_dir, workloads = sys.argv[1], sys.argv[2].split()
+entries = []
+for w in workloads:
+    kind, n_reads = bench.WORKLOADS[w][0], bench.WORKLOADS[w][1]
+    kname = bench.KERNELS[kind].split("<")[0]
+
+    def mean_counter(path, counter):
+        vals = []
+        if not os.path.exists(path):
+            return None
+        for row in csv.DictReader(open(path)):
+            if kname in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                vals.append(float(row["Counter_Value"]))
+        return sum(vals) / len(vals) if vals else None
+
+    f = mean_counter(os.path.join(out_dir, f"bench_{w}_pmc_fetch.csv"), "FETCH_SIZE")
+    wr = mean_counter(os.path.join(out_dir, f"bench_{w}_pmc_write.csv"), "WRITE_SIZE")
+    kms = None
+    sp = os.path.join(out_dir, f"bench_{w}_kernel_stats.csv")
+    if os.path.exists(sp):
+        for row in csv.DictReader(open(sp)):
+            if kname in row.get("Name", ""):
+                kms = float(row["AverageNs"]) / 1e6
+    if f is None or wr is None:
+        print("no counters for", w)
+        continue
+    entries.append({"workload": w, "reads_per_gpu": n_reads, "kernel": bench.KERNELS[kind], "FETCH_SIZE_KiB_mean": round(f), "WRITE_SIZE_KiB_mean": round(wr),
+                    "fetch_bytes_corrected": int(f * 1024 * 2), "write_bytes": int(wr * 1024), "hbm_bytes_per_launch": int(f * 2048 + wr * 1024),
+                    "rocprof_kernel_ms_avg": kms})
+json.dump({"note": "HBM traffic of one launch of the bench kernel: rocprofv3 --pmc passes on `python bench.py --workload W --steps 3 --warmup 1` "
+                   "(separate FETCH_SIZE and WRITE_SIZE passes; KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md: gfx950 tallies 128-byte read "
+                   "requests at 64 bytes). Raw CSVs beside this file.", "entries": entries}, open(os.path.join(out_dir, "traffic.json"), "w"), indent=1)
+print(json.dumps(entries, indent=1))
