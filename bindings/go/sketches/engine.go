@@ -176,6 +176,16 @@ func (b *Batch) ProteinMinimizerSketches(k, codonTable, frame, w int) (*Result, 
 		frame: C.int32_t(frame)})
 }
 
+// Translate is (*seq.Seq).Translate(codonTable, frame, false, false, true, false) (seq/seq.go:685) for every sequence of a
+// DNA/RNA batch, on the device; the protein constructors above do this themselves when the batch is not protein.
+func (b *Batch) Translate(codonTable, frame int) (*Batch, error) {
+	t := &Batch{eng: b.eng}
+	if err := b.eng.err(C.bsk_batch_translate(b.eng.ctx, b.h, C.int(codonTable), C.int(frame), &t.h)); err != nil {
+		return nil, err
+	}
+	return t, nil
+}
+
 func (r *Result) slice(i int) (codes []uint64, pos []uint32, status uint8, err error) {
 	a, e := r.offsets[i], r.offsets[i+1]
 	status = r.status[i]
