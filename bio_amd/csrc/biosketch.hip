@@ -20,6 +20,7 @@
 #include "kernels_protein.hpp"
 #include "kernels_translate.hpp"
 #include "kernels_tile.hpp"
+#include "kernels_simhash.hpp"
 
 using namespace bsk;
 
@@ -808,7 +809,7 @@ static int blocks_per_cu(K kernel) {
 
 // Which kernel runs a (batch, params) pair, on how many workgroups, and how the tuple arrays are organised.
 enum Which { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST, K_NT_FAST, K_SYN_P, K_SYN_A, K_KMER_P, K_KMER_A, K_SIM_P, K_SIM_A,
-             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST };
+             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST };
 struct Plan {
     Which which = K_MIN_GEN_P;
     int grid = 1;
@@ -874,9 +875,17 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
             per_cu = use_ascii ? blocks_per_cu(k_kmer<1>) : blocks_per_cu(k_kmer<0>);
         }
     } else if (p->kind == BSK_SIMHASH) {
-        pl.which = use_ascii ? K_SIM_A : K_SIM_P;
-        per_cu = use_ascii ? blocks_per_cu(k_simhash<1>) : blocks_per_cu(k_simhash<0>);
-        pl.ring_w = (u32)(p->k - p->m + 1);
+        const int nh = p->k - p->m + 1;
+        if (!use_ascii && nh <= 63 && b->maxlen + (u32)(p->circular ? p->k : 0) <= 16u * (BSK_NT_FAST_WORDS - 2) &&
+            !getenv("BSK_FORCE_GENERIC")) {
+            pl.which = K_SIM_FAST;  // bit-sliced counters: 5 planes count to 31, 6 to 63
+            pl.fast_w = nh <= 31 ? 5 : 6;
+            per_cu = nh <= 31 ? blocks_per_cu(k_simhash_fast<5>) : blocks_per_cu(k_simhash_fast<6>);
+        } else {
+            pl.which = use_ascii ? K_SIM_A : K_SIM_P;
+            per_cu = use_ascii ? blocks_per_cu(k_simhash<1>) : blocks_per_cu(k_simhash<0>);
+            pl.ring_w = (u32)nh;
+        }
     } else if (p->kind == BSK_PROT_HASH) {
         if (fast_prot_hash_supported(p->k) && !getenv("BSK_FORCE_GENERIC")) {
             pl.which = K_PROT_HASH_FAST;
@@ -1132,6 +1141,10 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_SYN_FAST: fast_syncmer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_PROT_MIN_FAST: fast_prot_launch(pl.fast_w, pl.fast_k, pl.grid, ctx->stream, a); break;
         case K_PROT_HASH_FAST: fast_prot_hash_launch(pl.fast_k, pl.grid, ctx->stream, a); break;
+        case K_SIM_FAST:
+            if (pl.fast_w == 5) hipLaunchKernelGGL(k_simhash_fast<5>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
+            else hipLaunchKernelGGL(k_simhash_fast<6>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
+            break;
         case K_NT_FAST:
             if (a.kind == BSK_KMER) hipLaunchKernelGGL(k_nthash_fast<2>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             else if (a.canonical) hipLaunchKernelGGL(k_nthash_fast<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
@@ -1163,7 +1176,8 @@ static u64 estimate_cap(const bsk_batch *b, const bsk_params *p, int circ_ext) {
         }
         case BSK_NTHASH: return bases + 16 * b->n + 64;  // runs are padded to whole 128-byte lines
         case BSK_KMER: return (p->canonical ? 1 : 2) * bases + 16 * b->n + 64;
-        case BSK_PROT_HASH: return bases + 16 * b->n + 64;
+        case BSK_PROT_HASH:
+        case BSK_SIMHASH: return bases + 16 * b->n + 64;
         default: return bases + 64;
     }
 }
@@ -1222,7 +1236,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         }
         cap = pl.slab ? pl.slab_total + ovf_used + ovf_used / 4 + 65536 : total + 64;  // size known now: re-run once
     }
-    if (sizing && (pl.slab || pl.which == K_NT_FAST || pl.which == K_PROT_HASH_FAST) && b->n) {  // slab / line-padded kernels: sum the per-read counts once
+    if (sizing && (pl.slab || pl.which == K_NT_FAST || pl.which == K_PROT_HASH_FAST || pl.which == K_SIM_FAST) && b->n) {  // slab / line-padded kernels: sum the per-read counts once
         HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, sizeof(u64), ctx->stream));
         hipLaunchKernelGGL(k_sum_counts, dim3(grid_for(ctx, b->n, 256)), dim3(256), 0, ctx->stream, (*result)->refs, b->n, ctx->d_total);
         hipError_t e = hipMemcpyAsync(ctx->h_pinned, ctx->d_total, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);

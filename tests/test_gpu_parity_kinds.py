@@ -100,7 +100,8 @@ def test_kmer_k_too_large(engine):
 
 
 @pytest.mark.parametrize("k,m,scale,canonical", [(21, 5, 5, True), (31, 5, 5, True), (21, 5, 1, True), (21, 21, 1, False),
-                                                 (16, 4, 13, True)])
+                                                 (16, 4, 13, True), (40, 5, 7, True), (36, 5, 2, False), (35, 4, 32, True),
+                                                 (67, 4, 3, True), (70, 6, 3, False)])  # k-m+1: <=31 five planes, <=63 six, else scalar counters
 def test_simhash(engine, oracle, k, m, scale, canonical):
     rng = random.Random(k * 100 + m)
     seqs = [rand_seq(rng, rng.choice([60, 150, rng.randint(1, 200)])) for _ in range(80)]
