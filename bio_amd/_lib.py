@@ -52,6 +52,12 @@ SYMBOLS = [
     ("bsk_batch_translate", C.c_int, [_vp, _vp, C.c_int, C.c_int, _pp]),
     ("bsk_codon_lut", C.c_int, [C.c_int, _vp, C.c_uint64]),
     ("bsk_batch_destroy", None, [_vp]),
+    ("bsk_fastx_open", C.c_int, [C.c_char_p, _pp]),
+    ("bsk_fastx_read_chunk", C.c_int, [_vp, C.c_uint64, C.c_uint64, _u64p, _pp, _pp, _pp, _pp, _pp]),
+    ("bsk_fastx_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("bsk_fastx_error", C.c_char_p, [_vp]),
+    ("bsk_fastx_close", None, [_vp]),
+    ("bsk_batch_from_fastx", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_int, _pp, _u64p]),
     ("bsk_sketch", C.c_int, [_vp, _vp, C.POINTER(Params), _pp]),
     ("bsk_sketch_timed", C.c_int, [_vp, _vp, C.POINTER(Params), _pp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     ("bsk_result_info", C.c_int, [_vp, _u64p, _u64p, C.POINTER(C.c_int)]),

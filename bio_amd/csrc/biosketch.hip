@@ -270,6 +270,9 @@ extern "C" const char *bsk_err_name(int e) {
         case BSK_ERR_DEVICE: return "device error";
         case BSK_ERR_UNSUPPORTED: return "unsupported";
         case BSK_ERR_NO_DEVICE: return "no gfx950 device";
+        case BSK_ERR_IO: return "fastx: cannot open or read the file";
+        case BSK_ERR_NOT_FASTX: return "fastx: invalid FASTA/Q format";
+        case BSK_ERR_BAD_FASTQ: return "fastx: bad FASTQ format";
         default: return "unknown";
     }
 }

@@ -1,0 +1,152 @@
+"""Python mirror of seqio/fastx (Reader.Read / ChunkChan, reader.go:233-369,562-608) over the C ABI's host-side reader.
+
+    reader, err = NewDefaultReader("reads.fq.gz")
+    while True:
+        record, err = reader.Read()          # (None, EOF) at the end, like io.EOF upstream
+        if err is not None: break
+        record.Name, record.ID, record.Seq.Seq, record.Seq.Qual
+
+    for chunk in reader.chunks(100000):      # the batching form the GPU path wants (ChunkChan)
+        batch = engine.batch_from_arrays(chunk.seq, chunk.offsets, chunk.alphabet)
+
+Names follow the reference (Record.ID = first word of the header, DefaultIDRegexp `^(\\S+)\\s?`, reader.go:109).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from typing import Iterator, Optional
+
+import numpy as np
+
+from . import _lib as L
+from .sketches import DNA, Protein, Seq
+
+
+class FastxError(Exception):
+    def __init__(self, code: int, msg: str):
+        super().__init__(msg)
+        self.code = code
+
+
+EOF = FastxError(0, "EOF")
+ErrNotFASTXFormat = FastxError(70, "fastx: invalid FASTA/Q format")   # reader.go:16
+ErrBadFASTQFormat = FastxError(71, "fastx: bad fastq format")         # reader.go:19 (also ErrUnequalSeqAndQual :22)
+_ERRS = {70: ErrNotFASTXFormat, 71: ErrBadFASTQFormat}
+_ID = re.compile(rb"^(\S+)\s?")
+
+
+class Record:
+    """fastx.Record (records.go:13-18): ID, Name, Desc, Seq (with Qual for FASTQ)."""
+
+    def __init__(self, name: bytes, seq: bytes, qual: Optional[bytes], alphabet):
+        self.Name = name
+        m = _ID.match(name)
+        self.ID = m.group(1) if m else name
+        self.Desc = name[m.end():] if m else b""
+        self.Seq = Seq(alphabet, seq)
+        self.Seq.Qual = qual if qual is not None else b""
+
+
+class Chunk:
+    def __init__(self, seq, offsets, names, name_offsets, qual, alphabet):
+        self.seq, self.offsets, self.names, self.name_offsets, self.qual, self.alphabet = seq, offsets, names, name_offsets, qual, alphabet
+
+    def __len__(self):
+        return len(self.offsets) - 1
+
+    def name(self, i: int) -> bytes:
+        return self.names[int(self.name_offsets[i]):int(self.name_offsets[i + 1])].tobytes()
+
+    def sequence(self, i: int) -> bytes:
+        return self.seq[int(self.offsets[i]):int(self.offsets[i + 1])].tobytes()
+
+    def quality(self, i: int) -> Optional[bytes]:
+        return None if self.qual is None else self.qual[int(self.offsets[i]):int(self.offsets[i + 1])].tobytes()
+
+
+class Reader:
+    def __init__(self, path: str):
+        self.lib = L.load()
+        self.h = C.c_void_p()
+        rc = self.lib.bsk_fastx_open(path.encode(), C.byref(self.h))
+        if rc != 0:
+            raise OSError(f"fastx: cannot open {path}")
+        self._pending: list = []
+        self._err: Optional[FastxError] = None
+
+    # -- chunked form
+    def read_chunk(self, max_records: int = 0, max_bytes: int = 0) -> Optional[Chunk]:
+        """Next chunk, None at end of file; raises FastxError on a format error."""
+        n = C.c_uint64()
+        sb, so, nb, no, qb = (C.c_void_p() for _ in range(5))
+        rc = self.lib.bsk_fastx_read_chunk(self.h, max_records, max_bytes, C.byref(n), C.byref(sb), C.byref(so), C.byref(nb), C.byref(no),
+                                           C.byref(qb))
+        if rc != 0:
+            raise _ERRS.get(rc, FastxError(rc, self.lib.bsk_fastx_error(self.h).decode()))
+        if n.value == 0:
+            return None
+        cnt = n.value
+        offs = np.ctypeslib.as_array(C.cast(so, C.POINTER(C.c_uint64)), (cnt + 1,)).copy()
+        noffs = np.ctypeslib.as_array(C.cast(no, C.POINTER(C.c_uint64)), (cnt + 1,)).copy()
+        seq = np.ctypeslib.as_array(C.cast(sb, C.POINTER(C.c_uint8)), (max(int(offs[-1]), 1),))[: int(offs[-1])].copy()
+        names = np.ctypeslib.as_array(C.cast(nb, C.POINTER(C.c_uint8)), (max(int(noffs[-1]), 1),))[: int(noffs[-1])].copy()
+        qual = None
+        if qb.value:
+            qual = np.ctypeslib.as_array(C.cast(qb, C.POINTER(C.c_uint8)), (max(int(offs[-1]), 1),))[: int(offs[-1])].copy()
+        return Chunk(seq, offs, names, noffs, qual, self.alphabet)
+
+    def chunks(self, max_records: int = 0, max_bytes: int = 0) -> Iterator[Chunk]:
+        while True:
+            c = self.read_chunk(max_records, max_bytes)
+            if c is None:
+                return
+            yield c
+
+    @property
+    def IsFastq(self) -> bool:
+        q, a = C.c_int(), C.c_int()
+        self.lib.bsk_fastx_info(self.h, C.byref(q), C.byref(a))
+        return q.value == 1
+
+    @property
+    def alphabet(self) -> int:
+        q, a = C.c_int(), C.c_int()
+        self.lib.bsk_fastx_info(self.h, C.byref(q), C.byref(a))
+        return a.value
+
+    # -- record form (Reader.Read, reader.go:233)
+    def Read(self):
+        if not self._pending and self._err is None:
+            try:
+                c = self.read_chunk(4096)
+            except FastxError as e:
+                self._err = e
+                c = None
+            if c is None and self._err is None:
+                self._err = EOF
+            if c is not None:
+                ab = Protein if c.alphabet == L.ALPHA_PROTEIN else DNA
+                self._pending = [Record(c.name(i), c.sequence(i), c.quality(i), ab) for i in range(len(c))][::-1]
+        if self._pending:
+            return self._pending.pop(), None
+        return None, self._err
+
+    def Close(self):
+        if self.h:
+            self.lib.bsk_fastx_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.Close()
+        except Exception:
+            pass
+
+
+def NewDefaultReader(path: str):
+    """fastx.NewDefaultReader (reader.go:112): (reader, err)."""
+    try:
+        return Reader(path), None
+    except OSError as e:
+        return None, e

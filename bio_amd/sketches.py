@@ -223,6 +223,14 @@ class Engine:
                                                  C.byref(h)))
         return Batch(self, h)
 
+    def batch_from_fastx(self, reader, max_records: int = 0, max_bytes: int = 0, alphabet: int = -1):
+        """Next chunk of a bio_amd.fastx.Reader straight into a device batch (bsk_batch_from_fastx): (Batch or None, n_records).
+        alphabet < 0: the reader's guess from its first record, as the reference does."""
+        h = C.c_void_p()
+        n = C.c_uint64()
+        self._chk(self.lib.bsk_batch_from_fastx(self.ctx, reader.h, max_records, max_bytes, alphabet, C.byref(h), C.byref(n)))
+        return (Batch(self, h) if n.value else None), n.value
+
     def synth(self, alphabet: int, n: int, length: int, seed: int) -> Batch:
         h = C.c_void_p()
         self._chk(self.lib.bsk_batch_synth(self.ctx, alphabet, n, length, seed, C.byref(h)))

@@ -57,7 +57,10 @@ typedef enum bsk_err {
     BSK_ERR_NOMEM = 65,        /* host or device allocation failed */
     BSK_ERR_DEVICE = 66,       /* HIP runtime error; text in bsk_last_error() */
     BSK_ERR_UNSUPPORTED = 67,  /* valid upstream, not implemented here (see DESIGN.md scope) */
-    BSK_ERR_NO_DEVICE = 68     /* no gfx950 device visible: there is NO CPU fallback */
+    BSK_ERR_NO_DEVICE = 68,    /* no gfx950 device visible: there is NO CPU fallback */
+    BSK_ERR_IO = 69,           /* FASTA/Q reader: cannot open / read */
+    BSK_ERR_NOT_FASTX = 70,    /* ErrNotFASTXFormat seqio/fastx/reader.go:16 */
+    BSK_ERR_BAD_FASTQ = 71     /* ErrBadFASTQFormat / ErrUnequalSeqAndQual reader.go:19-22 */
 } bsk_err;
 
 typedef enum bsk_kind {
@@ -155,6 +158,29 @@ int bsk_batch_translate(bsk_ctx *ctx, const bsk_batch *dna, int codon_table, int
  * [4352,4416) the 64 plain codons by 2-bit code (A0 C1 G2 T3, first base most significant).  lut_bytes >= 4416. */
 int bsk_codon_lut(int codon_table, uint8_t *lut, uint64_t lut_bytes);
 void bsk_batch_destroy(bsk_batch *b);
+
+/* ---- FASTA/FASTQ feeding (host side) --------------------------------
+ * Record reader with the semantics of seqio/fastx Reader.Read / parseRecord (reader.go:233-471): format from the first
+ * non-newline byte, records start at '>' / '@' after a newline, multi-line FASTA and FASTQ, CR dropped, quality lines that
+ * start with '@', the reference's edge cases (record without sequence, empty file, newline-only file).  gzip or plain,
+ * "-" = stdin.  bsk_fastx_read_chunk returns up to max_records records / stops after max_bytes sequence bytes (0 = no
+ * limit; at least one record): concatenated sequence bytes + offsets[n+1], header lines + offsets[n+1], and for FASTQ the
+ * concatenated qualities (same offsets as the sequences) -- pointers into reader-owned memory, valid until the next
+ * call.  *n == 0 with BSK_OK = end of file.  Errors: BSK_ERR_NOT_FASTX (ErrNotFASTXFormat), BSK_ERR_BAD_FASTQ
+ * (ErrBadFASTQFormat / ErrUnequalSeqAndQual), BSK_ERR_IO.  bsk_fastx_info: is_fastq (-1 before the first record) and the
+ * alphabet guessed from the first sequence as the reference does (seq/alphabet.go:413-452): BSK_ALPHA_DNA for DNA/RNA
+ * incl. ambiguity letters, BSK_ALPHA_PROTEIN, -1 for "Unlimit".
+ * bsk_batch_from_fastx = read_chunk + bsk_batch_from_ascii (alphabet < 0: use the guess). */
+typedef struct bsk_fastx bsk_fastx;
+int bsk_fastx_open(const char *path, bsk_fastx **out);
+int bsk_fastx_read_chunk(bsk_fastx *f, uint64_t max_records, uint64_t max_bytes, uint64_t *n, const uint8_t **seq_bytes,
+                         const uint64_t **seq_offsets, const uint8_t **name_bytes, const uint64_t **name_offsets,
+                         const uint8_t **qual_bytes);
+int bsk_fastx_info(const bsk_fastx *f, int *is_fastq, int *alphabet);
+const char *bsk_fastx_error(const bsk_fastx *f);
+void bsk_fastx_close(bsk_fastx *f);
+int bsk_batch_from_fastx(bsk_ctx *ctx, bsk_fastx *f, uint64_t max_records, uint64_t max_bytes, int alphabet, bsk_batch **out,
+                         uint64_t *n_records);
 
 /* ---- compute -------------------------------------------------------------------
  * Runs the iterator/sketch named by p->kind over every read of the batch.
