@@ -18,6 +18,10 @@
 
 namespace bsk {
 
+#define GLBQ __attribute__((address_space(1)))
+typedef u32x4 u32x4_u __attribute__((aligned(1)));  // byte-aligned 16-byte global load (unaligned access mode of the HSA ABI)
+typedef u32 u32_u __attribute__((aligned(1)));
+
 constexpr int ilcm4(int w) { return (w % 4 == 0) ? w : (w % 2 == 0 ? 2 * w : 4 * w); }
 
 template <int MB>
@@ -222,26 +226,34 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
             fp.nk = nk;
             fp.prev = 0xffffffffu;
             fp.tm = 0;
-            // residues are bytes at an arbitrary address: read aligned dwords and realign by (address & 3) bytes
+            // residues are bytes at an arbitrary address: byte-aligned 16- and 4-byte global loads (unaligned access mode of
+            // the HSA ABI).  Five aligned dword loads + realignment per macro block touched every cache line 32 times; with
+            // 6 wavefronts per CU walking 64 sequences each, the 48 KB of lines do not stay in the 32 KB L1.
             const u8 *p0 = a.ascii + off;
-            const u32 bsh = (u32)((size_t)p0 & 3) * 8;
-            const u32 *wp = reinterpret_cast<const u32 *>((size_t)p0 & ~(size_t)3);
-            u32 wprev = wp[0];
-            const u32 jmax = (u32)((L + bsh / 8 + 3) / 4);  // last aligned dword that holds a byte of this sequence
-            auto next_dword = [&](u32 j) {  // dword j of the sequence (bytes 4j..4j+3), realigned
+            const size_t gp0 = (size_t)p0;
+            auto load_dwords = [&](u32 *dst, int ndw, u32 j) {  // dwords j .. j+ndw-1 of the sequence (bytes 4j ..)
+                int g = 0;
 #ifdef PROT_EXP_FAKEIN  // dev experiment: no residue loads
-                const u32 wn = (j * 0x9E3779B9u) ^ (u32)lane;
+                for (; g < ndw; ++g) dst[g] = ((j + g) * 0x9E3779B9u) ^ (u32)lane;
 #else
-                const u32 wn = wp[j + 1 < jmax ? j + 1 : jmax];
+                for (; g + 4 <= ndw; g += 4) {
+                    const u64 bo = (u64)4 * (j + g) < L ? (u64)4 * (j + g) : L;  // never start beyond the sequence (+ buffer slack)
+                    const u32x4 v = *reinterpret_cast<const GLBQ u32x4_u *>(gp0 + bo);
+                    dst[g] = v.x;
+                    dst[g + 1] = v.y;
+                    dst[g + 2] = v.z;
+                    dst[g + 3] = v.w;
+                }
+                for (; g < ndw; ++g) {
+                    const u64 bo = (u64)4 * (j + g) < L ? (u64)4 * (j + g) : L;
+                    dst[g] = *reinterpret_cast<const GLBQ u32_u *>(gp0 + bo);
+                }
 #endif
-                const u32 v = __builtin_amdgcn_alignbit(wn, wprev, bsh);
-                wprev = wn;
-                return v;
             };
             u32 dj = 0;
             fp.slot = (u32)lane * 8u;  // staging persists across macro blocks (leftovers of fewer than 16 tuples stay in LDS)
-#pragma unroll
-            for (int g = 0; g < 5 + MB / 4; ++g) fp.R[g] = next_dword(dj++);
+            load_dwords(fp.R, 5 + MB / 4, 0);
+            dj = 5 + MB / 4;
             for (u32 i0 = 0; i0 < nk_max; i0 += MB) {
                 if (i0 == 0) fp.template macro<true>(i0);
                 else fp.template macro<false>(i0);
@@ -249,8 +261,8 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
                 for (int g = 0; g < 5; ++g) fp.R[g] = fp.R[g + MB / 4];
                 // residues of the NEXT macro block: requested and waited for BEFORE this round's flush stores are
                 // issued (vmcnt is in-order: a load issued after the stores could only be waited for together with them)
-#pragma unroll
-                for (int g = 0; g < MB / 4; ++g) fp.R[5 + g] = next_dword(dj++);
+                load_dwords(fp.R + 5, MB / 4, dj);
+                dj += MB / 4;
 #pragma unroll
                 for (int g = 0; g < MB / 4; ++g) asm volatile("" ::"v"(fp.R[5 + g]));
                 // ---- flush whole 16-tuple groups (= full 128-byte lines of hashes) of every lane to its slab ----
@@ -328,8 +340,6 @@ static inline void fast_prot_launch(int w, int k, int grid, hipStream_t stream, 
 // RS = 4*odd: regions are 16-byte aligned and ds_read_b128 of 64 different regions is 2-way conflicted at most).
 // One global_load_dwordx4 per source touches ~np16/8 lines (a per-lane walk touches 64 lines per instruction and
 // measured 2x slower end to end: the 64 KB of lines that 8 waves walk do not stay in the 32 KB L1).
-#define GLBQ __attribute__((address_space(1)))
-typedef u32x4 u32x4_u __attribute__((aligned(1)));  // byte-aligned 16-byte global load (unaligned access mode of the HSA ABI)
 #ifndef BSK_PH_UNR
 #define BSK_PH_UNR 16
 #endif

@@ -122,3 +122,40 @@ def test_synth_batch_roundtrip_and_digest(engine, oracle):
     nt2, ck2 = oracle.batch_run(2, data, offs, 21, 0, threads=2)
     d2 = res2.digest()
     assert d2["n_tuples"] == nt2 == 5000 * 130 and d2["checksum"] == ck2
+
+
+def test_contexts_are_independent_across_threads(oracle):
+    """SURVEY 8b threading: one context per worker, different contexts concurrently are safe (the reference's iterators are
+    one-goroutine objects with pooled allocation as the only shared state)."""
+    import threading
+    from bio_amd import sketches as S
+    rng = random.Random(99)
+    sets = [[rand_dna(rng, rng.randint(30, 400)) for _ in range(300)] for _ in range(4)]
+    errors = []
+
+    def worker(seqs, k, w):
+        try:
+            eng = S.Engine(0)
+            for _ in range(5):
+                b = eng.batch(seqs)
+                res = eng.run(b, eng.params(L.MINIMIZER, k, w=w))
+                for i in (0, 7, 150, 299):
+                    st, h, p = res.read(i)
+                    try:
+                        eh, ep, _, _ = oracle.minimizer(seqs[i], k, w, False, closed=True)
+                    except oracle.OracleError:
+                        assert (st & L.ST_CODE_MASK) == L.ST_SHORT
+                        continue
+                    assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep)
+                res.close()
+                b.close()
+            eng.close() if hasattr(eng, "close") else None
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(sets[i], 15 + 2 * i, 5 + i)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert errors == []
