@@ -37,9 +37,10 @@ WORKLOADS = {
     "protmin": ("pmin", 50_000_000, 300, 9, 5, "50M x 300 aa, protein minimizer sketch k=9 w=5 (BASELINE configs[4])"),
     "kmer": ("kmer", 10_000_000, 150, 21, 0, "10M x 150 bp reads, canonical 2-bit k-mer codes k=21"),
     "prothash": ("phash", 20_000_000, 300, 9, 0, "20M x 300 aa, protein k-mer hashes k=9"),
+    "simhash": ("sim", 20_000_000, 150, 21, 5, "20M x 150 bp reads, SimHash k=21 m=5 scale=5"),
 }
 KERNELS = {"min": "k_minimizer_fast<11,32,true>", "nt": "k_nthash_fast<1>", "syn": "k_syncmer_fast<20>", "pmin": "k_prot_minimizer_fast<5,9>",
-           "kmer": "k_nthash_fast<2>", "phash": "k_prot_hash_fast<9>"}
+           "kmer": "k_nthash_fast<2>", "phash": "k_prot_hash_fast<9>", "sim": "k_simhash_fast<5>"}
 NOTES = {
     "min": "integer-VALU bound, not HBM bound (DESIGN.md 3.1); frac is vs the 8 TB/s spec peak",
     "nt": "HBM-write bound (DESIGN.md 3.2); a plain 16 B/lane fill kernel reaches 5.2-5.9 TB/s on this part",
@@ -47,10 +48,11 @@ NOTES = {
     "pmin": "integer-VALU bound (wyhash from scratch per residue: 8 v_mad_u64_u32; DESIGN.md 3.4)",
     "kmer": "HBM-write bound, same streaming kernel as ntHash (DESIGN.md 3.2)",
     "phash": "HBM-write bound (DESIGN.md 3.4)",
+    "sim": "integer-VALU bound (two rolling hashes + bit-sliced counters, ~110 ops per k-mer; DESIGN.md 3.6)",
 }
-ORACLE_KIND = {"min": 4, "nt": 2, "syn": 5, "pmin": 7, "kmer": 1, "phash": 6}
+ORACLE_KIND = {"min": 4, "nt": 2, "syn": 5, "pmin": 7, "kmer": 1, "phash": 6, "sim": 3}
 PROTEIN = ("pmin", "phash")
-STREAM = ("nt", "kmer", "phash")
+STREAM = ("nt", "kmer", "phash", "sim")
 
 
 def cpu_baseline(kind: str, k: int, x: int, read_len: int, seed: int):
@@ -140,7 +142,7 @@ def main():
     batch = eng.synth(L.ALPHA_PROTEIN if kind in PROTEIN else L.ALPHA_DNA, n_reads, read_len, seed)
     p = {"min": lambda: eng.params(L.MINIMIZER, k, w=x), "nt": lambda: eng.params(L.NTHASH, k), "syn": lambda: eng.params(L.SYNCMER, k, s=x),
          "pmin": lambda: eng.params(L.PROT_MINIMIZER, k, w=x), "kmer": lambda: eng.params(L.KMER, k),
-         "phash": lambda: eng.params(L.PROT_HASH, k)}[kind]()
+         "phash": lambda: eng.params(L.PROT_HASH, k), "sim": lambda: eng.params(L.SIMHASH, k, m=x, scale=5)}[kind]()
 
     def barrier():
         if world > 1:
@@ -178,8 +180,9 @@ def main():
         unit = "Gresidues/s" if kind in PROTEIN else "Gbases/s"
         metric = {"min": "Gbases/s hashed (k=21 ntHash + minimizer)", "nt": "Gbases/s hashed (k=21 ntHash stream)",
                   "syn": "Gbases/s hashed (k=31 s=11 syncmer)", "pmin": "Gresidues/s hashed (k=9 w=5 protein minimizer)",
-                  "kmer": "Gbases/s encoded (k=21 canonical k-mer codes)", "phash": "Gresidues/s hashed (k=9 wyhash)"}[kind]
-        par = {"min": ("w", x), "syn": ("s", x), "pmin": ("w", x)}.get(kind, ("canonical", True))
+                  "kmer": "Gbases/s encoded (k=21 canonical k-mer codes)", "phash": "Gresidues/s hashed (k=9 wyhash)",
+                  "sim": "Gbases/s hashed (k=21 m=5 SimHash)"}[kind]
+        par = {"min": ("w", x), "syn": ("s", x), "pmin": ("w", x), "sim": ("m", x)}.get(kind, ("canonical", True))
         out = {
             "metric": metric,
             "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
