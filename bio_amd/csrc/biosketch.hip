@@ -56,6 +56,8 @@ struct bsk_batch {
     u64 *llen = nullptr;   // [n] bases
     u64 *adesc = nullptr;  // tile batches over ASCII: (first_byte << 24) | n_bases per tile
     bool alias = false;    // words / ascii belong to another batch (tile batches)
+    u32 *subset = nullptr; // reads with a non-ACGT letter, ascending (side launch of the ASCII kernels); nsub = n_nonacgt
+    u64 nsub = 0;
     u8 *rflags = nullptr;
     u8 *ascii = nullptr;  // DNA: kept only when some read has a non-ACGT byte; protein: always
     u64 *aoff = nullptr;
@@ -66,6 +68,7 @@ struct bsk_result {
     bsk_ctx *ctx = nullptr;
     u64 n = 0, cap = 0, n_tuples = 0;
     u64 ovf_cap = 0;  // slab kernels: tuples reserved (inside cap) for units that outgrow their slab
+    u64 main_cap = 0; // tuples [0, main_cap) belong to the main launch, [main_cap, cap) to the side launch (mixed batches)
     int kind = 0, has_pos = 0;
     u64 *refs = nullptr;  // per read: (first_tuple << 24) | n_tuples ; NULL for wide results
     u64 *wfirst = nullptr, *wcount = nullptr;  // wide results (tiled long sequences): first tuple and tuple count per sequence
@@ -160,6 +163,19 @@ __global__ void k_count_flags(const u8 *rflags, u64 n, u32 *count) {
         c += rflags[g] != 0;
     for (int d = 32; d; d >>= 1) c += __shfl_xor(c, d, 64);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+// indices of the flagged reads, ascending (one wavefront per 64 reads + look-back: deterministic order)
+__global__ __launch_bounds__(64) void k_compact_flags(const u8 *rflags, u64 n, u32 nunits, u32 *ticket, u64 *lookback, u32 *subset) {
+    const int lane = lane_id();
+    for (;;) {
+        const u32 unit = next_ticket(ticket, lane);
+        if (unit >= nunits) break;
+        const u64 r = (u64)unit * 64 + lane;
+        const bool f = r < n && rflags[r] != 0;
+        const u64 m = __ballot(f);
+        const u64 base = lookback_exclusive(lookback, unit, (u64)__builtin_popcountll(m), lane);
+        if (f) subset[base + __builtin_popcountll(m & ((1ULL << lane) - 1))] = (u32)r;
+    }
 }
 // circular: read r' = read r + its first k-1 bases (iterator.go:642-646).  One thread per output word.
 __global__ void k_extend_packed(const u32 *words, const u64 *desc, const u64 *ndesc, u64 n, u64 n_words_new, u32 *out) {
@@ -308,7 +324,7 @@ extern "C" int bsk_ctx_create(int device, bsk_ctx **out) {
     }
     ctx->cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&ctx->d_ticket, 2 * sizeof(u32)) != hipSuccess || hipMalloc(&ctx->d_total, 8 * sizeof(u64)) != hipSuccess ||
+        hipMalloc(&ctx->d_ticket, 4 * sizeof(u32)) != hipSuccess || hipMalloc(&ctx->d_total, 8 * sizeof(u64)) != hipSuccess ||
         hipHostMalloc(&ctx->h_pinned, 8 * sizeof(u64)) != hipSuccess) {
         bsk_ctx_destroy(ctx);
         return BSK_ERR_DEVICE;
@@ -361,12 +377,14 @@ extern "C" void bsk_batch_destroy(bsk_batch *b) {
     (void)hipFree(b->fw);
     (void)hipFree(b->llen);
     (void)hipFree(b->adesc);
+    (void)hipFree(b->subset);
     (void)hipFree(b->rflags);
     (void)hipFree(b->aoff);
     delete b;
 }
 
 static u64 pad_words(u32 maxlen) { return (u64)maxlen / 16 + 8; }
+static int build_subset(bsk_ctx *ctx, bsk_batch *b);
 
 extern "C" int bsk_batch_from_ascii(bsk_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet,
                                     bsk_batch **out) {
@@ -456,6 +474,8 @@ extern "C" int bsk_batch_from_ascii(bsk_ctx *ctx, const uint8_t *bytes, const ui
             b->ascii = nullptr;
             b->aoff = nullptr;
             b->device_bytes -= nbytes + 64 + (n + 1) * 8;
+        } else if ((rc = build_subset(ctx, b)) != BSK_OK) {
+            return bail(rc);
         }
     } else {
         BCHK(hipStreamSynchronize(ctx->stream));
@@ -800,6 +820,27 @@ static int ensure_scratch(bsk_ctx *ctx, size_t nunits, size_t ring_entries) {
     return BSK_OK;
 }
 
+// list of the reads that carry a non-ACGT letter (they are few in real data): the fast 2-bit kernels then run over the
+// whole batch and the general ASCII kernels re-do only these reads in a side launch (make_plan: "mixed")
+static int build_subset(bsk_ctx *ctx, bsk_batch *b) {
+    (void)hipFree(b->subset);
+    b->subset = nullptr;
+    b->nsub = 0;
+    if (!b->n_nonacgt || !b->rflags || b->n >= (1ULL << 32)) return BSK_OK;
+    const u32 nunits = (u32)((b->n + 63) / 64);
+    int rc = ensure_scratch(ctx, nunits, 0);
+    if (rc != BSK_OK) return rc;
+    HIPCHK(ctx, hipMalloc(&b->subset, b->n_nonacgt * sizeof(u32)));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket, 0, 4 * sizeof(u32), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_lookback, 0, (size_t)nunits * sizeof(u64), ctx->stream));
+    hipLaunchKernelGGL(k_compact_flags, dim3(std::min<u32>(nunits, (u32)ctx->cus * 8)), dim3(64), 0, ctx->stream, b->rflags, b->n, nunits,
+                       ctx->d_ticket, ctx->d_lookback, b->subset);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    b->nsub = b->n_nonacgt;
+    return BSK_OK;
+}
+
 template <class K>
 static int blocks_per_cu(K kernel) {
     int nb = 0;
@@ -825,11 +866,48 @@ struct Plan {
     size_t ring_entries = 0;
     u64 slab_read = 0;     // per-sequence slabs (protein fast path)
     int fast_k = 0;
+    // mixed batch: the fast 2-bit kernel over all reads + the general ASCII kernel over the reads with a non-ACGT letter
+    bool mixed = false;
+    Which side_which = K_MIN_GEN_A;
+    u32 side_nunits = 0, side_ring_w = 0;
+    int side_grid = 1;
 };
 
+static bool which_is_fast(Which w) {
+    return w == K_MIN_FAST || w == K_NT_FAST || w == K_SYN_FAST || w == K_SIM_FAST;
+}
+
+static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan &pl, bool use_ascii);
+
 static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan &pl) {
+    const bool has_n = b->alphabet == BSK_ALPHA_DNA && b->n_nonacgt > 0;
+    // few reads with a non-ACGT letter: plan the batch as 2-bit; if that lands on a fast kernel, the flagged reads are
+    // re-done by the general ASCII kernel in a side launch.  Otherwise the whole batch runs on the ASCII kernels.
+    if (has_n && b->subset && b->nsub * 4 <= b->n && !getenv("BSK_NO_MIXED") && !b->adesc) {
+        Plan t;
+        int rc = make_plan_enc(ctx, b, p, t, false);
+        if (rc != BSK_OK) return rc;
+        if (which_is_fast(t.which)) {
+            Plan sd;
+            bsk_batch sb = *b;  // shallow view with the side launch's shape
+            sb.n = b->nsub;
+            rc = make_plan_enc(ctx, &sb, p, sd, true);
+            if (rc != BSK_OK) return rc;
+            pl = t;
+            pl.mixed = true;
+            pl.side_which = sd.which;
+            pl.side_nunits = sd.nunits;
+            pl.side_ring_w = sd.ring_w;
+            pl.side_grid = sd.grid;
+            pl.ring_entries = std::max(pl.ring_entries, sd.ring_entries);
+            return BSK_OK;
+        }
+    }
+    return make_plan_enc(ctx, b, p, pl, has_n);
+}
+
+static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan &pl, bool use_ascii) {
     pl.nunits = (u32)((b->n + 63) / 64);
-    const bool use_ascii = b->alphabet == BSK_ALPHA_DNA && b->n_nonacgt > 0;
     int per_cu = 1;
     if (p->kind == BSK_MINIMIZER) {
         // fast path: 2-bit input, a window size with a compiled specialisation, positions that fit 15 bits
@@ -1111,20 +1189,20 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     a.status = res->status;
     a.hash = res->hash;
     a.pos = res->pos;
-    a.cap = res->cap;
+    a.cap = res->main_cap ? res->main_cap : res->cap;
     a.ovf_base = pl.slab_total;
     a.slab_read = pl.slab_read;
     a.ovf_cap = res->ovf_cap;
     a.ticket = ctx->d_ticket;
     a.total = ctx->d_total;
     a.ring_w = pl.ring_w;
-    int rc = ensure_scratch(ctx, pl.slab ? 1 : pl.nunits, pl.ring_entries);
+    int rc = ensure_scratch(ctx, std::max<u32>(pl.slab ? 1 : pl.nunits, pl.mixed ? pl.side_nunits : 0), pl.ring_entries);
     if (rc != BSK_OK) return rc;
     a.lookback = ctx->d_lookback;
     a.ring_h = ctx->d_ring_h;
     a.ring_p = ctx->d_ring_p;
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, 2 * sizeof(u64), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket, 0, 4 * sizeof(u32), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, 4 * sizeof(u64), ctx->stream));
     if (!pl.slab) HIPCHK(ctx, hipMemsetAsync(ctx->d_lookback, 0, (size_t)pl.nunits * sizeof(u64), ctx->stream));
     if (ev0) HIPCHK(ctx, hipEventRecord(ev0, ctx->stream));
     switch (pl.which) {
@@ -1154,6 +1232,27 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
             else hipLaunchKernelGGL(k_nthash_fast<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             break;
     }
+    if (pl.mixed) {  // the reads with a non-ACGT letter again, from their ASCII bytes, into [main_cap, cap)
+        KArgs sd = a;
+        sd.subset = b->subset;
+        sd.nsub = b->nsub;
+        sd.nunits = pl.side_nunits;
+        sd.out_base = res->main_cap;
+        sd.cap = res->cap;
+        sd.uniform_len = 0;
+        sd.ticket = ctx->d_ticket + 2;
+        sd.total = ctx->d_total + 2;
+        sd.ring_w = pl.side_ring_w;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_lookback, 0, (size_t)pl.side_nunits * sizeof(u64), ctx->stream));
+        switch (pl.side_which) {
+            case K_MIN_GEN_A: hipLaunchKernelGGL(k_minimizer_generic<1>, dim3(pl.side_grid), dim3(64), 0, ctx->stream, sd); break;
+            case K_NT_A: hipLaunchKernelGGL(k_nthash_stream<1>, dim3(pl.side_grid), dim3(64), 0, ctx->stream, sd); break;
+            case K_SYN_A: hipLaunchKernelGGL(k_syncmer<1>, dim3(pl.side_grid), dim3(64), 0, ctx->stream, sd); break;
+            case K_KMER_A: hipLaunchKernelGGL(k_kmer<1>, dim3(pl.side_grid), dim3(64), 0, ctx->stream, sd); break;
+            case K_SIM_A: hipLaunchKernelGGL(k_simhash<1>, dim3(pl.side_grid), dim3(64), 0, ctx->stream, sd); break;
+            default: ctx->err = "mixed plan without an ASCII kernel"; return BSK_ERR_DEVICE;
+        }
+    }
     if (ev1) HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
     HIPCHK(ctx, hipGetLastError());
     return BSK_OK;
@@ -1161,26 +1260,29 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
 
 // capacity guess (tuples) for the dense kernels; an undershoot is detected on device and the call re-runs
 // with the exact size
+static u64 estimate_cap_n(const bsk_params *p, u64 bases, u64 nreads);
 static u64 estimate_cap(const bsk_batch *b, const bsk_params *p, int circ_ext) {
-    const u64 bases = b->n_bases + b->n * (u64)circ_ext;
+    return estimate_cap_n(p, b->n_bases + b->n * (u64)circ_ext, b->n);
+}
+static u64 estimate_cap_n(const bsk_params *p, u64 bases, u64 nreads) {
     switch (p->kind) {
         case BSK_MINIMIZER:
         case BSK_PROT_MINIMIZER: {
             if (p->w <= 1) return bases + 64;
             double d = 2.6 / (p->w + 1.0);
             if (d > 1.0) d = 1.0;
-            return (u64)(bases * d) + b->n + 1024;
+            return (u64)(bases * d) + nreads + 1024;
         }
         case BSK_SYNCMER: {
             if (p->s == p->k) return bases + 64;
             double d = 2.6 / (p->k - p->s + 1.0);
             if (d > 1.0) d = 1.0;
-            return (u64)(bases * d) + b->n + 1024;
+            return (u64)(bases * d) + nreads + 1024;
         }
-        case BSK_NTHASH: return bases + 16 * b->n + 64;  // runs are padded to whole 128-byte lines
-        case BSK_KMER: return (p->canonical ? 1 : 2) * bases + 16 * b->n + 64;
+        case BSK_NTHASH: return bases + 16 * nreads + 64;  // runs are padded to whole 128-byte lines
+        case BSK_KMER: return (p->canonical ? 1 : 2) * bases + 16 * nreads + 64;
         case BSK_PROT_HASH:
-        case BSK_SIMHASH: return bases + 16 * b->n + 64;
+        case BSK_SIMHASH: return bases + 16 * nreads + 64;
         default: return bases + 64;
     }
 }
@@ -1207,24 +1309,33 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
     u64 ovf_cap = pl.slab ? std::max<u64>(65536, pl.slab_total / 50) : 0;
     if (pl.slab && *result && (*result)->ovf_cap > ovf_cap) ovf_cap = (*result)->ovf_cap;
     u64 cap = pl.slab ? pl.slab_total + ovf_cap : estimate_cap(b, p, circ_ext);
-    if (*result && (*result)->cap > cap) cap = (*result)->cap;
+    u64 side_cap = pl.mixed ? estimate_cap_n(p, b->nsub * (u64)b->maxlen, b->nsub) : 0;  // maxlen already includes a circular extension
+    if (*result && pl.mixed && (*result)->main_cap) {
+        cap = std::max(cap, (*result)->main_cap);
+        side_cap = std::max(side_cap, (*result)->cap - (*result)->main_cap);
+    } else if (*result && !pl.mixed && (*result)->cap > cap) {
+        cap = (*result)->cap;
+    }
     // bsk_sketch always runs (and sizes) once; bsk_sketch_timed on an existing result only repeats the launch
     const bool sizing = *result == nullptr || warmup + iters == 0;
     for (int attempt = 0; sizing && attempt < 3; ++attempt) {
-        rc = result_prepare(ctx, result, b->n, p->kind, cap);
+        rc = result_prepare(ctx, result, b->n, p->kind, cap + side_cap);
         if (rc != BSK_OK) return cleanup(rc);
         bsk_result *res = *result;
-        res->ovf_cap = pl.slab ? res->cap - pl.slab_total : 0;
+        res->main_cap = pl.mixed ? cap : 0;
+        res->ovf_cap = pl.slab ? (pl.mixed ? cap : res->cap) - pl.slab_total : 0;
         rc = launch(ctx, b, p, res, circ_ext, pl, nullptr, nullptr);
         if (rc != BSK_OK) return cleanup(rc);
-        hipError_t e = hipMemcpyAsync(ctx->h_pinned, ctx->d_total, 2 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_pinned + 2, ctx->d_ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e = hipMemcpyAsync(ctx->h_pinned, ctx->d_total, 4 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_pinned + 4, ctx->d_ticket, 4 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) return cleanup(fail_hip(ctx, e, "bsk_sketch run"));
-        const u64 total = ctx->h_pinned[0], ovf_used = ctx->h_pinned[1];
-        const u32 ovf = ((u32 *)(ctx->h_pinned + 2))[1];
+        const u64 total = ctx->h_pinned[0], ovf_used = ctx->h_pinned[1], side_end = ctx->h_pinned[2];
+        const u32 ovf = ((u32 *)(ctx->h_pinned + 4))[1], side_ovf = ((u32 *)(ctx->h_pinned + 4))[3];
         res->n_tuples = total;
-        if (!ovf) break;
+        if (!ovf && !side_ovf) break;
+        if (side_ovf && attempt < 2) side_cap = side_end - res->main_cap + 64;  // dense side kernel: its end is exact even when it overflowed
+        if (!ovf && attempt < 2) continue;
         if (attempt == 2) {
             ctx->err = "result capacity overflow after exact re-size";
             return cleanup(BSK_ERR_DEVICE);
@@ -1239,7 +1350,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         }
         cap = pl.slab ? pl.slab_total + ovf_used + ovf_used / 4 + 65536 : total + 64;  // size known now: re-run once
     }
-    if (sizing && (pl.slab || pl.which == K_NT_FAST || pl.which == K_PROT_HASH_FAST || pl.which == K_SIM_FAST) && b->n) {  // slab / line-padded kernels: sum the per-read counts once
+    if (sizing && (pl.mixed || pl.slab || pl.which == K_NT_FAST || pl.which == K_PROT_HASH_FAST || pl.which == K_SIM_FAST) && b->n) {  // slab / line-padded kernels: sum the per-read counts once
         HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, sizeof(u64), ctx->stream));
         hipLaunchKernelGGL(k_sum_counts, dim3(grid_for(ctx, b->n, 256)), dim3(256), 0, ctx->stream, (*result)->refs, b->n, ctx->d_total);
         hipError_t e = hipMemcpyAsync(ctx->h_pinned, ctx->d_total, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
@@ -1270,9 +1381,9 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         }
     }
     if (warmup + iters > 0) {
-        hipError_t e = hipMemcpyAsync(ctx->h_pinned + 2, ctx->d_ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e = hipMemcpyAsync(ctx->h_pinned + 2, ctx->d_ticket, 4 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e == hipSuccess && ((u32 *)(ctx->h_pinned + 2))[1]) {
+        if (e == hipSuccess && (((u32 *)(ctx->h_pinned + 2))[1] | ((u32 *)(ctx->h_pinned + 2))[3])) {
             drop_events();
             ctx->err = "result too small for this batch: call bsk_sketch first";
             return cleanup(BSK_ERR_ARG);
@@ -1593,6 +1704,13 @@ static int make_circular(bsk_ctx *ctx, const bsk_batch *b, int k, bsk_batch **ou
     if (e != hipSuccess) {
         bsk_batch_destroy(t);
         return fail_hip(ctx, e, "make_circular");
+    }
+    if (t->ascii) {
+        const int rc = build_subset(ctx, t);
+        if (rc != BSK_OK) {
+            bsk_batch_destroy(t);
+            return rc;
+        }
     }
     *out = t;
     return BSK_OK;

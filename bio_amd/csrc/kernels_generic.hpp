@@ -45,7 +45,19 @@ struct KArgs {
     u64 slab_read;  // per-sequence slab kernels (protein): tuples reserved per sequence
     u64 ovf_base;   // slab kernels: first tuple index of the overflow region, and its size
     u64 ovf_cap;
+    // side launch over a subset of the reads (the reads with a non-ACGT letter of an otherwise 2-bit batch): unit u holds
+    // reads subset[64u .. 64u+63]; their tuples go to [out_base, cap)
+    const u32 *subset;
+    u64 nsub;
+    u64 out_base;
 };
+
+// read handled by (unit, lane): the batch position, or the subset entry of a side launch (~0 = no read)
+__device__ __forceinline__ u64 read_index(const KArgs &a, u32 unit, int lane) {
+    const u64 i = (u64)unit * 64 + lane;
+    if (!a.subset) return i;
+    return i < a.nsub ? (u64)a.subset[i] : ~0ULL;
+}
 
 // byte range of read r in the ASCII buffer
 __device__ __forceinline__ void ascii_span(const KArgs &a, u64 r, u64 &off, u64 &L) {
@@ -271,7 +283,7 @@ __device__ __forceinline__ u64 unit_epilogue(const KArgs &a, u32 unit, int lane,
     const u32 incl = wave_incl_scan_u32(c, lane);
     const u32 excl = incl - c;
     const u32 T = wave_bcast_u32(incl, 63);
-    const u64 base = lookback_exclusive(a.lookback, unit, (u64)T, lane);
+    const u64 base = a.out_base + lookback_exclusive(a.lookback, unit, (u64)T, lane);
     const bool ovf = base + T > a.cap;
     // A lane that selected more than CAP tuples could not stage them all: then the whole unit is
     // written by the DIRECT re-run instead (rare; the caller checks the same ballot).
@@ -321,7 +333,7 @@ __global__ __launch_bounds__(64) void k_minimizer_generic(KArgs a) {
     for (;;) {
         const u32 unit = next_ticket(a.ticket, lane);
         if (unit >= a.nunits) break;
-        const u64 r = (u64)unit * 64 + lane;
+        const u64 r = read_index(a, unit, lane);
         u64 off = 0, L = 0;
         if (r < a.n) {
             if (ENC) {
@@ -365,7 +377,7 @@ __global__ __launch_bounds__(64) void k_minimizer_generic(KArgs a) {
         }
         if (r < a.n) {
             u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
-            if (tie) sbyte |= BSK_ST_FIRST_WINDOW_TIE;
+            if (tie && ok) sbyte |= BSK_ST_FIRST_WINDOW_TIE;
             if (ok && a.rflags) sbyte |= a.rflags[r];
             a.status[r] = sbyte;
         }
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(64) void k_nthash_stream(KArgs a) {
     for (;;) {
         const u32 unit = next_ticket(a.ticket, lane);
         if (unit >= a.nunits) break;
-        const u64 r = (u64)unit * 64 + lane;
+        const u64 r = read_index(a, unit, lane);
         u64 off = 0, L = 0;
         if (r < a.n) {
             if (ENC) {
@@ -414,7 +426,7 @@ __global__ __launch_bounds__(64) void k_nthash_stream(KArgs a) {
         const u64 incl = wave_incl_scan_u64((u64)nk, lane);
         const u64 T = wave_bcast_u64(incl, 63);
         // fixed-length batch: every earlier unit holds exactly 64*nk values, no prefix chain needed
-        const u64 base = a.uniform_len ? (u64)unit * 64 * nk_max : lookback_exclusive(a.lookback, unit, T, lane);
+        const u64 base = a.out_base + (a.uniform_len ? (u64)unit * 64 * nk_max : lookback_exclusive(a.lookback, unit, T, lane));
         const bool ovf = base + T > a.cap;
         if (ovf && lane == 0) atomicOr(&a.ticket[1], 1u);
         if (r < a.n) a.refs[r] = ((base + incl - nk) << 24) | nk;

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64) void k_prot_minimizer(KArgs a) {
             src.init(a.ascii, off, L, a.k);
             window_pass<WySrc, CAP, true>(src, nk, nk_max, W, ring_h, ring_p, lane, st, c2, t2, a.hash, a.pos, base + excl);
         }
-        if (r < a.n) a.status[r] = (u8)((ok ? BSK_ST_OK : BSK_ST_SHORT) | (tie ? BSK_ST_FIRST_WINDOW_TIE : 0));
+        if (r < a.n) a.status[r] = (u8)((ok ? BSK_ST_OK : BSK_ST_SHORT) | ((tie && ok) ? BSK_ST_FIRST_WINDOW_TIE : 0));
     }
 }
 
@@ -160,7 +160,7 @@ __device__ __forceinline__ bool stream_prologue(const KArgs &a, u32 unit, int la
     nk_max = wave_max_u32(nk);
     const u64 incl = wave_incl_scan_u64((u64)nk, lane);
     const u64 T = wave_bcast_u64(incl, 63);
-    const u64 base = lookback_exclusive(a.lookback, unit, T, lane);
+    const u64 base = a.out_base + lookback_exclusive(a.lookback, unit, T, lane);
     const bool ovf = base + T > a.cap;
     if (ovf && lane == 0) atomicOr(&a.ticket[1], 1u);
     if (r < a.n) {
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64) void k_kmer(KArgs a) {
     for (;;) {
         const u32 unit = next_ticket(a.ticket, lane);
         if (unit >= a.nunits) break;
-        const u64 r = (u64)unit * 64 + lane;
+        const u64 r = read_index(a, unit, lane);
         u64 off = 0, L = 0;
         if (r < a.n) {
             if (ENC) {
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64) void k_simhash(KArgs a) {
     for (;;) {
         const u32 unit = next_ticket(a.ticket, lane);
         if (unit >= a.nunits) break;
-        const u64 r = (u64)unit * 64 + lane;
+        const u64 r = read_index(a, unit, lane);
         u64 off = 0, L = 0;
         if (r < a.n) {
             if (ENC) {
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(64) void k_syncmer(KArgs a) {
     for (;;) {
         const u32 unit = next_ticket(a.ticket, lane);
         if (unit >= a.nunits) break;
-        const u64 r = (u64)unit * 64 + lane;
+        const u64 r = read_index(a, unit, lane);
         u64 off = 0, L = 0;
         if (r < a.n) {
             if (ENC) {
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(64) void k_syncmer(KArgs a) {
         }
         if (r < a.n) {
             u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
-            if (tie) sbyte |= BSK_ST_FIRST_WINDOW_TIE;
+            if (tie && ok) sbyte |= BSK_ST_FIRST_WINDOW_TIE;
             if (ok && a.rflags) sbyte |= a.rflags[r];
             a.status[r] = sbyte;
         }

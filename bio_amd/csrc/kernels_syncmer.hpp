@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves p
         if (r < a.n) {
             a.refs[r] = ((base + excl) << 24) | cnt;
             u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
-            if (tie) sbyte |= BSK_ST_FIRST_WINDOW_TIE;
+            if (tie && ok) sbyte |= BSK_ST_FIRST_WINDOW_TIE;
             if (ok && a.rflags) sbyte |= a.rflags[r];
             a.status[r] = sbyte;
         }

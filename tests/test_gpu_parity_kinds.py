@@ -277,3 +277,48 @@ def test_protein_constructors_on_dna_seq(engine, oracle):
         S.NewProteinIterator(seq, 9, 7, 1, engine)
     with pytest.raises(S.DeviceError, match="frame"):
         S.NewProteinIterator(seq, 9, 1, 0, engine)
+
+
+@pytest.mark.parametrize("frac", [0.01, 0.2, 0.6])
+def test_mixed_batches_fast_kernels_plus_ascii_side_launch(engine, oracle, frac):
+    """A batch where a few reads carry N / IUPAC letters: the 2-bit fast kernels run over everything and the general ASCII
+    kernels re-do the flagged reads in a side launch (frac <= 1/4), otherwise the whole batch runs on the ASCII kernels.
+    Either way every read must equal the oracle; BSK_NO_MIXED forces the second form for comparison of the digests."""
+    import os
+    rng = random.Random(int(frac * 1000))
+    seqs = []
+    for i in range(3000):
+        n = rng.choice([150, 150, rng.randint(1, 300)])
+        bad = rng.random() < frac
+        seqs.append(rand_seq(rng, n, "ACGTN" if bad and i % 2 else ("ACGTRYKMacgtn" if bad else "ACGT")))
+    b = engine.batch(seqs)
+    cases = [(L.MINIMIZER, dict(k=21, w=11), lambda q: oracle.minimizer(q, 21, 11, False, closed=True)[:2]),
+             (L.MINIMIZER, dict(k=15, w=7), lambda q: oracle.minimizer(q, 15, 7, False, closed=True)[:2]),      # generic w: no mixed plan
+             (L.SYNCMER, dict(k=31, s=11), lambda q: oracle.syncmer(q, 31, 11, False, closed=True)[:2]),
+             (L.NTHASH, dict(k=21), lambda q: (oracle.nthash(q, 21, True)[0], None)),
+             (L.KMER, dict(k=21), lambda q: (oracle.kmer_codes(q, 21, True, False), None)),
+             (L.SIMHASH, dict(k=21, m=5, scale=5), lambda q: (oracle.simhash(q, 21, 5, 5, True), None)),
+             (L.MINIMIZER, dict(k=11, w=5, circular=True), lambda q: oracle.minimizer(q, 11, 5, True, closed=True)[:2])]
+    for kind, pk, fn in cases:
+        res = engine.run(b, engine.params(kind, **pk))
+        for i, q in enumerate(seqs):
+            st, h, p = res.read(i)
+            try:
+                eh, ep = fn(q)
+            except oracle.OracleError as e:
+                assert e.name in ("ErrShortSeq", "ErrIllegalBase"), e.name
+                if e.name == "ErrShortSeq":
+                    assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0, (kind, i)
+                continue
+            assert np.array_equal(h, eh), (kind, pk, i, q)
+            if ep is not None:
+                assert np.array_equal(p & L.POS_MASK, ep), (kind, pk, i)
+            if kind != L.KMER:  # k-mer codes map IUPAC letters to a base (kmers.go:23-40): no flag there
+                assert bool(st & L.ST_HAS_NON_ACGT) == any(c not in "ACGTacgt" for c in q) or len(q) == 0, (kind, i, q, st)
+        d1 = res.digest()
+        os.environ["BSK_NO_MIXED"] = "1"
+        try:
+            d2 = engine.run(b, engine.params(kind, **pk)).digest()
+        finally:
+            del os.environ["BSK_NO_MIXED"]
+        assert d1 == d2, (kind, pk)
