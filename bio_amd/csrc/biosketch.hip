@@ -56,6 +56,7 @@ struct bsk_batch {
     u64 *llen = nullptr;   // [n] bases
     u64 *adesc = nullptr;  // tile batches over ASCII: (first_byte << 24) | n_bases per tile
     bool alias = false;    // words / ascii belong to another batch (tile batches)
+    u32 *wbits = nullptr;  // one bit per packed word: the word holds a non-ACGT letter (batches that may be tiled)
     u32 *subset = nullptr; // reads with a non-ACGT letter, ascending (side launch of the ASCII kernels); nsub = n_nonacgt
     u64 nsub = 0;
     u8 *rflags = nullptr;
@@ -128,7 +129,7 @@ __global__ void k_synth_protein(u8 *ascii, u64 *aoff, u64 n, u32 len, u64 seed) 
 // ASCII -> 2-bit words.  One thread per output word; the owning read is found by a
 // binary search over desc[] (first_word is monotone).  Not on the hot path.
 __global__ void k_pack(const u8 *ascii, const u64 *aoff, const u64 *desc, const u64 *fw, u64 n, u64 n_words, u32 *words, u8 *rflags,
-                       u32 *nonacgt_reads) {
+                       u32 *nonacgt_reads, u32 *wbits) {
     for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < n_words; g += (u64)gridDim.x * blockDim.x) {
         u64 lo = 0, hi = n - 1;  // largest r with first_word[r] <= g  (reads with 0 words share a first_word: take the last)
         while (lo < hi) {
@@ -152,6 +153,7 @@ __global__ void k_pack(const u8 *ascii, const u64 *aoff, const u64 *desc, const 
         }
         words[g] = v;
         if (bad) {
+            if (wbits) atomicOr(&wbits[g >> 5], 1u << (g & 31));
             if (rflags[lo] == 0) atomicAdd(nonacgt_reads, 1u);  // approximate under races; recounted on host
             rflags[lo] = BSK_ST_HAS_NON_ACGT;
         }
@@ -378,12 +380,17 @@ extern "C" void bsk_batch_destroy(bsk_batch *b) {
     (void)hipFree(b->llen);
     (void)hipFree(b->adesc);
     (void)hipFree(b->subset);
+    (void)hipFree(b->wbits);
     (void)hipFree(b->rflags);
     (void)hipFree(b->aoff);
     delete b;
 }
 
 static u64 pad_words(u32 maxlen) { return (u64)maxlen / 16 + 8; }
+static u32 env_u32(const char *name, u32 dflt) {
+    const char *v = getenv(name);
+    return v && *v ? (u32)strtoul(v, nullptr, 10) : dflt;
+}
 static int build_subset(bsk_ctx *ctx, bsk_batch *b);
 
 extern "C" int bsk_batch_from_ascii(bsk_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet,
@@ -457,9 +464,13 @@ extern "C" int bsk_batch_from_ascii(bsk_ctx *ctx, const uint8_t *bytes, const ui
         BCHK(hipMemsetAsync(b->rflags, 0, n ? n : 1, ctx->stream));
         if (n) BCHK(hipMemcpyAsync(wide ? b->fw : b->desc, desc.data(), n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
         BCHK(hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream));
+        if (maxlen > env_u32("BSK_TILE_MIN", 4096) && w) {  // this batch will be tiled: remember which words hold non-ACGT letters
+            BCHK(hipMalloc(&b->wbits, ((w + 31) / 32) * sizeof(u32)));
+            BCHK(hipMemsetAsync(b->wbits, 0, ((w + 31) / 32) * sizeof(u32), ctx->stream));
+        }
         if (n && w) {
             hipLaunchKernelGGL(k_pack, dim3(grid_for(ctx, w, 256)), dim3(256), 0, ctx->stream, b->ascii, b->aoff, b->desc, b->fw, n, w,
-                               b->words, b->rflags, ctx->d_ticket);
+                               b->words, b->rflags, ctx->d_ticket, b->wbits);
             hipLaunchKernelGGL(k_count_flags, dim3(grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, b->rflags, n,
                                ctx->d_ticket + 1);
         }
@@ -883,7 +894,7 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
     const bool has_n = b->alphabet == BSK_ALPHA_DNA && b->n_nonacgt > 0;
     // few reads with a non-ACGT letter: plan the batch as 2-bit; if that lands on a fast kernel, the flagged reads are
     // re-done by the general ASCII kernel in a side launch.  Otherwise the whole batch runs on the ASCII kernels.
-    if (has_n && b->subset && b->nsub * 4 <= b->n && !getenv("BSK_NO_MIXED") && !b->adesc) {
+    if (has_n && b->subset && b->nsub * 4 <= b->n && !getenv("BSK_NO_MIXED")) {
         Plan t;
         int rc = make_plan_enc(ctx, b, p, t, false);
         if (rc != BSK_OK) return rc;
@@ -1240,6 +1251,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         sd.out_base = res->main_cap;
         sd.cap = res->cap;
         sd.uniform_len = 0;
+        sd.inplace = !kind_has_pos(p->kind);  // stream kinds: overwrite the read's own run, keep the layout contiguous
         sd.ticket = ctx->d_ticket + 2;
         sd.total = ctx->d_total + 2;
         sd.ring_w = pl.side_ring_w;
@@ -1309,7 +1321,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
     u64 ovf_cap = pl.slab ? std::max<u64>(65536, pl.slab_total / 50) : 0;
     if (pl.slab && *result && (*result)->ovf_cap > ovf_cap) ovf_cap = (*result)->ovf_cap;
     u64 cap = pl.slab ? pl.slab_total + ovf_cap : estimate_cap(b, p, circ_ext);
-    u64 side_cap = pl.mixed ? estimate_cap_n(p, b->nsub * (u64)b->maxlen, b->nsub) : 0;  // maxlen already includes a circular extension
+    u64 side_cap = (pl.mixed && kind_has_pos(p->kind)) ? estimate_cap_n(p, b->nsub * (u64)b->maxlen, b->nsub) : 0;  // maxlen already includes a circular extension
     if (*result && pl.mixed && (*result)->main_cap) {
         cap = std::max(cap, (*result)->main_cap);
         side_cap = std::max(side_cap, (*result)->cap - (*result)->main_cap);
@@ -1398,11 +1410,6 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
 // ------------------------------------------------------------------------------------
 // long sequences: tile, run the ordinary kernels over the tiles, stitch (kernels_tile.hpp)
 // ------------------------------------------------------------------------------------
-static u32 env_u32(const char *name, u32 dflt) {
-    const char *v = getenv(name);
-    return v && *v ? (u32)strtoul(v, nullptr, 10) : dflt;
-}
-
 static bool kind_tiles(const bsk_params *p) {
     switch (p->kind) {
         case BSK_NTHASH:
@@ -1494,9 +1501,22 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, i
     TCHK(hipMalloc(&tt.seq, nta * 4));
     TCHK(hipMalloc(&tt.shift, nta * 8));
     TCHK(hipMalloc(&tt.keep, nta * 8));
+    u8 *tflags = nullptr;  // per tile: holds a non-ACGT letter (from the per-word bits of the batch); owned by tb later
+    if (use_ascii && b->wbits) {
+        TCHK(hipMalloc(&tflags, nta));
+        TCHK(hipMemsetAsync(tflags, 0, nta, ctx->stream));
+    }
     if (nt) {
-        hipLaunchKernelGGL(k_tile_build, dim3(grid_for(ctx, nt, 256)), dim3(256), 0, ctx->stream, seq, geo, tstart, nt, tt);
+        hipLaunchKernelGGL(k_tile_build, dim3(grid_for(ctx, nt, 256)), dim3(256), 0, ctx->stream, seq, geo, tstart, nt, tt, b->wbits, tflags);
         TCHK(hipGetLastError());
+    }
+    u64 n_bad_tiles = b->n_nonacgt;
+    if (tflags && nt) {
+        TCHK(hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream));
+        hipLaunchKernelGGL(k_count_flags, dim3(grid_for(ctx, nt, 256)), dim3(256), 0, ctx->stream, tflags, nt, ctx->d_ticket + 1);
+        TCHK(hipMemcpyAsync(ctx->h_pinned, ctx->d_ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+        TCHK(hipStreamSynchronize(ctx->stream));
+        n_bad_tiles = ((u32 *)ctx->h_pinned)[1];
     }
     tb = new (std::nothrow) bsk_batch();
     if (!tb) return done(BSK_ERR_NOMEM);
@@ -1508,7 +1528,12 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, i
     tb->ascii = b->ascii;
     tb->desc = tt.desc;
     tb->adesc = tt.adesc;
-    tb->n_nonacgt = b->n_nonacgt;
+    tb->n_nonacgt = n_bad_tiles;
+    tb->rflags = tflags;  // NULL: no per-tile knowledge, every tile runs on the ASCII kernels
+    if (tflags && n_bad_tiles && nt < (1ULL << 32)) {
+        rc = build_subset(ctx, tb);
+        if (rc != BSK_OK) return done(rc);
+    }
     const u64 over = p->kind == BSK_MINIMIZER ? 2ULL * p->w + p->k + 16 : p->kind == BSK_SYNCMER ? 3ULL * p->k + 16 : (u64)p->k;
     tb->maxlen = (u32)std::min<u64>((u64)geo.tp + over, (u64)b->maxlen);
     tb->n_bases = nt * tb->maxlen;  // upper bound: sizes the first capacity guess

@@ -50,6 +50,7 @@ struct KArgs {
     const u32 *subset;
     u64 nsub;
     u64 out_base;
+    int inplace;  // side launch of a stream kind: every read already owns its line-padded run (refs of the main launch)
 };
 
 // read handled by (unit, lane): the batch position, or the subset entry of a side launch (~0 = no read)
@@ -426,18 +427,25 @@ __global__ __launch_bounds__(64) void k_nthash_stream(KArgs a) {
         const u64 incl = wave_incl_scan_u64((u64)nk, lane);
         const u64 T = wave_bcast_u64(incl, 63);
         // fixed-length batch: every earlier unit holds exactly 64*nk values, no prefix chain needed
-        const u64 base = a.out_base + (a.uniform_len ? (u64)unit * 64 * nk_max : lookback_exclusive(a.lookback, unit, T, lane));
-        const bool ovf = base + T > a.cap;
-        if (ovf && lane == 0) atomicOr(&a.ticket[1], 1u);
-        if (r < a.n) a.refs[r] = ((base + incl - nk) << 24) | nk;
-        if (unit == a.nunits - 1 && lane == 63) *a.total = base + incl;
+        u64 first = 0;
+        bool ovf = false;
+        if (a.inplace) {
+            if (r < a.n) first = a.refs[r] >> 24;
+        } else {
+            const u64 base = a.out_base + (a.uniform_len ? (u64)unit * 64 * nk_max : lookback_exclusive(a.lookback, unit, T, lane));
+            ovf = base + T > a.cap;
+            if (ovf && lane == 0) atomicOr(&a.ticket[1], 1u);
+            if (unit == a.nunits - 1 && lane == 63) *a.total = base + incl;
+            first = base + incl - nk;
+        }
+        if (r < a.n) a.refs[r] = (first << 24) | nk;
         if (r < a.n) {
             u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
             if (ok && a.rflags) sbyte |= a.rflags[r];
             a.status[r] = sbyte;
         }
         if (ovf || nk_max == 0) continue;
-        s_off[lane] = base + incl - nk;
+        s_off[lane] = first;
         s_nk[lane] = nk;
         NtPacked sp;
         NtAscii sa;

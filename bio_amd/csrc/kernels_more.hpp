@@ -160,16 +160,23 @@ __device__ __forceinline__ bool stream_prologue(const KArgs &a, u32 unit, int la
     nk_max = wave_max_u32(nk);
     const u64 incl = wave_incl_scan_u64((u64)nk, lane);
     const u64 T = wave_bcast_u64(incl, 63);
-    const u64 base = a.out_base + lookback_exclusive(a.lookback, unit, T, lane);
-    const bool ovf = base + T > a.cap;
-    if (ovf && lane == 0) atomicOr(&a.ticket[1], 1u);
+    u64 first = 0;
+    bool ovf = false;
+    if (a.inplace) {  // side launch: the run the main launch reserved for this read
+        if (r < a.n) first = a.refs[r] >> 24;
+    } else {
+        const u64 base = a.out_base + lookback_exclusive(a.lookback, unit, T, lane);
+        ovf = base + T > a.cap;
+        if (ovf && lane == 0) atomicOr(&a.ticket[1], 1u);
+        if (unit == a.nunits - 1 && lane == 63) *a.total = base + incl;
+        first = base + incl - nk;
+    }
     if (r < a.n) {
-        a.refs[r] = ((base + incl - nk) << 24) | nk;
+        a.refs[r] = (first << 24) | nk;
         a.status[r] = sbyte;
     }
-    if (unit == a.nunits - 1 && lane == 63) *a.total = base + incl;
     if (ovf || nk_max == 0) return false;
-    s_off[lane] = base + incl - nk;
+    s_off[lane] = first;
     s_nk[lane] = nk;
     wave_sync_lds();
     return true;

@@ -77,7 +77,7 @@ struct TileTab {
     u64 *keep;    // [nt] lo | hi << 32: tile-local positions [lo, hi) belong to this tile
 };
 
-__global__ void k_tile_build(SeqTab seq, TileGeo g, const u64 *tstart, u64 nt, TileTab t) {
+__global__ void k_tile_build(SeqTab seq, TileGeo g, const u64 *tstart, u64 nt, TileTab t, const u32 *wbits, u8 *tflags) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += (u64)gridDim.x * blockDim.x) {
         u64 lo = 0, hi = seq.n - 1;  // largest r with tstart[r] <= i (sequences without tiles share their successor's start)
         while (lo < hi) {
@@ -107,6 +107,12 @@ __global__ void k_tile_build(SeqTab seq, TileGeo g, const u64 *tstart, u64 nt, T
         t.seq[i] = (u32)r;
         t.shift[i] = a0;
         t.keep[i] = (P0 - a0) | ((P1 - a0) << 32);
+        if (tflags) {  // any packed word of the tile marked by k_pack?
+            const u64 w0 = seq_first_word(seq, r) + (a0 >> 4), w1 = w0 + ((Lt + 15) >> 4);
+            u32 any = 0;
+            for (u64 w = w0; w < w1; ++w) any |= (wbits[w >> 5] >> (w & 31)) & 1u;
+            tflags[i] = any ? (u8)BSK_ST_HAS_NON_ACGT : (u8)0;
+        }
     }
 }
 

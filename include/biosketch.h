@@ -213,7 +213,7 @@ int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t first, uint64_t
 /* Device pointers (valid until release / next bsk_sketch on this result); refs[] as described above.
  * Long sequences: when a DNA batch holds a sequence longer than the tile threshold (4096 bases; always from 2^24
  * bases on) the engine cuts the sequences into overlapping tiles, runs the same kernels over the tiles and stitches
- * the tile results back (exactly the tuples of the un-tiled iterator; DESIGN.md section 2.4).  Such a result is
+ * the tile results back (exactly the tuples of the un-tiled iterator; DESIGN.md section 2.5).  Such a result is
  * "wide": a sequence can own more than 2^24 tuples, so *refs is NULL and bsk_result_device_wide returns
  * first[n] / count[n] instead (u64 each).  bsk_result_fetch / bsk_result_digest work for both layouts.
  * Not tiled (sequences of 2^24 bases or more are refused with BSK_ERR_UNSUPPORTED): the two-strand k-mer mode

@@ -216,3 +216,36 @@ def test_sequence_longer_than_2_pow_24(engine, oracle):
         engine.run(b, engine.params(L.KMER, 21, canonical=False))
     with pytest.raises(S.DeviceError):
         engine.run(b, engine.params(L.NTHASH, 21, circular=True))
+
+
+@pytest.mark.parametrize("tile_pos", [16, 48, 0])
+def test_tiles_with_sparse_non_acgt_use_the_mixed_plan(engine, oracle, tiny_tiles, tile_pos):
+    """Long sequences with a few N / IUPAC letters: only the tiles that touch them run on the ASCII kernels (per-word bits
+    from the packer -> per-tile flags -> side launch); stream kinds write those tiles' runs in place so the sequence's run
+    stays contiguous.  BSK_NO_MIXED gives the all-ASCII digest to compare with."""
+    tiny_tiles(40, tile_pos)
+    rng = random.Random(31 + tile_pos)
+    seqs = []
+    for n in (3000, 2500, 777, 5000, 64, 30):
+        q = list(rand_seq(rng, n))
+        for _ in range(max(1, n // 900)):
+            q[rng.randrange(n)] = rng.choice("NRYn")
+        seqs.append("".join(q))
+    seqs.append(rand_seq(rng, 4000))  # one clean sequence
+    check_sketch(engine, oracle, seqs, L.MINIMIZER, lambda q: oracle.minimizer(q, 21, 11, False, closed=True), k=21, w=11)
+    check_sketch(engine, oracle, seqs, L.SYNCMER, lambda q: oracle.syncmer(q, 31, 11, False, closed=True), k=31, s=11)
+    b = engine.batch(seqs)
+    for kind, pk, fn in ((L.NTHASH, dict(k=21), lambda q: oracle.nthash(q, 21, True)[0]),
+                         (L.KMER, dict(k=21), lambda q: oracle.kmer_codes(q, 21, True, False)),
+                         (L.SIMHASH, dict(k=21, m=5, scale=5), lambda q: oracle.simhash(q, 21, 5, 5, True))):
+        res = engine.run(b, engine.params(kind, **pk))
+        for i, q in enumerate(seqs):
+            _, h, _ = res.read(i)
+            assert np.array_equal(h, fn(q)), (kind, i, len(q))
+        d1 = res.digest()
+        os.environ["BSK_NO_MIXED"] = "1"
+        try:
+            d2 = engine.run(b, engine.params(kind, **pk)).digest()
+        finally:
+            del os.environ["BSK_NO_MIXED"]
+        assert d1 == d2
