@@ -66,7 +66,13 @@ SYMBOLS = [
     ("bsk_result_device_wide", C.c_int, [_vp, _pp, _pp]),
     ("bsk_result_digest", C.c_int, [_vp, _vp, _u64p, _u64p, _u64p]),
     ("bsk_result_release", None, [_vp]),
+    ("bsk_result_sets", C.c_int, [_vp, _vp, C.c_int, C.c_int, _pp]),
+    ("bsk_sets_info", C.c_int, [_vp, _u64p, _u64p]),
+    ("bsk_sets_fetch", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, _vp, C.c_uint64]),
+    ("bsk_sets_device", C.c_int, [_vp, _pp, _pp]),
+    ("bsk_sets_release", None, [_vp]),
 ]
+SETS_PER_SEQUENCE, SETS_WHOLE_BATCH = 0, 1
 
 _lib = None
 

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "biosketch.h"
+#include "host_types.hpp"
 #include "kernels_generic.hpp"
 #include "kernels_fast.hpp"
 #include "kernels_more.hpp"
@@ -23,79 +24,6 @@
 #include "kernels_simhash.hpp"
 
 using namespace bsk;
-
-// ------------------------------------------------------------------------------------
-struct bsk_ctx {
-    int device = 0;
-    int cus = 0;
-    hipStream_t stream = nullptr;
-    std::string err;
-    // per-launch synchronisation scratch
-    u32 *d_ticket = nullptr;    // [2]
-    u64 *d_total = nullptr;     // [1]
-    u64 *d_lookback = nullptr;  // [lookback_cap]
-    size_t lookback_cap = 0;
-    u64 *d_ring_h = nullptr;  // runtime-w ring scratch
-    u32 *d_ring_p = nullptr;
-    size_t ring_cap = 0;  // entries
-    u64 *h_pinned = nullptr;  // [8] pinned host words for small read-backs
-    u8 *d_lut = nullptr;      // codon tables of `lut_table` (kernels_translate.hpp layout)
-    int lut_table = 0;
-    bool no_prot_fast = false;  // set while a call falls back from the per-sequence-slab protein kernel
-};
-
-struct bsk_batch {
-    bsk_ctx *ctx = nullptr;
-    int alphabet = BSK_ALPHA_DNA;
-    u64 n = 0, n_bases = 0, n_words = 0, n_nonacgt = 0;
-    u32 maxlen = 0;
-    u32 uniform_len = 0;  // != 0: every read has this length (synthetic batches)
-    u32 *words = nullptr;
-    u64 *desc = nullptr;   // NULL when a sequence has 2^24 bases or more: fw + llen then locate the sequences (tiled runs only)
-    u64 *fw = nullptr;     // [n] first word
-    u64 *llen = nullptr;   // [n] bases
-    u64 *adesc = nullptr;  // tile batches over ASCII: (first_byte << 24) | n_bases per tile
-    bool alias = false;    // words / ascii belong to another batch (tile batches)
-    u32 *wbits = nullptr;  // one bit per packed word: the word holds a non-ACGT letter (batches that may be tiled)
-    u32 *subset = nullptr; // reads with a non-ACGT letter, ascending (side launch of the ASCII kernels); nsub = n_nonacgt
-    u64 nsub = 0;
-    u8 *rflags = nullptr;
-    u8 *ascii = nullptr;  // DNA: kept only when some read has a non-ACGT byte; protein: always
-    u64 *aoff = nullptr;
-    u64 device_bytes = 0;
-};
-
-struct bsk_result {
-    bsk_ctx *ctx = nullptr;
-    u64 n = 0, cap = 0, n_tuples = 0;
-    u64 ovf_cap = 0;  // slab kernels: tuples reserved (inside cap) for units that outgrow their slab
-    u64 main_cap = 0; // tuples [0, main_cap) belong to the main launch, [main_cap, cap) to the side launch (mixed batches)
-    int kind = 0, has_pos = 0;
-    u64 *refs = nullptr;  // per read: (first_tuple << 24) | n_tuples ; NULL for wide results
-    u64 *wfirst = nullptr, *wcount = nullptr;  // wide results (tiled long sequences): first tuple and tuple count per sequence
-    u8 *status = nullptr;
-    u64 *hash = nullptr;
-    u32 *pos = nullptr;
-};
-
-static int fail_hip(bsk_ctx *ctx, hipError_t e, const char *what) {
-    if (ctx) {
-        char buf[512];
-        snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
-        ctx->err = buf;
-    }
-    (void)hipGetLastError();
-    return e == hipErrorOutOfMemory ? BSK_ERR_NOMEM : BSK_ERR_DEVICE;
-}
-static int fail_arg(bsk_ctx *ctx, const char *what) {
-    if (ctx) ctx->err = what;
-    return BSK_ERR_ARG;
-}
-#define HIPCHK(ctx, call)                                        \
-    do {                                                         \
-        hipError_t e__ = (call);                                 \
-        if (e__ != hipSuccess) return fail_hip(ctx, e__, #call); \
-    } while (0)
 
 // ------------------------------------------------------------------------------------
 // utility kernels

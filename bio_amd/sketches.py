@@ -150,6 +150,22 @@ class BatchResult:
                                                     pos.ctypes.data if pos is not None else None, max(T, 1)))
         return offs, status[:count], hash_[:T], (pos[:T] if pos is not None else None)
 
+    def sets(self, whole_batch: bool = False, scale: int = 1):
+        """Sorted distinct hash values per sequence (or of the whole batch), optionally FracMinHash-filtered
+        (bsk_result_sets) -> (offsets[n_sets+1], values)."""
+        h = C.c_void_p()
+        self.eng._chk(self.eng.lib.bsk_result_sets(self.eng.ctx, self.h, L.SETS_WHOLE_BATCH if whole_batch else L.SETS_PER_SEQUENCE, scale,
+                                                   C.byref(h)))
+        try:
+            ns, nv = C.c_uint64(), C.c_uint64()
+            self.eng._chk(self.eng.lib.bsk_sets_info(h, C.byref(ns), C.byref(nv)))
+            offs = np.zeros(ns.value + 1, np.uint64)
+            vals = np.zeros(max(nv.value, 1), np.uint64)
+            self.eng._chk(self.eng.lib.bsk_sets_fetch(self.eng.ctx, h, 0, ns.value, offs.ctypes.data, vals.ctypes.data, vals.size))
+            return offs, vals[: nv.value]
+        finally:
+            self.eng.lib.bsk_sets_release(h)
+
     def digest(self):
         ck, nt = C.c_uint64(), C.c_uint64()
         sc = (C.c_uint64 * 4)()

@@ -229,6 +229,21 @@ int bsk_result_digest(bsk_ctx *ctx, const bsk_result *r, uint64_t *checksum, uin
                       uint64_t status_counts[4]);
 void bsk_result_release(bsk_result *r);
 
+/* ---- sketch sets ----------------------------------------------------
+ * The distinct hash values of a result in ascending order -- what the reference's consumers (kmcp, unikmer) build from
+ * the Next() stream of a sketch and keep on disk: collect, sort, de-duplicate.  scope: one set per sequence or one set
+ * for the whole batch.  scale > 1: FracMinHash, keep hash <= MaxUint64/scale (the rule of iterator.go:181-185).
+ * Computed on the device (rocPRIM segmented radix sort + scan); offsets[n_sets+1] and values[] stay there until
+ * bsk_sets_release.  At most 2^32 values per call. */
+typedef struct bsk_sets bsk_sets;
+enum { BSK_SETS_PER_SEQUENCE = 0, BSK_SETS_WHOLE_BATCH = 1 };
+int bsk_result_sets(bsk_ctx *ctx, const bsk_result *r, int scope, int scale, bsk_sets **out);
+int bsk_sets_info(const bsk_sets *s, uint64_t *n_sets, uint64_t *n_values);
+int bsk_sets_fetch(bsk_ctx *ctx, const bsk_sets *s, uint64_t first, uint64_t count, uint64_t *offsets, uint64_t *values,
+                   uint64_t value_cap);
+int bsk_sets_device(const bsk_sets *s, const uint64_t **offsets, const uint64_t **values);
+void bsk_sets_release(bsk_sets *s);
+
 #ifdef __cplusplus
 }
 #endif

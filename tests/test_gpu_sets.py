@@ -1,0 +1,67 @@
+"""Sketch sets on the device (bsk_result_sets): sorted distinct hash values per sequence / per batch, FracMinHash filter."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from bio_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_seq(rng, n, alpha="ACGT"):
+    return "".join(rng.choice(alpha) for _ in range(n))
+
+
+def expect_sets(res, n, scale, whole):
+    maxhash = (2**64 - 1) // scale if scale > 1 else 2**64 - 1
+    per = []
+    for i in range(n):
+        _, h, _ = res.read(i)
+        per.append(np.unique(h[h <= np.uint64(maxhash)]))
+    if whole:
+        return [np.unique(np.concatenate(per)) if per else np.zeros(0, np.uint64)]
+    return per
+
+
+@pytest.mark.parametrize("kind,pk", [(L.MINIMIZER, dict(k=21, w=11)), (L.SYNCMER, dict(k=31, s=11)), (L.NTHASH, dict(k=21)),
+                                     (L.MINIMIZER, dict(k=5, w=3)), (L.KMER, dict(k=4))])
+@pytest.mark.parametrize("scale", [1, 7])
+def test_sets_equal_numpy_unique(engine, kind, pk, scale):
+    rng = random.Random(len(pk) * 10 + scale)
+    seqs = [rand_seq(rng, rng.choice([150, 150, rng.randint(1, 400)])) for _ in range(500)]
+    seqs += ["", "A" * 300, "AC" * 200, "ACGTTGCAACGT" * 30, rand_seq(rng, 200, "ACGTN")]  # heavy duplicates, empty sets
+    b = engine.batch(seqs)
+    res = engine.run(b, engine.params(kind, **pk))
+    for whole in (False, True):
+        offs, vals = res.sets(whole_batch=whole, scale=scale)
+        want = expect_sets(res, len(seqs), scale, whole)
+        assert len(offs) == len(want) + 1 and int(offs[-1]) == len(vals)
+        for i, w in enumerate(want):
+            got = vals[int(offs[i]):int(offs[i + 1])]
+            assert np.array_equal(got, w), (kind, pk, scale, whole, i, len(got), len(w))
+
+
+def test_sets_of_tiled_and_mixed_results(engine):
+    os.environ["BSK_TILE_MIN"] = "64"
+    try:
+        rng = random.Random(5)
+        seqs = [rand_seq(rng, 3000), rand_seq(rng, 40), rand_seq(rng, 1500)[:700] + "N" + rand_seq(rng, 800), rand_seq(rng, 5000)]
+        b = engine.batch(seqs)
+        for kind, pk in ((L.MINIMIZER, dict(k=15, w=8)), (L.NTHASH, dict(k=11))):
+            res = engine.run(b, engine.params(kind, **pk))  # wide (tiled) result
+            offs, vals = res.sets(scale=3)
+            for i, w in enumerate(expect_sets(res, len(seqs), 3, False)):
+                assert np.array_equal(vals[int(offs[i]):int(offs[i + 1])], w), (kind, i)
+    finally:
+        del os.environ["BSK_TILE_MIN"]
+
+
+def test_sets_empty_result(engine):
+    b = engine.batch(["ACGT", "", "AC"])
+    res = engine.run(b, engine.params(L.MINIMIZER, 21, w=11))  # everything too short
+    offs, vals = res.sets()
+    assert list(offs) == [0, 0, 0, 0] and len(vals) == 0
+    offs, vals = res.sets(whole_batch=True)
+    assert list(offs) == [0, 0] and len(vals) == 0
