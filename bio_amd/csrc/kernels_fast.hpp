@@ -515,7 +515,9 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
 
 // ---- dispatch table --------------------------------------------------------------------
 #define BSK_FAST_CAP 32
-#define BSK_FAST_WS(X) X(4) X(5) X(8) X(10) X(11) X(12) X(15) X(16)
+#define BSK_FAST_WS(X) \
+    X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) \
+    X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 
 static inline bool fast_minimizer_supported(int w) {
     switch (w) {

@@ -52,7 +52,7 @@ def test_reference_known_answer(engine):
 
 
 @pytest.mark.parametrize("k,w", [(21, 11), (5, 3), (31, 15), (15, 10), (1, 1), (7, 1), (3, 2), (33, 5), (64, 4), (70, 3),
-                                 (21, 40)])
+                                 (21, 40), (21, 7), (21, 13), (21, 17), (25, 19), (21, 32), (15, 2), (15, 24), (9, 28), (21, 33)])
 def test_minimizer_random(engine, oracle, k, w):
     rng = random.Random(k * 1000 + w)
     seqs = [rand_dna(rng, rng.choice([150, 150, 150, rng.randint(1, 300)])) for _ in range(300)]
