@@ -89,6 +89,7 @@ struct FastMin {
     u32 prev, cnt, tie;
     u32 slot;                          // byte offset (from SH) of this lane's next staging slot = (cnt*65 + lane)*8
     u32 in_lo, in_hi, out_lo, out_hi;  // packed words of the current block
+    u32 in_h2, out_h2;                 // W > 16: a block spans up to three words
 
     __device__ __forceinline__ void load_block_words(u32 i0) {
         const u32 t0 = i0 + (u32)k - 1;
@@ -97,6 +98,10 @@ struct FastMin {
         const u32 p0 = i0 ? i0 - 1 : 0;
         out_lo = w[p0 >> 4];
         out_hi = w[(p0 >> 4) + 1];
+        if (W > 16) {
+            in_h2 = w[(t0 >> 4) + 2];
+            out_h2 = w[(p0 >> 4) + 2];
+        }
     }
     __device__ __forceinline__ void roll(u32x4 x) {
         const u32 a = __builtin_amdgcn_alignbit(fl, fh_, 31), b = __builtin_amdgcn_alignbit(fh_, fl, 31);
@@ -116,11 +121,19 @@ struct FastMin {
         u32 coutb;
         if (FIRST) coutb = out_lo << 2;  // slot 0: nothing leaves; slot o >= 1 sees base o-1
         else coutb = __builtin_amdgcn_alignbit(out_hi, out_lo, ((i0 - 1) & 15) * 2);
+        u32 cinb2 = 0, coutb2 = 0;  // W > 16: codes of slots 16..31
+        if (W > 16) {
+            cinb2 = __builtin_amdgcn_alignbit(in_h2, in_hi, (t0 & 15) * 2);
+            if (FIRST) coutb2 = __builtin_amdgcn_alignbit(out_hi, out_lo, 30);  // slot 16 sees base 15, ...
+            else coutb2 = __builtin_amdgcn_alignbit(out_h2, out_hi, ((i0 - 1) & 15) * 2);
+        }
         u32x4 xs[W];
 #pragma unroll
         for (int o = 0; o < W; ++o) {  // byte offset into the table = out*64 + in*16 ; row "nothing leaves" = 256 + in*16
-            const u32 a = (o >= 2 ? (cinb >> (2 * o - 4)) : (cinb << (4 - 2 * o))) & 0x30u;
-            const u32 b = (FIRST && o == 0) ? 0x100u : ((o >= 3 ? (coutb >> (2 * o - 6)) : (coutb << (6 - 2 * o))) & 0xC0u);
+            const int q = o & 15;
+            const u32 ci = o < 16 ? cinb : cinb2, co = o < 16 ? coutb : coutb2;
+            const u32 a = (q >= 2 ? (ci >> (2 * q - 4)) : (ci << (4 - 2 * q))) & 0x30u;
+            const u32 b = (FIRST && o == 0) ? 0x100u : ((q >= 3 ? (co >> (2 * q - 6)) : (co << (6 - 2 * q))) & 0xC0u);
             xs[o] = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB + (a | b));
         }
         load_block_words(i0 + W);  // next block's words: in flight while this block is hashed
