@@ -21,7 +21,9 @@ def dna_set(rng, n=200):
 
 
 @pytest.mark.parametrize("k,s,circular", [(31, 11, False), (5, 2, False), (31, 16, False), (7, 7, False), (15, 14, False),
-                                          (21, 1, False), (11, 5, True), (64, 33, False)])
+                                          (21, 1, False), (11, 5, True), (64, 33, False), (21, 19, False), (21, 17, False), (15, 8, False),
+                                          (21, 12, False), (31, 19, False), (31, 17, False), (31, 13, False), (31, 7, False), (40, 23, False),
+                                          (12, 9, False), (20, 14, True), (21, 10, False), (27, 14, False)])
 def test_syncmer(engine, oracle, k, s, circular):
     rng = random.Random(1000 * k + s)
     seqs = dna_set(rng)
