@@ -392,7 +392,7 @@ extern "C" int bsk_batch_from_ascii(bsk_ctx *ctx, const uint8_t *bytes, const ui
         BCHK(hipMemsetAsync(b->rflags, 0, n ? n : 1, ctx->stream));
         if (n) BCHK(hipMemcpyAsync(wide ? b->fw : b->desc, desc.data(), n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
         BCHK(hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream));
-        if (maxlen > env_u32("BSK_TILE_MIN", 4096) && w) {  // this batch will be tiled: remember which words hold non-ACGT letters
+        if (maxlen > env_u32("BSK_TILE_MIN", 16u * (BSK_NT_FAST_WORDS - 2)) && w) {  // this batch may be tiled: remember which words hold non-ACGT letters
             BCHK(hipMalloc(&b->wbits, ((w + 31) / 32) * sizeof(u32)));
             BCHK(hipMemsetAsync(b->wbits, 0, ((w + 31) / 32) * sizeof(u32), ctx->stream));
         }
@@ -1573,7 +1573,7 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
         circ_ext = p->k - 1;
     }
     const bool tiled = b->alphabet == BSK_ALPHA_DNA && kind_tiles(p) && !getenv("BSK_NO_TILES") &&
-                       (!b->desc || b->maxlen > env_u32("BSK_TILE_MIN", 4096));
+                       (!b->desc || b->maxlen > env_u32("BSK_TILE_MIN", kind_has_pos(p->kind) ? 4096u : 16u * (BSK_NT_FAST_WORDS - 2)));
     rc = tiled ? sketch_tiled(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms)
                : run_planned(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms);
     if (tmp) bsk_batch_destroy(tmp);

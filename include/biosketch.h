@@ -211,7 +211,7 @@ int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t first, uint64_t
                      uint64_t *offsets, uint8_t *status, uint64_t *hash, uint32_t *pos,
                      uint64_t tuple_cap);
 /* Device pointers (valid until release / next bsk_sketch on this result); refs[] as described above.
- * Long sequences: when a DNA batch holds a sequence longer than the tile threshold (4096 bases; always from 2^24
+ * Long sequences: when a DNA batch holds a sequence longer than the tile threshold (4096 bases, 512 for the every-position kinds; always from 2^24
  * bases on) the engine cuts the sequences into overlapping tiles, runs the same kernels over the tiles and stitches
  * the tile results back (exactly the tuples of the un-tiled iterator).  Such a result is
  * "wide": a sequence can own more than 2^24 tuples, so *refs is NULL and bsk_result_device_wide returns
