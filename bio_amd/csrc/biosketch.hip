@@ -765,7 +765,7 @@ static int build_subset(bsk_ctx *ctx, bsk_batch *b) {
     (void)hipFree(b->subset);
     b->subset = nullptr;
     b->nsub = 0;
-    if (!b->n_nonacgt || !b->rflags || b->n >= (1ULL << 32)) return BSK_OK;
+    if (!b->n || !b->n_nonacgt || !b->rflags || b->n >= (1ULL << 32)) return BSK_OK;
     const u32 nunits = (u32)((b->n + 63) / 64);
     int rc = ensure_scratch(ctx, nunits, 0);
     if (rc != BSK_OK) return rc;
@@ -1438,7 +1438,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, i
         hipLaunchKernelGGL(k_tile_build, dim3(grid_for(ctx, nt, 256)), dim3(256), 0, ctx->stream, seq, geo, tstart, nt, tt, b->wbits, tflags);
         TCHK(hipGetLastError());
     }
-    u64 n_bad_tiles = b->n_nonacgt;
+    u64 n_bad_tiles = tflags ? 0 : b->n_nonacgt;  // with per-tile flags: counted below (no tiles, no flagged tiles)
     if (tflags && nt) {
         TCHK(hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream));
         hipLaunchKernelGGL(k_count_flags, dim3(grid_for(ctx, nt, 256)), dim3(256), 0, ctx->stream, tflags, nt, ctx->d_ticket + 1);
