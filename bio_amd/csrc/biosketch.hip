@@ -1266,6 +1266,10 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         res->ovf_cap = pl.slab ? (pl.mixed ? cap : res->cap) - pl.slab_total : 0;
         rc = launch(ctx, b, p, res, circ_ext, pl, nullptr, nullptr);
         if (rc != BSK_OK) return cleanup(rc);
+        if (pl.nunits == 0) {  // empty batch: nothing was launched, the scratch counters are stale
+            res->n_tuples = 0;
+            break;
+        }
         hipError_t e = hipMemcpyAsync(ctx->h_pinned, ctx->d_total, 4 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_pinned + 4, ctx->d_ticket, 4 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

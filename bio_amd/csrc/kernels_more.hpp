@@ -604,7 +604,11 @@ __global__ __launch_bounds__(64) void k_syncmer(KArgs a) {
         NtPacked sp;
         NtAscii sa;
         if (skip) {
-            cnt = nkk;
+            cnt = nkk;  // every k-mer is selected: stage positions 0..cnt-1 as pass 1 would (when they fit)
+            if (!__ballot(cnt > (u32)CAP)) {
+                for (u32 e = 0; e < nkk_max; ++e)
+                    if (e < cnt) st.sp[Stage<CAP>::slot(e, lane)] = e;
+            }
         } else if (ns_max) {
             if (ENC) {
                 sa.init(a.ascii, off, L, a.s, 1, s_tabs, s_tabs + 256);

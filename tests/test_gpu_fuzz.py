@@ -150,3 +150,28 @@ def run_case(engine, oracle, seed):
 def test_differential_fuzz(engine, oracle, block):
     for seed in range(block * 25, block * 25 + 25):
         run_case(engine, oracle, 0xF0220000 + seed)
+
+
+def test_regressions_found_by_the_fuzz_campaign(engine, oracle):
+    """(1) s == k syncmers of reads with few k-mers took the staged path without staged positions (GPU memory fault);
+    (2) a tiled run whose batch has no tile at all read stale device counters (bogus capacity, out of memory)."""
+    rng = random.Random(1)
+    seqs = ["".join(rng.choice("ACGT") for _ in range(n)) for n in (31, 32, 35, 40, 40, 30, 12, 0)]
+    b = engine.batch(seqs)
+    res = engine.run(b, engine.params(L.SYNCMER, 31, s=31))
+    for i, q in enumerate(seqs):
+        st, h, p = res.read(i)
+        try:
+            eh, ep, es, _ = oracle.syncmer(q, 31, 31, False, closed=True)
+        except oracle.OracleError:
+            assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0
+            continue
+        assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep)
+    os.environ["BSK_TILE_MIN"] = "40"
+    try:
+        for kind, pk in ((L.MINIMIZER, dict(k=31, w=16, circular=True)), (L.SYNCMER, dict(k=40, s=19, circular=True)),
+                         (L.NTHASH, dict(k=41, circular=True))):
+            res = engine.run(b, engine.params(kind, **pk))  # every read is too short: a tiled run without tiles
+            assert res.info()["n_tuples"] == 0 and all((res.read(i)[0] & L.ST_CODE_MASK) == L.ST_SHORT for i in range(len(seqs)))
+    finally:
+        del os.environ["BSK_TILE_MIN"]
