@@ -34,6 +34,7 @@ struct bsk_fastx {
     size_t r = 0, n = 0;       // unread part of buf: [r, n)
     bool eof = false, started = false, finished = false;
     int is_fastq = -1;
+    int pending = 0;  // error met after some records of a chunk were read: returned by the next call
     int alphabet = -2;  // -2 not guessed yet, -1 "Unlimit", else BSK_ALPHA_*
     uint8_t delim = 0;
     std::string rec;  // bytes of the record being collected (after its delimiter)
@@ -230,8 +231,9 @@ extern "C" int bsk_fastx_read_chunk(bsk_fastx *f, uint64_t max_records, uint64_t
     f->seq_off.assign(1, 0);
     f->name_off.assign(1, 0);
     uint64_t cnt = 0;
-    int rc = BSK_OK;
-    while ((max_records == 0 || cnt < max_records) && (max_bytes == 0 || f->seq.size() < max_bytes)) {
+    int rc = f->pending;
+    f->pending = 0;
+    while (rc == BSK_OK && (max_records == 0 || cnt < max_records) && (max_bytes == 0 || f->seq.size() < max_bytes)) {
         const int st = next_record(f);
         if (st == 0) break;
         if (st < 0) {
@@ -255,7 +257,11 @@ extern "C" int bsk_fastx_read_chunk(bsk_fastx *f, uint64_t max_records, uint64_t
     if (name_offsets) *name_offsets = f->name_off.data();
     if (f->is_fastq == 1 && f->qual.empty()) f->qual.push_back(0);
     if (qual_bytes) *qual_bytes = f->is_fastq == 1 ? f->qual.data() : nullptr;  // NULL = FASTA
-    return cnt ? BSK_OK : rc;  // an error after some records is reported by the next call
+    if (cnt && rc != BSK_OK) {  // hand out the good records now, the error with the next call
+        f->pending = rc;
+        rc = BSK_OK;
+    }
+    return rc;
 }
 
 extern "C" int bsk_batch_from_fastx(bsk_ctx *ctx, bsk_fastx *f, uint64_t max_records, uint64_t max_bytes, int alphabet, bsk_batch **out,

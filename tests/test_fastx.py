@@ -82,6 +82,8 @@ CASES = {
     "cr_first.fa": b"\r\n>a\nAC\n",
     "protein.fa": b">p1\nMKVLAAGIVGLLLAQW\n>p2\nMSTNPKPQRKTKRNTNRRPQDVKFPGG\n",
     "spaces_kept.fa": b">a\nAC GT\nTT-A\n",
+    # found by scripts/fuzz_fastx.py: an error that follows good records of the same chunk must not be lost
+    "error_after_records.fq": b"@r0\nCGGTTCAGGCGNAATNN\n+\n>#I@@55I+@+55@55>\n@r1\n\n+r1\n\n@@@\nNTCANTTCTNGTCNNCN\n+\n+#@##@#+@##III5@\n@@@\n\n+@@\n\n",
 }
 
 
