@@ -136,6 +136,27 @@ def run_case(engine, oracle, seed):
                 assert np.array_equal(p >> 31, es), (seed, kind, pk, env, i)
         d = res.digest()
         assert d["n_tuples"] == res.info()["n_tuples"], (seed, kind, pk, env)
+        if rng.random() < 0.3:  # sketch sets of the same result against numpy
+            whole, scale = rng.random() < 0.4, rng.choice([1, 1, 2, 9])
+            offs, vals = res.sets(whole_batch=whole, scale=scale)
+            maxhash = (2**64 - 1) // scale if scale > 1 else 2**64 - 1
+            per = []
+            for i in range(len(seqs)):
+                h = res.read(i)[1]
+                per.append(np.unique(h[h <= np.uint64(maxhash)]))
+            want = [np.unique(np.concatenate(per))] if whole else per
+            assert len(offs) == len(want) + 1, (seed, kind, pk, env)
+            for i, w_ in enumerate(want):
+                assert np.array_equal(vals[int(offs[i]):int(offs[i + 1])], w_), (seed, kind, pk, env, "sets", whole, scale, i)
+        if not protein and max((len(q) for q in seqs), default=0) < 5000 and rng.random() < 0.2:  # translation of the same batch
+            table, frame = rng.choice([1, 3, 11, 25]), rng.choice([1, 2, 3, -1, -2, -3])
+            t = b.translate(table, frame)
+            data, toffs = t.fetch_ascii(0, len(seqs))
+            for i, q in enumerate(seqs):
+                got = data[int(toffs[i]):int(toffs[i + 1])].tobytes().decode("latin-1")
+                want = oracle.translate(q, table, frame) if len(q) >= 3 else ""
+                assert got == want, (seed, "translate", table, frame, i, len(q))
+            t.close()
         res.close()
         b.close()
     finally:
