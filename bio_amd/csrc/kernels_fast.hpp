@@ -268,7 +268,7 @@ __device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 e
 }
 
 template <int W, int CAP, bool POS16>
-__global__ __launch_bounds__(64) void k_minimizer_fast(KArgs a) {
+__global__ __launch_bounds__(64, ((W > 16 && W <= 24) ? 2 : 1)) void k_minimizer_fast(KArgs a) {  // W 17..24: capped at 256 VGPRs (2 waves per SIMD, measured 1.1-1.5x); wider windows spill too much
     typedef FLds<CAP, POS16> LY;
     __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
     LDSQ char *const ldsq = (LDSQ char *)lds;
