@@ -179,14 +179,10 @@ __device__ __forceinline__ void flush_rows(char *lds, int lane, u32 cnt, bool la
             const u32 e = ((ui - s_excl[owner]) << ushift) | (t & ((1u << ushift) - 1));
             const u32 sl = e * LY::ROW + owner;
             const u32 d = s_dst[owner];
-#ifdef PROT_EXP_NOSTORE  // dev experiment: everything but the global stores
-            if (d == 0xfffffff0u) a.pos[e] = sl;
-#else
             if (d != 0xffffffffu) {
                 a.hash[ubase + d + e] = *reinterpret_cast<const u64 *>(lds + LY::SH + sl * 8);
                 a.pos[ubase + d + e] = *reinterpret_cast<const u16 *>(lds + LY::SP + sl * 2);
             }
-#endif
         }
     }
     wave_sync_lds();
@@ -233,9 +229,6 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
             const size_t gp0 = (size_t)p0;
             auto load_dwords = [&](u32 *dst, int ndw, u32 j) {  // dwords j .. j+ndw-1 of the sequence (bytes 4j ..)
                 int g = 0;
-#ifdef PROT_EXP_FAKEIN  // dev experiment: no residue loads
-                for (; g < ndw; ++g) dst[g] = ((j + g) * 0x9E3779B9u) ^ (u32)lane;
-#else
                 for (; g + 4 <= ndw; g += 4) {
                     const u64 bo = (u64)4 * (j + g) < L ? (u64)4 * (j + g) : L;  // never start beyond the sequence (+ buffer slack)
                     const u32x4 v = *reinterpret_cast<const GLBQ u32x4_u *>(gp0 + bo);
@@ -248,7 +241,6 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
                     const u64 bo = (u64)4 * (j + g) < L ? (u64)4 * (j + g) : L;
                     dst[g] = *reinterpret_cast<const GLBQ u32_u *>(gp0 + bo);
                 }
-#endif
             };
             u32 dj = 0;
             fp.slot = (u32)lane * 8u;  // staging persists across macro blocks (leftovers of fewer than 16 tuples stay in LDS)
@@ -325,7 +317,7 @@ static inline void fast_prot_launch(int w, int k, int grid, hipStream_t stream, 
 // ---------------------------------------------------------------------------------------
 // Protein k-mer hashes (kind BSK_PROT_HASH; ProteinIterator.Next, iterator-protein.go:86-117)
 // for K = 9..16: value i of sequence r -> hash[first(r) + i].  One sequence per lane; the
-// residues of a 512-position chunk are realigned and staged in LDS ([dword][lane]) so that
+// residues of a 256-position chunk are staged in LDS (one region per lane, cooperative coalesced loads) so that
 // the hashing loop has no global loads (see k_nthash_fast: loads and stores in one loop make
 // every block wait for the previous flush); 16 hashes per lane go through the 64x16 tile and
 // leave as one aligned 128-byte line per sequence.  Runs are padded to 16 values.

@@ -157,7 +157,7 @@ def test_protein_minimizer_and_hash(engine, oracle, k, w):
 
 @pytest.mark.parametrize("k", [9, 10, 11, 12, 13, 14, 15, 16, 17])
 def test_protein_hash_register_kernel_all_k_and_long_sequences(engine, oracle, k):
-    """k = 9..16 run on k_prot_hash_fast<K> (512-position chunks staged in LDS); 17 on the general kernel."""
+    """k = 9..16 run on k_prot_hash_fast<K> (256-position chunks staged in LDS); 17 on the general kernel."""
     rng = random.Random(900 + k)
     lens = [3 * k - 1, 3 * k, 3 * k + 1, 47, 48, 49, 511, 512, 513, 512 + k - 1, 512 + k, 1023, 1024, 1025, 1500, 2600]
     seqs = [rand_seq(rng, n, AA) for n in lens] + [rand_seq(rng, rng.randint(1, 700), AA) for _ in range(150)]
