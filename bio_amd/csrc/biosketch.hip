@@ -1286,6 +1286,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         }
         if (pl.which == K_PROT_MIN_FAST) {  // a sequence outgrew its slab (unusual density): use the dense general kernel
             ctx->no_prot_fast = true;
+            pl = Plan();  // not just `which`: the slab fields of the abandoned plan must go too (they size the look-back scratch)
             rc = make_plan(ctx, b, p, pl);
             ctx->no_prot_fast = false;
             if (rc != BSK_OK) return cleanup(rc);
@@ -1349,6 +1350,8 @@ static bool kind_tiles(const bsk_params *p) {
         case BSK_MINIMIZER: return true;
         case BSK_KMER: return p->canonical != 0;  // the two-strand mode walks the reverse strand backwards (iterator.go:713-723)
         case BSK_SYNCMER: return p->s < p->k;     // s == k emits every k-mer with its own end rule (sketch.go:328-331)
+        case BSK_PROT_HASH:
+        case BSK_PROT_MINIMIZER: return true;
         default: return false;
     }
 }
@@ -1356,7 +1359,7 @@ static bool kind_tiles(const bsk_params *p) {
 // positions one tile owns: about 22 tuples per tile (the kernels stage 32 per lane; 16 for syncmers), a multiple of 16
 static u32 tile_positions(const bsk_params *p) {
     u32 tp;
-    if (p->kind == BSK_MINIMIZER) tp = 16u * std::max<u32>(2, (u32)(22.0 * (p->w + 1.0) / 2.0 / 16.0));
+    if (p->kind == BSK_MINIMIZER || p->kind == BSK_PROT_MINIMIZER) tp = 16u * std::max<u32>(2, (u32)(22.0 * (p->w + 1.0) / 2.0 / 16.0));
     else if (p->kind == BSK_SYNCMER) tp = 16u * std::max<u32>(2, (u32)(11.0 * (p->k - p->s + 1.0) / 2.0 / 16.0));
     else tp = 256;
     tp = std::min<u32>(tp, 8192);
@@ -1376,7 +1379,8 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, i
     geo.tp = tile_positions(p);
     geo.circ_ext = circ_ext;
     const bool stream = !kind_has_pos(p->kind);
-    SeqTab seq{b->desc, b->fw, b->llen, b->aoff, n};
+    const bool prot = b->alphabet == BSK_ALPHA_PROTEIN;
+    SeqTab seq{b->desc, b->fw, b->llen, b->aoff, n, prot ? b->rflags : nullptr};  // protein rflags: the translate kernel's short flags
     u64 *tstart = nullptr, *oexcl = nullptr, *sbad = nullptr;
     u32 *sflags = nullptr;
     TileTab tt{nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1426,7 +1430,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, i
         nt = ctx->h_pinned[0];
     }
     // 2. tile table + a batch whose "reads" are the tiles (aliases the words / bytes of b)
-    const bool use_ascii = b->n_nonacgt > 0;
+    const bool use_ascii = prot || b->n_nonacgt > 0;  // residues are bytes
     const size_t nta = nt ? nt : 1;
     TCHK(hipMalloc(&tt.desc, nta * 8));
     if (use_ascii) TCHK(hipMalloc(&tt.adesc, nta * 8));
@@ -1434,16 +1438,17 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, i
     TCHK(hipMalloc(&tt.shift, nta * 8));
     TCHK(hipMalloc(&tt.keep, nta * 8));
     u8 *tflags = nullptr;  // per tile: holds a non-ACGT letter (from the per-word bits of the batch); owned by tb later
-    if (use_ascii && b->wbits) {
+    if (prot || (use_ascii && b->wbits)) {  // protein: all-zero flags = "the input-length rule was already applied" for every tile
         TCHK(hipMalloc(&tflags, nta));
         TCHK(hipMemsetAsync(tflags, 0, nta, ctx->stream));
     }
     if (nt) {
-        hipLaunchKernelGGL(k_tile_build, dim3(grid_for(ctx, nt, 256)), dim3(256), 0, ctx->stream, seq, geo, tstart, nt, tt, b->wbits, tflags);
+        hipLaunchKernelGGL(k_tile_build, dim3(grid_for(ctx, nt, 256)), dim3(256), 0, ctx->stream, seq, geo, tstart, nt, tt, b->wbits,
+                           prot ? nullptr : tflags);
         TCHK(hipGetLastError());
     }
     u64 n_bad_tiles = tflags ? 0 : b->n_nonacgt;  // with per-tile flags: counted below (no tiles, no flagged tiles)
-    if (tflags && nt) {
+    if (tflags && nt && !prot) {
         TCHK(hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream));
         hipLaunchKernelGGL(k_count_flags, dim3(grid_for(ctx, nt, 256)), dim3(256), 0, ctx->stream, tflags, nt, ctx->d_ticket + 1);
         TCHK(hipMemcpyAsync(ctx->h_pinned, ctx->d_ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
@@ -1453,7 +1458,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, i
     tb = new (std::nothrow) bsk_batch();
     if (!tb) return done(BSK_ERR_NOMEM);
     tb->ctx = ctx;
-    tb->alphabet = BSK_ALPHA_DNA;
+    tb->alphabet = b->alphabet;
     tb->alias = true;
     tb->n = nt;
     tb->words = b->words;
@@ -1462,11 +1467,14 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, i
     tb->adesc = tt.adesc;
     tb->n_nonacgt = n_bad_tiles;
     tb->rflags = tflags;  // NULL: no per-tile knowledge, every tile runs on the ASCII kernels
-    if (tflags && n_bad_tiles && nt < (1ULL << 32)) {
+    if (prot) tb->n_nonacgt = 0;
+    if (!prot && tflags && n_bad_tiles && nt < (1ULL << 32)) {
         rc = build_subset(ctx, tb);
         if (rc != BSK_OK) return done(rc);
     }
-    const u64 over = p->kind == BSK_MINIMIZER ? 2ULL * p->w + p->k + 16 : p->kind == BSK_SYNCMER ? 3ULL * p->k + 16 : (u64)p->k;
+    const u64 over = (p->kind == BSK_MINIMIZER || p->kind == BSK_PROT_MINIMIZER) ? 2ULL * p->w + p->k + 16
+                     : p->kind == BSK_SYNCMER                                     ? 3ULL * p->k + 16
+                                                                                  : (u64)p->k;
     tb->maxlen = (u32)std::min<u64>((u64)geo.tp + over, (u64)b->maxlen);
     tb->n_bases = nt * tb->maxlen;  // upper bound: sizes the first capacity guess
     tb->n_words = b->n_words;
@@ -1534,7 +1542,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, i
     TCHK(hipMemsetAsync(ctx->d_total, 0, 2 * sizeof(u64), ctx->stream));
     if (n) {
         hipLaunchKernelGGL(k_tile_finish, dim3(grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, seq, geo, tstart, stream ? nullptr : oexcl,
-                           tres->refs, b->rflags, sflags, sbad, fin->wfirst, fin->wcount, fin->status, ctx->d_total);
+                           tres->refs, prot ? nullptr : b->rflags, sflags, sbad, fin->wfirst, fin->wcount, fin->status, ctx->d_total);
         TCHK(hipGetLastError());
     }
     TCHK(hipMemcpyAsync(ctx->h_pinned, ctx->d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1576,8 +1584,10 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
         b = tmp;
         circ_ext = p->k - 1;
     }
-    const bool tiled = b->alphabet == BSK_ALPHA_DNA && kind_tiles(p) && !getenv("BSK_NO_TILES") &&
-                       (!b->desc || b->maxlen > env_u32("BSK_TILE_MIN", kind_has_pos(p->kind) ? 4096u : 16u * (BSK_NT_FAST_WORDS - 2)));
+    // long sequences run as tiles; protein: only when really long (the protein kernels take any length per lane, slowly)
+    const bool is_dna = b->alphabet == BSK_ALPHA_DNA;
+    const u32 tile_min = env_u32("BSK_TILE_MIN", (!is_dna || kind_has_pos(p->kind)) ? 4096u : 16u * (BSK_NT_FAST_WORDS - 2));
+    const bool tiled = kind_tiles(p) && (is_dna != prot_kind) && !getenv("BSK_NO_TILES") && ((is_dna && !b->desc) || b->maxlen > tile_min);
     rc = tiled ? sketch_tiled(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms)
                : run_planned(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms);
     if (tmp) bsk_batch_destroy(tmp);

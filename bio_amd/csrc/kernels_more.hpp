@@ -99,8 +99,7 @@ __global__ __launch_bounds__(64) void k_prot_minimizer(KArgs a) {
         const u64 r = (u64)unit * 64 + lane;
         u64 off = 0, L = 0;
         if (r < a.n) {
-            off = a.aoff[r];
-            L = a.aoff[r + 1] - off;
+            ascii_span(a, r, off, L);
         }
         // sketch-protein.go:66,73: len < 3k -> ErrShortSeq ; len < 3k+w-1 -> ErrShortSeq (on the INPUT length)
         const bool ok = r < a.n && prot_len_ok(a, r, L, (u64)a.k * 3 + (u64)W - 1);
@@ -194,8 +193,7 @@ __global__ __launch_bounds__(64) void k_prot_hash(KArgs a) {
         const u64 r = (u64)unit * 64 + lane;
         u64 off = 0, L = 0;
         if (r < a.n) {
-            off = a.aoff[r];
-            L = a.aoff[r + 1] - off;
+            ascii_span(a, r, off, L);
         }
         const bool ok = r < a.n && prot_len_ok(a, r, L, (u64)a.k * 3);  // iterator-protein.go:50 (checked on the input length)
         const u32 nk = (ok && L >= (u64)a.k) ? (u32)(L - a.k + 1) : 0u;

@@ -206,8 +206,7 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
         const u64 r = (u64)unit * 64 + lane;
         u64 off = 0, L = 0;
         if (r < a.n) {
-            off = a.aoff[r];
-            L = a.aoff[r + 1] - off;
+            ascii_span(a, r, off, L);
         }
         const bool ok = r < a.n && prot_len_ok(a, r, L, (u64)K * 3 + (u64)W - 1);  // sketch-protein.go:66,73
         const u32 nk = (ok && L >= (u64)K + (u64)W - 1) ? (u32)(L - K + 1) : 0u;
@@ -382,7 +381,8 @@ __global__ __launch_bounds__(64) void k_prot_hash_fast(KArgs a) {
           for (u32 unit = u0; unit < u1; ++unit) {
               const u64 r = (u64)unit * 64 + lane;
               u64 L = 0;
-              if (r < a.n) L = a.aoff[r + 1] - a.aoff[r];
+              u64 off_ = 0;
+              if (r < a.n) ascii_span(a, r, off_, L);
               const bool ok = r < a.n && prot_len_ok(a, r, L, (u64)K * 3);
               const u32 pk = (ok && L >= (u64)K) ? ((u32)(L - K + 1) + 15u) & ~15u : 0u;
               if (lane == 0) s_base[unit - u0] = run;
@@ -397,8 +397,7 @@ __global__ __launch_bounds__(64) void k_prot_hash_fast(KArgs a) {
         const u64 r = (u64)unit * 64 + lane;
         u64 off = 0, L = 0;
         if (r < a.n) {
-            off = a.aoff[r];
-            L = a.aoff[r + 1] - off;
+            ascii_span(a, r, off, L);
         }
         const bool ok = r < a.n && prot_len_ok(a, r, L, (u64)K * 3);  // iterator-protein.go:50 (checked on the input length)
         const u32 nk = (ok && L >= (u64)K) ? (u32)(L - K + 1) : 0u;

@@ -26,15 +26,25 @@ struct TileGeo {
     int circ_ext;       // bases the circular copy appended (length checks look at L - circ_ext)
 };
 
-struct SeqTab {  // where the sequences of a DNA batch are: desc (reads shorter than 2^24) or fw + llen
+struct SeqTab {  // where the sequences of a batch are: DNA desc (reads shorter than 2^24) or fw + llen; protein: aoff only
     const u64 *desc, *fw, *llen, *aoff;
     u64 n;
+    const u8 *short_flag;  // protein batch that came out of the translate kernel: 1 = too few nucleotides (ErrShortSeq)
 };
-__device__ __forceinline__ u64 seq_first_word(const SeqTab &t, u64 r) { return t.desc ? t.desc[r] >> 24 : t.fw[r]; }
-__device__ __forceinline__ u64 seq_len(const SeqTab &t, u64 r) { return t.desc ? t.desc[r] & 0xffffffULL : t.llen[r]; }
+__device__ __forceinline__ u64 seq_first_word(const SeqTab &t, u64 r) { return t.desc ? t.desc[r] >> 24 : (t.fw ? t.fw[r] : 0); }
+__device__ __forceinline__ u64 seq_len(const SeqTab &t, u64 r) {
+    return t.desc ? t.desc[r] & 0xffffffULL : (t.llen ? t.llen[r] : t.aoff[r + 1] - t.aoff[r]);
+}
 
 // positions (values, or selectable k-mer starts) of a sequence of L bases; 0: the constructor returns ErrShortSeq
-__host__ __device__ __forceinline__ u64 tile_npos(const TileGeo &g, u64 L) {
+__host__ __device__ __forceinline__ u64 tile_npos(const TileGeo &g, u64 L, int short_flag = -1) {
+    if (g.kind == BSK_PROT_HASH || g.kind == BSK_PROT_MINIMIZER) {
+        // iterator-protein.go:50, sketch-protein.go:66,73: the constructors look at the INPUT length (3k, 3k+w-1); the
+        // residues may then be too few for a k-mer / a window, which yields nothing
+        const u64 wm1 = g.kind == BSK_PROT_MINIMIZER ? (u64)g.w - 1 : 0;
+        const bool shrt = short_flag >= 0 ? short_flag != 0 : L < 3ULL * g.k + wm1;
+        return (!shrt && L >= (u64)g.k + wm1) ? L - (u64)g.k + 1 : 0;
+    }
     if (L < (u64)g.circ_ext) return 0;
     const u64 L0 = L - (u64)g.circ_ext;
     switch (g.kind) {
@@ -43,7 +53,19 @@ __host__ __device__ __forceinline__ u64 tile_npos(const TileGeo &g, u64 L) {
         default: return L0 >= (u64)g.k ? L - (u64)g.k + 1 : 0;  // iterator.go:619,672,128
     }
 }
-__host__ __device__ __forceinline__ u64 tile_count(const TileGeo &g, u64 L) { return (tile_npos(g, L) + g.tp - 1) / g.tp; }
+// does the reference constructor refuse the sequence (ErrShortSeq)?  Not the same as "no position": a translation can pass
+// the nucleotide-length rule and still be too short for a k-mer or a window -- that yields nothing and is no error
+__host__ __device__ __forceinline__ bool tile_short(const TileGeo &g, u64 L, int short_flag = -1) {
+    if (g.kind == BSK_PROT_HASH || g.kind == BSK_PROT_MINIMIZER) {
+        const u64 wm1 = g.kind == BSK_PROT_MINIMIZER ? (u64)g.w - 1 : 0;
+        return short_flag >= 0 ? short_flag != 0 : L < 3ULL * g.k + wm1;
+    }
+    return tile_npos(g, L) == 0;
+}
+__host__ __device__ __forceinline__ u64 tile_count(const TileGeo &g, u64 L, int short_flag = -1) {
+    return (tile_npos(g, L, short_flag) + g.tp - 1) / g.tp;
+}
+__device__ __forceinline__ int seq_short(const SeqTab &t, u64 r) { return t.short_flag ? (int)t.short_flag[r] : -1; }
 
 struct TileArgs {
     SeqTab seq;
@@ -61,7 +83,7 @@ __global__ __launch_bounds__(64) void k_tile_count(TileArgs a) {
         const u32 unit = next_ticket(a.ticket, lane);
         if (unit >= a.nunits) break;
         const u64 r = (u64)unit * 64 + lane;
-        const u64 c = r < a.seq.n ? tile_count(a.geo, seq_len(a.seq, r)) : 0;
+        const u64 c = r < a.seq.n ? tile_count(a.geo, seq_len(a.seq, r), seq_short(a.seq, r)) : 0;
         const u64 incl = wave_incl_scan_u64(c, lane);
         const u64 base = lookback_exclusive(a.lookback, unit, wave_bcast_u64(incl, 63), lane);
         if (r < a.seq.n) a.tstart[r] = base + incl - c;
@@ -85,14 +107,15 @@ __global__ void k_tile_build(SeqTab seq, TileGeo g, const u64 *tstart, u64 nt, T
             if (tstart[mid] <= i) lo = mid;
             else hi = mid - 1;
         }
-        const u64 r = lo, L = seq_len(seq, r), np = tile_npos(g, L);
+        const u64 r = lo, L = seq_len(seq, r), np = tile_npos(g, L, seq_short(seq, r));
+        const bool prot = g.kind == BSK_PROT_HASH || g.kind == BSK_PROT_MINIMIZER;
         const u64 P0 = (i - tstart[r]) * g.tp, P1 = (P0 + g.tp < np) ? P0 + g.tp : np;
         u64 a0, Lt;
-        if (g.kind == BSK_MINIMIZER) {
+        if (g.kind == BSK_MINIMIZER || g.kind == BSK_PROT_MINIMIZER) {
             const u64 nwin = np - (u64)g.w + 1;
             const u64 jlo = P0 + 1 > (u64)g.w ? P0 + 1 - (u64)g.w : 0;
             const u64 jhi = P1 - 1 < nwin - 1 ? P1 - 1 : nwin - 1;
-            a0 = jlo & ~15ULL;
+            a0 = prot ? jlo : (jlo & ~15ULL);  // residues are bytes: no word alignment
             Lt = jhi + (u64)g.w + (u64)g.k - 1 - a0;
         } else if (g.kind == BSK_SYNCMER) {
             const u64 ilo = P0 + 1 > (u64)g.w ? P0 + 1 - (u64)g.w : 0;
@@ -102,7 +125,7 @@ __global__ void k_tile_build(SeqTab seq, TileGeo g, const u64 *tstart, u64 nt, T
             a0 = P0;
             Lt = (P1 - P0) + (u64)g.k - 1;
         }
-        t.desc[i] = ((seq_first_word(seq, r) + (a0 >> 4)) << 24) | Lt;
+        t.desc[i] = prot ? 0 : ((seq_first_word(seq, r) + (a0 >> 4)) << 24) | Lt;
         if (t.adesc) t.adesc[i] = ((seq.aoff[r] + a0) << 24) | Lt;
         t.seq[i] = (u32)r;
         t.shift[i] = a0;
@@ -200,15 +223,14 @@ __global__ void k_tile_finish(SeqTab seq, TileGeo g, const u64 *tstart, const u6
     for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < seq.n; r += (u64)gridDim.x * blockDim.x) {
         const u64 t0 = tstart[r], t1 = tstart[r + 1];
         u64 first = 0, cnt = 0;
-        u8 st = BSK_ST_SHORT;
+        u8 st = tile_short(g, seq_len(seq, r), seq_short(seq, r)) ? BSK_ST_SHORT : BSK_ST_OK;
         if (t1 > t0) {
-            st = BSK_ST_OK;
             if (oexcl) {
                 first = oexcl[t0];
                 cnt = oexcl[t1] - first;
             } else {
                 first = trefs[t0] >> 24;
-                cnt = tile_npos(g, seq_len(seq, r));
+                cnt = tile_npos(g, seq_len(seq, r), seq_short(seq, r));
                 const u64 bad = sbad[r];
                 if (bad != ~0ULL) {  // NextKmer stopped at the first k-mer with an illegal base (iterator.go:746)
                     cnt = (bad - t0) * g.tp + (trefs[bad] & 0xffffffULL);

@@ -35,7 +35,10 @@ def draw_batch(rng, protein=False):
             lens.append(rng.randint(0, 40))
     if protein:
         alpha = rng.choice([AA, AA, AA + "X*", "AC"])
-        return ["".join(rng.choice(alpha) for _ in range(min(x, 1500))) for x in lens]
+        seqs = ["".join(rng.choice(alpha) for _ in range(min(x, 1500))) for x in lens]
+        if rng.random() < 0.3:  # a low-complexity sequence among them (dense minimizers: slab overflow of the register kernel)
+            seqs[rng.randrange(len(seqs))] = rng.choice(["A", "AC", "ACD"]) * rng.randint(10, 200)
+        return seqs
     style = rng.choice(["acgt", "acgt", "fewN", "iupac", "junk"])
     seqs = []
     for x in lens:

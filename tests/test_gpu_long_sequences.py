@@ -249,3 +249,69 @@ def test_tiles_with_sparse_non_acgt_use_the_mixed_plan(engine, oracle, tiny_tile
         finally:
             del os.environ["BSK_NO_MIXED"]
         assert d1 == d2
+
+
+AA = "ACDEFGHIKLMNPQRSTVWY"
+
+
+@pytest.mark.parametrize("tile_pos", [16, 48, 0])
+def test_protein_sequences_tiled(engine, oracle, tiny_tiles, tile_pos):
+    """Long protein sequences (and long translations) run as tiles too: the window closed form is the minimizer's, and
+    the constructors' input-length rule is applied to the sequence, not to its tiles."""
+    tiny_tiles(60, tile_pos)
+    rng = random.Random(70 + tile_pos)
+    seqs = [rand_seq(rng, n, AA) for n in (1, 26, 27, 31, 32, 61, 100, 300, 777, 2500)] + [rand_seq(rng, rng.randint(1, 900), AA) for _ in range(40)]
+    seqs += ["A" * 500, "AC" * 300]
+    b = engine.batch(seqs, L.ALPHA_PROTEIN)
+    for k, w in ((9, 5), (10, 3), (3, 1), (12, 8), (33, 4)):
+        rm = engine.run(b, engine.params(L.PROT_MINIMIZER, k, w=w))
+        rh = engine.run(b, engine.params(L.PROT_HASH, k))
+        for i, q in enumerate(seqs):
+            st, h, p = rm.read(i)
+            try:
+                eh, ep, fl = oracle.protein_minimizer(q, k, w, closed=True)
+            except oracle.OracleError:
+                assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0, (k, w, i, len(q))
+            else:
+                assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep) and (st & 0xF0) == fl, (k, w, i, len(q))
+            st, h, _ = rh.read(i)
+            try:
+                e = oracle.protein_hashes(q, k)
+            except oracle.OracleError:
+                assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0
+            else:
+                assert np.array_equal(h, e), (k, i, len(q))
+    # DNA fed: the translation of a long contig is tiled, the length rule still looks at the nucleotides
+    dna = [rand_seq(rng, n) for n in (26, 27, 29, 31, 100, 3000, 7001)]
+    bd = engine.batch(dna)
+    for frame in (1, -2):
+        rm = engine.run(bd, engine.params(L.PROT_MINIMIZER, 9, w=5, codon_table=11, frame=frame))
+        rh = engine.run(bd, engine.params(L.PROT_HASH, 9, codon_table=11, frame=frame))
+        for i, q in enumerate(dna):
+            st, h, p = rm.read(i)
+            try:
+                eh, ep, _ = oracle.protein_minimizer_nt(q, 9, 5, 11, frame)
+            except oracle.OracleError:
+                assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0, (frame, i)
+            else:
+                assert (st & L.ST_CODE_MASK) == L.ST_OK and np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep), (frame, i)
+            st, h, _ = rh.read(i)
+            try:
+                e = oracle.protein_hashes_nt(q, 9, 11, frame)
+            except oracle.OracleError:
+                assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0
+            else:
+                assert np.array_equal(h, e), (frame, i)
+
+
+def test_long_protein_default_tiles(engine, oracle):
+    rng = random.Random(9)
+    seqs = [rand_seq(rng, n, AA) for n in (35_000, 300, 4097, 12_000)]
+    b = engine.batch(seqs, L.ALPHA_PROTEIN)
+    rm = engine.run(b, engine.params(L.PROT_MINIMIZER, 9, w=5))
+    rh = engine.run(b, engine.params(L.PROT_HASH, 10))
+    for i, q in enumerate(seqs):
+        _, h, p = rm.read(i)
+        eh, ep, _ = oracle.protein_minimizer(q, 9, 5, closed=True)
+        assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep), i
+        assert np.array_equal(rh.read(i)[1], oracle.protein_hashes(q, 10)), i

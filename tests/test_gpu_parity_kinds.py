@@ -324,3 +324,24 @@ def test_mixed_batches_fast_kernels_plus_ascii_side_launch(engine, oracle, frac)
         finally:
             del os.environ["BSK_NO_MIXED"]
         assert d1 == d2, (kind, pk)
+
+
+def test_protein_slab_overflow_falls_back_with_many_units(engine, oracle):
+    """A low-complexity protein selects a new minimizer at every position and outgrows its slab of the register kernel: the
+    call re-plans on the general kernel.  With more than 64 sequences that re-plan once kept the slab flags of the abandoned
+    plan and under-sized the look-back scratch (nondeterministic results)."""
+    rng = random.Random(123)
+    seqs = [rand_seq(rng, rng.randint(40, 400), AA) for _ in range(400)]
+    seqs[137] = "A" * 400
+    seqs[300] = "AC" * 150
+    b = engine.batch(seqs, L.ALPHA_PROTEIN)
+    for _ in range(3):
+        res = engine.run(b, engine.params(L.PROT_MINIMIZER, 9, w=5))
+        for i, q in enumerate(seqs):
+            st, h, p = res.read(i)
+            try:
+                eh, ep, fl = oracle.protein_minimizer(q, 9, 5, closed=True)
+            except oracle.OracleError:
+                assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0
+                continue
+            assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep), (i, len(q))
