@@ -19,8 +19,8 @@ AA = "ACDEFGHIKLMNPQRSTVWY"
 
 
 def draw_batch(rng, protein=False):
-    shape = rng.choice(["reads", "ragged", "long", "mixedlen", "tiny"])
-    n = rng.randint(1, 180)
+    shape = rng.choice(["reads", "ragged", "long", "mixedlen", "tiny", "many"])
+    n = rng.randint(1, 180) if shape != "many" else rng.randint(500, 2500)  # "many": several tickets of 8 units
     lens = []
     for _ in range(n):
         if shape == "reads":
@@ -31,6 +31,8 @@ def draw_batch(rng, protein=False):
             lens.append(rng.choice([rng.randint(400, 900), rng.randint(900, 6000)]))
         elif shape == "mixedlen":
             lens.append(rng.choice([0, 1, 30, 150, 513, 700, 4097, rng.randint(1, 9000)]))
+        elif shape == "many":
+            lens.append(rng.choice([rng.randint(20, 220), 150]))
         else:
             lens.append(rng.randint(0, 40))
     if protein:
