@@ -26,6 +26,10 @@ struct bsk_ctx {
     u64 *h_pinned = nullptr;  // [8] pinned host words for small read-backs
     u8 *d_lut = nullptr;      // codon tables of `lut_table` (kernels_translate.hpp layout)
     int lut_table = 0;
+    // tiled calls: grow-only temporaries (hipMalloc / hipFree of ten buffers per call cost more than the kernels)
+    void *tmp[12] = {};
+    size_t tmp_cap[12] = {};
+    struct bsk_result *tile_res = nullptr;  // tile-level result of the previous tiled call, reused
     bool no_prot_fast = false;  // set while a call falls back from the per-sequence-slab protein kernel
 };
 
@@ -53,6 +57,7 @@ struct bsk_batch {
 struct bsk_result {
     bsk_ctx *ctx = nullptr;
     u64 n = 0, cap = 0, n_tuples = 0;
+    u64 n_cap = 0;  // reads the refs / status arrays were allocated for
     u64 ovf_cap = 0;  // slab kernels: tuples reserved (inside cap) for units that outgrow their slab
     u64 main_cap = 0; // tuples [0, main_cap) belong to the main launch, [main_cap, cap) to the side launch (mixed batches)
     int kind = 0, has_pos = 0;
