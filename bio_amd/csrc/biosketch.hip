@@ -18,8 +18,7 @@
 #include "kernels_generic.hpp"
 #include "kernels_fast.hpp"
 #include "kernels_more.hpp"
-#include "kernels_syncmer.hpp"
-#include "kernels_protein.hpp"
+#include "fast_dispatch.hpp"
 #include "kernels_translate.hpp"
 #include "kernels_tile.hpp"
 #include "kernels_simhash.hpp"

@@ -1,0 +1,29 @@
+// fast_dispatch.hpp -- host-side entry points of the specialised kernel families.  Each family is instantiated in its own
+// translation unit (k_minimizer.hip, k_syncmer.hip, k_protein.hip) so that the library builds in parallel; biosketch.hip only
+// sees these declarations.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kernels_generic.hpp"  // KArgs
+
+#define BSK_FAST_CAP 32   // tuples staged per read by k_minimizer_fast (slab = 64 * CAP tuples per unit)
+#define BSK_SYN_CAP 16    // same for k_syncmer_fast
+#define BSK_ASCII_PAD 1024  // slack behind residue / ASCII buffers: the 16-byte staging loads read past a chunk's end
+
+namespace bsk {
+bool fast_minimizer_supported(int w);
+int fast_minimizer_blocks_per_cu(int w);
+void fast_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a);
+
+bool fast_syncmer_supported(int k, int s);
+int fast_syncmer_blocks_per_cu(int w);
+void fast_syncmer_launch(int w, int grid, hipStream_t stream, const KArgs &a);
+
+bool fast_prot_supported(int w, int k);
+int fast_prot_blocks_per_cu(int w, int k);
+void fast_prot_launch(int w, int k, int grid, hipStream_t stream, const KArgs &a);
+
+bool fast_prot_hash_supported(int k);
+int fast_prot_hash_blocks_per_cu(int k);
+void fast_prot_hash_launch(int k, int grid, hipStream_t stream, const KArgs &a);
+}  // namespace bsk

@@ -23,7 +23,7 @@
 // HBM traffic is the packed bases in and the selected (hash, pos|strand) tuples
 // plus one 8-byte reference per read out; tuples leave LDS as whole 512-/256-byte rows.
 #pragma once
-#include "kernels_generic.hpp"
+#include "fast_dispatch.hpp"
 
 namespace bsk {
 
@@ -527,12 +527,12 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
 }
 
 // ---- dispatch table --------------------------------------------------------------------
-#define BSK_FAST_CAP 32
+#ifdef BSK_IMPL_MINIMIZER  // dispatch functions: compiled in the family's own translation unit
 #define BSK_FAST_WS(X) \
     X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) \
     X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
 
-static inline bool fast_minimizer_supported(int w) {
+bool fast_minimizer_supported(int w) {
     switch (w) {
 #define X(WW) case WW:
         BSK_FAST_WS(X)
@@ -559,10 +559,10 @@ static inline int fast_minimizer_blocks_per_cu_t(int w) {
     }
     return nb;
 }
-static inline int fast_minimizer_blocks_per_cu(int w) { return fast_minimizer_blocks_per_cu_t<true>(w); }
+int fast_minimizer_blocks_per_cu(int w) { return fast_minimizer_blocks_per_cu_t<true>(w); }
 
 // staged positions are 15 bit + strand: the fast path takes reads shorter than 32768 bases (longer: generic kernel)
-static inline void fast_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a) {
+void fast_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a) {
     switch (w) {
 #define X(WW) \
     case WW: hipLaunchKernelGGL((k_minimizer_fast<WW, BSK_FAST_CAP, true>), dim3(grid), dim3(64), 0, stream, a); break;
@@ -571,5 +571,7 @@ static inline void fast_minimizer_launch(int w, int grid, hipStream_t stream, co
         default: break;
     }
 }
+
+#endif  // BSK_IMPL_MINIMIZER
 
 }  // namespace bsk

@@ -83,7 +83,7 @@ struct WySrc {  // hash source over residues
 // ---------------------------------------------------------------------------------------
 // PROT_MINIMIZER: the window machine of kernels_generic.hpp fed by WySrc.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_prot_minimizer(KArgs a) {
+static __global__ __launch_bounds__(64) void k_prot_minimizer(KArgs a) {
     constexpr int CAP = BSK_GEN_CAP;
     __shared__ u64 s_h[CAP * 64];
     __shared__ u32 s_p[CAP * 64];
@@ -182,7 +182,7 @@ __device__ __forceinline__ bool stream_prologue(const KArgs &a, u32 unit, int la
 }
 
 // ---- PROT_HASH ----
-__global__ __launch_bounds__(64) void k_prot_hash(KArgs a) {
+static __global__ __launch_bounds__(64) void k_prot_hash(KArgs a) {
     __shared__ u64 s_tile[64 * TILE_LD];
     __shared__ u64 s_off[64];
     __shared__ u32 s_nk[64];

@@ -285,15 +285,16 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
     }
 }
 
+#ifdef BSK_IMPL_PROTEIN
 #define BSK_PROT_KW(X) X(5, 9) X(5, 10) X(3, 10) X(4, 12)
-static inline bool fast_prot_supported(int w, int k) {
+bool fast_prot_supported(int w, int k) {
 #define X(WW, KK) \
     if (w == WW && k == KK) return true;
     BSK_PROT_KW(X)
 #undef X
     return false;
 }
-static inline int fast_prot_blocks_per_cu(int w, int k) {
+int fast_prot_blocks_per_cu(int w, int k) {
     int nb = 0;
     hipError_t e = hipErrorInvalidValue;
 #define X(WW, KK) \
@@ -306,12 +307,14 @@ static inline int fast_prot_blocks_per_cu(int w, int k) {
     }
     return nb;
 }
-static inline void fast_prot_launch(int w, int k, int grid, hipStream_t stream, const KArgs &a) {
+void fast_prot_launch(int w, int k, int grid, hipStream_t stream, const KArgs &a) {
 #define X(WW, KK) \
     if (w == WW && k == KK) hipLaunchKernelGGL((k_prot_minimizer_fast<WW, KK>), dim3(grid), dim3(64), 0, stream, a);
     BSK_PROT_KW(X)
 #undef X
 }
+
+#endif  // BSK_IMPL_PROTEIN
 
 // ---------------------------------------------------------------------------------------
 // Protein k-mer hashes (kind BSK_PROT_HASH; ProteinIterator.Next, iterator-protein.go:86-117)
@@ -324,7 +327,6 @@ static inline void fast_prot_launch(int w, int k, int grid, hipStream_t stream, 
 #ifndef BSK_PH_CHUNK
 #define BSK_PH_CHUNK 256
 #endif
-#define BSK_ASCII_PAD 1024  // slack behind the residue buffer: the staging below reads whole 16-byte pieces past a chunk's end
 
 // Cooperative staging of one residue chunk per sequence: for every source lane s in `want`, the wavefront copies
 // np16 16-byte pieces starting at that lane's (byte-aligned) address A into the lane's LDS region (RS dwords apart,
@@ -470,9 +472,10 @@ __global__ __launch_bounds__(64) void k_prot_hash_fast(KArgs a) {
     }
 }
 
+#ifdef BSK_IMPL_PROTEIN
 #define BSK_PH_KS(X) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
-static inline bool fast_prot_hash_supported(int k) { return k >= 9 && k <= 16; }
-static inline int fast_prot_hash_blocks_per_cu(int k) {
+bool fast_prot_hash_supported(int k) { return k >= 9 && k <= 16; }
+int fast_prot_hash_blocks_per_cu(int k) {
     int nb = 0;
     hipError_t e = hipErrorInvalidValue;
 #define X(KK) \
@@ -485,11 +488,13 @@ static inline int fast_prot_hash_blocks_per_cu(int k) {
     }
     return nb;
 }
-static inline void fast_prot_hash_launch(int k, int grid, hipStream_t stream, const KArgs &a) {
+void fast_prot_hash_launch(int k, int grid, hipStream_t stream, const KArgs &a) {
 #define X(KK) \
     if (k == KK) hipLaunchKernelGGL((k_prot_hash_fast<KK>), dim3(grid), dim3(64), 0, stream, a);
     BSK_PH_KS(X)
 #undef X
 }
+
+#endif  // BSK_IMPL_PROTEIN
 
 }  // namespace bsk

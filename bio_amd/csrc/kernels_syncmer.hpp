@@ -228,7 +228,6 @@ struct FastSyn {
     }
 };
 
-#define BSK_SYN_CAP 16
 
 template <int W>
 __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves per SIMD: at most 256 VGPRs
@@ -311,8 +310,9 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves p
     }
 }
 
+#ifdef BSK_IMPL_SYNCMER  // dispatch functions: compiled in the family's own translation unit
 #define BSK_SYN_WS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(18) X(20) X(24)
-static inline bool fast_syncmer_supported(int k, int s) {
+bool fast_syncmer_supported(int k, int s) {
     switch (k - s) {
 #define X(WW) case WW:
         BSK_SYN_WS(X)
@@ -321,7 +321,7 @@ static inline bool fast_syncmer_supported(int k, int s) {
         default: return false;
     }
 }
-static inline int fast_syncmer_blocks_per_cu(int w) {
+int fast_syncmer_blocks_per_cu(int w) {
     int nb = 0;
     hipError_t e = hipErrorInvalidValue;
     switch (w) {
@@ -337,7 +337,7 @@ static inline int fast_syncmer_blocks_per_cu(int w) {
     }
     return nb;
 }
-static inline void fast_syncmer_launch(int w, int grid, hipStream_t stream, const KArgs &a) {
+void fast_syncmer_launch(int w, int grid, hipStream_t stream, const KArgs &a) {
     switch (w) {
 #define X(WW) \
     case WW: hipLaunchKernelGGL((k_syncmer_fast<WW>), dim3(grid), dim3(64), 0, stream, a); break;
@@ -346,5 +346,7 @@ static inline void fast_syncmer_launch(int w, int grid, hipStream_t stream, cons
         default: break;
     }
 }
+
+#endif  // BSK_IMPL_SYNCMER
 
 }  // namespace bsk
