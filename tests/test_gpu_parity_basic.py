@@ -159,3 +159,28 @@ def test_contexts_are_independent_across_threads(oracle):
     for t in ts:
         t.join()
     assert errors == []
+
+
+def test_degenerate_batches(engine):
+    """No reads, only empty reads, one base: every kind answers with empty results and SHORT statuses, sets and digests
+    included; nothing launches with an empty grid."""
+    for seqs in ([], [""], ["", "", ""], ["A"], ["A", "", "C"]):
+        for alpha, kinds in ((L.ALPHA_DNA, [(L.MINIMIZER, dict(k=5, w=3)), (L.SYNCMER, dict(k=5, s=2)), (L.NTHASH, dict(k=3)),
+                                            (L.KMER, dict(k=3)), (L.KMER, dict(k=3, canonical=False)), (L.SIMHASH, dict(k=8, m=4, scale=1)),
+                                            (L.PROT_HASH, dict(k=2)), (L.PROT_MINIMIZER, dict(k=2, w=2)),
+                                            (L.MINIMIZER, dict(k=5, w=3, circular=True))]),
+                             (L.ALPHA_PROTEIN, [(L.PROT_HASH, dict(k=9)), (L.PROT_MINIMIZER, dict(k=9, w=5))])):
+            b = engine.batch(seqs, alpha)
+            for kind, pk in kinds:
+                res = engine.run(b, engine.params(kind, **pk))
+                assert res.info()["n_reads"] == len(seqs) and res.info()["n_tuples"] == 0
+                d = res.digest()
+                assert d["n_tuples"] == 0 and d["short"] == len(seqs)
+                offs, vals = res.sets()
+                assert len(offs) == len(seqs) + 1 and len(vals) == 0
+                res.close()
+            if alpha == L.ALPHA_DNA:
+                t = b.translate(1, 1)
+                assert t.info()["n_bases"] == 0
+                t.close()
+            b.close()
