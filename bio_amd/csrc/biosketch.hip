@@ -1574,7 +1574,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, i
             sa.cap = cap;
             sa.ticket = ctx->d_ticket;
             sa.lookback = ctx->d_lookback;
-            hipLaunchKernelGGL(k_tile_stitch, dim3(std::min<u32>(tunits, (u32)ctx->cus * 8)), dim3(64), 0, ctx->stream, sa);
+            hipLaunchKernelGGL(k_tile_stitch, dim3(std::min<u32>(tunits, (u32)ctx->cus * 24)), dim3(64), 0, ctx->stream, sa);  // latency-bound: many waves
             TCHK(hipGetLastError());
         }
     }

@@ -199,18 +199,25 @@ __global__ __launch_bounds__(64) void k_tile_stitch(StitchArgs a) {
             continue;
         }
         s_src[lane] = src;
-        s_dst[lane] = dst;
+        s_dst[lane] = incl;  // inclusive prefix of the kept counts inside the unit
         s_shift[lane] = sh;
         s_cnt[lane] = kept;
         wave_sync_lds();
-        for (int q = 0; q < 64; ++q) {
-            const u32 c = s_cnt[q];
-            const u64 sb = s_src[q], db = s_dst[q], shq = s_shift[q];
-            for (u32 i = (u32)lane; i < c; i += 64) {
-                a.ohash[db + i] = a.thash[sb + i];
-                const u32 p = a.tpos[sb + i];
-                a.opos[db + i] = (p & BSK_POS_STRAND_BIT) | (u32)((p & BSK_POS_MASK) + shq);
+        // the unit's kept tuples are one contiguous output run [base, base + K): output k belongs to the first tile whose
+        // inclusive prefix exceeds k (6-step search over the 64 prefixes); iterations are independent, so their loads overlap
+        const u32 K = (u32)wave_bcast_u64(incl, 63);
+        for (u32 k = (u32)lane; k < K; k += 64) {
+            u32 lo_ = 0, hi_ = 63;
+            while (lo_ < hi_) {
+                const u32 mid = (lo_ + hi_) >> 1;
+                if ((u32)s_dst[mid] > k) hi_ = mid;
+                else lo_ = mid + 1;
             }
+            const u32 j = k - ((u32)s_dst[lo_] - s_cnt[lo_]);
+            const u64 sidx = s_src[lo_] + j;
+            a.ohash[base + k] = a.thash[sidx];
+            const u32 p = a.tpos[sidx];
+            a.opos[base + k] = (p & BSK_POS_STRAND_BIT) | (u32)((p & BSK_POS_MASK) + s_shift[lo_]);
         }
         wave_sync_lds();
     }
