@@ -801,7 +801,7 @@ static int blocks_per_cu(K kernel) {
 
 // Which kernel runs a (batch, params) pair, on how many workgroups, and how the tuple arrays are organised.
 enum Which { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST, K_NT_FAST, K_SYN_P, K_SYN_A, K_KMER_P, K_KMER_A, K_SIM_P, K_SIM_A,
-             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST };
+             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST, K_MIN_DENSE };
 struct Plan {
     Which which = K_MIN_GEN_P;
     int grid = 1;
@@ -822,7 +822,7 @@ struct Plan {
 };
 
 static bool which_is_fast(Which w) {
-    return w == K_MIN_FAST || w == K_NT_FAST || w == K_SYN_FAST || w == K_SIM_FAST;
+    return w == K_MIN_FAST || w == K_NT_FAST || w == K_SYN_FAST || w == K_SIM_FAST || w == K_MIN_DENSE;
 }
 
 static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan &pl, bool use_ascii);
@@ -860,7 +860,19 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
     int per_cu = 1;
     if (p->kind == BSK_MINIMIZER) {
         // fast path: 2-bit input, a window size with a compiled specialisation, positions that fit 15 bits
-        if (!use_ascii && fast_minimizer_supported(p->w) && b->maxlen < 32768u && !getenv("BSK_FORCE_GENERIC")) {
+        // windows that select more positions per read than the slab kernel stages (32): per-read slabs + mid-read flushes
+        const double nwin = (double)b->maxlen - p->k - p->w + 2;
+        if (!use_ascii && dense_minimizer_supported(p->w) && b->maxlen < 32768u && nwin * 2.0 / (p->w + 1.0) > 26.0 && !ctx->no_dense &&
+            !getenv("BSK_FORCE_GENERIC") && !getenv("BSK_NO_DENSE")) {
+            pl.which = K_MIN_DENSE;
+            pl.fast_w = p->w;
+            pl.slab = true;
+            pl.slab_read = std::min<u64>((u64)nwin, (u64)(nwin * 2.6 / (p->w + 1.0)) + 16);
+            pl.slab_read = (pl.slab_read + 15) & ~(u64)15;  // whole 128-byte lines of hashes per read
+            pl.slab_unit = 64 * pl.slab_read;
+            pl.slab_total = (u64)pl.nunits * pl.slab_unit;
+            per_cu = dense_minimizer_blocks_per_cu(p->w);
+        } else if (!use_ascii && fast_minimizer_supported(p->w) && b->maxlen < 32768u && !getenv("BSK_FORCE_GENERIC")) {
             pl.which = K_MIN_FAST;
             pl.fast_w = p->w;
             pl.slab = true;
@@ -1160,6 +1172,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_NT_P: hipLaunchKernelGGL(k_nthash_stream<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_NT_A: hipLaunchKernelGGL(k_nthash_stream<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_MIN_FAST: fast_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
+        case K_MIN_DENSE: dense_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_SYN_P: hipLaunchKernelGGL(k_syncmer<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_SYN_A: hipLaunchKernelGGL(k_syncmer<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_KMER_P: hipLaunchKernelGGL(k_kmer<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
@@ -1294,13 +1307,15 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
             ctx->err = "result capacity overflow after exact re-size";
             return cleanup(BSK_ERR_DEVICE);
         }
-        if (pl.which == K_PROT_MIN_FAST) {  // a sequence outgrew its slab (unusual density): use the dense general kernel
+        if (pl.which == K_PROT_MIN_FAST || pl.which == K_MIN_DENSE) {  // a sequence outgrew its slab (unusual density): re-plan without that kernel
             ctx->no_prot_fast = true;
+            ctx->no_dense = true;
             pl = Plan();  // not just `which`: the slab fields of the abandoned plan must go too (they size the look-back scratch)
             rc = make_plan(ctx, b, p, pl);
             ctx->no_prot_fast = false;
+            ctx->no_dense = false;
             if (rc != BSK_OK) return cleanup(rc);
-            cap = estimate_cap(b, p, circ_ext);
+            cap = pl.slab ? pl.slab_total + std::max<u64>(65536, pl.slab_total / 50) : estimate_cap(b, p, circ_ext);
             continue;
         }
         cap = pl.slab ? pl.slab_total + ovf_used + ovf_used / 4 + 65536 : total + 64;  // size known now: re-run once

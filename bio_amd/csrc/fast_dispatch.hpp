@@ -14,6 +14,9 @@ namespace bsk {
 bool fast_minimizer_supported(int w);
 int fast_minimizer_blocks_per_cu(int w);
 void fast_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a);
+bool dense_minimizer_supported(int w);  // per-read slabs + mid-read flushes: windows that select more than 32 positions per read
+int dense_minimizer_blocks_per_cu(int w);
+void dense_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a);
 
 bool fast_syncmer_supported(int k, int s);
 int fast_syncmer_blocks_per_cu(int w);

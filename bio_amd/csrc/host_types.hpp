@@ -30,7 +30,8 @@ struct bsk_ctx {
     void *tmp[12] = {};
     size_t tmp_cap[12] = {};
     struct bsk_result *tile_res = nullptr;  // tile-level result of the previous tiled call, reused
-    bool no_prot_fast = false;  // set while a call falls back from the per-sequence-slab protein kernel
+    bool no_prot_fast = false;
+    bool no_dense = false;      // same for the dense-minimizer kernel (per-read slabs)  // set while a call falls back from the per-sequence-slab protein kernel
 };
 
 struct bsk_batch {

@@ -68,7 +68,9 @@ struct FLds {
     static constexpr int EXCL = SP + (((CAP + 1) * ROW * PB + 15) & ~15);   // u32 [64]
     static constexpr int HEADS = EXCL + 256;  // u64 [CAP+1]: bit j of word c: a lane's run starts at output 64c+j
     static constexpr int NZ = HEADS + (CAP + 1) * 8;  // u8 [64]: rank among non-empty lanes -> lane
-    static constexpr int TOTAL = NZ + 64;
+    static constexpr int DST = NZ + 64;               // u32 [64]: flush_rows (kernels with per-read slabs)
+    static constexpr int ROWS = CAP + 1;
+    static constexpr int TOTAL = DST + 256;
 };
 
 template <int W, int CAP, bool POS16, bool DIRECT>
@@ -348,6 +350,168 @@ __global__ __launch_bounds__(64, ((W > 16 && W <= 24) ? 2 : 1)) void k_minimizer
     }
 }
 
+// Flush staged tuples to the per-sequence slabs.  Regular rounds move only whole groups of 16 tuples per lane
+// (a full, aligned 128-byte line of hashes and 64 bytes of positions: no partial-line writes; measured 2.2x
+// faster than flushing every tuple of every round); the final round moves what is left.
+// STRAND16: staged positions carry the strand in bit 15 (DNA kernels); it moves to bit 31 on the way out.
+template <class LY, bool STRAND16>
+__device__ __forceinline__ void flush_rows(char *lds, int lane, u32 cnt, bool last, u32 done, u64 slab_read, u64 ubase,
+                                           const KArgs &a) {
+    u32 *s_excl = reinterpret_cast<u32 *>(lds + LY::EXCL);
+    u64 *s_heads = reinterpret_cast<u64 *>(lds + LY::HEADS);
+    u8 *s_nz = reinterpret_cast<u8 *>(lds + LY::NZ);
+    u32 *s_dst = reinterpret_cast<u32 *>(lds + LY::DST);
+    // unit of work: a group of 16 tuples (regular round) or a single tuple (final round)
+    const u32 units = last ? cnt : (cnt >> 4);
+    const u32 ushift = last ? 0u : 4u;
+    const u32 incl = wave_incl_scan_u32(units, lane);
+    const u32 excl = incl - units;
+    const u32 U = wave_bcast_u32(incl, 63);
+    if (U == 0) return;
+    const u64 nzmask = __builtin_amdgcn_ballot_w64(units > 0);
+    const bool fits = (u64)done + ((u64)units << ushift) <= slab_read;
+    if (__builtin_amdgcn_ballot_w64(!fits) && lane == 0) atomicOr(&a.ticket[1], 1u);  // slab too small: host falls back
+    s_excl[lane] = excl;
+    s_dst[lane] = fits ? (u32)(lane * slab_read + done) : 0xffffffffu;
+    if (lane < LY::ROWS) s_heads[lane] = 0;
+    wave_sync_lds();
+    if (units > 0) {
+        s_nz[__builtin_amdgcn_mbcnt_hi((u32)(nzmask >> 32), __builtin_amdgcn_mbcnt_lo((u32)nzmask, 0))] = (u8)lane;
+        atomicOr(&s_heads[excl >> 6], 1ULL << (excl & 63));
+    }
+    wave_sync_lds();
+    const u32 T = U << ushift;  // tuples to move
+    u32 heads_before = 0, word = 0xffffffffu;
+    u64 M = 0;
+    for (u32 t0 = 0; t0 < T; t0 += 64) {
+        const u32 t = t0 + lane;
+        const u32 ui = t >> ushift;  // work-unit index of this lane's tuple
+        if ((t0 >> ushift >> 6) != word) {  // next 64 work units: next head word (wave-uniform)
+            heads_before += (u32)__builtin_popcountll(M);
+            word = t0 >> ushift >> 6;
+            M = s_heads[word];
+        }
+        if (t < T) {
+            const u32 bit = ui & 63;
+            const u32 upto = (u32)__builtin_popcountll(M & (bit == 63 ? ~0ULL : ((2ULL << bit) - 1)));
+            const u32 owner = s_nz[heads_before + upto - 1];
+            const u32 e = ((ui - s_excl[owner]) << ushift) | (t & ((1u << ushift) - 1));
+            const u32 sl = e * LY::ROW + owner;
+            const u32 d = s_dst[owner];
+            if (d != 0xffffffffu) {
+                a.hash[ubase + d + e] = *reinterpret_cast<const u64 *>(lds + LY::SH + sl * 8);
+                u32 p = *reinterpret_cast<const u16 *>(lds + LY::SP + sl * 2);
+                if (STRAND16) p = (p & 0x7fffu) | ((p & 0x8000u) << 16);
+                a.pos[ubase + d + e] = p;
+            }
+        }
+    }
+    wave_sync_lds();
+}
+
+// ---------------------------------------------------------------------------------------
+// Dense minimizers (small w): a 150-bp read at w = 5 selects ~43 positions, more than the 32 k_minimizer_fast stages per
+// read, so almost every unit took its recompute-and-store-directly path (w = 5: 250 Gbases/s against 620 at w = 10).
+// Here every read owns a slab of `slab_read` tuples (as the protein minimizer does) and the wavefront flushes its staging
+// every NB blocks in whole groups of 16 tuples per read (flush_rows); fewer than 16 stay staged until the next round.
+// ---------------------------------------------------------------------------------------
+template <int W>
+struct DenseCfg {
+    static constexpr int NB = (24 / W) > 0 ? (24 / W) : 1;  // blocks per flush round (~24 steps)
+    static constexpr int CAP = NB * W + 15;                 // rows = CAP + 1: 15 left-over + NB*W new + the scribble row
+};
+
+template <int W>
+__global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
+    constexpr int CAP = DenseCfg<W>::CAP, NB = DenseCfg<W>::NB;
+    typedef FLds<CAP, true> LY;
+    __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
+    LDSQ char *const ldsq = (LDSQ char *)lds;
+    const int lane = lane_id();
+    build_xtab(reinterpret_cast<uint4 *>(lds + LY::TAB), a.k, lane);
+    __syncthreads();
+    const u64 slab_read = a.slab_read;
+    for (u32 unit = next_ticket(a.ticket, lane) * 4u, uend = unit + 4u; unit < a.nunits; ++unit, ({
+             if (unit == uend) {
+                 unit = next_ticket(a.ticket, lane) * 4u;
+                 uend = unit + 4u;
+             }
+         })) {
+        const u64 r = (u64)unit * 64 + lane;
+        u64 off = 0, L = 0;
+        if (r < a.n) {
+            const u64 d = a.desc[r];
+            off = d >> 24;
+            L = d & 0xffffffULL;
+        }
+        const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
+        const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
+        const u32 nk_max = wave_max_u32(nk);
+        const bool uni = __builtin_amdgcn_ballot_w64(nk != nk_max) == 0;
+        const u64 ubase = (u64)unit * 64 * slab_read;
+        u32 done = 0, tie = 0;
+        if (nk_max) {
+            FastMin<W, CAP, true, false> fm;
+            fm.w = a.words + off;
+            fm.lds = ldsq;
+            fm.k = a.k;
+            fm.lane = lane;
+            fm.nk = nk;
+            fm.fl = fm.fh_ = fm.rl = fm.rh_ = 0;
+            fm.prev = 0xffffffffu;
+            fm.tie = 0;
+            fm.slot = (u32)lane * 8u;
+            for (int t0 = 0; t0 < a.k - 1; t0 += 16) {  // warm-up: bases 0..k-2 enter, nothing leaves
+                const u32 word = fm.w[t0 >> 4];
+                const int nb = (a.k - 1 - t0) < 16 ? (a.k - 1 - t0) : 16;
+                for (int j = 0; j < nb; ++j)
+                    fm.roll(*reinterpret_cast<LDSQ const u32x4 *>(ldsq + LY::TAB + 256 + (((word >> (2 * j)) & 3) << 4)));
+            }
+            fm.load_block_words(0);
+            int inround = 0;
+            for (u32 i0 = 0; i0 < nk_max; i0 += W) {
+                if (i0 == 0) {
+                    if (uni) fm.template block<true, true, false>(0);
+                    else fm.template block<true, false, false>(0);
+                } else if (i0 + W > nk_max || !uni) {
+                    fm.template block<false, false, false>(i0);
+                } else {
+                    fm.template block<false, true, false>(i0);
+                }
+                const bool last = i0 + W >= nk_max;
+                if (++inround == NB || last) {
+                    inround = 0;
+                    const u32 cnt = (fm.slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);  // staged, left-overs included
+                    flush_rows<LY, true>(lds, lane, cnt, last, done, slab_read, ubase, a);
+                    const u32 nfl = last ? cnt : (cnt & ~15u);
+                    if (!last) {  // move the left-over (< 16 tuples) down to row 0
+                        const u32 left = cnt - nfl;
+                        if (__builtin_amdgcn_ballot_w64(nfl != 0)) {
+                            for (u32 e = 0; e < 15; ++e) {
+                                if (nfl && e < left) {
+                                    const u32 src = (nfl + e) * LY::ROW + lane, dst = e * LY::ROW + lane;
+                                    *reinterpret_cast<u64 *>(lds + LY::SH + dst * 8) = *reinterpret_cast<const u64 *>(lds + LY::SH + src * 8);
+                                    *reinterpret_cast<u16 *>(lds + LY::SP + dst * 2) = *reinterpret_cast<const u16 *>(lds + LY::SP + src * 2);
+                                }
+                            }
+                        }
+                        fm.slot = (left * LY::ROW + (u32)lane) * 8u;
+                    }
+                    done += nfl;
+                }
+            }
+            tie = fm.tie;
+        }
+        if (r < a.n) {
+            a.refs[r] = ((ubase + (u64)lane * slab_read) << 24) | done;
+            u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
+            if (tie && ok) sbyte |= BSK_ST_FIRST_WINDOW_TIE;
+            if (ok && a.rflags) sbyte |= a.rflags[r];
+            a.status[r] = sbyte;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // ntHash stream (kind BSK_NTHASH), 2-bit input: value i of read r -> hash[first(r) + i].
 // Same rolling core as above, unrolled by 16 (one packed word of bases per block); the 16
@@ -562,6 +726,33 @@ static inline int fast_minimizer_blocks_per_cu_t(int w) {
 int fast_minimizer_blocks_per_cu(int w) { return fast_minimizer_blocks_per_cu_t<true>(w); }
 
 // staged positions are 15 bit + strand: the fast path takes reads shorter than 32768 bases (longer: generic kernel)
+#define BSK_DENSE_WS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9)
+bool dense_minimizer_supported(int w) { return w >= 2 && w <= 9; }
+int dense_minimizer_blocks_per_cu(int w) {
+    int nb = 0;
+    hipError_t e = hipErrorInvalidValue;
+    switch (w) {
+#define X(WW) \
+    case WW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_minimizer_dense<WW>, 64, 0); break;
+        BSK_DENSE_WS(X)
+#undef X
+        default: break;
+    }
+    if (e != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        nb = 1;
+    }
+    return nb;
+}
+void dense_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a) {
+    switch (w) {
+#define X(WW) \
+    case WW: hipLaunchKernelGGL((k_minimizer_dense<WW>), dim3(grid), dim3(64), 0, stream, a); break;
+        BSK_DENSE_WS(X)
+#undef X
+        default: break;
+    }
+}
 void fast_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a) {
     switch (w) {
 #define X(WW) \

@@ -132,62 +132,6 @@ struct FastProt {
     }
 };
 
-// Flush staged tuples to the per-sequence slabs.  Regular rounds move only whole groups of 16 tuples per lane
-// (a full, aligned 128-byte line of hashes and 64 bytes of positions: no partial-line writes; measured 2.2x
-// faster than flushing every tuple of every round); the final round moves what is left.
-template <class LY>
-__device__ __forceinline__ void flush_rows(char *lds, int lane, u32 cnt, bool last, u32 done, u64 slab_read, u64 ubase,
-                                           const KArgs &a) {
-    u32 *s_excl = reinterpret_cast<u32 *>(lds + LY::EXCL);
-    u64 *s_heads = reinterpret_cast<u64 *>(lds + LY::HEADS);
-    u8 *s_nz = reinterpret_cast<u8 *>(lds + LY::NZ);
-    u32 *s_dst = reinterpret_cast<u32 *>(lds + LY::DST);
-    // unit of work: a group of 16 tuples (regular round) or a single tuple (final round)
-    const u32 units = last ? cnt : (cnt >> 4);
-    const u32 ushift = last ? 0u : 4u;
-    const u32 incl = wave_incl_scan_u32(units, lane);
-    const u32 excl = incl - units;
-    const u32 U = wave_bcast_u32(incl, 63);
-    if (U == 0) return;
-    const u64 nzmask = __builtin_amdgcn_ballot_w64(units > 0);
-    const bool fits = (u64)done + ((u64)units << ushift) <= slab_read;
-    if (__builtin_amdgcn_ballot_w64(!fits) && lane == 0) atomicOr(&a.ticket[1], 1u);  // slab too small: host falls back
-    s_excl[lane] = excl;
-    s_dst[lane] = fits ? (u32)(lane * slab_read + done) : 0xffffffffu;
-    if (lane < LY::ROWS) s_heads[lane] = 0;
-    wave_sync_lds();
-    if (units > 0) {
-        s_nz[__builtin_amdgcn_mbcnt_hi((u32)(nzmask >> 32), __builtin_amdgcn_mbcnt_lo((u32)nzmask, 0))] = (u8)lane;
-        atomicOr(&s_heads[excl >> 6], 1ULL << (excl & 63));
-    }
-    wave_sync_lds();
-    const u32 T = U << ushift;  // tuples to move
-    u32 heads_before = 0, word = 0xffffffffu;
-    u64 M = 0;
-    for (u32 t0 = 0; t0 < T; t0 += 64) {
-        const u32 t = t0 + lane;
-        const u32 ui = t >> ushift;  // work-unit index of this lane's tuple
-        if ((t0 >> ushift >> 6) != word) {  // next 64 work units: next head word (wave-uniform)
-            heads_before += (u32)__builtin_popcountll(M);
-            word = t0 >> ushift >> 6;
-            M = s_heads[word];
-        }
-        if (t < T) {
-            const u32 bit = ui & 63;
-            const u32 upto = (u32)__builtin_popcountll(M & (bit == 63 ? ~0ULL : ((2ULL << bit) - 1)));
-            const u32 owner = s_nz[heads_before + upto - 1];
-            const u32 e = ((ui - s_excl[owner]) << ushift) | (t & ((1u << ushift) - 1));
-            const u32 sl = e * LY::ROW + owner;
-            const u32 d = s_dst[owner];
-            if (d != 0xffffffffu) {
-                a.hash[ubase + d + e] = *reinterpret_cast<const u64 *>(lds + LY::SH + sl * 8);
-                a.pos[ubase + d + e] = *reinterpret_cast<const u16 *>(lds + LY::SP + sl * 2);
-            }
-        }
-    }
-    wave_sync_lds();
-}
-
 template <int W, int K>
 __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
     typedef FastProt<W, K> FP;
@@ -259,7 +203,7 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
                 // ---- flush whole 16-tuple groups (= full 128-byte lines of hashes) of every lane to its slab ----
                 const u32 cnt = (fp.slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);  // staged, leftovers included
                 const bool last = i0 + MB >= nk_max;                              // final round: flush everything
-                flush_rows<LY>(lds, lane, cnt, last, done, slab_read, ubase, a);
+                flush_rows<LY, false>(lds, lane, cnt, last, done, slab_read, ubase, a);
                 const u32 nfl = last ? cnt : (cnt & ~15u);
                 if (!last) {  // move the leftover (< 16 tuples) down to row 0
                     const u32 left = cnt - nfl;

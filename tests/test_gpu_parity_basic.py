@@ -184,3 +184,14 @@ def test_degenerate_batches(engine):
                 assert t.info()["n_bases"] == 0
                 t.close()
             b.close()
+
+
+@pytest.mark.parametrize("k,w", [(21, 2), (21, 5), (15, 8), (31, 4)])
+def test_dense_minimizers_and_their_fallback(engine, oracle, k, w):
+    """Small windows select more than 32 positions per 150-bp read: the per-read-slab kernel (k_minimizer_dense) flushes
+    mid-read; a low-complexity read (a new minimizer at every position) outgrows its slab and makes the call re-plan."""
+    rng = random.Random(k * 7 + w)
+    seqs = [rand_dna(rng, rng.choice([150, 150, 250, rng.randint(1, 300)])) for _ in range(300)]
+    check_minimizer(engine, oracle, seqs, k, w)                                   # dense kernel
+    check_minimizer(engine, oracle, seqs + ["A" * 250, "AC" * 100], k, w)        # slab overflow -> re-plan
+    check_minimizer(engine, oracle, seqs + [rand_dna(rng, 200, "ACGTN")], k, w)  # mixed: dense main launch + ASCII side launch
