@@ -144,6 +144,45 @@ func (b *Batch) run(p C.bsk_params) (*Result, error) {
 	return res, nil
 }
 
+// SketchSets runs the sketch named by p and returns, per sequence (wholeBatch = false) or for the whole batch, the
+// sorted distinct hash values -- optionally FracMinHash-filtered (hash <= MaxUint64/scale) -- computed on the device
+// (bsk_result_sets): what a caller otherwise builds with append + sort + dedup over the Next() stream.
+func (b *Batch) sketchSets(p C.bsk_params, wholeBatch bool, scale int) (offsets []uint64, values []uint64, err error) {
+	var r *C.bsk_result
+	if err = b.eng.err(C.bsk_sketch(b.eng.ctx, b.h, &p, &r)); err != nil {
+		return nil, nil, err
+	}
+	defer C.bsk_result_release(r)
+	scope := C.int(C.BSK_SETS_PER_SEQUENCE)
+	if wholeBatch {
+		scope = C.int(C.BSK_SETS_WHOLE_BATCH)
+	}
+	var s *C.bsk_sets
+	if err = b.eng.err(C.bsk_result_sets(b.eng.ctx, r, scope, C.int(scale), &s)); err != nil {
+		return nil, nil, err
+	}
+	defer C.bsk_sets_release(s)
+	var nSets, nValues C.uint64_t
+	C.bsk_sets_info(s, &nSets, &nValues)
+	offsets = make([]uint64, int(nSets)+1)
+	values = make([]uint64, int(nValues)+1)
+	rc := C.bsk_sets_fetch(b.eng.ctx, s, 0, nSets, (*C.uint64_t)(unsafe.Pointer(&offsets[0])), (*C.uint64_t)(unsafe.Pointer(&values[0])), nValues+1)
+	if err = b.eng.err(rc); err != nil {
+		return nil, nil, err
+	}
+	return offsets, values[:int(nValues)], nil
+}
+
+// MinimizerSets: sorted distinct minimizer hashes of every sequence (or of the batch).
+func (b *Batch) MinimizerSets(k, w int, wholeBatch bool, scale int) ([]uint64, []uint64, error) {
+	return b.sketchSets(C.bsk_params{kind: C.BSK_MINIMIZER, k: C.int32_t(k), w: C.int32_t(w), canonical: 1}, wholeBatch, scale)
+}
+
+// SyncmerSets: the same for the syncmer sketch.
+func (b *Batch) SyncmerSets(k, s int, wholeBatch bool, scale int) ([]uint64, []uint64, error) {
+	return b.sketchSets(C.bsk_params{kind: C.BSK_SYNCMER, k: C.int32_t(k), s: C.int32_t(s), canonical: 1}, wholeBatch, scale)
+}
+
 func b2i(b bool) C.int32_t {
 	if b {
 		return 1
