@@ -7,7 +7,7 @@
 #include "kernels_generic.hpp"  // KArgs
 
 #define BSK_FAST_CAP 32   // tuples staged per read by k_minimizer_fast (slab = 64 * CAP tuples per unit)
-#define BSK_SYN_CAP 16    // same for k_syncmer_fast
+#define BSK_SYN_CAP 28    // same for k_syncmer_fast (19.9 KB of LDS per wavefront: still 8 per CU)
 #define BSK_ASCII_PAD 1024  // slack behind residue / ASCII buffers: the 16-byte staging loads read past a chunk's end
 
 namespace bsk {
