@@ -862,7 +862,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         // fast path: 2-bit input, a window size with a compiled specialisation, positions that fit 15 bits
         // windows that select more positions per read than the slab kernel stages (32): per-read slabs + mid-read flushes
         const double nwin = (double)b->maxlen - p->k - p->w + 2;
-        if (!use_ascii && dense_minimizer_supported(p->w) && b->maxlen < 32768u && nwin * 2.0 / (p->w + 1.0) > 26.0 && !ctx->no_dense &&
+        if (!use_ascii && dense_minimizer_supported(p->w) && b->maxlen < 32768u && nwin * 2.0 / (p->w + 1.0) > 22.0 && !ctx->no_dense &&
             !getenv("BSK_FORCE_GENERIC") && !getenv("BSK_NO_DENSE")) {
             pl.which = K_MIN_DENSE;
             pl.fast_w = p->w;
