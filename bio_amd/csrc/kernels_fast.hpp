@@ -726,8 +726,21 @@ static inline int fast_minimizer_blocks_per_cu_t(int w) {
 int fast_minimizer_blocks_per_cu(int w) { return fast_minimizer_blocks_per_cu_t<true>(w); }
 
 // staged positions are 15 bit + strand: the fast path takes reads shorter than 32768 bases (longer: generic kernel)
-#define BSK_DENSE_WS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9)
-bool dense_minimizer_supported(int w) { return w >= 2 && w <= 9; }
+void fast_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a) {
+    switch (w) {
+#define X(WW) \
+    case WW: hipLaunchKernelGGL((k_minimizer_fast<WW, BSK_FAST_CAP, true>), dim3(grid), dim3(64), 0, stream, a); break;
+        BSK_FAST_WS(X)
+#undef X
+        default: break;
+    }
+}
+
+#endif  // BSK_IMPL_MINIMIZER
+
+#ifdef BSK_IMPL_DENSE  // k_minimizer_dense<W>: its own translation unit (k_minimizer_dense.hip)
+#define BSK_DENSE_WS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+bool dense_minimizer_supported(int w) { return w >= 2 && w <= 16; }
 int dense_minimizer_blocks_per_cu(int w) {
     int nb = 0;
     hipError_t e = hipErrorInvalidValue;
@@ -753,16 +766,6 @@ void dense_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a)
         default: break;
     }
 }
-void fast_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a) {
-    switch (w) {
-#define X(WW) \
-    case WW: hipLaunchKernelGGL((k_minimizer_fast<WW, BSK_FAST_CAP, true>), dim3(grid), dim3(64), 0, stream, a); break;
-        BSK_FAST_WS(X)
-#undef X
-        default: break;
-    }
-}
-
-#endif  // BSK_IMPL_MINIMIZER
+#endif  // BSK_IMPL_DENSE
 
 }  // namespace bsk
