@@ -195,3 +195,28 @@ def test_dense_minimizers_and_their_fallback(engine, oracle, k, w):
     check_minimizer(engine, oracle, seqs, k, w)                                   # dense kernel
     check_minimizer(engine, oracle, seqs + ["A" * 250, "AC" * 100], k, w)        # slab overflow -> re-plan
     check_minimizer(engine, oracle, seqs + [rand_dna(rng, 200, "ACGTN")], k, w)  # mixed: dense main launch + ASCII side launch
+
+
+def test_timed_entry_point_on_every_plan(engine):
+    """bsk_sketch_timed (the bench's entry) must leave the same result as bsk_sketch whatever plan the batch takes:
+    slab, dense, mixed, tiled, protein, translated."""
+    rng = random.Random(31)
+    reads = [rand_dna(rng, rng.choice([150, 250, rng.randint(30, 300)])) for _ in range(400)]
+    with_n = reads[:399] + [rand_dna(rng, 200, "ACGTN")]
+    contigs = [rand_dna(rng, n) for n in (6000, 300, 9000)]
+    prot = ["".join(rng.choice("ACDEFGHIKLMNPQRSTVWY") for _ in range(rng.randint(40, 500))) for _ in range(200)]
+    cases = [(reads, L.ALPHA_DNA, [(L.MINIMIZER, dict(k=21, w=11)), (L.MINIMIZER, dict(k=21, w=5)), (L.SYNCMER, dict(k=31, s=11)), (L.NTHASH, dict(k=21)),
+                                   (L.SIMHASH, dict(k=21, m=5, scale=5)), (L.PROT_MINIMIZER, dict(k=9, w=5, frame=2))]),
+             (with_n, L.ALPHA_DNA, [(L.MINIMIZER, dict(k=21, w=11)), (L.NTHASH, dict(k=21)), (L.SYNCMER, dict(k=21, s=11))]),
+             (contigs, L.ALPHA_DNA, [(L.MINIMIZER, dict(k=21, w=11)), (L.NTHASH, dict(k=31)), (L.SYNCMER, dict(k=31, s=16))]),
+             (prot, L.ALPHA_PROTEIN, [(L.PROT_MINIMIZER, dict(k=9, w=5)), (L.PROT_HASH, dict(k=10))])]
+    for seqs, alpha, kinds in cases:
+        b = engine.batch(seqs, alpha)
+        for kind, pk in kinds:
+            p = engine.params(kind, **pk)
+            want = engine.run(b, p).digest()
+            res, ms = engine.run_timed(b, p, 1, 2)
+            assert len(ms) == 2 and all(m > 0 for m in ms)
+            assert res.digest() == want, (kind, pk)
+            res2, _ = engine.run_timed(b, p, 0, 1, reuse=res)   # the bench's pattern: repeat on the sized result
+            assert res2.digest() == want, (kind, pk)
