@@ -821,6 +821,13 @@ struct Plan {
     int side_grid = 1;
 };
 
+// per-read slabs are sized by the LONGEST read: acceptable only while that does not blow the result arrays up (a batch of
+// short reads with one long outlier would otherwise reserve the outlier's slab for every read)
+static bool slab_budget_ok(const bsk_batch *b, u64 slab_read) {
+    const double mean = b->n ? (double)b->n_bases / (double)b->n : 0.0;
+    return (double)b->maxlen <= 4.0 * mean + 64.0 || (double)b->n * (double)slab_read * 12.0 < 256.0 * 1024 * 1024;
+}
+
 static bool which_is_fast(Which w) {
     return w == K_MIN_FAST || w == K_NT_FAST || w == K_SYN_FAST || w == K_SIM_FAST || w == K_MIN_DENSE;
 }
@@ -862,7 +869,8 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         // fast path: 2-bit input, a window size with a compiled specialisation, positions that fit 15 bits
         // windows that select more positions per read than the slab kernel stages (32): per-read slabs + mid-read flushes
         const double nwin = (double)b->maxlen - p->k - p->w + 2;
-        if (!use_ascii && dense_minimizer_supported(p->w) && b->maxlen < 32768u && nwin * 2.0 / (p->w + 1.0) > 22.0 && !ctx->no_dense &&
+        const u64 dense_slab = (std::min<u64>((u64)std::max(nwin, 0.0), (u64)(std::max(nwin, 0.0) * 2.6 / (p->w + 1.0)) + 16) + 15) & ~(u64)15;
+        if (!use_ascii && dense_minimizer_supported(p->w) && b->maxlen < 32768u && nwin * 2.0 / (p->w + 1.0) > (double)env_u32("BSK_DENSE_MIN", 22) && !ctx->no_dense && slab_budget_ok(b, dense_slab) &&
             !getenv("BSK_FORCE_GENERIC") && !getenv("BSK_NO_DENSE")) {
             pl.which = K_MIN_DENSE;
             pl.fast_w = p->w;
@@ -939,7 +947,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         }
     } else if (p->kind == BSK_PROT_MINIMIZER) {
         if (fast_prot_supported(p->w, p->k) && b->maxlen < 65536u && b->maxlen >= (u32)(p->k + p->w) && !getenv("BSK_FORCE_GENERIC") &&
-            !ctx->no_prot_fast) {
+            !ctx->no_prot_fast && slab_budget_ok(b, (u64)b->maxlen)) {
             pl.which = K_PROT_MIN_FAST;
             pl.fast_w = p->w;
             pl.fast_k = p->k;
@@ -1645,7 +1653,8 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
     // long sequences run as tiles; protein: only when really long (the protein kernels take any length per lane, slowly)
     const bool is_dna = b->alphabet == BSK_ALPHA_DNA;
     const u32 tile_min = env_u32("BSK_TILE_MIN", (!is_dna || kind_has_pos(p->kind)) ? 4096u : 16u * (BSK_NT_FAST_WORDS - 2));
-    const bool tiled = kind_tiles(p) && (is_dna != prot_kind) && !getenv("BSK_NO_TILES") && ((is_dna && !b->desc) || b->maxlen > tile_min);
+    const bool outlier = !is_dna && p->kind == BSK_PROT_MINIMIZER && b->maxlen > 512 && !slab_budget_ok(b, (u64)b->maxlen);  // tiles are uniform: small slabs
+    const bool tiled = kind_tiles(p) && (is_dna != prot_kind) && !getenv("BSK_NO_TILES") && ((is_dna && !b->desc) || b->maxlen > tile_min || outlier);
     rc = tiled ? sketch_tiled(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms)
                : run_planned(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms);
     if (tmp) bsk_batch_destroy(tmp);

@@ -345,3 +345,30 @@ def test_protein_slab_overflow_falls_back_with_many_units(engine, oracle):
                 assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0
                 continue
             assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep), (i, len(q))
+
+
+def test_long_outliers_do_not_inflate_per_read_slabs(engine, oracle):
+    """Kernels with one slab per read size it by the longest read: a batch of short sequences with one long outlier must not
+    reserve the outlier's slab for everybody (proteins: the batch is tiled instead; DNA: the unit-slab kernel is used)."""
+    rng = random.Random(5)
+    prot = [rand_seq(rng, rng.randint(30, 120), AA) for _ in range(6000)]
+    prot[1234] = rand_seq(rng, 3000, AA)
+    b = engine.batch(prot, L.ALPHA_PROTEIN)
+    res = engine.run(b, engine.params(L.PROT_MINIMIZER, 9, w=5))
+    assert b.info()["device_bytes"] < 50e6
+    for i in list(range(0, 6000, 97)) + [1233, 1234, 1235]:
+        st, h, p = res.read(i)
+        try:
+            eh, ep, _ = oracle.protein_minimizer(prot[i], 9, 5, closed=True)
+        except oracle.OracleError:
+            assert (st & L.ST_CODE_MASK) == L.ST_SHORT
+            continue
+        assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep), i
+    dna = [rand_seq(rng, 150) for _ in range(4000)]
+    dna[77] = rand_seq(rng, 3500)
+    b = engine.batch(dna)
+    res = engine.run(b, engine.params(L.MINIMIZER, 21, w=5))
+    for i in (0, 76, 77, 78, 3999):
+        st, h, p = res.read(i)
+        eh, ep, es, _ = oracle.minimizer(dna[i], 21, 5, False, closed=True)
+        assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep), i
