@@ -1291,6 +1291,18 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
     const bool sizing = *result == nullptr || warmup + iters == 0;
     for (int attempt = 0; sizing && attempt < 3; ++attempt) {
         rc = result_prepare(ctx, result, b->n, p->kind, cap + side_cap);
+        if (rc == BSK_ERR_NOMEM && (pl.which == K_MIN_DENSE || pl.which == K_PROT_MIN_FAST) && attempt < 2) {
+            // per-read slabs did not fit the device: the unit-slab / dense-CSR kernels need far less
+            ctx->no_prot_fast = true;
+            ctx->no_dense = true;
+            pl = Plan();
+            rc = make_plan(ctx, b, p, pl);
+            ctx->no_prot_fast = false;
+            ctx->no_dense = false;
+            if (rc != BSK_OK) return cleanup(rc);
+            cap = pl.slab ? pl.slab_total + std::max<u64>(65536, pl.slab_total / 50) : estimate_cap(b, p, circ_ext);
+            continue;
+        }
         if (rc != BSK_OK) return cleanup(rc);
         bsk_result *res = *result;
         res->main_cap = pl.mixed ? cap : 0;
