@@ -1,6 +1,7 @@
 // C++ mirror of the reference's sketches/sketch_test.go + iterator_test.go, driven through
 // bio_amd/csrc/sketches.hpp -> C ABI -> GPU.  Built by __graft_entry__.build(), run by tests/test_gpu_cpp_mirror.py.
 #include <cstdio>
+#include <string>
 #include <vector>
 
 #include "sketches.hpp"
@@ -104,6 +105,54 @@ int main() {
         CHECK(m >= 1 && m <= n);
         Seq tiny{false, dna.substr(0, 3 * k - 1)};
         CHECK(!NewProteinIterator(tiny, k, 1, 1, &err) && err == ErrShortSeq);  // iterator-protein.go:50
+    }
+    {  // plain C ABI, file to sketch sets: FASTQ -> bsk_fastx -> device batch -> minimizers -> sorted distinct hashes
+        const char *path = "/tmp/bsk_cpp_test.fq";
+        FILE *f = std::fopen(path, "w");
+        CHECK(f != nullptr);
+        const std::string r1 = "AAGTTTGAATCATTCAACTATCTAGTTTTCAGAGAACAATGTTCTCTAAAGAATAGAAAAGAGTCATTGTGCGGTGATGATGGCGGGAAGGATCCACCTG";
+        if (f) {
+            std::fprintf(f, "@r1 first\n%s\n+\n%s\n@r2\n%s\n+\n%s\n@r3\nACGT\n+\n@@@@\n", r1.c_str(), std::string(r1.size(), 'I').c_str(),
+                         r1.c_str(), std::string(r1.size(), '@').c_str());
+            std::fclose(f);
+        }
+        bsk_ctx *ctx = nullptr;
+        CHECK(bsk_ctx_create(0, &ctx) == BSK_OK);
+        bsk_fastx *fx = nullptr;
+        CHECK(bsk_fastx_open(path, &fx) == BSK_OK);
+        bsk_batch *b = nullptr;
+        uint64_t nrec = 0;
+        CHECK(bsk_batch_from_fastx(ctx, fx, 0, 0, -1, &b, &nrec) == BSK_OK && nrec == 3);
+        int isq = 0, alpha = -1;
+        CHECK(bsk_fastx_info(fx, &isq, &alpha) == BSK_OK && isq == 1 && alpha == BSK_ALPHA_DNA);
+        bsk_params p{};
+        p.kind = BSK_MINIMIZER;
+        p.k = 21;
+        p.w = 11;
+        p.canonical = 1;
+        bsk_result *res = nullptr;
+        CHECK(bsk_sketch(ctx, b, &p, &res) == BSK_OK);
+        bsk_sets *sets = nullptr;
+        CHECK(bsk_result_sets(ctx, res, BSK_SETS_PER_SEQUENCE, 1, &sets) == BSK_OK);
+        uint64_t ns = 0, nv = 0;
+        CHECK(bsk_sets_info(sets, &ns, &nv) == BSK_OK && ns == 3 && nv > 0);
+        std::vector<uint64_t> offs(ns + 1), vals(nv + 1);
+        CHECK(bsk_sets_fetch(ctx, sets, 0, ns, offs.data(), vals.data(), nv + 1) == BSK_OK);
+        CHECK(offs[1] - offs[0] == offs[2] - offs[1] && offs[3] == offs[2]);  // r1 == r2, r3 is too short
+        bool same = true, sorted = true;
+        for (uint64_t i = 0; i < offs[1]; ++i) {
+            same = same && vals[i] == vals[offs[1] + i];
+            sorted = sorted && (i == 0 || vals[i - 1] < vals[i]);
+        }
+        CHECK(same && sorted);
+        bsk_sets_release(sets);
+        bsk_result_release(res);
+        bsk_batch_destroy(b);
+        uint64_t again = 1;
+        CHECK(bsk_batch_from_fastx(ctx, fx, 0, 0, -1, &b, &again) == BSK_OK && again == 0);  // end of file
+        bsk_fastx_close(fx);
+        bsk_ctx_destroy(ctx);
+        std::remove(path);
     }
     std::printf(fails ? "FAILED %d checks\n" : "all C++ mirror checks passed\n", fails);
     return fails ? 1 : 0;
