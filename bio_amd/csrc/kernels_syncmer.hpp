@@ -230,7 +230,8 @@ struct FastSyn {
 
 
 template <int W>
-__global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves per SIMD: at most 256 VGPRs
+__global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves per SIMD: at most 256 VGPRs.  One wave with 512 registers
+                                                                    // removes the W >= 13 spills but runs 1.5x slower (432 -> 284 Gbases/s at W = 20)
     constexpr int CAP = BSK_SYN_CAP;
     typedef SynLds<W, CAP> LY;
     __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves p
         const bool any_over = __builtin_amdgcn_ballot_w64(cnt > (u32)CAP) != 0;
         u64 base = (u64)unit * slab;
         if (!any_over) {
-            fast_copyout<LY, true, CAP>(lds, lane, cnt, excl, T, base, a);
+            fast_copyout<LY, true, CAP, (W >= 13 ? 1 : 4)>(lds, lane, cnt, excl, T, base, a);
         } else {
             u64 ob = 0;
             if (lane == 0) ob = atomicAdd(a.total + 1, (u64)T);
