@@ -29,6 +29,8 @@ namespace bsk {
 
 typedef u64 lmask;  // one bit per lane, lives in an SGPR pair
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+#define GLBQ __attribute__((address_space(1)))
+typedef u32x4 u32x4_u __attribute__((aligned(1)));  // byte-aligned 16-byte global load (unaligned access mode of the HSA ABI)
 
 // VOP3 compare -> SGPR pair, VOP3 select <- SGPR pair.  (v_cmp -> v_cndmask through an
 // SGPR needs no software wait states on gfx9; the asm only pins the encoding.)
@@ -92,7 +94,12 @@ struct FastMin {
     u32 slot;                          // byte offset (from SH) of this lane's next staging slot = (cnt*65 + lane)*8
     u32 in_lo, in_hi, out_lo, out_hi;  // packed words of the current block
     u32 in_h2, out_h2;                 // W > 16: a block spans up to three words
+    u32x4 pw;                          // run(): the read's first four words, loaded by the caller (one unit ahead)
 
+    __device__ __forceinline__ u32 first_word(u32 i) const {  // i is wave-uniform
+        if (i < 4) return i == 0 ? pw.x : i == 1 ? pw.y : i == 2 ? pw.z : pw.w;
+        return w[i];
+    }
     __device__ __forceinline__ void load_block_words(u32 i0) {
         const u32 t0 = i0 + (u32)k - 1;
         in_lo = w[t0 >> 4];
@@ -203,12 +210,34 @@ struct FastMin {
         slot = (u32)lane * 8u;
         // warm-up: bases 0..k-2 enter, nothing leaves (table rows 16..19)
         for (int t0 = 0; t0 < k - 1; t0 += 16) {
-            const u32 word = w[t0 >> 4];
+            const u32 word = first_word((u32)t0 >> 4);
             const int nb = (k - 1 - t0) < 16 ? (k - 1 - t0) : 16;
-            for (int j = 0; j < nb; ++j)
+            int j = 0;
+            for (; j + 4 <= nb; j += 4) {  // four table rows in flight (one row per trip exposes the LDS latency 20 times per read)
+                const u32 sub = word >> (2 * j);
+                const u32x4 x0 = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB + 256 + ((sub & 3) << 4));
+                const u32x4 x1 = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB + 256 + ((sub & 0xc) << 2));
+                const u32x4 x2 = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB + 256 + (sub & 0x30));
+                const u32x4 x3 = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB + 256 + ((sub & 0xc0) >> 2));
+                roll(x0);
+                roll(x1);
+                roll(x2);
+                roll(x3);
+            }
+            for (; j < nb; ++j)
                 roll(*reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB + 256 + (((word >> (2 * j)) & 3) << 4)));
         }
-        load_block_words(0);
+        {  // block 0's words come from the preloaded four (k <= 33; beyond, from memory)
+            const u32 wi = ((u32)k - 1) >> 4;
+            in_lo = first_word(wi);
+            in_hi = first_word(wi + 1);
+            out_lo = pw.x;
+            out_hi = pw.y;
+            if (W > 16) {
+                in_h2 = first_word(wi + 2);
+                out_h2 = pw.z;
+            }
+        }
         block<true, UNI, false>(0);
         const u32 guard_from = (u32)((CAP - W) * LY::ROW + lane) * 8u;  // slot value from which a block could overrun row CAP-1
         for (u32 i0 = W; i0 < nk_max; i0 += W) {
@@ -294,6 +323,9 @@ __global__ __launch_bounds__(64, ((W > 16 && W <= 24) ? 2 : 1)) void k_minimizer
     build_xtab(reinterpret_cast<uint4 *>(lds + LY::TAB), a.k, lane);
     __syncthreads();
     const u64 slab = (u64)64 * CAP;
+    u64 d_next = 0;
+    u32x4 pw_next = {0, 0, 0, 0};
+    bool pre = false;
     // work distribution: a wave takes 8 consecutive units per ticket (one atomic per 512 reads)
     for (u32 unit = next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; unit < a.nunits; ++unit, ({
              if (unit == uend) {
@@ -302,12 +334,21 @@ __global__ __launch_bounds__(64, ((W > 16 && W <= 24) ? 2 : 1)) void k_minimizer
              }
          })) {
         const u64 r = (u64)unit * 64 + lane;
-        u64 off = 0, L = 0;
-        if (r < a.n) {
-            const u64 d = a.desc[r];
-            off = d >> 24;
-            L = d & 0xffffffULL;
+        // The descriptor and the first four words of a unit are loaded one unit ahead (within a ticket): a load issued at
+        // the unit's start returns only after the previous unit's copy-out stores have drained (loads and stores share the
+        // in-order vmcnt) and then costs two dependent memory latencies before the first base can be hashed.
+        u64 d;
+        u32x4 pw;
+        if (pre) {
+            d = d_next;
+            pw = pw_next;
+        } else {
+            d = r < a.n ? a.desc[r] : 0;
+            pw = *reinterpret_cast<const GLBQ u32x4_u *>((size_t)(a.words + (d >> 24)));
         }
+        const u64 off = d >> 24, L = d & 0xffffffULL;
+        const bool nxt = unit + 1 != uend && unit + 1 < a.nunits;
+        if (nxt) d_next = r + 64 < a.n ? a.desc[r + 64] : 0;
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
         const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
         const u32 nk_max = wave_max_u32(nk);
@@ -316,6 +357,7 @@ __global__ __launch_bounds__(64, ((W > 16 && W <= 24) ? 2 : 1)) void k_minimizer
         if (nk_max) {
             FastMin<W, CAP, POS16, false> fm;
             fm.w = a.words + off;
+            fm.pw = pw;
             fm.lds = ldsq;
             fm.k = a.k;
             fm.lane = lane;
@@ -325,6 +367,8 @@ __global__ __launch_bounds__(64, ((W > 16 && W <= 24) ? 2 : 1)) void k_minimizer
             cnt = fm.cnt;
             tie = fm.tie;
         }
+        if (nxt) pw_next = *reinterpret_cast<const GLBQ u32x4_u *>((size_t)(a.words + (d_next >> 24)));  // ahead of the copy-out stores
+        pre = nxt;
         // ---- unit epilogue: LDS -> HBM in read order into the unit's slab ----
         const u32 incl = wave_incl_scan_u32(cnt, lane);
         const u32 excl = incl - cnt;
@@ -343,6 +387,7 @@ __global__ __launch_bounds__(64, ((W > 16 && W <= 24) ? 2 : 1)) void k_minimizer
                 base = a.ovf_base + ob;
                 FastMin<W, CAP, POS16, true> fm;
                 fm.w = a.words + off;
+                fm.pw = pw;
                 fm.lds = ldsq;
                 fm.k = a.k;
                 fm.lane = lane;
@@ -480,7 +525,19 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
             for (int t0 = 0; t0 < a.k - 1; t0 += 16) {  // warm-up: bases 0..k-2 enter, nothing leaves
                 const u32 word = fm.w[t0 >> 4];
                 const int nb = (a.k - 1 - t0) < 16 ? (a.k - 1 - t0) : 16;
-                for (int j = 0; j < nb; ++j)
+                int j = 0;
+                for (; j + 4 <= nb; j += 4) {  // four table rows in flight
+                    const u32 sub = word >> (2 * j);
+                    const u32x4 x0 = *reinterpret_cast<LDSQ const u32x4 *>(ldsq + LY::TAB + 256 + ((sub & 3) << 4));
+                    const u32x4 x1 = *reinterpret_cast<LDSQ const u32x4 *>(ldsq + LY::TAB + 256 + ((sub & 0xc) << 2));
+                    const u32x4 x2 = *reinterpret_cast<LDSQ const u32x4 *>(ldsq + LY::TAB + 256 + (sub & 0x30));
+                    const u32x4 x3 = *reinterpret_cast<LDSQ const u32x4 *>(ldsq + LY::TAB + 256 + ((sub & 0xc0) >> 2));
+                    fm.roll(x0);
+                    fm.roll(x1);
+                    fm.roll(x2);
+                    fm.roll(x3);
+                }
+                for (; j < nb; ++j)
                     fm.roll(*reinterpret_cast<LDSQ const u32x4 *>(ldsq + LY::TAB + 256 + (((word >> (2 * j)) & 3) << 4)));
             }
             fm.load_block_words(0);

@@ -18,8 +18,6 @@
 
 namespace bsk {
 
-#define GLBQ __attribute__((address_space(1)))
-typedef u32x4 u32x4_u __attribute__((aligned(1)));  // byte-aligned 16-byte global load (unaligned access mode of the HSA ABI)
 typedef u32 u32_u __attribute__((aligned(1)));
 
 constexpr int ilcm4(int w) { return (w % 4 == 0) ? w : (w % 2 == 0 ? 2 * w : 4 * w); }

@@ -210,15 +210,36 @@ struct FastSyn {
         tie = 0;
         tm = 0;
         slot = (u32)lane * 8u;
+        // warm-ups: four table rows in flight per trip (one row per trip exposes the LDS latency k + s - 2 times per read)
         for (int t0 = 0; t0 < s - 1; t0 += 16) {  // s-mer warm-up
             const u32 word = w[t0 >> 4];
             const int nb = (s - 1 - t0) < 16 ? (s - 1 - t0) : 16;
-            for (int j = 0; j < nb; ++j) rolls(tabs(256 + (((word >> (2 * j)) & 3) << 4)));
+            int j = 0;
+            for (; j + 4 <= nb; j += 4) {
+                const u32 sub = word >> (2 * j);
+                const u32x4 x0 = tabs(256 + ((sub & 3) << 4)), x1 = tabs(256 + ((sub & 0xc) << 2)), x2 = tabs(256 + (sub & 0x30)),
+                            x3 = tabs(256 + ((sub & 0xc0) >> 2));
+                rolls(x0);
+                rolls(x1);
+                rolls(x2);
+                rolls(x3);
+            }
+            for (; j < nb; ++j) rolls(tabs(256 + (((word >> (2 * j)) & 3) << 4)));
         }
         for (int t0 = 0; t0 < k - 1; t0 += 16) {  // k-mer warm-up
             const u32 word = w[t0 >> 4];
             const int nb = (k - 1 - t0) < 16 ? (k - 1 - t0) : 16;
-            for (int j = 0; j < nb; ++j) rollk(tabk(256 + (((word >> (2 * j)) & 3) << 4)));
+            int j = 0;
+            for (; j + 4 <= nb; j += 4) {
+                const u32 sub = word >> (2 * j);
+                const u32x4 x0 = tabk(256 + ((sub & 3) << 4)), x1 = tabk(256 + ((sub & 0xc) << 2)), x2 = tabk(256 + (sub & 0x30)),
+                            x3 = tabk(256 + ((sub & 0xc0) >> 2));
+                rollk(x0);
+                rollk(x1);
+                rollk(x2);
+                rollk(x3);
+            }
+            for (; j < nb; ++j) rollk(tabk(256 + (((word >> (2 * j)) & 3) << 4)));
         }
         block<0>(0);
         if (ns_max > (u32)W) block<1>(W);
@@ -241,6 +262,8 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves p
     build_xtab(reinterpret_cast<uint4 *>(lds + LY::TABS), a.s, lane);
     __syncthreads();
     const u64 slab = (u64)64 * CAP;
+    u64 d_next = 0;
+    bool pre = false;
     for (u32 unit = next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; unit < a.nunits; ++unit, ({
              if (unit == uend) {
                  unit = next_ticket(a.ticket, lane) * 8u;
@@ -248,12 +271,11 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves p
              }
          })) {
         const u64 r = (u64)unit * 64 + lane;
-        u64 off = 0, L = 0;
-        if (r < a.n) {
-            const u64 d = a.desc[r];
-            off = d >> 24;
-            L = d & 0xffffffULL;
-        }
+        // the next unit's descriptors are loaded one unit ahead (a load issued here waits for the copy-out stores to drain)
+        const u64 d = pre ? d_next : (r < a.n ? a.desc[r] : 0);
+        const u64 off = d >> 24, L = d & 0xffffffULL;
+        pre = unit + 1 != uend && unit + 1 < a.nunits;
+        if (pre) d_next = r + 64 < a.n ? a.desc[r + 64] : 0;
         const long long Lorig = (long long)L - a.circ_ext;
         const bool ok = r < a.n && Lorig >= 0 && Lorig >= 2LL * a.k - a.s - 1 && L >= (u64)a.k;  // sketch.go:149
         const u32 nwin = ok ? (u32)(L - 2 * (u64)a.k + a.s + 2) : 0u;                             // end + 1
