@@ -75,9 +75,38 @@ struct FLds {
     static constexpr int TOTAL = DST + 256;
 };
 
-template <int W, int CAP, bool POS16, bool DIRECT>
+// Paired staging columns (k_minimizer_fast): lanes l and l+32 share column l & 31 of R rows; the low lane fills it from row
+// 0 upwards, the high lane from row R-1 downwards.  A column overflows when the two counts reach R together, so the
+// capacity follows the SUM of two reads' counts (k=21 w=11, 150 bp: mean 44.3, sd 3.5) instead of the maximum of each
+// (22.1, sd 2.45): 56 shared rows overflow as rarely as 2 x 32 private ones (1 % of units) and the wave's LDS drops
+// from 22.3 KB to 19.2 KB -- 8 waves per CU instead of 7, and throughput is linear in the waves.
+// Row R is the spare row for lanes that ran out of the column; the copy-out keeps its exclusive offsets there.
+#define BSK_PAIR_ROWS 56
+template <int R, bool POS16>
+struct PLds {
+    static constexpr int ROW = 33;  // 32 columns + 1: consecutive rows of a column rotate through the banks
+    static constexpr int PB = POS16 ? 2 : 4;
+    static constexpr int TAB = 0;
+    static constexpr int SH = 512;                                         // u64 [(R+1)*33]
+    static constexpr int SP = SH + (R + 1) * ROW * 8;                      // u16|u32 [(R+1)*33]
+    static constexpr int HEADS = SP + (((R + 1) * ROW * PB + 15) & ~15);   // u64 [NHEADS]
+    static constexpr int NHEADS = (32 * (R - 1)) / 64 + 2;                 // a unit holds at most 32*(R-1) tuples; the last word is never set
+    static constexpr int NZ = HEADS + NHEADS * 8;                          // u8 [64]
+    static constexpr int EXCL = SH + R * ROW * 8;                          // u32 [64] in the spare row (free once the pass is over)
+    static constexpr int TOTAL = NZ + 64;
+};
+template <bool PAIR, int CAP, bool POS16>
+struct MinLds {
+    typedef FLds<CAP, POS16> type;
+};
+template <int CAP, bool POS16>
+struct MinLds<true, CAP, POS16> {
+    typedef PLds<BSK_PAIR_ROWS, POS16> type;
+};
+
+template <int W, int CAP, bool POS16, bool DIRECT, bool PAIR = false>
 struct FastMin {
-    typedef FLds<CAP, POS16> LY;
+    typedef typename MinLds<PAIR, CAP, POS16>::type LY;
     static constexpr u32 SBIT = POS16 ? 0x8000u : 0x80000000u;  // strand bit inside the staged pos word
     const u32 *__restrict__ w;
     LDSQ char *lds;
@@ -92,6 +121,7 @@ struct FastMin {
     HV P;                  // running prefix minimum of the current block
     u32 prev, cnt, tie;
     u32 slot;                          // byte offset (from SH) of this lane's next staging slot = (cnt*65 + lane)*8
+    u32 sstep, slim, sspare;           // PAIR: signed row stride, last byte offset inside the column, the lane's spare slot
     u32 in_lo, in_hi, out_lo, out_hi;  // packed words of the current block
     u32 in_h2, out_h2;                 // W > 16: a block spans up to three words
     u32x4 pw;                          // run(): the read's first four words, loaded by the caller (one unit ahead)
@@ -147,7 +177,7 @@ struct FastMin {
         }
         load_block_words(i0 + W);  // next block's words: in flight while this block is hashed
         u32 vi = i0;               // k-mer index as a VGPR (selects need VGPR operands)
-        const u32 spare = (u32)(CAP * LY::ROW + lane) * 8u;
+        const u32 spare = PAIR ? sspare : (u32)(CAP * LY::ROW + lane) * 8u;
 #pragma unroll
         for (int o = 0; o < W; ++o) {
             roll(xs[o]);
@@ -171,11 +201,11 @@ struct FastMin {
                     // branch-free: every candidate is stored to the lane's next slot; the slot only advances when the
                     // candidate is a new selection, so anything else is overwritten (or left beyond the count)
                     u32 addr = slot;
-                    if (GUARD) addr = sel(__builtin_amdgcn_ballot_w64(slot < spare), slot, spare);
+                    if (GUARD) addr = sel(__builtin_amdgcn_ballot_w64(PAIR ? slot <= slim : slot < spare), slot, spare);  // (a column left downwards wraps above slim)
                     *reinterpret_cast<LDSQ u64 *>(lds + LY::SH + addr) = ((u64)m.hi << 32) | m.lo;
                     if (POS16) *reinterpret_cast<LDSQ u16 *>(lds + LY::SP + (addr >> 2)) = (u16)m.p;
                     else *reinterpret_cast<LDSQ u32 *>(lds + LY::SP + (addr >> 1)) = m.p;
-                    slot = sel(e, slot + (u32)(LY::ROW * 8), slot);
+                    slot = sel(e, slot + (PAIR ? sstep : (u32)(LY::ROW * 8)), slot);
                 } else {
                     if ((e >> lane) & 1) {
                         const u32 c = (slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);
@@ -208,6 +238,14 @@ struct FastMin {
         prev = 0xffffffffu;
         tie = 0;
         slot = (u32)lane * 8u;
+        const u32 col8 = (u32)(lane & 31) * 8u;
+        const bool up = lane < 32;
+        if (PAIR) {
+            slim = (u32)((BSK_PAIR_ROWS - 1) * LY::ROW * 8) + col8;
+            sspare = (u32)(BSK_PAIR_ROWS * LY::ROW * 8) + col8;
+            slot = up ? col8 : slim;
+            sstep = up ? (u32)(LY::ROW * 8) : (u32)(-(int)(LY::ROW * 8));
+        }
         // warm-up: bases 0..k-2 enter, nothing leaves (table rows 16..19)
         for (int t0 = 0; t0 < k - 1; t0 += 16) {
             const u32 word = first_word((u32)t0 >> 4);
@@ -239,10 +277,12 @@ struct FastMin {
             }
         }
         block<true, UNI, false>(0);
-        const u32 guard_from = (u32)((CAP - W) * LY::ROW + lane) * 8u;  // slot value from which a block could overrun row CAP-1
+        // slot value from which a block could overrun the lane's rows (PAIR: the whole column, counted from the lane's end)
+        const u32 guard_from = PAIR ? (u32)((BSK_PAIR_ROWS - W) * LY::ROW * 8) + col8 : (u32)((CAP - W) * LY::ROW + lane) * 8u;
         for (u32 i0 = W; i0 < nk_max; i0 += W) {
             // a lane stages at most W tuples per block: the bounded store is only needed near the cap
-            const bool guard = !DIRECT && __builtin_amdgcn_ballot_w64(slot > guard_from) != 0;
+            const u32 filled = (PAIR && !up) ? slim + col8 - slot : slot;  // = (rows used * ROW) * 8 + col8
+            const bool guard = !DIRECT && __builtin_amdgcn_ballot_w64(filled > guard_from) != 0;
             if (i0 + W > nk_max) {  // partial last block: per-lane bound check even when the wave is uniform
                 if (guard) block<false, false, true>(i0);
                 else block<false, false, false>(i0);
@@ -252,14 +292,16 @@ struct FastMin {
                 block<false, UNI, false>(i0);
             }
         }
-        cnt = (slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);
+        if (PAIR) cnt = ((up ? slot : slim + col8 - slot)) / (u32)(LY::ROW * 8);  // col8 < ROW*8: the quotient is the row count
+        else cnt = (slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);
     }
 };
 
 // LDS -> HBM copy-out of one unit's staged tuples in read order (shared by the fast kernels).
 // owner of output t = lane whose run [excl, excl+cnt) holds t: one head bit per non-empty lane,
 // popcount below the bit -> rank among non-empty lanes -> lane (no per-output map in LDS).
-template <class LY, bool POS16, int CAP, int U = 4>
+// PAIR: the staging of PLds (row = e for the low lane of a column, R-1-e for the high one); CAP is then the last head word.
+template <class LY, bool POS16, int CAP, int U = 4, bool PAIR = false>
 __device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 excl, u32 T, u64 base, const KArgs &a) {
     u32 *s_excl = reinterpret_cast<u32 *>(lds + LY::EXCL);
     u64 *s_heads = reinterpret_cast<u64 *>(lds + LY::HEADS);
@@ -297,7 +339,12 @@ __device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 e
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const u32 t = t0 + 64 * j + lane;
-            sl[j] = t < T ? (t - ex[j]) * LY::ROW + owner[j] : 0u;
+            if (PAIR) {
+                const u32 e = t - ex[j];
+                sl[j] = t < T ? (owner[j] < 32u ? e : (u32)(BSK_PAIR_ROWS - 1) - e) * LY::ROW + (owner[j] & 31u) : 0u;
+            } else {
+                sl[j] = t < T ? (t - ex[j]) * LY::ROW + owner[j] : 0u;
+            }
             hv[j] = sh[sl[j]];
             if (POS16) pv[j] = *reinterpret_cast<const u16 *>(lds + LY::SP + sl[j] * 2);
             else pv[j] = *reinterpret_cast<const u32 *>(lds + LY::SP + sl[j] * 4);
@@ -315,8 +362,9 @@ __device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 e
 }
 
 template <int W, int CAP, bool POS16>
-__global__ __launch_bounds__(64, ((W > 16 && W <= 24) ? 2 : 1)) void k_minimizer_fast(KArgs a) {  // W 17..24: capped at 256 VGPRs (2 waves per SIMD, measured 1.1-1.5x); wider windows spill too much
-    typedef FLds<CAP, POS16> LY;
+__global__ __launch_bounds__(64, ((W >= 16 && W <= 24) ? 2 : 1)) void k_minimizer_fast(KArgs a) {  // W 16..24: capped at 256 VGPRs (2 waves per SIMD, measured 1.1-1.5x); wider windows spill too much
+    constexpr bool PAIR = POS16;  // paired staging columns (8 waves per CU); 32-bit positions keep the private columns
+    typedef typename MinLds<PAIR, CAP, POS16>::type LY;
     __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
     LDSQ char *const ldsq = (LDSQ char *)lds;
     const int lane = lane_id();
@@ -355,7 +403,7 @@ __global__ __launch_bounds__(64, ((W > 16 && W <= 24) ? 2 : 1)) void k_minimizer
         const bool uni = __builtin_amdgcn_ballot_w64(nk != nk_max) == 0;
         u32 cnt = 0, tie = 0;
         if (nk_max) {
-            FastMin<W, CAP, POS16, false> fm;
+            FastMin<W, CAP, POS16, false, PAIR> fm;
             fm.w = a.words + off;
             fm.pw = pw;
             fm.lds = ldsq;
@@ -373,10 +421,14 @@ __global__ __launch_bounds__(64, ((W > 16 && W <= 24) ? 2 : 1)) void k_minimizer
         const u32 incl = wave_incl_scan_u32(cnt, lane);
         const u32 excl = incl - cnt;
         const u32 T = wave_bcast_u32(incl, 63);
-        const bool any_over = __builtin_amdgcn_ballot_w64(cnt > (u32)CAP) != 0;
+        // PAIR: a column is full when its two lanes' counts reach R together (its last free row takes the unselected candidates)
+        const u32 cnt_pair = PAIR ? cnt + (u32)__builtin_amdgcn_ds_bpermute((lane ^ 32) * 4, (int)cnt) : 0u;
+        const bool any_over = PAIR ? __builtin_amdgcn_ballot_w64(cnt_pair >= (u32)BSK_PAIR_ROWS) != 0 : __builtin_amdgcn_ballot_w64(cnt > (u32)CAP) != 0;
         u64 base = (u64)unit * slab;
         if (!any_over) {
-            fast_copyout<LY, POS16, CAP>(lds, lane, cnt, excl, T, base, a);
+            // copy-out rows in flight: what keeps the kernel within 256 VGPRs (two waves per SIMD)
+            if (PAIR) fast_copyout<LY, POS16, LY::NHEADS - 1, (W <= 11 ? 4 : W <= 15 ? 2 : 1), true>(lds, lane, cnt, excl, T, base, a);
+            else fast_copyout<LY, POS16, CAP>(lds, lane, cnt, excl, T, base, a);
         } else {
             // rare (0.6 % of units at k=21 w=11 CAP=32): a lane selected more than CAP tuples.  The unit may not
             // fit its slab: take T tuples from the overflow region and recompute, storing straight to HBM.

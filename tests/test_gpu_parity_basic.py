@@ -92,6 +92,26 @@ def test_minimizer_overflow_of_lds_staging(engine, oracle):
     check_minimizer(engine, oracle, seqs, 15, 1)
 
 
+def test_minimizer_paired_staging_columns(engine, oracle, monkeypatch):
+    """k_minimizer_fast stages lanes l and l+32 in one LDS column filled from both ends: columns that overflow because of
+    their SUM, lanes that run out of the column alone (both directions), and one-sided columns (BSK_NO_DENSE keeps these
+    batches on that kernel)."""
+    monkeypatch.setenv("BSK_NO_DENSE", "1")
+    rng = random.Random(56)
+    seqs = [rand_dna(rng, rng.randint(150, 330)) for _ in range(200)]  # 22..52 tuples per read: some column sums reach 56, some do not
+    check_minimizer(engine, oracle, seqs, 21, 11)
+    seqs = [rand_dna(rng, 150) for _ in range(128)]
+    for lane in (3, 45, 64 + 31, 64 + 32):  # ~150 tuples: beyond the whole column, upwards (lane < 32) and downwards
+        seqs[lane] = rand_dna(rng, 900)
+    check_minimizer(engine, oracle, seqs, 21, 11)
+    for lo, hi in ((10, 280), (280, 10), (0, 330), (330, 25)):  # one lane of every column (nearly) empty, the other up to ~48 tuples
+        seqs = [rand_dna(rng, lo if (i & 32) == 0 else hi) for i in range(192)]
+        check_minimizer(engine, oracle, seqs, 21, 11)
+    seqs = [rand_dna(rng, rng.choice([150, 151, 170, 200])) for _ in range(700)]  # several tickets, ragged, w > 16 too
+    for k, w in ((21, 11), (31, 15), (15, 20), (25, 32)):
+        check_minimizer(engine, oracle, seqs, k, w)
+
+
 @pytest.mark.parametrize("k,canonical,circular", [(21, True, False), (21, False, False), (10, True, True), (1, True, False),
                                                   (31, True, False), (65, True, False), (100, False, True)])
 def test_nthash_stream(engine, oracle, k, canonical, circular):
