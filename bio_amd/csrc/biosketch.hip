@@ -870,7 +870,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         // windows that select more positions per read than the slab kernel stages (32): per-read slabs + mid-read flushes
         const double nwin = (double)b->maxlen - p->k - p->w + 2;
         const u64 dense_slab = (std::min<u64>((u64)std::max(nwin, 0.0), (u64)(std::max(nwin, 0.0) * 2.6 / (p->w + 1.0)) + 16) + 15) & ~(u64)15;
-        if (!use_ascii && dense_minimizer_supported(p->w) && b->maxlen < 32768u && nwin * 2.0 / (p->w + 1.0) > (double)env_u32("BSK_DENSE_MIN", 23) && !ctx->no_dense && slab_budget_ok(b, dense_slab) &&
+        if (!use_ascii && dense_minimizer_supported(p->w) && b->maxlen < 32768u && nwin * 2.0 / (p->w + 1.0) > (double)env_u32("BSK_DENSE_MIN", 21) && !ctx->no_dense && slab_budget_ok(b, dense_slab) &&
             !getenv("BSK_FORCE_GENERIC") && !getenv("BSK_NO_DENSE")) {
             pl.which = K_MIN_DENSE;
             pl.fast_w = p->w;

@@ -32,6 +32,13 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 #define GLBQ __attribute__((address_space(1)))
 typedef u32x4 u32x4_u __attribute__((aligned(1)));  // byte-aligned 16-byte global load (unaligned access mode of the HSA ABI)
 
+// 16-byte non-temporal store (8-byte aligned): the outputs are written once and never read by the kernels; keeping them out
+// of the L2's retained set leaves it to the inputs (k-mer codes 629 -> 663 Gbases/s, protein minimizer input re-fetches 5x -> 1.9x)
+__device__ __forceinline__ void nt_store_u64x2(u64 *p, u64 a, u64 b) {
+    typedef u64 u64x2v __attribute__((ext_vector_type(2), aligned(8)));
+    __builtin_nontemporal_store((u64x2v){a, b}, reinterpret_cast<u64x2v *>(p));
+}
+
 // VOP3 compare -> SGPR pair, VOP3 select <- SGPR pair.  (v_cmp -> v_cndmask through an
 // SGPR needs no software wait states on gfx9; the asm only pins the encoding.)
 __device__ __forceinline__ lmask lt64(u32 alo, u32 ahi, u32 blo, u32 bhi) {
@@ -353,8 +360,8 @@ __device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 e
         for (int j = 0; j < U; ++j) {
             const u32 t = t0 + 64 * j + lane;
             if (t < T) {
-                a.hash[base + t] = hv[j];
-                a.pos[base + t] = POS16 ? ((pv[j] & 0x7fffu) | ((pv[j] & 0x8000u) << 16)) : pv[j];
+                __builtin_nontemporal_store(hv[j], &a.hash[base + t]);  // write-once output (see flush_rows)
+                __builtin_nontemporal_store(POS16 ? ((pv[j] & 0x7fffu) | ((pv[j] & 0x8000u) << 16)) : pv[j], &a.pos[base + t]);
             }
         }
     }
@@ -467,16 +474,20 @@ __global__ __launch_bounds__(64, ((W >= 16 && W <= 24) ? 2 : 1)) void k_minimize
 // (a full, aligned 128-byte line of hashes and 64 bytes of positions: no partial-line writes; measured 2.2x
 // faster than flushing every tuple of every round); the final round moves what is left.
 // STRAND16: staged positions carry the strand in bit 15 (DNA kernels); it moves to bit 31 on the way out.
-template <class LY, bool STRAND16>
+// GL = log2 of the tuples per flushed group.  Groups of 16 are whole 128-byte lines of hashes but keep up to 15 left-over rows
+// per lane staged; groups of 8 (aligned 64-byte pieces) need 8 rows less -- two more waves per CU, protein minimizer w=5
+// 366 -> 424 G residues/s -- but every half-line write is a read-modify-write in HBM (traffic 1.3x -> 2.2x the algorithmic
+// bytes).  The kernels therefore keep GL = 4 and flush more often instead (fewer new rows between two flushes).
+template <class LY, bool STRAND16, int GL>
 __device__ __forceinline__ void flush_rows(char *lds, int lane, u32 cnt, bool last, u32 done, u64 slab_read, u64 ubase,
                                            const KArgs &a) {
     u32 *s_excl = reinterpret_cast<u32 *>(lds + LY::EXCL);
     u64 *s_heads = reinterpret_cast<u64 *>(lds + LY::HEADS);
     u8 *s_nz = reinterpret_cast<u8 *>(lds + LY::NZ);
     u32 *s_dst = reinterpret_cast<u32 *>(lds + LY::DST);
-    // unit of work: a group of 16 tuples (regular round) or a single tuple (final round)
-    const u32 units = last ? cnt : (cnt >> 4);
-    const u32 ushift = last ? 0u : 4u;
+    // unit of work: a group of 1 << GL tuples (regular round) or a single tuple (final round)
+    const u32 units = last ? cnt : (cnt >> GL);
+    const u32 ushift = last ? 0u : (u32)GL;
     const u32 incl = wave_incl_scan_u32(units, lane);
     const u32 excl = incl - units;
     const u32 U = wave_bcast_u32(incl, 63);
@@ -512,10 +523,12 @@ __device__ __forceinline__ void flush_rows(char *lds, int lane, u32 cnt, bool la
             const u32 sl = e * LY::ROW + owner;
             const u32 d = s_dst[owner];
             if (d != 0xffffffffu) {
-                a.hash[ubase + d + e] = *reinterpret_cast<const u64 *>(lds + LY::SH + sl * 8);
+                // write-once output: non-temporal stores, so that the tuples streaming out do not push the sequences'
+                // lines (re-read every round by per-lane loads) out of the L2
+                __builtin_nontemporal_store(*reinterpret_cast<const u64 *>(lds + LY::SH + sl * 8), &a.hash[ubase + d + e]);
                 u32 p = *reinterpret_cast<const u16 *>(lds + LY::SP + sl * 2);
                 if (STRAND16) p = (p & 0x7fffu) | ((p & 0x8000u) << 16);
-                a.pos[ubase + d + e] = p;
+                __builtin_nontemporal_store(p, &a.pos[ubase + d + e]);
             }
         }
     }
@@ -530,13 +543,17 @@ __device__ __forceinline__ void flush_rows(char *lds, int lane, u32 cnt, bool la
 // ---------------------------------------------------------------------------------------
 template <int W>
 struct DenseCfg {
-    static constexpr int NB = (24 / W) > 0 ? (24 / W) : 1;  // blocks per flush round (~24 steps)
-    static constexpr int CAP = NB * W + 15;                 // rows = CAP + 1: 15 left-over + NB*W new + the scribble row
+    // blocks per flush round: <= 13 steps, so that 15 left-over rows + the new ones + the scribble row leave 8 waves per CU.
+    // (<= 24 steps: 5-6 waves; groups of 8 tuples with <= 20 steps: 8 waves and as fast, but half-line writes double the traffic.)
+    static constexpr int NB = (13 / W) > 0 ? (13 / W) : 1;
+    static constexpr int GL = 4;
+    static constexpr int G = 1 << GL;
+    static constexpr int CAP = NB * W + G - 1;              // rows = CAP + 1: the left-over of a group + NB*W new + the scribble row
 };
 
 template <int W>
 __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
-    constexpr int CAP = DenseCfg<W>::CAP, NB = DenseCfg<W>::NB;
+    constexpr int CAP = DenseCfg<W>::CAP, NB = DenseCfg<W>::NB, GL = DenseCfg<W>::GL, G = DenseCfg<W>::G;
     typedef FLds<CAP, true> LY;
     __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
     LDSQ char *const ldsq = (LDSQ char *)lds;
@@ -607,12 +624,12 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
                 if (++inround == NB || last) {
                     inround = 0;
                     const u32 cnt = (fm.slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);  // staged, left-overs included
-                    flush_rows<LY, true>(lds, lane, cnt, last, done, slab_read, ubase, a);
-                    const u32 nfl = last ? cnt : (cnt & ~15u);
-                    if (!last) {  // move the left-over (< 16 tuples) down to row 0
+                    flush_rows<LY, true, GL>(lds, lane, cnt, last, done, slab_read, ubase, a);
+                    const u32 nfl = last ? cnt : (cnt & ~(u32)(G - 1));
+                    if (!last) {  // move the left-over (less than a group) down to row 0
                         const u32 left = cnt - nfl;
                         if (__builtin_amdgcn_ballot_w64(nfl != 0)) {
-                            for (u32 e = 0; e < 15; ++e) {
+                            for (u32 e = 0; e < (u32)(G - 1); ++e) {
                                 if (nfl && e < left) {
                                     const u32 src = (nfl + e) * LY::ROW + lane, dst = e * LY::ROW + lane;
                                     *reinterpret_cast<u64 *>(lds + LY::SH + dst * 8) = *reinterpret_cast<const u64 *>(lds + LY::SH + src * 8);
@@ -806,7 +823,7 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
                     u64x2_a8 vv;
                     vv.a = ((u64)tv[rr].y << 32) | tv[rr].x;
                     vv.b = ((u64)tv[rr].w << 32) | tv[rr].z;
-                    *reinterpret_cast<u64x2_a8 *>(a.hash + roff[rr] + i0) = vv;
+                    nt_store_u64x2(a.hash + roff[rr] + i0, vv.a, vv.b);
                 }
             }
             wave_sync_lds();

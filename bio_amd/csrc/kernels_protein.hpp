@@ -22,10 +22,10 @@ typedef u32 u32_u __attribute__((aligned(1)));
 
 constexpr int ilcm4(int w) { return (w % 4 == 0) ? w : (w % 2 == 0 ? 2 * w : 4 * w); }
 
-template <int MB>
+template <int MB, int G = 16>
 struct ProtLds {
     static constexpr int ROW = 65;
-    static constexpr int ROWS = MB + 16;                      // up to 15 leftover tuples + MB new ones + 1 spare row
+    static constexpr int ROWS = MB + G;                       // the left-over of a flush group (< G) + MB new tuples + 1 spare row
     static constexpr int SH = 0;                              // u64 [ROWS*65]
     static constexpr int SP = SH + ROWS * ROW * 8;            // u16 [ROWS*65]
     static constexpr int EXCL = SP + ((ROWS * ROW * 2 + 15) & ~15);
@@ -48,7 +48,13 @@ template <int W, int K>
 struct FastProt {
     static_assert(K >= 9 && K <= 16, "register wyhash covers 9..16 residues");
     static constexpr int MB = ilcm4(W);  // steps per macro block: a whole number of windows-blocks and of dwords
-    typedef ProtLds<MB> LY;
+    // Tuples leave in whole groups of 16 (full 128-byte lines of hashes; groups of 8 were 18 % faster through two more waves per
+    // CU but doubled the HBM traffic: half-line writes are read-modify-write).  The staging holds the left-over of a group
+    // (< 16) plus what the steps between two flushes can select (HS), so where a whole macro block does not leave 8 waves per
+    // CU the flush also runs in the middle of it.
+    static constexpr int GL = 4, G = 16;
+    static constexpr int HS = (ProtLds<MB, 16>::TOTAL <= 20480) ? MB : MB / 2;
+    typedef ProtLds<HS, G> LY;
     LDSQ char *lds;
     int lane;
     u32 nk;
@@ -82,12 +88,12 @@ struct FastProt {
         return mum64((u32)s1, (u32)(s1 >> 32), (u32)fin, (u32)(fin >> 32));
     }
 
-    // one macro block of MB steps starting at k-mer position i0 (FIRSTMB: i0 == 0)
-    template <bool FIRSTMB>
+    // steps T0 .. T1-1 of the macro block (MB steps) starting at k-mer position i0 (FIRSTMB: i0 == 0)
+    template <bool FIRSTMB, int T0, int T1>
     __device__ __forceinline__ void macro(u32 i0) {
-        u32 vi = i0;
+        u32 vi = i0 + T0;
 #pragma unroll
-        for (int t = 0; t < MB; ++t) {
+        for (int t = T0; t < T1; ++t) {
             const int g = t >> 2;
             u64 h;
             switch (t & 3) {
@@ -133,8 +139,8 @@ struct FastProt {
 template <int W, int K>
 __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
     typedef FastProt<W, K> FP;
-    constexpr int MB = FP::MB;
-    typedef ProtLds<MB> LY;
+    constexpr int MB = FP::MB, GL = FP::GL, G = FP::G, HS = FP::HS;
+    typedef typename FP::LY LY;
     __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
     LDSQ char *const ldsq = (LDSQ char *)lds;
     const int lane = lane_id();
@@ -184,12 +190,38 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
                 }
             };
             u32 dj = 0;
-            fp.slot = (u32)lane * 8u;  // staging persists across macro blocks (leftovers of fewer than 16 tuples stay in LDS)
+            fp.slot = (u32)lane * 8u;  // staging persists across macro blocks (leftovers of less than a flush group stay in LDS)
             load_dwords(fp.R, 5 + MB / 4, 0);
             dj = 5 + MB / 4;
+            // ---- flush whole groups of 16 tuples (full 128-byte lines of hashes) of every lane to its slab ----
+            auto flush = [&](bool last) {  // last: everything that is staged
+                const u32 cnt = (fp.slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);  // staged, leftovers included
+                flush_rows<LY, false, GL>(lds, lane, cnt, last, done, slab_read, ubase, a);
+                const u32 nfl = last ? cnt : (cnt & ~(u32)(G - 1));
+                const u32 left = cnt - nfl;
+                if (!last && __builtin_amdgcn_ballot_w64(nfl != 0)) {  // move the leftover (less than a group) down to row 0
+                    for (u32 e = 0; e < (u32)(G - 1); ++e) {
+                        if (nfl && e < left) {
+                            const u32 src = (nfl + e) * LY::ROW + lane, dst = e * LY::ROW + lane;
+                            *reinterpret_cast<u64 *>(lds + LY::SH + dst * 8) = *reinterpret_cast<const u64 *>(lds + LY::SH + src * 8);
+                            *reinterpret_cast<u16 *>(lds + LY::SP + dst * 2) = *reinterpret_cast<const u16 *>(lds + LY::SP + src * 2);
+                        }
+                    }
+                }
+                fp.slot = (left * LY::ROW + (u32)lane) * 8u;
+                done += nfl;
+            };
             for (u32 i0 = 0; i0 < nk_max; i0 += MB) {
-                if (i0 == 0) fp.template macro<true>(i0);
-                else fp.template macro<false>(i0);
+                if (HS < MB) {
+                    if (i0 == 0) fp.template macro<true, 0, HS>(i0);
+                    else fp.template macro<false, 0, HS>(i0);
+                    flush(i0 + HS >= nk_max);
+                    if (i0 == 0) fp.template macro<true, HS, MB>(i0);
+                    else fp.template macro<false, HS, MB>(i0);
+                } else {
+                    if (i0 == 0) fp.template macro<true, 0, MB>(i0);
+                    else fp.template macro<false, 0, MB>(i0);
+                }
 #pragma unroll
                 for (int g = 0; g < 5; ++g) fp.R[g] = fp.R[g + MB / 4];
                 // residues of the NEXT macro block: requested and waited for BEFORE this round's flush stores are
@@ -198,25 +230,7 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
                 dj += MB / 4;
 #pragma unroll
                 for (int g = 0; g < MB / 4; ++g) asm volatile("" ::"v"(fp.R[5 + g]));
-                // ---- flush whole 16-tuple groups (= full 128-byte lines of hashes) of every lane to its slab ----
-                const u32 cnt = (fp.slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);  // staged, leftovers included
-                const bool last = i0 + MB >= nk_max;                              // final round: flush everything
-                flush_rows<LY, false>(lds, lane, cnt, last, done, slab_read, ubase, a);
-                const u32 nfl = last ? cnt : (cnt & ~15u);
-                if (!last) {  // move the leftover (< 16 tuples) down to row 0
-                    const u32 left = cnt - nfl;
-                    if (__builtin_amdgcn_ballot_w64(nfl != 0)) {
-                        for (u32 e = 0; e < 15; ++e) {
-                            if (nfl && e < left) {
-                                const u32 src = (nfl + e) * LY::ROW + lane, dst = e * LY::ROW + lane;
-                                *reinterpret_cast<u64 *>(lds + LY::SH + dst * 8) = *reinterpret_cast<const u64 *>(lds + LY::SH + src * 8);
-                                *reinterpret_cast<u16 *>(lds + LY::SP + dst * 2) = *reinterpret_cast<const u16 *>(lds + LY::SP + src * 2);
-                            }
-                        }
-                    }
-                    fp.slot = (left * LY::ROW + (u32)lane) * 8u;
-                }
-                done += nfl;
+                flush(i0 + MB >= nk_max);
             }
             tie = (u32)((fp.tm >> lane) & 1);
         }
@@ -404,7 +418,7 @@ __global__ __launch_bounds__(64) void k_prot_hash_fast(KArgs a) {
                         u64x2_a8 vv;
                         vv.a = ((u64)tv[rr].y << 32) | tv[rr].x;
                         vv.b = ((u64)tv[rr].w << 32) | tv[rr].z;
-                        *reinterpret_cast<u64x2_a8 *>(a.hash + roff[rr] + i0) = vv;
+                        nt_store_u64x2(a.hash + roff[rr] + i0, vv.a, vv.b);
                     }
                 }
                 wave_sync_lds();

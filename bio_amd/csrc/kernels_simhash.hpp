@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64) void k_simhash_fast(KArgs a) {
                     u64x2_a8 vv;
                     vv.a = ((u64)tv[rr].y << 32) | tv[rr].x;
                     vv.b = ((u64)tv[rr].w << 32) | tv[rr].z;
-                    *reinterpret_cast<u64x2_a8 *>(a.hash + roff[rr] + i0) = vv;
+                    nt_store_u64x2(a.hash + roff[rr] + i0, vv.a, vv.b);
                 }
             }
             wave_sync_lds();
