@@ -930,7 +930,9 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             !getenv("BSK_FORCE_GENERIC")) {
             pl.which = K_SIM_FAST;  // bit-sliced counters: 5 planes count to 31, 6 to 63
             pl.fast_w = nh <= 31 ? 5 : 6;
-            per_cu = nh <= 31 ? blocks_per_cu(k_simhash_fast<5>) : blocks_per_cu(k_simhash_fast<6>);
+            pl.fast_k = (b->maxlen + (u32)(p->circular ? p->k : 0) <= 16u * (BSK_SIM_SHORT_WORDS - 2)) ? 1 : 0;  // short reads: less LDS, more waves
+            if (pl.fast_k) per_cu = nh <= 31 ? blocks_per_cu(k_simhash_fast<5, BSK_SIM_SHORT_WORDS>) : blocks_per_cu(k_simhash_fast<6, BSK_SIM_SHORT_WORDS>);
+            else per_cu = nh <= 31 ? blocks_per_cu(k_simhash_fast<5>) : blocks_per_cu(k_simhash_fast<6>);
         } else {
             pl.which = use_ascii ? K_SIM_A : K_SIM_P;
             per_cu = use_ascii ? blocks_per_cu(k_simhash<1>) : blocks_per_cu(k_simhash<0>);
@@ -1193,7 +1195,10 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_PROT_MIN_FAST: fast_prot_launch(pl.fast_w, pl.fast_k, pl.grid, ctx->stream, a); break;
         case K_PROT_HASH_FAST: fast_prot_hash_launch(pl.fast_k, pl.grid, ctx->stream, a); break;
         case K_SIM_FAST:
-            if (pl.fast_w == 5) hipLaunchKernelGGL(k_simhash_fast<5>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
+            if (pl.fast_k) {
+                if (pl.fast_w == 5) hipLaunchKernelGGL((k_simhash_fast<5, BSK_SIM_SHORT_WORDS>), dim3(pl.grid), dim3(64), 0, ctx->stream, a);
+                else hipLaunchKernelGGL((k_simhash_fast<6, BSK_SIM_SHORT_WORDS>), dim3(pl.grid), dim3(64), 0, ctx->stream, a);
+            } else if (pl.fast_w == 5) hipLaunchKernelGGL(k_simhash_fast<5>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             else hipLaunchKernelGGL(k_simhash_fast<6>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             break;
         case K_NT_FAST:

@@ -35,10 +35,11 @@ struct RollNt {  // ntHash-1 of the current m-mer, both strands
     }
 };
 
-template <int PL>
+// NWL = packed words of a read staged in LDS: 12 (reads of up to 160 bases) leaves 12 waves per CU, 34 (512 bases) 8
+#define BSK_SIM_SHORT_WORDS 12
+template <int PL, int NWL = BSK_NT_FAST_WORDS>
 __global__ __launch_bounds__(64) void k_simhash_fast(KArgs a) {
     constexpr int TL = 18;
-    constexpr int NWL = BSK_NT_FAST_WORDS;
     constexpr int SW_OFF = 512 + 64 * TL * 8;
     __shared__ __attribute__((aligned(16))) char lds[SW_OFF + NWL * 64 * 4];
     __shared__ u64 s_off[64];
