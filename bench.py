@@ -40,7 +40,7 @@ WORKLOADS = {
     "simhash": ("sim", 20_000_000, 150, 21, 5, "20M x 150 bp reads, SimHash k=21 m=5 scale=5"),
 }
 KERNELS = {"min": "k_minimizer_fast<11,32,true>", "nt": "k_nthash_fast<1>", "syn": "k_syncmer_fast<20>", "pmin": "k_prot_minimizer_fast<5,9>",
-           "kmer": "k_nthash_fast<2>", "phash": "k_prot_hash_fast<9>", "sim": "k_simhash_fast<5>"}
+           "kmer": "k_nthash_fast<2>", "phash": "k_prot_hash_fast<9>", "sim": "k_simhash_fast<5,12>"}
 NOTES = {
     "min": "integer-VALU bound, not HBM bound (DESIGN.md 3.1); frac is vs the 8 TB/s spec peak",
     "nt": "HBM-write bound (DESIGN.md 3.2); a plain 16 B/lane fill kernel reaches 5.2-5.9 TB/s on this part",
