@@ -77,9 +77,9 @@ struct FLds {
     static constexpr int EXCL = SP + (((CAP + 1) * ROW * PB + 15) & ~15);   // u32 [64]
     static constexpr int HEADS = EXCL + 256;  // u64 [CAP+1]: bit j of word c: a lane's run starts at output 64c+j
     static constexpr int NZ = HEADS + (CAP + 1) * 8;  // u8 [64]: rank among non-empty lanes -> lane
-    static constexpr int DST = NZ + 64;               // u32 [64]: flush_rows (kernels with per-read slabs)
+    static constexpr int DST = NZ + 64;               // u32 [64] + u32 [64] ring heads: flush_rows (kernels with per-read slabs)
     static constexpr int ROWS = CAP + 1;
-    static constexpr int TOTAL = DST + 256;
+    static constexpr int TOTAL = DST + 512;
 };
 
 // Paired staging columns (k_minimizer_fast): lanes l and l+32 share column l & 31 of R rows; the low lane fills it from row
@@ -111,7 +111,8 @@ struct MinLds<true, CAP, POS16> {
     typedef PLds<BSK_PAIR_ROWS, POS16> type;
 };
 
-template <int W, int CAP, bool POS16, bool DIRECT, bool PAIR = false>
+// RING: the lane's CAP+1 rows are a ring (k_minimizer_dense: no left-over moves after a flush); `send` = one row past the last.
+template <int W, int CAP, bool POS16, bool DIRECT, bool PAIR = false, bool RING = false>
 struct FastMin {
     typedef typename MinLds<PAIR, CAP, POS16>::type LY;
     static constexpr u32 SBIT = POS16 ? 0x8000u : 0x80000000u;  // strand bit inside the staged pos word
@@ -129,6 +130,7 @@ struct FastMin {
     u32 prev, cnt, tie;
     u32 slot;                          // byte offset (from SH) of this lane's next staging slot = (cnt*65 + lane)*8
     u32 sstep, slim, sspare;           // PAIR: signed row stride, last byte offset inside the column, the lane's spare slot
+    u32 send;                          // RING: slot offset one row past the lane's last row
     u32 in_lo, in_hi, out_lo, out_hi;  // packed words of the current block
     u32 in_h2, out_h2;                 // W > 16: a block spans up to three words
     u32x4 pw;                          // run(): the read's first four words, loaded by the caller (one unit ahead)
@@ -212,7 +214,9 @@ struct FastMin {
                     *reinterpret_cast<LDSQ u64 *>(lds + LY::SH + addr) = ((u64)m.hi << 32) | m.lo;
                     if (POS16) *reinterpret_cast<LDSQ u16 *>(lds + LY::SP + (addr >> 2)) = (u16)m.p;
                     else *reinterpret_cast<LDSQ u32 *>(lds + LY::SP + (addr >> 1)) = m.p;
-                    slot = sel(e, slot + (PAIR ? sstep : (u32)(LY::ROW * 8)), slot);
+                    u32 nxt = slot + (PAIR ? sstep : (u32)(LY::ROW * 8));
+                    if (RING) nxt = sel(__builtin_amdgcn_ballot_w64(nxt == send), (u32)lane * 8u, nxt);
+                    slot = sel(e, nxt, slot);
                 } else {
                     if ((e >> lane) & 1) {
                         const u32 c = (slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);
@@ -478,9 +482,10 @@ __global__ __launch_bounds__(64, ((W >= 16 && W <= 24) ? 2 : 1)) void k_minimize
 // per lane staged; groups of 8 (aligned 64-byte pieces) need 8 rows less -- two more waves per CU, protein minimizer w=5
 // 366 -> 424 G residues/s -- but every half-line write is a read-modify-write in HBM (traffic 1.3x -> 2.2x the algorithmic
 // bytes).  The kernels therefore keep GL = 4 and flush more often instead (fewer new rows between two flushes).
-template <class LY, bool STRAND16, int GL>
+// RING > 0: the lane's rows are a ring of RING rows starting at row `head` (no left-over moves; LY::HEAD0 holds the heads).
+template <class LY, bool STRAND16, int GL, int RING = 0>
 __device__ __forceinline__ void flush_rows(char *lds, int lane, u32 cnt, bool last, u32 done, u64 slab_read, u64 ubase,
-                                           const KArgs &a) {
+                                           const KArgs &a, u32 head = 0) {
     u32 *s_excl = reinterpret_cast<u32 *>(lds + LY::EXCL);
     u64 *s_heads = reinterpret_cast<u64 *>(lds + LY::HEADS);
     u8 *s_nz = reinterpret_cast<u8 *>(lds + LY::NZ);
@@ -497,6 +502,7 @@ __device__ __forceinline__ void flush_rows(char *lds, int lane, u32 cnt, bool la
     if (__builtin_amdgcn_ballot_w64(!fits) && lane == 0) atomicOr(&a.ticket[1], 1u);  // slab too small: host falls back
     s_excl[lane] = excl;
     s_dst[lane] = fits ? (u32)(lane * slab_read + done) : 0xffffffffu;
+    if (RING) reinterpret_cast<u32 *>(lds + LY::DST)[64 + lane] = head;
     if (lane < LY::ROWS) s_heads[lane] = 0;
     wave_sync_lds();
     if (units > 0) {
@@ -520,7 +526,12 @@ __device__ __forceinline__ void flush_rows(char *lds, int lane, u32 cnt, bool la
             const u32 upto = (u32)__builtin_popcountll(M & (bit == 63 ? ~0ULL : ((2ULL << bit) - 1)));
             const u32 owner = s_nz[heads_before + upto - 1];
             const u32 e = ((ui - s_excl[owner]) << ushift) | (t & ((1u << ushift) - 1));
-            const u32 sl = e * LY::ROW + owner;
+            u32 row = e;
+            if (RING) {
+                row += reinterpret_cast<const u32 *>(lds + LY::DST)[64 + owner];
+                row = row >= (u32)RING ? row - (u32)RING : row;
+            }
+            const u32 sl = row * LY::ROW + owner;
             const u32 d = s_dst[owner];
             if (d != 0xffffffffu) {
                 // write-once output: non-temporal stores, so that the tuples streaming out do not push the sequences'
@@ -581,8 +592,9 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
         const u64 ubase = (u64)unit * 64 * slab_read;
         u32 done = 0, tie = 0;
         if (nk_max) {
-            FastMin<W, CAP, true, false> fm;
+            FastMin<W, CAP, true, false, false, true> fm;
             fm.w = a.words + off;
+            fm.send = (u32)((CAP + 1) * LY::ROW + lane) * 8u;
             fm.lds = ldsq;
             fm.k = a.k;
             fm.lane = lane;
@@ -611,6 +623,7 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
             }
             fm.load_block_words(0);
             int inround = 0;
+            u32 head = 0;
             for (u32 i0 = 0; i0 < nk_max; i0 += W) {
                 if (i0 == 0) {
                     if (uni) fm.template block<true, true, false>(0);
@@ -623,22 +636,13 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
                 const bool last = i0 + W >= nk_max;
                 if (++inround == NB || last) {
                     inround = 0;
-                    const u32 cnt = (fm.slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);  // staged, left-overs included
-                    flush_rows<LY, true, GL>(lds, lane, cnt, last, done, slab_read, ubase, a);
+                    // the lane's rows are a ring starting at `head` (moving the left-over down after every flush cost more than the wrap test)
+                    const u32 wrow = (fm.slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);
+                    const u32 cnt = wrow >= head ? wrow - head : wrow + (u32)(CAP + 1) - head;  // staged: left-over < 16 + NB*W new
+                    flush_rows<LY, true, GL, CAP + 1>(lds, lane, cnt, last, done, slab_read, ubase, a, head);
                     const u32 nfl = last ? cnt : (cnt & ~(u32)(G - 1));
-                    if (!last) {  // move the left-over (less than a group) down to row 0
-                        const u32 left = cnt - nfl;
-                        if (__builtin_amdgcn_ballot_w64(nfl != 0)) {
-                            for (u32 e = 0; e < (u32)(G - 1); ++e) {
-                                if (nfl && e < left) {
-                                    const u32 src = (nfl + e) * LY::ROW + lane, dst = e * LY::ROW + lane;
-                                    *reinterpret_cast<u64 *>(lds + LY::SH + dst * 8) = *reinterpret_cast<const u64 *>(lds + LY::SH + src * 8);
-                                    *reinterpret_cast<u16 *>(lds + LY::SP + dst * 2) = *reinterpret_cast<const u16 *>(lds + LY::SP + src * 2);
-                                }
-                            }
-                        }
-                        fm.slot = (left * LY::ROW + (u32)lane) * 8u;
-                    }
+                    head += nfl;
+                    head = head >= (u32)(CAP + 1) ? head - (u32)(CAP + 1) : head;
                     done += nfl;
                 }
             }

@@ -31,8 +31,8 @@ struct ProtLds {
     static constexpr int EXCL = SP + ((ROWS * ROW * 2 + 15) & ~15);
     static constexpr int HEADS = EXCL + 256;                  // u64 [ROWS]
     static constexpr int NZ = HEADS + ROWS * 8;
-    static constexpr int DST = NZ + 64;                       // u32 [64]: lane's next free tuple index inside the unit's region
-    static constexpr int TOTAL = DST + 256;
+    static constexpr int DST = NZ + 64;                       // u32 [64]: lane's next free tuple index inside the unit's region, u32 [64]: ring heads
+    static constexpr int TOTAL = DST + 512;
 };
 
 __device__ __forceinline__ u64 mum64(u32 a0, u32 a1, u32 b0, u32 b1) {  // hi64(a*b) ^ lo64(a*b)
@@ -59,7 +59,7 @@ struct FastProt {
     int lane;
     u32 nk;
     HV S[W], P;
-    u32 prev, slot;
+    u32 prev, slot, send;  // send: the slot offset one row past the lane's last row
     u32 R[5 + MB / 4];  // residues: R[0..4] = the 20 bytes at the macro block's first position, R[5..] = the following ones
     lmask tm;
 
@@ -117,7 +117,9 @@ struct FastProt {
                 prev = m.p;
                 *reinterpret_cast<LDSQ u64 *>(lds + LY::SH + slot) = ((u64)m.hi << 32) | m.lo;
                 *reinterpret_cast<LDSQ u16 *>(lds + LY::SP + (slot >> 2)) = (u16)m.p;
-                slot = sel(e, slot + (u32)(LY::ROW * 8), slot);
+                u32 nxt = slot + (u32)(LY::ROW * 8);  // the lane's rows are a ring: past the last row comes row 0
+                nxt = sel(__builtin_amdgcn_ballot_w64(nxt == send), (u32)lane * 8u, nxt);
+                slot = sel(e, nxt, slot);
             }
             S[o] = v;
             vi += 1;
@@ -191,24 +193,20 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
             };
             u32 dj = 0;
             fp.slot = (u32)lane * 8u;  // staging persists across macro blocks (leftovers of less than a flush group stay in LDS)
+            fp.send = (u32)(LY::ROWS * LY::ROW + lane) * 8u;
             load_dwords(fp.R, 5 + MB / 4, 0);
             dj = 5 + MB / 4;
             // ---- flush whole groups of 16 tuples (full 128-byte lines of hashes) of every lane to its slab ----
+            // The lane's ROWS rows are a ring (head = row of its oldest staged tuple): moving the < 16 left-over tuples down to
+            // row 0 after every flush was a third of the kernel's instructions.
+            u32 head = 0;
             auto flush = [&](bool last) {  // last: everything that is staged
-                const u32 cnt = (fp.slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);  // staged, leftovers included
-                flush_rows<LY, false, GL>(lds, lane, cnt, last, done, slab_read, ubase, a);
+                const u32 wrow = (fp.slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);  // row of the next write
+                const u32 cnt = wrow >= head ? wrow - head : wrow + (u32)LY::ROWS - head;  // staged (< ROWS: left-over < 16, new <= HS)
+                flush_rows<LY, false, GL, LY::ROWS>(lds, lane, cnt, last, done, slab_read, ubase, a, head);
                 const u32 nfl = last ? cnt : (cnt & ~(u32)(G - 1));
-                const u32 left = cnt - nfl;
-                if (!last && __builtin_amdgcn_ballot_w64(nfl != 0)) {  // move the leftover (less than a group) down to row 0
-                    for (u32 e = 0; e < (u32)(G - 1); ++e) {
-                        if (nfl && e < left) {
-                            const u32 src = (nfl + e) * LY::ROW + lane, dst = e * LY::ROW + lane;
-                            *reinterpret_cast<u64 *>(lds + LY::SH + dst * 8) = *reinterpret_cast<const u64 *>(lds + LY::SH + src * 8);
-                            *reinterpret_cast<u16 *>(lds + LY::SP + dst * 2) = *reinterpret_cast<const u16 *>(lds + LY::SP + src * 2);
-                        }
-                    }
-                }
-                fp.slot = (left * LY::ROW + (u32)lane) * 8u;
+                head += nfl;
+                head = head >= (u32)LY::ROWS ? head - (u32)LY::ROWS : head;
                 done += nfl;
             };
             for (u32 i0 = 0; i0 < nk_max; i0 += MB) {
