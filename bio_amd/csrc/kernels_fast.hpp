@@ -50,6 +50,12 @@ __device__ __forceinline__ u32 sel(lmask m, u32 t, u32 f) {  // m ? t : f
     return r;
 }
 
+__device__ __forceinline__ u32 sel01(lmask m) {  // m ? 1 : 0 (both operands inline constants: no VGPR copies of wave-uniform values)
+    u32 r;
+    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(m));
+    return r;
+}
+
 struct HV {  // hash (lo, hi) + pos|strand
     u32 lo, hi, p;
 };
@@ -194,7 +200,7 @@ struct FastMin {
             HV v;
             v.lo = sel(rev, rl, fl);
             v.hi = sel(rev, rh_, fh_);
-            v.p = sel(rev, vi | SBIT, vi);
+            v.p = (sel01(rev) << (POS16 ? 15 : 31)) | vi;  // vi is wave-uniform: one select + one v_lshl_or instead of two copies + a select
             if (o == 0) {
                 P = v;
             } else {

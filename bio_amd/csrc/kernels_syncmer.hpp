@@ -12,8 +12,8 @@
 //     min of s-mers [j, j+W-1]; the 2W window of idx is min(M[idx], M[idx+W]) with the left
 //     half winning ties, and "left half" / "right half" is exactly the prefix / suffix rule;
 //     M[idx] was produced W steps earlier at the same block offset, so it sits in D[o];
-//   * the selected position b lies in [idx, idx+W-1]: bit (b-idx) of a per-lane pending
-//     mask is set; the mask shifts right once per step, so bit 0 says "position idx is
+//   * the selected position b lies in [idx, idx+W-1]: bit 31-(b-idx) of a per-lane pending
+//     mask is set; the mask shifts left once per step, so its sign bit says "position idx is
 //     selected" exactly when the k-mer stream (which runs AT idx) has that k-mer's hash --
 //     this is the reference's "emit when idx reaches it" queue (sketch.go:424-475) without a
 //     queue, de-duplication is the OR, and selections beyond `end` never reach bit 0;
@@ -118,15 +118,15 @@ struct FastSyn {
                 const u32 idx = i0 + O - (2 * W - 1);
                 const lmask right = lt64(M.lo, M.hi, D[O].lo, D[O].hi);  // strict: the left half wins ties
                 const u32 b = sel(right, M.p - (u32)W, D[O].p);          // sketch.go:413-420
-                pend |= 1u << (b - idx);
+                pend |= 0x80000000u >> (b - idx);  // bit 31 = position idx: "selected" is the sign bit
                 // k-mer at idx
                 const u32 ko = (MODE == 1) ? 0x100u : kout.template out_off<O>();
                 rollk(tabk(kin.template in_off<O>() | ko));
                 const lmask krev = lt64(krl, krh, kfl, kfh);
                 const u32 hl = sel(krev, krl, kfl), hh = sel(krev, krh, kfh);
-                const u32 ps = sel(krev, idx | 0x8000u, idx);
-                lmask e = __builtin_amdgcn_ballot_w64((pend & 1u) != 0) & __builtin_amdgcn_ballot_w64(idx < end_plus1);
-                pend >>= 1;
+                const u32 ps = (sel01(krev) << 15) | idx;
+                lmask e = __builtin_amdgcn_ballot_w64((int)pend < 0) & __builtin_amdgcn_ballot_w64(idx < end_plus1);
+                pend <<= 1;
                 if (!DIRECT) {
                     const u32 spare = (u32)(CAP * LY::ROW + lane) * 8u;
                     const u32 addr = slot < spare ? slot : spare;  // a full lane scribbles on the spare row
