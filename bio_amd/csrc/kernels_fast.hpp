@@ -56,6 +56,13 @@ __device__ __forceinline__ u32 sel01(lmask m) {  // m ? 1 : 0 (both operands inl
     return r;
 }
 
+// tm |= lanes where a == b.  Compare and OR in one asm block: left to itself the scheduler issues all W(W-1)/2 compares of the
+// first-window tie test first and spills their SGPR pairs to VGPR lanes (v_writelane + s_nop + v_readlane for every pair).
+__device__ __forceinline__ void or_eq64(lmask &tm, u64 a, u64 b) {
+    lmask t;
+    asm("v_cmp_eq_u64_e64 %1, %2, %3\n\ts_or_b64 %0, %0, %1" : "+s"(tm), "=&s"(t) : "v"(a), "v"(b));
+}
+
 struct HV {  // hash (lo, hi) + pos|strand
     u32 lo, hi, p;
 };
@@ -240,8 +247,7 @@ struct FastMin {
 #pragma unroll
             for (int a = 0; a + 1 < W; ++a)
 #pragma unroll
-                for (int b = a + 1; b < W; ++b)
-                    tm |= __builtin_amdgcn_ballot_w64((((u64)S[a].hi << 32) | S[a].lo) == (((u64)S[b].hi << 32) | S[b].lo));
+                for (int b = a + 1; b < W; ++b) or_eq64(tm, ((u64)S[a].hi << 32) | S[a].lo, ((u64)S[b].hi << 32) | S[b].lo);
             tie = (u32)((tm >> lane) & 1);
         }
 #pragma unroll

@@ -129,7 +129,7 @@ struct FastProt {
                     for (int x = 0; x + 1 < W; ++x)
 #pragma unroll
                         for (int y = x + 1; y < W; ++y)
-                            tm |= __builtin_amdgcn_ballot_w64((((u64)S[x].hi << 32) | S[x].lo) == (((u64)S[y].hi << 32) | S[y].lo));
+                            or_eq64(tm, ((u64)S[x].hi << 32) | S[x].lo, ((u64)S[y].hi << 32) | S[y].lo);
                 }
 #pragma unroll
                 for (int q = W - 2; q >= 0; --q) S[q] = selv(lt64(S[q + 1].lo, S[q + 1].hi, S[q].lo, S[q].hi), S[q + 1], S[q]);

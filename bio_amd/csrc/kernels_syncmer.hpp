@@ -145,10 +145,10 @@ struct FastSyn {
         if (!DIRECT && MODE == 1) {  // first-window tie flag: compare with every earlier s-mer of blocks 0 and 1
 #pragma unroll
             for (int j = 0; j < W; ++j)
-                tm |= __builtin_amdgcn_ballot_w64((((u64)R0h[j] << 32) | R0l[j]) == (((u64)v.hi << 32) | v.lo));
+                or_eq64(tm, ((u64)R0h[j] << 32) | R0l[j], ((u64)v.hi << 32) | v.lo);
 #pragma unroll
             for (int j = 0; j < O; ++j)
-                tm |= __builtin_amdgcn_ballot_w64((((u64)S[j].hi << 32) | S[j].lo) == (((u64)v.hi << 32) | v.lo));
+                or_eq64(tm, ((u64)S[j].hi << 32) | S[j].lo, ((u64)v.hi << 32) | v.lo);
         }
         S[O] = v;
     }
@@ -197,7 +197,7 @@ struct FastSyn {
             for (int a = 0; a + 1 < W; ++a)
 #pragma unroll
                 for (int b = a + 1; b < W; ++b)
-                    tm |= __builtin_amdgcn_ballot_w64((((u64)S[a].hi << 32) | S[a].lo) == (((u64)S[b].hi << 32) | S[b].lo));
+                    or_eq64(tm, ((u64)S[a].hi << 32) | S[a].lo, ((u64)S[b].hi << 32) | S[b].lo);
         }
 #pragma unroll
         for (int q = W - 2; q >= 0; --q) S[q] = selv(lt64(S[q + 1].lo, S[q + 1].hi, S[q].lo, S[q].hi), S[q + 1], S[q]);
