@@ -188,20 +188,31 @@ struct FastMin {
             if (FIRST) coutb2 = __builtin_amdgcn_alignbit(out_hi, out_lo, 30);  // slot 16 sees base 15, ...
             else coutb2 = __builtin_amdgcn_alignbit(out_h2, out_hi, ((i0 - 1) & 15) * 2);
         }
+        // Table rows: all W of the block are fetched up front for W <= 16; wider windows fetch them in chunks of XC, one chunk
+        // ahead (4W VGPRs of rows in flight would push W >= 17 past 256 VGPRs, i.e. to one wave per SIMD or into spills).
+        constexpr int XC = W > 16 ? 8 : W;
         u32x4 xs[W];
+        auto fetch = [&](int o0) {
 #pragma unroll
-        for (int o = 0; o < W; ++o) {  // byte offset into the table = out*64 + in*16 ; row "nothing leaves" = 256 + in*16
-            const int q = o & 15;
-            const u32 ci = o < 16 ? cinb : cinb2, co = o < 16 ? coutb : coutb2;
-            const u32 a = (q >= 2 ? (ci >> (2 * q - 4)) : (ci << (4 - 2 * q))) & 0x30u;
-            const u32 b = (FIRST && o == 0) ? 0x100u : ((q >= 3 ? (co >> (2 * q - 6)) : (co << (6 - 2 * q))) & 0xC0u);
-            xs[o] = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB + (a | b));
-        }
+            for (int o = o0; o < o0 + XC && o < W; ++o) {  // byte offset into the table = out*64 + in*16 ; row "nothing leaves" = 256 + in*16
+                const int q = o & 15;
+                const u32 ci = o < 16 ? cinb : cinb2, co = o < 16 ? coutb : coutb2;
+                const u32 a = (q >= 2 ? (ci >> (2 * q - 4)) : (ci << (4 - 2 * q))) & 0x30u;
+                const u32 b = (FIRST && o == 0) ? 0x100u : ((q >= 3 ? (co >> (2 * q - 6)) : (co << (6 - 2 * q))) & 0xC0u);
+                xs[o] = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB + (a | b));
+            }
+        };
+        fetch(0);
+        if (XC < W) fetch(XC);
         load_block_words(i0 + W);  // next block's words: in flight while this block is hashed
         u32 vi = i0;               // k-mer index as a VGPR (selects need VGPR operands)
         const u32 spare = PAIR ? sspare : (u32)(CAP * LY::ROW + lane) * 8u;
 #pragma unroll
         for (int o = 0; o < W; ++o) {
+            if (XC < W && o && o % XC == 0 && o + XC < W) {
+                __builtin_amdgcn_sched_barrier(0);  // keep the next chunk's reads here (hoisted, they are all live at once again)
+                fetch(o + XC);
+            }
             roll(xs[o]);
             const lmask rev = lt64(rl, rh_, fl, fh_);
             HV v;
@@ -385,7 +396,7 @@ __device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 e
 }
 
 template <int W, int CAP, bool POS16>
-__global__ __launch_bounds__(64, ((W >= 16 && W <= 24) ? 2 : 1)) void k_minimizer_fast(KArgs a) {  // W 16..24: capped at 256 VGPRs (2 waves per SIMD, measured 1.1-1.5x); wider windows spill too much
+__global__ __launch_bounds__(64, ((W >= 16 && W <= 29) ? 2 : 1)) void k_minimizer_fast(KArgs a) {  // W 16..29: capped at 256 VGPRs (2 waves per SIMD); wider windows spill too much (W = 30: 395 against 448, W = 32: 376 against 478 Gbases/s)
     constexpr bool PAIR = POS16;  // paired staging columns (8 waves per CU); 32-bit positions keep the private columns
     typedef typename MinLds<PAIR, CAP, POS16>::type LY;
     __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
