@@ -240,7 +240,7 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
 }
 
 #ifdef BSK_IMPL_PROTEIN
-#define BSK_PROT_KW(X) X(5, 9) X(5, 10) X(3, 10) X(4, 12)
+#define BSK_PROT_KW(X) X(5, 9) X(5, 10) X(3, 10) X(4, 12) X(3, 9) X(4, 9) X(4, 10) X(5, 12) X(8, 9) X(8, 10) X(3, 12) X(5, 14)
 bool fast_prot_supported(int w, int k) {
 #define X(WW, KK) \
     if (w == WW && k == KK) return true;
