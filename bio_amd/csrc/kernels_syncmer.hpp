@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves p
 }
 
 #ifdef BSK_IMPL_SYNCMER  // dispatch functions: compiled in the family's own translation unit
-#define BSK_SYN_WS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(18) X(20) X(24)
+#define BSK_SYN_WS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
 bool fast_syncmer_supported(int k, int s) {
     switch (k - s) {
 #define X(WW) case WW:
