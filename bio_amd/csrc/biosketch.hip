@@ -930,8 +930,10 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             !getenv("BSK_FORCE_GENERIC")) {
             pl.which = K_SIM_FAST;  // bit-sliced counters: 5 planes count to 31, 6 to 63
             pl.fast_w = nh <= 31 ? 5 : 6;
-            pl.fast_k = (b->maxlen + (u32)(p->circular ? p->k : 0) <= 16u * (BSK_SIM_SHORT_WORDS - 2)) ? 1 : 0;  // short reads: less LDS, more waves
-            if (pl.fast_k) per_cu = nh <= 31 ? blocks_per_cu(k_simhash_fast<5, BSK_SIM_SHORT_WORDS>) : blocks_per_cu(k_simhash_fast<6, BSK_SIM_SHORT_WORDS>);
+            const u32 ext_len = b->maxlen + (u32)(p->circular ? p->k : 0);
+            pl.fast_k = ext_len <= 16u * (BSK_SIM_SHORT_WORDS - 2) ? 1 : ext_len <= 16u * (BSK_SIM_MID_WORDS - 2) ? 2 : 0;  // shorter reads: less LDS, more waves
+            if (pl.fast_k == 1) per_cu = nh <= 31 ? blocks_per_cu(k_simhash_fast<5, BSK_SIM_SHORT_WORDS>) : blocks_per_cu(k_simhash_fast<6, BSK_SIM_SHORT_WORDS>);
+            else if (pl.fast_k == 2) per_cu = nh <= 31 ? blocks_per_cu(k_simhash_fast<5, BSK_SIM_MID_WORDS>) : blocks_per_cu(k_simhash_fast<6, BSK_SIM_MID_WORDS>);
             else per_cu = nh <= 31 ? blocks_per_cu(k_simhash_fast<5>) : blocks_per_cu(k_simhash_fast<6>);
         } else {
             pl.which = use_ascii ? K_SIM_A : K_SIM_P;
@@ -1195,9 +1197,12 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_PROT_MIN_FAST: fast_prot_launch(pl.fast_w, pl.fast_k, pl.grid, ctx->stream, a); break;
         case K_PROT_HASH_FAST: fast_prot_hash_launch(pl.fast_k, pl.grid, ctx->stream, a); break;
         case K_SIM_FAST:
-            if (pl.fast_k) {
+            if (pl.fast_k == 1) {
                 if (pl.fast_w == 5) hipLaunchKernelGGL((k_simhash_fast<5, BSK_SIM_SHORT_WORDS>), dim3(pl.grid), dim3(64), 0, ctx->stream, a);
                 else hipLaunchKernelGGL((k_simhash_fast<6, BSK_SIM_SHORT_WORDS>), dim3(pl.grid), dim3(64), 0, ctx->stream, a);
+            } else if (pl.fast_k == 2) {
+                if (pl.fast_w == 5) hipLaunchKernelGGL((k_simhash_fast<5, BSK_SIM_MID_WORDS>), dim3(pl.grid), dim3(64), 0, ctx->stream, a);
+                else hipLaunchKernelGGL((k_simhash_fast<6, BSK_SIM_MID_WORDS>), dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             } else if (pl.fast_w == 5) hipLaunchKernelGGL(k_simhash_fast<5>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             else hipLaunchKernelGGL(k_simhash_fast<6>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             break;

@@ -35,8 +35,9 @@ struct RollNt {  // ntHash-1 of the current m-mer, both strands
     }
 };
 
-// NWL = packed words of a read staged in LDS: 12 (reads of up to 160 bases) leaves 12 waves per CU, 34 (512 bases) 8
+// NWL = packed words of a read staged in LDS: 12 (reads of up to 160 bases) leaves 12 waves per CU, 20 (288 bases) 10, 34 (512 bases) 8
 #define BSK_SIM_SHORT_WORDS 12
+#define BSK_SIM_MID_WORDS 20
 template <int PL, int NWL = BSK_NT_FAST_WORDS>
 __global__ __launch_bounds__(64) void k_simhash_fast(KArgs a) {
     constexpr int TL = 18;
