@@ -190,7 +190,8 @@ struct FastMin {
         }
         // Table rows: all W of the block are fetched up front for W <= 16; wider windows fetch them in chunks of XC, one chunk
         // ahead (4W VGPRs of rows in flight would push W >= 17 past 256 VGPRs, i.e. to one wave per SIMD or into spills).
-        constexpr int XC = W > 16 ? 8 : W;
+        // Chunks of 4 measured best (w = 28: 734 Gbases/s against 679 / 540 / 390 with chunks of 6 / 8 / 12).
+        constexpr int XC = W > 16 ? 4 : W;
         u32x4 xs[W];
         auto fetch = [&](int o0) {
 #pragma unroll
@@ -396,7 +397,7 @@ __device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 e
 }
 
 template <int W, int CAP, bool POS16>
-__global__ __launch_bounds__(64, ((W >= 16 && W <= 29) ? 2 : 1)) void k_minimizer_fast(KArgs a) {  // W 16..29: capped at 256 VGPRs (2 waves per SIMD); wider windows spill too much (W = 30: 395 against 448, W = 32: 376 against 478 Gbases/s)
+__global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs a) {  // W >= 16: capped at 256 VGPRs (two waves per SIMD)
     constexpr bool PAIR = POS16;  // paired staging columns (8 waves per CU); 32-bit positions keep the private columns
     typedef typename MinLds<PAIR, CAP, POS16>::type LY;
     __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
