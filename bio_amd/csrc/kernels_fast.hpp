@@ -63,6 +63,10 @@ __device__ __forceinline__ void or_eq64(lmask &tm, u64 a, u64 b) {
     asm("v_cmp_eq_u64_e64 %1, %2, %3\n\ts_or_b64 %0, %0, %1" : "+s"(tm), "=&s"(t) : "v"(a), "v"(b));
 }
 
+__device__ __forceinline__ lmask eq64(u32 alo, u32 ahi, u32 blo, u32 bhi) {
+    return __builtin_amdgcn_ballot_w64((((u64)ahi << 32) | alo) == (((u64)bhi << 32) | blo));
+}
+
 struct HV {  // hash (lo, hi) + pos|strand
     u32 lo, hi, p;
 };
@@ -72,6 +76,26 @@ __device__ __forceinline__ HV selv(lmask m, HV t, HV f) {
     r.hi = sel(m, t.hi, f.hi);
     r.p = sel(m, t.p, f.p);
     return r;
+}
+
+// Suffix-minimum pass over the W values of a finished block: S[q] = min(S[q..W-1]), the older (left) element winning ties.
+// FIRST (the block is the sequence's first sorted window, sketch.go:236): also evaluates BSK_ST_FIRST_WINDOW_TIE --
+//   tie <=> two equal hashes h[t1] == h[t2], t1 < t2, inside the first window with nothing smaller in (t1, end of the window),
+// i.e. "the minimum of [q, W) occurs twice" for some q: the only ties whose order after the reference's unstable first sort can
+// ever reach buf[0] (two tied entries are both in the buffer while their value is its minimum only if nothing after t1 in the
+// first window is smaller).  One equality test per element on top of the pass's own compare; the chain is scalar mask logic.
+template <int W, bool FIRST>
+__device__ __forceinline__ void suffix_min_pass(HV (&S)[W], lmask &tm) {
+    lmask dup = 0;
+#pragma unroll
+    for (int q = W - 2; q >= 0; --q) {
+        const lmask lt = lt64(S[q + 1].lo, S[q + 1].hi, S[q].lo, S[q].hi);
+        if (FIRST) {
+            dup = eq64(S[q + 1].lo, S[q + 1].hi, S[q].lo, S[q].hi) | (lt & dup);  // equal: twice; S[q] smaller: unique so far
+            tm |= dup;
+        }
+        S[q] = selv(lt, S[q + 1], S[q]);
+    }
 }
 
 // LDS plan of one wavefront (bytes).  7 wavefronts per CU fit in the 160 KB.
@@ -254,17 +278,14 @@ struct FastMin {
             S[o] = v;
             vi += 1;
         }
-        if (FIRST && !DIRECT) {  // BSK_ST_FIRST_WINDOW_TIE: two equal hashes among the first W
+        if (FIRST && !DIRECT) {
             lmask tm = 0;
-#pragma unroll
-            for (int a = 0; a + 1 < W; ++a)
-#pragma unroll
-                for (int b = a + 1; b < W; ++b) or_eq64(tm, ((u64)S[a].hi << 32) | S[a].lo, ((u64)S[b].hi << 32) | S[b].lo);
+            suffix_min_pass<W, true>(S, tm);
             tie = (u32)((tm >> lane) & 1);
+        } else {
+            lmask tm = 0;
+            suffix_min_pass<W, false>(S, tm);
         }
-#pragma unroll
-        for (int q = W - 2; q >= 0; --q)  // S[q] = min(S[q..W-1]), the older (left) element wins ties
-            S[q] = selv(lt64(S[q + 1].lo, S[q + 1].hi, S[q].lo, S[q].hi), S[q + 1], S[q]);
     }
 
     template <bool UNI>
@@ -862,9 +883,11 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
 
 // ---- dispatch table --------------------------------------------------------------------
 #ifdef BSK_IMPL_MINIMIZER  // dispatch functions: compiled in the family's own translation unit
+#ifndef BSK_FAST_WS  // (dev builds narrow the list: -D'BSK_FAST_WS(X)=X(11)')
 #define BSK_FAST_WS(X) \
     X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) \
     X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
+#endif
 
 bool fast_minimizer_supported(int w) {
     switch (w) {

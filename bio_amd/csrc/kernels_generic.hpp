@@ -247,14 +247,9 @@ __device__ __forceinline__ void window_pass(Src &src, u32 nk, u32 nk_max, int W,
         ring_h[o * 64 + lane] = h;
         ring_p[o * 64 + lane] = ps;
         if (o == W - 1) {
-            if (first && !DIRECT) {  // BSK_ST_FIRST_WINDOW_TIE: any two equal hashes among the first W
-                for (int a = 0; a + 1 < W; ++a) {
-                    u64 ha = ring_h[a * 64 + lane];
-                    for (int b = a + 1; b < W; ++b) tie |= (ring_h[b * 64 + lane] == ha) ? 1u : 0u;
-                }
-            }
             u64 nh = h;
             u32 np = ps;
+            u32 dup = 0;  // BSK_ST_FIRST_WINDOW_TIE: the minimum of [q, W) occurs twice for some q (kernels_fast.hpp, suffix_min_pass)
             for (int q = W - 2; q >= 0; --q) {  // ring[q] = min(ring[q..W-1]), leftmost on ties
                 u64 ah = ring_h[q * 64 + lane];
                 u32 ap = ring_p[q * 64 + lane];
@@ -262,9 +257,11 @@ __device__ __forceinline__ void window_pass(Src &src, u32 nk, u32 nk_max, int W,
                     ring_h[q * 64 + lane] = nh;
                     ring_p[q * 64 + lane] = np;
                 } else {
+                    dup = ah == nh ? 1u : 0u;
                     nh = ah;
                     np = ap;
                 }
+                if (first && !DIRECT) tie |= dup;
             }
             o = 0;
             first = false;

@@ -528,14 +528,9 @@ __device__ __forceinline__ void syncmer_pass1(Src &src, u32 ns, u32 ns_max, int 
         ring_h[o * 64 + lane] = h;
         ring_p[o * 64 + lane] = i;
         if (o == W2 - 1) {
-            if (first && !DIRECT) {
-                for (int x = 0; x + 1 < W2; ++x) {
-                    const u64 hx = ring_h[x * 64 + lane];
-                    for (int y = x + 1; y < W2; ++y) tie |= (ring_h[y * 64 + lane] == hx) ? 1u : 0u;
-                }
-            }
             u64 nh = h;
             u32 np = i;
+            u32 dup = 0;  // BSK_ST_FIRST_WINDOW_TIE over the first 2w s-mers (kernels_fast.hpp, suffix_min_pass)
             for (int q = W2 - 2; q >= 0; --q) {
                 const u64 ah = ring_h[q * 64 + lane];
                 const u32 ap = ring_p[q * 64 + lane];
@@ -543,9 +538,11 @@ __device__ __forceinline__ void syncmer_pass1(Src &src, u32 ns, u32 ns_max, int 
                     ring_h[q * 64 + lane] = nh;
                     ring_p[q * 64 + lane] = np;
                 } else {
+                    dup = ah == nh ? 1u : 0u;
                     nh = ah;
                     np = ap;
                 }
+                if (first && !DIRECT) tie |= dup;
             }
             o = 0;
             first = false;

@@ -124,15 +124,8 @@ struct FastProt {
             S[o] = v;
             vi += 1;
             if (o == W - 1) {
-                if (first) {  // BSK_ST_FIRST_WINDOW_TIE
-#pragma unroll
-                    for (int x = 0; x + 1 < W; ++x)
-#pragma unroll
-                        for (int y = x + 1; y < W; ++y)
-                            or_eq64(tm, ((u64)S[x].hi << 32) | S[x].lo, ((u64)S[y].hi << 32) | S[y].lo);
-                }
-#pragma unroll
-                for (int q = W - 2; q >= 0; --q) S[q] = selv(lt64(S[q + 1].lo, S[q + 1].hi, S[q].lo, S[q].hi), S[q + 1], S[q]);
+                if (first) suffix_min_pass<W, true>(S, tm);  // + BSK_ST_FIRST_WINDOW_TIE (kernels_fast.hpp)
+                else suffix_min_pass<W, false>(S, tm);
             }
         }
     }

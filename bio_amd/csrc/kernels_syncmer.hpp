@@ -46,6 +46,24 @@ struct Codes32 {
         lo = __builtin_amdgcn_alignbit(w1, w0, sh);
         hi = __builtin_amdgcn_alignbit(w2, w1, sh);
     }
+    // the same in two halves: the three words are requested one block ahead (issue) and cut to codes when the block starts
+    // (finish) -- loaded where they are used, every block began with four dependent L2 round trips
+    struct Raw {
+        u32 a, b, c;
+    };
+    static __device__ __forceinline__ Raw issue(const u32 *__restrict__ w, u32 p0) {
+        const u32 wi = p0 >> 4;
+        Raw r;
+        r.a = w[wi];
+        r.b = w[wi + 1];
+        r.c = w[wi + 2];
+        return r;
+    }
+    __device__ __forceinline__ void finish(const Raw &r, u32 p0) {
+        const u32 sh = (p0 & 15) * 2;
+        lo = __builtin_amdgcn_alignbit(r.b, r.a, sh);
+        hi = __builtin_amdgcn_alignbit(r.c, r.b, sh);
+    }
     template <int O>
     __device__ __forceinline__ u32 in_off() const {  // code O as table byte offset (<< 4)
         constexpr int o = O & 15;
@@ -73,8 +91,9 @@ struct FastSyn {
     // state
     u32 kfl, kfh, krl, krh, sfl, sfh, srl, srh;
     HV S[W], D[W], P;
-    u32 R0l[W], R0h[W];  // raw s-mer hashes of block 0 (first-window tie flag)
     u32 pend, slot, tie, cnt;
+    Codes32::Raw nsin, nsout, nkin, nkout;  // packed words of the NEXT steady block's four code streams
+    u32 Al, Ah;  // first-window tie flag: the smallest suffix minimum of block 0 that occurs twice inside block 0 (~0: none)
     lmask tm;
 
     __device__ __forceinline__ void rollk(u32x4 x) {
@@ -142,14 +161,6 @@ struct FastSyn {
             }
             D[O] = M;
         }
-        if (!DIRECT && MODE == 1) {  // first-window tie flag: compare with every earlier s-mer of blocks 0 and 1
-#pragma unroll
-            for (int j = 0; j < W; ++j)
-                or_eq64(tm, ((u64)R0h[j] << 32) | R0l[j], ((u64)v.hi << 32) | v.lo);
-#pragma unroll
-            for (int j = 0; j < O; ++j)
-                or_eq64(tm, ((u64)S[j].hi << 32) | S[j].lo, ((u64)v.hi << 32) | v.lo);
-        }
         S[O] = v;
     }
 
@@ -161,21 +172,36 @@ struct FastSyn {
         }
     }
 
+    __device__ __forceinline__ void prefetch(u32 i0) {  // words of the steady block starting at s-mer i0
+        const u32 idx0 = i0 - (2 * W - 1);
+        nsin = Codes32::issue(w, i0 + (u32)s - 1);
+        nsout = Codes32::issue(w, i0 - 1);
+        nkin = Codes32::issue(w, idx0 + (u32)k - 1);
+        nkout = Codes32::issue(w, idx0 - 1);
+    }
+
     template <int MODE>
     __device__ __forceinline__ void block(u32 i0) {
         Codes32 sin, sout, kin, kout;
-        sin.load(w, i0 + (u32)s - 1);
-        sout.load(w, i0 ? i0 - 1 : 0);
+        if (MODE == 2) {
+            const u32 idx0 = i0 - (2 * W - 1);
+            sin.finish(nsin, i0 + (u32)s - 1);
+            sout.finish(nsout, i0 - 1);
+            kin.finish(nkin, idx0 + (u32)k - 1);
+            kout.finish(nkout, idx0 - 1);
+            prefetch(i0 + W);  // (past the last block: inside the buffer's slack, never used)
+        } else {
+            sin.load(w, i0 + (u32)s - 1);
+            sout.load(w, i0 ? i0 - 1 : 0);
+        }
         if (MODE == 0) {  // block 0: offset o >= 1 sees base o-1 (offset 0 takes the "nothing leaves" row)
             const u64 v = (((u64)sout.hi << 32) | sout.lo) << 2;
             sout.lo = (u32)v;
             sout.hi = (u32)(v >> 32);
         }
-        const u32 idx0 = i0 - (2 * W - 1);  // idx of offset 0 (meaningful for MODE 2; MODE 1 only uses offset W-1)
         if (MODE == 2) {
-            kin.load(w, idx0 + (u32)k - 1);
-            kout.load(w, idx0 - 1);
         } else if (MODE == 1) {
+            prefetch(2 * W);
             // only offset W-1 is a fused step: idx = 0, incoming base k-1; place it at code index W-1
             kin.load(w, (u32)k - 1);
             // shift so that code 0 of the load appears at index W-1
@@ -187,20 +213,39 @@ struct FastSyn {
             kin.lo = kin.hi = kout.lo = kout.hi = 0;
         }
         steps<MODE, 0>(i0, sin, sout, kin, kout);
+        // BSK_ST_FIRST_WINDOW_TIE over the first 2W s-mers (blocks 0 and 1; definition: kernels_fast.hpp, suffix_min_pass):
+        // "the minimum of s-mers [q, 2W) occurs twice".  For q in block 1 that is the chain of block 1's own pass.  For q in
+        // block 0, with S0[q] = min of block 0 from q and T = min of block 1:  S0[q] == T,  or  S0[q] < T and S0[q] occurs
+        // twice inside block 0.  Block 0 therefore leaves A = the smallest such S0[q] (S0 is non-increasing towards q = 0, so
+        // the last q of the descending pass wins) and parks its W suffix minima in the lane's staging rows 1..W, which hold no
+        // tuple before the end of block 1; block 1 compares both with T.  3W instructions per read instead of W(2W-1) compares.
         if (MODE == 0 && !DIRECT) {
+            lmask dup = 0;
 #pragma unroll
-            for (int a = 0; a < W; ++a) {
-                R0l[a] = S[a].lo;
-                R0h[a] = S[a].hi;
+            for (int q = W - 2; q >= 0; --q) {
+                const lmask lt = lt64(S[q + 1].lo, S[q + 1].hi, S[q].lo, S[q].hi);
+                dup = eq64(S[q + 1].lo, S[q + 1].hi, S[q].lo, S[q].hi) | (lt & dup);
+                S[q] = selv(lt, S[q + 1], S[q]);
+                if (dup) {  // wave-uniform and rare (a tie inside 2W s-mers: ~1 % of reads)
+                    Al = sel(dup, S[q].lo, Al);
+                    Ah = sel(dup, S[q].hi, Ah);
+                }
             }
 #pragma unroll
-            for (int a = 0; a + 1 < W; ++a)
+            for (int q = 0; q < W; ++q)
+                *reinterpret_cast<LDSQ u64 *>(lds + LY::SH + (u32)((q + 1) * LY::ROW + lane) * 8u) = ((u64)S[q].hi << 32) | S[q].lo;
+        } else if (MODE == 1 && !DIRECT) {
+            suffix_min_pass<W, true>(S, tm);
+            tm |= lt64(Al, Ah, S[0].lo, S[0].hi);
 #pragma unroll
-                for (int b = a + 1; b < W; ++b)
-                    or_eq64(tm, ((u64)S[a].hi << 32) | S[a].lo, ((u64)S[b].hi << 32) | S[b].lo);
+            for (int q = 0; q < W; ++q) {
+                const u64 x = *reinterpret_cast<LDSQ const u64 *>(lds + LY::SH + (u32)((q + 1) * LY::ROW + lane) * 8u);
+                tm |= eq64((u32)x, (u32)(x >> 32), S[0].lo, S[0].hi);
+            }
+        } else {
+            lmask t0 = 0;
+            suffix_min_pass<W, false>(S, t0);
         }
-#pragma unroll
-        for (int q = W - 2; q >= 0; --q) S[q] = selv(lt64(S[q + 1].lo, S[q + 1].hi, S[q].lo, S[q].hi), S[q + 1], S[q]);
     }
 
     // ns_max: wave maximum of the number of s-mers (L - s + 1)
@@ -209,6 +254,7 @@ struct FastSyn {
         pend = 0;
         tie = 0;
         tm = 0;
+        Al = Ah = 0xffffffffu;
         slot = (u32)lane * 8u;
         // warm-ups: four table rows in flight per trip (one row per trip exposes the LDS latency k + s - 2 times per read)
         for (int t0 = 0; t0 < s - 1; t0 += 16) {  // s-mer warm-up
@@ -242,7 +288,8 @@ struct FastSyn {
             for (; j < nb; ++j) rollk(tabk(256 + (((word >> (2 * j)) & 3) << 4)));
         }
         block<0>(0);
-        if (ns_max > (u32)W) block<1>(W);
+        block<1>(W);  // unconditional: a lane that is not short has at least 2W s-mers (sketch.go:149), and a conditional block leaves
+                      // D[] undefined on one path -- the compiler then keeps last unit's registers alive across the unit loop
         for (u32 i0 = 2 * W; i0 < ns_max; i0 += W) block<2>(i0);
         tie = (u32)((tm >> lane) & 1);
         cnt = (slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);
@@ -334,7 +381,9 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves p
 }
 
 #ifdef BSK_IMPL_SYNCMER  // dispatch functions: compiled in the family's own translation unit
+#ifndef BSK_SYN_WS  // (dev builds narrow the list: -D'BSK_SYN_WS(X)=X(20)')
 #define BSK_SYN_WS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
+#endif
 bool fast_syncmer_supported(int k, int s) {
     switch (k - s) {
 #define X(WW) case WW:

@@ -85,10 +85,13 @@ typedef enum bsk_alphabet {
 #define BSK_ST_SHORT 0x01             /* constructor would return ErrShortSeq; 0 tuples */
 #define BSK_ST_ILLEGAL 0x02           /* NextKmer hit ErrIllegalBase (iterator.go:731,746); tuples before it kept */
 #define BSK_ST_CODE_MASK 0x0f
-#define BSK_ST_FIRST_WINDOW_TIE 0x10  /* two equal hashes in the first sorted window: upstream's unstable
-                                         sorts.Quicksort (sketch.go:236,351) may order them differently;
-                                         this engine returns the leftmost.  Bit-exactness vs Go is claimed
-                                         for reads WITHOUT this flag. */
+#define BSK_ST_FIRST_WINDOW_TIE 0x10  /* the first sorted window (first w k-mer hashes; first 2(k-s) s-mer hashes for
+                                         syncmers) holds two equal hashes h[t1] == h[t2], t1 < t2, with nothing smaller
+                                         behind t1 inside that window -- the only ties that can sit at buf[0] together,
+                                         where upstream's unstable sorts.Quicksort (sketch.go:236,351) may order them
+                                         either way; this engine returns the leftmost.  Bit-exactness vs Go is claimed
+                                         for reads WITHOUT this flag.  (A tie with a smaller hash behind its first entry
+                                         never reaches the front of the buffer while both entries are in it.) */
 #define BSK_ST_HAS_NON_ACGT 0x20      /* a byte outside ACGTacgt was hashed (ntHash seed table for such
                                          bytes is unpinned upstream) */
 

@@ -315,8 +315,17 @@ struct orc_sketch {
 
 /* stands in for sorts.Quicksort(idxValues(buf)) (sketch.go:236,351): orders by
  * Val only.  Upstream is unstable (PARITY UNPINNED on ties); here: stable
- * insertion sort + ORC_FLAG_FIRST_WINDOW_TIE when any two Vals are equal. */
+ * insertion sort + ORC_FLAG_FIRST_WINDOW_TIE (same rule as tie_flag() below: a tied pair
+ * with nothing smaller behind its first entry inside this window). */
 static void first_window_sort(orc_idxval *buf, int n, unsigned *flags) {
+    for (int a = 0; a < n; a++) /* buf is still in Idx order here */
+        for (int b = a + 1; b < n; b++) {
+            if (buf[a].val != buf[b].val) continue;
+            int smaller = 0;
+            for (int c = a + 1; c < n; c++)
+                if (buf[c].val < buf[a].val) { smaller = 1; break; }
+            if (!smaller) *flags |= ORC_FLAG_FIRST_WINDOW_TIE;
+        }
     for (int i = 1; i < n; i++) {
         orc_idxval x = buf[i];
         int j = i - 1;
@@ -326,8 +335,6 @@ static void first_window_sort(orc_idxval *buf, int n, unsigned *flags) {
         }
         buf[j + 1] = x;
     }
-    for (int i = 1; i < n; i++)
-        if (buf[i].val == buf[i - 1].val) *flags |= ORC_FLAG_FIRST_WINDOW_TIE;
 }
 
 static void scan_non_acgt(const uint8_t *s, size_t n, unsigned *flags) {
@@ -660,10 +667,20 @@ static int hash_vec(const uint8_t *s, size_t L, int k, hvec *v) {
     return 1;
 }
 
+/* ORC_FLAG_FIRST_WINDOW_TIE over the first sorted window h[0..n) (sketch.go:236,351; sketch-protein.go:137):
+ * two equal hashes h[t1] == h[t2], t1 < t2 < n, with nothing smaller in (t1, n).  Only such a pair can sit at buf[0]
+ * together: two tied entries are both in the buffer while their value is its minimum only if no entry after t1 inside
+ * the first window is smaller (later entries are inserted behind equal ones, sketch.go:263-295, so they never reorder).
+ * Any other tie never reaches buf[0] with both entries present, so the unstable sort cannot show in the output. */
 static void tie_flag(const uint64_t *h, size_t n, unsigned *flags) {
     for (size_t a = 0; a < n; a++)
-        for (size_t b = a + 1; b < n; b++)
-            if (h[a] == h[b]) { *flags |= ORC_FLAG_FIRST_WINDOW_TIE; return; }
+        for (size_t b = a + 1; b < n; b++) {
+            if (h[a] != h[b]) continue;
+            int smaller = 0;
+            for (size_t c = a + 1; c < n; c++)
+                if (h[c] < h[a]) { smaller = 1; break; }
+            if (!smaller) { *flags |= ORC_FLAG_FIRST_WINDOW_TIE; return; }
+        }
 }
 
 static size_t leftmost_argmin(const uint64_t *h, size_t lo, size_t n) {

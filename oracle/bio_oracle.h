@@ -51,7 +51,7 @@ enum {
 
 /* per-sequence flags (same bit values as include/biosketch.h BSK_ST_*) */
 enum {
-    ORC_FLAG_FIRST_WINDOW_TIE = 0x10, /* >=2 equal hashes inside the first sorted window */
+    ORC_FLAG_FIRST_WINDOW_TIE = 0x10, /* a tied pair in the first sorted window with nothing smaller behind its first entry */
     ORC_FLAG_HAS_NON_ACGT = 0x20      /* a byte outside ACGTacgt was hashed */
 };
 
