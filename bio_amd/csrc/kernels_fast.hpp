@@ -128,6 +128,7 @@ struct FLds {
 #define BSK_PAIR_ROWS 56
 template <int R, bool POS16>
 struct PLds {
+    static constexpr int PR = R;    // rows of a column
     static constexpr int ROW = 33;  // 32 columns + 1: consecutive rows of a column rotate through the banks
     static constexpr int PB = POS16 ? 2 : 4;
     static constexpr int TAB = 0;
@@ -139,19 +140,20 @@ struct PLds {
     static constexpr int EXCL = SH + R * ROW * 8;                          // u32 [64] in the spare row (free once the pass is over)
     static constexpr int TOTAL = NZ + 64;
 };
-template <bool PAIR, int CAP, bool POS16>
+template <bool PAIR, int CAP, bool POS16, int PR>
 struct MinLds {
     typedef FLds<CAP, POS16> type;
 };
-template <int CAP, bool POS16>
-struct MinLds<true, CAP, POS16> {
-    typedef PLds<BSK_PAIR_ROWS, POS16> type;
+template <int CAP, bool POS16, int PR>
+struct MinLds<true, CAP, POS16, PR> {
+    typedef PLds<PR, POS16> type;
 };
 
 // RING: the lane's CAP+1 rows are a ring (k_minimizer_dense: no left-over moves after a flush); `send` = one row past the last.
-template <int W, int CAP, bool POS16, bool DIRECT, bool PAIR = false, bool RING = false>
+// PR: rows of a paired column.  XCH: table rows fetched per chunk (0: all W up front for W <= 16, 4 beyond).
+template <int W, int CAP, bool POS16, bool DIRECT, bool PAIR = false, bool RING = false, int PR = BSK_PAIR_ROWS, int XCH = 0>
 struct FastMin {
-    typedef typename MinLds<PAIR, CAP, POS16>::type LY;
+    typedef typename MinLds<PAIR, CAP, POS16, PR>::type LY;
     static constexpr u32 SBIT = POS16 ? 0x8000u : 0x80000000u;  // strand bit inside the staged pos word
     const u32 *__restrict__ w;
     LDSQ char *lds;
@@ -215,7 +217,7 @@ struct FastMin {
         // Table rows: all W of the block are fetched up front for W <= 16; wider windows fetch them in chunks of XC, one chunk
         // ahead (4W VGPRs of rows in flight would push W >= 17 past 256 VGPRs, i.e. to one wave per SIMD or into spills).
         // Chunks of 4 measured best (w = 28: 734 Gbases/s against 679 / 540 / 390 with chunks of 6 / 8 / 12).
-        constexpr int XC = W > 16 ? 4 : W;
+        constexpr int XC = XCH ? (XCH < W ? XCH : W) : (W > 16 ? 4 : W);
         u32x4 xs[W];
         auto fetch = [&](int o0) {
 #pragma unroll
@@ -288,8 +290,8 @@ struct FastMin {
         }
     }
 
-    template <bool UNI>
-    __device__ __forceinline__ void run(u32 nk_max) {
+    // state reset, warm-up over the first k-1 bases, and the words of block 0
+    __device__ __forceinline__ void begin() {
         fl = fh_ = rl = rh_ = 0;
         prev = 0xffffffffu;
         tie = 0;
@@ -297,8 +299,8 @@ struct FastMin {
         const u32 col8 = (u32)(lane & 31) * 8u;
         const bool up = lane < 32;
         if (PAIR) {
-            slim = (u32)((BSK_PAIR_ROWS - 1) * LY::ROW * 8) + col8;
-            sspare = (u32)(BSK_PAIR_ROWS * LY::ROW * 8) + col8;
+            slim = (u32)((PR - 1) * LY::ROW * 8) + col8;
+            sspare = (u32)(PR * LY::ROW * 8) + col8;
             slot = up ? col8 : slim;
             sstep = up ? (u32)(LY::ROW * 8) : (u32)(-(int)(LY::ROW * 8));
         }
@@ -332,9 +334,16 @@ struct FastMin {
                 out_h2 = pw.z;
             }
         }
+    }
+
+    template <bool UNI>
+    __device__ __forceinline__ void run(u32 nk_max) {
+        begin();
+        const u32 col8 = (u32)(lane & 31) * 8u;
+        const bool up = lane < 32;
         block<true, UNI, false>(0);
         // slot value from which a block could overrun the lane's rows (PAIR: the whole column, counted from the lane's end)
-        const u32 guard_from = PAIR ? (u32)((BSK_PAIR_ROWS - W) * LY::ROW * 8) + col8 : (u32)((CAP - W) * LY::ROW + lane) * 8u;
+        const u32 guard_from = PAIR ? (u32)((PR - W) * LY::ROW * 8) + col8 : (u32)((CAP - W) * LY::ROW + lane) * 8u;
         for (u32 i0 = W; i0 < nk_max; i0 += W) {
             // a lane stages at most W tuples per block: the bounded store is only needed near the cap
             const u32 filled = (PAIR && !up) ? slim + col8 - slot : slot;  // = (rows used * ROW) * 8 + col8
@@ -420,7 +429,7 @@ __device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 e
 template <int W, int CAP, bool POS16>
 __global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs a) {  // W >= 16: capped at 256 VGPRs (two waves per SIMD)
     constexpr bool PAIR = POS16;  // paired staging columns (8 waves per CU); 32-bit positions keep the private columns
-    typedef typename MinLds<PAIR, CAP, POS16>::type LY;
+    typedef typename MinLds<PAIR, CAP, POS16, BSK_PAIR_ROWS>::type LY;
     __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
     LDSQ char *const ldsq = (LDSQ char *)lds;
     const int lane = lane_id();
@@ -581,10 +590,15 @@ __device__ __forceinline__ void flush_rows(char *lds, int lane, u32 cnt, bool la
             if (d != 0xffffffffu) {
                 // write-once output: non-temporal stores, so that the tuples streaming out do not push the sequences'
                 // lines (re-read every round by per-lane loads) out of the L2
-                __builtin_nontemporal_store(*reinterpret_cast<const u64 *>(lds + LY::SH + sl * 8), &a.hash[ubase + d + e]);
                 u32 p = *reinterpret_cast<const u16 *>(lds + LY::SP + sl * 2);
                 if (STRAND16) p = (p & 0x7fffu) | ((p & 0x8000u) << 16);
+#ifndef BSK_FLUSH_PLAIN  // (dev switch: plain stores, for the write-combining experiments of DESIGN.md 3.1)
+                __builtin_nontemporal_store(*reinterpret_cast<const u64 *>(lds + LY::SH + sl * 8), &a.hash[ubase + d + e]);
                 __builtin_nontemporal_store(p, &a.pos[ubase + d + e]);
+#else
+                a.hash[ubase + d + e] = *reinterpret_cast<const u64 *>(lds + LY::SH + sl * 8);
+                a.pos[ubase + d + e] = p;
+#endif
             }
         }
     }
@@ -602,7 +616,10 @@ struct DenseCfg {
     // blocks per flush round: <= 13 steps, so that 15 left-over rows + the new ones + the scribble row leave 8 waves per CU.
     // (<= 24 steps: 5-6 waves; groups of 8 tuples with <= 20 steps: 8 waves and as fast, but half-line writes double the traffic.)
     static constexpr int NB = (13 / W) > 0 ? (13 / W) : 1;
-    static constexpr int GL = 4;
+#ifndef BSK_DENSE_GL
+#define BSK_DENSE_GL 4
+#endif
+    static constexpr int GL = BSK_DENSE_GL;
     static constexpr int G = 1 << GL;
     static constexpr int CAP = NB * W + G - 1;              // rows = CAP + 1: the left-over of a group + NB*W new + the scribble row
 };
