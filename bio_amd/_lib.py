@@ -17,7 +17,7 @@ SO_PATH = os.environ.get("BSK_LIB") or os.path.join(_HERE, "csrc", "libbiosketch
 OK = 0
 ERR_INVALID_K, ERR_EMPTY_SEQ, ERR_SHORT_SEQ, ERR_ILLEGAL_BASE, ERR_K_TOO_LARGE = 1, 2, 3, 4, 5
 ERR_INVALID_M, ERR_INVALID_SCALE, ERR_INVALID_S, ERR_INVALID_W, ERR_BUF_NIL, ERR_BUF_NOT_EMPTY = 6, 7, 8, 9, 10, 11
-ERR_ARG, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED, ERR_NO_DEVICE = 64, 65, 66, 67, 68
+ERR_ARG, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_IO = 64, 65, 66, 67, 68, 69
 
 KMER, NTHASH, SIMHASH, MINIMIZER, SYNCMER, PROT_HASH, PROT_MINIMIZER = 1, 2, 3, 4, 5, 6, 7
 ALPHA_DNA, ALPHA_PROTEIN = 0, 1

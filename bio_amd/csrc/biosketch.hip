@@ -1686,6 +1686,23 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
         b = tmp;
         circ_ext = p->k - 1;
     }
+    // the two-strand k-mer mode (iterator.go:713-723) yields 2(L-k+1) values per read and is not tiled: a read's count must fit
+    // the 24-bit field of its reference word
+    if (p->kind == BSK_KMER && !p->canonical && (u64)b->maxlen >= (1ull << 23) + (u64)p->k - 1) {
+        if (tmp) bsk_batch_destroy(tmp);
+        ctx->err = "two-strand k-mer codes: sequences of 2^23 k-mers or more are not supported";
+        return BSK_ERR_UNSUPPORTED;
+    }
+    // tile descriptors keep the tile length (~ positions + 2w + k) in 24 bits, and the generic kernels size their window ring by w
+    if ((u64)p->k >= (1ull << 22) || ((p->kind == BSK_MINIMIZER || p->kind == BSK_PROT_MINIMIZER) && (u64)p->w >= (1ull << 22)) ||
+        (p->kind == BSK_SYNCMER && (u64)(p->k - p->s) >= (1ull << 21))) {
+        // such a window cannot fit a sequence below 2^24 bases with room to select anything; longer sequences would need wider descriptors
+        if (b->maxlen >= (1u << 22)) {
+            if (tmp) bsk_batch_destroy(tmp);
+            ctx->err = "k / w of 2^22 or more on sequences of 2^22 bases or more is not supported";
+            return BSK_ERR_UNSUPPORTED;
+        }
+    }
     // long sequences run as tiles; protein: only when really long (the protein kernels take any length per lane, slowly)
     const bool is_dna = b->alphabet == BSK_ALPHA_DNA;
     const u32 tile_min = env_u32("BSK_TILE_MIN", (!is_dna || kind_has_pos(p->kind)) ? 4096u : 16u * (BSK_NT_FAST_WORDS - 2));

@@ -32,7 +32,7 @@ struct bsk_fastx {
     gzFile fh = nullptr;
     std::vector<uint8_t> buf;  // file window
     size_t r = 0, n = 0;       // unread part of buf: [r, n)
-    bool eof = false, started = false, finished = false;
+    bool eof = false, started = false, finished = false, io_error = false;
     int is_fastq = -1;
     int pending = 0;  // error met after some records of a chunk were read: returned by the next call
     int alphabet = -2;  // -2 not guessed yet, -1 "Unlimit", else BSK_ALPHA_*
@@ -53,6 +53,14 @@ bool fill(bsk_fastx *f) {  // refill the window; false at end of file
     f->r = 0;
     const int got = gzread(f->fh, f->buf.data(), (unsigned)f->buf.size());
     if (got <= 0) {
+        // 0 is the end of the file; a damaged or truncated gzip stream / an I/O error shows as -1, or as 0 with a pending
+        // Z_BUF_ERROR.  The reference reader hands a read error to the caller and yields nothing more (reader.go:262-268).
+        int zerr = Z_OK;
+        const char *msg = gzerror(f->fh, &zerr);
+        if (got < 0 || (zerr != Z_OK && zerr != Z_STREAM_END)) {
+            f->io_error = true;
+            f->err = std::string("fastx: read error: ") + (msg && *msg ? msg : "unknown");
+        }
         f->eof = true;
         f->n = 0;
         return false;
@@ -122,7 +130,7 @@ int next_record(bsk_fastx *f) {
         for (;;) {
             if (f->r >= f->n && !fill(f)) {
                 f->finished = true;
-                return 0;
+                return f->io_error ? -BSK_ERR_IO : 0;
             }
             const uint8_t c = f->buf[f->r++];
             if (c == '\n') continue;
@@ -140,6 +148,10 @@ int next_record(bsk_fastx *f) {
     for (;;) {
         if (f->r >= f->n && !fill(f)) {  // end of file: what was collected is the last record
             f->finished = true;
+            if (f->io_error) {  // not an end of file: the bytes collected so far are not a record
+                f->rec.clear();
+                return -BSK_ERR_IO;
+            }
             const int st = parse(f);
             f->rec.clear();
             if (st == 3) return 0;

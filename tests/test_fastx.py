@@ -171,3 +171,23 @@ def test_window_boundaries_gzip_and_chunking(tmp_path, monkeypatch):
     rd = fastx.Reader(str(plain))
     c = rd.read_chunk(max_bytes=1)
     assert len(c) >= 1 and int(c.offsets[-1]) >= 1     # at least one record, stops once the byte budget is reached
+
+
+def test_truncated_gzip_is_an_io_error(tmp_path):
+    """A damaged / truncated .gz must not end as a clean (shorter) file: the reference hands the read error to the caller
+    (seqio/fastx/reader.go:262-268); here the good records of the chunk come first, then BSK_ERR_IO."""
+    rng = random.Random(5)
+    text = "".join("@r%d\n%s\n+\n%s\n" % (i, "".join(rng.choice("ACGT") for _ in range(100)), "I" * 100) for i in range(20000))
+    blob = gzip.compress(text.encode(), 6)
+    p = tmp_path / "cut.fq.gz"
+    p.write_bytes(blob[: len(blob) // 2])  # cut in the middle of the deflate stream
+    recs, _, err = read_all(str(p))
+    assert err is not None and err.code == L.ERR_IO, err
+    assert 0 < len(recs) < 20000
+    for name, s, q in recs[:-1]:  # everything handed out before the error is a whole record
+        assert len(s) == 100 and len(q) == 100
+    # the intact file still reads clean
+    p2 = tmp_path / "ok.fq.gz"
+    p2.write_bytes(blob)
+    recs, _, err = read_all(str(p2))
+    assert err is None and len(recs) == 20000

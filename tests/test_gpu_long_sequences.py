@@ -315,3 +315,24 @@ def test_long_protein_default_tiles(engine, oracle):
         eh, ep, _ = oracle.protein_minimizer(q, 9, 5, closed=True)
         assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep), i
         assert np.array_equal(rh.read(i)[1], oracle.protein_hashes(q, 10)), i
+
+
+def test_two_strand_kmer_count_must_fit_the_reference_word(engine):
+    """NextKmer's two-strand mode (iterator.go:713-723) yields 2(L-k+1) values and is not tiled: from 2^23 k-mers on the count no
+    longer fits the 24-bit field of the read's reference word -- refused, not silently wrapped into the first-tuple bits."""
+    from bio_amd import sketches as S
+    n = (1 << 23) + 5000
+    rng = np.random.default_rng(4)
+    big = np.array(list(b"ACGT"), np.uint8)[rng.integers(0, 4, n)]
+    b = engine.batch_from_arrays(big, np.array([0, n], np.uint64))
+    with pytest.raises(S.DeviceError, match="2\\^23"):
+        engine.run(b, engine.params(L.KMER, 21, canonical=False))
+    res = engine.run(b, engine.params(L.KMER, 21, canonical=True))  # the canonical mode tiles: any length
+    assert res.info()["n_tuples"] == n - 20
+    # just below the limit the two-strand mode still runs, with both strands' counts intact
+    m = (1 << 23) - 100
+    b2 = engine.batch_from_arrays(big[:m], np.array([0, m], np.uint64))
+    r2 = engine.run(b2, engine.params(L.KMER, 21, canonical=False))
+    assert r2.info()["n_tuples"] == 2 * (m - 20)
+    b.close()
+    b2.close()
