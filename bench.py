@@ -7,19 +7,24 @@ One "step" = one pass of the minimizer kernel over the whole device-resident bat
 (2-bit packed reads in HBM -> (hash, pos|strand) tuples + per-read index in HBM).
 Reads shard by record: with N GPUs every rank owns its own 100M-read batch (weak
 scaling, no data-path collective); the only collective is one RCCL all_gather of the
-per-rank counters at the end.
+per-rank counters at the end, issued through the library's own C ABI (bsk_gather_counts).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the fields).
+
+`--backend gloo --plumbing-only` (tests/test_shard_gloo.py) runs the N > 1 control flow -- rendezvous, barriers, counter
+gather, whole-job arithmetic, the JSON line -- on CPUs with fixed stand-in counters and NO kernel; its line says so and is not
+a measurement.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,7 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0   # measured float4-copy ceiling on this part (same guide)
 
 WORKLOADS = {
     # name: (kind, n_reads, read_len, k, w_or_s, description)
@@ -39,10 +45,8 @@ WORKLOADS = {
     "prothash": ("phash", 20_000_000, 300, 9, 0, "20M x 300 aa, protein k-mer hashes k=9"),
     "simhash": ("sim", 20_000_000, 150, 21, 5, "20M x 150 bp reads, SimHash k=21 m=5 scale=5"),
 }
-KERNELS = {"min": "k_minimizer_fast<11,32,true>", "nt": "k_nthash_fast<1>", "syn": "k_syncmer_fast<20>", "pmin": "k_prot_minimizer_fast<5,9>",
-           "kmer": "k_nthash_fast<2>", "phash": "k_prot_hash_fast<9>", "sim": "k_simhash_fast<5,12>"}
 NOTES = {
-    "min": "integer-VALU bound, not HBM bound (DESIGN.md 3.1); frac is vs the 8 TB/s spec peak",
+    "min": "integer-VALU / issue bound, not HBM bound (DESIGN.md 3.1)",
     "nt": "HBM-write bound (DESIGN.md 3.2); a plain 16 B/lane fill kernel reaches 5.2-5.9 TB/s on this part",
     "syn": "integer-VALU bound (two rolling hashes + a 2(k-s) window per base; DESIGN.md 3.3)",
     "pmin": "integer-VALU bound (wyhash from scratch per residue: 8 v_mad_u64_u32; DESIGN.md 3.4)",
@@ -55,44 +59,66 @@ PROTEIN = ("pmin", "phash")
 STREAM = ("nt", "kmer", "phash", "sim")
 
 
-def cpu_baseline(kind: str, k: int, x: int, read_len: int, seed: int):
+def cpu_baseline(kind: str, k: int, x: int, read_len: int, batch):
     """Oracle (a CPU restatement of the reference algorithm, NOT the Go binary) on the host cores.
 
-    Bounded sample of the same synthetic workload; the reference's per-read iterator
-    state machine (sorted buffer, binary-search insert), one iterator per read, OpenMP over reads.
+    A bounded sample of THE SAME synthetic batch the GPU hashes (its first reads, decoded back to ASCII): the reference's
+    per-read iterator state machine (sorted buffer, binary-search insert), one recycled iterator per thread as sync.Pool gives
+    a Go worker, reads borrowed not copied, OpenMP over reads.  Thread-scaling row: 1 / 16 / 64 / all threads.
     """
-    import numpy as np
     from oracle import oracle as O
     cores = len(os.sched_getaffinity(0))
-    rng = np.random.default_rng(seed)
     okind = ORACLE_KIND[kind]
-    letters = b"ACDEFGHIKLMNPQRSTVWY" if kind in PROTEIN else b"ACGT"
-
-    def run(n, threads):
-        data = np.frombuffer(letters, np.uint8)[rng.integers(0, len(letters), n * read_len)]
-        offs = (np.arange(n + 1, dtype=np.uint64) * read_len)
-        O.batch_run(okind, data[: 1000 * read_len], offs[:1001], k, x, threads=threads)  # warm
-        t = time.perf_counter()
-        O.batch_run(okind, data, offs, k, x, threads=threads)
-        return n * read_len / (time.perf_counter() - t) / 1e9
-
     scale = 150.0 / read_len
-    v1 = run(int(200_000 * scale), 1)
-    n_all = int(min(4_000_000, 400_000 * cores) * scale)
-    vall = run(n_all, cores)
-    return {
-        "value": round(vall, 4), "unit": "Gbases/s", "cores": cores, "kind": "port",
-        "value_1thread": round(v1, 4),
-        "sample": f"{n_all} synthetic {read_len}-letter sequences on {cores} threads (and {int(200_000 * scale)} on 1 thread); "
-                  "C restatement of the reference state machine (oracle/bio_oracle.c), not the Go binary",
+    threads = sorted({t for t in (1, 16, 64, cores) if t <= cores})
+    n_max = int(min(4_000_000, 200_000 * cores) * scale)
+    n_max = min(n_max, batch.info()["n_reads"])
+    data, offs = batch.fetch_ascii(0, n_max)
+    O.batch_run(okind, data[: int(offs[1000])], offs[:1001], k, x, threads=1)  # warm
+    rows = []
+    for t in threads:
+        n = min(n_max, int(200_000 * t * scale))
+        t0 = time.perf_counter()
+        O.batch_run(okind, data, offs[: n + 1], k, x, threads=t)
+        dt = time.perf_counter() - t0
+        rows.append({"threads": t, "reads": n, "value": round(n * read_len / dt / 1e9, 4)})
+    v1, vall = rows[0]["value"], rows[-1]["value"]
+    quota = None
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().split()
+    except OSError:
+        pass
+    smt = 1
+    try:
+        sib = open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list").read().strip()
+        smt = max(1, len([p for p in sib.replace("-", ",").split(",") if p]))
+    except OSError:
+        pass
+    phys = max(1, cores // smt)
+    out = {
+        "value": vall, "unit": "Gresidues/s" if kind in PROTEIN else "Gbases/s", "cores": cores, "kind": "port",
+        "value_1thread": v1, "thread_scaling": rows,
+        "speedup_all_over_1": round(vall / v1, 2) if v1 else None,
+        "physical_cores": phys, "scaling_efficiency_vs_physical_cores": round(vall / v1 / phys, 3) if v1 else None,
+        "sample": f"the first {rows[-1]['reads']} sequences of the GPU's own synthetic batch ({read_len} letters each) on {cores} threads; "
+                  "C restatement of the reference state machine (oracle/bio_oracle.c), pooled iterators, not the Go binary",
     }
+    if quota:
+        out["cgroup_cpu_max"] = " ".join(quota)
+        if quota[0] != "max":
+            out["note"] = f"cgroup CPU quota {quota[0]}/{quota[1]} us limits the all-thread run"
+    if "note" not in out and v1 and vall / v1 < 0.5 * phys:
+        out["note"] = (f"{smt}-way SMT: {cores} hardware threads share {phys} cores, and ~300 B/read of short-lived iterator state "
+                       "per thread keeps the run memory/allocator-bound well before all threads are busy")
+    return out
 
 
-def measured_traffic(workload: str, n_reads: int):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*/traffic.json), or None.
+def measured_profile(workload: str, n_reads: int):
+    """HBM bytes per launch / VALU utilisation from the committed rocprofv3 PMC passes (profiles/*/traffic.json), or None.
 
-    bench.py cannot run the profiler on itself; the counters were collected on this same command in separate
-    --pmc passes (FETCH_SIZE, WRITE_SIZE) and corrected as MI355X_MICROARCH.md prescribes (KiB units, FETCH x2).
+    bench.py cannot run the profiler on itself; the counters were collected on this same command in separate --pmc passes
+    (FETCH_SIZE, WRITE_SIZE; SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES) and corrected as MI355X_MICROARCH.md prescribes.
+    The entry names the kernel it was measured on: a stale file shows as a kernel-name mismatch in the JSON line.
     """
     best = None
     pdir = os.path.join(ROOT, "profiles")
@@ -101,69 +127,108 @@ def measured_traffic(workload: str, n_reads: int):
         if os.path.exists(f):
             for e in json.load(open(f)).get("entries", []):
                 if e.get("workload") == workload and e.get("reads_per_gpu") == n_reads:
-                    best = e.get("hbm_bytes_per_launch")
+                    best = dict(e, profile=d)
     return best
+
+
+def plumbing_counters(rank: int):
+    """Stand-in counters of --plumbing-only: [nanoseconds, bases, tuples, first-window-tie reads, non-ACGT reads]."""
+    return [int((1.0 + 0.5 * rank) * 1e9), 15_000_000_000 + rank, 2_211_224_063 + 7 * rank, 88 + rank, 0]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="minimizer", choices=sorted(WORKLOADS))
     ap.add_argument("--reads", type=float, default=0, help="override reads per GPU (dev)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the rendezvous / barriers")
+    ap.add_argument("--plumbing-only", action="store_true", help="tests: N>1 control flow with stand-in counters, no GPU, no kernel")
     args = ap.parse_args()
-
-    import torch
-    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the sketch engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if args.plumbing_only and args.backend != "gloo":
+        raise SystemExit("--plumbing-only is the CPU test mode: use --backend gloo")
+
+    import torch
+    import torch.distributed as dist
+
+    dev = None
+    if not args.plumbing_only:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the sketch engine has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    from bio_amd import _lib as L
-    from bio_amd import sketches as S
-
-    kind, n_reads, read_len, k, x, desc = WORKLOADS[args.workload]
-    if args.reads:
-        n_reads = int(args.reads)
-    seed = 0x5EED0000 + 3 + 0x1000000 * rank  # each rank hashes its own shard of the synthetic stream
-    eng = S.Engine(local_rank)
-    batch = eng.synth(L.ALPHA_PROTEIN if kind in PROTEIN else L.ALPHA_DNA, n_reads, read_len, seed)
-    p = {"min": lambda: eng.params(L.MINIMIZER, k, w=x), "nt": lambda: eng.params(L.NTHASH, k), "syn": lambda: eng.params(L.SYNCMER, k, s=x),
-         "pmin": lambda: eng.params(L.PROT_MINIMIZER, k, w=x), "kmer": lambda: eng.params(L.KMER, k),
-         "phash": lambda: eng.params(L.PROT_HASH, k), "sim": lambda: eng.params(L.SIMHASH, k, m=x, scale=5)}[kind]()
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if dev is not None:
+            torch.cuda.synchronize()
 
-    # untimed: first run sizes the result buffers; then W warm-up steps
-    res = eng.run(batch, p)
-    res, _ = eng.run_timed(batch, p, args.warmup, 0, reuse=res)
-    barrier()
-    t0 = time.perf_counter()
-    res, kernel_ms = eng.run_timed(batch, p, 0, args.steps, reuse=res)  # exactly K steps, HIP events around each kernel
-    barrier()
-    dt = time.perf_counter() - t0
+    kind, n_reads, read_len, k, x, desc = WORKLOADS[args.workload]
+    if args.reads:
+        n_reads = int(args.reads)
 
-    info = res.info()
-    tuples = info["n_tuples"]
-    # whole-job numbers: MAX time over ranks, SUM of units over ranks (one RCCL all_gather of counters)
-    from bio_amd.shard import gather_counters, whole_job
-    job = whole_job(gather_counters([dt, float(n_reads * read_len), float(tuples)], device=dev), args.steps)
+    eng = batch = res = None
+    kernel_ms = []
+    plan = {"kernel": "none (plumbing-only)", "grid": 0, "waves_per_cu": 0}
+    if args.plumbing_only:
+        barrier()
+        barrier()
+        mine = plumbing_counters(rank)
+    else:
+        from bio_amd import _lib as L
+        from bio_amd import sketches as S
+
+        seed = 0x5EED0000 + 3 + 0x1000000 * rank  # each rank hashes its own shard of the synthetic stream
+        eng = S.Engine(local_rank)
+        if world > 1:  # the communicator of the one collective: RCCL behind the C ABI; the id travels over the launcher's store
+            uid = [eng.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            eng.comm_init_rank(uid[0], rank, world)
+        batch = eng.synth(L.ALPHA_PROTEIN if kind in PROTEIN else L.ALPHA_DNA, n_reads, read_len, seed)
+        p = {"min": lambda: eng.params(L.MINIMIZER, k, w=x), "nt": lambda: eng.params(L.NTHASH, k), "syn": lambda: eng.params(L.SYNCMER, k, s=x),
+             "pmin": lambda: eng.params(L.PROT_MINIMIZER, k, w=x), "kmer": lambda: eng.params(L.KMER, k),
+             "phash": lambda: eng.params(L.PROT_HASH, k), "sim": lambda: eng.params(L.SIMHASH, k, m=x, scale=5)}[kind]()
+        # untimed: first run sizes the result buffers; then W warm-up steps
+        res = eng.run(batch, p)
+        res, _ = eng.run_timed(batch, p, args.warmup, 0, reuse=res)
+        barrier()
+        t0 = time.perf_counter()
+        res, kernel_ms = eng.run_timed(batch, p, 0, args.steps, reuse=res)  # exactly K steps, HIP events around each kernel
+        barrier()
+        dt = time.perf_counter() - t0
+        dg = res.digest()
+        plan = res.plan()
+        mine = [int(dt * 1e9), n_reads * read_len, int(res.info()["n_tuples"]), int(dg["first_window_tie"]), int(dg["has_non_acgt"])]
+
+    # whole-job numbers: MAX time over ranks, SUM of units over ranks -- ONE all_gather of five u64 counters per rank
+    if world == 1:
+        rows = [mine]
+    elif args.plumbing_only:
+        t = torch.tensor(mine, dtype=torch.int64)
+        outl = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(outl, t)
+        rows = [[int(v) for v in o.tolist()] for o in outl]
+    else:
+        rows = eng.gather_counts(mine)  # bsk_gather_counts: RCCL all_gather
+    from bio_amd.shard import whole_job
+    job = whole_job([[r[0] / 1e9, float(r[1]), float(r[2])] for r in rows], args.steps)
     dt_max, bases_total, tuples_total = job["seconds"], job["bases"], job["tuples"]
+    tuples = mine[2]
 
     if rank == 0:
         ms_per_step = dt_max / args.steps * 1e3
@@ -175,8 +240,6 @@ def main():
             alg_bytes = in_bytes + 8 * tuples  # positions and offsets implicit
         else:
             alg_bytes = in_bytes + 12 * tuples + 8 * n_reads
-        k_ms = sum(kernel_ms) / len(kernel_ms)
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         unit = "Gresidues/s" if kind in PROTEIN else "Gbases/s"
         metric = {"min": "Gbases/s hashed (k=21 ntHash + minimizer)", "nt": "Gbases/s hashed (k=21 ntHash stream)",
                   "syn": "Gbases/s hashed (k=31 s=11 syncmer)", "pmin": "Gresidues/s hashed (k=9 w=5 protein minimizer)",
@@ -187,21 +250,41 @@ def main():
             "metric": metric,
             "value": round(value, 2), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
+            "dtype": "u64", "data": "synthetic" if not args.plumbing_only else "none (plumbing-only: stand-in counters, NO kernel ran; not a measurement)",
             "config": {"workload": desc, "reads_per_gpu": n_reads, "read_len": read_len, "k": k, par[0]: par[1],
                        "tuples_per_gpu": int(tuples), "tuples_total": int(tuples_total),
-                       "parallelism": f"reads sharded by record over {world} GPU(s), no data-path collective",
+                       "first_window_tie_reads": int(sum(r[3] for r in rows)), "non_acgt_reads": int(sum(r[4] for r in rows)),
+                       "per_rank_seconds": [round(r[0] / 1e9, 6) for r in rows],
+                       "parallelism": f"reads sharded by record over {world} GPU(s), no data-path collective; counters gathered by "
+                                      + ("bsk_gather_counts (RCCL)" if world > 1 and not args.plumbing_only else "torch gloo (plumbing-only)" if world > 1 else "nothing (1 GPU)"),
                        "input": ("residues (1 B each)" if kind in PROTEIN else "2-bit packed reads") + " resident in HBM",
                        "output": ("hash u64 per position" if kind in STREAM else "hash u64 + pos|strand u32") + " + u64 index per read, in HBM"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, n_reads),
-                         "kernel": KERNELS[kind],
-                         "kernel_ms_avg": round(k_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "read_only_frac": round(in_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "note": NOTES[kind] + "; read_only_frac = input bytes alone over the same peak (north_star's 'HBM-read roofline')"},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(kind, k, x, read_len, 12345)
+        if kernel_ms:
+            k_ms = sum(kernel_ms) / len(kernel_ms)
+            k_med = statistics.median(kernel_ms)
+            achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+            prof = measured_profile(args.workload, n_reads)
+            kern = plan["kernel"]
+            out["roofline"] = {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": prof.get("hbm_bytes_per_launch") if prof else None,
+                "kernel": kern, "grid": plan["grid"], "waves_per_cu": plan["waves_per_cu"],
+                "kernel_ms_avg": round(k_ms, 4), "kernel_ms_median": round(k_med, 4), "kernel_ms_min": round(min(kernel_ms), 4),
+                "launches_timed": len(kernel_ms),
+                "algorithmic_bytes_per_launch": int(alg_bytes),
+                "frac_of_6.29TBps_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
+                "read_only_frac": round(in_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "valu_util": prof.get("valu_util") if prof else None,
+                "profile": ({"dir": "profiles/" + prof["profile"], "kernel": prof.get("kernel"),
+                             "kernel_matches_this_run": prof.get("kernel", "").split("<")[0] == kern.split("<")[0] and (prof.get("kernel", "") in kern or kern in prof.get("kernel", ""))}
+                            if prof else None),
+                "note": NOTES[kind] + "; frac is vs the 8 TB/s spec peak; read_only_frac = input bytes alone over the same peak "
+                                      "(north_star's 'HBM-read roofline'); valu_util = SQ_ACTIVE_INST_VALU*4/SQ_BUSY_CU_CYCLES of the committed PMC pass",
+            }
+        if world == 1 and not args.no_cpu_baseline and not args.plumbing_only:
+            out["cpu_baseline"] = cpu_baseline(kind, k, x, read_len, batch)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

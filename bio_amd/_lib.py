@@ -60,6 +60,13 @@ SYMBOLS = [
     ("bsk_batch_from_fastx", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_int, _pp, _u64p]),
     ("bsk_sketch", C.c_int, [_vp, _vp, C.POINTER(Params), _pp]),
     ("bsk_sketch_timed", C.c_int, [_vp, _vp, C.POINTER(Params), _pp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    ("bsk_comm_unique_id", C.c_int, [_vp]),
+    ("bsk_comm_init_rank", C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    ("bsk_comm_init_all", C.c_int, [_pp, C.c_int]),
+    ("bsk_gather_counts", C.c_int, [_vp, _vp, C.c_int, _vp]),
+    ("bsk_gather_counts_all", C.c_int, [_pp, C.c_int, _vp, C.c_int, _vp]),
+    ("bsk_comm_destroy", None, [_vp]),
+    ("bsk_result_plan", C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("bsk_result_info", C.c_int, [_vp, _u64p, _u64p, C.POINTER(C.c_int)]),
     ("bsk_result_fetch", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp, C.c_uint64]),
     ("bsk_result_device", C.c_int, [_vp, _pp, _pp, _pp, _pp]),

@@ -267,6 +267,7 @@ extern "C" void bsk_ctx_destroy(bsk_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    bsk_comm_destroy(ctx);
     (void)hipFree(ctx->d_ticket);
     (void)hipFree(ctx->d_total);
     (void)hipFree(ctx->d_lookback);
@@ -627,6 +628,14 @@ extern "C" int bsk_result_info(const bsk_result *r, uint64_t *n_reads, uint64_t 
     if (n_reads) *n_reads = r->n;
     if (n_tuples) *n_tuples = r->n_tuples;
     if (has_pos) *has_pos = r->has_pos;
+    return BSK_OK;
+}
+
+extern "C" int bsk_result_plan(const bsk_result *r, const char **kernel, int *grid, int *waves_per_cu) {
+    if (!r) return BSK_ERR_ARG;
+    if (kernel) *kernel = r->plan;
+    if (grid) *grid = r->plan_grid;
+    if (waves_per_cu) *waves_per_cu = r->plan_per_cu;
     return BSK_OK;
 }
 
@@ -1148,6 +1157,39 @@ extern "C" int bsk_batch_translate(bsk_ctx *ctx, const bsk_batch *dna, int codon
     return rc;
 }
 
+// name of the planned kernel, as rocprofv3 shows it (bsk_result_plan; bench.py's roofline.kernel)
+static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, bsk_result *res) {
+    char b[80];
+    switch (pl.which) {
+        case K_MIN_GEN_P: snprintf(b, sizeof b, "k_minimizer_generic<0>"); break;
+        case K_MIN_GEN_A: snprintf(b, sizeof b, "k_minimizer_generic<1>"); break;
+        case K_NT_P: snprintf(b, sizeof b, "k_nthash_stream<0>"); break;
+        case K_NT_A: snprintf(b, sizeof b, "k_nthash_stream<1>"); break;
+        case K_MIN_FAST: snprintf(b, sizeof b, "k_minimizer_fast<%d,%d,true>", pl.fast_w, BSK_FAST_CAP); break;
+        case K_MIN_DENSE: snprintf(b, sizeof b, "k_minimizer_dense<%d>", pl.fast_w); break;
+        case K_MIN_SEG: snprintf(b, sizeof b, "k_minimizer_seg<%d>", pl.fast_w); break;
+        case K_NT_FAST: snprintf(b, sizeof b, "k_nthash_fast<%d>", p->kind == BSK_KMER ? 2 : p->canonical ? 1 : 0); break;
+        case K_SYN_P: snprintf(b, sizeof b, "k_syncmer<0>"); break;
+        case K_SYN_A: snprintf(b, sizeof b, "k_syncmer<1>"); break;
+        case K_KMER_P: snprintf(b, sizeof b, "k_kmer<0>"); break;
+        case K_KMER_A: snprintf(b, sizeof b, "k_kmer<1>"); break;
+        case K_SIM_P: snprintf(b, sizeof b, "k_simhash<0>"); break;
+        case K_SIM_A: snprintf(b, sizeof b, "k_simhash<1>"); break;
+        case K_PROT_HASH: snprintf(b, sizeof b, "k_prot_hash"); break;
+        case K_PROT_MIN: snprintf(b, sizeof b, "k_prot_minimizer"); break;
+        case K_SYN_FAST: snprintf(b, sizeof b, "k_syncmer_fast<%d>", pl.fast_w); break;
+        case K_PROT_MIN_FAST: snprintf(b, sizeof b, "k_prot_minimizer_fast<%d,%d>", pl.fast_w, pl.fast_k); break;
+        case K_PROT_HASH_FAST: snprintf(b, sizeof b, "k_prot_hash_fast<%d>", pl.fast_k); break;
+        case K_SIM_FAST:
+            snprintf(b, sizeof b, "k_simhash_fast<%d,%d>", pl.fast_w, pl.fast_k == 1 ? BSK_SIM_SHORT_WORDS : pl.fast_k == 2 ? BSK_SIM_MID_WORDS : BSK_NT_FAST_WORDS);
+            break;
+        default: snprintf(b, sizeof b, "?"); break;
+    }
+    snprintf(res->plan, sizeof res->plan, "%s%s%s", b, pl.mixed ? " + ASCII side launch" : "", tiled ? " (over tiles)" : "");
+    res->plan_grid = pl.grid;
+    res->plan_per_cu = cus > 0 ? (pl.grid + cus - 1) / cus : 0;
+}
+
 // One launch of the planned kernel into res.  ev0/ev1 (optional) bracket the kernel itself.
 static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_result *res, int circ_ext, const Plan &pl,
                   hipEvent_t ev0, hipEvent_t ev1) {
@@ -1331,6 +1373,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         bsk_result *res = *result;
         res->main_cap = pl.mixed ? cap : 0;
         res->ovf_cap = pl.slab ? (pl.mixed ? cap : res->cap) - pl.slab_total : 0;
+        plan_name(pl, p, false, ctx->cus, res);
         rc = launch(ctx, b, p, res, circ_ext, pl, nullptr, nullptr);
         if (rc != BSK_OK) return cleanup(rc);
         if (pl.nunits == 0) {  // empty batch: nothing was launched, the scratch counters are stale
@@ -1385,6 +1428,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         for (hipEvent_t e : evs)
             if (e) (void)hipEventDestroy(e);
     };
+    if (*result) plan_name(pl, p, false, ctx->cus, *result);
     for (int it = 0; it < warmup + iters; ++it) {
         const bool timed = it >= warmup && kernel_ms;
         rc = launch(ctx, b, p, *result, circ_ext, pl, timed ? evs[2 * (it - warmup)] : nullptr,
@@ -1652,6 +1696,9 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, i
         return done(BSK_ERR_DEVICE);
     }
     fin->n_tuples = ctx->h_pinned[0];
+    snprintf(fin->plan, sizeof fin->plan, "%.70s (over tiles)", tres->plan);
+    fin->plan_grid = tres->plan_grid;
+    fin->plan_per_cu = tres->plan_per_cu;
 #undef TCHK
     *result = fin;
     lap("finish");

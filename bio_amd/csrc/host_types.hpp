@@ -30,6 +30,10 @@ struct bsk_ctx {
     void *tmp[12] = {};
     size_t tmp_cap[12] = {};
     struct bsk_result *tile_res = nullptr;  // tile-level result of the previous tiled call, reused
+    // the one collective of the path (comm.cpp): an RCCL communicator over the GPUs that share a job
+    void *comm = nullptr;  // ncclComm_t
+    int comm_rank = 0, comm_world = 0;
+    u64 *d_comm = nullptr;  // [(world + 1) * BSK_MAX_COUNTERS] device staging of bsk_gather_counts
     bool no_prot_fast = false;
     bool no_dense = false;      // same for the dense-minimizer kernel (per-read slabs)  // set while a call falls back from the per-sequence-slab protein kernel
 };
@@ -67,6 +71,8 @@ struct bsk_result {
     u8 *status = nullptr;
     u64 *hash = nullptr;
     u32 *pos = nullptr;
+    char plan[96] = "";   // what ran: kernel name of the last launch into this result (bsk_result_plan)
+    int plan_grid = 0, plan_per_cu = 0;
 };
 
 static inline int fail_hip(bsk_ctx *ctx, hipError_t e, const char *what) {

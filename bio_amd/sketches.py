@@ -133,6 +133,12 @@ class BatchResult:
         self.eng._chk(self.eng.lib.bsk_result_info(self.h, C.byref(n), C.byref(t), C.byref(hp)))
         return dict(n_reads=n.value, n_tuples=t.value, has_pos=bool(hp.value))
 
+    def plan(self):
+        """What ran: the kernel the planner launched for this result, its grid and wavefronts per CU (bsk_result_plan)."""
+        name, grid, per_cu = C.c_char_p(), C.c_int(), C.c_int()
+        self.eng._chk(self.eng.lib.bsk_result_plan(self.h, C.byref(name), C.byref(grid), C.byref(per_cu)))
+        return dict(kernel=(name.value or b"").decode(), grid=grid.value, waves_per_cu=per_cu.value)
+
     def fetch(self, first: int = 0, count: Optional[int] = None):
         """-> (offsets[count+1] rebased, status[count], hash[T], pos[T] or None)"""
         inf = self.info()
@@ -213,6 +219,25 @@ class Engine:
         if rc in _SENTINELS:
             raise _SENTINELS[rc]
         raise DeviceError(f"{self.lib.bsk_err_name(rc).decode()}: {self.lib.bsk_last_error(self.ctx).decode()}")
+
+    # -- multi-GPU: the one collective of the path (bsk_comm_* / bsk_gather_counts: RCCL behind the C ABI)
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * 128)()
+        self._chk(self.lib.bsk_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init_rank(self, uid: bytes, rank: int, world: int) -> None:
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._chk(self.lib.bsk_comm_init_rank(self.ctx, buf, rank, world))
+        self._world = world
+
+    def gather_counts(self, mine: Sequence[int]) -> List[List[int]]:
+        """all_gather of this rank's u64 counters; one list per rank, in rank order."""
+        world = getattr(self, "_world", 0)
+        a = np.asarray(list(mine), np.uint64)
+        out = np.zeros(max(world, 1) * len(a), np.uint64)
+        self._chk(self.lib.bsk_gather_counts(self.ctx, a.ctypes.data, len(a), out.ctypes.data))
+        return [[int(v) for v in row] for row in out.reshape(world, len(a))]
 
     # -- batches
     def batch(self, seqs: Sequence, alphabet: int = L.ALPHA_DNA) -> Batch:

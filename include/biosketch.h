@@ -208,6 +208,10 @@ int bsk_sketch_timed(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, 
                      int warmup, int iters, float *kernel_ms);
 
 int bsk_result_info(const bsk_result *r, uint64_t *n_reads, uint64_t *n_tuples, int *has_pos);
+/* What ran: the name of the kernel the planner launched for this result, as a profiler shows it
+ * ("k_minimizer_fast<11,32,true>", "k_syncmer<1>", "... (over tiles)"), its grid and the workgroups (= wavefronts) per CU
+ * that grid amounts to.  The string lives as long as the result.  Any out-pointer may be NULL. */
+int bsk_result_plan(const bsk_result *r, const char **kernel, int *grid, int *waves_per_cu);
 /* Copy reads [first, first+count) to the host.  offsets[count+1] are rebased to 0;
  * hash/pos may be NULL; tuple_cap = capacity (in tuples) of hash[]/pos[]. */
 int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t first, uint64_t count,
@@ -231,6 +235,26 @@ int bsk_result_device_wide(const bsk_result *r, const uint64_t **first, const ui
 int bsk_result_digest(bsk_ctx *ctx, const bsk_result *r, uint64_t *checksum, uint64_t *n_tuples,
                       uint64_t status_counts[4]);
 void bsk_result_release(bsk_result *r);
+
+/* ---- multi-GPU: the one collective of the path ----------------------------
+ * Reads shard by record; no tuple ever crosses GPUs.  What a job gathers at its end is a handful of u64 counters per GPU
+ * (reads, bases, tuples, flagged reads ...): one all_gather over RCCL (xGMI inside a node), 8 * n_counters bytes per rank.
+ * librccl is opened on first use; a single-GPU caller never loads it.
+ *   one process (or thread) per GPU:  rank 0 calls bsk_comm_unique_id and hands the 128 bytes to the other ranks by whatever
+ *     channel the host has (the job launcher's store, a Go channel); every rank then calls bsk_comm_init_rank on its own
+ *     context and bsk_gather_counts after its work;
+ *   one thread driving several contexts (a Go host with one goroutine per GPU that joins before reporting):
+ *     bsk_comm_init_all once, bsk_gather_counts_all after the work -- mine[n][n_counters] in rank order, all[n][n_counters]
+ *     as every rank received it (checked to be identical).
+ * all[] is world * n_counters values in rank order.  The calls block until the data is on the host. */
+#define BSK_UNIQUE_ID_BYTES 128
+#define BSK_MAX_COUNTERS 16
+int bsk_comm_unique_id(uint8_t *id /* [BSK_UNIQUE_ID_BYTES] */);
+int bsk_comm_init_rank(bsk_ctx *ctx, const uint8_t *id, int rank, int world);
+int bsk_comm_init_all(bsk_ctx *const *ctxs, int n);
+int bsk_gather_counts(bsk_ctx *ctx, const uint64_t *mine, int n_counters, uint64_t *all);
+int bsk_gather_counts_all(bsk_ctx *const *ctxs, int n, const uint64_t *mine, int n_counters, uint64_t *all);
+void bsk_comm_destroy(bsk_ctx *ctx);
 
 /* ---- sketch sets ----------------------------------------------------
  * The distinct hash values of a result in ascending order -- what the reference's consumers (kmcp, unikmer) build from

@@ -296,6 +296,8 @@ long long orc_simhash_all(const uint8_t *seq, size_t len, int k, int m, int scal
 struct orc_sketch {
     uint8_t *S;
     size_t len;
+    int borrowed; /* S points into the caller's buffer */
+    int bufcap;   /* entries allocated for buf */
     int k, s, w, r, kMs;
     int minimizer, skip;
     orc_nthi hasher, hasherS;
@@ -382,32 +384,60 @@ static void buf_insert(orc_sketch *s, long long idx, uint64_t code) {
     }
 }
 
-static orc_sketch *sketch_alloc(const uint8_t *seq, size_t len, int k, int circular, int bufcap) {
-    orc_sketch *s = (orc_sketch *)calloc(1, sizeof *s);
-    if (!s) return NULL;
-    s->S = dup_seq(seq, len, k, circular, &s->len);
-    s->buf = (orc_idxval *)calloc((size_t)bufcap + 2, sizeof(orc_idxval));
-    s->precap = 8;
-    s->pre = (long long *)calloc((size_t)s->precap, sizeof(long long));
+/* reuse != NULL: a sketch that has finished, taken back "from the pool" (poolSketch, sketch.go:79: the Go objects are
+ * recycled, their buffers with them); borrow: keep a pointer to the caller's bytes as the reference does (`S.Seq`, copied
+ * only when circular, sketch.go:106-110) instead of the private copy the test-facing constructors make. */
+static orc_sketch *sketch_alloc(orc_sketch *reuse, int borrow, const uint8_t *seq, size_t len, int k, int circular, int bufcap) {
+    orc_sketch *s = reuse;
+    if (s) {
+        orc_idxval *buf = s->buf;
+        long long *pre = s->pre;
+        const int bc = s->bufcap, pc = s->precap;
+        if (!s->borrowed) free(s->S);
+        memset(s, 0, sizeof *s);
+        s->buf = buf;
+        s->bufcap = bc;
+        s->pre = pre;
+        s->precap = pc;
+    } else {
+        s = (orc_sketch *)calloc(1, sizeof *s);
+        if (!s) return NULL;
+    }
+    if (borrow && !circular) {
+        s->S = (uint8_t *)(uintptr_t)seq;
+        s->len = len;
+        s->borrowed = 1;
+    } else {
+        s->S = dup_seq(seq, len, k, circular, &s->len);
+    }
+    if (s->bufcap < bufcap + 2) {
+        free(s->buf);
+        s->buf = (orc_idxval *)calloc((size_t)bufcap + 2, sizeof(orc_idxval));
+        s->bufcap = bufcap + 2;
+    }
+    if (!s->pre) {
+        s->precap = 8;
+        s->pre = (long long *)calloc((size_t)s->precap, sizeof(long long));
+    }
     if (!s->S || !s->buf || !s->pre) { orc_sketch_free(s); return NULL; }
     return s;
 }
 
 void orc_sketch_free(orc_sketch *s) {
     if (!s) return;
-    free(s->S);
+    if (!s->borrowed) free(s->S);
     free(s->buf);
     free(s->pre);
     free(s);
 }
 
 /* NewMinimizerSketch sketch.go:85-138 */
-int orc_minimizer_new(const uint8_t *seq, size_t len, int k, int w, int circular, orc_sketch **out) {
+static int minimizer_init(orc_sketch *reuse, int borrow, const uint8_t *seq, size_t len, int k, int w, int circular, orc_sketch **out) {
     *out = NULL;
     if (k < 1) return ORC_ERR_INVALID_K;                                  /* :86 */
     if (w < 1) return ORC_ERR_INVALID_W;                                  /* :89 (w <= 2^31-1 by type) */
     if (len < (size_t)k + (size_t)w - 1) return ORC_ERR_SHORT_SEQ;        /* :92 */
-    orc_sketch *s = sketch_alloc(seq, len, k, circular, w);
+    orc_sketch *s = sketch_alloc(reuse, borrow, seq, len, k, circular, w);
     if (!s) return ORC_ERR_NOMEM;
     s->minimizer = 1;
     s->k = k;
@@ -418,18 +448,21 @@ int orc_minimizer_new(const uint8_t *seq, size_t len, int k, int w, int circular
     s->r = w - 1;                   /* :115 */
     orc_nthi_init(&s->hasher, s->S, s->len, (unsigned)k);
     s->preMinIdx = -1;
-    scan_non_acgt(s->S, s->len, &s->flags);
+    if (!borrow) scan_non_acgt(s->S, s->len, &s->flags); /* oracle-only flag; the reference makes no such pass */
     *out = s;
     return ORC_OK;
 }
+int orc_minimizer_new(const uint8_t *seq, size_t len, int k, int w, int circular, orc_sketch **out) {
+    return minimizer_init(NULL, 0, seq, len, k, w, circular, out);
+}
 
 /* NewSyncmerSketch sketch.go:142-202 */
-int orc_syncmer_new(const uint8_t *seq, size_t len, int k, int sm, int circular, orc_sketch **out) {
+static int syncmer_init(orc_sketch *reuse, int borrow, const uint8_t *seq, size_t len, int k, int sm, int circular, orc_sketch **out) {
     *out = NULL;
     if (k < 1) return ORC_ERR_INVALID_K;                      /* :143 */
     if (sm > k || sm <= 0) return ORC_ERR_INVALID_S;          /* :146 (s==0; negative s would panic upstream) */
     if ((long long)len < 2LL * k - sm - 1) return ORC_ERR_SHORT_SEQ; /* :149 */
-    orc_sketch *s = sketch_alloc(seq, len, k, circular, (k - sm) * 2);
+    orc_sketch *s = sketch_alloc(reuse, borrow, seq, len, k, circular, (k - sm) * 2);
     if (!s) return ORC_ERR_NOMEM;
     s->minimizer = 0;
     s->k = k;
@@ -442,13 +475,16 @@ int orc_syncmer_new(const uint8_t *seq, size_t len, int k, int sm, int circular,
     s->w = k - sm;
     if (orc_nthi_init(&s->hasher, s->S, s->len, (unsigned)k) != ORC_OK ||
         orc_nthi_init(&s->hasherS, s->S, s->len, (unsigned)sm) != ORC_OK) {
-        orc_sketch_free(s);
+        if (!reuse) orc_sketch_free(s); /* a recycled object stays with its owner */
         return ORC_ERR_SHORT_SEQ;
     }
     s->preMinIdx = -1;
-    scan_non_acgt(s->S, s->len, &s->flags);
+    if (!borrow) scan_non_acgt(s->S, s->len, &s->flags);
     *out = s;
     return ORC_OK;
+}
+int orc_syncmer_new(const uint8_t *seq, size_t len, int k, int sm, int circular, orc_sketch **out) {
+    return syncmer_init(NULL, 0, seq, len, k, sm, circular, out);
 }
 
 /* NextMinimizer sketch.go:205-309 */
@@ -1148,7 +1184,14 @@ int orc_batch_run(int kind, const uint8_t *seqs, const uint64_t *offsets, uint32
     uint64_t tot = 0, sum = 0;
     int err = 0;
 #ifdef _OPENMP
-#pragma omp parallel for num_threads(threads) reduction(+ : tot, sum) schedule(static)
+#pragma omp parallel num_threads(threads) reduction(+ : tot, sum)
+#endif
+  {
+    /* one recycled sketch object per thread: what sync.Pool amounts to for a worker goroutine that finishes one iterator
+     * before it asks for the next (sketch.go:79,214,321); the reads are borrowed, not copied (sketch.go:106-110) */
+    orc_sketch *pooled = NULL;
+#ifdef _OPENMP
+#pragma omp for schedule(static)
 #endif
     for (long long r = 0; r < (long long)n; r++) {
         const uint8_t *s = seqs + offsets[r];
@@ -1166,14 +1209,15 @@ int orc_batch_run(int kind, const uint8_t *seqs, const uint64_t *offsets, uint32
             }
         } else if (kind == 4 || kind == 5) {
             orc_sketch *sk;
-            int rc = (kind == 4) ? orc_minimizer_new(s, len, k, w_or_s, 0, &sk)
-                                 : orc_syncmer_new(s, len, k, w_or_s, 0, &sk);
+            int rc = (kind == 4) ? minimizer_init(pooled, 1, s, len, k, w_or_s, 0, &sk)
+                                 : syncmer_init(pooled, 1, s, len, k, w_or_s, 0, &sk);
+            if (rc == ORC_ERR_NOMEM) pooled = NULL; /* sketch_alloc released it */
             if (rc != ORC_OK) continue;
             while (orc_sketch_next(sk, &code)) {
                 sum += code * (2 * (uint64_t)orc_sketch_index(sk) + 1);
                 tot++;
             }
-            orc_sketch_free(sk);
+            pooled = sk; /* back to the pool */
         } else if (kind == 7) {
             enum { CAP = 4096 };
             uint64_t hb[CAP];
@@ -1193,6 +1237,8 @@ int orc_batch_run(int kind, const uint8_t *seqs, const uint64_t *offsets, uint32
             err = 1;
         }
     }
+    orc_sketch_free(pooled);
+  }
     (void)threads;
     if (n_tuples) *n_tuples = tot;
     if (checksum) *checksum = sum;

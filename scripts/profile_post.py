@@ -9,13 +9,19 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import bench  # noqa: E402  (WORKLOADS / KERNELS tables)
+import bench  # noqa: E402  (WORKLOADS table)
+
+# the sketch kernel family each workload's plan lands on (only used to pick that kernel's rows out of the CSVs; the full
+# instantiated name is read from the rows themselves)
+FAMILY = {"min": "k_minimizer_", "nt": "k_nthash_fast", "syn": "k_syncmer_fast", "pmin": "k_prot_minimizer_fast", "kmer": "k_nthash_fast",
+          "phash": "k_prot_hash_fast", "sim": "k_simhash_fast"}
 
 out_dir, workloads = sys.argv[1], sys.argv[2].split()
 entries = []
 for w in workloads:
     kind, n_reads = bench.WORKLOADS[w][0], bench.WORKLOADS[w][1]
-    kname = bench.KERNELS[kind].split("<")[0]
+    kname = FAMILY[kind]
+    full = {"name": None}
 
     def mean_counter(path, counter):
         vals = []
@@ -24,6 +30,7 @@ for w in workloads:
         for row in csv.DictReader(open(path)):
             if kname in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
                 vals.append(float(row["Counter_Value"]))
+                full["name"] = row["Kernel_Name"].replace("void bsk::", "").replace("(bsk::KArgs)", "").replace(", ", ",")
         return sum(vals) / len(vals) if vals else None
 
     f = mean_counter(os.path.join(out_dir, f"bench_{w}_pmc_fetch.csv"), "FETCH_SIZE")
@@ -37,7 +44,13 @@ for w in workloads:
     if f is None or wr is None:
         print("no counters for", w)
         continue
-    entries.append({"workload": w, "reads_per_gpu": n_reads, "kernel": bench.KERNELS[kind], "FETCH_SIZE_KiB_mean": round(f), "WRITE_SIZE_KiB_mean": round(wr),
+    # VALU utilisation: wave-instructions issued to the VALU (one quad-cycle each) over the SIMD-cycles of the dispatch
+    # (256 CUs x 4 SIMDs x the shader clock cycles GRBM_GUI_ACTIVE counts per XCD; 8 XCDs are summed in the CSV)
+    sqp = os.path.join(out_dir, f"bench_{w}_pmc_sq.csv")
+    va, gui = mean_counter(sqp, "SQ_ACTIVE_INST_VALU"), mean_counter(sqp, "GRBM_GUI_ACTIVE")
+    valu_util = round(va * 4 / (gui / 8 * 1024), 4) if va and gui else None
+    entries.append({"workload": w, "reads_per_gpu": n_reads, "kernel": full["name"], "valu_util": valu_util,
+                    "SQ_ACTIVE_INST_VALU": va, "GRBM_GUI_ACTIVE_sum_over_xcds": gui, "FETCH_SIZE_KiB_mean": round(f), "WRITE_SIZE_KiB_mean": round(wr),
                     "fetch_bytes_corrected": int(f * 1024 * 2), "write_bytes": int(wr * 1024), "hbm_bytes_per_launch": int(f * 2048 + wr * 1024),
                     "rocprof_kernel_ms_avg": kms})
 json.dump({"note": "HBM traffic of one launch of the bench kernel: rocprofv3 --pmc passes on `python bench.py --workload W --steps 3 --warmup 1` "

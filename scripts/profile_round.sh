@@ -15,6 +15,8 @@ for w in $WORKLOADS; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$w/stats -- $CMD > /tmp/prof_$w.log 2>&1
   timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_$w/fetch -- $CMD >> /tmp/prof_$w.log 2>&1
   timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_$w/write -- $CMD >> /tmp/prof_$w.log 2>&1
+  timeout 600 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof_$w/sq -- $CMD >> /tmp/prof_$w.log 2>&1
+  cp $(find /tmp/prof_$w/sq -name '*counter_collection.csv' | head -1) "$OUT/bench_${w}_pmc_sq.csv" 2>/dev/null
   cp $(find /tmp/prof_$w/stats -name '*kernel_stats.csv' | head -1) "$OUT/bench_${w}_kernel_stats.csv" 2>/dev/null
   cp $(find /tmp/prof_$w/fetch -name '*counter_collection.csv' | head -1) "$OUT/bench_${w}_pmc_fetch.csv" 2>/dev/null
   cp $(find /tmp/prof_$w/write -name '*counter_collection.csv' | head -1) "$OUT/bench_${w}_pmc_write.csv" 2>/dev/null
@@ -23,6 +25,6 @@ done
 cd "$REPO"
 python scripts/profile_post.py "$OUT" "$WORKLOADS" && mkdir -p profiles/$ROUND && cp "$OUT/traffic.json" profiles/$ROUND/traffic.json
 for w in $WORKLOADS; do
-  python bench.py --workload $w --steps 5 --warmup 2 > "$OUT/BENCH_${w}_n1.json" 2> "$OUT/BENCH_${w}_n1.err" || true
+  python bench.py --workload $w --steps 20 --warmup 3 > "$OUT/BENCH_${w}_n1.json" 2> "$OUT/BENCH_${w}_n1.err" || true
 done
 ls -la "$OUT"

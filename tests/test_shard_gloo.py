@@ -50,3 +50,33 @@ def test_two_rank_gather_over_gloo(tmp_path):
     assert d["rows"] == [[1.0, 501 * 150.0, 501 * 22.0], [2.0, 500 * 150.0, 500 * 22.0]]
     assert d["job"]["seconds"] == 2.0 and d["job"]["bases"] == 1001 * 150.0 and d["job"]["tuples"] == 1001 * 22.0
     assert abs(d["job"]["gbases_per_s"] - 1001 * 150.0 * 2 / 2.0 / 1e9) < 1e-12
+
+
+def test_bench_world2_control_flow_over_gloo():
+    """bench.py's WORLD_SIZE > 1 branch -- rendezvous on 127.0.0.1, barriers, the counter gather, MAX-seconds / SUM-units
+    arithmetic and the one JSON line of rank 0 -- driven on CPUs (`--backend gloo --plumbing-only`: stand-in counters, no
+    kernel).  The GPU run differs only in the collective going through bsk_gather_counts (tests/test_gpu_comm.py)."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--backend", "gloo", "--plumbing-only"]
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]  # only rank 0 prints the line
+    lines = [ln for ln in outs[0][0].strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    sys.path.insert(0, ROOT)
+    import bench
+    c0, c1 = bench.plumbing_counters(0), bench.plumbing_counters(1)
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert "plumbing-only" in d["data"] and "roofline" not in d and "cpu_baseline" not in d
+    assert d["config"]["per_rank_seconds"] == [c0[0] / 1e9, c1[0] / 1e9]
+    secs = max(c0[0], c1[0]) / 1e9  # MAX over ranks
+    assert abs(d["ms_per_step"] - secs / 4 * 1e3) < 1e-6
+    assert abs(d["value"] - round((c0[1] + c1[1]) * 4 / secs / 1e9, 2)) < 1e-9  # SUM of bases over ranks
+    assert d["config"]["tuples_total"] == c0[2] + c1[2] and d["config"]["first_window_tie_reads"] == c0[3] + c1[3]
