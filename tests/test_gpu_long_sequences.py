@@ -212,7 +212,7 @@ def test_sequence_longer_than_2_pow_24(engine, oracle):
     st, h, _ = rn.read(1)
     assert len(h) == n - 30 and np.array_equal(h, oracle.nthash(q, 31, True)[0])
     from bio_amd import sketches as S
-    with pytest.raises(S.DeviceError, match="2\\^24"):
+    with pytest.raises(S.DeviceError, match="2\\^2[34]"):  # refused by the 2^23-k-mer rule of the two-strand mode before the 2^24-base one
         engine.run(b, engine.params(L.KMER, 21, canonical=False))
     with pytest.raises(S.DeviceError):
         engine.run(b, engine.params(L.NTHASH, 21, circular=True))
