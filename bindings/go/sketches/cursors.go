@@ -35,8 +35,8 @@ func (it *Iterator) next() (uint64, bool) {
 	it.i++
 	return c, true
 }
-func (it *Iterator) NextHash() (uint64, bool)    { return it.next() } // iterator.go:658
-func (it *Iterator) NextSimHash() (uint64, bool) { return it.next() } // iterator.go:191
+func (it *Iterator) NextHash() (code uint64, ok bool) { return it.next() } // iterator.go:658
+func (it *Iterator) NextSimHash() (code uint64, ok bool) { return it.next() } // iterator.go:191
 func (it *Iterator) NextKmer() (uint64, bool, error) { // iterator.go:708
 	c, ok := it.next()
 	if !ok && it.illegal {
@@ -85,12 +85,72 @@ func (s *Sketch) Index() int                    { return s.idx }    // sketch.go
 // Strand is an extension: true iff the reverse-strand hash was the canonical one.
 func (s *Sketch) Strand() bool { return s.rev }
 
-// ProteinIterator / ProteinMinimizerSketch (iterator-protein.go:33, sketch-protein.go:31)
-type ProteinIterator struct{ Iterator }
+// IdxValues: the tuples of record i as the reference's exported pair type (sketch.go:496).
+func (r *Result) IdxValues(i int) ([]IdxValue, error) {
+	codes, pos, _, err := r.slice(i)
+	if err != nil {
+		return nil, err
+	}
+	out := make([]IdxValue, len(codes))
+	for j, c := range codes {
+		p := j
+		if pos != nil {
+			p = int(pos[j] & 0x7fffffff)
+		}
+		out[j] = IdxValue{Idx: p, Val: c}
+	}
+	return out, nil
+}
 
-func (p *ProteinIterator) Next() (uint64, bool) { return p.next() } // iterator-protein.go:76
+// ProteinIterator replaces sketches.ProteinIterator (iterator-protein.go:35): Next / Index only, as upstream.
+type ProteinIterator struct {
+	codes  []uint64
+	i, idx int
+}
 
-type ProteinMinimizerSketch struct{ Sketch }
+func (r *Result) ProteinIterator(i int) (*ProteinIterator, error) {
+	codes, _, _, err := r.slice(i)
+	if err != nil {
+		return nil, err
+	}
+	return &ProteinIterator{codes: codes, idx: -1}, nil
+}
+func (iter *ProteinIterator) Next() (code uint64, ok bool) { // iterator-protein.go:76
+	if iter.i >= len(iter.codes) {
+		return 0, false
+	}
+	code = iter.codes[iter.i]
+	iter.idx = iter.i
+	iter.i++
+	return code, true
+}
+func (iter *ProteinIterator) Index() int { return iter.idx } // iterator-protein.go:93
+
+// ProteinMinimizerSketch replaces sketches.ProteinMinimizerSketch (sketch-protein.go:32).
+type ProteinMinimizerSketch struct {
+	codes []uint64
+	pos   []uint32
+	i     int
+	idx   int
+}
+
+func (r *Result) ProteinMinimizerSketch(i int) (*ProteinMinimizerSketch, error) {
+	codes, pos, _, err := r.slice(i)
+	if err != nil {
+		return nil, err
+	}
+	return &ProteinMinimizerSketch{codes: codes, pos: pos, idx: -1}, nil
+}
+func (s *ProteinMinimizerSketch) Next() (code uint64, ok bool) { // sketch-protein.go:106
+	if s.i >= len(s.codes) {
+		return 0, false
+	}
+	code = s.codes[s.i]
+	s.idx = int(s.pos[s.i] & 0x7fffffff)
+	s.i++
+	return code, true
+}
+func (s *ProteinMinimizerSketch) Index() int { return s.idx } // sketch-protein.go:213
 
 // ---- the reference's single-sequence constructors: a batch of one on the default engine ----
 var defaultEngine *Engine
@@ -176,4 +236,31 @@ func NewSyncmerSketch(S *seq.Seq, k int, s int, circular bool) (*Sketch, error) 
 		return nil, err
 	}
 	return r.Sketch(0)
+}
+
+func NewProteinIterator(s *seq.Seq, k int, codonTable int, frame int) (*ProteinIterator, error) { // iterator-protein.go:46
+	b, err := one(s)
+	if err != nil {
+		return nil, err
+	}
+	r, err := b.ProteinIterators(k, codonTable, frame)
+	if err != nil {
+		return nil, err
+	}
+	return r.ProteinIterator(0)
+}
+
+func NewProteinMinimizerSketch(S *seq.Seq, k int, codonTable int, frame int, w int) (*ProteinMinimizerSketch, error) { // sketch-protein.go:62
+	if k >= 1 && len(S.Seq) < k*3 { // upstream's order: k, then this length check (:66), only then w (:69)
+		return nil, ErrShortSeq
+	}
+	b, err := one(S)
+	if err != nil {
+		return nil, err
+	}
+	r, err := b.ProteinMinimizerSketches(k, codonTable, frame, w)
+	if err != nil {
+		return nil, err
+	}
+	return r.ProteinMinimizerSketch(0)
 }

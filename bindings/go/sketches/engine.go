@@ -119,7 +119,9 @@ type Result struct {
 
 func (b *Batch) run(p C.bsk_params) (*Result, error) {
 	var r *C.bsk_result
-	if err := b.eng.err(C.bsk_sketch(b.eng.ctx, b.h, &p, &r)); err != nil {
+	rc0 := C.bsk_sketch(b.eng.ctx, b.h, &p, &r)
+	runtime.KeepAlive(b)
+	if err := b.eng.err(rc0); err != nil {
 		return nil, err
 	}
 	defer C.bsk_result_release(r)
@@ -218,10 +220,13 @@ func (b *Batch) ProteinMinimizerSketches(k, codonTable, frame, w int) (*Result, 
 // Translate is (*seq.Seq).Translate(codonTable, frame, false, false, true, false) (seq/seq.go:685) for every sequence of a
 // DNA/RNA batch, on the device; the protein constructors above do this themselves when the batch is not protein.
 func (b *Batch) Translate(codonTable, frame int) (*Batch, error) {
-	t := &Batch{eng: b.eng}
-	if err := b.eng.err(C.bsk_batch_translate(b.eng.ctx, b.h, C.int(codonTable), C.int(frame), &t.h)); err != nil {
+	t := &Batch{eng: b.eng, n: b.n, protein: true}
+	rc := C.bsk_batch_translate(b.eng.ctx, b.h, C.int(codonTable), C.int(frame), &t.h)
+	runtime.KeepAlive(b) // the source batch must outlive the call (its finalizer frees device memory)
+	if err := b.eng.err(rc); err != nil {
 		return nil, err
 	}
+	runtime.SetFinalizer(t, func(t *Batch) { C.bsk_batch_destroy(t.h) })
 	return t, nil
 }
 
@@ -236,4 +241,41 @@ func (r *Result) slice(i int) (codes []uint64, pos []uint32, status uint8, err e
 		pos = r.pos[a:e]
 	}
 	return
+}
+
+// ---- multi-GPU: one Engine per GPU, reads sharded by record, ONE collective at the end (DESIGN.md 5) ----
+
+// JoinEngines forms the RCCL communicator of the engines of one process (bsk_comm_init_all): rank i = engines[i].
+func JoinEngines(engines []*Engine) error {
+	ctxs := make([]*C.bsk_ctx, len(engines))
+	for i, e := range engines {
+		ctxs[i] = e.ctx
+	}
+	rc := C.bsk_comm_init_all((**C.bsk_ctx)(unsafe.Pointer(&ctxs[0])), C.int(len(engines)))
+	runtime.KeepAlive(engines)
+	return engines[0].err(rc)
+}
+
+// GatherCounts all_gathers every engine's counters (reads, bases, tuples, flagged reads ...) over RCCL / xGMI
+// (bsk_gather_counts_all) and returns them in rank order.  Call it once the worker goroutines have joined.
+func GatherCounts(engines []*Engine, mine [][]uint64) ([][]uint64, error) {
+	n, nc := len(engines), len(mine[0])
+	ctxs := make([]*C.bsk_ctx, n)
+	flat := make([]uint64, n*nc)
+	for i, e := range engines {
+		ctxs[i] = e.ctx
+		copy(flat[i*nc:], mine[i])
+	}
+	all := make([]uint64, n*nc)
+	rc := C.bsk_gather_counts_all((**C.bsk_ctx)(unsafe.Pointer(&ctxs[0])), C.int(n), (*C.uint64_t)(unsafe.Pointer(&flat[0])), C.int(nc),
+		(*C.uint64_t)(unsafe.Pointer(&all[0])))
+	runtime.KeepAlive(engines)
+	if err := engines[0].err(rc); err != nil {
+		return nil, err
+	}
+	out := make([][]uint64, n)
+	for i := range out {
+		out[i] = all[i*nc : (i+1)*nc]
+	}
+	return out, nil
 }

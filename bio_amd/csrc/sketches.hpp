@@ -216,6 +216,10 @@ inline std::unique_ptr<ProteinIterator> NewProteinIterator(const Seq &s, int k, 
 }
 inline std::unique_ptr<ProteinMinimizerSketch> NewProteinMinimizerSketch(const Seq &S, int k, int codonTable, int frame, int w, int *err,
                                                                          Engine *e = nullptr) {
+    if (k >= 1 && S.Seq_.size() < (size_t)k * 3) {  // upstream's order: k, then this length check (sketch-protein.go:66), only then w (:69)
+        if (err) *err = BSK_ERR_SHORT_SEQ;
+        return nullptr;
+    }
     auto p = detail::params(BSK_PROT_MINIMIZER, k);
     p.w = w;
     p.codon_table = codonTable;

@@ -467,6 +467,8 @@ def NewProteinIterator(s: Seq, k: int, codonTable: int, frame: int, engine: Opti
 
 def NewProteinMinimizerSketch(S: Seq, k: int, codonTable: int, frame: int, w: int, engine: Optional[Engine] = None):
     alpha = L.ALPHA_PROTEIN if S.Alphabet is Protein else L.ALPHA_DNA
+    if k >= 1 and len(S.Seq) < k * 3:  # upstream's order: k, then this length check (sketch-protein.go:66), only then w (:69)
+        return None, ErrShortSeq
     got, _, err = _single(S, Engine.params(L.PROT_MINIMIZER, k, w=w, codon_table=codonTable, frame=frame), alpha, engine)
     if err is not None:
         return None, err

@@ -154,6 +154,70 @@ int main() {
         bsk_ctx_destroy(ctx);
         std::remove(path);
     }
+    {  // the exact C-ABI call sequences of the Go shim (bindings/go/sketches/engine.go), one block per shim function
+        bsk_ctx *ctx = nullptr;
+        CHECK(bsk_ctx_create(0, &ctx) == BSK_OK);  // NewEngine
+        const std::string dna = "AAGTTTGAATCATTCAACTATCTAGTTTTCAGAGAACAATGTTCTCTAAAGAATAGAAAAGAGTCATTGTGCGGTGATGATGGCGGGAAGGATCCACCTG";
+        const std::string shortr = "ACGTACGTAC";
+        // Engine.NewBatchFromSeqs: one malloc'd byte buffer + offsets[n+1], bsk_batch_from_ascii, buffers freed after the call
+        std::string bytes = dna + shortr + dna;
+        std::vector<uint64_t> offs = {0, dna.size(), dna.size() + shortr.size(), 2 * dna.size() + shortr.size()};
+        bsk_batch *b = nullptr;
+        CHECK(bsk_batch_from_ascii(ctx, (const uint8_t *)bytes.data(), offs.data(), 3, BSK_ALPHA_DNA, &b) == BSK_OK);
+        bytes.assign(bytes.size(), 'x');  // the shim frees its C buffer right after: the library must not look at it again
+        // Batch.run (every *Iterators / *Sketches method): bsk_sketch, bsk_result_info, bsk_result_fetch(cap = n_tuples + 1), release
+        auto run = [&](bsk_batch *bb, bsk_params p, std::vector<uint64_t> &o, std::vector<uint8_t> &st, std::vector<uint64_t> &h,
+                       std::vector<uint32_t> &pos) {
+            bsk_result *r = nullptr;
+            if (bsk_sketch(ctx, bb, &p, &r) != BSK_OK) return false;
+            uint64_t nr = 0, nt = 0;
+            int hp = 0;
+            bsk_result_info(r, &nr, &nt, &hp);
+            o.assign(nr + 1, 0);
+            st.assign(nr + 1, 0);
+            h.assign(nt + 1, 0);
+            pos.assign(hp ? nt + 1 : 0, 0);
+            const int rc = bsk_result_fetch(ctx, r, 0, nr, o.data(), st.data(), h.data(), hp ? pos.data() : nullptr, nt + 1);
+            bsk_result_release(r);
+            return rc == BSK_OK && o[nr] == nt;
+        };
+        std::vector<uint64_t> o, h, o2, h2;
+        std::vector<uint8_t> st, st2;
+        std::vector<uint32_t> pos, pos2;
+        bsk_params pm{};
+        pm.kind = BSK_MINIMIZER;
+        pm.k = 21;
+        pm.w = 11;
+        pm.canonical = 1;
+        CHECK(run(b, pm, o, st, h, pos));  // Batch.MinimizerSketches
+        CHECK((st[1] & BSK_ST_CODE_MASK) == BSK_ST_SHORT && o[1] == o[2]);  // Result.slice -> ErrShortSeq for record 1
+        CHECK(o[1] - o[0] == o[3] - o[2] && o[1] > 0 && pos.size() == h.size());
+        // Batch.ProteinMinimizerSketches on a DNA batch == Batch.Translate + the same call on the translated batch
+        bsk_params pp{};
+        pp.kind = BSK_PROT_MINIMIZER;
+        pp.k = 9;
+        pp.w = 3;
+        pp.codon_table = 1;
+        pp.frame = 1;
+        CHECK(run(b, pp, o, st, h, pos));
+        bsk_batch *t = nullptr;
+        CHECK(bsk_batch_translate(ctx, b, 1, 1, &t) == BSK_OK);  // Batch.Translate (the result is a protein batch with a finalizer)
+        uint64_t tn = 0, tb = 0;
+        CHECK(bsk_batch_info(t, &tn, &tb, nullptr, nullptr) == BSK_OK && tn == 3 && tb == 2 * (dna.size() / 3) + shortr.size() / 3);
+        CHECK(run(t, pp, o2, st2, h2, pos2));
+        CHECK(h == h2 && pos == pos2 && o[1] == o2[1] && o[3] == o2[3]);
+        pp.kind = BSK_PROT_HASH;  // Batch.ProteinIterators
+        CHECK(run(b, pp, o, st, h, pos) && pos.empty() && o[1] == dna.size() / 3 - 9 + 1);
+        // JoinEngines / GatherCounts: bsk_comm_init_all over the engines' contexts, bsk_gather_counts_all after the work
+        bsk_ctx *ctxs[1] = {ctx};
+        const uint64_t mine[5] = {3, dna.size() * 2 + shortr.size(), o[3], 0, 0};
+        uint64_t all[5] = {0};
+        CHECK(bsk_comm_init_all(ctxs, 1) == BSK_OK);
+        CHECK(bsk_gather_counts_all(ctxs, 1, mine, 5, all) == BSK_OK && all[0] == 3 && all[2] == o[3]);
+        bsk_batch_destroy(t);
+        bsk_batch_destroy(b);
+        bsk_ctx_destroy(ctx);  // also drops the communicator
+    }
     std::printf(fails ? "FAILED %d checks\n" : "all C++ mirror checks passed\n", fails);
     return fails ? 1 : 0;
 }
