@@ -120,6 +120,62 @@ def cpu_baseline(kind: str, k: int, x: int, read_len: int, batch):
     return out
 
 
+def end_to_end(kind: str, p, batch, read_len: int, n_streams: int = 3):
+    """Host bytes -> tuples on the host (bsk_pipeline_*; SURVEY 8d "reported separately, not the metric"): the same reads,
+    decoded back to ASCII, go (a) from host memory and (b) from a plain / a gzip FASTQ (FASTA for protein) file through
+    pinned chunks, H2D + pack, the kernel and the D2H of every tuple, with n_streams streams overlapping those stages.
+    Bounded samples (a few seconds in all).  NEVER `value`."""
+    import gzip
+    import tempfile
+
+    import numpy as np
+    from bio_amd import sketches as S
+    n_have = batch.info()["n_reads"]
+    scale = 150.0 / read_len
+    n_mem = min(n_have, int(8_000_000 * scale))
+    data, offs = batch.fetch_ascii(0, n_mem)
+    alpha = 1 if kind in PROTEIN else 0
+    out = {"n_streams": n_streams, "chunk_records": 1 << 20,
+           "what": "host ASCII -> pinned chunks -> H2D + 2-bit pack -> kernel -> every tuple back in pinned host memory; stages of different chunks overlap"}
+    st = S.Engine.pipeline_memory(data, offs, p, n_streams=n_streams, chunk_records=1 << 20, repeat=1, fetch=True, alphabet=alpha)
+    out["from_memory"] = {"value": round(st["bases"] / st["seconds"] / 1e9, 3), "unit": "Gresidues/s" if alpha else "Gbases/s",
+                          "reads": st["records"], "seconds": round(st["seconds"], 4),
+                          "stage_seconds_summed_over_streams": {k: round(st[k], 4) for k in ("reader_seconds", "reader_wait_seconds", "h2d_pack_seconds", "kernel_seconds", "fetch_seconds")},
+                          "bound": "PCIe: %.0f B/read in + %.0f B/read of tuples out" % (read_len + 8, (12.0 if kind not in STREAM else 8.0) * st["tuples"] / max(st["records"], 1) + 9)}
+    # the same reads as files: fixed-width names, constant qualities (SURVEY 8d)
+    n_file = min(n_mem, int(2_000_000 * scale))
+    rec = 12 + read_len + (3 + read_len if not alpha else 0)
+    arr = np.empty((n_file, rec), np.uint8)
+    names = np.char.zfill(np.arange(n_file).astype("U9"), 9)
+    arr[:, 0] = ord(">") if alpha else ord("@")
+    arr[:, 1] = ord("r")
+    arr[:, 2:11] = np.frombuffer("".join(names.tolist()).encode(), np.uint8).reshape(n_file, 9)
+    arr[:, 11] = 10
+    arr[:, 12:12 + read_len] = data[: n_file * read_len].reshape(n_file, read_len)
+    if not alpha:
+        arr[:, 12 + read_len] = 10
+        arr[:, 13 + read_len] = ord("+")
+        arr[:, 14 + read_len] = 10
+        arr[:, 15 + read_len:15 + 2 * read_len] = ord("I")
+        arr = np.concatenate([arr, np.full((n_file, 1), 10, np.uint8)], axis=1)
+    else:
+        arr = np.concatenate([arr, np.full((n_file, 1), 10, np.uint8)], axis=1)
+    with tempfile.TemporaryDirectory() as td:
+        plain = os.path.join(td, "reads.fx")
+        arr.tofile(plain)
+        n_gz = min(n_file, int(500_000 * scale))
+        gzp = os.path.join(td, "reads.fx.gz")
+        with open(gzp, "wb") as f:
+            f.write(gzip.compress(arr[:n_gz].tobytes(), 1))
+        for tag, path in (("from_plain_file", plain), ("from_gzip_file", gzp)):
+            st = S.Engine.pipeline_fastx(path, p, n_streams=n_streams, chunk_records=1 << 20, fetch=True, alphabet=alpha)
+            out[tag] = {"value": round(st["bases"] / st["seconds"] / 1e9, 3), "unit": "Gresidues/s" if alpha else "Gbases/s",
+                        "reads": st["records"], "file_bytes": os.path.getsize(path), "seconds": round(st["seconds"], 4),
+                        "reader_seconds": round(st["reader_seconds"], 4), "reader_wait_seconds": round(st["reader_wait_seconds"], 4),
+                        "bound": "the single-threaded record reader" if st["reader_seconds"] > 0.7 * st["seconds"] else "device side"}
+    return out
+
+
 def measured_profile(workload: str, n_reads: int):
     """HBM bytes per launch / VALU utilisation from the committed rocprofv3 PMC passes (profiles/*/traffic.json), or None.
 
@@ -151,6 +207,7 @@ def main():
     ap.add_argument("--workload", default="minimizer", choices=sorted(WORKLOADS))
     ap.add_argument("--reads", type=float, default=0, help="override reads per GPU (dev)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the file/host-memory -> host-tuples side measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the rendezvous / barriers")
     ap.add_argument("--plumbing-only", action="store_true", help="tests: N>1 control flow with stand-in counters, no GPU, no kernel")
     args = ap.parse_args()
@@ -292,6 +349,11 @@ def main():
             }
         if world == 1 and not args.no_cpu_baseline and not args.plumbing_only:
             out["cpu_baseline"] = cpu_baseline(kind, k, x, read_len, batch)
+        if world == 1 and not args.no_end_to_end and not args.plumbing_only:
+            try:
+                out["end_to_end"] = end_to_end(kind, p, batch, read_len)
+            except Exception as e:  # never let the side measurement cost the line
+                out["end_to_end"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

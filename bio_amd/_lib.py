@@ -27,6 +27,15 @@ ST_FIRST_WINDOW_TIE, ST_HAS_NON_ACGT = 0x10, 0x20
 POS_STRAND_BIT, POS_MASK = 0x80000000, 0x7FFFFFFF
 
 
+class PipelineStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("records", "bases", "tuples", "chunks", "checksum")] + \
+               [(n, C.c_double) for n in ("seconds", "reader_seconds", "reader_wait_seconds", "h2d_pack_seconds", "kernel_seconds", "fetch_seconds")] + \
+               [("n_streams", C.c_int32), ("reserved", C.c_int32)]
+
+    def asdict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
 class Params(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("kind", "k", "w", "s", "m", "scale", "canonical", "circular", "codon_table", "frame")]
@@ -60,6 +69,9 @@ SYMBOLS = [
     ("bsk_batch_from_fastx", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_int, _pp, _u64p]),
     ("bsk_sketch", C.c_int, [_vp, _vp, C.POINTER(Params), _pp]),
     ("bsk_sketch_timed", C.c_int, [_vp, _vp, C.POINTER(Params), _pp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    ("bsk_batch_refill_ascii", C.c_int, [_vp, _pp, _vp, _vp, C.c_uint64, C.c_int]),
+    ("bsk_pipeline_fastx", C.c_int, [C.c_int, C.c_char_p, C.c_int, _vp, C.c_int, C.c_uint64, C.c_int, _vp]),
+    ("bsk_pipeline_memory", C.c_int, [C.c_int, _vp, _vp, C.c_uint64, C.c_int, _vp, C.c_int, C.c_uint64, C.c_int, C.c_int, _vp]),
     ("bsk_comm_unique_id", C.c_int, [_vp]),
     ("bsk_comm_init_rank", C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     ("bsk_comm_init_all", C.c_int, [_pp, C.c_int]),

@@ -277,6 +277,7 @@ extern "C" void bsk_ctx_destroy(bsk_ctx *ctx) {
     for (void *t : ctx->tmp) (void)hipFree(t);
     if (ctx->tile_res) bsk_result_release(ctx->tile_res);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->h_refs) (void)hipHostFree(ctx->h_refs);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -314,6 +315,8 @@ extern "C" void bsk_batch_destroy(bsk_batch *b) {
     (void)hipFree(b->wbits);
     (void)hipFree(b->rflags);
     (void)hipFree(b->aoff);
+    (void)hipFree(b->spare_ascii);
+    (void)hipFree(b->spare_aoff);
     delete b;
 }
 
@@ -324,12 +327,37 @@ static u32 env_u32(const char *name, u32 dflt) {
 }
 static int build_subset(bsk_ctx *ctx, bsk_batch *b);
 
-extern "C" int bsk_batch_from_ascii(bsk_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet,
-                                    bsk_batch **out) {
+// donor: a batch whose device buffers may be taken over (bsk_batch_refill_ascii); it is consumed
+static int batch_from_ascii_impl(bsk_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet, bsk_batch *donor,
+                                 bsk_batch **out) {
     if (!ctx || !out || (!offsets && n) || (n && !bytes && offsets[n] > 0)) return fail_arg(ctx, "bsk_batch_from_ascii: null argument");
     if (alphabet != BSK_ALPHA_DNA && alphabet != BSK_ALPHA_PROTEIN) return fail_arg(ctx, "bad alphabet");
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (donor && !donor->ascii && donor->spare_ascii) {  // a pure-ACGT donor parked its ASCII buffers
+        donor->ascii = donor->spare_ascii;
+        donor->aoff = donor->spare_aoff;
+        donor->spare_ascii = nullptr;
+        donor->spare_aoff = nullptr;
+    }
+    // device buffer of at least `bytes`: the donor's if it is large enough, else a fresh one with 1/8 of slack
+    auto take = [&](void **dst, size_t *cap_dst, size_t need, void **src, size_t *cap_src) -> hipError_t {
+        if (donor && src && *src && *cap_src >= need) {
+            *dst = *src;
+            *cap_dst = *cap_src;
+            *src = nullptr;
+            *cap_src = 0;
+            return hipSuccess;
+        }
+        const size_t want = donor ? need + need / 8 + 256 : need;
+        const hipError_t e = hipMalloc(dst, want ? want : 1);
+        if (e == hipSuccess) *cap_dst = want;
+        return e;
+    };
+    struct DonorGuard {  // whatever was not taken over goes away with the donor
+        bsk_batch *d;
+        ~DonorGuard() { if (d) bsk_batch_destroy(d); }
+    } donor_guard{donor};
     bsk_batch *b = new (std::nothrow) bsk_batch();
     if (!b) return BSK_ERR_NOMEM;
     b->ctx = ctx;
@@ -363,8 +391,8 @@ extern "C" int bsk_batch_from_ascii(bsk_ctx *ctx, const uint8_t *bytes, const ui
         if (e__ != hipSuccess) return bail(fail_hip(ctx, e__, #call)); \
     } while (0)
     // ascii + offsets to the device
-    BCHK(hipMalloc(&b->ascii, nbytes + BSK_ASCII_PAD));
-    BCHK(hipMalloc(&b->aoff, (n + 1) * sizeof(u64)));
+    BCHK(take((void **)&b->ascii, &b->c_ascii, nbytes + BSK_ASCII_PAD, donor ? (void **)&donor->ascii : nullptr, donor ? &donor->c_ascii : nullptr));
+    BCHK(take((void **)&b->aoff, &b->c_aoff, (n + 1) * sizeof(u64), donor ? (void **)&donor->aoff : nullptr, donor ? &donor->c_aoff : nullptr));
     if (nbytes) BCHK(hipMemcpyAsync(b->ascii, bytes, nbytes, hipMemcpyHostToDevice, ctx->stream));
     if (n) BCHK(hipMemcpyAsync(b->aoff, offsets, (n + 1) * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
     else {
@@ -384,13 +412,14 @@ extern "C" int bsk_batch_from_ascii(bsk_ctx *ctx, const uint8_t *bytes, const ui
         }
         b->n_words = w;
         const u64 alloc_words = w + pad_words(maxlen);
-        BCHK(hipMalloc(&b->words, alloc_words * sizeof(u32)));
-        BCHK(hipMalloc(wide ? &b->fw : &b->desc, (n ? n : 1) * sizeof(u64)));
+        BCHK(take((void **)&b->words, &b->c_words, alloc_words * sizeof(u32), donor ? (void **)&donor->words : nullptr, donor ? &donor->c_words : nullptr));
+        if (wide) BCHK(hipMalloc(&b->fw, (n ? n : 1) * sizeof(u64)));
+        else BCHK(take((void **)&b->desc, &b->c_desc, (n ? n : 1) * sizeof(u64), donor ? (void **)&donor->desc : nullptr, donor ? &donor->c_desc : nullptr));
         if (wide) {
             BCHK(hipMalloc(&b->llen, n * sizeof(u64)));
             BCHK(hipMemcpyAsync(b->llen, llen.data(), n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
         }
-        BCHK(hipMalloc(&b->rflags, n ? n : 1));
+        BCHK(take((void **)&b->rflags, &b->c_rflags, n ? n : 1, donor ? (void **)&donor->rflags : nullptr, donor ? &donor->c_rflags : nullptr));
         BCHK(hipMemsetAsync(b->words, 0, alloc_words * sizeof(u32), ctx->stream));
         BCHK(hipMemsetAsync(b->rflags, 0, n ? n : 1, ctx->stream));
         if (n) BCHK(hipMemcpyAsync(wide ? b->fw : b->desc, desc.data(), n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
@@ -411,8 +440,14 @@ extern "C" int bsk_batch_from_ascii(bsk_ctx *ctx, const uint8_t *bytes, const ui
         b->n_nonacgt = ((u32 *)ctx->h_pinned)[1];
         b->device_bytes += alloc_words * 4 + n * 9;
         if (b->n_nonacgt == 0) {  // pure ACGT: the 2-bit stream is all the kernels need
-            (void)hipFree(b->ascii);
-            (void)hipFree(b->aoff);
+            if (donor) {  // streaming caller: park the buffers for the next refill instead of freeing them
+                b->spare_ascii = b->ascii;
+                b->spare_aoff = b->aoff;
+            } else {
+                (void)hipFree(b->ascii);
+                (void)hipFree(b->aoff);
+                b->c_ascii = b->c_aoff = 0;
+            }
             b->ascii = nullptr;
             b->aoff = nullptr;
             b->device_bytes -= nbytes + 64 + (n + 1) * 8;
@@ -425,6 +460,19 @@ extern "C" int bsk_batch_from_ascii(bsk_ctx *ctx, const uint8_t *bytes, const ui
 #undef BCHK
     *out = b;
     return rc;
+}
+
+extern "C" int bsk_batch_from_ascii(bsk_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet,
+                                    bsk_batch **out) {
+    return batch_from_ascii_impl(ctx, bytes, offsets, n, alphabet, nullptr, out);
+}
+
+extern "C" int bsk_batch_refill_ascii(bsk_ctx *ctx, bsk_batch **batch, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet) {
+    if (!ctx || !batch) return fail_arg(ctx, "bsk_batch_refill_ascii: null argument");
+    bsk_batch *old = *batch;
+    if (old && (old->ctx != ctx || old->alias)) return fail_arg(ctx, "bsk_batch_refill_ascii: the batch belongs to another context");
+    *batch = nullptr;  // consumed whatever happens
+    return batch_from_ascii_impl(ctx, bytes, offsets, n, alphabet, old, batch);
 }
 
 extern "C" int bsk_batch_from_packed(bsk_ctx *ctx, const uint32_t *words, uint64_t n_words, const uint64_t *desc, uint64_t n,
@@ -662,22 +710,49 @@ extern "C" int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t firs
     if (first + count > r->n) return fail_arg(ctx, "bsk_result_fetch: range outside result");
     if (pos && !r->pos) return fail_arg(ctx, "bsk_result_fetch: this kind has implicit positions");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    std::vector<u64> refs(count ? count : 1);
-    if (count) HIPCHK(ctx, hipMemcpy(refs.data(), (r->refs ? r->refs : r->wcount) + first, count * 8, hipMemcpyDeviceToHost));
+    // everything goes over the context's stream through grow-only buffers: no hipMalloc / hipFree (a device-wide
+    // synchronisation) and no pageable staging per call -- a streaming caller fetches chunk after chunk
+    if (ctx->h_refs_cap < count + 1) {
+        if (ctx->h_refs) (void)hipHostFree(ctx->h_refs);
+        ctx->h_refs = nullptr;
+        ctx->h_refs_cap = 0;
+        const size_t want = (count + 1) + (count + 1) / 4 + 64;
+        HIPCHK(ctx, hipHostMalloc(&ctx->h_refs, want * 8));
+        ctx->h_refs_cap = want;
+    }
+    u64 *refs = ctx->h_refs;
+    if (count) {
+        HIPCHK(ctx, hipMemcpyAsync(refs, (r->refs ? r->refs : r->wcount) + first, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (status) HIPCHK(ctx, hipMemcpyAsync(status, r->status + first, count, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     offsets[0] = 0;
     for (u64 i = 0; i < count; ++i) offsets[i + 1] = offsets[i] + (r->refs ? (refs[i] & 0xffffffULL) : refs[i]);
     const u64 T = offsets[count];
-    if (status && count) HIPCHK(ctx, hipMemcpy(status, r->status + first, count, hipMemcpyDeviceToHost));
     if (!hash && !pos) return BSK_OK;
     if (T > tuple_cap) return fail_arg(ctx, "bsk_result_fetch: tuple_cap too small");
     if (T == 0) return BSK_OK;
     // pack on the device (the tuple arrays are slab-organised), then one D2H copy per array
     u64 *d_off = nullptr, *d_h = nullptr;
     u32 *d_p = nullptr;
-    hipError_t e = hipMalloc(&d_off, count * 8);
-    if (e == hipSuccess && hash) e = hipMalloc(&d_h, T * 8);
-    if (e == hipSuccess && pos) e = hipMalloc(&d_p, T * 4);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_off, offsets, count * 8, hipMemcpyHostToDevice, ctx->stream);
+    auto fpool = [&](int slot, size_t bytes, void **out) -> hipError_t {
+        if (ctx->tmp_cap[slot] < bytes) {
+            (void)hipFree(ctx->tmp[slot]);
+            ctx->tmp[slot] = nullptr;
+            ctx->tmp_cap[slot] = 0;
+            const size_t want = bytes + bytes / 4 + 256;
+            const hipError_t e2 = hipMalloc(&ctx->tmp[slot], want);
+            if (e2 != hipSuccess) return e2;
+            ctx->tmp_cap[slot] = want;
+        }
+        *out = ctx->tmp[slot];
+        return hipSuccess;
+    };
+    hipError_t e = fpool(12, count * 8, (void **)&d_off);
+    if (e == hipSuccess && hash) e = fpool(13, T * 8, (void **)&d_h);
+    if (e == hipSuccess && pos) e = fpool(14, T * 4, (void **)&d_p);
+    for (u64 i = 0; i < count; ++i) refs[i] = offsets[i];  // the pinned buffer carries the offsets back up
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, refs, count * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_gather, dim3(grid_for(ctx, count * 64, 256)), dim3(256), 0, ctx->stream, r->hash, r->pos,
                            r->refs ? r->refs + first : nullptr, r->refs ? nullptr : r->wfirst + first,
@@ -687,9 +762,6 @@ extern "C" int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t firs
     if (e == hipSuccess && hash) e = hipMemcpyAsync(hash, d_h, T * 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess && pos) e = hipMemcpyAsync(pos, d_p, T * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_off);
-    (void)hipFree(d_h);
-    (void)hipFree(d_p);
     if (e != hipSuccess) return fail_hip(ctx, e, "bsk_result_fetch");
     return BSK_OK;
 }

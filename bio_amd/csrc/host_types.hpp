@@ -27,8 +27,10 @@ struct bsk_ctx {
     u8 *d_lut = nullptr;      // codon tables of `lut_table` (kernels_translate.hpp layout)
     int lut_table = 0;
     // tiled calls: grow-only temporaries (hipMalloc / hipFree of ten buffers per call cost more than the kernels)
-    void *tmp[12] = {};
-    size_t tmp_cap[12] = {};
+    void *tmp[16] = {};      // 0-9: tiled calls, 12-14: bsk_result_fetch
+    size_t tmp_cap[16] = {};
+    u64 *h_refs = nullptr;   // pinned staging of bsk_result_fetch (refs down, offsets up), grow-only
+    size_t h_refs_cap = 0;
     struct bsk_result *tile_res = nullptr;  // tile-level result of the previous tiled call, reused
     // the one collective of the path (comm.cpp): an RCCL communicator over the GPUs that share a job
     void *comm = nullptr;  // ncclComm_t
@@ -57,6 +59,12 @@ struct bsk_batch {
     u8 *ascii = nullptr;  // DNA: kept only when some read has a non-ACGT byte; protein: always
     u64 *aoff = nullptr;
     u64 device_bytes = 0;
+    // capacities (bytes) of the device buffers, and the ASCII buffers parked while a batch is pure ACGT: a streaming caller
+    // re-fills one batch object per stream (bsk_batch_refill_ascii) instead of allocating per chunk -- hipFree synchronises the
+    // whole device and would serialise the streams
+    size_t c_words = 0, c_desc = 0, c_rflags = 0, c_ascii = 0, c_aoff = 0;
+    u8 *spare_ascii = nullptr;
+    u64 *spare_aoff = nullptr;
 };
 
 struct bsk_result {

@@ -1,0 +1,283 @@
+// pipeline.cpp -- the end-to-end path: file (or host memory) -> pinned chunks -> H2D + pack -> sketch kernel -> tuples on the host,
+// with the stages of different chunks overlapping.
+//
+// This is host code that uses nothing but the public C ABI -- what the reference-side host (Go: a producer goroutine over
+// fastx.Reader as ChunkChan is, seqio/fastx/reader.go:562-608, and one worker goroutine per stream) would write itself:
+//   * ONE producer thread reads chunks (bsk_fastx_read_chunk) and copies them into pinned buffers from a free list;
+//   * n_streams worker threads, each with its own context (= HIP stream), re-fill one batch object (bsk_batch_refill_ascii:
+//     no allocation per chunk), run bsk_sketch into one re-used result and fetch the tuples into pinned memory
+//     (bsk_result_fetch).  While one worker waits for its copy or kernel the others' streams run: H2D, kernels and D2H of
+//     different chunks overlap without any cross-stream choreography.
+// The statistics say where the time went; `seconds` is the wall time from the first read to the last tuple on the host.
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "host_types.hpp"
+
+namespace {
+
+using clk = std::chrono::steady_clock;
+inline double secs(clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); }
+
+struct PinBuf {  // grow-only pinned host buffer
+    void *p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes) {
+        if (cap >= bytes) return true;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc(&p, want) != hipSuccess) return false;
+        cap = want;
+        return true;
+    }
+    ~PinBuf() {
+        if (p) (void)hipHostFree(p);
+    }
+};
+
+struct Chunk {
+    PinBuf bytes, offs;
+    uint64_t n = 0, nbytes = 0;
+};
+
+struct Queue {  // chunks handed from the producer to the workers, and back
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Chunk *> q;
+    bool closed = false;
+    void push(Chunk *c) {
+        {
+            std::lock_guard<std::mutex> l(m);
+            q.push_back(c);
+        }
+        cv.notify_one();
+    }
+    Chunk *pop() {  // nullptr: closed and empty
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return !q.empty() || closed; });
+        if (q.empty()) return nullptr;
+        Chunk *c = q.front();
+        q.pop_front();
+        return c;
+    }
+    void close() {
+        {
+            std::lock_guard<std::mutex> l(m);
+            closed = true;
+        }
+        cv.notify_all();
+    }
+};
+
+struct Source {  // next chunk into c; returns 0 at the end, <0 on error
+    virtual ~Source() {}
+    virtual int next(Chunk *c, uint64_t max_records) = 0;
+    int alphabet = BSK_ALPHA_DNA;
+    std::string err;
+};
+
+struct FastxSource : Source {
+    bsk_fastx *f = nullptr;
+    int want_alpha = -1;
+    int next(Chunk *c, uint64_t max_records) override {
+        uint64_t n = 0;
+        const uint8_t *sb = nullptr;
+        const uint64_t *so = nullptr;
+        const int rc = bsk_fastx_read_chunk(f, max_records, 0, &n, &sb, &so, nullptr, nullptr, nullptr);
+        if (rc != BSK_OK) {
+            err = bsk_fastx_error(f);
+            return -rc;
+        }
+        if (n == 0) return 0;
+        if (want_alpha < 0) {
+            int isq = 0, a = -1;
+            bsk_fastx_info(f, &isq, &a);
+            alphabet = a == BSK_ALPHA_PROTEIN ? BSK_ALPHA_PROTEIN : BSK_ALPHA_DNA;
+        } else {
+            alphabet = want_alpha;
+        }
+        if (!c->bytes.ensure(so[n] + 1) || !c->offs.ensure((n + 1) * 8)) return -BSK_ERR_NOMEM;
+        memcpy(c->bytes.p, sb, so[n]);
+        memcpy(c->offs.p, so, (n + 1) * 8);
+        c->n = n;
+        c->nbytes = so[n];
+        return 1;
+    }
+};
+
+struct MemorySource : Source {
+    const uint8_t *bytes = nullptr;
+    const uint64_t *offsets = nullptr;
+    uint64_t n = 0, at = 0;
+    int repeat = 1, pass = 0;
+    int next(Chunk *c, uint64_t max_records) override {
+        if (at >= n) {
+            if (++pass >= repeat) return 0;
+            at = 0;
+        }
+        const uint64_t m = std::min<uint64_t>(max_records ? max_records : n, n - at);
+        const uint64_t b0 = offsets[at], nb = offsets[at + m] - b0;
+        if (!c->bytes.ensure(nb + 1) || !c->offs.ensure((m + 1) * 8)) return -BSK_ERR_NOMEM;
+        memcpy(c->bytes.p, bytes + b0, nb);
+        uint64_t *o = (uint64_t *)c->offs.p;
+        for (uint64_t i = 0; i <= m; ++i) o[i] = offsets[at + i] - b0;
+        c->n = m;
+        c->nbytes = nb;
+        at += m;
+        return 1;
+    }
+};
+
+int run_pipeline(int device, Source &src, const bsk_params *p, int n_streams, uint64_t chunk_records, int fetch, bsk_pipeline_stats *st) {
+    if (!p || !st || n_streams < 1 || n_streams > 16) return BSK_ERR_ARG;
+    memset(st, 0, sizeof *st);
+    if (hipSetDevice(device) != hipSuccess) return BSK_ERR_NO_DEVICE;
+    const int nchunks = 2 * n_streams + 1;  // double buffering per stream + the one the producer is filling
+    std::vector<Chunk> chunks(nchunks);
+    Queue free_q, full_q;
+    for (auto &c : chunks) free_q.push(&c);
+    std::atomic<int> error{0};
+    std::mutex stm;
+    std::string errtext;
+    auto fail = [&](int code, const std::string &text) {
+        int z = 0;
+        if (error.compare_exchange_strong(z, code)) {
+            std::lock_guard<std::mutex> l(stm);
+            errtext = text;
+        }
+        full_q.close();
+        free_q.close();
+    };
+    const auto t_start = clk::now();
+    double reader_s = 0, reader_wait_s = 0;
+    std::thread producer([&] {
+        (void)hipSetDevice(device);
+        for (;;) {
+            const auto w0 = clk::now();
+            Chunk *c = free_q.pop();
+            reader_wait_s += secs(w0, clk::now());
+            if (!c || error.load()) break;
+            const auto r0 = clk::now();
+            const int rc = src.next(c, chunk_records);
+            reader_s += secs(r0, clk::now());
+            if (rc < 0) {
+                fail(-rc, src.err);
+                break;
+            }
+            if (rc == 0) break;
+            full_q.push(c);
+        }
+        full_q.close();
+    });
+    std::vector<std::thread> workers;
+    for (int w = 0; w < n_streams; ++w) {
+        workers.emplace_back([&, w] {
+            (void)w;
+            bsk_ctx *ctx = nullptr;
+            if (bsk_ctx_create(device, &ctx) != BSK_OK) {
+                fail(BSK_ERR_NO_DEVICE, "bsk_ctx_create");
+                return;
+            }
+            bsk_batch *batch = nullptr;
+            bsk_result *res = nullptr;
+            PinBuf o_off, o_st, o_hash, o_pos;
+            bsk_pipeline_stats loc;
+            memset(&loc, 0, sizeof loc);
+            for (;;) {
+                Chunk *c = full_q.pop();
+                if (!c || error.load()) break;
+                auto t0 = clk::now();
+                int rc = bsk_batch_refill_ascii(ctx, &batch, (const uint8_t *)c->bytes.p, (const uint64_t *)c->offs.p, c->n, src.alphabet);
+                const uint64_t n = c->n, nb = c->nbytes;
+                free_q.push(c);  // the bytes are on the device: the producer may refill this buffer
+                auto t1 = clk::now();
+                loc.h2d_pack_seconds += secs(t0, t1);
+                if (rc == BSK_OK) rc = bsk_sketch(ctx, batch, p, &res);
+                auto t2 = clk::now();
+                loc.kernel_seconds += secs(t1, t2);
+                uint64_t nr = 0, nt = 0;
+                int hp = 0;
+                if (rc == BSK_OK) rc = bsk_result_info(res, &nr, &nt, &hp);
+                if (rc == BSK_OK && fetch) {
+                    if (!o_off.ensure((nr + 1) * 8) || !o_st.ensure(nr + 1) || !o_hash.ensure((nt + 1) * 8) || (hp && !o_pos.ensure((nt + 1) * 4))) rc = BSK_ERR_NOMEM;
+                    if (rc == BSK_OK)
+                        rc = bsk_result_fetch(ctx, res, 0, nr, (uint64_t *)o_off.p, (uint8_t *)o_st.p, (uint64_t *)o_hash.p, hp ? (uint32_t *)o_pos.p : nullptr, nt + 1);
+                    if (rc == BSK_OK) {  // the caller's consumer would start here; the statistics keep an order-independent digest
+                        const uint64_t *h = (const uint64_t *)o_hash.p, *oo = (const uint64_t *)o_off.p;
+                        const uint32_t *ps = (const uint32_t *)o_pos.p;
+                        uint64_t sum = 0;
+                        for (uint64_t r = 0; r < nr; ++r)
+                            for (uint64_t j = oo[r]; j < oo[r + 1]; ++j) sum += h[j] * (2 * (uint64_t)(hp ? (ps[j] & BSK_POS_MASK) : j - oo[r]) + 1);
+                        loc.checksum += sum;
+                    }
+                } else if (rc == BSK_OK) {
+                    uint64_t ck = 0, ntt = 0;
+                    rc = bsk_result_digest(ctx, res, &ck, &ntt, nullptr);
+                    loc.checksum += ck;
+                }
+                loc.fetch_seconds += secs(t2, clk::now());
+                if (rc != BSK_OK) {
+                    fail(rc, bsk_last_error(ctx));
+                    break;
+                }
+                loc.records += n;
+                loc.bases += nb;
+                loc.tuples += nt;
+                loc.chunks += 1;
+            }
+            bsk_result_release(res);
+            bsk_batch_destroy(batch);
+            bsk_ctx_destroy(ctx);
+            std::lock_guard<std::mutex> l(stm);
+            st->records += loc.records;
+            st->bases += loc.bases;
+            st->tuples += loc.tuples;
+            st->chunks += loc.chunks;
+            st->checksum += loc.checksum;
+            st->h2d_pack_seconds += loc.h2d_pack_seconds;
+            st->kernel_seconds += loc.kernel_seconds;
+            st->fetch_seconds += loc.fetch_seconds;
+        });
+    }
+    producer.join();
+    for (auto &t : workers) t.join();
+    st->seconds = secs(t_start, clk::now());
+    st->reader_seconds = reader_s;
+    st->reader_wait_seconds = reader_wait_s;
+    st->n_streams = n_streams;
+    return error.load();
+}
+
+}  // namespace
+
+extern "C" int bsk_pipeline_fastx(int device, const char *path, int alphabet, const bsk_params *p, int n_streams, uint64_t chunk_records,
+                                  int fetch_tuples, bsk_pipeline_stats *stats) {
+    if (!path) return BSK_ERR_ARG;
+    FastxSource src;
+    src.want_alpha = alphabet;
+    int rc = bsk_fastx_open(path, &src.f);
+    if (rc != BSK_OK) return rc;
+    rc = run_pipeline(device, src, p, n_streams, chunk_records, fetch_tuples, stats);
+    bsk_fastx_close(src.f);
+    return rc;
+}
+
+extern "C" int bsk_pipeline_memory(int device, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet, const bsk_params *p,
+                                   int n_streams, uint64_t chunk_records, int repeat, int fetch_tuples, bsk_pipeline_stats *stats) {
+    if (!bytes || !offsets || !n || repeat < 1) return BSK_ERR_ARG;
+    MemorySource src;
+    src.bytes = bytes;
+    src.offsets = offsets;
+    src.n = n;
+    src.repeat = repeat;
+    src.alphabet = alphabet;
+    return run_pipeline(device, src, p, n_streams, chunk_records, fetch_tuples, stats);
+}

@@ -239,6 +239,29 @@ class Engine:
         self._chk(self.lib.bsk_gather_counts(self.ctx, a.ctypes.data, len(a), out.ctypes.data))
         return [[int(v) for v in row] for row in out.reshape(world, len(a))]
 
+    # -- end to end: file / host memory -> tuples on the host, stages overlapped over n_streams contexts (bsk_pipeline_*)
+    @staticmethod
+    def pipeline_fastx(path: str, params, n_streams: int = 2, chunk_records: int = 1 << 20, fetch: bool = True, alphabet: int = -1, device: int = 0):
+        lib = L.load()
+        st = L.PipelineStats()
+        rc = lib.bsk_pipeline_fastx(device, path.encode(), alphabet, C.byref(params), n_streams, chunk_records, 1 if fetch else 0, C.byref(st))
+        if rc != L.OK:
+            raise _SENTINELS.get(rc) or DeviceError(f"bsk_pipeline_fastx: {lib.bsk_err_name(rc).decode()}")
+        return st.asdict()
+
+    @staticmethod
+    def pipeline_memory(data: np.ndarray, offsets: np.ndarray, params, n_streams: int = 2, chunk_records: int = 1 << 20, repeat: int = 1,
+                        fetch: bool = True, alphabet: int = L.ALPHA_DNA, device: int = 0):
+        lib = L.load()
+        data = np.ascontiguousarray(data, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        st = L.PipelineStats()
+        rc = lib.bsk_pipeline_memory(device, data.ctypes.data, offsets.ctypes.data, len(offsets) - 1, alphabet, C.byref(params), n_streams,
+                                     chunk_records, repeat, 1 if fetch else 0, C.byref(st))
+        if rc != L.OK:
+            raise _SENTINELS.get(rc) or DeviceError(f"bsk_pipeline_memory: {lib.bsk_err_name(rc).decode()}")
+        return st.asdict()
+
     # -- batches
     def batch(self, seqs: Sequence, alphabet: int = L.ALPHA_DNA) -> Batch:
         bs = [s.Seq if isinstance(s, Seq) else (s.encode() if isinstance(s, str) else bytes(s)) for s in seqs]

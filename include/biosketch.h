@@ -236,6 +236,33 @@ int bsk_result_digest(bsk_ctx *ctx, const bsk_result *r, uint64_t *checksum, uin
                       uint64_t status_counts[4]);
 void bsk_result_release(bsk_result *r);
 
+/* ---- streaming callers: bounded allocation and the end-to-end pipeline ------------------------
+ * bsk_batch_refill_ascii: bsk_batch_from_ascii into an EXISTING batch object (*batch may be NULL the first time): the device
+ * buffers are kept and only grow, so a caller that feeds chunk after chunk through one batch per stream allocates nothing in
+ * steady state (hipFree synchronises the whole device and would serialise the streams).  The old contents are gone after the
+ * call; on error *batch is NULL.  bsk_result_fetch likewise works out of grow-only buffers of its context.
+ *
+ * bsk_pipeline_fastx / bsk_pipeline_memory: the whole path host bytes -> tuples on the host with its stages overlapped --
+ * one producer thread (the role of fastx's ChunkChan goroutine, seqio/fastx/reader.go:562-608) filling pinned chunks of
+ * chunk_records records, n_streams workers, each with its own context, doing refill (H2D + pack) -> bsk_sketch ->
+ * bsk_result_fetch into pinned memory (fetch_tuples != 0) or only a device digest (fetch_tuples == 0).  It uses nothing but
+ * the calls above: a Go host gets the same overlap from one goroutine per stream.  stats->seconds is the wall time from the
+ * first read to the last tuple; the per-stage seconds are summed over the workers (they overlap, so they add up to more
+ * than `seconds`); checksum is the digest of bsk_result_digest summed over the chunks (positions are per sequence). */
+int bsk_batch_refill_ascii(bsk_ctx *ctx, bsk_batch **batch, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet);
+typedef struct bsk_pipeline_stats {
+    uint64_t records, bases, tuples, chunks, checksum;
+    double seconds;              /* wall */
+    double reader_seconds;       /* producer: inside the reader + the copy into pinned memory */
+    double reader_wait_seconds;  /* producer: waiting for a free chunk buffer (the device side was the slower one) */
+    double h2d_pack_seconds, kernel_seconds, fetch_seconds; /* summed over the workers */
+    int32_t n_streams, reserved;
+} bsk_pipeline_stats;
+int bsk_pipeline_fastx(int device, const char *path, int alphabet /* -1: guess from the first record */, const bsk_params *p, int n_streams,
+                       uint64_t chunk_records, int fetch_tuples, bsk_pipeline_stats *stats);
+int bsk_pipeline_memory(int device, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet, const bsk_params *p,
+                        int n_streams, uint64_t chunk_records, int repeat, int fetch_tuples, bsk_pipeline_stats *stats);
+
 /* ---- multi-GPU: the one collective of the path ----------------------------
  * Reads shard by record; no tuple ever crosses GPUs.  What a job gathers at its end is a handful of u64 counters per GPU
  * (reads, bases, tuples, flagged reads ...): one all_gather over RCCL (xGMI inside a node), 8 * n_counters bytes per rank.

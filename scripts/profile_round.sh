@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out/$ROUND
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for w in $WORKLOADS; do
-  CMD="python $REPO/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline"
+  CMD="python $REPO/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end"
   rm -rf /tmp/prof_$w
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$w/stats -- $CMD > /tmp/prof_$w.log 2>&1
   timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_$w/fetch -- $CMD >> /tmp/prof_$w.log 2>&1

@@ -1,0 +1,85 @@
+"""The end-to-end path (bsk_pipeline_fastx / bsk_pipeline_memory / bsk_batch_refill_ascii): file or host memory -> pinned chunks ->
+H2D + pack -> kernel -> tuples on the host over several streams must give exactly what one big batch gives."""
+import ctypes as C
+import gzip
+import random
+
+import numpy as np
+import pytest
+
+from bio_amd import _lib as L
+from bio_amd import sketches as S
+
+pytestmark = pytest.mark.gpu
+
+
+def make_reads(n, seed, with_n=True):
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(30, 260, n)
+    lens[::7] = 150
+    offs = np.zeros(n + 1, np.uint64)
+    offs[1:] = np.cumsum(lens)
+    data = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(offs[-1]))].copy()
+    if with_n:
+        data[rng.integers(0, len(data), n // 50)] = ord("N")  # ~2 % of the reads take the ASCII side launch
+    return data, offs
+
+
+def write_fastq(path, data, offs, gz):
+    opener = gzip.open if gz else open
+    with opener(path, "wb") as f:
+        for i in range(len(offs) - 1):
+            s = data[int(offs[i]):int(offs[i + 1])].tobytes()
+            f.write(b"@r%d some description\n%s\n+\n%s\n" % (i, s, b"I" * len(s)))
+
+
+@pytest.mark.parametrize("kind,pk", [(L.MINIMIZER, dict(k=21, w=11)), (L.SYNCMER, dict(k=31, s=11)), (L.NTHASH, dict(k=21))])
+def test_pipeline_equals_one_batch(engine, tmp_path, kind, pk):
+    n = 60_000
+    data, offs = make_reads(n, 3)
+    p = engine.params(kind, **pk)
+    whole = engine.run(engine.batch_from_arrays(data, offs), p)
+    want = whole.digest()
+    for streams, chunk, fetch in ((1, 7000, True), (3, 5001, True), (2, 100000, False)):
+        st = S.Engine.pipeline_memory(data, offs, p, n_streams=streams, chunk_records=chunk, fetch=fetch)
+        assert st["records"] == n and st["bases"] == int(offs[-1]) and st["tuples"] == want["n_tuples"], (streams, st)
+        assert st["checksum"] == want["checksum"], (streams, chunk, fetch)
+        assert st["chunks"] == -(-n // chunk) and st["n_streams"] == streams and st["seconds"] > 0
+    for gz in (False, True):
+        path = str(tmp_path / ("reads.fq.gz" if gz else "reads.fq"))
+        write_fastq(path, data, offs, gz)
+        st = S.Engine.pipeline_fastx(path, p, n_streams=2, chunk_records=9000, fetch=True)
+        assert (st["records"], st["bases"], st["tuples"], st["checksum"]) == (n, int(offs[-1]), want["n_tuples"], want["checksum"])
+    st = S.Engine.pipeline_memory(data, offs, p, n_streams=2, chunk_records=20000, repeat=3)
+    assert st["records"] == 3 * n and st["checksum"] == (3 * want["checksum"]) % (1 << 64)
+
+
+def test_refill_reuses_one_batch_object(engine):
+    """bsk_batch_refill_ascii: growing, shrinking, pure-ACGT and N-carrying chunks through ONE batch object, every result equal to
+    a fresh batch's."""
+    lib = engine.lib
+    h = C.c_void_p()
+    p = engine.params(L.MINIMIZER, 15, w=7)
+    for i, (n, with_n) in enumerate([(500, False), (4000, True), (100, False), (4000, False), (1, True), (9000, True), (0, False)]):
+        data, offs = make_reads(max(n, 1), 10 + i, with_n)
+        if n == 0:
+            data, offs = np.zeros(1, np.uint8), np.zeros(1, np.uint64)
+        engine._chk(lib.bsk_batch_refill_ascii(engine.ctx, C.byref(h), data.ctypes.data, offs.ctypes.data, n, L.ALPHA_DNA))
+        got = S.BatchResult(engine, *_run(engine, h, p)).digest()
+        want = engine.run(engine.batch_from_arrays(data, offs) if n else engine.batch([]), p).digest()
+        assert got == want, (i, n)
+    lib.bsk_batch_destroy(h)
+
+
+def _run(engine, batch_handle, p):
+    r = C.c_void_p()
+    engine._chk(engine.lib.bsk_sketch(engine.ctx, batch_handle, C.byref(p), C.byref(r)))
+    return r, p
+
+
+def test_pipeline_reports_reader_errors(tmp_path):
+    path = str(tmp_path / "bad.fq")
+    with open(path, "w") as f:
+        f.write("@r1\nACGTACGTACGTACGTACGTACGTACGT\n+\nIIII\n")  # quality shorter than the sequence
+    with pytest.raises(S.DeviceError):
+        S.Engine.pipeline_fastx(path, S.Engine.params(L.NTHASH, 5), n_streams=2, chunk_records=10)
