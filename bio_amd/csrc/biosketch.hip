@@ -882,7 +882,7 @@ static int blocks_per_cu(K kernel) {
 
 // Which kernel runs a (batch, params) pair, on how many workgroups, and how the tuple arrays are organised.
 enum Which { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST, K_NT_FAST, K_SYN_P, K_SYN_A, K_KMER_P, K_KMER_A, K_SIM_P, K_SIM_A,
-             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST, K_MIN_DENSE, K_MIN_SEG };
+             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST, K_MIN_DENSE, K_MIN_SEG, K_MIN_WPR };
 struct Plan {
     Which which = K_MIN_GEN_P;
     int grid = 1;
@@ -910,7 +910,7 @@ static bool slab_budget_ok(const bsk_batch *b, u64 slab_read) {
 }
 
 static bool which_is_fast(Which w) {
-    return w == K_MIN_FAST || w == K_NT_FAST || w == K_SYN_FAST || w == K_SIM_FAST || w == K_MIN_DENSE || w == K_MIN_SEG;
+    return w == K_MIN_FAST || w == K_NT_FAST || w == K_SYN_FAST || w == K_SIM_FAST || w == K_MIN_DENSE || w == K_MIN_SEG || w == K_MIN_WPR;
 }
 
 static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan &pl, bool use_ascii);
@@ -954,6 +954,16 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         // k_minimizer_seg: per-read slabs of the expected count + 30 % + 4 (150 bp, w = 11: 32 tuples), rounded to 64-byte pieces
         const double exp_sel = std::max(nwin, 0.0) * 2.0 / (p->w + 1.0) + 1.0;
         const u64 seg_slab = (std::min<u64>((u64)std::max(nwin, 1.0), (u64)(exp_sel * 1.3) + 4) + 7) & ~(u64)7;
+        if (!use_ascii && p->w == 11 && p->k + p->w <= 65 && b->maxlen < 32768u && nwin >= 1.0 && env_u32("BSK_WPR", 0) && !ctx->no_dense && slab_budget_ok(b, seg_slab) &&
+            !getenv("BSK_FORCE_GENERIC")) {
+            pl.which = K_MIN_WPR;  // the A/B experiment: one read per wavefront (kernels_wpr.hpp); a ticket is 64 reads
+            pl.fast_w = p->w;
+            pl.slab = true;
+            pl.slab_read = seg_slab;
+            pl.slab_unit = 64 * pl.slab_read;
+            pl.slab_total = (u64)pl.nunits * pl.slab_unit;
+            per_cu = wpr_minimizer_blocks_per_cu();
+        } else
         if (!use_ascii && seg_minimizer_supported(p->w) && b->maxlen < 32768u && nwin >= 1.0 && env_u32("BSK_SEG", 0) && !ctx->no_dense && slab_budget_ok(b, seg_slab) &&
             !getenv("BSK_FORCE_GENERIC")) {
             pl.which = K_MIN_SEG;
@@ -1240,6 +1250,7 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
         case K_MIN_FAST: snprintf(b, sizeof b, "k_minimizer_fast<%d,%d,true>", pl.fast_w, BSK_FAST_CAP); break;
         case K_MIN_DENSE: snprintf(b, sizeof b, "k_minimizer_dense<%d>", pl.fast_w); break;
         case K_MIN_SEG: snprintf(b, sizeof b, "k_minimizer_seg<%d>", pl.fast_w); break;
+        case K_MIN_WPR: snprintf(b, sizeof b, "k_minimizer_wpr<%d>", pl.fast_w); break;
         case K_NT_FAST: snprintf(b, sizeof b, "k_nthash_fast<%d>", p->kind == BSK_KMER ? 2 : p->canonical ? 1 : 0); break;
         case K_SYN_P: snprintf(b, sizeof b, "k_syncmer<0>"); break;
         case K_SYN_A: snprintf(b, sizeof b, "k_syncmer<1>"); break;
@@ -1313,6 +1324,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_MIN_FAST: fast_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_MIN_DENSE: dense_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_MIN_SEG: seg_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
+        case K_MIN_WPR: wpr_minimizer_launch(pl.grid, ctx->stream, a); break;
         case K_SYN_P: hipLaunchKernelGGL(k_syncmer<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_SYN_A: hipLaunchKernelGGL(k_syncmer<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_KMER_P: hipLaunchKernelGGL(k_kmer<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
@@ -1429,7 +1441,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
     const bool sizing = *result == nullptr || warmup + iters == 0;
     for (int attempt = 0; sizing && attempt < 3; ++attempt) {
         rc = result_prepare(ctx, result, b->n, p->kind, cap + side_cap);
-        if (rc == BSK_ERR_NOMEM && (pl.which == K_MIN_DENSE || pl.which == K_MIN_SEG || pl.which == K_PROT_MIN_FAST) && attempt < 2) {
+        if (rc == BSK_ERR_NOMEM && (pl.which == K_MIN_DENSE || pl.which == K_MIN_SEG || pl.which == K_MIN_WPR || pl.which == K_PROT_MIN_FAST) && attempt < 2) {
             // per-read slabs did not fit the device: the unit-slab / dense-CSR kernels need far less
             ctx->no_prot_fast = true;
             ctx->no_dense = true;

@@ -22,6 +22,9 @@ bool seg_minimizer_supported(int w);  // per-read slabs + a flush of everything 
 int seg_minimizer_blocks_per_cu(int w);
 void seg_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a);
 
+void wpr_minimizer_launch(int grid, hipStream_t stream, const KArgs &a);  // one read per wavefront, w = 11 (the A/B experiment, kernels_wpr.hpp)
+int wpr_minimizer_blocks_per_cu();
+
 bool fast_syncmer_supported(int k, int s);
 int fast_syncmer_blocks_per_cu(int w);
 void fast_syncmer_launch(int w, int grid, hipStream_t stream, const KArgs &a);

@@ -25,6 +25,7 @@
 // an experiment (BSK_SEG=1) and k_minimizer_fast (whole unit staged, one contiguous copy-out, 8 waves) stays the plan.
 #pragma once
 #include "kernels_fast.hpp"
+#include "kernels_wpr.hpp"
 
 namespace bsk {
 
@@ -255,6 +256,17 @@ void seg_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a) {
 #undef X
         default: break;
     }
+}
+void wpr_minimizer_launch(int grid, hipStream_t stream, const KArgs &a) {
+    hipLaunchKernelGGL((k_minimizer_wpr<11>), dim3(grid), dim3(64), 0, stream, a);
+}
+int wpr_minimizer_blocks_per_cu() {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_minimizer_wpr<11>, 64, 0) != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        nb = 1;
+    }
+    return nb;
 }
 #endif  // BSK_IMPL_SEG
 

@@ -46,6 +46,7 @@ struct PinBuf {  // grow-only pinned host buffer
 struct Chunk {
     PinBuf bytes, offs;
     uint64_t n = 0, nbytes = 0;
+    uint64_t src_at = 0;  // memory source: first record of the chunk (the worker copies it into the pinned buffers itself)
 };
 
 struct Queue {  // chunks handed from the producer to the workers, and back
@@ -80,6 +81,7 @@ struct Queue {  // chunks handed from the producer to the workers, and back
 struct Source {  // next chunk into c; returns 0 at the end, <0 on error
     virtual ~Source() {}
     virtual int next(Chunk *c, uint64_t max_records) = 0;
+    virtual int materialize(Chunk *) { return BSK_OK; }  // worker side: whatever the producer left to do (runs in parallel)
     int alphabet = BSK_ALPHA_DNA;
     std::string err;
 };
@@ -123,16 +125,22 @@ struct MemorySource : Source {
             if (++pass >= repeat) return 0;
             at = 0;
         }
+        // the bytes are already in host memory: the producer only hands out ranges, the staging copy into pinned memory is the
+        // workers' (one memcpy thread could not keep several streams busy: 6.7 GB/s against the 3 x 20 GB/s they can move)
         const uint64_t m = std::min<uint64_t>(max_records ? max_records : n, n - at);
-        const uint64_t b0 = offsets[at], nb = offsets[at + m] - b0;
-        if (!c->bytes.ensure(nb + 1) || !c->offs.ensure((m + 1) * 8)) return -BSK_ERR_NOMEM;
-        memcpy(c->bytes.p, bytes + b0, nb);
-        uint64_t *o = (uint64_t *)c->offs.p;
-        for (uint64_t i = 0; i <= m; ++i) o[i] = offsets[at + i] - b0;
+        c->src_at = at;
         c->n = m;
-        c->nbytes = nb;
+        c->nbytes = offsets[at + m] - offsets[at];
         at += m;
         return 1;
+    }
+    int materialize(Chunk *c) override {
+        const uint64_t a = c->src_at, m = c->n, b0 = offsets[a], nb = c->nbytes;
+        if (!c->bytes.ensure(nb + 1) || !c->offs.ensure((m + 1) * 8)) return BSK_ERR_NOMEM;
+        memcpy(c->bytes.p, bytes + b0, nb);
+        uint64_t *o = (uint64_t *)c->offs.p;
+        for (uint64_t i = 0; i <= m; ++i) o[i] = offsets[a + i] - b0;
+        return BSK_OK;
     }
 };
 
@@ -195,7 +203,8 @@ int run_pipeline(int device, Source &src, const bsk_params *p, int n_streams, ui
                 Chunk *c = full_q.pop();
                 if (!c || error.load()) break;
                 auto t0 = clk::now();
-                int rc = bsk_batch_refill_ascii(ctx, &batch, (const uint8_t *)c->bytes.p, (const uint64_t *)c->offs.p, c->n, src.alphabet);
+                int rc = src.materialize(c);
+                if (rc == BSK_OK) rc = bsk_batch_refill_ascii(ctx, &batch, (const uint8_t *)c->bytes.p, (const uint64_t *)c->offs.p, c->n, src.alphabet);
                 const uint64_t n = c->n, nb = c->nbytes;
                 free_q.push(c);  // the bytes are on the device: the producer may refill this buffer
                 auto t1 = clk::now();
