@@ -101,12 +101,25 @@ def test_ragged_batch_matches_uniform(engine):
 
 
 def test_config4_shard_syncmer_k31_s11(engine, oracle):
-    """BASELINE configs[3], one GPU's worth of the path at reduced count: closed syncmer k=31 s=11."""
-    n = 2_000_000
+    """BASELINE configs[3], ONE GPU's full shard of the 1 B-read job: 125M x 150 bp, closed syncmer k=31 s=11 (the other seven
+    shards differ only in the seed; the 8-GPU run itself is the driver's)."""
+    n = 125_000_000
     b = engine.synth(L.ALPHA_DNA, n, 150, SEED + 1)
     res = engine.run(b, engine.params(L.SYNCMER, 31, s=11))
     d = res.digest()
-    assert 6.9 < d["n_tuples"] / n < 7.3  # measured density 7.1 per read (SURVEY 8a)
+    assert 7.0 < d["n_tuples"] / n < 7.2  # measured density 7.09 per read (SURVEY 8a)
+    assert d["short"] == 0 and d["illegal"] == 0 and d["has_non_acgt"] == 0
+    assert 0.0005 < d["first_window_tie"] / n < 0.003  # ties that can reach the front of the first sorted window: 0.13 % of reads
+    assert engine.run(b, engine.params(L.SYNCMER, 31, s=11), reuse=res).digest() == d  # deterministic
+    # sampled bit-exact parity (tuples and flags) at the start, in the middle and at the very end of the shard
+    for first in (0, 62_000_000, n - 800):
+        data, offs = b.fetch_ascii(first, 800)
+        o, st, h, p = res.fetch(first, 800)
+        for r in range(800):
+            eh, ep, es, fl = oracle.syncmer(data[int(offs[r]):int(offs[r + 1])].tobytes(), 31, 11, closed=True)
+            a, e = int(o[r]), int(o[r + 1])
+            assert np.array_equal(h[a:e], eh) and np.array_equal(p[a:e] & L.POS_MASK, ep) and np.array_equal(p[a:e] >> 31, es), (first, r)
+            assert (int(st[r]) & 0xF0) == fl, (first, r)
     data, offs = b.fetch_ascii(0, 50_000)
     nt, ck = oracle.batch_run(5, data, offs, 31, 11, threads=os.cpu_count() or 1)
     small = engine.run(engine.synth(L.ALPHA_DNA, 50_000, 150, SEED + 1), engine.params(L.SYNCMER, 31, s=11)).digest()
@@ -119,12 +132,22 @@ def test_config4_shard_syncmer_k31_s11(engine, oracle):
 
 
 def test_config5_protein_minimizer_k9_w5(engine, oracle):
-    """BASELINE configs[4] at reduced count: protein minimizer k=9 w=5 over 300-aa sequences."""
-    n = 500_000
+    """BASELINE configs[4] at full size: 50M x 300 aa, protein minimizer k=9 w=5."""
+    n = 50_000_000
     b = engine.synth(L.ALPHA_PROTEIN, n, 300, SEED + 2)
     res = engine.run(b, engine.params(L.PROT_MINIMIZER, 9, w=5))
     d = res.digest()
-    assert 95 < d["n_tuples"] / n < 99  # 1 + 287*2/6 = 96.7
+    assert 96.2 < d["n_tuples"] / n < 97.2  # 1 + 287*2/6 = 96.7
+    assert d["short"] == 0 and d["n_tuples"] == res.info()["n_tuples"]
+    assert engine.run(b, engine.params(L.PROT_MINIMIZER, 9, w=5), reuse=res).digest() == d
+    for first in (0, 25_000_000, n - 300):  # sampled bit-exact parity: start, middle, end
+        data, offs = b.fetch_ascii(first, 300)
+        o, st, h, p = res.fetch(first, 300)
+        for r in range(300):
+            eh, ep, fl = oracle.protein_minimizer(data[int(offs[r]):int(offs[r + 1])].tobytes(), 9, 5)
+            a, e = int(o[r]), int(o[r + 1])
+            assert np.array_equal(h[a:e], eh) and np.array_equal(p[a:e] & L.POS_MASK, ep), (first, r)
+            assert (int(st[r]) & 0xF0) == fl
     data, offs = b.fetch_ascii(0, 20_000)
     assert set(np.unique(data).tolist()) <= set(b"ACDEFGHIKLMNPQRSTVWY")
     nt, ck = oracle.batch_run(7, data, offs, 9, 5, threads=os.cpu_count() or 1)
