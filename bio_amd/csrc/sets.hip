@@ -84,6 +84,74 @@ __global__ void k_new_offsets(const u64 *offs_in, const u64 *pos, u64 n_sets, u6
         offs_out[s] = offs_in[s] < n_in ? pos[offs_in[s]] : n_out;
 }
 
+// ---- small sets: every sequence holds at most 64 values (short reads: ~22 minimizers, ~7 syncmers per 150-bp read) ----
+// A segmented radix sort spends eight digit passes on segments of two dozen keys.  Here a sequence is sorted by a GROUP of
+// G = 32 (or 64) lanes holding one value each: the group loads the sequence's values with one coalesced load, runs a bitonic
+// network across its lanes (log2(G)(log2(G)+1)/2 exchange steps: ds_bpermute + 64-bit compare + select, no LDS memory, a
+// dozen registers -- full occupancy), drops duplicates by comparing with the lane below, and stores the distinct values as
+// one dense run at the sequence's input offset (ballot + mbcnt).  k_move_seqs then shifts the runs to their final offsets.
+#define SMALL_CAP 64
+template <int G>
+__global__ __launch_bounds__(256) void k_sets_small(const u64 *hash, const u64 *refs, const u64 *wfirst, const u64 *wcount, const u64 *offs, u64 n,
+                                                    u64 maxhash, u64 *tmp, u64 *ucount) {
+    constexpr int PER_WAVE = 64 / G;
+    const int lane = threadIdx.x & 63, gl = lane & (G - 1), grp = lane / G;
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
+    const u64 ngroups = (n + PER_WAVE - 1) / PER_WAVE;  // wave iterations
+    for (u64 it = wave; it < ngroups; it += nw) {
+        const u64 r = it * PER_WAVE + grp;
+        u64 first = 0, c = 0;
+        if (r < n) seq_span(refs, wfirst, wcount, r, first, c);
+        u64 v = ~0ULL;
+        bool valid = false;
+        if ((u64)gl < c) {
+            v = hash[first + gl];
+            valid = v <= maxhash;
+            if (!valid) v = ~0ULL;  // filtered values sort to the end with the padding
+        }
+        const u64 vm = __ballot(valid);
+        const u32 nvalid = (u32)__builtin_popcountll(G == 64 ? vm : ((vm >> (grp * G)) & ((1ULL << (G & 63)) - 1)));
+#pragma unroll
+        for (int k = 2; k <= G; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const u64 o = __shfl_xor(v, j, 64);
+                const bool up = (gl & k) == 0;             // this block of k lanes sorts ascending
+                const bool lower = (gl & j) == 0;          // this lane keeps the smaller one when ascending
+                const bool take_min = lower == up;
+                const bool o_less = o < v;
+                v = (take_min == o_less) ? o : v;
+            }
+        }
+        // ascending within the group; lanes < nvalid hold the values that passed the filter
+        const u64 below = __shfl_up(v, 1, 64);
+        const bool keep = (u32)gl < nvalid && (gl == 0 || v != below);
+        const u64 km = __ballot(keep);
+        const u64 gm = G == 64 ? km : ((km >> (grp * G)) & ((1ULL << (G & 63)) - 1));
+        const u32 rank = (u32)__builtin_popcountll(gm & ((1ULL << gl) - 1));
+        if (keep) tmp[offs[r] + rank] = v;
+        if (gl == 0 && r < n) ucount[r] = (u64)__builtin_popcountll(gm);
+    }
+}
+// final placement: sequence r's run [in_off[r], +ucount[r]) -> [out_off[r], ...); a group of 32 lanes per sequence
+__global__ void k_move_seqs(const u64 *tmp, const u64 *in_off, const u64 *out_off, const u64 *ucount, u64 n, u64 *out) {
+    const u64 g = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 5, ng = ((u64)gridDim.x * blockDim.x) >> 5;
+    const u32 gl = threadIdx.x & 31;
+    for (u64 r = g; r < n; r += ng) {
+        const u64 s0 = in_off[r], d0 = out_off[r], t = ucount[r];
+        for (u64 i = gl; i < t; i += 32) out[d0 + i] = tmp[s0 + i];
+    }
+}
+__global__ void k_max_count(const u64 *cnt, u64 n, u64 *mx) {
+    u64 m = 0;
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) m = cnt[r] > m ? cnt[r] : m;
+    for (int d = 32; d; d >>= 1) {
+        const u64 t = __shfl_xor(m, d, 64);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(mx, m);
+}
+
 int grid_of(bsk_ctx *ctx, u64 items, int block) {
     const u64 g = (items + block - 1) / block;
     return (int)std::max<u64>(1, std::min<u64>(g, (u64)ctx->cus * 16));
@@ -133,16 +201,21 @@ extern "C" int bsk_result_sets(bsk_ctx *ctx, const bsk_result *r, int scope, int
         if (e__ != hipSuccess) return done(fail_hip(ctx, e__, #call)); \
     } while (0)
     // 1. dense copy of the values, sequence after sequence
-    SCHK(hipMalloc(&cnt, (n + 1) * 8));
-    SCHK(hipMalloc(&offs, (n + 2) * 8));
-    SCHK(hipMemsetAsync(cnt, 0, (n + 1) * 8, st));
-    if (n) hipLaunchKernelGGL(k_counts, dim3(grid_of(ctx, n, 256)), dim3(256), 0, st, r->refs, r->wfirst, r->wcount, n, cnt);
+    SCHK(hipMalloc(&cnt, (n + 66) * 8));
+    SCHK(hipMalloc(&offs, (n + 66) * 8));  // (+64: the small-set path reads offs[64 * unit] of a last, partial unit)
+    SCHK(hipMemsetAsync(cnt, 0, (n + 66) * 8, st));
+    SCHK(hipMemsetAsync(ctx->d_total, 0, 8, st));
+    if (n) {
+        hipLaunchKernelGGL(k_counts, dim3(grid_of(ctx, n, 256)), dim3(256), 0, st, r->refs, r->wfirst, r->wcount, n, cnt);
+        hipLaunchKernelGGL(k_max_count, dim3(grid_of(ctx, n, 256)), dim3(256), 0, st, cnt, n, ctx->d_total);
+    }
     size_t tb = 0;
-    SCHK(rocprim::exclusive_scan(nullptr, tb, cnt, offs, (u64)0, n + 1, rocprim::plus<u64>(), st));
+    SCHK(rocprim::exclusive_scan(nullptr, tb, cnt, offs, (u64)0, n + 65, rocprim::plus<u64>(), st));
     SCHK(hipMalloc(&tmp, tb ? tb : 8));
-    SCHK(rocprim::exclusive_scan(tmp, tb, cnt, offs, (u64)0, n + 1, rocprim::plus<u64>(), st));
-    u64 N = 0;
+    SCHK(rocprim::exclusive_scan(tmp, tb, cnt, offs, (u64)0, n + 65, rocprim::plus<u64>(), st));
+    u64 N = 0, max_count = 0;
     SCHK(hipMemcpyAsync(&N, offs + n, 8, hipMemcpyDeviceToHost, st));
+    SCHK(hipMemcpyAsync(&max_count, ctx->d_total, 8, hipMemcpyDeviceToHost, st));
     SCHK(hipStreamSynchronize(st));
     (void)hipFree(tmp);
     tmp = nullptr;
@@ -159,6 +232,35 @@ extern "C" int bsk_result_sets(bsk_ctx *ctx, const bsk_result *r, int scope, int
     if (N == 0) {
         SCHK(hipMemsetAsync(res->offsets, 0, (n_sets + 1) * 8, st));
         SCHK(hipStreamSynchronize(st));
+        *out = res;
+        return done(BSK_OK);
+    }
+    if (scope == BSK_SETS_PER_SEQUENCE && max_count <= SMALL_CAP && !getenv("BSK_SETS_NO_SMALL")) {
+        // short reads: one sequence per group of 32 / 64 lanes, bitonic network across the lanes (k_sets_small)
+        u64 *ucount = nullptr, *ooffs = nullptr;
+        SCHK(hipMalloc(&vin, N * 8));                    // the sequences' distinct values at their input offsets
+        SCHK(hipMalloc(&keep, (n + 66) * 8));            // ucount (as u64)
+        SCHK(hipMalloc(&vsorted, (n + 66) * 8));         // output offsets
+        ucount = (u64 *)keep;
+        ooffs = vsorted;
+        SCHK(hipMemsetAsync(ucount, 0, (n + 66) * 8, st));
+        const unsigned sgrid = (unsigned)std::max<u64>(1, std::min<u64>((n + 7) / 8, (u64)ctx->cus * 32));
+        if (max_count <= 32)
+            hipLaunchKernelGGL(k_sets_small<32>, dim3(sgrid), dim3(256), 0, st, r->hash, r->refs, r->wfirst, r->wcount, offs, n, maxhash, vin, ucount);
+        else
+            hipLaunchKernelGGL(k_sets_small<64>, dim3(sgrid), dim3(256), 0, st, r->hash, r->refs, r->wfirst, r->wcount, offs, n, maxhash, vin, ucount);
+        SCHK(hipGetLastError());
+        SCHK(rocprim::exclusive_scan(nullptr, tb, ucount, ooffs, (u64)0, n + 1, rocprim::plus<u64>(), st));
+        SCHK(hipMalloc(&tmp, tb ? tb : 8));
+        SCHK(rocprim::exclusive_scan(tmp, tb, ucount, ooffs, (u64)0, n + 1, rocprim::plus<u64>(), st));
+        hipLaunchKernelGGL(k_move_seqs, dim3((unsigned)std::max<u64>(1, std::min<u64>((n + 7) / 8, (u64)ctx->cus * 32))), dim3(256), 0, st, vin, offs, ooffs, ucount, n,
+                           res->values);
+        SCHK(hipGetLastError());
+        SCHK(hipMemcpyAsync(res->offsets, ooffs, (n + 1) * 8, hipMemcpyDeviceToDevice, st));
+        u64 M = 0;
+        SCHK(hipMemcpyAsync(&M, ooffs + n, 8, hipMemcpyDeviceToHost, st));
+        SCHK(hipStreamSynchronize(st));
+        res->n_values = M;
         *out = res;
         return done(BSK_OK);
     }

@@ -61,6 +61,30 @@ for name, alpha, n, ln, p, okind, (k, x) in CASES:
     rows.append(row)
     print(json.dumps(row), flush=True)
     del res, b
+# f4: sketch SETS on the device (bsk_result_sets): sorted distinct hashes per sequence / per batch, plain and FracMinHash (scale 10)
+import ctypes as C  # noqa: E402
+for name, n, p in (("f4 sets of MinimizerSketch k=21 w=11, 10M reads", 10_000_000, eng.params(L.MINIMIZER, 21, w=11)),
+                   ("f4 sets of SyncmerSketch k=31 s=11, 12.5M reads", 12_500_000, eng.params(L.SYNCMER, 31, s=11))):
+    b = eng.synth(L.ALPHA_DNA, n, 150, 0x5EED0003)
+    res = eng.run(b, p)
+    T = res.info()["n_tuples"]
+    for scope, sname in ((L.SETS_PER_SEQUENCE, "per sequence"), (L.SETS_WHOLE_BATCH, "whole batch")):
+        for scale in (1, 10):
+            best, nv = 1e9, C.c_uint64()
+            for _ in range(3):
+                h = C.c_void_p()
+                eng.lib.bsk_ctx_sync(eng.ctx)
+                t = time.perf_counter()
+                eng._chk(eng.lib.bsk_result_sets(eng.ctx, res.h, scope, scale, C.byref(h)))
+                best = min(best, time.perf_counter() - t)
+                eng.lib.bsk_sets_info(h, None, C.byref(nv))
+                eng.lib.bsk_sets_release(h)
+            row = {"case": f"{name}, {sname}, scale {scale}", "tuples_in": T, "values_out": nv.value, "call_ms": round(best * 1e3, 3),
+                   "G_tuples_per_s": round(T / best / 1e9, 2), "algorithmic_GB": round((8 * T + 8 * nv.value + 16 * n) / 1e9, 3),
+                   "achieved_GBps": round((8 * T + 8 * nv.value + 16 * n) / best / 1e9, 1)}
+            rows.append(row)
+            print(json.dumps(row), flush=True)
+    del res, b
 if len(sys.argv) > 1:
     json.dump({"rows": rows, "note": "units = bases (DNA) or residues (protein); device-resident input/output"},
               open(sys.argv[1], "w"), indent=1)
