@@ -108,17 +108,20 @@ __global__ __launch_bounds__(64) void k_compact_flags(const u8 *rflags, u64 n, u
     }
 }
 // circular: read r' = read r + its first k-1 bases (iterator.go:642-646).  One thread per output word.
-__global__ void k_extend_packed(const u32 *words, const u64 *desc, const u64 *ndesc, u64 n, u64 n_words_new, u32 *out) {
+// Source / destination sequences are located by packed descriptors (desc: (first_word << 24) | bases) or, when a sequence has
+// 2^24 bases or more, by first-word + length arrays (fw / llen).
+__global__ void k_extend_packed(const u32 *words, const u64 *desc, const u64 *fw, const u64 *llen, const u64 *ndesc, const u64 *nfw,
+                                const u64 *nllen, u64 n, u64 n_words_new, u32 *out) {
     for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < n_words_new; g += (u64)gridDim.x * blockDim.x) {
         u64 lo = 0, hi = n - 1;
         while (lo < hi) {
             u64 mid = (lo + hi + 1) >> 1;
-            if ((ndesc[mid] >> 24) <= g) lo = mid;
+            if ((ndesc ? (ndesc[mid] >> 24) : nfw[mid]) <= g) lo = mid;
             else hi = mid - 1;
         }
-        const u64 L = desc[lo] & 0xffffffULL, L2 = ndesc[lo] & 0xffffffULL;
-        const u32 *src = words + (desc[lo] >> 24);
-        const u64 j0 = (g - (ndesc[lo] >> 24)) * 16;
+        const u64 L = desc ? (desc[lo] & 0xffffffULL) : llen[lo], L2 = ndesc ? (ndesc[lo] & 0xffffffULL) : nllen[lo];
+        const u32 *src = words + (desc ? (desc[lo] >> 24) : fw[lo]);
+        const u64 j0 = (g - (ndesc ? (ndesc[lo] >> 24) : nfw[lo])) * 16;
         u32 v = 0;
         for (u64 b = 0; b < 16 && j0 + b < L2; ++b) {
             u64 p = j0 + b;
@@ -1859,13 +1862,10 @@ extern "C" int bsk_sketch_timed(bsk_ctx *ctx, const bsk_batch *batch, const bsk_
 // (iterator.go:642-646, sketch.go:106-110,163-167).
 static int make_circular(bsk_ctx *ctx, const bsk_batch *b, int k, bsk_batch **out) {
     *out = nullptr;
-    if (!b->desc) {
-        ctx->err = "circular: sequences of 2^24 bases or more are not supported";
-        return BSK_ERR_UNSUPPORTED;
-    }
     const u64 n = b->n;
-    std::vector<u64> desc(n ? n : 1), nd(n ? n : 1);
-    if (n) HIPCHK(ctx, hipMemcpy(desc.data(), b->desc, n * 8, hipMemcpyDeviceToHost));
+    // lengths of the sequences: from the packed descriptors, or (a batch with a sequence of 2^24 bases or more) from llen
+    std::vector<u64> desc(n ? n : 1), nd(n ? n : 1), nl;
+    if (n) HIPCHK(ctx, hipMemcpy(desc.data(), b->desc ? b->desc : b->llen, n * 8, hipMemcpyDeviceToHost));
     bsk_batch *t = new (std::nothrow) bsk_batch();
     if (!t) return BSK_ERR_NOMEM;
     t->ctx = ctx;
@@ -1874,16 +1874,28 @@ static int make_circular(bsk_ctx *ctx, const bsk_batch *b, int k, bsk_batch **ou
     u64 w = 0, nb = 0;
     u32 maxlen = 0;
     std::vector<u64> nao(n + 1);
+    bool wide = false;  // the extended batch needs first-word / length arrays (it will run as tiles)
     for (u64 r = 0; r < n; ++r) {
-        const u64 L = desc[r] & 0xffffffULL;
+        const u64 L = b->desc ? (desc[r] & 0xffffffULL) : desc[r];
         const u64 ext = std::min<u64>(L, (u64)(k - 1));  // reads shorter than k-1 are ErrShortSeq anyway
+        if (L + ext >= (1ULL << 24)) wide = true;
+    }
+    if (wide) nl.resize(n);
+    for (u64 r = 0; r < n; ++r) {
+        const u64 L = b->desc ? (desc[r] & 0xffffffULL) : desc[r];
+        const u64 ext = std::min<u64>(L, (u64)(k - 1));
         const u64 L2 = L + ext;
-        if (L2 >= (1ULL << 24)) {
+        if (L2 >= (1ULL << 31)) {
             delete t;
-            ctx->err = "circular read too long";
+            ctx->err = "circular sequence too long (2^31 bases with its k-1 appended bases)";
             return BSK_ERR_UNSUPPORTED;
         }
-        nd[r] = (w << 24) | L2;
+        if (wide) {
+            nd[r] = w;
+            nl[r] = L2;
+        } else {
+            nd[r] = (w << 24) | L2;
+        }
         nao[r] = nb;
         w += (L2 + 15) / 16;
         nb += L2;
@@ -1897,17 +1909,20 @@ static int make_circular(bsk_ctx *ctx, const bsk_batch *b, int k, bsk_batch **ou
     t->uniform_len = (b->uniform_len && b->uniform_len >= (u32)(k - 1)) ? b->uniform_len + (u32)(k - 1) : 0;
     const u64 alloc_words = w + pad_words(maxlen);
     hipError_t e;
-    if ((e = hipMalloc(&t->words, alloc_words * 4)) != hipSuccess || (e = hipMalloc(&t->desc, (n ? n : 1) * 8)) != hipSuccess ||
+    if ((e = hipMalloc(&t->words, alloc_words * 4)) != hipSuccess || (e = hipMalloc(wide ? &t->fw : &t->desc, (n ? n : 1) * 8)) != hipSuccess ||
+        (wide && (e = hipMalloc(&t->llen, (n ? n : 1) * 8)) != hipSuccess) ||
         (e = hipMalloc(&t->rflags, n ? n : 1)) != hipSuccess ||
         (e = hipMemsetAsync(t->words, 0, alloc_words * 4, ctx->stream)) != hipSuccess ||
-        (n && (e = hipMemcpyAsync(t->desc, nd.data(), n * 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) ||
+        (n && (e = hipMemcpyAsync(wide ? t->fw : t->desc, nd.data(), n * 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) ||
+        (n && wide && (e = hipMemcpyAsync(t->llen, nl.data(), n * 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) ||
         (n && (e = hipMemcpyAsync(t->rflags, b->rflags, n, hipMemcpyDeviceToDevice, ctx->stream)) != hipSuccess)) {
         bsk_batch_destroy(t);
         return fail_hip(ctx, e, "make_circular alloc");
     }
     if (n && w)
-        hipLaunchKernelGGL(k_extend_packed, dim3(grid_for(ctx, w, 256)), dim3(256), 0, ctx->stream, b->words, b->desc, t->desc, n, w,
-                           t->words);
+        hipLaunchKernelGGL(k_extend_packed, dim3(grid_for(ctx, w, 256)), dim3(256), 0, ctx->stream, b->words, b->desc, b->fw, b->llen, t->desc,
+                           t->fw, t->llen, n, w, t->words);
+
     if (b->ascii && n) {  // batches with non-ACGT bytes are hashed from ASCII: extend that too
         if ((e = hipMalloc(&t->ascii, nb + BSK_ASCII_PAD)) != hipSuccess || (e = hipMalloc(&t->aoff, (n + 1) * 8)) != hipSuccess ||
             (e = hipMemcpyAsync(t->aoff, nao.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) {

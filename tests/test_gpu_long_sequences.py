@@ -214,8 +214,16 @@ def test_sequence_longer_than_2_pow_24(engine, oracle):
     from bio_amd import sketches as S
     with pytest.raises(S.DeviceError, match="2\\^2[34]"):  # refused by the 2^23-k-mer rule of the two-strand mode before the 2^24-base one
         engine.run(b, engine.params(L.KMER, 21, canonical=False))
-    with pytest.raises(S.DeviceError):
-        engine.run(b, engine.params(L.NTHASH, 21, circular=True))
+    # circular = true tiles too: the sequence with its first k-1 bases appended (iterator.go:642-646) is one more long sequence
+    rc = engine.run(b, engine.params(L.NTHASH, 21, circular=True))
+    st, h, _ = rc.read(1)
+    assert len(h) == n and np.array_equal(h, oracle.nthash(q, 21, True, True)[0])
+    rmc = engine.run(b, engine.params(L.MINIMIZER, 21, w=11, circular=True))
+    st, h, p = rmc.read(1)
+    eh, ep, es, fl = oracle.minimizer(q, 21, 11, True, closed=True)
+    assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep) and np.array_equal(p >> 31, es)
+    st, h, p = rmc.read(0)  # the 28-base neighbour stays ErrShortSeq: the length check is on the un-extended sequence (sketch.go:92)
+    assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0
 
 
 @pytest.mark.parametrize("tile_pos", [16, 48, 0])
