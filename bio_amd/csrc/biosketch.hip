@@ -898,6 +898,7 @@ struct Plan {
     size_t ring_entries = 0;
     u64 slab_read = 0;     // per-sequence slabs (protein fast path)
     int fast_k = 0;
+    bool fused_dna = false;  // protein minimizer of a 2-bit DNA batch: the kernel translates where it fetches its residues
     // mixed batch: the fast 2-bit kernel over all reads + the general ASCII kernel over the reads with a non-ACGT letter
     bool mixed = false;
     Which side_which = K_MIN_GEN_A;
@@ -911,6 +912,8 @@ static bool slab_budget_ok(const bsk_batch *b, u64 slab_read) {
     const double mean = b->n ? (double)b->n_bases / (double)b->n : 0.0;
     return (double)b->maxlen <= 4.0 * mean + 64.0 || (double)b->n * (double)slab_read * 12.0 < 256.0 * 1024 * 1024;
 }
+
+#define BSK_REPLAN_UNFUSED (-1000)  // internal: the fused DNA -> protein plan gave up, run the two-step path
 
 static bool which_is_fast(Which w) {
     return w == K_MIN_FAST || w == K_NT_FAST || w == K_SYN_FAST || w == K_SIM_FAST || w == K_MIN_DENSE || w == K_MIN_SEG || w == K_MIN_WPR;
@@ -1057,13 +1060,17 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             per_cu = blocks_per_cu(k_prot_hash);
         }
     } else if (p->kind == BSK_PROT_MINIMIZER) {
-        if (fast_prot_supported(p->w, p->k) && b->maxlen < 65536u && b->maxlen >= (u32)(p->k + p->w) && !getenv("BSK_FORCE_GENERIC") &&
-            !ctx->no_prot_fast && slab_budget_ok(b, (u64)b->maxlen)) {
+        // a DNA batch here means the fused plan (sketch_impl checked that it applies): lengths in residues
+        const u32 plen = b->alphabet == BSK_ALPHA_DNA ? (u32)translated_len(b->maxlen, 1) : b->maxlen;
+        if (b->alphabet == BSK_ALPHA_DNA && ctx->no_prot_fast) return BSK_REPLAN_UNFUSED;  // slabs too small / too large: sketch_impl translates first
+        if (b->alphabet == BSK_ALPHA_DNA || (fast_prot_supported(p->w, p->k) && b->maxlen < 65536u && b->maxlen >= (u32)(p->k + p->w) && !getenv("BSK_FORCE_GENERIC") &&
+            !ctx->no_prot_fast && slab_budget_ok(b, (u64)b->maxlen))) {
             pl.which = K_PROT_MIN_FAST;
+            pl.fused_dna = b->alphabet == BSK_ALPHA_DNA;
             pl.fast_w = p->w;
             pl.fast_k = p->k;
             pl.slab = true;
-            const u64 nwin = (u64)b->maxlen - p->k - p->w + 2;
+            const u64 nwin = plen >= (u32)(p->k + p->w) ? (u64)plen - p->k - p->w + 2 : 1;
             pl.slab_read = std::min<u64>(nwin, (u64)(nwin * 2.6 / (p->w + 1.0)) + 8);  // mean 2/(w+1) of the windows, +30 %
             pl.slab_read = (pl.slab_read + 15) & ~(u64)15;  // whole 128-byte lines of hashes per sequence
             pl.slab_unit = 64 * pl.slab_read;
@@ -1147,6 +1154,20 @@ extern "C" int bsk_codon_lut(int table, uint8_t *lut, uint64_t lut_bytes) {
 
 // Translate every sequence of a DNA batch into a new protein batch.  need != 0: sequences shorter than `need` bases are
 // flagged (rflags) so that the protein kernels report them as ErrShortSeq -- the reference checks the INPUT length.
+// the codon tables of `table` on the device (kernels_translate.hpp layout), cached per context
+static int ensure_lut(bsk_ctx *ctx, int table) {
+    if (ctx->lut_table == table && ctx->d_lut) return BSK_OK;
+    uint8_t lut[BSK_LUT_BYTES];
+    if (bsk_codon_lut(table, lut, sizeof lut) != BSK_OK) {
+        ctx->err = "invalid codon table";  // seq/seq.go:691
+        return BSK_ERR_ARG;
+    }
+    if (!ctx->d_lut) HIPCHK(ctx, hipMalloc(&ctx->d_lut, BSK_LUT_BYTES));
+    HIPCHK(ctx, hipMemcpy(ctx->d_lut, lut, BSK_LUT_BYTES, hipMemcpyHostToDevice));
+    ctx->lut_table = table;
+    return BSK_OK;
+}
+
 static int translate_batch(bsk_ctx *ctx, const bsk_batch *b, int table, int frame, u64 need, bsk_batch **out) {
     *out = nullptr;
     if (!b->desc) {
@@ -1157,16 +1178,8 @@ static int translate_batch(bsk_ctx *ctx, const bsk_batch *b, int table, int fram
         ctx->err = "invalid frame (available: 1, 2, 3, -1, -2, -3)";  // seq/seq.go:694
         return BSK_ERR_ARG;
     }
-    if (ctx->lut_table != table || !ctx->d_lut) {
-        uint8_t lut[BSK_LUT_BYTES];
-        if (bsk_codon_lut(table, lut, sizeof lut) != BSK_OK) {
-            ctx->err = "invalid codon table";  // seq/seq.go:691
-            return BSK_ERR_ARG;
-        }
-        if (!ctx->d_lut) HIPCHK(ctx, hipMalloc(&ctx->d_lut, BSK_LUT_BYTES));
-        HIPCHK(ctx, hipMemcpy(ctx->d_lut, lut, BSK_LUT_BYTES, hipMemcpyHostToDevice));
-        ctx->lut_table = table;
-    }
+    int rc0 = ensure_lut(ctx, table);
+    if (rc0 != BSK_OK) return rc0;
     bsk_batch *t = new (std::nothrow) bsk_batch();
     if (!t) return BSK_ERR_NOMEM;
     t->ctx = ctx;
@@ -1264,7 +1277,7 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
         case K_PROT_HASH: snprintf(b, sizeof b, "k_prot_hash"); break;
         case K_PROT_MIN: snprintf(b, sizeof b, "k_prot_minimizer"); break;
         case K_SYN_FAST: snprintf(b, sizeof b, "k_syncmer_fast<%d>", pl.fast_w); break;
-        case K_PROT_MIN_FAST: snprintf(b, sizeof b, "k_prot_minimizer_fast<%d,%d>", pl.fast_w, pl.fast_k); break;
+        case K_PROT_MIN_FAST: snprintf(b, sizeof b, "k_prot_minimizer_fast<%d,%d,%s>", pl.fast_w, pl.fast_k, pl.fused_dna ? "true" : "false"); break;
         case K_PROT_HASH_FAST: snprintf(b, sizeof b, "k_prot_hash_fast<%d>", pl.fast_k); break;
         case K_SIM_FAST:
             snprintf(b, sizeof b, "k_simhash_fast<%d,%d>", pl.fast_w, pl.fast_k == 1 ? BSK_SIM_SHORT_WORDS : pl.fast_k == 2 ? BSK_SIM_MID_WORDS : BSK_NT_FAST_WORDS);
@@ -1337,7 +1350,15 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_PROT_HASH: hipLaunchKernelGGL(k_prot_hash, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_PROT_MIN: hipLaunchKernelGGL(k_prot_minimizer, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_SYN_FAST: fast_syncmer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
-        case K_PROT_MIN_FAST: fast_prot_launch(pl.fast_w, pl.fast_k, pl.grid, ctx->stream, a); break;
+        case K_PROT_MIN_FAST:
+            if (pl.fused_dna) {
+                a.frame = p->frame;
+                a.lut = ctx->d_lut;
+                fast_prot_dna_launch(pl.fast_w, pl.fast_k, pl.grid, ctx->stream, a);
+            } else {
+                fast_prot_launch(pl.fast_w, pl.fast_k, pl.grid, ctx->stream, a);
+            }
+            break;
         case K_PROT_HASH_FAST: fast_prot_hash_launch(pl.fast_k, pl.grid, ctx->stream, a); break;
         case K_SIM_FAST:
             if (pl.fast_k == 1) {
@@ -1808,12 +1829,26 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
     bsk_batch *tmp = nullptr;
     int circ_ext = 0;
     const bool prot_kind = p->kind == BSK_PROT_HASH || p->kind == BSK_PROT_MINIMIZER;
+    bool fused = false;
     if (batch->alphabet == BSK_ALPHA_DNA && prot_kind) {
         // iterator-protein.go:50,62-67 / sketch-protein.go:66-75,83-88: length checks on the nucleotides, then Translate
-        const u64 need = (u64)p->k * 3 + (p->kind == BSK_PROT_MINIMIZER ? (u64)p->w - 1 : 0);
-        rc = translate_batch(ctx, batch, p->codon_table, p->frame, need, &tmp);
-        if (rc != BSK_OK) return rc;
-        b = tmp;
+        if (p->frame < -3 || p->frame > 3 || p->frame == 0) {
+            ctx->err = "invalid frame (available: 1, 2, 3, -1, -2, -3)";  // seq/seq.go:694
+            return BSK_ERR_ARG;
+        }
+        // pure-ACGT 2-bit batches and a compiled (w, k): the protein minimizer kernel translates on the fly (no translated copy)
+        fused = p->kind == BSK_PROT_MINIMIZER && batch->desc && batch->n_nonacgt == 0 && fast_prot_supported(p->w, p->k) &&
+                translated_len(batch->maxlen, 1) < 65536u && !getenv("BSK_FORCE_GENERIC") && !getenv("BSK_NO_FUSED_TRANSLATE") && !ctx->no_prot_fast &&
+                slab_budget_ok(batch, (u64)translated_len(batch->maxlen, 1));
+        if (fused) {
+            rc = ensure_lut(ctx, p->codon_table);
+            if (rc != BSK_OK) return rc;
+        } else {
+            const u64 need = (u64)p->k * 3 + (p->kind == BSK_PROT_MINIMIZER ? (u64)p->w - 1 : 0);
+            rc = translate_batch(ctx, batch, p->codon_table, p->frame, need, &tmp);
+            if (rc != BSK_OK) return rc;
+            b = tmp;
+        }
     } else if (p->circular && p->k > 1 && batch->alphabet == BSK_ALPHA_DNA) {
         rc = make_circular(ctx, batch, p->k, &tmp);
         if (rc != BSK_OK) return rc;
@@ -1844,6 +1879,14 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
     const bool tiled = kind_tiles(p) && (is_dna != prot_kind) && !getenv("BSK_NO_TILES") && ((is_dna && !b->desc) || b->maxlen > tile_min || outlier);
     rc = tiled ? sketch_tiled(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms)
                : run_planned(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms);
+    if (rc == BSK_REPLAN_UNFUSED && fused) {  // unusual density (a sequence outgrew its slab) or slabs that do not fit: translate, then sketch
+        ctx->no_prot_fast = false;
+        const u64 need = (u64)p->k * 3 + (u64)p->w - 1;
+        rc = translate_batch(ctx, batch, p->codon_table, p->frame, need, &tmp);
+        if (rc != BSK_OK) return rc;
+        const bool tiled2 = kind_tiles(p) && !getenv("BSK_NO_TILES") && tmp->maxlen > tile_min;
+        rc = tiled2 ? sketch_tiled(ctx, tmp, p, 0, result, warmup, iters, kernel_ms) : run_planned(ctx, tmp, p, 0, result, warmup, iters, kernel_ms);
+    }
     if (tmp) bsk_batch_destroy(tmp);
     return rc;
 }

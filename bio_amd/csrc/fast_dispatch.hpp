@@ -32,6 +32,7 @@ void fast_syncmer_launch(int w, int grid, hipStream_t stream, const KArgs &a);
 bool fast_prot_supported(int w, int k);
 int fast_prot_blocks_per_cu(int w, int k);
 void fast_prot_launch(int w, int k, int grid, hipStream_t stream, const KArgs &a);
+void fast_prot_dna_launch(int w, int k, int grid, hipStream_t stream, const KArgs &a);  // 2-bit DNA batch, translation fused in
 
 bool fast_prot_hash_supported(int k);
 int fast_prot_hash_blocks_per_cu(int k);

@@ -51,6 +51,9 @@ struct KArgs {
     u64 nsub;
     u64 out_base;
     int inplace;  // side launch of a stream kind: every read already owns its line-padded run (refs of the main launch)
+    // protein kinds fed with 2-bit DNA (translation fused into the residue fetch, kernels_protein.hpp)
+    int frame;       // 1,2,3,-1,-2,-3
+    const u8 *lut;   // device codon tables of the context (kernels_translate.hpp layout)
 };
 
 // read handled by (unit, lane): the batch position, or the subset entry of a side launch (~0 = no read)

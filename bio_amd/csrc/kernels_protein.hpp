@@ -15,6 +15,7 @@
 #pragma once
 #include "kernels_fast.hpp"
 #include "kernels_more.hpp"
+#include "kernels_translate.hpp"
 
 namespace bsk {
 
@@ -131,14 +132,27 @@ struct FastProt {
     }
 };
 
-template <int W, int K>
+// DNA: the batch is 2-bit packed DNA and the residues are translated where they are fetched (Translate with the constructor's
+// arguments, sketch-protein.go:83-88): a dword of four residues is 12 bases = one 24-bit field of the packed stream, and a
+// codon's amino acid is one byte of a 64-entry LDS table indexed by the codon's raw 6 bits (one table for the plus frames, one
+// with the reverse-complemented codons for the minus frames, which walk the sequence downwards).  ~5 instructions per residue
+// on top of ~60 for its hash and window; no translated copy of the batch ever exists.
+typedef u64 u64_a4 __attribute__((aligned(4)));
+template <int W, int K, bool DNA = false>
 __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
     typedef FastProt<W, K> FP;
     constexpr int MB = FP::MB, GL = FP::GL, G = FP::G, HS = FP::HS;
     typedef typename FP::LY LY;
-    __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
+    __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL + (DNA ? 64 : 0)];
     LDSQ char *const ldsq = (LDSQ char *)lds;
     const int lane = lane_id();
+    const int frame = a.frame;
+    if (DNA) {  // amino acid of the codon whose three bases, lowest position first, are the 2-bit codes b0 b1 b2 of `six`
+        const u32 six = (u32)lane, b0 = six & 3, b1 = (six >> 2) & 3, b2 = six >> 4;
+        const u32 idx = frame > 0 ? (b0 << 4) | (b1 << 2) | b2 : ((b2 ^ 3) << 4) | ((b1 ^ 3) << 2) | (b0 ^ 3);
+        reinterpret_cast<u8 *>(lds + LY::TOTAL)[lane] = a.lut[4096 + 256 + idx];
+        __syncthreads();
+    }
     const u64 slab_read = a.slab_read;  // tuples reserved per sequence
     for (u32 unit = next_ticket(a.ticket, lane) * 4u, uend = unit + 4u; unit < a.nunits; ++unit, ({
              if (unit == uend) {
@@ -148,10 +162,20 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
          })) {
         const u64 r = (u64)unit * 64 + lane;
         u64 off = 0, L = 0;
-        if (r < a.n) {
-            ascii_span(a, r, off, L);
+        u32 Lnt = 0;  // DNA: nucleotides of the sequence
+        bool ok;
+        if (DNA) {
+            if (r < a.n) {
+                const u64 d = a.desc[r];
+                off = d >> 24;
+                Lnt = (u32)(d & 0xffffffULL);
+            }
+            ok = r < a.n && (u64)Lnt >= (u64)K * 3 + (u64)W - 1;  // sketch-protein.go:66,73: on the nucleotide length
+            L = translated_len((u64)Lnt, frame);                   // codon_tables.go:224,256
+        } else {
+            if (r < a.n) ascii_span(a, r, off, L);
+            ok = r < a.n && prot_len_ok(a, r, L, (u64)K * 3 + (u64)W - 1);  // sketch-protein.go:66,73
         }
-        const bool ok = r < a.n && prot_len_ok(a, r, L, (u64)K * 3 + (u64)W - 1);  // sketch-protein.go:66,73
         const u32 nk = (ok && L >= (u64)K + (u64)W - 1) ? (u32)(L - K + 1) : 0u;
         const u32 nk_max = wave_max_u32(nk);
         u32 done = 0;  // tuples of this lane already in HBM
@@ -169,8 +193,33 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
             // 6 wavefronts per CU walking 64 sequences each, the 48 KB of lines do not stay in the 32 KB L1.
             const u8 *p0 = a.ascii + off;
             const size_t gp0 = (size_t)p0;
+            const u32 *const wseq = a.words + off;
+            const LDSQ u8 *const aat = reinterpret_cast<const LDSQ u8 *>(ldsq + LY::TOTAL);
+            // DNA: residue dword jd = residues 4jd .. 4jd+3 = 12 bases = one 24-bit field F of the packed stream, lowest base `lo`.
+            // Plus frames: residue t is F's bits [6t, 6t+6).  Minus frames walk downwards: residue t's codon ends 3t bases below the
+            // field's top base Lnt + frame - 12 jd, so it is bits [18-6t, 24-6t) (complemented and reversed by the table); a field
+            // that starts before base 0 (the sequence's last residues) is shifted up instead of moved.
+            auto dna_lo = [&](u32 jd) -> int { return frame > 0 ? (frame - 1) + 12 * (int)jd : (int)Lnt + frame - 12 * (int)jd - 11; };
+            auto dna_issue = [&](u32 jd) -> u64 {  // the two packed words that hold the field (requested early: see the block loop)
+                int lo = dna_lo(jd);
+                lo = lo < 0 ? 0 : (lo > (int)Lnt ? (int)Lnt : lo);  // (fields wholly past the end are never hashed; stay inside the buffer)
+                return *reinterpret_cast<const GLBQ u64_a4 *>((size_t)(wseq + ((u32)lo >> 4)));
+            };
+            auto dna_finish = [&](u64 two, u32 jd) -> u32 {
+                int lo = dna_lo(jd);
+                u32 F;
+                if (lo < 0) F = (u32)(two << (2u * (u32)(lo < -12 ? 12 : -lo)));
+                else F = (u32)(two >> (((u32)(lo > (int)Lnt ? (int)Lnt : lo) & 15u) * 2u));
+                if (frame > 0) return (u32)aat[F & 63u] | ((u32)aat[(F >> 6) & 63u] << 8) | ((u32)aat[(F >> 12) & 63u] << 16) | ((u32)aat[(F >> 18) & 63u] << 24);
+                return (u32)aat[(F >> 18) & 63u] | ((u32)aat[(F >> 12) & 63u] << 8) | ((u32)aat[(F >> 6) & 63u] << 16) | ((u32)aat[F & 63u] << 24);
+            };
             auto load_dwords = [&](u32 *dst, int ndw, u32 j) {  // dwords j .. j+ndw-1 of the sequence (bytes 4j ..)
                 int g = 0;
+                if (DNA) {
+#pragma unroll
+                    for (; g < ndw; ++g) dst[g] = dna_finish(dna_issue(j + (u32)g), j + (u32)g);
+                    return;
+                }
                 for (; g + 4 <= ndw; g += 4) {
                     const u64 bo = (u64)4 * (j + g) < L ? (u64)4 * (j + g) : L;  // never start beyond the sequence (+ buffer slack)
                     const u32x4 v = *reinterpret_cast<const GLBQ u32x4_u *>(gp0 + bo);
@@ -203,6 +252,11 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
                 done += nfl;
             };
             for (u32 i0 = 0; i0 < nk_max; i0 += MB) {
+                u64 raw[MB / 4];  // DNA: the next macro block's packed words are requested here, a whole block of hashing ahead of their use
+                if (DNA) {
+#pragma unroll
+                    for (int g = 0; g < MB / 4; ++g) raw[g] = dna_issue(dj + (u32)g);
+                }
                 if (HS < MB) {
                     if (i0 == 0) fp.template macro<true, 0, HS>(i0);
                     else fp.template macro<false, 0, HS>(i0);
@@ -217,7 +271,12 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
                 for (int g = 0; g < 5; ++g) fp.R[g] = fp.R[g + MB / 4];
                 // residues of the NEXT macro block: requested and waited for BEFORE this round's flush stores are
                 // issued (vmcnt is in-order: a load issued after the stores could only be waited for together with them)
-                load_dwords(fp.R + 5, MB / 4, dj);
+                if (DNA) {
+#pragma unroll
+                    for (int g = 0; g < MB / 4; ++g) fp.R[5 + g] = dna_finish(raw[g], dj + (u32)g);
+                } else {
+                    load_dwords(fp.R + 5, MB / 4, dj);
+                }
                 dj += MB / 4;
 #pragma unroll
                 for (int g = 0; g < MB / 4; ++g) asm volatile("" ::"v"(fp.R[5 + g]));
@@ -233,7 +292,9 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
 }
 
 #ifdef BSK_IMPL_PROTEIN
-#define BSK_PROT_KW(X) X(5, 9) X(5, 10) X(3, 10) X(4, 12) X(3, 9) X(4, 9) X(4, 10) X(5, 12) X(8, 9) X(8, 10) X(3, 12) X(5, 14)
+// every window 2..8 with every k 9..16 (the register wyhash covers 9..16 residues), protein-fed and DNA-fed
+#define BSK_PROT_K(X, WW) X(WW, 9) X(WW, 10) X(WW, 11) X(WW, 12) X(WW, 13) X(WW, 14) X(WW, 15) X(WW, 16)
+#define BSK_PROT_KW(X) BSK_PROT_K(X, 2) BSK_PROT_K(X, 3) BSK_PROT_K(X, 4) BSK_PROT_K(X, 5) BSK_PROT_K(X, 6) BSK_PROT_K(X, 7) BSK_PROT_K(X, 8)
 bool fast_prot_supported(int w, int k) {
 #define X(WW, KK) \
     if (w == WW && k == KK) return true;
@@ -245,7 +306,7 @@ int fast_prot_blocks_per_cu(int w, int k) {
     int nb = 0;
     hipError_t e = hipErrorInvalidValue;
 #define X(WW, KK) \
-    if (w == WW && k == KK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_prot_minimizer_fast<WW, KK>, 64, 0);
+    if (w == WW && k == KK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_prot_minimizer_fast<WW, KK, false>, 64, 0);
     BSK_PROT_KW(X)
 #undef X
     if (e != hipSuccess || nb < 1) {
@@ -256,7 +317,13 @@ int fast_prot_blocks_per_cu(int w, int k) {
 }
 void fast_prot_launch(int w, int k, int grid, hipStream_t stream, const KArgs &a) {
 #define X(WW, KK) \
-    if (w == WW && k == KK) hipLaunchKernelGGL((k_prot_minimizer_fast<WW, KK>), dim3(grid), dim3(64), 0, stream, a);
+    if (w == WW && k == KK) hipLaunchKernelGGL((k_prot_minimizer_fast<WW, KK, false>), dim3(grid), dim3(64), 0, stream, a);
+    BSK_PROT_KW(X)
+#undef X
+}
+void fast_prot_dna_launch(int w, int k, int grid, hipStream_t stream, const KArgs &a) {  // 2-bit DNA in, translated on the fly
+#define X(WW, KK) \
+    if (w == WW && k == KK) hipLaunchKernelGGL((k_prot_minimizer_fast<WW, KK, true>), dim3(grid), dim3(64), 0, stream, a);
     BSK_PROT_KW(X)
 #undef X
 }

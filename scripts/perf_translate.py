@@ -23,3 +23,12 @@ print(f"DNA-fed protein minimizer (translate + sketch) wall ms first {t1*1e3:.1f
 tb = b.translate(1, 1)
 res2, ms = eng.run_timed(tb, p, 1, 3)
 print("protein-batch sketch kernel ms", [round(m, 3) for m in ms], "tuples", res2.info()["n_tuples"])
+# fused (the kernel translates where it fetches residues) against the two-step path, same digest
+res_f, ms_f = eng.run_timed(b, p, 1, 3)
+os.environ["BSK_NO_FUSED_TRANSLATE"] = "1"
+t = time.time(); res_u = eng.run(b, p); t3 = time.time() - t
+t = time.time(); res_u = eng.run(b, p, res_u); t4 = time.time() - t
+del os.environ["BSK_NO_FUSED_TRANSLATE"]
+print("fused DNA-fed kernel ms", [round(m, 3) for m in ms_f], res_f.plan()["kernel"], "| two-step call wall ms", round(t4 * 1e3, 2), res_u.plan()["kernel"])
+assert res_f.digest() == res_u.digest() == res2.digest(), (res_f.digest(), res_u.digest(), res2.digest())
+print("digests equal:", res_f.digest())

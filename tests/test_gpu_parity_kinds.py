@@ -372,3 +372,39 @@ def test_long_outliers_do_not_inflate_per_read_slabs(engine, oracle):
         st, h, p = res.read(i)
         eh, ep, es, _ = oracle.minimizer(dna[i], 21, 5, False, closed=True)
         assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep), i
+
+
+@pytest.mark.parametrize("w", [2, 3, 4, 5, 6, 7, 8])
+def test_protein_minimizer_register_kernel_whole_grid(engine, oracle, w):
+    """Every window 2..8 with every k 9..16 runs on k_prot_minimizer_fast<W,K> -- protein-fed and, for 2-bit DNA batches, with the
+    translation fused into its residue fetch (all six frames): both against the oracle, and the plan is the register kernel."""
+    for k in range(9, 17):
+        rng = random.Random(w * 100 + k)
+        prot = [rand_seq(rng, rng.choice([300, rng.randint(1, 500)]), AA) for _ in range(70)] + ["A" * 90, rand_seq(rng, 3 * k + w - 1, AA)]
+        b = engine.batch(prot, L.ALPHA_PROTEIN)
+        res = engine.run(b, engine.params(L.PROT_MINIMIZER, k, w=w))
+        assert f"k_prot_minimizer_fast<{w},{k},false>" in res.plan()["kernel"], res.plan()
+        for i, q in enumerate(prot):
+            st, h, p = res.read(i)
+            try:
+                eh, ep, fl = oracle.protein_minimizer(q, k, w, closed=True)
+            except oracle.OracleError:
+                assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0
+            else:
+                assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep) and (st & 0xF0) == fl, (w, k, i)
+        b.close()
+        frame = (1, 2, 3, -1, -2, -3)[(w + k) % 6]
+        dna = [rand_seq(rng, n) for n in (3 * k - 1, 3 * k, 3 * k + w - 2, 3 * k + w - 1, 3 * (k + w) + 1, 36 * 4 + frame % 3, 900, 901, 902)]
+        dna += [rand_seq(rng, rng.randint(1, 1500)) for _ in range(60)]
+        bd = engine.batch(dna)
+        rd = engine.run(bd, engine.params(L.PROT_MINIMIZER, k, w=w, codon_table=1 + (k % 2) * 10, frame=frame))
+        assert f"k_prot_minimizer_fast<{w},{k},true>" in rd.plan()["kernel"], rd.plan()
+        for i, q in enumerate(dna):
+            st, h, p = rd.read(i)
+            try:
+                eh, ep, fl = oracle.protein_minimizer_nt(q, k, w, 1 + (k % 2) * 10, frame)
+            except oracle.OracleError:
+                assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0, (w, k, frame, i, len(q))
+            else:
+                assert (st & L.ST_CODE_MASK) == 0 and np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep), (w, k, frame, i, len(q))
+        bd.close()
