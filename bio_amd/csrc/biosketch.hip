@@ -1439,7 +1439,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
                        float *kernel_ms) {
     int rc = BSK_OK;
     if (!b->desc && b->alphabet == BSK_ALPHA_DNA) {
-        ctx->err = "sequences of 2^24 bases or more are only supported by the kinds that tile (not: two-strand k-mer codes, s == k syncmers)";
+        ctx->err = "sequences of 2^24 bases or more are only supported by the kinds that tile (not: two-strand k-mer codes)";
         return BSK_ERR_UNSUPPORTED;
     }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1570,7 +1570,7 @@ static bool kind_tiles(const bsk_params *p) {
         case BSK_SIMHASH:
         case BSK_MINIMIZER: return true;
         case BSK_KMER: return p->canonical != 0;  // the two-strand mode walks the reverse strand backwards (iterator.go:713-723)
-        case BSK_SYNCMER: return p->s < p->k;     // s == k emits every k-mer with its own end rule (sketch.go:328-331)
+        case BSK_SYNCMER: return true;            // (s == k, "every k-mer", runs as the w = 1 minimizer: sketch_tiled)
         case BSK_PROT_HASH:
         case BSK_PROT_MINIMIZER: return true;
         default: return false;
@@ -1589,8 +1589,18 @@ static u32 tile_positions(const bsk_params *p) {
     return tp;
 }
 
-static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, int circ_ext, bsk_result **result, int warmup, int iters,
+static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in, int circ_ext, bsk_result **result, int warmup, int iters,
                         float *kernel_ms) {
+    // a syncmer sketch with s == k yields every k-mer with its index (sketch.go:328-331) -- exactly the minimizer sketch with
+    // w = 1 (sketch.go:218-222), and both refuse a sequence shorter than k (the syncmer through its hasher, sketch.go:179-182):
+    // tiles run it as that
+    bsk_params pw1 = *p_in;
+    const bool syn_all = p_in->kind == BSK_SYNCMER && p_in->s == p_in->k;
+    if (syn_all) {
+        pw1.kind = BSK_MINIMIZER;
+        pw1.w = 1;
+    }
+    const bsk_params *p = &pw1;
     const u64 n = b->n;
     TileGeo geo;
     geo.kind = p->kind;
@@ -1746,7 +1756,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, i
     if (!fin) return done(BSK_ERR_NOMEM);
     fin->ctx = ctx;
     fin->n = n;
-    fin->kind = p->kind;
+    fin->kind = p_in->kind;
     fin->has_pos = stream ? 0 : 1;
     TCHK(hipMalloc(&fin->status, n ? n : 1));
     TCHK(hipMalloc(&fin->wfirst, (n ? n : 1) * 8));

@@ -223,10 +223,11 @@ int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t first, uint64_t
  * the tile results back (exactly the tuples of the un-tiled iterator).  Such a result is
  * "wide": a sequence can own more than 2^24 tuples, so *refs is NULL and bsk_result_device_wide returns
  * first[n] / count[n] instead (u64 each).  bsk_result_fetch / bsk_result_digest work for both layouts.
- * circular = 1 tiles as well (the sequence with its first k-1 bases appended is one more long sequence).
- * Not tiled (sequences of 2^24 bases or more -- 2^23 k-mers for the first -- are refused with BSK_ERR_UNSUPPORTED): the
- * two-strand k-mer mode (KMER with canonical = 0: the second strand walks the sequence backwards, iterator.go:713-723),
- * syncmers with s == k (every k-mer, with its own end rule, sketch.go:328-331), translation of such a sequence. */
+ * circular = 1 tiles as well (the sequence with its first k-1 bases appended is one more long sequence), and so do syncmers
+ * with s == k (every k-mer with its index, sketch.go:328-331: the w = 1 minimizer).
+ * Not tiled (refused with BSK_ERR_UNSUPPORTED): the two-strand k-mer mode (KMER with canonical = 0: the second strand walks
+ * the sequence backwards, iterator.go:713-723) from 2^23 k-mers per sequence on, and the translation of a single sequence
+ * of 2^24 bases or more. */
 int bsk_result_device(const bsk_result *r, const uint64_t **refs, const uint8_t **status,
                       const uint64_t **hash, const uint32_t **pos);
 int bsk_result_device_wide(const bsk_result *r, const uint64_t **first, const uint64_t **count);

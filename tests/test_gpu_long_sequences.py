@@ -76,7 +76,7 @@ def test_minimizer_tiled(engine, oracle, tiny_tiles, k, w, tile_pos):
 
 
 @pytest.mark.parametrize("tile_pos", [16, 64, 0])
-@pytest.mark.parametrize("k,s", [(31, 11), (31, 16), (5, 2), (15, 14), (21, 1), (64, 33), (11, 6)])
+@pytest.mark.parametrize("k,s", [(31, 11), (31, 16), (5, 2), (15, 14), (21, 1), (64, 33), (11, 6), (9, 9), (31, 31)])
 def test_syncmer_tiled(engine, oracle, tiny_tiles, k, s, tile_pos):
     tiny_tiles(40, tile_pos)
     rng = random.Random(k * 100 + s + tile_pos)
@@ -214,6 +214,10 @@ def test_sequence_longer_than_2_pow_24(engine, oracle):
     from bio_amd import sketches as S
     with pytest.raises(S.DeviceError, match="2\\^2[34]"):  # refused by the 2^23-k-mer rule of the two-strand mode before the 2^24-base one
         engine.run(b, engine.params(L.KMER, 21, canonical=False))
+    rs = engine.run(b, engine.params(L.SYNCMER, 15, s=15))  # s == k: every k-mer with its index (runs as the w = 1 minimizer over tiles)
+    st, h, p = rs.read(1)
+    eh, ep, es, fl = oracle.syncmer(q, 15, 15, False, closed=True)
+    assert len(h) == n - 14 and np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep) and np.array_equal(p >> 31, es)
     # circular = true tiles too: the sequence with its first k-1 bases appended (iterator.go:642-646) is one more long sequence
     rc = engine.run(b, engine.params(L.NTHASH, 21, circular=True))
     st, h, _ = rc.read(1)
