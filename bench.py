@@ -249,6 +249,7 @@ def main():
     eng = batch = res = None
     kernel_ms = []
     plan = {"kernel": "none (plumbing-only)", "grid": 0, "waves_per_cu": 0}
+    gather_via = "bsk_gather_counts (RCCL)"
     if args.plumbing_only:
         barrier()
         barrier()
@@ -259,10 +260,19 @@ def main():
 
         seed = 0x5EED0000 + 3 + 0x1000000 * rank  # each rank hashes its own shard of the synthetic stream
         eng = S.Engine(local_rank)
+        gather_via = "bsk_gather_counts (RCCL)"
         if world > 1:  # the communicator of the one collective: RCCL behind the C ABI; the id travels over the launcher's store
-            uid = [eng.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            eng.comm_init_rank(uid[0], rank, world)
+            try:
+                uid = [eng.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                eng.comm_init_rank(uid[0], rank, world)
+            except Exception as e:  # never lose the run to plumbing: fall back to the launcher's own collective, and say so
+                gather_via = f"torch.distributed all_gather (bsk_comm_init_rank failed: {e!r})"
+            # every rank must take the same path
+            flag = torch.tensor([0 if gather_via.startswith("bsk") else 1], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()) and gather_via.startswith("bsk"):
+                gather_via = "torch.distributed all_gather (another rank could not join the bsk communicator)"
         batch = eng.synth(L.ALPHA_PROTEIN if kind in PROTEIN else L.ALPHA_DNA, n_reads, read_len, seed)
         p = {"min": lambda: eng.params(L.MINIMIZER, k, w=x), "nt": lambda: eng.params(L.NTHASH, k), "syn": lambda: eng.params(L.SYNCMER, k, s=x),
              "pmin": lambda: eng.params(L.PROT_MINIMIZER, k, w=x), "kmer": lambda: eng.params(L.KMER, k),
@@ -287,8 +297,13 @@ def main():
         outl = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(outl, t)
         rows = [[int(v) for v in o.tolist()] for o in outl]
-    else:
+    elif gather_via.startswith("bsk"):
         rows = eng.gather_counts(mine)  # bsk_gather_counts: RCCL all_gather
+    else:
+        t = torch.tensor(mine, dtype=torch.int64, device=dev)
+        outl = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(outl, t)
+        rows = [[int(v) for v in o.tolist()] for o in outl]
     from bio_amd.shard import whole_job
     job = whole_job([[r[0] / 1e9, float(r[1]), float(r[2])] for r in rows], args.steps)
     dt_max, bases_total, tuples_total = job["seconds"], job["bases"], job["tuples"]
@@ -320,7 +335,7 @@ def main():
                        "first_window_tie_reads": int(sum(r[3] for r in rows)), "non_acgt_reads": int(sum(r[4] for r in rows)),
                        "per_rank_seconds": [round(r[0] / 1e9, 6) for r in rows],
                        "parallelism": f"reads sharded by record over {world} GPU(s), no data-path collective; counters gathered by "
-                                      + ("bsk_gather_counts (RCCL)" if world > 1 and not args.plumbing_only else "torch gloo (plumbing-only)" if world > 1 else "nothing (1 GPU)"),
+                                      + (gather_via if world > 1 and not args.plumbing_only else "torch gloo (plumbing-only)" if world > 1 else "nothing (1 GPU)"),
                        "input": ("residues (1 B each)" if kind in PROTEIN else "2-bit packed reads") + " resident in HBM",
                        "output": ("hash u64 per position" if kind in STREAM else "hash u64 + pos|strand u32") + " + u64 index per read, in HBM"},
         }
