@@ -83,3 +83,31 @@ def test_pipeline_reports_reader_errors(tmp_path):
         f.write("@r1\nACGTACGTACGTACGTACGTACGTACGT\n+\nIIII\n")  # quality shorter than the sequence
     with pytest.raises(S.DeviceError):
         S.Engine.pipeline_fastx(path, S.Engine.params(L.NTHASH, 5), n_streams=2, chunk_records=10)
+
+
+def test_pipeline_and_refill_protein(engine, tmp_path):
+    """Protein FASTA through the pipeline (alphabet guessed from the first record, as the reference's reader does) and protein chunks
+    through one re-filled batch object."""
+    rng = random.Random(9)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    seqs = ["".join(rng.choice(aa) for _ in range(rng.randint(5, 420))) for _ in range(5000)]
+    path = str(tmp_path / "prot.fa")
+    with open(path, "w") as f:
+        for i, s in enumerate(seqs):
+            f.write(">p%d\n" % i)
+            for j in range(0, len(s), 60):  # multi-line FASTA
+                f.write(s[j:j + 60] + "\n")
+    p = engine.params(L.PROT_MINIMIZER, 9, w=5)
+    want = engine.run(engine.batch(seqs, L.ALPHA_PROTEIN), p).digest()
+    st = S.Engine.pipeline_fastx(path, p, n_streams=2, chunk_records=700, fetch=True)
+    assert (st["records"], st["tuples"], st["checksum"]) == (5000, want["n_tuples"], want["checksum"])
+    h = C.c_void_p()
+    for lo, hi in ((0, 900), (900, 1000), (1000, 5000)):
+        chunk = seqs[lo:hi]
+        data = np.frombuffer("".join(chunk).encode(), np.uint8)
+        offs = np.zeros(len(chunk) + 1, np.uint64)
+        offs[1:] = np.cumsum([len(s) for s in chunk])
+        engine._chk(engine.lib.bsk_batch_refill_ascii(engine.ctx, C.byref(h), data.ctypes.data, offs.ctypes.data, len(chunk), L.ALPHA_PROTEIN))
+        got = S.BatchResult(engine, *_run(engine, h, p)).digest()
+        assert got == engine.run(engine.batch(chunk, L.ALPHA_PROTEIN), p).digest(), (lo, hi)
+    engine.lib.bsk_batch_destroy(h)
