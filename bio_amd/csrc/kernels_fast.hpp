@@ -116,7 +116,8 @@ struct FLds {
     static constexpr int NZ = HEADS + (CAP + 1) * 8;  // u8 [64]: rank among non-empty lanes -> lane
     static constexpr int DST = NZ + 64;               // u32 [64] + u32 [64] ring heads: flush_rows (kernels with per-read slabs)
     static constexpr int ROWS = CAP + 1;
-    static constexpr int TOTAL = DST + 512;
+    static constexpr int TAB2 = DST + 512;            // 16 x uint4: warm-up table of two bases (build_xtab2)
+    static constexpr int TOTAL = TAB2 + 256;
 };
 
 // Paired staging columns (k_minimizer_fast): lanes l and l+32 share column l & 31 of R rows; the low lane fills it from row
@@ -138,7 +139,8 @@ struct PLds {
     static constexpr int NHEADS = (32 * (R - 1)) / 64 + 2;                 // a unit holds at most 32*(R-1) tuples; the last word is never set
     static constexpr int NZ = HEADS + NHEADS * 8;                          // u8 [64]
     static constexpr int EXCL = SH + R * ROW * 8;                          // u32 [64] in the spare row (free once the pass is over)
-    static constexpr int TOTAL = NZ + 64;
+    static constexpr int TAB2 = NZ + 64;                                   // 16 x uint4: warm-up table of two bases (build_xtab2)
+    static constexpr int TOTAL = TAB2 + 256;
 };
 template <bool PAIR, int CAP, bool POS16, int PR>
 struct MinLds {
@@ -157,6 +159,7 @@ struct FastMin {
     static constexpr u32 SBIT = POS16 ? 0x8000u : 0x80000000u;  // strand bit inside the staged pos word
     const u32 *__restrict__ w;
     LDSQ char *lds;
+    static constexpr bool USE_T2 = PAIR && !RING && !DIRECT && XCH == 0;  // k_minimizer_fast's staged pass builds the two-base warm-up table
     int k, lane;
     u32 nk;
     u64 *__restrict__ ghash;
@@ -193,6 +196,15 @@ struct FastMin {
     __device__ __forceinline__ void roll(u32x4 x) {
         const u32 a = __builtin_amdgcn_alignbit(fl, fh_, 31), b = __builtin_amdgcn_alignbit(fh_, fl, 31);
         const u32 c = __builtin_amdgcn_alignbit(rh_, rl, 1), d = __builtin_amdgcn_alignbit(rl, rh_, 1);
+        fl = a ^ x.x;
+        fh_ = b ^ x.y;
+        rl = c ^ x.z;
+        rh_ = d ^ x.w;
+    }
+
+    __device__ __forceinline__ void roll2(u32x4 x) {  // two warm-up bases at once: fh' = rol(fh, 2) ^ F2, rh' = ror(rh, 2) ^ R2
+        const u32 a = __builtin_amdgcn_alignbit(fl, fh_, 30), b = __builtin_amdgcn_alignbit(fh_, fl, 30);
+        const u32 c = __builtin_amdgcn_alignbit(rh_, rl, 2), d = __builtin_amdgcn_alignbit(rl, rh_, 2);
         fl = a ^ x.x;
         fh_ = b ^ x.y;
         rl = c ^ x.z;
@@ -309,6 +321,20 @@ struct FastMin {
             const u32 word = first_word((u32)t0 >> 4);
             const int nb = (k - 1 - t0) < 16 ? (k - 1 - t0) : 16;
             int j = 0;
+            if (USE_T2) {
+                for (; j + 8 <= nb; j += 8) {  // eight bases = four rows of the two-base table in flight
+                    const u32 sub = word >> (2 * j);
+                    const u32x4 x0 = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB2 + ((sub & 0xf) << 4));
+                    const u32x4 x1 = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB2 + (sub & 0xf0));
+                    const u32x4 x2 = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB2 + ((sub & 0xf00) >> 4));
+                    const u32x4 x3 = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB2 + ((sub & 0xf000) >> 8));
+                    roll2(x0);
+                    roll2(x1);
+                    roll2(x2);
+                    roll2(x3);
+                }
+                for (; j + 2 <= nb; j += 2) roll2(*reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB2 + (((word >> (2 * j)) & 0xf) << 4)));
+            }
             for (; j + 4 <= nb; j += 4) {  // four table rows in flight (one row per trip exposes the LDS latency 20 times per read)
                 const u32 sub = word >> (2 * j);
                 const u32x4 x0 = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB + 256 + ((sub & 3) << 4));
@@ -411,7 +437,7 @@ __device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 e
                 sl[j] = t < T ? (t - ex[j]) * LY::ROW + owner[j] : 0u;
             }
             hv[j] = sh[sl[j]];
-            if (POS16) pv[j] = *reinterpret_cast<const u16 *>(lds + LY::SP + sl[j] * 2);
+            if (POS16) pv[j] = (u32)(int)*reinterpret_cast<const short *>(lds + LY::SP + sl[j] * 2);  // sign-extending read: the strand bit lands in bit 31
             else pv[j] = *reinterpret_cast<const u32 *>(lds + LY::SP + sl[j] * 4);
         }
 #pragma unroll
@@ -419,7 +445,7 @@ __device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 e
             const u32 t = t0 + 64 * j + lane;
             if (t < T) {
                 __builtin_nontemporal_store(hv[j], &a.hash[base + t]);  // write-once output (see flush_rows)
-                __builtin_nontemporal_store(POS16 ? ((pv[j] & 0x7fffu) | ((pv[j] & 0x8000u) << 16)) : pv[j], &a.pos[base + t]);
+                __builtin_nontemporal_store(POS16 ? (pv[j] & 0x80007fffu) : pv[j], &a.pos[base + t]);
             }
         }
     }
@@ -434,6 +460,12 @@ __global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs 
     LDSQ char *const ldsq = (LDSQ char *)lds;
     const int lane = lane_id();
     build_xtab(reinterpret_cast<uint4 *>(lds + LY::TAB), a.k, lane);
+    if (PAIR && lane < 16) {  // two-base warm-up table: entry (c0 | c1 << 2), c0 entering first, nothing leaving
+        const unsigned c0 = (unsigned)lane & 3u, c1 = (unsigned)lane >> 2;
+        const u64 f = rol64(seed_fwd_code(c0), 1) ^ seed_fwd_code(c1);
+        const u64 r = ror64(rol64(seed_rev_code(c0), (unsigned)(a.k - 1)), 1) ^ rol64(seed_rev_code(c1), (unsigned)(a.k - 1));
+        reinterpret_cast<uint4 *>(lds + LY::TAB2)[lane] = make_uint4((u32)f, (u32)(f >> 32), (u32)r, (u32)(r >> 32));
+    }
     __syncthreads();
     const u64 slab = (u64)64 * CAP;
     u64 d_next = 0;
