@@ -1026,7 +1026,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.ring_w = (u32)std::max(1, 2 * (p->k - p->s));
         }
     } else if (p->kind == BSK_KMER) {
-        if (!use_ascii && p->canonical && b->maxlen + (u32)(p->circular ? p->k : 0) <= 16u * (BSK_NT_FAST_WORDS - 2) &&
+        if (!use_ascii && p->canonical > 0 && b->maxlen + (u32)(p->circular ? p->k : 0) <= 16u * (BSK_NT_FAST_WORDS - 2) &&
             !getenv("BSK_FORCE_GENERIC")) {
             pl.which = K_NT_FAST;  // same streaming kernel, MODE 2
             per_cu = blocks_per_cu(k_nthash_fast<2>);
@@ -1170,10 +1170,6 @@ static int ensure_lut(bsk_ctx *ctx, int table) {
 
 static int translate_batch(bsk_ctx *ctx, const bsk_batch *b, int table, int frame, u64 need, bsk_batch **out) {
     *out = nullptr;
-    if (!b->desc) {
-        ctx->err = "translate: sequences of 2^24 bases or more are not supported";
-        return BSK_ERR_UNSUPPORTED;
-    }
     if (frame < -3 || frame > 3 || frame == 0) {
         ctx->err = "invalid frame (available: 1, 2, 3, -1, -2, -3)";  // seq/seq.go:694
         return BSK_ERR_ARG;
@@ -1207,6 +1203,8 @@ static int translate_batch(bsk_ctx *ctx, const bsk_batch *b, int table, int fram
         memset(&a, 0, sizeof a);
         a.words = b->words;
         a.desc = b->desc;
+        a.fw = b->fw;
+        a.llen = b->llen;
         a.ascii = b->ascii;
         a.aoff = b->aoff;
         a.n = b->n;
@@ -1309,7 +1307,8 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     a.s = p->s;
     a.m = p->m;
     a.scale = p->scale;
-    a.canonical = p->canonical ? 1 : 0;
+    a.canonical = p->canonical > 0 ? 1 : 0;
+    a.one_strand = p->canonical < 0 ? 1 : 0;  // sketch_tiled's internal value
     a.circ_ext = circ_ext;
     a.uniform_len = b->uniform_len;
     a.refs = res->refs;
@@ -1569,7 +1568,7 @@ static bool kind_tiles(const bsk_params *p) {
         case BSK_NTHASH:
         case BSK_SIMHASH:
         case BSK_MINIMIZER: return true;
-        case BSK_KMER: return p->canonical != 0;  // the two-strand mode walks the reverse strand backwards (iterator.go:713-723)
+        case BSK_KMER: return true;  // two-strand mode (iterator.go:713-723): forward codes over tiles, then k_two_strand
         case BSK_SYNCMER: return true;            // (s == k, "every k-mer", runs as the w = 1 minimizer: sketch_tiled)
         case BSK_PROT_HASH:
         case BSK_PROT_MINIMIZER: return true;
@@ -1600,6 +1599,8 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
         pw1.kind = BSK_MINIMIZER;
         pw1.w = 1;
     }
+    const bool two_strand = p_in->kind == BSK_KMER && !p_in->canonical;
+    if (two_strand) pw1.canonical = -1;  // internal: forward codes only (KArgs::one_strand)
     const bsk_params *p = &pw1;
     const u64 n = b->n;
     TileGeo geo;
@@ -1761,7 +1762,10 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     TCHK(hipMalloc(&fin->status, n ? n : 1));
     TCHK(hipMalloc(&fin->wfirst, (n ? n : 1) * 8));
     TCHK(hipMalloc(&fin->wcount, (n ? n : 1) * 8));
-    if (stream) {  // the tile runs are adjacent: the tile result's value array IS the sequence result
+    if (two_strand) {  // twice the room; filled after k_tile_finish (k_two_strand)
+        fin->cap = 2 * tres->cap + 64;
+        TCHK(hipMalloc(&fin->hash, fin->cap * 8));
+    } else if (stream) {  // the tile runs are adjacent: the tile result's value array IS the sequence result
         fin->hash = tres->hash;
         fin->cap = tres->cap;
         tres->hash = nullptr;
@@ -1804,6 +1808,14 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     if (n) {
         hipLaunchKernelGGL(k_tile_finish, dim3(grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, seq, geo, tstart, stream ? nullptr : oexcl,
                            tres->refs, prot ? nullptr : b->rflags, sflags, sbad, fin->wfirst, fin->wcount, fin->status, ctx->d_total);
+        TCHK(hipGetLastError());
+    }
+    if (two_strand && nt) {
+        hipLaunchKernelGGL(k_two_strand, dim3((u32)std::min<u64>(nt, (u64)ctx->cus * 32)), dim3(256), 0, ctx->stream, tres->refs, tt.seq, nt,
+                           tres->hash, fin->hash, fin->wfirst, fin->wcount, fin->status, p->k, b->n_nonacgt ? b->ascii : nullptr, b->aoff);
+        TCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_two_strand_refs, dim3(grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, n, fin->wfirst, fin->wcount, fin->status,
+                           ctx->d_total);
         TCHK(hipGetLastError());
     }
     TCHK(hipMemcpyAsync(ctx->h_pinned, ctx->d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1865,11 +1877,11 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
         b = tmp;
         circ_ext = p->k - 1;
     }
-    // the two-strand k-mer mode (iterator.go:713-723) yields 2(L-k+1) values per read and is not tiled: a read's count must fit
-    // the 24-bit field of its reference word
-    if (p->kind == BSK_KMER && !p->canonical && (u64)b->maxlen >= (1ull << 23) + (u64)p->k - 1) {
+    // the two-strand k-mer mode (iterator.go:713-723) yields 2(L-k+1) values per read: without tiles (dev switch) a read's count must
+    // fit the 24-bit field of its reference word
+    if (p->kind == BSK_KMER && !p->canonical && getenv("BSK_NO_TILES") && (u64)b->maxlen >= (1ull << 23) + (u64)p->k - 1) {
         if (tmp) bsk_batch_destroy(tmp);
-        ctx->err = "two-strand k-mer codes: sequences of 2^23 k-mers or more are not supported";
+        ctx->err = "two-strand k-mer codes: sequences of 2^23 k-mers or more need the tiled path";
         return BSK_ERR_UNSUPPORTED;
     }
     // tile descriptors keep the tile length (~ positions + 2w + k) in 24 bits, and the generic kernels size their window ring by w

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64) void k_kmer(KArgs a) {
             }
         }
         if (ok && a.rflags && !ENC) sbyte |= a.rflags[r];
-        const bool two = !a.canonical && sbyte != BSK_ST_ILLEGAL;  // the reverse strand is only reached without an error
+        const bool two = !a.canonical && !a.one_strand && sbyte != BSK_ST_ILLEGAL;  // the reverse strand is only reached without an error
         const u32 nvals = two ? 2u * nk : nk;
         u32 nv_max;
         if (!stream_prologue(a, unit, lane, r, nvals, sbyte, s_off, s_nk, nv_max)) continue;

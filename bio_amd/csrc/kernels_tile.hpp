@@ -256,4 +256,56 @@ __global__ void k_tile_finish(SeqTab seq, TileGeo g, const u64 *tstart, const u6
     if ((threadIdx.x & 63) == 0 && sum) atomicAdd((unsigned long long *)total, (unsigned long long)sum);
 }
 
+// Two-strand k-mer codes over tiles (NextKmer with canonical = false, iterator.go:713-723): once the forward strand is exhausted
+// the reference reverse-complements the sequence in place and walks it again, Index() restarting at 0 -- value j of the second
+// strand is the reverse complement of forward k-mer n-1-j.  A sequence that hit an illegal base never gets there
+// (iterator.go:746-748 returns the error first).  The forward codes of sequence r sit at src[first, first + cnt); its two strands
+// go to dst[2 first, 2 first + 2 cnt).  One workgroup per tile.
+// A sequence with a letter outside ACGTacgt takes its second strand from the bytes: RevComInplace pairs LETTERS (N stays N, R <-> Y;
+// seq/alphabet.go:361-367) and base2bit then maps the paired letter, which is not the complement of the code.
+__global__ __launch_bounds__(256) void k_two_strand(const u64 *trefs, const u32 *tseq, u64 nt, const u64 *src, u64 *dst, const u64 *wfirst,
+                                                    const u64 *wcount, const u8 *status, int k, const u8 *ascii, const u64 *aoff) {
+    const unsigned sh = 64u - 2u * (unsigned)k;
+    for (u64 t = blockIdx.x; t < nt; t += gridDim.x) {
+        const u64 ref = trefs[t];
+        const u64 base = ref >> 24;
+        const u32 cnt_t = (u32)(ref & 0xffffffULL);
+        const u32 r = tseq[t];
+        const u64 first = wfirst[r], cnt = wcount[r];
+        const bool two = (status[r] & BSK_ST_CODE_MASK) != BSK_ST_ILLEGAL;
+        const u8 *letters = (ascii && (status[r] & BSK_ST_HAS_NON_ACGT)) ? ascii + aoff[r] : nullptr;
+        for (u32 i = threadIdx.x; i < cnt_t; i += blockDim.x) {
+            const u64 j = base + i - first;
+            if (j >= cnt) break;
+            const u64 f = src[base + i];
+            dst[2 * first + j] = f;
+            if (two && letters) {
+                u64 v = 0;  // first base of the second-strand k-mer = pair of the last letter of forward k-mer j
+                for (int t = k - 1; t >= 0; --t) v = (v << 2) | (base2bit_dev(dna_pair_dev(letters[j + (u64)t])) & 3u);
+                dst[2 * first + 2 * cnt - 1 - j] = v;
+            } else if (two) {
+                u64 v = ~f;  // complement, then reverse the order of the 2-bit groups
+                v = ((v >> 2) & 0x3333333333333333ULL) | ((v & 0x3333333333333333ULL) << 2);
+                v = ((v >> 4) & 0x0f0f0f0f0f0f0f0fULL) | ((v & 0x0f0f0f0f0f0f0f0fULL) << 4);
+                v = __builtin_bswap64(v);
+                dst[2 * first + 2 * cnt - 1 - j] = v >> sh;
+            }
+        }
+    }
+}
+
+__global__ void k_two_strand_refs(u64 n, u64 *wfirst, u64 *wcount, const u8 *status, u64 *total) {
+    u64 sum = 0;
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) {
+        const u64 cnt = wcount[r];
+        wfirst[r] *= 2;
+        if ((status[r] & BSK_ST_CODE_MASK) != BSK_ST_ILLEGAL) {
+            wcount[r] = 2 * cnt;
+            sum += cnt;
+        }
+    }
+    sum = wave_sum_u64(sum);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd((unsigned long long *)total, (unsigned long long)sum);
+}
+
 }  // namespace bsk

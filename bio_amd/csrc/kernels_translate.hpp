@@ -18,7 +18,8 @@ namespace bsk {
 
 struct TArgs {
     const u32 *words;   // 2-bit input
-    const u64 *desc;
+    const u64 *desc;    // (first word << 24) | bases; NULL for a batch with a sequence of 2^24 bases or more:
+    const u64 *fw, *llen;  // then first word / bases per sequence
     const u8 *ascii;    // ASCII input
     const u64 *aoff;
     u64 n;
@@ -59,10 +60,13 @@ __global__ __launch_bounds__(64) void k_translate(TArgs a) {
         const u64 r = (u64)unit * 64 + lane;
         u64 src = 0, L = 0;
         if (r < a.n) {
-            if (ENC == 0) {
+            if (ENC == 0 && a.desc) {
                 const u64 d = a.desc[r];
                 src = d >> 24;
                 L = d & 0xffffffULL;
+            } else if (ENC == 0) {
+                src = a.fw[r];
+                L = a.llen[r];
             } else {
                 src = a.aoff[r];
                 L = a.aoff[r + 1] - src;

@@ -225,9 +225,9 @@ int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t first, uint64_t
  * first[n] / count[n] instead (u64 each).  bsk_result_fetch / bsk_result_digest work for both layouts.
  * circular = 1 tiles as well (the sequence with its first k-1 bases appended is one more long sequence), and so do syncmers
  * with s == k (every k-mer with its index, sketch.go:328-331: the w = 1 minimizer).
- * Not tiled (refused with BSK_ERR_UNSUPPORTED): the two-strand k-mer mode (KMER with canonical = 0: the second strand walks
- * the sequence backwards, iterator.go:713-723) from 2^23 k-mers per sequence on, and the translation of a single sequence
- * of 2^24 bases or more. */
+ * The two-strand k-mer mode (KMER with canonical = 0, iterator.go:713-723) tiles too: forward codes per tile, then the second
+ * strand per sequence (the reverse complements of the forward codes, backwards).  Protein kinds on a DNA batch translate a
+ * sequence of any length (up to 2^31 bases); the translation is then tiled like any long protein sequence. */
 int bsk_result_device(const bsk_result *r, const uint64_t **refs, const uint8_t **status,
                       const uint64_t **hash, const uint32_t **pos);
 int bsk_result_device_wide(const bsk_result *r, const uint64_t **first, const uint64_t **count);

@@ -90,7 +90,7 @@ def test_streams_tiled(engine, oracle, tiny_tiles, tile_pos):
     tiny_tiles(40, tile_pos)
     rng = random.Random(5 + tile_pos)
     for alpha in ("ACGT", "ACGTNacgt"):
-        for k, canonical in ((21, True), (21, False), (5, True), (32, True), (300, True)):
+        for k, canonical in ((21, True), (21, False), (5, True), (5, False), (32, True), (32, False), (300, True)):
             seqs = seq_set(rng, alpha, k)
             b = engine.batch(seqs)
             rn = engine.run(b, engine.params(L.NTHASH, k, canonical=canonical))
@@ -103,16 +103,16 @@ def test_streams_tiled(engine, oracle, tiny_tiles, tile_pos):
                     continue
                 assert np.array_equal(h, e), ("nthash", k, canonical, i, len(q))
             rn.close()
-            if k <= 32 and canonical:
-                rk = engine.run(b, engine.params(L.KMER, k, canonical=True))
+            if k <= 32:  # both NextKmer modes; canonical = False: two strands, the second from the reverse-complemented letters
+                rk = engine.run(b, engine.params(L.KMER, k, canonical=canonical))
                 for i, q in enumerate(seqs):
                     st, h, _ = rk.read(i)
                     try:
-                        e = oracle.kmer_codes(q, k, True, False)
+                        e = oracle.kmer_codes(q, k, canonical, False)
                     except oracle.OracleError as err:
                         assert err.name == "ErrShortSeq" and (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0
                         continue
-                    assert np.array_equal(h, e), ("kmer", k, i, len(q))
+                    assert np.array_equal(h, e), ("kmer", k, canonical, i, len(q))
                 rk.close()
             b.close()
     seqs = seq_set(rng, "ACGT", 21)[:40]
@@ -211,9 +211,11 @@ def test_sequence_longer_than_2_pow_24(engine, oracle):
     rn = engine.run(b, engine.params(L.NTHASH, 31))
     st, h, _ = rn.read(1)
     assert len(h) == n - 30 and np.array_equal(h, oracle.nthash(q, 31, True)[0])
-    from bio_amd import sketches as S
-    with pytest.raises(S.DeviceError, match="2\\^2[34]"):  # refused by the 2^23-k-mer rule of the two-strand mode before the 2^24-base one
-        engine.run(b, engine.params(L.KMER, 21, canonical=False))
+    rk = engine.run(b, engine.params(L.KMER, 21, canonical=False))  # two strands: 2(L-k+1) values, the second strand backwards
+    st, h, _ = rk.read(1)
+    assert len(h) == 2 * (n - 20) and np.array_equal(h, oracle.kmer_codes(q, 21, False, False))
+    assert len(rk.read(0)[1]) == 2 * (28 - 20) and rk.info()["n_tuples"] == 2 * (n - 20) + 4 * 8
+    rk.close()
     rs = engine.run(b, engine.params(L.SYNCMER, 15, s=15))  # s == k: every k-mer with its index (runs as the w = 1 minimizer over tiles)
     st, h, p = rs.read(1)
     eh, ep, es, fl = oracle.syncmer(q, 15, 15, False, closed=True)
@@ -329,22 +331,73 @@ def test_long_protein_default_tiles(engine, oracle):
         assert np.array_equal(rh.read(i)[1], oracle.protein_hashes(q, 10)), i
 
 
-def test_two_strand_kmer_count_must_fit_the_reference_word(engine):
-    """NextKmer's two-strand mode (iterator.go:713-723) yields 2(L-k+1) values and is not tiled: from 2^23 k-mers on the count no
-    longer fits the 24-bit field of the read's reference word -- refused, not silently wrapped into the first-tuple bits."""
+def test_translation_of_a_chromosome_sized_sequence(engine, oracle):
+    """Protein kinds fed DNA translate first (iterator-protein.go:62-67); a sequence of 2^24 bases or more is located by first word +
+    length instead of the packed descriptor, and its translation (here more than 2^24 residues) runs as tiles."""
+    n = 3 * (1 << 24) + 1000
+    rng = np.random.default_rng(9)
+    big = np.array(list(b"ACGT"), np.uint8)[rng.integers(0, 4, n)]
+    small = np.frombuffer(b"ACGTTGCATGCATGCAAACCGGTTACGTAAGGCC", np.uint8)
+    data = np.concatenate([small, big])
+    b = engine.batch_from_arrays(data, np.array([0, len(small), len(small) + n], np.uint64))
+    q = big.tobytes().decode()
+    for frame in (1, -2):
+        rm = engine.run(b, engine.params(L.PROT_MINIMIZER, 9, w=5, codon_table=1, frame=frame))
+        st, h, p = rm.read(1)
+        eh, ep, _ = oracle.protein_minimizer_nt(q, 9, 5, 1, frame)
+        assert (st & L.ST_CODE_MASK) == L.ST_OK and np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep), frame
+        eh0, ep0, _ = oracle.protein_minimizer_nt(small.tobytes().decode(), 9, 5, 1, frame)
+        st0, h0, p0 = rm.read(0)
+        assert np.array_equal(h0, eh0) and np.array_equal(p0 & L.POS_MASK, ep0)
+        rm.close()
+    rh = engine.run(b, engine.params(L.PROT_HASH, 10, codon_table=11, frame=-1))
+    assert np.array_equal(rh.read(1)[1], oracle.protein_hashes_nt(q, 10, 11, -1))
+    rh.close()
+    pb = b.translate(1, 3)  # the stand-alone Translate
+    assert pb.info()["n_bases"] == (n - 2) // 3 + (len(small) - 2) // 3
+    pb.close()
+    b.close()
+
+
+def test_two_strand_kmer_codes_tile(engine, oracle, tiny_tiles):
+    """NextKmer's two-strand mode (iterator.go:713-723) over tiles: forward codes per tile, then the second strand per sequence --
+    including sequences whose 2(L-k+1) values no longer fit a 24-bit count, an illegal base (no second strand: the error comes
+    first, iterator.go:746-748), and IUPAC letters (RevComInplace pairs letters, base2bit maps the pair)."""
     from bio_amd import sketches as S
     n = (1 << 23) + 5000
     rng = np.random.default_rng(4)
     big = np.array(list(b"ACGT"), np.uint8)[rng.integers(0, 4, n)]
     b = engine.batch_from_arrays(big, np.array([0, n], np.uint64))
-    with pytest.raises(S.DeviceError, match="2\\^23"):
-        engine.run(b, engine.params(L.KMER, 21, canonical=False))
-    res = engine.run(b, engine.params(L.KMER, 21, canonical=True))  # the canonical mode tiles: any length
-    assert res.info()["n_tuples"] == n - 20
-    # just below the limit the two-strand mode still runs, with both strands' counts intact
-    m = (1 << 23) - 100
-    b2 = engine.batch_from_arrays(big[:m], np.array([0, m], np.uint64))
-    r2 = engine.run(b2, engine.params(L.KMER, 21, canonical=False))
-    assert r2.info()["n_tuples"] == 2 * (m - 20)
+    res = engine.run(b, engine.params(L.KMER, 21, canonical=False))
+    assert res.info()["n_tuples"] == 2 * (n - 20)
+    assert np.array_equal(res.read(0)[1], oracle.kmer_codes(big.tobytes().decode(), 21, False, False))
+    os.environ["BSK_NO_TILES"] = "1"  # the per-lane kernels keep a sequence's count in 24 bits: refused, not wrapped
+    try:
+        with pytest.raises(S.DeviceError, match="2\\^23"):
+            engine.run(b, engine.params(L.KMER, 21, canonical=False))
+    finally:
+        del os.environ["BSK_NO_TILES"]
     b.close()
-    b2.close()
+    tiny_tiles(40, 16)
+    r = random.Random(12)
+    k = 9
+    seqs = [rand_seq(r, 700), rand_seq(r, 300, "ACGTNRYKMacgtn"), rand_seq(r, 5), rand_seq(r, 9), rand_seq(r, 1200, "ACGTSWBDHVU")]
+    bad = list(rand_seq(r, 800))
+    bad[333] = "X"
+    seqs.append("".join(bad))
+    for circular in (False, True):
+        b = engine.batch(seqs)
+        res = engine.run(b, engine.params(L.KMER, k, canonical=False, circular=circular))
+        for i, q in enumerate(seqs):
+            st, h, _ = res.read(i)
+            try:
+                e = oracle.kmer_codes(q, k, False, circular)
+            except oracle.OracleError as err:
+                if err.name == "ErrShortSeq":
+                    assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0
+                else:
+                    assert err.name == "ErrIllegalBase" and (st & L.ST_CODE_MASK) == L.ST_ILLEGAL and len(h) == 333 - k + 1
+                    assert np.array_equal(h, oracle.kmer_codes(q[:333], k, False, False)[: 333 - k + 1])
+                continue
+            assert (st & L.ST_CODE_MASK) == L.ST_OK and np.array_equal(h, e), (i, circular, len(h), len(e))
+        b.close()
