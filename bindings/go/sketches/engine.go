@@ -93,9 +93,22 @@ func (e *Engine) NewBatchFromSeqs(seqs []*seq.Seq) (*Batch, error) {
 		o += copy(bytes[o:], s.Seq)
 	}
 	offs[n] = C.uint64_t(o)
+	// the batch's alphabet: the first sequence's, as a file has one (fastx guesses it once, reader.go:430-435).  Only the
+	// two-strand NextKmer mode tells the nucleotide alphabets apart (RevComInplace pairs letters per alphabet, iterator.go:719).
 	alpha := C.int(C.BSK_ALPHA_DNA)
-	if protein {
-		alpha = C.BSK_ALPHA_PROTEIN
+	if n > 0 {
+		switch seqs[0].Alphabet {
+		case seq.Protein:
+			alpha = C.BSK_ALPHA_PROTEIN
+		case seq.DNA:
+			alpha = C.BSK_ALPHA_DNA_PLAIN
+		case seq.RNA:
+			alpha = C.BSK_ALPHA_RNA
+		case seq.RNAredundant:
+			alpha = C.BSK_ALPHA_RNA_REDUNDANT
+		case seq.Unlimit:
+			alpha = C.BSK_ALPHA_UNLIMIT
+		}
 	}
 	b := &Batch{eng: e, n: n, protein: protein}
 	rc := C.bsk_batch_from_ascii(e.ctx, (*C.uint8_t)(unsafe.Pointer(&bytes[0])), &offs[0], C.uint64_t(n), alpha, &b.h)

@@ -21,6 +21,8 @@ ERR_ARG, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_IO = 64, 65,
 
 KMER, NTHASH, SIMHASH, MINIMIZER, SYNCMER, PROT_HASH, PROT_MINIMIZER = 1, 2, 3, 4, 5, 6, 7
 ALPHA_DNA, ALPHA_PROTEIN = 0, 1
+# the other nucleotide alphabets of seq/alphabet.go (they only change which letters the two-strand k-mer mode pairs)
+ALPHA_DNA_PLAIN, ALPHA_RNA, ALPHA_RNA_REDUNDANT, ALPHA_UNLIMIT = 2, 3, 4, 5
 
 ST_OK, ST_SHORT, ST_ILLEGAL, ST_CODE_MASK = 0x00, 0x01, 0x02, 0x0F
 ST_FIRST_WINDOW_TIE, ST_HAS_NON_ACGT = 0x10, 0x20

@@ -334,7 +334,9 @@ static int build_subset(bsk_ctx *ctx, bsk_batch *b);
 static int batch_from_ascii_impl(bsk_ctx *ctx, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet, bsk_batch *donor,
                                  bsk_batch **out) {
     if (!ctx || !out || (!offsets && n) || (n && !bytes && offsets[n] > 0)) return fail_arg(ctx, "bsk_batch_from_ascii: null argument");
-    if (alphabet != BSK_ALPHA_DNA && alphabet != BSK_ALPHA_PROTEIN) return fail_arg(ctx, "bad alphabet");
+    if (alphabet < BSK_ALPHA_DNA || alphabet > BSK_ALPHA_UNLIMIT) return fail_arg(ctx, "bad alphabet");
+    const int pairs = alphabet == BSK_ALPHA_PROTEIN ? BSK_ALPHA_DNA : alphabet;  // which PairLetter the two-strand k-mer mode uses
+    if (alphabet != BSK_ALPHA_PROTEIN) alphabet = BSK_ALPHA_DNA;                 // nucleotides: one engine alphabet
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     if (donor && !donor->ascii && donor->spare_ascii) {  // a pure-ACGT donor parked its ASCII buffers
@@ -365,6 +367,7 @@ static int batch_from_ascii_impl(bsk_ctx *ctx, const uint8_t *bytes, const uint6
     if (!b) return BSK_ERR_NOMEM;
     b->ctx = ctx;
     b->alphabet = alphabet;
+    b->pairs = pairs;
     b->n = n;
     const u64 nbytes = n ? offsets[n] : 0;
     b->n_bases = nbytes;
@@ -1309,6 +1312,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     a.scale = p->scale;
     a.canonical = p->canonical > 0 ? 1 : 0;
     a.one_strand = p->canonical < 0 ? 1 : 0;  // sketch_tiled's internal value
+    a.pairs = b->pairs;
     a.circ_ext = circ_ext;
     a.uniform_len = b->uniform_len;
     a.refs = res->refs;
@@ -1713,6 +1717,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     if (!tb) return done(BSK_ERR_NOMEM);
     tb->ctx = ctx;
     tb->alphabet = b->alphabet;
+    tb->pairs = b->pairs;
     tb->alias = true;
     tb->n = nt;
     tb->words = b->words;
@@ -1812,7 +1817,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     }
     if (two_strand && nt) {
         hipLaunchKernelGGL(k_two_strand, dim3((u32)std::min<u64>(nt, (u64)ctx->cus * 32)), dim3(256), 0, ctx->stream, tres->refs, tt.seq, nt,
-                           tres->hash, fin->hash, fin->wfirst, fin->wcount, fin->status, p->k, b->n_nonacgt ? b->ascii : nullptr, b->aoff);
+                           tres->hash, fin->hash, fin->wfirst, fin->wcount, fin->status, p->k, b->n_nonacgt ? b->ascii : nullptr, b->aoff, b->pairs);
         TCHK(hipGetLastError());
         hipLaunchKernelGGL(k_two_strand_refs, dim3(grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, n, fin->wfirst, fin->wcount, fin->status,
                            ctx->d_total);
@@ -1935,6 +1940,7 @@ static int make_circular(bsk_ctx *ctx, const bsk_batch *b, int k, bsk_batch **ou
     if (!t) return BSK_ERR_NOMEM;
     t->ctx = ctx;
     t->alphabet = b->alphabet;
+    t->pairs = b->pairs;
     t->n = n;
     u64 w = 0, nb = 0;
     u32 maxlen = 0;

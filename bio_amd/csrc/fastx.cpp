@@ -118,7 +118,11 @@ int guess_alphabet(const std::string &s) {  // GuessAlphabetLessConservatively, 
             if (seen[i] && !ok[i]) return false;
         return true;
     };
-    if (subset("acgtryswkmbdhvACGTRYSWKMBDHV -.nN") || subset("acguryswkmbdhvACGURYSWKMBDHV -.nN")) return BSK_ALPHA_DNA;
+    // the reference's order (seq/alphabet.go:423-437): DNA, RNA, DNAredundant, RNAredundant, Protein; letters + gaps + ambiguous of :353-383
+    if (subset("acgtACGT -.nN")) return BSK_ALPHA_DNA_PLAIN;
+    if (subset("acguACGU -.nN")) return BSK_ALPHA_RNA;
+    if (subset("acgtryswkmbdhvACGTRYSWKMBDHV -.nN")) return BSK_ALPHA_DNA;
+    if (subset("acguryswkmbdhvACGURYSWKMBDHV -.nN")) return BSK_ALPHA_RNA_REDUNDANT;
     if (subset("abcdefghijklmnopqrstuvwyzABCDEFGHIJKLMNOPQRSTUVWYZ -xX*_.")) return BSK_ALPHA_PROTEIN;
     return -1;
 }
@@ -285,6 +289,6 @@ extern "C" int bsk_batch_from_fastx(bsk_ctx *ctx, bsk_fastx *f, uint64_t max_rec
     int rc = bsk_fastx_read_chunk(f, max_records, max_bytes, n_records, &sb, &so, nullptr, nullptr, nullptr);
     if (rc != BSK_OK || *n_records == 0) return rc;
     if (alphabet < 0) alphabet = f->alphabet;
-    if (alphabet != BSK_ALPHA_DNA && alphabet != BSK_ALPHA_PROTEIN) return BSK_ERR_UNSUPPORTED;  // "Unlimit": the caller must say what it is
+    if (alphabet < BSK_ALPHA_DNA || alphabet > BSK_ALPHA_UNLIMIT) return BSK_ERR_UNSUPPORTED;  // guessed "Unlimit" (-1): the caller must say what it is
     return bsk_batch_from_ascii(ctx, sb, so, *n_records, alphabet, out);
 }

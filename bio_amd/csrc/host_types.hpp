@@ -43,6 +43,7 @@ struct bsk_ctx {
 struct bsk_batch {
     bsk_ctx *ctx = nullptr;
     int alphabet = BSK_ALPHA_DNA;
+    int pairs = BSK_ALPHA_DNA;  // nucleotide batches: the alphabet whose PairLetter the two-strand k-mer mode applies (BSK_ALPHA_DNA = DNAredundant, 2..5)
     u64 n = 0, n_bases = 0, n_words = 0, n_nonacgt = 0;
     u32 maxlen = 0;
     u32 uniform_len = 0;  // != 0: every read has this length (synthetic batches)

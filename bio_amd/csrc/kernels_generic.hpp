@@ -54,6 +54,7 @@ struct KArgs {
     // protein kinds fed with 2-bit DNA (translation fused into the residue fetch, kernels_protein.hpp)
     int frame;       // 1,2,3,-1,-2,-3
     const u8 *lut;   // device codon tables of the context (kernels_translate.hpp layout)
+    int pairs;       // KMER, canonical = 0: the alphabet whose PairLetter builds the second strand (bsk_alphabet; 0 = DNAredundant)
     int one_strand;  // KMER, canonical = 0, over tiles: forward codes only (k_two_strand appends the second strand per sequence)
 };
 

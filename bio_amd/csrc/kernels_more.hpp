@@ -222,15 +222,27 @@ __device__ __forceinline__ unsigned base2bit_dev(unsigned b) {
     }
 }
 
-// complement letter of seq.DNAredundant (seq/alphabet.go:361-367); letters without a pair stay (seq/seq.go:390)
-__device__ __forceinline__ unsigned dna_pair_dev(unsigned b) {
+// complement letter (Alphabet.PairLetter, seq/alphabet.go:313-325) of the batch's alphabet `pairs` (bsk_alphabet): DNAredundant (0),
+// DNA (2), RNA (3), RNAredundant (4) -- seq/alphabet.go:353-383 -- or Unlimit (5: ComplementInplace returns at once,
+// seq/seq.go:381-383).  Letters without a pair stay (the error is dropped, seq/seq.go:390).
+__device__ __forceinline__ unsigned dna_pair_dev(unsigned b, int pairs) {
+    if (pairs == BSK_ALPHA_UNLIMIT) return b;
     const unsigned lower = b & 0x20, u = b & ~0x20u;
+    const bool rna = pairs == BSK_ALPHA_RNA || pairs == BSK_ALPHA_RNA_REDUNDANT;
+    const bool redundant = pairs == BSK_ALPHA_DNA || pairs == BSK_ALPHA_RNA_REDUNDANT;
     unsigned p;
     switch (u) {
-        case 'A': p = 'T'; break;
+        case 'A': p = rna ? 'U' : 'T'; break;
         case 'C': p = 'G'; break;
         case 'G': p = 'C'; break;
-        case 'T': p = 'A'; break;
+        case 'T': if (rna) return b; p = 'A'; break;
+        case 'U': if (!rna) return b; p = 'A'; break;
+        default:
+            if (!redundant) return b;
+            p = 0;
+    }
+    if (p) return p | lower;
+    switch (u) {
         case 'R': p = 'Y'; break;
         case 'Y': p = 'R'; break;
         case 'K': p = 'M'; break;
@@ -244,12 +256,21 @@ __device__ __forceinline__ unsigned dna_pair_dev(unsigned b) {
     return p | lower;
 }
 
+// the same on 2-bit codes (A0 C1 G2 T3) of a pure-ACGT sequence, as four 2-bit entries: DNA 3,2,1,0; RNA 3,2,1,3 (a 'T' has no pair and
+// stays); Unlimit 0,1,2,3
+__host__ __device__ __forceinline__ unsigned pair_map2(int pairs) {
+    if (pairs == BSK_ALPHA_UNLIMIT) return 0xE4u;
+    if (pairs == BSK_ALPHA_RNA || pairs == BSK_ALPHA_RNA_REDUNDANT) return 0xDBu;
+    return 0x1Bu;
+}
+
 template <int ENC>
 struct KmerSrc {
     const u32 *w;
     const u8 *a;
     u64 L;
-    int k, canonical;
+    int k, canonical, pairs;
+    unsigned map2;
     u64 code, rc, rc2, mask1;  // rc: arithmetic complement (canonical, iterator.go:740); rc2: code of the
                                // reverse-COMPLEMENTED LETTERS (second strand of the non-canonical mode, iterator.go:719)
     unsigned sh2;
@@ -258,10 +279,12 @@ struct KmerSrc {
         return (w[t >> 4] >> ((t & 15) * 2)) & 3u;
     }
     __device__ __forceinline__ unsigned cbase(u64 t, unsigned b) const {  // 2-bit code of the complement letter
-        if (ENC) return t < L ? base2bit_dev(dna_pair_dev(a[t])) & 3u : 0u;
-        return b ^ 3u;
+        if (ENC) return t < L ? base2bit_dev(dna_pair_dev(a[t], pairs)) & 3u : 0u;
+        return (map2 >> (2u * b)) & 3u;
     }
-    __device__ __forceinline__ void init(const u32 *words, const u8 *ascii, u64 off, u64 len, int k_, int canon) {
+    __device__ __forceinline__ void init(const u32 *words, const u8 *ascii, u64 off, u64 len, int k_, int canon, int pairs_ = 0) {
+        pairs = pairs_;
+        map2 = pair_map2(pairs_);
         w = words + (ENC ? 0 : off);
         a = ascii + (ENC ? off : 0);
         L = len;
@@ -337,7 +360,7 @@ __global__ __launch_bounds__(64) void k_kmer(KArgs a) {
         if (!stream_prologue(a, unit, lane, r, nvals, sbyte, s_off, s_nk, nv_max)) continue;
         const u32 nk_max = wave_max_u32(nk);
         KmerSrc<ENC> src;
-        src.init(a.words, a.ascii, off, L, a.k, a.canonical);
+        src.init(a.words, a.ascii, off, L, a.k, a.canonical, a.pairs);
         const bool any_two = __ballot(two) != 0;
         for (u32 i = 0; i < nk_max; ++i) {
             u64 f, rcv;

@@ -264,7 +264,8 @@ __global__ void k_tile_finish(SeqTab seq, TileGeo g, const u64 *tstart, const u6
 // A sequence with a letter outside ACGTacgt takes its second strand from the bytes: RevComInplace pairs LETTERS (N stays N, R <-> Y;
 // seq/alphabet.go:361-367) and base2bit then maps the paired letter, which is not the complement of the code.
 __global__ __launch_bounds__(256) void k_two_strand(const u64 *trefs, const u32 *tseq, u64 nt, const u64 *src, u64 *dst, const u64 *wfirst,
-                                                    const u64 *wcount, const u8 *status, int k, const u8 *ascii, const u64 *aoff) {
+                                                    const u64 *wcount, const u8 *status, int k, const u8 *ascii, const u64 *aoff, int pairs) {
+    const unsigned map2 = pair_map2(pairs);
     const unsigned sh = 64u - 2u * (unsigned)k;
     for (u64 t = blockIdx.x; t < nt; t += gridDim.x) {
         const u64 ref = trefs[t];
@@ -281,7 +282,11 @@ __global__ __launch_bounds__(256) void k_two_strand(const u64 *trefs, const u32 
             dst[2 * first + j] = f;
             if (two && letters) {
                 u64 v = 0;  // first base of the second-strand k-mer = pair of the last letter of forward k-mer j
-                for (int t = k - 1; t >= 0; --t) v = (v << 2) | (base2bit_dev(dna_pair_dev(letters[j + (u64)t])) & 3u);
+                for (int t = k - 1; t >= 0; --t) v = (v << 2) | (base2bit_dev(dna_pair_dev(letters[j + (u64)t], pairs)) & 3u);
+                dst[2 * first + 2 * cnt - 1 - j] = v;
+            } else if (two && map2 != 0x1Bu) {  // RNA alphabets keep a 'T', Unlimit complements nothing: base by base
+                u64 v = 0;
+                for (int t = 0; t < k; ++t) v = (v << 2) | ((map2 >> (2u * (unsigned)((f >> (2 * t)) & 3u))) & 3u);
                 dst[2 * first + 2 * cnt - 1 - j] = v;
             } else if (two) {
                 u64 v = ~f;  // complement, then reverse the order of the 2-bit groups

@@ -102,7 +102,7 @@ struct FastxSource : Source {
         if (want_alpha < 0) {
             int isq = 0, a = -1;
             bsk_fastx_info(f, &isq, &a);
-            alphabet = a == BSK_ALPHA_PROTEIN ? BSK_ALPHA_PROTEIN : BSK_ALPHA_DNA;
+            alphabet = a < 0 ? BSK_ALPHA_DNA : a;  // the guessed alphabet (a nucleotide flavour or protein); "Unlimit" files run as nucleotides
         } else {
             alphabet = want_alpha;
         }

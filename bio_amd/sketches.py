@@ -69,7 +69,15 @@ class Alphabet:
 DNA = Alphabet("DNA")
 DNAredundant = Alphabet("DNAredundant")
 RNA = Alphabet("RNA")
+RNAredundant = Alphabet("RNAredundant")
 Protein = Alphabet("Protein")
+Unlimit = Alphabet("Unlimit")
+
+
+def _alpha_code(a: Alphabet) -> int:
+    """bsk_alphabet of a Seq's Alphabet: the nucleotide alphabets differ only in the letters RevComInplace pairs (iterator.go:719)."""
+    return {DNA: L.ALPHA_DNA_PLAIN, RNA: L.ALPHA_RNA, RNAredundant: L.ALPHA_RNA_REDUNDANT, Unlimit: L.ALPHA_UNLIMIT,
+            Protein: L.ALPHA_PROTEIN}.get(a, L.ALPHA_DNA)
 
 
 class Seq:
@@ -450,7 +458,8 @@ def NewHashIterator(s: Seq, k: int, canonical: bool, circular: bool, engine: Opt
 
 
 def NewKmerIterator(s: Seq, k: int, canonical: bool, circular: bool, engine: Optional[Engine] = None):
-    got, _, err = _single(s, Engine.params(L.KMER, k, canonical=canonical, circular=circular), L.ALPHA_DNA, engine)
+    alpha = _alpha_code(s.Alphabet)
+    got, _, err = _single(s, Engine.params(L.KMER, k, canonical=canonical, circular=circular), L.ALPHA_DNA if alpha == L.ALPHA_PROTEIN else alpha, engine)
     if err is not None:
         return None, err
     nps = None if canonical else (len(s.Seq) + (k - 1 if circular else 0) - k + 1)

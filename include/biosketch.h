@@ -74,9 +74,19 @@ typedef enum bsk_kind {
 } bsk_kind;
 
 typedef enum bsk_alphabet {
-    BSK_ALPHA_DNA = 0,    /* seq.DNA / DNAredundant / RNA*: hashed with ntHash, 2-bit packed on device */
-    BSK_ALPHA_PROTEIN = 1 /* seq.Protein: one byte per residue (the `S.Alphabet == seq.Protein`
+    BSK_ALPHA_DNA = 0,    /* nucleotides (seq.DNAredundant): hashed with ntHash, 2-bit packed on device */
+    BSK_ALPHA_PROTEIN = 1,/* seq.Protein: one byte per residue (the `S.Alphabet == seq.Protein`
                              branch of iterator-protein.go:62 / sketch-protein.go:83) */
+    /* The other nucleotide alphabets of seq/alphabet.go:352-383.  They are BSK_ALPHA_DNA everywhere but in ONE place: the
+     * second strand of NextKmer's two-strand mode comes from RevComInplace (iterator.go:719), which pairs letters with the
+     * sequence's OWN alphabet and leaves every other byte as it is (seq/seq.go:386-392):
+     *   DNA            acgtACGT <-> tgcaTGCA            RNA            acguACGU <-> ugcaUGCA  (a 'T' stays)
+     *   DNAredundant   + ryswkmbdhv <-> yrswmkvhdb      RNAredundant   + ryswkmbdhv <-> yrswmkvhdb
+     *   Unlimit        not complemented at all (seq/seq.go:381-383): the second strand is the reversed sequence. */
+    BSK_ALPHA_DNA_PLAIN = 2,
+    BSK_ALPHA_RNA = 3,
+    BSK_ALPHA_RNA_REDUNDANT = 4,
+    BSK_ALPHA_UNLIMIT = 5
 } bsk_alphabet;
 
 /* Per-read status byte (bsk_result status[]).  Low nibble = what the reference
@@ -171,8 +181,8 @@ void bsk_batch_destroy(bsk_batch *b);
  * concatenated qualities (same offsets as the sequences) -- pointers into reader-owned memory, valid until the next
  * call.  *n == 0 with BSK_OK = end of file.  Errors: BSK_ERR_NOT_FASTX (ErrNotFASTXFormat), BSK_ERR_BAD_FASTQ
  * (ErrBadFASTQFormat / ErrUnequalSeqAndQual), BSK_ERR_IO.  bsk_fastx_info: is_fastq (-1 before the first record) and the
- * alphabet guessed from the first sequence as the reference does (seq/alphabet.go:413-452): BSK_ALPHA_DNA for DNA/RNA
- * incl. ambiguity letters, BSK_ALPHA_PROTEIN, -1 for "Unlimit".
+ * alphabet guessed from the first sequence as the reference does, in its order (seq/alphabet.go:413-452): BSK_ALPHA_DNA_PLAIN,
+ * BSK_ALPHA_RNA, BSK_ALPHA_DNA (DNAredundant), BSK_ALPHA_RNA_REDUNDANT, BSK_ALPHA_PROTEIN, -1 for "Unlimit".
  * bsk_batch_from_fastx = read_chunk + bsk_batch_from_ascii (alphabet < 0: use the guess). */
 typedef struct bsk_fastx bsk_fastx;
 int bsk_fastx_open(const char *path, bsk_fastx **out);

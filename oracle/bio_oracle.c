@@ -147,24 +147,27 @@ static const uint8_t base2bit[256] = {
     4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,
     4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4};
 
-/* seq.RevComInplace (seq/seq.go:350) with the DNAredundant pair table
- * (seq/alphabet.go:361-367); bytes without a pair stay unchanged (PairLetter's
- * error is ignored, seq/seq.go:390). */
-static uint8_t dna_pair(uint8_t b) {
-    static const char from[] = "acgtryswkmbdhvACGTRYSWKMBDHV";
-    static const char to[] = "tgcayrswmkvhdbTGCAYRSWMKVHDB";
-    for (int i = 0; from[i]; i++)
-        if ((uint8_t)from[i] == b) return (uint8_t)to[i];
+/* seq.RevComInplace (seq/seq.go:350) with the pair table of the sequence's own alphabet
+ * (seq/alphabet.go:353-383; `alphabet` numbered as in include/biosketch.h: 0 DNAredundant,
+ * 2 DNA, 3 RNA, 4 RNAredundant, 5 Unlimit = ComplementInplace returns at once,
+ * seq/seq.go:381-383); gap / ambiguous letters pair with themselves (alphabet.go:155-160) and bytes
+ * without a pair stay unchanged (PairLetter's error is ignored, seq/seq.go:390). */
+static uint8_t dna_pair(uint8_t b, int alphabet) {
+    static const char *const from[] = {"acgtryswkmbdhvACGTRYSWKMBDHV", "", "acgtACGT", "acguACGU", "acguryswkmbdhvACGURYSWKMBDHV", ""};
+    static const char *const to[] = {"tgcayrswmkvhdbTGCAYRSWMKVHDB", "", "tgcaTGCA", "ugcaUGCA", "ugcayrswmkvhdbUGCAYRSWMKVHDB", ""};
+    if (alphabet < 0 || alphabet > 5) alphabet = 0;
+    for (int i = 0; from[alphabet][i]; i++)
+        if ((uint8_t)from[alphabet][i] == b) return (uint8_t)to[alphabet][i];
     return b;
 }
-static void revcom_inplace(uint8_t *s, size_t n) {
+static void revcom_inplace(uint8_t *s, size_t n, int alphabet) {
     for (size_t i = 0, j = n; i + 1 < j; i++) {
         j--;
         uint8_t t = s[i];
         s[i] = s[j];
         s[j] = t;
     }
-    for (size_t i = 0; i < n; i++) s[i] = dna_pair(s[i]);
+    for (size_t i = 0; i < n; i++) s[i] = dna_pair(s[i], alphabet);
 }
 
 /* NextKmer iterator.go:708-759.  first k-mer: kmers.Encode + kmers.MustRevComp
@@ -172,6 +175,10 @@ static void revcom_inplace(uint8_t *s, size_t n) {
  * iterator.go:736,740: first base in the most significant pair). */
 long long orc_kmer_all(const uint8_t *seq, size_t len, int k, int canonical, int circular,
                        uint64_t *out, size_t cap) {
+    return orc_kmer_all_alpha(seq, len, k, canonical, circular, 0, out, cap);
+}
+long long orc_kmer_all_alpha(const uint8_t *seq, size_t len, int k, int canonical, int circular, int alphabet,
+                             uint64_t *out, size_t cap) {
     if (k < 1) return ORC_ERR_INVALID_K;            /* iterator.go:669 */
     if (len < (size_t)k) return ORC_ERR_SHORT_SEQ;  /* iterator.go:672 */
     if (k > 32) return ORC_ERR_K_TOO_LARGE;         /* kmers.Encode -> ErrKOverflow at first Next */
@@ -184,7 +191,7 @@ long long orc_kmer_all(const uint8_t *seq, size_t len, int k, int canonical, int
     long long n = 0;
     size_t end = L - (size_t)k + 1;
     for (int strand = 0; strand < (canonical ? 1 : 2); strand++) {
-        if (strand == 1) revcom_inplace(s, L); /* iterator.go:719 */
+        if (strand == 1) revcom_inplace(s, L, alphabet); /* iterator.go:719 */
         uint64_t pre = 0, preRC = 0;
         for (size_t idx = 0; idx < end; idx++) {
             uint64_t code, rc;

@@ -81,6 +81,10 @@ long long orc_nthash_all(const uint8_t *seq, size_t len, int k, int canonical, i
  * (iterator.go:713-723) => 2*(L-k+1) codes. */
 long long orc_kmer_all(const uint8_t *seq, size_t len, int k, int canonical, int circular,
                        uint64_t *out, size_t cap);
+/* the same for a sequence whose Alphabet is not DNAredundant (numbered as bsk_alphabet: 2 DNA, 3 RNA, 4 RNAredundant,
+ * 5 Unlimit): only the second strand of canonical = 0 differs (RevComInplace pairs letters per alphabet) */
+long long orc_kmer_all_alpha(const uint8_t *seq, size_t len, int k, int canonical, int circular, int alphabet,
+                             uint64_t *out, size_t cap);
 
 /* ---- A3: NewSimHashIterator / NextSimHash  (iterator.go:113-612) ---- */
 long long orc_simhash_all(const uint8_t *seq, size_t len, int k, int m, int scale, int canonical,

@@ -55,6 +55,8 @@ def lib():
         L.orc_nthash_all.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, u64p, u8p, C.c_size_t]
         L.orc_kmer_all.restype = C.c_longlong
         L.orc_kmer_all.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, u64p, C.c_size_t]
+        L.orc_kmer_all_alpha.restype = C.c_longlong
+        L.orc_kmer_all_alpha.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, u64p, C.c_size_t]
         L.orc_simhash_all.restype = C.c_longlong
         L.orc_simhash_all.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u64p, C.c_size_t]
         for name in ("orc_minimizer_all", "orc_syncmer_all", "orc_minimizer_closed", "orc_syncmer_closed"):
@@ -110,12 +112,13 @@ def nthash(seq, k, canonical=True, circular=False):
     return out[:n].copy(), st[:n].copy()
 
 
-def kmer_codes(seq, k, canonical=True, circular=False):
-    """NewKmerIterator/NextKmer (iterator.go:668-759)."""
+def kmer_codes(seq, k, canonical=True, circular=False, alphabet=0):
+    """NewKmerIterator/NextKmer (iterator.go:668-759).  alphabet (numbered as bsk_alphabet: 0 DNAredundant, 2 DNA, 3 RNA,
+    4 RNAredundant, 5 Unlimit) = the Seq's Alphabet, whose PairLetter builds the second strand of canonical=False."""
     s = _b(seq)
     cap = 2 * (len(s) + max(k, 1)) + 2
     out = np.zeros(cap, np.uint64)
-    n = _chk(lib().orc_kmer_all(s, len(s), k, int(canonical), int(circular), _p(out, C.c_uint64), cap))
+    n = _chk(lib().orc_kmer_all_alpha(s, len(s), k, int(canonical), int(circular), int(alphabet), _p(out, C.c_uint64), cap))
     return out[:n].copy()
 
 

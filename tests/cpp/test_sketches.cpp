@@ -124,7 +124,7 @@ int main() {
         uint64_t nrec = 0;
         CHECK(bsk_batch_from_fastx(ctx, fx, 0, 0, -1, &b, &nrec) == BSK_OK && nrec == 3);
         int isq = 0, alpha = -1;
-        CHECK(bsk_fastx_info(fx, &isq, &alpha) == BSK_OK && isq == 1 && alpha == BSK_ALPHA_DNA);
+        CHECK(bsk_fastx_info(fx, &isq, &alpha) == BSK_OK && isq == 1 && alpha == BSK_ALPHA_DNA_PLAIN);
         bsk_params p{};
         p.kind = BSK_MINIMIZER;
         p.k = 21;

@@ -123,7 +123,8 @@ def test_alphabet_guess_and_record_api(tmp_path):
     rec, e = rd.Read()
     assert e is None and rec.ID == b"p1" and rd.alphabet == L.ALPHA_PROTEIN
     rd.Close()
-    for data, want in ((b">a\nACGTNNRY\n", L.ALPHA_DNA), (b">a\nACGUUU\n", L.ALPHA_DNA), (b">a\nACGT12\n", -1), (b">a\n>b\nAC\n", -1)):
+    for data, want in ((b">a\nACGTNNRY\n", L.ALPHA_DNA), (b">a\nACGUUU\n", L.ALPHA_RNA), (b">a\nACGTN-.\n", L.ALPHA_DNA_PLAIN),
+                       (b">a\nACGURY\n", L.ALPHA_RNA_REDUNDANT), (b">a\nACGTU\n", L.ALPHA_PROTEIN), (b">a\nACGT12\n", -1), (b">a\n>b\nAC\n", -1)):
         q = tmp_path / "g.fa"
         q.write_bytes(data)
         rd = fastx.Reader(str(q))

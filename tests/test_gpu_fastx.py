@@ -45,7 +45,7 @@ def test_fastq_file_to_minimizers(engine, oracle, tmp_path):
         seen += n
         res.close()
         b.close()
-    assert seen == 1000 and rd.IsFastq and rd.alphabet == L.ALPHA_DNA
+    assert seen == 1000 and rd.IsFastq and rd.alphabet == L.ALPHA_DNA_PLAIN  # seq.DNA: the first record is pure ACGT
 
 
 def test_reference_fastq_and_protein_fasta(engine, oracle, tmp_path):
@@ -58,10 +58,18 @@ def test_reference_fastq_and_protein_fasta(engine, oracle, tmp_path):
         _, h, _ = res.read(i)
         assert np.array_equal(h, oracle.nthash(want[i][1].decode(), 21, True)[0])
     assert engine.batch_from_fastx(rd) == (None, 0)
-    # test.fa is RNA (U): DNA alphabet by the reference's guess; hashed from ASCII with the published table
+    # test.fa is RNA (U): seq.RNA by the reference's guess -- a nucleotide batch; hashed from ASCII with the published table
     rd = fastx.Reader(os.path.join(GOLD, "test.fa"))
     b, n = engine.batch_from_fastx(rd)
-    assert n == 6 and rd.alphabet == L.ALPHA_DNA and b.info()["n_non_acgt_reads"] >= 1
+    assert n == 6 and rd.alphabet == L.ALPHA_RNA and b.info()["n_non_acgt_reads"] >= 1
+    want, _, _ = FO.read_records(open(os.path.join(GOLD, "test.fa"), "rb").read())
+    res = engine.run(b, engine.params(L.KMER, 11, canonical=False))  # second strand: RevComInplace with the RNA pairs (A <-> U)
+    for i in range(n):
+        if len(want[i][1]) >= 11:
+            assert np.array_equal(res.read(i)[1], oracle.kmer_codes(want[i][1].decode(), 11, False, False, L.ALPHA_RNA)), i
+        else:
+            assert (res.read(i)[0] & L.ST_CODE_MASK) == L.ST_SHORT
+    assert not np.array_equal(res.read(0)[1], oracle.kmer_codes(want[0][1].decode(), 11, False, False, L.ALPHA_DNA))
     p = tmp_path / "p.fa"
     p.write_bytes(b">p1\n" + b"MKVLAAGIVGLLLAQWERTYIPASDFGHKLCVNM" * 3 + b"\n>p2\nMSTNPKPQRKTKRNTNRRPQDVKFPGGGQIVGGVYLLPRRGPRLGVRATRK\n")
     rd = fastx.Reader(str(p))

@@ -1,4 +1,5 @@
 """GPU parity for the remaining iterator kinds: syncmer, k-mer codes, SimHash, protein hash / minimizer."""
+import os
 import random
 
 import numpy as np
@@ -93,6 +94,47 @@ def test_kmer_codes(engine, oracle, k, canonical, circular):
             continue
         assert (st & L.ST_CODE_MASK) == L.ST_OK, (i, q, st)
         assert np.array_equal(h, e), (i, q, k, h[:4], e[:4])
+
+
+@pytest.mark.parametrize("alphabet", [L.ALPHA_DNA, L.ALPHA_DNA_PLAIN, L.ALPHA_RNA, L.ALPHA_RNA_REDUNDANT, L.ALPHA_UNLIMIT])
+@pytest.mark.parametrize("tiles", [False, True])
+def test_two_strand_kmer_codes_pair_letters_with_the_sequences_own_alphabet(engine, oracle, alphabet, tiles):
+    """The second strand of NextKmer's canonical=false mode is RevComInplace of the Seq (iterator.go:719): PairLetter of ITS alphabet
+    (seq/alphabet.go:353-383) -- RNA pairs A with U and leaves a T, plain DNA leaves R/Y..., Unlimit complements nothing
+    (seq/seq.go:381-383).  Pure-ACGT reads (2-bit kernels) and reads with other letters (ASCII kernels), per lane and over tiles."""
+    rng = random.Random(alphabet * 2 + tiles)
+    seqs = [rand_seq(rng, rng.randint(12, 400)) for _ in range(80)]
+    seqs += [rand_seq(rng, rng.randint(12, 400), "ACGU") for _ in range(20)]
+    seqs += [rand_seq(rng, rng.randint(12, 400), "ACGTUacgtuNRYSWKMBDHVryswkmbdhvn") for _ in range(40)]
+    seqs += [rand_seq(rng, 2000), rand_seq(rng, 1500, "ACGUTRYN")]
+    saved = {k: os.environ.get(k) for k in ("BSK_TILE_MIN", "BSK_TILE_POS")}
+    if tiles:
+        os.environ["BSK_TILE_MIN"], os.environ["BSK_TILE_POS"] = "40", "16"
+    try:
+        for k, circular in ((11, False), (7, True), (32, False)):
+            b = engine.batch(seqs, alphabet)
+            res = engine.run(b, engine.params(L.KMER, k, canonical=False, circular=circular))
+            for i, q in enumerate(seqs):
+                st, h, _ = res.read(i)
+                try:
+                    e = oracle.kmer_codes(q, k, False, circular, alphabet)
+                except oracle.OracleError as err:
+                    assert err.name == "ErrShortSeq" and (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0
+                    continue
+                assert np.array_equal(h, e), (alphabet, tiles, k, circular, i, q[:40])
+            rc = engine.run(b, engine.params(L.KMER, k, canonical=True, circular=circular))  # the canonical mode never looks at the alphabet
+            for i in (0, 85, 110, 141):
+                if len(seqs[i]) >= k:
+                    assert np.array_equal(rc.read(i)[1], oracle.kmer_codes(seqs[i], k, True, circular))
+            res.close()
+            rc.close()
+            b.close()
+    finally:
+        for k_, v in saved.items():
+            if v is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v
 
 
 def test_kmer_k_too_large(engine):
