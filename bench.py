@@ -132,18 +132,18 @@ def end_to_end(kind: str, p, batch, read_len: int, n_streams: int = 3):
     from bio_amd import sketches as S
     n_have = batch.info()["n_reads"]
     scale = 150.0 / read_len
-    n_mem = min(n_have, int(8_000_000 * scale))
+    n_mem = min(n_have, int(16_000_000 * scale))
     data, offs = batch.fetch_ascii(0, n_mem)
     alpha = 1 if kind in PROTEIN else 0
     out = {"n_streams": n_streams, "chunk_records": 1 << 20,
            "what": "host ASCII -> pinned chunks -> H2D + 2-bit pack -> kernel -> every tuple back in pinned host memory; stages of different chunks overlap"}
-    st = S.Engine.pipeline_memory(data, offs, p, n_streams=n_streams, chunk_records=1 << 20, repeat=4, fetch=True, alphabet=alpha)
+    st = S.Engine.pipeline_memory(data, offs, p, n_streams=n_streams, chunk_records=1 << 20, repeat=2, fetch=True, alphabet=alpha)
     out["from_memory"] = {"value": round(st["bases"] / st["seconds"] / 1e9, 3), "unit": "Gresidues/s" if alpha else "Gbases/s",
                           "reads": st["records"], "seconds": round(st["seconds"], 4),
                           "stage_seconds_summed_over_streams": {k: round(st[k], 4) for k in ("reader_seconds", "reader_wait_seconds", "h2d_pack_seconds", "kernel_seconds", "fetch_seconds")},
                           "bound": "PCIe: %.0f B/read in + %.0f B/read of tuples out" % (read_len + 8, (12.0 if kind not in STREAM else 8.0) * st["tuples"] / max(st["records"], 1) + 9)}
     # the same reads as files: fixed-width names, constant qualities
-    n_file = min(n_mem, int(2_000_000 * scale))
+    n_file = n_mem
     rec = 12 + read_len + (3 + read_len if not alpha else 0)
     arr = np.empty((n_file, rec), np.uint8)
     names = np.char.zfill(np.arange(n_file).astype("U9"), 9)
@@ -172,7 +172,9 @@ def end_to_end(kind: str, p, batch, read_len: int, n_streams: int = 3):
             out[tag] = {"value": round(st["bases"] / st["seconds"] / 1e9, 3), "unit": "Gresidues/s" if alpha else "Gbases/s",
                         "reads": st["records"], "file_bytes": os.path.getsize(path), "seconds": round(st["seconds"], 4),
                         "reader_seconds": round(st["reader_seconds"], 4), "reader_wait_seconds": round(st["reader_wait_seconds"], 4),
-                        "bound": "the single-threaded record reader" if st["reader_seconds"] > 0.7 * st["seconds"] else "device side"}
+                        "reader": ("block-parallel, %d parser threads, %d pieces re-parsed" % (st["reader_threads"], st["reparsed_pieces"]))
+                        if st["reader_threads"] else "serial record reader (one gzip stream)",
+                        "bound": "the record reader" if st["reader_seconds"] > 0.7 * st["seconds"] else "device side"}
     return out
 
 

@@ -32,10 +32,10 @@ POS_STRAND_BIT, POS_MASK = 0x80000000, 0x7FFFFFFF
 class PipelineStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("records", "bases", "tuples", "chunks", "checksum")] + \
                [(n, C.c_double) for n in ("seconds", "reader_seconds", "reader_wait_seconds", "h2d_pack_seconds", "kernel_seconds", "fetch_seconds")] + \
-               [("n_streams", C.c_int32), ("reserved", C.c_int32)]
+               [("n_streams", C.c_int32), ("reader_threads", C.c_int32), ("reparsed_pieces", C.c_uint64)]
 
     def asdict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+        return {n: getattr(self, n) for n, _ in self._fields_}
 
 
 class Params(C.Structure):
@@ -68,6 +68,13 @@ SYMBOLS = [
     ("bsk_fastx_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("bsk_fastx_error", C.c_char_p, [_vp]),
     ("bsk_fastx_close", None, [_vp]),
+    ("bsk_fastx_par_open", C.c_int, [C.c_char_p, C.c_int, C.c_uint64, C.POINTER(_vp)]),
+    ("bsk_fastx_par_next", C.c_int, [_vp, C.POINTER(_vp)]),
+    ("bsk_fastx_piece_data", C.c_int, [_vp, C.POINTER(C.c_uint64), C.POINTER(_vp), C.POINTER(_vp)]),
+    ("bsk_fastx_piece_release", None, [_vp, _vp]),
+    ("bsk_fastx_par_info", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    ("bsk_fastx_par_error", C.c_char_p, [_vp]),
+    ("bsk_fastx_par_close", None, [_vp]),
     ("bsk_batch_from_fastx", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_int, _pp, _u64p]),
     ("bsk_sketch", C.c_int, [_vp, _vp, C.POINTER(Params), _pp]),
     ("bsk_sketch_timed", C.c_int, [_vp, _vp, C.POINTER(Params), _pp, C.c_int, C.c_int, C.POINTER(C.c_float)]),

@@ -14,13 +14,22 @@
 //     neither header nor sequence ends the file (:440-442);
 //   * the alphabet is guessed from (the first 10 000 letters of) the first sequence (:432-438, seq/alphabet.go:413-452).
 // gzip input is read through zlib (gzread also passes plain files through), "-" is stdin.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
+#include <atomic>
+#include <cerrno>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "biosketch.h"
@@ -30,6 +39,9 @@ struct bsk_batch;
 
 struct bsk_fastx {
     gzFile fh = nullptr;
+    int fd = -1;               // the other byte source (block-parallel reader below): pread from `foff` on
+    uint64_t foff = 0;         // next file offset to read
+    uint64_t win_off = 0;      // file offset of buf[0]
     std::vector<uint8_t> buf;  // file window
     size_t r = 0, n = 0;       // unread part of buf: [r, n)
     bool eof = false, started = false, finished = false, io_error = false;
@@ -51,6 +63,24 @@ namespace {
 bool fill(bsk_fastx *f) {  // refill the window; false at end of file
     if (f->eof) return false;
     f->r = 0;
+    if (f->fd >= 0) {  // a byte range of a plain file
+        ssize_t got;
+        do got = pread(f->fd, f->buf.data(), f->buf.size(), (off_t)f->foff);
+        while (got < 0 && errno == EINTR);
+        if (got <= 0) {
+            if (got < 0) {
+                f->io_error = true;
+                f->err = std::string("fastx: read error: ") + strerror(errno);
+            }
+            f->eof = true;
+            f->n = 0;
+            return false;
+        }
+        f->win_off = f->foff;
+        f->foff += (uint64_t)got;
+        f->n = (size_t)got;
+        return true;
+    }
     const int got = gzread(f->fh, f->buf.data(), (unsigned)f->buf.size());
     if (got <= 0) {
         // 0 is the end of the file; a damaged or truncated gzip stream / an I/O error shows as -1, or as 0 with a pending
@@ -291,4 +321,372 @@ extern "C" int bsk_batch_from_fastx(bsk_ctx *ctx, bsk_fastx *f, uint64_t max_rec
     if (alphabet < 0) alphabet = f->alphabet;
     if (alphabet < BSK_ALPHA_DNA || alphabet > BSK_ALPHA_UNLIMIT) return BSK_ERR_UNSUPPORTED;  // guessed "Unlimit" (-1): the caller must say what it is
     return bsk_batch_from_ascii(ctx, sb, so, *n_records, alphabet, out);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Block-parallel reader for plain (uncompressed) files: the same records as the reader above, sequences only, parsed by
+// n_threads threads that work ahead on consecutive byte ranges ("pieces") of the file.
+//
+// A piece is the records whose delimiter lies in [lo, hi).  Its thread guesses where the first of them starts -- FASTA: the
+// first '>' after a newline, which always opens a record (reader.go:312-352); FASTQ: the first '@' after a newline whose
+// next lines look like a record (third line '+', equal lengths, another '@' after the fourth), because a quality line may
+// start with '@' too -- and then runs the ordinary record state machine (next_record above, over pread instead of gzread)
+// from there until the first record that starts at or after `hi`.  The consumer hands the pieces out in file order and
+// checks each guess against the previous piece's true end: a piece that started anywhere else (multi-line FASTQ defeats the
+// guess, for instance) is parsed again from the right offset, serially.  So the result is that of the serial reader
+// whatever the file looks like; only the speed depends on the guess.
+// ------------------------------------------------------------------------------------------------------------------------
+struct bsk_fastx_piece {
+    uint64_t idx = 0;
+    int64_t start = -1;      // file offset of the delimiter the parse started at; -1: no record start found in [lo, hi)
+    uint64_t end = 0;        // file offset of the delimiter of the first record after the piece
+    bool file_done = false;  // the reader finished inside this piece (end of file, an error, or reader.go:440-442)
+    int err = BSK_OK;        // met after the records below
+    std::string errtext;
+    std::vector<uint8_t> seq;
+    std::vector<uint64_t> off;
+};
+
+struct bsk_fastx_par {
+    int fd = -1;
+    uint64_t fsize = 0, first = 0, piece_bytes = 0, n_pieces = 0;
+    int is_fastq = -1, alphabet = -2;
+    uint8_t delim = 0;
+    size_t window = 0;
+    std::string err;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    uint64_t next_idx = 0, consumed = 0, ahead = 0;
+    std::map<uint64_t, bsk_fastx_piece *> done;
+    std::vector<bsk_fastx_piece *> pool;
+    bool stop = false;
+    std::vector<std::thread> threads;
+    uint64_t cur = 0;  // consumer: delimiter of the next record to deliver
+    bool finished = false;
+    int pending = 0;
+    uint64_t reparsed = 0;  // pieces whose guessed start was wrong (statistics)
+    bsk_fastx serial;       // the consumer's own record reader (re-parses)
+};
+
+namespace {
+
+bool pread_full(int fd, uint8_t *dst, size_t len, uint64_t off) {
+    while (len) {
+        const ssize_t got = pread(fd, dst, len, (off_t)off);
+        if (got < 0 && errno == EINTR) continue;
+        if (got <= 0) return false;
+        dst += got;
+        len -= (size_t)got;
+        off += (uint64_t)got;
+    }
+    return true;
+}
+
+// does a FASTQ record plausibly start at b[k] ('@' after a newline)?  1 yes, 0 no, -1 the buffer ends too early to tell
+int looks_like_fastq_record(const uint8_t *b, size_t len, size_t k, bool at_eof) {
+    const uint8_t *e = b + len;
+    const uint8_t *nl1 = (const uint8_t *)memchr(b + k, '\n', len - k);
+    if (!nl1) return at_eof ? 1 : -1;
+    const uint8_t *l2 = nl1 + 1;
+    const uint8_t *nl2 = l2 < e ? (const uint8_t *)memchr(l2, '\n', (size_t)(e - l2)) : nullptr;
+    if (!nl2) return at_eof ? 1 : -1;
+    const uint8_t *l3 = nl2 + 1;
+    if (l3 >= e) return at_eof ? 1 : -1;
+    if (*l3 != '+') return 0;
+    const uint8_t *nl3 = (const uint8_t *)memchr(l3, '\n', (size_t)(e - l3));
+    if (!nl3) return at_eof ? 1 : -1;
+    const uint8_t *l4 = nl3 + 1;
+    const uint8_t *nl4 = l4 < e ? (const uint8_t *)memchr(l4, '\n', (size_t)(e - l4)) : nullptr;
+    if (!nl4) return at_eof ? 1 : -1;
+    size_t sl = (size_t)(nl2 - l2), ql = (size_t)(nl4 - l4);
+    if (sl && l2[sl - 1] == '\r') --sl;
+    if (ql && l4[ql - 1] == '\r') --ql;
+    if (sl != ql) return 0;
+    if (nl4 + 1 >= e) return at_eof ? 1 : -1;
+    return nl4[1] == '@' ? 1 : 0;
+}
+
+// first guessed record start in [lo, hi) (lo > 0), or -1
+int64_t find_start(bsk_fastx_par *p, uint64_t lo, uint64_t hi, std::vector<uint8_t> &tmp) {
+    const uint64_t base = lo - 1;
+    size_t want = 1u << 16;
+    for (;;) {
+        const size_t len = (size_t)std::min<uint64_t>(want, p->fsize - base);
+        tmp.resize(len);
+        if (!pread_full(p->fd, tmp.data(), len, base)) return -1;  // the parse reports the I/O error
+        const bool at_eof = base + len == p->fsize;
+        const uint8_t *b = tmp.data();
+        const size_t scan_end = (size_t)std::min<uint64_t>(len, hi - base);
+        size_t i = 1;
+        bool need_more = false;
+        while (i < scan_end) {
+            const uint8_t *d = (const uint8_t *)memchr(b + i, p->delim, scan_end - i);
+            if (!d) break;
+            const size_t k = (size_t)(d - b);
+            if (b[k - 1] == '\n') {
+                if (!p->is_fastq) return (int64_t)(base + k);
+                const int ok = looks_like_fastq_record(b, len, k, at_eof);
+                if (ok == 1) return (int64_t)(base + k);
+                if (ok < 0) {
+                    need_more = true;
+                    break;
+                }
+            }
+            i = k + 1;
+        }
+        if (!need_more && (base + len >= hi || at_eof)) return -1;
+        if (at_eof) return -1;
+        want *= 8;
+    }
+}
+
+void reader_for_range(bsk_fastx *f, const bsk_fastx_par *p, uint64_t from) {
+    f->fd = p->fd;
+    f->foff = from + 1;  // the bytes after the delimiter
+    f->win_off = 0;
+    if (f->buf.size() != p->window) f->buf.resize(p->window);
+    f->r = f->n = 0;
+    f->eof = f->finished = f->io_error = false;
+    f->started = true;
+    f->is_fastq = p->is_fastq;
+    f->delim = p->delim;
+    f->pending = 0;
+    f->rec.clear();
+    f->err.clear();
+}
+
+// the records whose delimiter lies in [from, hi); `from` is the offset of a record's delimiter
+void parse_span(bsk_fastx *f, const bsk_fastx_par *p, uint64_t from, uint64_t hi, bsk_fastx_piece *out) {
+    reader_for_range(f, p, from);
+    out->start = (int64_t)from;
+    out->end = p->fsize;
+    out->file_done = false;
+    out->err = BSK_OK;
+    out->errtext.clear();
+    out->seq.clear();
+    out->off.assign(1, 0);
+    for (;;) {
+        const int st = next_record(f);
+        if (st <= 0) {
+            out->file_done = true;
+            if (st < 0) {
+                out->err = -st;
+                out->errtext = f->err;
+            }
+            return;
+        }
+        out->seq.insert(out->seq.end(), f->p_seq.begin(), f->p_seq.end());
+        out->off.push_back(out->seq.size());
+        if (f->finished) {  // that was the last record of the file
+            out->file_done = true;
+            return;
+        }
+        const uint64_t next_start = f->win_off + f->r - 1;  // next_record stopped right after the next record's delimiter
+        if (next_start >= hi) {
+            out->end = next_start;
+            return;
+        }
+    }
+}
+
+void piece_range(const bsk_fastx_par *p, uint64_t idx, uint64_t &lo, uint64_t &hi) {
+    lo = p->first + idx * p->piece_bytes;
+    hi = std::min<uint64_t>(lo + p->piece_bytes, p->fsize);
+}
+
+void par_worker(bsk_fastx_par *p) {
+    bsk_fastx rd;
+    std::vector<uint8_t> tmp;
+    for (;;) {
+        bsk_fastx_piece *pc = nullptr;
+        uint64_t idx;
+        {
+            std::unique_lock<std::mutex> l(p->m);
+            p->cv_work.wait(l, [&] { return p->stop || (p->next_idx < p->n_pieces && p->next_idx < p->consumed + p->ahead); });
+            if (p->stop) return;
+            idx = p->next_idx++;
+            if (!p->pool.empty()) {
+                pc = p->pool.back();
+                p->pool.pop_back();
+            }
+        }
+        if (!pc) pc = new bsk_fastx_piece();
+        pc->idx = idx;
+        uint64_t lo, hi;
+        piece_range(p, idx, lo, hi);
+        const int64_t s = idx == 0 ? (int64_t)p->first : find_start(p, lo, hi, tmp);
+        if (s >= 0) {
+            parse_span(&rd, p, (uint64_t)s, hi, pc);
+        } else {
+            pc->start = -1;
+            pc->seq.clear();
+            pc->off.assign(1, 0);
+            pc->err = BSK_OK;
+            pc->file_done = false;
+        }
+        {
+            std::lock_guard<std::mutex> l(p->m);
+            p->done[idx] = pc;
+        }
+        p->cv_done.notify_all();
+    }
+}
+
+}  // namespace
+
+extern "C" int bsk_fastx_par_open(const char *path, int n_threads, uint64_t piece_bytes, bsk_fastx_par **out) {
+    if (!path || !out || n_threads < 1 || n_threads > 256) return BSK_ERR_ARG;
+    *out = nullptr;
+    if (strcmp(path, "-") == 0) return BSK_ERR_UNSUPPORTED;  // a stream has no byte ranges
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return BSK_ERR_IO;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) {
+        close(fd);
+        return BSK_ERR_UNSUPPORTED;
+    }
+    bsk_fastx_par *p = new (std::nothrow) bsk_fastx_par();
+    if (!p) {
+        close(fd);
+        return BSK_ERR_NOMEM;
+    }
+    p->fd = fd;
+    p->fsize = (uint64_t)sb.st_size;
+    uint8_t magic[2] = {0, 0};
+    if (p->fsize >= 2 && pread_full(fd, magic, 2, 0) && magic[0] == 0x1f && magic[1] == 0x8b) {  // gzip: one serial stream
+        close(fd);
+        delete p;
+        return BSK_ERR_UNSUPPORTED;
+    }
+    // format: the first byte that is not '\n' (reader.go:273-305)
+    std::vector<uint8_t> tmp(1u << 16);
+    uint64_t at = 0;
+    bool found = false;
+    while (at < p->fsize && !found) {
+        const size_t len = (size_t)std::min<uint64_t>(tmp.size(), p->fsize - at);
+        if (!pread_full(fd, tmp.data(), len, at)) {
+            close(fd);
+            delete p;
+            return BSK_ERR_IO;
+        }
+        for (size_t i = 0; i < len; ++i)
+            if (tmp[i] != '\n') {
+                if (tmp[i] != '>' && tmp[i] != '@') {
+                    close(fd);
+                    delete p;
+                    return BSK_ERR_NOT_FASTX;
+                }
+                p->is_fastq = tmp[i] == '@';
+                p->delim = tmp[i];
+                p->first = at + i;
+                found = true;
+                break;
+            }
+        at += len;
+    }
+    const char *pb = getenv("BSK_FASTX_PIECE");  // tests: tiny pieces put a piece boundary at every kind of place
+    p->piece_bytes = piece_bytes ? piece_bytes : (pb && atoll(pb) > 0 ? (uint64_t)atoll(pb) : (uint64_t)(8u << 20));
+    const char *bs = getenv("BSK_FASTX_BUF");
+    p->window = bs && atoi(bs) > 0 ? (size_t)atoi(bs) : (size_t)(1u << 20);
+    p->n_pieces = found ? (p->fsize - p->first + p->piece_bytes - 1) / p->piece_bytes : 0;  // no record at all: nothing to do
+    p->cur = p->first;
+    p->ahead = 2 * (uint64_t)n_threads + 2;
+    p->finished = !found;
+    for (int t = 0; t < n_threads && (uint64_t)t < p->n_pieces; ++t) p->threads.emplace_back(par_worker, p);
+    *out = p;
+    return BSK_OK;
+}
+
+extern "C" void bsk_fastx_par_close(bsk_fastx_par *p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> l(p->m);
+        p->stop = true;
+    }
+    p->cv_work.notify_all();
+    for (auto &t : p->threads) t.join();
+    for (auto &kv : p->done) delete kv.second;
+    for (auto *pc : p->pool) delete pc;
+    if (p->fd >= 0) close(p->fd);
+    p->serial.fd = -1;
+    delete p;
+}
+
+extern "C" const char *bsk_fastx_par_error(const bsk_fastx_par *p) { return p ? p->err.c_str() : "null reader"; }
+
+extern "C" int bsk_fastx_par_info(const bsk_fastx_par *p, int *is_fastq, int *alphabet, uint64_t *reparsed_pieces) {
+    if (!p) return BSK_ERR_ARG;
+    if (is_fastq) *is_fastq = p->is_fastq;
+    if (alphabet) *alphabet = p->alphabet == -2 ? -1 : p->alphabet;
+    if (reparsed_pieces) *reparsed_pieces = p->reparsed;
+    return BSK_OK;
+}
+
+extern "C" void bsk_fastx_piece_release(bsk_fastx_par *p, bsk_fastx_piece *pc) {
+    if (!p || !pc) return;
+    std::lock_guard<std::mutex> l(p->m);
+    p->pool.push_back(pc);
+}
+
+extern "C" int bsk_fastx_piece_data(const bsk_fastx_piece *pc, uint64_t *n, const uint8_t **seq_bytes, const uint64_t **seq_offsets) {
+    if (!pc || !n) return BSK_ERR_ARG;
+    *n = pc->off.size() - 1;
+    static const uint8_t zero = 0;
+    if (seq_bytes) *seq_bytes = pc->seq.empty() ? &zero : pc->seq.data();
+    if (seq_offsets) *seq_offsets = pc->off.data();
+    return BSK_OK;
+}
+
+extern "C" int bsk_fastx_par_next(bsk_fastx_par *p, bsk_fastx_piece **piece) {
+    if (!p || !piece) return BSK_ERR_ARG;
+    *piece = nullptr;
+    if (p->pending) {
+        const int rc = p->pending;
+        p->pending = 0;
+        p->finished = true;
+        return rc;
+    }
+    for (;;) {
+        if (p->finished || p->consumed >= p->n_pieces) return BSK_OK;
+        bsk_fastx_piece *pc;
+        {
+            std::unique_lock<std::mutex> l(p->m);
+            p->cv_done.wait(l, [&] { return p->done.count(p->consumed) != 0; });
+            auto it = p->done.find(p->consumed);
+            pc = it->second;
+            p->done.erase(it);
+            p->consumed++;
+        }
+        p->cv_work.notify_all();
+        uint64_t lo, hi;
+        piece_range(p, pc->idx, lo, hi);
+        if (p->cur >= hi) {  // the previous piece's last record runs over this whole range
+            bsk_fastx_piece_release(p, pc);
+            continue;
+        }
+        if (pc->start != (int64_t)p->cur) {  // no guess or a wrong one: the records of [cur, hi), serially
+            p->reparsed++;
+            parse_span(&p->serial, p, p->cur, hi, pc);
+        }
+        if (pc->file_done) p->finished = true;
+        else p->cur = pc->end;
+        const uint64_t n = pc->off.size() - 1;
+        if (p->alphabet == -2 && n) p->alphabet = guess_alphabet(std::string((const char *)pc->seq.data(), (size_t)pc->off[1]));
+        if (pc->err != BSK_OK) {
+            p->err = pc->errtext;
+            if (n == 0) {
+                const int rc = pc->err;
+                p->finished = true;
+                bsk_fastx_piece_release(p, pc);
+                return rc;
+            }
+            p->pending = pc->err;  // the good records now, the error with the next call (as bsk_fastx_read_chunk)
+        }
+        if (n == 0) {
+            bsk_fastx_piece_release(p, pc);
+            continue;
+        }
+        *piece = pc;
+        return BSK_OK;
+    }
 }

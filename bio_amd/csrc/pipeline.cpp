@@ -47,6 +47,7 @@ struct Chunk {
     PinBuf bytes, offs;
     uint64_t n = 0, nbytes = 0;
     uint64_t src_at = 0;  // memory source: first record of the chunk (the worker copies it into the pinned buffers itself)
+    std::vector<bsk_fastx_piece *> parts;  // block-parallel file source: the parsed pieces of the chunk (copied by the worker)
 };
 
 struct Queue {  // chunks handed from the producer to the workers, and back
@@ -112,6 +113,64 @@ struct FastxSource : Source {
         c->n = n;
         c->nbytes = so[n];
         return 1;
+    }
+};
+
+// plain files: n parser threads work ahead (bsk_fastx_par_*); the producer only strings pieces together, the workers copy them
+struct ParFastxSource : Source {
+    bsk_fastx_par *f = nullptr;
+    int want_alpha = -1;
+    int next(Chunk *c, uint64_t max_records) override {
+        c->parts.clear();
+        c->n = c->nbytes = 0;
+        while (max_records == 0 || c->n < max_records) {
+            bsk_fastx_piece *pc = nullptr;
+            const int rc = bsk_fastx_par_next(f, &pc);
+            if (rc != BSK_OK) {
+                err = bsk_fastx_par_error(f);
+                for (auto *q : c->parts) bsk_fastx_piece_release(f, q);
+                c->parts.clear();
+                return -rc;
+            }
+            if (!pc) break;
+            uint64_t n = 0;
+            const uint64_t *so = nullptr;
+            bsk_fastx_piece_data(pc, &n, nullptr, &so);
+            c->parts.push_back(pc);
+            c->n += n;
+            c->nbytes += so[n];
+        }
+        if (c->parts.empty()) return 0;
+        if (want_alpha < 0) {
+            int a = -1;
+            bsk_fastx_par_info(f, nullptr, &a, nullptr);
+            alphabet = a < 0 ? BSK_ALPHA_DNA : a;
+        } else {
+            alphabet = want_alpha;
+        }
+        return 1;
+    }
+    int materialize(Chunk *c) override {
+        int rc = BSK_OK;
+        if (!c->bytes.ensure(c->nbytes + 1) || !c->offs.ensure((c->n + 1) * 8)) rc = BSK_ERR_NOMEM;
+        uint64_t *o = (uint64_t *)c->offs.p;
+        uint64_t at = 0, nb = 0;
+        for (auto *pc : c->parts) {
+            uint64_t n = 0;
+            const uint8_t *sb = nullptr;
+            const uint64_t *so = nullptr;
+            bsk_fastx_piece_data(pc, &n, &sb, &so);
+            if (rc == BSK_OK) {
+                memcpy((uint8_t *)c->bytes.p + nb, sb, so[n]);
+                for (uint64_t i = 0; i < n; ++i) o[at + i] = nb + so[i];
+                at += n;
+                nb += so[n];
+            }
+            bsk_fastx_piece_release(f, pc);
+        }
+        c->parts.clear();
+        if (rc == BSK_OK) o[at] = nb;
+        return rc;
     }
 };
 
@@ -270,6 +329,24 @@ int run_pipeline(int device, Source &src, const bsk_params *p, int n_streams, ui
 extern "C" int bsk_pipeline_fastx(int device, const char *path, int alphabet, const bsk_params *p, int n_streams, uint64_t chunk_records,
                                   int fetch_tuples, bsk_pipeline_stats *stats) {
     if (!path) return BSK_ERR_ARG;
+    // a plain file: block-parallel parsing (the serial record reader delivers ~0.8 Gbases/s, a third of what ONE stream sketches)
+    if (!getenv("BSK_FASTX_SERIAL")) {
+        ParFastxSource ps;
+        ps.want_alpha = alphabet;
+        const char *tv = getenv("BSK_FASTX_THREADS");
+        int nt = tv && atoi(tv) > 0 ? atoi(tv) : (int)std::thread::hardware_concurrency() - n_streams - 1;
+        nt = std::max(1, std::min(nt, 12));
+        const int orc = bsk_fastx_par_open(path, nt, 0, &ps.f);
+        if (orc == BSK_OK) {
+            const int rc = run_pipeline(device, ps, p, n_streams, chunk_records, fetch_tuples, stats);
+            uint64_t rep = 0;
+            bsk_fastx_par_info(ps.f, nullptr, nullptr, &rep);
+            if (stats) stats->reader_threads = nt, stats->reparsed_pieces = rep;
+            bsk_fastx_par_close(ps.f);
+            return rc;
+        }
+        if (orc != BSK_ERR_UNSUPPORTED) return orc;  // gzip / stdin: the serial reader below
+    }
     FastxSource src;
     src.want_alpha = alphabet;
     int rc = bsk_fastx_open(path, &src.f);

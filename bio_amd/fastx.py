@@ -65,6 +65,56 @@ class Chunk:
         return None if self.qual is None else self.qual[int(self.offsets[i]):int(self.offsets[i + 1])].tobytes()
 
 
+class ParallelReader:
+    """Block-parallel reader for plain files (bsk_fastx_par_*): the serial reader's records in its order, sequences only."""
+
+    def __init__(self, path: str, threads: int = 4, piece_bytes: int = 0):
+        self.lib = L.load()
+        self.h = C.c_void_p()
+        rc = self.lib.bsk_fastx_par_open(path.encode(), threads, piece_bytes, C.byref(self.h))
+        if rc != 0:
+            self.h = None
+            raise _ERRS.get(rc, FastxError(rc, f"cannot open {path} for block-parallel reading"))
+
+    def pieces(self) -> Iterator[Tuple[np.ndarray, np.ndarray]]:
+        """(sequence bytes, offsets[n+1]) of every piece; raises FastxError where the serial reader would."""
+        while True:
+            pc = C.c_void_p()
+            rc = self.lib.bsk_fastx_par_next(self.h, C.byref(pc))
+            if rc != 0:
+                raise _ERRS.get(rc, FastxError(rc, self.lib.bsk_fastx_par_error(self.h).decode()))
+            if not pc.value:
+                return
+            n, sb, so = C.c_uint64(), C.c_void_p(), C.c_void_p()
+            self.lib.bsk_fastx_piece_data(pc, C.byref(n), C.byref(sb), C.byref(so))
+            offs = np.ctypeslib.as_array(C.cast(so, C.POINTER(C.c_uint64)), (n.value + 1,)).copy()
+            seq = np.ctypeslib.as_array(C.cast(sb, C.POINTER(C.c_uint8)), (max(int(offs[-1]), 1),))[: int(offs[-1])].copy()
+            self.lib.bsk_fastx_piece_release(self.h, pc)
+            yield seq, offs
+
+    def sequences(self) -> list:
+        out = []
+        for seq, offs in self.pieces():
+            out += [seq[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(len(offs) - 1)]
+        return out
+
+    def info(self):
+        q, a, r = C.c_int(), C.c_int(), C.c_uint64()
+        self.lib.bsk_fastx_par_info(self.h, C.byref(q), C.byref(a), C.byref(r))
+        return dict(is_fastq=q.value, alphabet=a.value, reparsed_pieces=r.value)
+
+    def close(self):
+        if self.h:
+            self.lib.bsk_fastx_par_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Reader:
     def __init__(self, path: str):
         self.lib = L.load()

@@ -195,6 +195,26 @@ void bsk_fastx_close(bsk_fastx *f);
 int bsk_batch_from_fastx(bsk_ctx *ctx, bsk_fastx *f, uint64_t max_records, uint64_t max_bytes, int alphabet, bsk_batch **out,
                          uint64_t *n_records);
 
+/* Block-parallel reader for PLAIN files (what ChunkChan's producer goroutine, reader.go:562-608, becomes when one thread cannot
+ * feed a GPU): the same records in the same order as bsk_fastx_read_chunk, sequences only.  n_threads parser threads work
+ * ahead on consecutive byte ranges of `piece_bytes` (0: 8 MiB); each guesses the first record start of its range, runs the
+ * record state machine of the serial reader from there, and the consumer (bsk_fastx_par_next, one thread) validates every
+ * guess against the previous piece's true end and re-parses a piece that started anywhere else -- so the records are the serial
+ * reader's for ANY input (multi-line FASTQ merely runs serially); bsk_fastx_par_info reports how many pieces were re-parsed.
+ * bsk_fastx_par_open: BSK_ERR_UNSUPPORTED for gzip files and "-" (use bsk_fastx_open), BSK_ERR_NOT_FASTX as above.
+ * bsk_fastx_par_next: the next piece with at least one record, *piece == NULL at the end; an error inside a piece is returned
+ * by the call after the one that delivered the records before it.  A piece stays valid until bsk_fastx_piece_release (any
+ * thread), which must precede bsk_fastx_par_close. */
+typedef struct bsk_fastx_par bsk_fastx_par;
+typedef struct bsk_fastx_piece bsk_fastx_piece;
+int bsk_fastx_par_open(const char *path, int n_threads, uint64_t piece_bytes, bsk_fastx_par **out);
+int bsk_fastx_par_next(bsk_fastx_par *f, bsk_fastx_piece **piece);
+int bsk_fastx_piece_data(const bsk_fastx_piece *piece, uint64_t *n, const uint8_t **seq_bytes, const uint64_t **seq_offsets);
+void bsk_fastx_piece_release(bsk_fastx_par *f, bsk_fastx_piece *piece);
+int bsk_fastx_par_info(const bsk_fastx_par *f, int *is_fastq, int *alphabet, uint64_t *reparsed_pieces);
+const char *bsk_fastx_par_error(const bsk_fastx_par *f);
+void bsk_fastx_par_close(bsk_fastx_par *f);
+
 /* ---- compute -------------------------------------------------------------------
  * Runs the iterator/sketch named by p->kind over every read of the batch.
  * *result == NULL: a result is allocated; otherwise it is reused (bench loops).
@@ -269,7 +289,9 @@ typedef struct bsk_pipeline_stats {
     double reader_seconds;       /* producer: inside the reader + the copy into pinned memory */
     double reader_wait_seconds;  /* producer: waiting for a free chunk buffer (the device side was the slower one) */
     double h2d_pack_seconds, kernel_seconds, fetch_seconds; /* summed over the workers */
-    int32_t n_streams, reserved;
+    int32_t n_streams;
+    int32_t reader_threads;      /* bsk_pipeline_fastx on a plain file: parser threads of the block-parallel reader (0: serial reader) */
+    uint64_t reparsed_pieces;    /* ... and the pieces whose guessed record start was wrong (parsed again, serially) */
 } bsk_pipeline_stats;
 int bsk_pipeline_fastx(int device, const char *path, int alphabet /* -1: guess from the first record */, const bsk_params *p, int n_streams,
                        uint64_t chunk_records, int fetch_tuples, bsk_pipeline_stats *stats);

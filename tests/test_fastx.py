@@ -192,3 +192,89 @@ def test_truncated_gzip_is_an_io_error(tmp_path):
     p2.write_bytes(blob)
     recs, _, err = read_all(str(p2))
     assert err is None and len(recs) == 20000
+
+
+def par_read(path, threads=3, piece=0):
+    try:
+        rd = fastx.ParallelReader(path, threads, piece)
+    except fastx.FastxError as e:
+        return [], e, None
+    seqs, err = [], None
+    try:
+        for seq, offs in rd.pieces():
+            seqs += [seq[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(len(offs) - 1)]
+    except fastx.FastxError as e:
+        err = e
+    info = rd.info()
+    rd.close()
+    return seqs, err, info
+
+
+def same_error(a, b):
+    return (a is None and b is None) or (a is not None and b is not None and (a is b or getattr(a, "code", 1) == getattr(b, "code", 2)))
+
+
+def test_block_parallel_reader_gives_the_serial_readers_records(tmp_path, monkeypatch):
+    """bsk_fastx_par_*: every edge case and the reference's fixtures, with pieces of 1 byte ... 1 MiB (a piece boundary at every
+    byte of every file) and tiny read windows: the same sequences in the same order, and the same error, as the serial reader."""
+    files = [os.path.join(GOLD, f) for f in ("test.fa", "test.fq", "test2.fq", "test3.fq", "test4.fa", "blank.fx", "blank1.fx", "empty.fx")]
+    for name, data in CASES.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        files.append(str(p))
+    for path in files:
+        recs, _, err = read_all(path)
+        want = [s for _, s, _ in recs]
+        for piece in (1, 2, 3, 5, 16, 37, 100, 1 << 20):
+            for buf in ("1", "3", "64", ""):
+                if buf:
+                    monkeypatch.setenv("BSK_FASTX_BUF", buf)
+                else:
+                    monkeypatch.delenv("BSK_FASTX_BUF", raising=False)
+                got, perr, info = par_read(path, 3, piece)
+                assert got == want, (path, piece, buf, len(got), len(want))
+                assert same_error(err, perr), (path, piece, buf, err, perr)
+
+
+def test_block_parallel_reader_on_generated_fastq(tmp_path):
+    """4-line FASTQ with qualities full of '@', '+', '>' (quality lines starting with '@' are where a guess can go wrong), FASTA with
+    '>' inside lines, multi-line FASTQ (no guess passes: every piece is re-parsed serially) and CRLF: pieces of many sizes."""
+    rng = random.Random(11)
+
+    def fastq(nrec, width=0, crlf=False):
+        out = bytearray()
+        nl = b"\r\n" if crlf else b"\n"
+        for i in range(nrec):
+            n = rng.choice([0, 1, 30, 75, 150])
+            s = bytes(rng.choice(b"ACGTN") for _ in range(n))
+            q = bytes(rng.choice(b"@@+>I5#") for _ in range(n))
+            if width:
+                s = nl.join(s[j:j + width] for j in range(0, max(n, 1), width))
+                q = nl.join(q[j:j + width] for j in range(0, max(n, 1), width))
+            out += b"@r%d @x>y" % i + nl + s + nl + b"+" + nl + q + nl
+        return bytes(out)
+
+    fa = bytearray()
+    for i in range(400):
+        s = bytes(rng.choice(b"ACGT>@") for _ in range(rng.choice([0, 5, 61, 200])))
+        fa += b">s%d a>b\n" % i + b"\n".join(s[j:j + 60] for j in range(0, max(len(s), 1), 60)) + b"\n"
+    for name, data, expect_reparse in (("a.fq", fastq(2000), False), ("crlf.fq", fastq(500, crlf=True), False), ("ml.fq", fastq(300, width=40), True),
+                                       ("a.fa", bytes(fa), False)):
+        p = tmp_path / name
+        p.write_bytes(data)
+        recs, _, err = read_all(str(p))
+        assert err is None
+        want = [s for _, s, _ in recs]
+        for piece in (64, 1000, 4096, 50000, 0):
+            for threads in (1, 4):
+                got, perr, info = par_read(str(p), threads, piece)
+                assert perr is None and got == want, (name, piece, threads, len(got), len(want))
+                if piece == 4096 and not expect_reparse:
+                    assert info["reparsed_pieces"] <= 2, (name, info)  # the guess is right nearly always
+    # a gzip file is not for this reader
+    gz = tmp_path / "z.fq.gz"
+    with gzip.open(gz, "wb") as g:
+        g.write(fastq(10))
+    with pytest.raises(fastx.FastxError) as ei:
+        fastx.ParallelReader(str(gz), 2)
+    assert ei.value.code == L.ERR_UNSUPPORTED

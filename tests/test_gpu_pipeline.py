@@ -2,6 +2,7 @@
 H2D + pack -> kernel -> tuples on the host over several streams must give exactly what one big batch gives."""
 import ctypes as C
 import gzip
+import os
 import random
 
 import numpy as np
@@ -50,6 +51,17 @@ def test_pipeline_equals_one_batch(engine, tmp_path, kind, pk):
         write_fastq(path, data, offs, gz)
         st = S.Engine.pipeline_fastx(path, p, n_streams=2, chunk_records=9000, fetch=True)
         assert (st["records"], st["bases"], st["tuples"], st["checksum"]) == (n, int(offs[-1]), want["n_tuples"], want["checksum"])
+        assert (st["reader_threads"] > 0) == (not gz)  # plain files: the block-parallel reader; gzip: one serial stream
+        if not gz:  # pieces far smaller than a chunk, and the serial reader on the same file
+            for env in ({"BSK_FASTX_PIECE": "20000", "BSK_FASTX_THREADS": "5"}, {"BSK_FASTX_SERIAL": "1"}):
+                os.environ.update(env)
+                try:
+                    st2 = S.Engine.pipeline_fastx(path, p, n_streams=3, chunk_records=7001, fetch=True)
+                finally:
+                    for k_ in env:
+                        del os.environ[k_]
+                assert (st2["records"], st2["tuples"], st2["checksum"]) == (n, want["n_tuples"], want["checksum"]), env
+                assert (st2["reader_threads"] == 0) == ("BSK_FASTX_SERIAL" in env)
     st = S.Engine.pipeline_memory(data, offs, p, n_streams=2, chunk_records=20000, repeat=3)
     assert st["records"] == 3 * n and st["checksum"] == (3 * want["checksum"]) % (1 << 64)
 
