@@ -37,6 +37,18 @@ def read_lib(path):
     except fastx.FastxError as e: err = e
     r.Close(); return recs, err
 
+def read_par(path, threads, piece):
+    try:
+        r = fastx.ParallelReader(path, threads, piece)
+    except fastx.FastxError as e:
+        return [], e
+    seqs = []; err = None
+    try:
+        for seq, offs in r.pieces():
+            seqs += [seq[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(len(offs) - 1)]
+    except fastx.FastxError as e: err = e
+    r.close(); return seqs, err
+
 rng_chunk = [0]
 first, count = int(sys.argv[1]), int(sys.argv[2])
 bad = 0
@@ -53,6 +65,11 @@ for seed in range(first, first + count):
     ok = got == want and ((oerr is None) == (err is None))
     if ok and oerr is not None:
         ok = (isinstance(oerr, FO.NotFastx) and err is fastx.ErrNotFASTXFormat) or (not isinstance(oerr, FO.NotFastx) and err is fastx.ErrBadFASTQFormat)
+    if ok:  # the block-parallel reader: the serial reader's sequences and error, whatever the piece size
+        piece, threads = rng.choice([1, 2, 3, 7, 20, 50, 200, 1 << 20]), rng.choice([1, 2, 4])
+        pgot, perr = read_par(path, threads, piece)
+        ok = pgot == [s_ for _, s_, _ in want] and ((perr is None) == (err is None)) and (perr is None or perr is err or perr.code == err.code)
+        if not ok: print("PARALLEL piece", piece, "threads", threads, pgot[:3], perr)
     if not ok:
         bad += 1
         print("SEED", seed, "buf", os.environ["BSK_FASTX_BUF"], repr(data[:200]), "\n  lib", got[:3], err, "\n  ora", want[:3], oerr)
