@@ -135,9 +135,9 @@ def end_to_end(kind: str, p, batch, read_len: int, n_streams: int = 3):
     n_mem = min(n_have, int(16_000_000 * scale))
     data, offs = batch.fetch_ascii(0, n_mem)
     alpha = 1 if kind in PROTEIN else 0
-    out = {"n_streams": n_streams, "chunk_records": 1 << 20,
+    out = {"n_streams": n_streams, "chunk_records": 1 << 18,
            "what": "host ASCII -> pinned chunks -> H2D + 2-bit pack -> kernel -> every tuple back in pinned host memory; stages of different chunks overlap"}
-    st = S.Engine.pipeline_memory(data, offs, p, n_streams=n_streams, chunk_records=1 << 20, repeat=2, fetch=True, alphabet=alpha)
+    st = S.Engine.pipeline_memory(data, offs, p, n_streams=n_streams, chunk_records=1 << 18, repeat=2, fetch=True, alphabet=alpha)
     out["from_memory"] = {"value": round(st["bases"] / st["seconds"] / 1e9, 3), "unit": "Gresidues/s" if alpha else "Gbases/s",
                           "reads": st["records"], "seconds": round(st["seconds"], 4),
                           "stage_seconds_summed_over_streams": {k: round(st[k], 4) for k in ("reader_seconds", "reader_wait_seconds", "h2d_pack_seconds", "kernel_seconds", "fetch_seconds")},
@@ -168,7 +168,7 @@ def end_to_end(kind: str, p, batch, read_len: int, n_streams: int = 3):
         with open(gzp, "wb") as f:
             f.write(gzip.compress(arr[:n_gz].tobytes(), 1))
         for tag, path in (("from_plain_file", plain), ("from_gzip_file", gzp)):
-            st = S.Engine.pipeline_fastx(path, p, n_streams=n_streams, chunk_records=1 << 20, fetch=True, alphabet=alpha)
+            st = S.Engine.pipeline_fastx(path, p, n_streams=n_streams, chunk_records=1 << 18, fetch=True, alphabet=alpha)
             out[tag] = {"value": round(st["bases"] / st["seconds"] / 1e9, 3), "unit": "Gresidues/s" if alpha else "Gbases/s",
                         "reads": st["records"], "file_bytes": os.path.getsize(path), "seconds": round(st["seconds"], 4),
                         "reader_seconds": round(st["reader_seconds"], 4), "reader_wait_seconds": round(st["reader_wait_seconds"], 4),

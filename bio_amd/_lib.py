@@ -32,7 +32,7 @@ POS_STRAND_BIT, POS_MASK = 0x80000000, 0x7FFFFFFF
 class PipelineStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("records", "bases", "tuples", "chunks", "checksum")] + \
                [(n, C.c_double) for n in ("seconds", "reader_seconds", "reader_wait_seconds", "h2d_pack_seconds", "kernel_seconds", "fetch_seconds")] + \
-               [("n_streams", C.c_int32), ("reader_threads", C.c_int32), ("reparsed_pieces", C.c_uint64)]
+               [("n_streams", C.c_int32), ("reader_threads", C.c_int32), ("reparsed_pieces", C.c_uint64), ("pin_seconds", C.c_double)]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -25,16 +25,21 @@ namespace {
 using clk = std::chrono::steady_clock;
 inline double secs(clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); }
 
+std::atomic<uint64_t> g_pin_ns{0};  // time spent pinning / unpinning host memory (all threads), for the statistics
+
 struct PinBuf {  // grow-only pinned host buffer
     void *p = nullptr;
     size_t cap = 0;
     bool ensure(size_t bytes) {
         if (cap >= bytes) return true;
+        const auto t0 = clk::now();
         if (p) (void)hipHostFree(p);
         p = nullptr;
         cap = 0;
         const size_t want = bytes + bytes / 4 + 4096;
-        if (hipHostMalloc(&p, want) != hipSuccess) return false;
+        const bool ok = hipHostMalloc(&p, want) == hipSuccess;
+        g_pin_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count();
+        if (!ok) return false;
         cap = want;
         return true;
     }
@@ -224,6 +229,7 @@ int run_pipeline(int device, Source &src, const bsk_params *p, int n_streams, ui
         free_q.close();
     };
     const auto t_start = clk::now();
+    const uint64_t pin0 = g_pin_ns.load();
     double reader_s = 0, reader_wait_s = 0;
     std::thread producer([&] {
         (void)hipSetDevice(device);
@@ -321,6 +327,7 @@ int run_pipeline(int device, Source &src, const bsk_params *p, int n_streams, ui
     st->reader_seconds = reader_s;
     st->reader_wait_seconds = reader_wait_s;
     st->n_streams = n_streams;
+    st->pin_seconds = (double)(g_pin_ns.load() - pin0) * 1e-9;
     return error.load();
 }
 

@@ -249,7 +249,7 @@ class Engine:
 
     # -- end to end: file / host memory -> tuples on the host, stages overlapped over n_streams contexts (bsk_pipeline_*)
     @staticmethod
-    def pipeline_fastx(path: str, params, n_streams: int = 2, chunk_records: int = 1 << 20, fetch: bool = True, alphabet: int = -1, device: int = 0):
+    def pipeline_fastx(path: str, params, n_streams: int = 2, chunk_records: int = 1 << 18, fetch: bool = True, alphabet: int = -1, device: int = 0):
         lib = L.load()
         st = L.PipelineStats()
         rc = lib.bsk_pipeline_fastx(device, path.encode(), alphabet, C.byref(params), n_streams, chunk_records, 1 if fetch else 0, C.byref(st))

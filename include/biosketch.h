@@ -292,6 +292,7 @@ typedef struct bsk_pipeline_stats {
     int32_t n_streams;
     int32_t reader_threads;      /* bsk_pipeline_fastx on a plain file: parser threads of the block-parallel reader (0: serial reader) */
     uint64_t reparsed_pieces;    /* ... and the pieces whose guessed record start was wrong (parsed again, serially) */
+    double pin_seconds;          /* summed over all threads: hipHostMalloc / hipHostFree of the chunk and result buffers (start-up cost) */
 } bsk_pipeline_stats;
 int bsk_pipeline_fastx(int device, const char *path, int alphabet /* -1: guess from the first record */, const bsk_params *p, int n_streams,
                        uint64_t chunk_records, int fetch_tuples, bsk_pipeline_stats *stats);
