@@ -38,14 +38,6 @@ __device__ __forceinline__ void seq_span(const u64 *refs, const u64 *wfirst, con
     }
 }
 
-__global__ void k_counts(const u64 *refs, const u64 *wfirst, const u64 *wcount, u64 n, u64 *cnt) {
-    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) {
-        u64 f, c;
-        seq_span(refs, wfirst, wcount, r, f, c);
-        cnt[r] = c;
-    }
-}
-
 // dense copy of every sequence's values (one wavefront per sequence); values above maxhash become the sentinel ~0 so that
 // they sort to the end of their segment
 __global__ void k_gather_values(const u64 *hash, const u64 *refs, const u64 *wfirst, const u64 *wcount, const u64 *dst, u64 n, u64 maxhash,
@@ -85,54 +77,267 @@ __global__ void k_new_offsets(const u64 *offs_in, const u64 *pos, u64 n_sets, u6
 }
 
 // ---- small sets: every sequence holds at most 64 values (short reads: ~22 minimizers, ~7 syncmers per 150-bp read) ----
-// A segmented radix sort spends eight digit passes on segments of two dozen keys.  Here a sequence is sorted by a GROUP of
-// G = 32 (or 64) lanes holding one value each: the group loads the sequence's values with one coalesced load, runs a bitonic
-// network across its lanes (log2(G)(log2(G)+1)/2 exchange steps: ds_bpermute + 64-bit compare + select, no LDS memory, a
-// dozen registers -- full occupancy), drops duplicates by comparing with the lane below, and stores the distinct values as
-// one dense run at the sequence's input offset (ballot + mbcnt).  k_move_seqs then shifts the runs to their final offsets.
+// A segmented radix sort spends eight digit passes on segments of two dozen keys.  Here a sequence is sorted by ONE ROW of 16
+// lanes (a DPP row: four sequences per wavefront), every lane holding E = 2 or 4 of its values (element e = reg * 16 + lane):
+// a bitonic network whose exchange distances 1, 2, 4, 8 are DPP moves inside the row (quad_perm, row_half_mirror, row_ror:8 --
+// no LDS crossbar: the first version, one value per lane and ds_bpermute for every distance, was bound by it at 5.4 ms per 10^7
+// reads) and whose distances 16, 32 are compare-exchanges between a lane's own registers.  A wavefront takes the 32-value
+// network unless one of its four sequences holds more than 32 values (0.3 % of 150-bp reads at k = 21, w = 11), the 16-value
+// network when none holds more than 16 (syncmers).  Duplicates go by comparing with the element below; the distinct values
+// leave as one dense run at the sequence's input offset (ballot + bit counts), k_move_seqs then shifts the runs to their final
+// offsets.  (Measured and dropped: ONE kernel that stages a unit of 32 sequences in LDS, takes its final offset from a
+// decoupled look-back and writes the final array directly -- no dense copy, no second scan, no move, half the traffic -- ran
+// 4.4 ms against the 2.8 ms of rows + move: at 9 waves per CU, the 16 KB of staging, a unit's ticket, reference words, values
+// and look-back are five exposed round trips per 32 sequences.)
 #define SMALL_CAP 64
-template <int G>
-__global__ __launch_bounds__(256) void k_sets_small(const u64 *hash, const u64 *refs, const u64 *wfirst, const u64 *wcount, const u64 *offs, u64 n,
-                                                    u64 maxhash, u64 *tmp, u64 *ucount) {
-    constexpr int PER_WAVE = 64 / G;
-    const int lane = threadIdx.x & 63, gl = lane & (G - 1), grp = lane / G;
-    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
-    const u64 ngroups = (n + PER_WAVE - 1) / PER_WAVE;  // wave iterations
-    for (u64 it = wave; it < ngroups; it += nw) {
-        const u64 r = it * PER_WAVE + grp;
-        u64 first = 0, c = 0;
-        if (r < n) seq_span(refs, wfirst, wcount, r, first, c);
-        u64 v = ~0ULL;
-        bool valid = false;
-        if ((u64)gl < c) {
-            v = hash[first + gl];
-            valid = v <= maxhash;
-            if (!valid) v = ~0ULL;  // filtered values sort to the end with the padding
-        }
-        const u64 vm = __ballot(valid);
-        const u32 nvalid = (u32)__builtin_popcountll(G == 64 ? vm : ((vm >> (grp * G)) & ((1ULL << (G & 63)) - 1)));
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_mov(u32 x) {
+    return (u32)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, 0xf, 0xf, false);
+}
+template <int J>
+__device__ __forceinline__ u64 row_xor(u64 v) {  // lane l of every row of 16 receives lane l ^ J
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+    if (J == 1) {
+        lo = dpp_mov<0xB1>(lo);  // quad_perm [1,0,3,2]
+        hi = dpp_mov<0xB1>(hi);
+    } else if (J == 2) {
+        lo = dpp_mov<0x4E>(lo);  // quad_perm [2,3,0,1]
+        hi = dpp_mov<0x4E>(hi);
+    } else if (J == 4) {
+        lo = dpp_mov<0x1B>(dpp_mov<0x141>(lo));  // row_half_mirror (l -> 7 - l within 8), then quad_perm [3,2,1,0]
+        hi = dpp_mov<0x1B>(dpp_mov<0x141>(hi));
+    } else {
+        lo = dpp_mov<0x128>(lo);  // row_ror:8
+        hi = dpp_mov<0x128>(hi);
+    }
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 row_below(u64 v) {  // lane l receives lane (l - 1) & 15 of its row
+    return ((u64)dpp_mov<0x121>((u32)(v >> 32)) << 32) | dpp_mov<0x121>((u32)v);  // row_ror:1
+}
+
+// ascending bitonic sort of the 16 * E values of every row (element e = reg * 16 + l)
+template <int E>
+__device__ __forceinline__ void sort_rows(u64 (&v)[E], int l) {
+    constexpr int NE = 16 * E;
 #pragma unroll
-        for (int k = 2; k <= G; k <<= 1) {
+    for (int k = 2; k <= NE; k <<= 1) {
 #pragma unroll
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                const u64 o = __shfl_xor(v, j, 64);
-                const bool up = (gl & k) == 0;             // this block of k lanes sorts ascending
-                const bool lower = (gl & j) == 0;          // this lane keeps the smaller one when ascending
-                const bool take_min = lower == up;
-                const bool o_less = o < v;
-                v = (take_min == o_less) ? o : v;
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 16) {  // partner in another register of the same lane
+                const int dj = j >> 4;
+#pragma unroll
+                for (int reg = 0; reg < E; ++reg) {
+                    if (reg & dj) continue;
+                    const bool asc = ((reg * 16) & k) == 0;
+                    const u64 a = v[reg], b = v[reg | dj];
+                    const bool lt = b < a;
+                    const u64 mn = lt ? b : a, mx = lt ? a : b;
+                    v[reg] = asc ? mn : mx;
+                    v[reg | dj] = asc ? mx : mn;
+                }
+            } else {
+                const bool lower = (l & j) == 0;
+#pragma unroll
+                for (int reg = 0; reg < E; ++reg) {
+                    const bool asc = k < 16 ? (l & k) == 0 : ((reg * 16) & k) == 0;
+                    const bool take_min = lower == asc;
+                    u64 o;
+                    switch (j) {
+                        case 1: o = row_xor<1>(v[reg]); break;
+                        case 2: o = row_xor<2>(v[reg]); break;
+                        case 4: o = row_xor<4>(v[reg]); break;
+                        default: o = row_xor<8>(v[reg]); break;
+                    }
+                    const bool o_less = o < v[reg];
+                    v[reg] = (take_min == o_less) ? o : v[reg];
+                }
             }
         }
-        // ascending within the group; lanes < nvalid hold the values that passed the filter
-        const u64 below = __shfl_up(v, 1, 64);
-        const bool keep = (u32)gl < nvalid && (gl == 0 || v != below);
-        const u64 km = __ballot(keep);
-        const u64 gm = G == 64 ? km : ((km >> (grp * G)) & ((1ULL << (G & 63)) - 1));
-        const u32 rank = (u32)__builtin_popcountll(gm & ((1ULL << gl) - 1));
-        if (keep) tmp[offs[r] + rank] = v;
-        if (gl == 0 && r < n) ucount[r] = (u64)__builtin_popcountll(gm);
     }
 }
+
+// load, filter, sort and flag the distinct values of the row's sequence: keep[reg] / rank rk[reg] of element reg * 16 + l among
+// the kept ones; returns their number (the same in all 16 lanes of the row)
+template <int E>
+__device__ __forceinline__ u32 row_set(const u64 *src, u32 c, u64 maxhash, int l, int row, u64 (&v)[E], bool (&keep)[E], u32 (&rk)[E]) {
+    u32 nvalid = 0;
+#pragma unroll
+    for (int reg = 0; reg < E; ++reg) {
+        const u32 e = (u32)(reg * 16 + l);
+        u64 x = ~0ULL;
+        bool valid = false;
+        if (e < c) {
+            x = src[e];
+            valid = x <= maxhash;
+            if (!valid) x = ~0ULL;  // filtered values sort to the end with the padding
+        }
+        v[reg] = x;
+        const u64 vm = __ballot(valid);
+        nvalid += (u32)__builtin_popcount((u32)(vm >> (row * 16)) & 0xffffu);
+    }
+    sort_rows<E>(v, l);
+    u32 base = 0;
+#pragma unroll
+    for (int reg = 0; reg < E; ++reg) {
+        const u64 t = (reg > 0 && l == 15) ? v[reg - 1] : v[reg];  // lane 0 looks at lane 15 of the register below
+        const u64 below = row_below(t);
+        const u32 e = (u32)(reg * 16 + l);
+        keep[reg] = e < nvalid && (e == 0 || v[reg] != below);
+        const u32 bits = (u32)(__ballot(keep[reg]) >> (row * 16)) & 0xffffu;
+        rk[reg] = base + (u32)__builtin_popcount(bits & ((1u << l) - 1u));
+        base += (u32)__builtin_popcount(bits);
+    }
+    return base;
+}
+
+template <int E>
+__device__ __forceinline__ u32 rows_store(const u64 *src, u32 c, u64 maxhash, int l, int row, u64 *dst) {
+    u64 v[E];
+    bool keep[E];
+    u32 rk[E];
+    const u32 u = row_set<E>(src, c, maxhash, l, row, v, keep, rk);
+#pragma unroll
+    for (int reg = 0; reg < E; ++reg)
+        if (keep[reg]) dst[rk[reg]] = v[reg];
+    return u;
+}
+__global__ __launch_bounds__(256) void k_sets_rows(const u64 *hash, const u64 *refs, const u64 *wfirst, const u64 *wcount, const u64 *offs, u64 n,
+                                                   u64 maxhash, u64 *tmp, u64 *ucount) {
+    const int lane = threadIdx.x & 63, l = lane & 15, row = lane >> 4;
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
+    const u64 nit = (n + 3) / 4;  // wave iterations: four sequences each
+    for (u64 it = wave; it < nit; it += nw) {
+        const u64 r = it * 4 + (u64)row;
+        u64 first = 0, c = 0, d = 0;
+        if (r < n) {
+            seq_span(refs, wfirst, wcount, r, first, c);
+            d = offs[r];
+        }
+        u32 u;
+        if (__ballot(c > 32)) u = rows_store<4>(hash + first, (u32)c, maxhash, l, row, tmp + d);
+        else if (__ballot(c > 16)) u = rows_store<2>(hash + first, (u32)c, maxhash, l, row, tmp + d);
+        else u = rows_store<1>(hash + first, (u32)c, maxhash, l, row, tmp + d);
+        if (l == 0 && r < n) ucount[r] = u;
+    }
+}
+
+// ---- exclusive scan of n per-sequence numbers (counts taken from the result's reference words, or an array) into out[0 .. n]
+// (out[n] = the total); three small kernels: block sums, one block over the block sums, local scan + block offset ----
+struct CountOf {
+    const u64 *refs, *wfirst, *wcount;
+    __device__ __forceinline__ u64 operator()(u64 r) const {
+        u64 f, c;
+        seq_span(refs, wfirst, wcount, r, f, c);
+        return c;
+    }
+};
+struct ArrayOf {
+    const u64 *a;
+    __device__ __forceinline__ u64 operator()(u64 r) const { return a[r]; }
+};
+#define SCAN_PER_THREAD 8
+#define SCAN_BLOCK 256
+#define SCAN_CHUNK (SCAN_PER_THREAD * SCAN_BLOCK)
+__device__ __forceinline__ u64 wave_incl(u64 x, int lane) {
+    for (int d = 1; d < 64; d <<= 1) {
+        const u64 t = __shfl_up(x, d, 64);
+        if (lane >= d) x += t;
+    }
+    return x;
+}
+template <class F>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_sums(F f, u64 n, u64 *part, u64 *mx) {
+    __shared__ u64 s_w[SCAN_BLOCK / 64];
+    const u64 b0 = (u64)blockIdx.x * SCAN_CHUNK;
+    u64 sum = 0, m = 0, x[SCAN_PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < SCAN_PER_THREAD; ++i) {  // all loads in flight before the first use
+        const u64 r = b0 + (u64)i * SCAN_BLOCK + threadIdx.x;
+        x[i] = r < n ? f(r) : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < SCAN_PER_THREAD; ++i) {
+        sum += x[i];
+        m = x[i] > m ? x[i] : m;
+    }
+    for (int d = 32; d; d >>= 1) {
+        sum += __shfl_xor(sum, d, 64);
+        const u64 t = __shfl_xor(m, d, 64);
+        m = t > m ? t : m;
+    }
+    __shared__ u64 s_m[SCAN_BLOCK / 64];
+    if ((threadIdx.x & 63) == 0) {
+        s_w[threadIdx.x >> 6] = sum;
+        s_m[threadIdx.x >> 6] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 t = 0, bm = 0;
+        for (int w = 0; w < SCAN_BLOCK / 64; ++w) {
+            t += s_w[w];
+            bm = s_m[w] > bm ? s_m[w] : bm;
+        }
+        part[blockIdx.x] = t;
+        // one atomic per block, and only when it can raise the maximum (thousands of blocks hitting one address serialise in the L2)
+        if (mx && bm > __hip_atomic_load(mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax((unsigned long long *)mx, (unsigned long long)bm);
+    }
+}
+__global__ __launch_bounds__(1024) void k_scan_top(u64 *part, u64 nb, u64 *total) {  // in place: part[b] <- sum of part[0 .. b)
+    __shared__ u64 s_w[16];
+    __shared__ u64 s_carry;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (u64 b0 = 0; b0 < nb; b0 += 1024) {
+        const u64 i = b0 + threadIdx.x;
+        const u64 x = i < nb ? part[i] : 0;
+        const u64 inc = wave_incl(x, lane);
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        u64 before = s_carry;
+        for (int q = 0; q < w; ++q) before += s_w[q];
+        if (i < nb) part[i] = before + inc - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+template <class F>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(F f, u64 n, const u64 *part, const u64 *total, u64 *out) {
+    __shared__ u64 s_w[SCAN_BLOCK / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // thread t owns SCAN_PER_THREAD consecutive numbers
+    const u64 r0 = (u64)blockIdx.x * SCAN_CHUNK + (u64)threadIdx.x * SCAN_PER_THREAD;
+    u64 x[SCAN_PER_THREAD], sum = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_PER_THREAD; ++i) x[i] = r0 + i < n ? f(r0 + i) : 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_PER_THREAD; ++i) sum += x[i];
+    const u64 inc = wave_incl(sum, lane);
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    u64 run = part[blockIdx.x] + inc - sum;
+    for (int q = 0; q < w; ++q) run += s_w[q];
+#pragma unroll
+    for (int i = 0; i < SCAN_PER_THREAD; ++i) {
+        if (r0 + i < n) out[r0 + i] = run;
+        run += x[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
+}
+// out[0..n] = exclusive scan of f(0..n-1); *total_dev (device) receives the total, *mx_dev (may be NULL) the maximum
+template <class F>
+hipError_t scan_counts(hipStream_t st, F f, u64 n, u64 *part, u64 *out, u64 *total_dev, u64 *mx_dev) {
+    const u64 nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (nb) hipLaunchKernelGGL(k_scan_sums<F>, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, f, n, part, mx_dev);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, st, part, nb, total_dev);
+    if (nb) hipLaunchKernelGGL(k_scan_apply<F>, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, f, n, part, total_dev, out);
+    else hipLaunchKernelGGL(k_scan_apply<F>, dim3(1), dim3(SCAN_BLOCK), 0, st, f, n, part, total_dev, out);
+    return hipGetLastError();
+}
+
 // final placement: sequence r's run [in_off[r], +ucount[r]) -> [out_off[r], ...); a group of 32 lanes per sequence
 __global__ void k_move_seqs(const u64 *tmp, const u64 *in_off, const u64 *out_off, const u64 *ucount, u64 n, u64 *out) {
     const u64 g = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 5, ng = ((u64)gridDim.x * blockDim.x) >> 5;
@@ -142,16 +347,6 @@ __global__ void k_move_seqs(const u64 *tmp, const u64 *in_off, const u64 *out_of
         for (u64 i = gl; i < t; i += 32) out[d0 + i] = tmp[s0 + i];
     }
 }
-__global__ void k_max_count(const u64 *cnt, u64 n, u64 *mx) {
-    u64 m = 0;
-    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) m = cnt[r] > m ? cnt[r] : m;
-    for (int d = 32; d; d >>= 1) {
-        const u64 t = __shfl_xor(m, d, 64);
-        m = t > m ? t : m;
-    }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(mx, m);
-}
-
 int grid_of(bsk_ctx *ctx, u64 items, int block) {
     const u64 g = (items + block - 1) / block;
     return (int)std::max<u64>(1, std::min<u64>(g, (u64)ctx->cus * 16));
@@ -178,14 +373,12 @@ extern "C" int bsk_result_sets(bsk_ctx *ctx, const bsk_result *r, int scope, int
     const u64 maxhash = scale > 1 ? ~0ULL / (u64)scale : ~0ULL;
     const u64 n_sets = scope == BSK_SETS_WHOLE_BATCH ? 1 : n;
     hipStream_t st = ctx->stream;
-    u64 *cnt = nullptr, *offs = nullptr, *vin = nullptr, *vsorted = nullptr, *pos = nullptr;
+    u64 *offs = nullptr /* pooled */, *vin = nullptr, *vsorted = nullptr, *pos = nullptr;
     u8 *head = nullptr;
     u32 *keep = nullptr;
     void *tmp = nullptr;
     bsk_sets *res = nullptr;
     auto done = [&](int code) {
-        (void)hipFree(cnt);
-        (void)hipFree(offs);
         (void)hipFree(vin);
         (void)hipFree(vsorted);
         (void)hipFree(pos);
@@ -200,25 +393,31 @@ extern "C" int bsk_result_sets(bsk_ctx *ctx, const bsk_result *r, int scope, int
         hipError_t e__ = (call);                                    \
         if (e__ != hipSuccess) return done(fail_hip(ctx, e__, #call)); \
     } while (0)
-    // 1. dense copy of the values, sequence after sequence
-    SCHK(hipMalloc(&cnt, (n + 66) * 8));
-    SCHK(hipMalloc(&offs, (n + 66) * 8));  // (+64: the small-set path reads offs[64 * unit] of a last, partial unit)
-    SCHK(hipMemsetAsync(cnt, 0, (n + 66) * 8, st));
-    SCHK(hipMemsetAsync(ctx->d_total, 0, 8, st));
-    if (n) {
-        hipLaunchKernelGGL(k_counts, dim3(grid_of(ctx, n, 256)), dim3(256), 0, st, r->refs, r->wfirst, r->wcount, n, cnt);
-        hipLaunchKernelGGL(k_max_count, dim3(grid_of(ctx, n, 256)), dim3(256), 0, st, cnt, n, ctx->d_total);
-    }
-    size_t tb = 0;
-    SCHK(rocprim::exclusive_scan(nullptr, tb, cnt, offs, (u64)0, n + 65, rocprim::plus<u64>(), st));
-    SCHK(hipMalloc(&tmp, tb ? tb : 8));
-    SCHK(rocprim::exclusive_scan(tmp, tb, cnt, offs, (u64)0, n + 65, rocprim::plus<u64>(), st));
+    // temporaries of every call come from the context's grow-only pool (hipMalloc / hipFree synchronise the device)
+    auto pool = [&](int slot, size_t bytes, void **outp) -> hipError_t {
+        if (ctx->tmp_cap[slot] < bytes) {
+            (void)hipFree(ctx->tmp[slot]);
+            ctx->tmp[slot] = nullptr;
+            ctx->tmp_cap[slot] = 0;
+            const size_t want = bytes + bytes / 4 + 256;
+            const hipError_t e = hipMalloc(&ctx->tmp[slot], want);
+            if (e != hipSuccess) return e;
+            ctx->tmp_cap[slot] = want;
+        }
+        *outp = ctx->tmp[slot];
+        return hipSuccess;
+    };
+    // 1. where every sequence's values go in a dense copy: exclusive scan of the counts (+ the largest count)
+    u64 *part = nullptr;
+    SCHK(pool(0, (n + 2) * 8, (void **)&offs));
+    SCHK(pool(1, ((n + SCAN_CHUNK - 1) / SCAN_CHUNK + 2) * 8, (void **)&part));
+    SCHK(hipMemsetAsync(ctx->d_total, 0, 16, st));  // [0] largest count, [1] total
+    SCHK(scan_counts(st, CountOf{r->refs, r->wfirst, r->wcount}, n, part, offs, ctx->d_total + 1, ctx->d_total));
     u64 N = 0, max_count = 0;
-    SCHK(hipMemcpyAsync(&N, offs + n, 8, hipMemcpyDeviceToHost, st));
+    SCHK(hipMemcpyAsync(&N, ctx->d_total + 1, 8, hipMemcpyDeviceToHost, st));
     SCHK(hipMemcpyAsync(&max_count, ctx->d_total, 8, hipMemcpyDeviceToHost, st));
     SCHK(hipStreamSynchronize(st));
-    (void)hipFree(tmp);
-    tmp = nullptr;
+    size_t tb = 0;
     if (N >= (1ULL << 32)) {
         ctx->err = "bsk_result_sets: more than 2^32 values in one call (split the batch)";
         return done(BSK_ERR_UNSUPPORTED);
@@ -236,29 +435,19 @@ extern "C" int bsk_result_sets(bsk_ctx *ctx, const bsk_result *r, int scope, int
         return done(BSK_OK);
     }
     if (scope == BSK_SETS_PER_SEQUENCE && max_count <= SMALL_CAP && !getenv("BSK_SETS_NO_SMALL")) {
-        // short reads: one sequence per group of 32 / 64 lanes, bitonic network across the lanes (k_sets_small)
-        u64 *ucount = nullptr, *ooffs = nullptr;
-        SCHK(hipMalloc(&vin, N * 8));                    // the sequences' distinct values at their input offsets
-        SCHK(hipMalloc(&keep, (n + 66) * 8));            // ucount (as u64)
-        SCHK(hipMalloc(&vsorted, (n + 66) * 8));         // output offsets
-        ucount = (u64 *)keep;
-        ooffs = vsorted;
-        SCHK(hipMemsetAsync(ucount, 0, (n + 66) * 8, st));
-        const unsigned sgrid = (unsigned)std::max<u64>(1, std::min<u64>((n + 7) / 8, (u64)ctx->cus * 32));
-        if (max_count <= 32)
-            hipLaunchKernelGGL(k_sets_small<32>, dim3(sgrid), dim3(256), 0, st, r->hash, r->refs, r->wfirst, r->wcount, offs, n, maxhash, vin, ucount);
-        else
-            hipLaunchKernelGGL(k_sets_small<64>, dim3(sgrid), dim3(256), 0, st, r->hash, r->refs, r->wfirst, r->wcount, offs, n, maxhash, vin, ucount);
+        // short reads: one sequence per row of 16 lanes, bitonic network over DPP moves (k_sets_rows)
+        u64 *ucount = nullptr, *dense = nullptr;
+        SCHK(pool(2, N * 8, (void **)&dense));          // the sequences' distinct values at their input offsets
+        SCHK(pool(3, (n + 2) * 8, (void **)&ucount));
+        const unsigned sgrid = (unsigned)std::max<u64>(1, std::min<u64>((n + 15) / 16, (u64)ctx->cus * 32));
+        hipLaunchKernelGGL(k_sets_rows, dim3(sgrid), dim3(256), 0, st, r->hash, r->refs, r->wfirst, r->wcount, offs, n, maxhash, dense, ucount);
         SCHK(hipGetLastError());
-        SCHK(rocprim::exclusive_scan(nullptr, tb, ucount, ooffs, (u64)0, n + 1, rocprim::plus<u64>(), st));
-        SCHK(hipMalloc(&tmp, tb ? tb : 8));
-        SCHK(rocprim::exclusive_scan(tmp, tb, ucount, ooffs, (u64)0, n + 1, rocprim::plus<u64>(), st));
-        hipLaunchKernelGGL(k_move_seqs, dim3((unsigned)std::max<u64>(1, std::min<u64>((n + 7) / 8, (u64)ctx->cus * 32))), dim3(256), 0, st, vin, offs, ooffs, ucount, n,
-                           res->values);
+        SCHK(scan_counts(st, ArrayOf{ucount}, n, part, res->offsets, ctx->d_total + 1, (u64 *)nullptr));
+        hipLaunchKernelGGL(k_move_seqs, dim3((unsigned)std::max<u64>(1, std::min<u64>((n + 7) / 8, (u64)ctx->cus * 32))), dim3(256), 0, st, dense, offs, res->offsets,
+                           ucount, n, res->values);
         SCHK(hipGetLastError());
-        SCHK(hipMemcpyAsync(res->offsets, ooffs, (n + 1) * 8, hipMemcpyDeviceToDevice, st));
         u64 M = 0;
-        SCHK(hipMemcpyAsync(&M, ooffs + n, 8, hipMemcpyDeviceToHost, st));
+        SCHK(hipMemcpyAsync(&M, ctx->d_total + 1, 8, hipMemcpyDeviceToHost, st));
         SCHK(hipStreamSynchronize(st));
         res->n_values = M;
         *out = res;

@@ -43,6 +43,52 @@ def test_sets_equal_numpy_unique(engine, kind, pk, scale):
             assert np.array_equal(got, w), (kind, pk, scale, whole, i, len(got), len(w))
 
 
+def oracle_values(oracle, kind, pk, q):
+    """Next*() values of the reference iterator / sketch for one sequence, from the CPU oracle ([] where the constructor fails)."""
+    try:
+        if kind == L.MINIMIZER:
+            return oracle.minimizer(q, pk["k"], pk["w"], False, closed=True)[0]
+        if kind == L.SYNCMER:
+            return oracle.syncmer(q, pk["k"], pk["s"], False, closed=True)[0]
+        if kind == L.NTHASH:
+            return oracle.nthash(q, pk["k"], True)[0]
+        return oracle.kmer_codes(q, pk["k"], True, False)
+    except oracle.OracleError:
+        return np.zeros(0, np.uint64)
+
+
+@pytest.mark.parametrize("kind,pk", [(L.MINIMIZER, dict(k=21, w=11)), (L.SYNCMER, dict(k=31, s=11)), (L.NTHASH, dict(k=21)),
+                                     (L.MINIMIZER, dict(k=7, w=4)), (L.KMER, dict(k=6))])
+@pytest.mark.parametrize("scale", [1, 10])
+def test_sets_equal_the_oracles_sorted_distinct_values(engine, oracle, kind, pk, scale):
+    """What kmcp / unikmer keep of a sketch: collect every Next*() value of the reference iterator, drop those above
+    MaxUint64/scale (the FracMinHash rule of iterator.go:181-185), sort, de-duplicate -- computed here from the CPU ORACLE's values,
+    not from the engine's own tuples: per sequence (both the one-group-per-sequence bitonic kernel for small counts and the
+    segmented radix sort) and for the whole batch."""
+    rng = random.Random(kind * 100 + scale)
+    seqs = [rand_seq(rng, rng.choice([150, 150, rng.randint(1, 400)])) for _ in range(300)]
+    seqs += ["", "A" * 300, "AC" * 200, "ACGTTGCAACGT" * 30, rand_seq(rng, 3000), rand_seq(rng, 9000)]  # duplicates; counts above 64
+    maxhash = np.uint64((2**64 - 1) // scale)
+    per = []
+    for q in seqs:
+        v = np.asarray(oracle_values(oracle, kind, pk, q), np.uint64)
+        per.append(np.unique(v[v <= maxhash]))
+    b = engine.batch(seqs)
+    res = engine.run(b, engine.params(kind, **pk))
+    offs, vals = res.sets(whole_batch=False, scale=scale)
+    assert len(offs) == len(seqs) + 1 and int(offs[-1]) == len(vals)
+    for i, w in enumerate(per):
+        assert np.array_equal(vals[int(offs[i]):int(offs[i + 1])], w), (kind, pk, scale, i, len(w))
+    offs, vals = res.sets(whole_batch=True, scale=scale)
+    assert list(offs) == [0, len(vals)] and np.array_equal(vals, np.unique(np.concatenate(per)))
+    # short reads only: every count <= 64, the small-set kernel alone
+    b2 = engine.batch(seqs[:300])
+    res2 = engine.run(b2, engine.params(kind, **pk))
+    offs, vals = res2.sets(whole_batch=False, scale=scale)
+    for i, w in enumerate(per[:300]):
+        assert np.array_equal(vals[int(offs[i]):int(offs[i + 1])], w), ("small", kind, pk, scale, i)
+
+
 def test_sets_of_tiled_and_mixed_results(engine):
     os.environ["BSK_TILE_MIN"] = "64"
     try:
