@@ -143,8 +143,10 @@ def end_to_end(kind: str, p, batch, read_len: int, n_streams: int = 3):
                           "stage_seconds_summed_over_streams": {k: round(st[k], 4) for k in ("reader_seconds", "reader_wait_seconds", "h2d_pack_seconds", "kernel_seconds", "fetch_seconds")},
                           "bound": "PCIe: %.0f B/read in + %.0f B/read of tuples out" % (read_len + 8, (12.0 if kind not in STREAM else 8.0) * st["tuples"] / max(st["records"], 1) + 9)}
     # the same reads as files: fixed-width names, constant qualities
-    n_file = n_mem
     rec = 12 + read_len + (3 + read_len if not alpha else 0)
+    import shutil
+    free = shutil.disk_usage(tempfile.gettempdir()).free
+    n_file = max(1000, min(n_mem, int(0.25 * free / (rec + 1))))  # the sample file never takes more than a quarter of the free space
     arr = np.empty((n_file, rec), np.uint8)
     names = np.char.zfill(np.arange(n_file).astype("U9"), 9)
     arr[:, 0] = ord(">") if alpha else ord("@")
