@@ -1614,6 +1614,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     geo.s = p->s;
     geo.tp = tile_positions(p);
     geo.circ_ext = circ_ext;
+    geo.syn_all = syn_all ? 1 : 0;
     const bool stream = !kind_has_pos(p->kind);
     const bool prot = b->alphabet == BSK_ALPHA_PROTEIN;
     SeqTab seq{b->desc, b->fw, b->llen, b->aoff, n, prot ? b->rflags : nullptr};  // protein rflags: the translate kernel's short flags

@@ -24,6 +24,7 @@ struct TileGeo {
     int kind, k, w, s;  // w: minimizer window, or k - s for the syncmer
     u32 tp;             // positions owned by one tile (multiple of 16)
     int circ_ext;       // bases the circular copy appended (length checks look at L - circ_ext)
+    int syn_all;        // the w = 1 minimizer stands in for a syncmer sketch with s == k: that constructor's length rule applies
 };
 
 struct SeqTab {  // where the sequences of a batch are: DNA desc (reads shorter than 2^24) or fw + llen; protein: aoff only
@@ -48,7 +49,10 @@ __host__ __device__ __forceinline__ u64 tile_npos(const TileGeo &g, u64 L, int s
     if (L < (u64)g.circ_ext) return 0;
     const u64 L0 = L - (u64)g.circ_ext;
     switch (g.kind) {
-        case BSK_MINIMIZER: return (L0 + 1 >= (u64)g.k + (u64)g.w) ? L - (u64)g.k + 1 : 0;  // sketch.go:92
+        case BSK_MINIMIZER:
+            // (s == k syncmer: len(S.Seq) < 2k-s-1 = k-1 refuses, sketch.go:149, and the hasher needs k bases of the extended copy, :179)
+            if (g.syn_all) return (L0 + 1 >= (u64)g.k && L >= (u64)g.k) ? L - (u64)g.k + 1 : 0;
+            return (L0 + 1 >= (u64)g.k + (u64)g.w) ? L - (u64)g.k + 1 : 0;  // sketch.go:92
         case BSK_SYNCMER: return (L0 + 1 + (u64)g.s >= 2ULL * g.k && L >= (u64)g.k) ? L + (u64)g.s + 2 - 2ULL * g.k : 0;  // sketch.go:149,170
         default: return L0 >= (u64)g.k ? L - (u64)g.k + 1 : 0;  // iterator.go:619,672,128
     }

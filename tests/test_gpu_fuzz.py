@@ -96,8 +96,9 @@ def run_case(engine, oracle, seed):
             k, canon = rng.choice([1, 5, 21, 31, 64, 100, 300]), rng.random() < 0.7
             pk, fn = dict(k=k, canonical=canon, circular=circular), lambda q: (oracle.nthash(q, k, canon, circular)[0], None, None, None)
         elif kind == L.KMER:
-            k, canon = rng.choice([1, 4, 11, 21, 31, 32]), rng.random() < 0.7
-            pk, fn = dict(k=k, canonical=canon, circular=circular), lambda q: (oracle.kmer_codes(q, k, canon, circular), None, None, None)
+            k, canon = rng.choice([1, 4, 11, 21, 31, 32]), rng.random() < 0.6
+            nuc_alpha = rng.choice([L.ALPHA_DNA, L.ALPHA_DNA, L.ALPHA_DNA_PLAIN, L.ALPHA_RNA, L.ALPHA_RNA_REDUNDANT, L.ALPHA_UNLIMIT])  # second strand: PairLetter of the Seq's alphabet
+            pk, fn = dict(k=k, canonical=canon, circular=circular), lambda q: (oracle.kmer_codes(q, k, canon, circular, nuc_alpha), None, None, None)
         elif kind == L.SIMHASH:
             k = rng.choice([8, 16, 21, 31, 40, 70])
             m = rng.randint(4, min(k, 12))
@@ -116,7 +117,7 @@ def run_case(engine, oracle, seed):
             pk = dict(k=k, w=w, codon_table=table, frame=frame)
             fn = (lambda q: oracle.protein_minimizer_nt(q, k, w, table, frame)[:2] + (None, None)) if dna_fed else \
                 (lambda q: oracle.protein_minimizer(q, k, w, closed=True)[:2] + (None, None))
-        b = engine.batch(seqs, L.ALPHA_PROTEIN if (protein and not dna_fed) else L.ALPHA_DNA)
+        b = engine.batch(seqs, L.ALPHA_PROTEIN if (protein and not dna_fed) else (nuc_alpha if kind == L.KMER else L.ALPHA_DNA))
         try:
             res = engine.run(b, engine.params(kind, **pk))
         except Exception as e:  # refusals must be the documented ones

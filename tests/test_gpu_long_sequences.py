@@ -159,6 +159,19 @@ def test_circular_long_and_refusals(engine, oracle, tiny_tiles):
         assert np.array_equal(h, oracle.nthash(q, 9, True, True)[0])
 
 
+def test_circular_every_kmer_syncmer_keeps_its_own_length_rule_over_tiles(engine, oracle, tiny_tiles):
+    """s == k syncmers run over tiles as the w = 1 minimizer, but refuse by the SYNCMER constructor's rule: circular, a sequence of
+    k-1 bases passes len < 2k-s-1 (sketch.go:149) and its extended copy (2k-2 bases) can be hashed -- the minimizer would refuse it
+    (found by the fuzz campaign, seed 101422)."""
+    tiny_tiles(40, 16)
+    rng = random.Random(21)
+    k = 31
+    seqs = [rand_seq(rng, n) for n in (k - 2, k - 1, k, k + 1, 300, 2000)]
+    for circular in (True, False):
+        check_sketch(engine, oracle, seqs, L.SYNCMER, lambda q: oracle.syncmer(q, k, k, circular, closed=True), k=k, s=k, circular=circular)
+        check_sketch(engine, oracle, seqs, L.MINIMIZER, lambda q: oracle.minimizer(q, k, 1, circular, closed=True), k=k, w=1, circular=circular)
+
+
 def test_long_sequences_with_default_tiles(engine, oracle):
     """1 Mbp (BASELINE configs[0]) and mixed contig lengths with the default tile size."""
     rng = np.random.default_rng(11)
