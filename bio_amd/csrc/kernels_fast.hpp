@@ -273,7 +273,7 @@ struct FastMin {
                     // branch-free: every candidate is stored to the lane's next slot; the slot only advances when the
                     // candidate is a new selection, so anything else is overwritten (or left beyond the count)
                     u32 addr = slot;
-                    if (GUARD) addr = sel(__builtin_amdgcn_ballot_w64(PAIR ? slot <= slim : slot < spare), slot, spare);  // (a column left downwards wraps above slim)
+                    if (GUARD) addr = slot < spare ? slot : spare;  // one v_min_u32 (a column left downwards wraps far above the spare row, one left upwards lands on it)
                     *reinterpret_cast<LDSQ u64 *>(lds + LY::SH + addr) = ((u64)m.hi << 32) | m.lo;
                     if (POS16) *reinterpret_cast<LDSQ u16 *>(lds + LY::SP + (addr >> 2)) = (u16)m.p;
                     else *reinterpret_cast<LDSQ u32 *>(lds + LY::SP + (addr >> 1)) = m.p;
