@@ -88,6 +88,7 @@ struct Source {  // next chunk into c; returns 0 at the end, <0 on error
     virtual ~Source() {}
     virtual int next(Chunk *c, uint64_t max_records) = 0;
     virtual int materialize(Chunk *) { return BSK_OK; }  // worker side: whatever the producer left to do (runs in parallel)
+    virtual void discard(Chunk *) {}                      // a chunk that was handed out but never materialised (a failed run)
     int alphabet = BSK_ALPHA_DNA;
     std::string err;
 };
@@ -176,6 +177,10 @@ struct ParFastxSource : Source {
         c->parts.clear();
         if (rc == BSK_OK) o[at] = nb;
         return rc;
+    }
+    void discard(Chunk *c) override {
+        for (auto *pc : c->parts) bsk_fastx_piece_release(f, pc);
+        c->parts.clear();
     }
 };
 
@@ -323,6 +328,7 @@ int run_pipeline(int device, Source &src, const bsk_params *p, int n_streams, ui
     }
     producer.join();
     for (auto &t : workers) t.join();
+    for (auto &c : chunks) src.discard(&c);
     st->seconds = secs(t_start, clk::now());
     st->reader_seconds = reader_s;
     st->reader_wait_seconds = reader_wait_s;

@@ -123,3 +123,27 @@ def test_pipeline_and_refill_protein(engine, tmp_path):
         got = S.BatchResult(engine, *_run(engine, h, p)).digest()
         assert got == engine.run(engine.batch(chunk, L.ALPHA_PROTEIN), p).digest(), (lo, hi)
     engine.lib.bsk_batch_destroy(h)
+
+
+def test_pipeline_reports_a_damaged_file(engine, tmp_path):
+    """A record with a longer quality than sequence (ErrBadFASTQFormat, reader.go:19) in the middle of a plain FASTQ: both readers stop
+    the pipeline with the reader's error -- and the run leaves nothing behind (a second run on a good file works)."""
+    data, offs = make_reads(30_000, 9, with_n=False)
+    good = str(tmp_path / "good.fq")
+    write_fastq(good, data, offs, False)
+    text = open(good, "rb").read()
+    cut = text.index(b"@r15000 ")
+    bad = str(tmp_path / "bad.fq")
+    with open(bad, "wb") as f:
+        f.write(text[:cut] + b"@broken\nACGT\n+\nIIIIIIII\n" + text[cut:])
+    p = engine.params(L.MINIMIZER, 21, w=11)
+    for env in ({"BSK_FASTX_PIECE": "100000"}, {"BSK_FASTX_SERIAL": "1"}):
+        os.environ.update(env)
+        try:
+            with pytest.raises(S.DeviceError, match="unknown|bad|fastq|71|BSK|bsk"):
+                S.Engine.pipeline_fastx(bad, p, n_streams=2, chunk_records=4000, fetch=True)
+            st = S.Engine.pipeline_fastx(good, p, n_streams=2, chunk_records=4000, fetch=True)
+            assert st["records"] == 30_000
+        finally:
+            for k_ in env:
+                del os.environ[k_]
