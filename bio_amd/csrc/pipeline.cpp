@@ -14,6 +14,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -53,6 +54,8 @@ struct Chunk {
     uint64_t n = 0, nbytes = 0;
     uint64_t src_at = 0;  // memory source: first record of the chunk (the worker copies it into the pinned buffers itself)
     std::vector<bsk_fastx_piece *> parts;  // block-parallel file source: the parsed pieces of the chunk (copied by the worker)
+    struct Slot *slot = nullptr;           // where the chunk came from (several files can be in flight)
+    int alphabet = BSK_ALPHA_DNA;
 };
 
 struct Queue {  // chunks handed from the producer to the workers, and back
@@ -91,6 +94,12 @@ struct Source {  // next chunk into c; returns 0 at the end, <0 on error
     virtual void discard(Chunk *) {}                      // a chunk that was handed out but never materialised (a failed run)
     int alphabet = BSK_ALPHA_DNA;
     std::string err;
+};
+
+struct Slot {  // one source of a run: closed as soon as it is exhausted and its last chunk is on the device
+    Source *src = nullptr;
+    std::atomic<int> inflight{0};
+    std::atomic<bool> finished{false}, closed{false};
 };
 
 struct FastxSource : Source {
@@ -213,11 +222,27 @@ struct MemorySource : Source {
     }
 };
 
-int run_pipeline(int device, Source &src, const bsk_params *p, int n_streams, uint64_t chunk_records, int fetch, bsk_pipeline_stats *st) {
-    if (!p || !st || n_streams < 1 || n_streams > 16) return BSK_ERR_ARG;
+// The sources of a run are opened by the producer threads themselves, in order (`open(i)`: nullptr + *rc on failure) -- one file after
+// the other with one producer, several files at once with several.
+struct SourceSet {
+    virtual ~SourceSet() {}
+    virtual int count() const = 0;
+    virtual Source *open(int i, int *rc, std::string *errtext) = 0;
+    virtual void close(Source *s) = 0;
+};
+struct OneSource : SourceSet {
+    Source *s;
+    explicit OneSource(Source *s_) : s(s_) {}
+    int count() const override { return 1; }
+    Source *open(int, int *, std::string *) override { return s; }
+    void close(Source *) override {}
+};
+
+int run_pipeline(int device, SourceSet &set, int n_producers, const bsk_params *p, int n_streams, uint64_t chunk_records, int fetch, bsk_pipeline_stats *st) {
+    if (!p || !st || n_streams < 1 || n_streams > 16 || n_producers < 1 || n_producers > 64) return BSK_ERR_ARG;
     memset(st, 0, sizeof *st);
     if (hipSetDevice(device) != hipSuccess) return BSK_ERR_NO_DEVICE;
-    const int nchunks = 2 * n_streams + 1;  // double buffering per stream + the one the producer is filling
+    const int nchunks = 2 * n_streams + n_producers;  // double buffering per stream + the one every producer is filling
     std::vector<Chunk> chunks(nchunks);
     Queue free_q, full_q;
     for (auto &c : chunks) free_q.push(&c);
@@ -236,25 +261,58 @@ int run_pipeline(int device, Source &src, const bsk_params *p, int n_streams, ui
     const auto t_start = clk::now();
     const uint64_t pin0 = g_pin_ns.load();
     double reader_s = 0, reader_wait_s = 0;
-    std::thread producer([&] {
-        (void)hipSetDevice(device);
-        for (;;) {
-            const auto w0 = clk::now();
-            Chunk *c = free_q.pop();
-            reader_wait_s += secs(w0, clk::now());
-            if (!c || error.load()) break;
-            const auto r0 = clk::now();
-            const int rc = src.next(c, chunk_records);
-            reader_s += secs(r0, clk::now());
-            if (rc < 0) {
-                fail(-rc, src.err);
-                break;
+    std::atomic<int> next_source{0}, producers_left{n_producers};
+    std::unique_ptr<Slot[]> slots(new Slot[(size_t)std::max(1, set.count())]);
+    auto close_once = [&](Slot *sl) {
+        if (!sl->closed.exchange(true)) set.close(sl->src);
+    };
+    std::vector<std::thread> producers;
+    for (int pi = 0; pi < n_producers; ++pi) {
+        producers.emplace_back([&] {
+            (void)hipSetDevice(device);
+            double rs = 0, ws = 0;
+            for (;;) {
+                const int si = next_source++;
+                if (si >= set.count() || error.load()) break;
+                int orc = BSK_OK;
+                std::string otext;
+                Source *src = set.open(si, &orc, &otext);
+                if (!src) {
+                    fail(orc, otext);
+                    break;
+                }
+                Slot *sl = &slots[si];
+                sl->src = src;
+                for (;;) {
+                    const auto w0 = clk::now();
+                    Chunk *c = free_q.pop();
+                    ws += secs(w0, clk::now());
+                    if (!c || error.load()) break;
+                    const auto r0 = clk::now();
+                    const int rc = src->next(c, chunk_records);
+                    rs += secs(r0, clk::now());
+                    if (rc <= 0) {
+                        if (rc < 0) fail(-rc, src->err);
+                        else free_q.push(c);  // the source is exhausted: the buffer goes back
+                        break;
+                    }
+                    c->slot = sl;
+                    c->alphabet = src->alphabet;
+                    sl->inflight++;
+                    full_q.push(c);
+                }
+                if (error.load()) break;
+                sl->finished = true;
+                if (sl->inflight.load() == 0) close_once(sl);
             }
-            if (rc == 0) break;
-            full_q.push(c);
-        }
-        full_q.close();
-    });
+            {
+                std::lock_guard<std::mutex> l(stm);
+                reader_s += rs;
+                reader_wait_s += ws;
+            }
+            if (--producers_left == 0) full_q.close();
+        });
+    }
     std::vector<std::thread> workers;
     for (int w = 0; w < n_streams; ++w) {
         workers.emplace_back([&, w] {
@@ -273,8 +331,11 @@ int run_pipeline(int device, Source &src, const bsk_params *p, int n_streams, ui
                 Chunk *c = full_q.pop();
                 if (!c || error.load()) break;
                 auto t0 = clk::now();
-                int rc = src.materialize(c);
-                if (rc == BSK_OK) rc = bsk_batch_refill_ascii(ctx, &batch, (const uint8_t *)c->bytes.p, (const uint64_t *)c->offs.p, c->n, src.alphabet);
+                Slot *sl = c->slot;
+                int rc = sl->src->materialize(c);
+                if (rc == BSK_OK) rc = bsk_batch_refill_ascii(ctx, &batch, (const uint8_t *)c->bytes.p, (const uint64_t *)c->offs.p, c->n, c->alphabet);
+                c->slot = nullptr;
+                if (--sl->inflight == 0 && sl->finished.load()) close_once(sl);
                 const uint64_t n = c->n, nb = c->nbytes;
                 free_q.push(c);  // the bytes are on the device: the producer may refill this buffer
                 auto t1 = clk::now();
@@ -326,9 +387,12 @@ int run_pipeline(int device, Source &src, const bsk_params *p, int n_streams, ui
             st->fetch_seconds += loc.fetch_seconds;
         });
     }
-    producer.join();
+    for (auto &t : producers) t.join();
     for (auto &t : workers) t.join();
-    for (auto &c : chunks) src.discard(&c);
+    for (auto &c : chunks)
+        if (c.slot && !c.slot->closed.load()) c.slot->src->discard(&c);
+    for (int i = 0; i < set.count(); ++i)
+        if (slots[i].src) close_once(&slots[i]);
     st->seconds = secs(t_start, clk::now());
     st->reader_seconds = reader_s;
     st->reader_wait_seconds = reader_wait_s;
@@ -351,7 +415,8 @@ extern "C" int bsk_pipeline_fastx(int device, const char *path, int alphabet, co
         nt = std::max(1, std::min(nt, 12));
         const int orc = bsk_fastx_par_open(path, nt, 0, &ps.f);
         if (orc == BSK_OK) {
-            const int rc = run_pipeline(device, ps, p, n_streams, chunk_records, fetch_tuples, stats);
+            OneSource one(&ps);
+            const int rc = run_pipeline(device, one, 1, p, n_streams, chunk_records, fetch_tuples, stats);
             uint64_t rep = 0;
             bsk_fastx_par_info(ps.f, nullptr, nullptr, &rep);
             if (stats) stats->reader_threads = nt, stats->reparsed_pieces = rep;
@@ -364,7 +429,8 @@ extern "C" int bsk_pipeline_fastx(int device, const char *path, int alphabet, co
     src.want_alpha = alphabet;
     int rc = bsk_fastx_open(path, &src.f);
     if (rc != BSK_OK) return rc;
-    rc = run_pipeline(device, src, p, n_streams, chunk_records, fetch_tuples, stats);
+    OneSource one(&src);
+    rc = run_pipeline(device, one, 1, p, n_streams, chunk_records, fetch_tuples, stats);
     bsk_fastx_close(src.f);
     return rc;
 }
@@ -378,5 +444,83 @@ extern "C" int bsk_pipeline_memory(int device, const uint8_t *bytes, const uint6
     src.n = n;
     src.repeat = repeat;
     src.alphabet = alphabet;
-    return run_pipeline(device, src, p, n_streams, chunk_records, fetch_tuples, stats);
+    OneSource one(&src);
+    return run_pipeline(device, one, 1, p, n_streams, chunk_records, fetch_tuples, stats);
+}
+
+// several files, n_readers of them read at once (each by its own producer thread: the block-parallel reader for a plain file, the serial
+// one for a gzip file -- which is how gzip input scales: one zlib stream per file, several files)
+namespace {
+struct FileSet : SourceSet {
+    std::vector<std::string> paths;
+    int want_alpha = -1, threads_per_file = 1;
+    std::mutex m;
+    uint64_t reparsed = 0;
+    int par_files = 0;
+    int count() const override { return (int)paths.size(); }
+    Source *open(int i, int *rc, std::string *errtext) override {
+        if (!getenv("BSK_FASTX_SERIAL")) {
+            auto *ps = new ParFastxSource();
+            ps->want_alpha = want_alpha;
+            const int orc = bsk_fastx_par_open(paths[i].c_str(), threads_per_file, 0, &ps->f);
+            if (orc == BSK_OK) {
+                std::lock_guard<std::mutex> l(m);
+                par_files++;
+                return ps;
+            }
+            delete ps;
+            if (orc != BSK_ERR_UNSUPPORTED) {
+                *rc = orc;
+                *errtext = "cannot read " + paths[i];
+                return nullptr;
+            }
+        }
+        auto *fs = new FastxSource();
+        fs->want_alpha = want_alpha;
+        const int orc = bsk_fastx_open(paths[i].c_str(), &fs->f);
+        if (orc != BSK_OK) {
+            delete fs;
+            *rc = orc;
+            *errtext = "cannot open " + paths[i];
+            return nullptr;
+        }
+        return fs;
+    }
+    void close(Source *s) override {
+        if (auto *ps = dynamic_cast<ParFastxSource *>(s)) {
+            uint64_t rep = 0;
+            bsk_fastx_par_info(ps->f, nullptr, nullptr, &rep);
+            {
+                std::lock_guard<std::mutex> l(m);
+                reparsed += rep;
+            }
+            bsk_fastx_par_close(ps->f);
+        } else if (auto *fs = dynamic_cast<FastxSource *>(s)) {
+            bsk_fastx_close(fs->f);
+        }
+        delete s;
+    }
+};
+}  // namespace
+
+extern "C" int bsk_pipeline_fastx_files(int device, const char *const *paths, int n_paths, int alphabet, const bsk_params *p, int n_streams, int n_readers,
+                                        uint64_t chunk_records, int fetch_tuples, bsk_pipeline_stats *stats) {
+    if (!paths || n_paths < 1 || n_readers < 0) return BSK_ERR_ARG;
+    FileSet set;
+    for (int i = 0; i < n_paths; ++i) {
+        if (!paths[i]) return BSK_ERR_ARG;
+        set.paths.emplace_back(paths[i]);
+    }
+    set.want_alpha = alphabet;
+    if (n_readers == 0) n_readers = std::min(n_paths, 8);
+    n_readers = std::min(n_readers, std::min(n_paths, 64));
+    const char *tv = getenv("BSK_FASTX_THREADS");
+    const int budget = tv && atoi(tv) > 0 ? atoi(tv) : std::max(1, (int)std::thread::hardware_concurrency() - n_streams - n_readers);
+    set.threads_per_file = std::max(1, std::min(budget, 12) / n_readers);
+    const int rc = run_pipeline(device, set, n_readers, p, n_streams, chunk_records, fetch_tuples, stats);
+    if (stats) {
+        stats->reader_threads = set.par_files ? set.threads_per_file : 0;
+        stats->reparsed_pieces = set.reparsed;
+    }
+    return rc;
 }

@@ -258,6 +258,19 @@ class Engine:
         return st.asdict()
 
     @staticmethod
+    def pipeline_fastx_files(paths, params, n_streams: int = 3, n_readers: int = 0, chunk_records: int = 1 << 18, fetch: bool = True,
+                             alphabet: int = -1, device: int = 0):
+        """Several FASTA/FASTQ files (plain or gzip) through one pipeline, n_readers of them read at once."""
+        lib = L.load()
+        st = L.PipelineStats()
+        arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+        rc = lib.bsk_pipeline_fastx_files(device, arr, len(paths), alphabet, C.byref(params), n_streams, n_readers, chunk_records, 1 if fetch else 0,
+                                          C.byref(st))
+        if rc != L.OK:
+            raise _SENTINELS.get(rc) or DeviceError(f"bsk_pipeline_fastx_files: {lib.bsk_err_name(rc).decode()}")
+        return st.asdict()
+
+    @staticmethod
     def pipeline_memory(data: np.ndarray, offsets: np.ndarray, params, n_streams: int = 2, chunk_records: int = 1 << 20, repeat: int = 1,
                         fetch: bool = True, alphabet: int = L.ALPHA_DNA, device: int = 0):
         lib = L.load()

@@ -298,6 +298,11 @@ int bsk_pipeline_fastx(int device, const char *path, int alphabet /* -1: guess f
                        uint64_t chunk_records, int fetch_tuples, bsk_pipeline_stats *stats);
 int bsk_pipeline_memory(int device, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet, const bsk_params *p,
                         int n_streams, uint64_t chunk_records, int repeat, int fetch_tuples, bsk_pipeline_stats *stats);
+/* Several files through ONE pipeline, n_readers of them (0: min(n_paths, 8)) read at the same time, each by its own producer thread --
+ * the block-parallel reader for a plain file, the serial one for a gzip file (one zlib stream per file is how gzip input scales).
+ * A file is closed as soon as its last chunk is on the device.  The statistics are those of the whole job. */
+int bsk_pipeline_fastx_files(int device, const char *const *paths, int n_paths, int alphabet, const bsk_params *p, int n_streams, int n_readers,
+                             uint64_t chunk_records, int fetch_tuples, bsk_pipeline_stats *stats);
 
 /* ---- multi-GPU: the one collective of the path ----------------------------
  * Reads shard by record; no tuple ever crosses GPUs.  What a job gathers at its end is a handful of u64 counters per GPU

@@ -147,3 +147,30 @@ def test_pipeline_reports_a_damaged_file(engine, tmp_path):
         finally:
             for k_ in env:
                 del os.environ[k_]
+
+
+def test_pipeline_over_several_files(engine, tmp_path):
+    """bsk_pipeline_fastx_files: plain and gzip files, FASTQ and FASTA, read concurrently by several producers: the job's records,
+    tuples and checksum are the sums over the files (each file == one batch of its reads)."""
+    p = engine.params(L.MINIMIZER, 21, w=11)
+    paths, want = [], dict(records=0, tuples=0, checksum=0)
+    for i in range(7):
+        data, offs = make_reads(4000 + 3000 * i, 30 + i)
+        d = engine.run(engine.batch_from_arrays(data, offs), p).digest()
+        want["records"] += len(offs) - 1
+        want["tuples"] += d["n_tuples"]
+        want["checksum"] = (want["checksum"] + d["checksum"]) % (1 << 64)
+        path = str(tmp_path / ("f%d.fq%s" % (i, ".gz" if i % 2 else "")))
+        if i == 4:  # one FASTA among them
+            path = str(tmp_path / "f4.fa")
+            with open(path, "wb") as f:
+                for j in range(len(offs) - 1):
+                    f.write(b">s%d\n%s\n" % (j, data[int(offs[j]):int(offs[j + 1])].tobytes()))
+        else:
+            write_fastq(path, data, offs, bool(i % 2))
+        paths.append(path)
+    for readers, streams, chunk in ((0, 2, 3000), (1, 1, 100000), (3, 3, 1777), (7, 2, 5000)):
+        st = S.Engine.pipeline_fastx_files(paths, p, n_streams=streams, n_readers=readers, chunk_records=chunk)
+        assert (st["records"], st["tuples"], st["checksum"]) == (want["records"], want["tuples"], want["checksum"]), (readers, streams, chunk)
+    with pytest.raises(S.DeviceError):
+        S.Engine.pipeline_fastx_files(paths + [str(tmp_path / "missing.fq")], p)
