@@ -379,12 +379,6 @@ extern "C" int bsk_result_sets(bsk_ctx *ctx, const bsk_result *r, int scope, int
     void *tmp = nullptr;
     bsk_sets *res = nullptr;
     auto done = [&](int code) {
-        (void)hipFree(vin);
-        (void)hipFree(vsorted);
-        (void)hipFree(pos);
-        (void)hipFree(head);
-        (void)hipFree(keep);
-        (void)hipFree(tmp);
         if (code != BSK_OK && res) bsk_sets_release(res);
         return code;
     };
@@ -453,8 +447,8 @@ extern "C" int bsk_result_sets(bsk_ctx *ctx, const bsk_result *r, int scope, int
         *out = res;
         return done(BSK_OK);
     }
-    SCHK(hipMalloc(&vin, N * 8));
-    SCHK(hipMalloc(&vsorted, N * 8));
+    SCHK(pool(2, N * 8, (void **)&vin));  // (all temporaries are pooled: in a process that has already cycled ~100 GB of batches a
+    SCHK(pool(5, N * 8, (void **)&vsorted));  //  hipMalloc / hipFree of these buffers cost 70-200 ms per call against 10-18 ms of kernels)
     hipLaunchKernelGGL(k_gather_values, dim3(grid_of(ctx, n * 64, 256)), dim3(256), 0, st, r->hash, r->refs, r->wfirst, r->wcount, offs, n,
                        maxhash, vin);
     SCHK(hipGetLastError());
@@ -465,26 +459,24 @@ extern "C" int bsk_result_sets(bsk_ctx *ctx, const bsk_result *r, int scope, int
         SCHK(hipStreamSynchronize(st));                           // the gather above still reads offs
         SCHK(hipMemcpy(offs, two, 16, hipMemcpyHostToDevice));   // offs has n + 2 >= 2 entries
         SCHK(rocprim::radix_sort_keys(nullptr, tb, vin, vsorted, (size_t)N, 0, 64, st));
-        SCHK(hipMalloc(&tmp, tb ? tb : 8));
+        SCHK(pool(9, tb ? tb : 8, &tmp));
         SCHK(rocprim::radix_sort_keys(tmp, tb, vin, vsorted, (size_t)N, 0, 64, st));
     } else {
         SCHK(rocprim::segmented_radix_sort_keys(nullptr, tb, vin, vsorted, (unsigned)N, (unsigned)n, offs, offs + 1, 0, 64, st));
-        SCHK(hipMalloc(&tmp, tb ? tb : 8));
+        SCHK(pool(9, tb ? tb : 8, &tmp));
         SCHK(rocprim::segmented_radix_sort_keys(tmp, tb, vin, vsorted, (unsigned)N, (unsigned)n, offs, offs + 1, 0, 64, st));
     }
-    (void)hipFree(tmp);
-    tmp = nullptr;
     // 3. first occurrences that pass the filter -> compacted sets
-    SCHK(hipMalloc(&head, N));
-    SCHK(hipMalloc(&keep, N * 4));
-    SCHK(hipMalloc(&pos, (N + 1) * 8));
+    SCHK(pool(6, N, (void **)&head));
+    SCHK(pool(7, N * 4, (void **)&keep));
+    SCHK(pool(8, (N + 1) * 8, (void **)&pos));
     SCHK(hipMemsetAsync(head, 0, N, st));
     hipLaunchKernelGGL(k_mark_heads, dim3(grid_of(ctx, n_sets, 256)), dim3(256), 0, st, set_offs, n_sets, head);
     hipLaunchKernelGGL(k_flag_unique, dim3(grid_of(ctx, N, 256)), dim3(256), 0, st, vsorted, head, N, maxhash, keep);
     SCHK(hipGetLastError());
     auto keep64 = rocprim::make_transform_iterator(keep, [] __device__(u32 k) -> u64 { return (u64)k; });
     SCHK(rocprim::exclusive_scan(nullptr, tb, keep64, pos, (u64)0, (size_t)N, rocprim::plus<u64>(), st));
-    SCHK(hipMalloc(&tmp, tb ? tb : 8));
+    SCHK(pool(9, tb ? tb : 8, &tmp));
     SCHK(rocprim::exclusive_scan(tmp, tb, keep64, pos, (u64)0, (size_t)N, rocprim::plus<u64>(), st));
     u64 last_pos = 0;
     u32 last_keep = 0;
