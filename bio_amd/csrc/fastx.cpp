@@ -37,9 +37,43 @@
 struct bsk_ctx;
 struct bsk_batch;
 
+// Byte ranges of a file for the block-parallel reader: a plain file (pread), or a BGZF file (the blocked gzip variant of htslib's
+// bgzip: every gzip member holds at most 64 KiB and records its own compressed size in a "BC" extra field, so the members can be
+// located without inflating anything and inflated independently) addressed by UNCOMPRESSED offset.
+struct RangeFile {
+    int fd = -1;
+    uint64_t size = 0;                 // bytes of (uncompressed) text
+    bool bgzf = false;
+    std::vector<uint64_t> coff, uoff;  // BGZF: compressed / uncompressed offset of block i; one more entry = the end
+};
+struct RangeCursor {  // one per reading thread: the last inflated block
+    z_stream zs;
+    bool zs_ready = false;
+    std::vector<uint8_t> comp, text;
+    uint64_t block = ~0ULL;
+    ~RangeCursor() {
+        if (zs_ready) inflateEnd(&zs);
+    }
+};
+// up to len bytes at (uncompressed) offset off; < 0: I/O or format error, 0: end of file
+static ssize_t range_read(const RangeFile *rf, RangeCursor *cur, uint8_t *dst, size_t len, uint64_t off);
+static bool range_read_full(const RangeFile *rf, RangeCursor *cur, uint8_t *dst, size_t len, uint64_t off) {
+    while (len) {
+        const ssize_t got = range_read(rf, cur, dst, len, off);
+        if (got <= 0) return false;
+        dst += got;
+        len -= (size_t)got;
+        off += (uint64_t)got;
+    }
+    return true;
+}
+
+
 struct bsk_fastx {
     gzFile fh = nullptr;
-    int fd = -1;               // the other byte source (block-parallel reader below): pread from `foff` on
+    const RangeFile *rf = nullptr;  // the other byte source (block-parallel reader below): range_read from `foff` on
+    RangeCursor cursor;
+    int fd = -1;
     uint64_t foff = 0;         // next file offset to read
     uint64_t win_off = 0;      // file offset of buf[0]
     std::vector<uint8_t> buf;  // file window
@@ -63,14 +97,12 @@ namespace {
 bool fill(bsk_fastx *f) {  // refill the window; false at end of file
     if (f->eof) return false;
     f->r = 0;
-    if (f->fd >= 0) {  // a byte range of a plain file
-        ssize_t got;
-        do got = pread(f->fd, f->buf.data(), f->buf.size(), (off_t)f->foff);
-        while (got < 0 && errno == EINTR);
+    if (f->rf) {  // a byte range of a plain or BGZF file
+        const ssize_t got = range_read(f->rf, &f->cursor, f->buf.data(), f->buf.size(), f->foff);
         if (got <= 0) {
             if (got < 0) {
                 f->io_error = true;
-                f->err = std::string("fastx: read error: ") + strerror(errno);
+                f->err = std::string("fastx: read error: ") + (f->rf->bgzf && errno == 0 ? "damaged BGZF block" : strerror(errno));
             }
             f->eof = true;
             f->n = 0;
@@ -348,7 +380,7 @@ struct bsk_fastx_piece {
 };
 
 struct bsk_fastx_par {
-    int fd = -1;
+    RangeFile rf;
     uint64_t fsize = 0, first = 0, piece_bytes = 0, n_pieces = 0;
     int is_fastq = -1, alphabet = -2;
     uint8_t delim = 0;
@@ -382,6 +414,48 @@ bool pread_full(int fd, uint8_t *dst, size_t len, uint64_t off) {
     return true;
 }
 
+// BGZF block header (SAM specification 4.1): gzip member with FEXTRA whose extra field holds the subfield 'B','C',2,BSIZE-1
+bool bgzf_block_size(const uint8_t *h, size_t have, uint32_t *bsize, uint32_t *data_off) {
+    if (have < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
+    const uint32_t xlen = h[10] | (h[11] << 8);
+    if (have < 12 + xlen) return false;
+    for (uint32_t i = 0; i + 4 <= xlen;) {
+        const uint8_t *sf = h + 12 + i;
+        const uint32_t slen = sf[2] | (sf[3] << 8);
+        if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && i + 6 <= xlen) {
+            *bsize = (uint32_t)(sf[4] | (sf[5] << 8)) + 1;
+            *data_off = 12 + xlen;
+            return true;
+        }
+        i += 4 + slen;
+    }
+    return false;
+}
+// 1: a BGZF file, index built; 0: some other gzip file; < 0: I/O error
+int bgzf_index(RangeFile *rf, uint64_t file_bytes) {
+    uint64_t c = 0, u = 0;
+    uint8_t h[512];
+    while (c < file_bytes) {
+        const size_t have = (size_t)std::min<uint64_t>(sizeof h, file_bytes - c);
+        if (!pread_full(rf->fd, h, have, c)) return -1;
+        uint32_t bsize = 0, doff = 0;
+        if (!bgzf_block_size(h, have, &bsize, &doff) || bsize < doff + 8 || c + bsize > file_bytes) return rf->coff.empty() ? 0 : -1;
+        uint8_t isz[4];
+        if (!pread_full(rf->fd, isz, 4, c + bsize - 4)) return -1;
+        const uint32_t isize = isz[0] | (isz[1] << 8) | (isz[2] << 16) | ((uint32_t)isz[3] << 24);
+        if (isize > 65536) return -1;
+        rf->coff.push_back(c);
+        rf->uoff.push_back(u);
+        c += bsize;
+        u += isize;
+    }
+    rf->coff.push_back(c);
+    rf->uoff.push_back(u);
+    rf->size = u;
+    rf->bgzf = true;
+    return 1;
+}
+
 // does a FASTQ record plausibly start at b[k] ('@' after a newline)?  1 yes, 0 no, -1 the buffer ends too early to tell
 int looks_like_fastq_record(const uint8_t *b, size_t len, size_t k, bool at_eof) {
     const uint8_t *e = b + len;
@@ -407,13 +481,13 @@ int looks_like_fastq_record(const uint8_t *b, size_t len, size_t k, bool at_eof)
 }
 
 // first guessed record start in [lo, hi) (lo > 0), or -1
-int64_t find_start(bsk_fastx_par *p, uint64_t lo, uint64_t hi, std::vector<uint8_t> &tmp) {
+int64_t find_start(bsk_fastx_par *p, RangeCursor *cur, uint64_t lo, uint64_t hi, std::vector<uint8_t> &tmp) {
     const uint64_t base = lo - 1;
     size_t want = 1u << 16;
     for (;;) {
         const size_t len = (size_t)std::min<uint64_t>(want, p->fsize - base);
         tmp.resize(len);
-        if (!pread_full(p->fd, tmp.data(), len, base)) return -1;  // the parse reports the I/O error
+        if (!range_read_full(&p->rf, cur, tmp.data(), len, base)) return -1;  // the parse reports the I/O error
         const bool at_eof = base + len == p->fsize;
         const uint8_t *b = tmp.data();
         const size_t scan_end = (size_t)std::min<uint64_t>(len, hi - base);
@@ -440,8 +514,66 @@ int64_t find_start(bsk_fastx_par *p, uint64_t lo, uint64_t hi, std::vector<uint8
     }
 }
 
+}  // namespace
+
+static ssize_t range_read(const RangeFile *rf, RangeCursor *cur, uint8_t *dst, size_t len, uint64_t off) {
+    errno = 0;
+    if (off >= rf->size || len == 0) return 0;
+    if (!rf->bgzf) {
+        ssize_t got;
+        do got = pread(rf->fd, dst, (size_t)std::min<uint64_t>(len, rf->size - off), (off_t)off);
+        while (got < 0 && errno == EINTR);
+        return got;
+    }
+    size_t done = 0;
+    // block holding `off`: the last i with uoff[i] <= off (empty blocks share an offset: take the last of them that has data)
+    size_t b = (size_t)(std::upper_bound(rf->uoff.begin(), rf->uoff.end(), off) - rf->uoff.begin()) - 1;
+    while (done < len && off < rf->size) {
+        while (b + 1 < rf->uoff.size() && rf->uoff[b + 1] <= off) ++b;
+        if (b + 1 >= rf->uoff.size()) break;
+        if (cur->block != b) {  // inflate block b
+            const uint32_t bsize = (uint32_t)(rf->coff[b + 1] - rf->coff[b]);
+            cur->comp.resize(bsize);
+            if (!pread_full(rf->fd, cur->comp.data(), bsize, rf->coff[b])) return -1;
+            uint32_t bs2 = 0, doff = 0;
+            if (!bgzf_block_size(cur->comp.data(), bsize, &bs2, &doff) || bs2 != bsize) {
+                errno = 0;
+                return -1;
+            }
+            const uint32_t isize = (uint32_t)(rf->uoff[b + 1] - rf->uoff[b]);
+            cur->text.resize(isize ? isize : 1);
+            if (!cur->zs_ready) {
+                memset(&cur->zs, 0, sizeof cur->zs);
+                if (inflateInit2(&cur->zs, -15) != Z_OK) return -1;
+                cur->zs_ready = true;
+            } else {
+                inflateReset(&cur->zs);
+            }
+            cur->zs.next_in = cur->comp.data() + doff;
+            cur->zs.avail_in = bsize - doff - 8;
+            cur->zs.next_out = cur->text.data();
+            cur->zs.avail_out = isize;
+            const int zr = inflate(&cur->zs, Z_FINISH);
+            if (zr != Z_STREAM_END || cur->zs.avail_out != 0) {  // a damaged block
+                cur->block = ~0ULL;
+                errno = 0;
+                return -1;
+            }
+            cur->block = b;
+        }
+        const uint64_t in_block = off - rf->uoff[b];
+        const size_t take = (size_t)std::min<uint64_t>(len - done, rf->uoff[b + 1] - off);
+        memcpy(dst + done, cur->text.data() + in_block, take);
+        done += take;
+        off += take;
+    }
+    return (ssize_t)done;
+}
+
+namespace {
+
 void reader_for_range(bsk_fastx *f, const bsk_fastx_par *p, uint64_t from) {
-    f->fd = p->fd;
+    f->rf = &p->rf;
     f->foff = from + 1;  // the bytes after the delimiter
     f->win_off = 0;
     if (f->buf.size() != p->window) f->buf.resize(p->window);
@@ -514,7 +646,7 @@ void par_worker(bsk_fastx_par *p) {
         pc->idx = idx;
         uint64_t lo, hi;
         piece_range(p, idx, lo, hi);
-        const int64_t s = idx == 0 ? (int64_t)p->first : find_start(p, lo, hi, tmp);
+        const int64_t s = idx == 0 ? (int64_t)p->first : find_start(p, &rd.cursor, lo, hi, tmp);
         if (s >= 0) {
             parse_span(&rd, p, (uint64_t)s, hi, pc);
         } else {
@@ -550,21 +682,27 @@ extern "C" int bsk_fastx_par_open(const char *path, int n_threads, uint64_t piec
         close(fd);
         return BSK_ERR_NOMEM;
     }
-    p->fd = fd;
-    p->fsize = (uint64_t)sb.st_size;
+    p->rf.fd = fd;
+    p->rf.size = (uint64_t)sb.st_size;
     uint8_t magic[2] = {0, 0};
-    if (p->fsize >= 2 && pread_full(fd, magic, 2, 0) && magic[0] == 0x1f && magic[1] == 0x8b) {  // gzip: one serial stream
-        close(fd);
-        delete p;
-        return BSK_ERR_UNSUPPORTED;
+    if (p->rf.size >= 2 && pread_full(fd, magic, 2, 0) && magic[0] == 0x1f && magic[1] == 0x8b) {
+        // gzip: one serial stream -- unless it is BGZF, whose members are found by their recorded sizes and inflated independently
+        const int bz = bgzf_index(&p->rf, (uint64_t)sb.st_size);
+        if (bz != 1) {
+            close(fd);
+            delete p;
+            return BSK_ERR_UNSUPPORTED;  // (a damaged BGZF file too: the serial reader reports where it breaks)
+        }
     }
+    p->fsize = p->rf.size;
     // format: the first byte that is not '\n' (reader.go:273-305)
     std::vector<uint8_t> tmp(1u << 16);
+    RangeCursor cur0;
     uint64_t at = 0;
     bool found = false;
     while (at < p->fsize && !found) {
         const size_t len = (size_t)std::min<uint64_t>(tmp.size(), p->fsize - at);
-        if (!pread_full(fd, tmp.data(), len, at)) {
+        if (!range_read_full(&p->rf, &cur0, tmp.data(), len, at)) {
             close(fd);
             delete p;
             return BSK_ERR_IO;
@@ -607,8 +745,7 @@ extern "C" void bsk_fastx_par_close(bsk_fastx_par *p) {
     for (auto &t : p->threads) t.join();
     for (auto &kv : p->done) delete kv.second;
     for (auto *pc : p->pool) delete pc;
-    if (p->fd >= 0) close(p->fd);
-    p->serial.fd = -1;
+    if (p->rf.fd >= 0) close(p->rf.fd);
     delete p;
 }
 

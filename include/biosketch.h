@@ -201,7 +201,10 @@ int bsk_batch_from_fastx(bsk_ctx *ctx, bsk_fastx *f, uint64_t max_records, uint6
  * record state machine of the serial reader from there, and the consumer (bsk_fastx_par_next, one thread) validates every
  * guess against the previous piece's true end and re-parses a piece that started anywhere else -- so the records are the serial
  * reader's for ANY input (multi-line FASTQ merely runs serially); bsk_fastx_par_info reports how many pieces were re-parsed.
- * bsk_fastx_par_open: BSK_ERR_UNSUPPORTED for gzip files and "-" (use bsk_fastx_open), BSK_ERR_NOT_FASTX as above.
+ * BGZF files (bgzip: gzip members of at most 64 KiB that record their own compressed size in a "BC" extra field) are taken too:
+ * the members are located without inflating anything, pieces are ranges of the UNCOMPRESSED text, and every parser thread inflates
+ * the blocks of its own range.  bsk_fastx_par_open: BSK_ERR_UNSUPPORTED for every other gzip file and for "-" (one serial stream:
+ * use bsk_fastx_open), BSK_ERR_NOT_FASTX as above.
  * bsk_fastx_par_next: the next piece with at least one record, *piece == NULL at the end; an error inside a piece is returned
  * by the call after the one that delivered the records before it.  A piece stays valid until bsk_fastx_piece_release (any
  * thread), which must precede bsk_fastx_par_close. */

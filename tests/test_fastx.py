@@ -278,3 +278,70 @@ def test_block_parallel_reader_on_generated_fastq(tmp_path):
     with pytest.raises(fastx.FastxError) as ei:
         fastx.ParallelReader(str(gz), 2)
     assert ei.value.code == L.ERR_UNSUPPORTED
+
+
+def bgzf_compress(data: bytes, block: int = 0xff00, level: int = 6, rng=None) -> bytes:
+    """BGZF (SAM specification 4.1): gzip members of at most 64 KiB, each with the 'BC' extra subfield = its own size - 1, and the
+    empty end-of-file member.  rng: random block sizes (block boundaries everywhere)."""
+    import struct
+    import zlib
+    out = bytearray()
+    i = 0
+    chunks = []
+    while i < len(data):
+        n = block if rng is None else rng.randint(1, block)
+        chunks.append(data[i:i + n])
+        i += n
+    chunks.append(b"")
+    for c in chunks:
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = co.compress(c) + co.flush()
+        bsize = 12 + 6 + len(comp) + 8
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+        out += comp + struct.pack("<II", zlib.crc32(c) & 0xffffffff, len(c))
+    return bytes(out)
+
+
+def test_block_parallel_reader_reads_bgzf(tmp_path):
+    """A BGZF file (bgzip: blocked gzip whose members record their own size) is a gzip file the block-parallel reader CAN take: its
+    members are located without inflating and inflated independently, pieces are ranges of the uncompressed text.  Same records as the
+    serial reader (which reads it as the multi-member gzip it is); an ordinary gzip file stays with the serial reader."""
+    rng = random.Random(17)
+    text = bytearray()
+    for i in range(3000):
+        n = rng.choice([0, 1, 30, 75, 150, 400])
+        s = bytes(rng.choice(b"ACGTN") for _ in range(n))
+        q = bytes(rng.choice(b"@@+>I5#") for _ in range(n))
+        text += b"@r%d x@y\n" % i + s + b"\n+\n" + q + b"\n"
+    text = bytes(text)
+    plain = tmp_path / "r.fq"
+    plain.write_bytes(text)
+    want = [s for _, s, _ in read_all(str(plain))[0]]
+    assert len(want) == 3000
+    for name, blob in (("big.fq.gz", bgzf_compress(text)), ("ragged.fq.gz", bgzf_compress(text, 700, 1, rng)),
+                       ("tiny.fq.gz", bgzf_compress(text[:5000], 7, 6, rng))):
+        p = tmp_path / name
+        p.write_bytes(blob)
+        assert gzip.decompress(blob) == (text if name != "tiny.fq.gz" else text[:5000])  # it IS a gzip file
+        ser = [s for _, s, _ in read_all(str(p))[0]]
+        for piece in (0, 100, 1777, 50000):
+            for threads in (1, 4):
+                got, perr, info = par_read(str(p), threads, piece)
+                assert perr is None and got == ser, (name, piece, threads, len(got), len(ser))
+        if name != "tiny.fq.gz":
+            assert ser == want
+    # FASTA, and an empty BGZF file (only the end-of-file member)
+    fa = b"".join(b">s%d\n%s\n" % (i, bytes(rng.choice(b"ACGT") for _ in range(rng.choice([0, 61, 200])))) for i in range(500))
+    p = tmp_path / "a.fa.gz"
+    p.write_bytes(bgzf_compress(fa, 333, 6, rng))
+    assert par_read(str(p), 3, 500)[0] == [s for _, s, _ in read_all(str(p))[0]]
+    p = tmp_path / "empty.fa.gz"
+    p.write_bytes(bgzf_compress(b""))
+    assert par_read(str(p), 2, 0)[:2] == ([], None)
+    # a damaged block: an error, not silence
+    blob = bytearray(bgzf_compress(text, 4000))
+    blob[len(blob) // 2] ^= 0x55
+    p = tmp_path / "bad.fq.gz"
+    p.write_bytes(bytes(blob))
+    got, perr, _ = par_read(str(p), 3, 20000)
+    assert perr is not None and len(got) < 3000
