@@ -65,8 +65,11 @@ for seed in range(first, first + count):
     ok = got == want and ((oerr is None) == (err is None))
     if ok and oerr is not None:
         ok = (isinstance(oerr, FO.NotFastx) and err is fastx.ErrNotFASTXFormat) or (not isinstance(oerr, FO.NotFastx) and err is fastx.ErrBadFASTQFormat)
-    if ok:  # the block-parallel reader: the serial reader's sequences and error, whatever the piece size
+    if ok:  # the block-parallel reader: the serial reader's sequences and error, whatever the piece size -- plain or BGZF
         piece, threads = rng.choice([1, 2, 3, 7, 20, 50, 200, 1 << 20]), rng.choice([1, 2, 4])
+        if rng.random() < 0.4:
+            path = os.path.join(d, "x.fx.gz")
+            open(path, "wb").write(FO.bgzf_compress(data, rng.choice([1, 5, 40, 1000]), 1, rng))
         pgot, perr = read_par(path, threads, piece)
         ok = pgot == [s_ for _, s_, _ in want] and ((perr is None) == (err is None)) and (perr is None or perr is err or perr.code == err.code)
         if not ok: print("PARALLEL piece", piece, "threads", threads, pgot[:3], perr)

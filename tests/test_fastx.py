@@ -280,26 +280,7 @@ def test_block_parallel_reader_on_generated_fastq(tmp_path):
     assert ei.value.code == L.ERR_UNSUPPORTED
 
 
-def bgzf_compress(data: bytes, block: int = 0xff00, level: int = 6, rng=None) -> bytes:
-    """BGZF (SAM specification 4.1): gzip members of at most 64 KiB, each with the 'BC' extra subfield = its own size - 1, and the
-    empty end-of-file member.  rng: random block sizes (block boundaries everywhere)."""
-    import struct
-    import zlib
-    out = bytearray()
-    i = 0
-    chunks = []
-    while i < len(data):
-        n = block if rng is None else rng.randint(1, block)
-        chunks.append(data[i:i + n])
-        i += n
-    chunks.append(b"")
-    for c in chunks:
-        co = zlib.compressobj(level, zlib.DEFLATED, -15)
-        comp = co.compress(c) + co.flush()
-        bsize = 12 + 6 + len(comp) + 8
-        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
-        out += comp + struct.pack("<II", zlib.crc32(c) & 0xffffffff, len(c))
-    return bytes(out)
+bgzf_compress = FO.bgzf_compress
 
 
 def test_block_parallel_reader_reads_bgzf(tmp_path):
