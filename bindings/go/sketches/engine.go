@@ -292,3 +292,38 @@ func GatherCounts(engines []*Engine, mine [][]uint64) ([][]uint64, error) {
 	}
 	return out, nil
 }
+
+// ---- file -> tuples, stages overlapped (bsk_pipeline_fastx_files; DESIGN.md 4) ----
+
+// PipelineStats mirrors bsk_pipeline_stats: whole-job counters and where the time went.
+type PipelineStats struct {
+	Records, Bases, Tuples, Chunks, Checksum uint64
+	Seconds, ReaderSeconds, ReaderWaitSeconds float64
+	H2DPackSeconds, KernelSeconds, FetchSeconds float64
+	Streams, ReaderThreads                      int
+	ReparsedPieces                              uint64
+	PinSeconds                                  float64
+}
+
+// SketchFiles runs FASTA/FASTQ files (plain, BGZF or gzip) through one device pipeline: `readers` files are read at the same
+// time (0: up to eight), plain and BGZF files by the block-parallel reader, the sketch named by p runs on `streams` HIP streams and
+// every tuple comes back to pinned host memory.  What a host loop over fastx.Reader + NewMinimizerSketch per record becomes when
+// the GPU does the hashing: the reader is no longer allowed to be one goroutine.
+func SketchFiles(device int, paths []string, p C.bsk_params, streams, readers int, chunkRecords uint64) (PipelineStats, error) {
+	cs := make([]*C.char, len(paths))
+	for i, s := range paths {
+		cs[i] = C.CString(s)
+		defer C.free(unsafe.Pointer(cs[i]))
+	}
+	var st C.bsk_pipeline_stats
+	rc := C.bsk_pipeline_fastx_files(C.int(device), (**C.char)(unsafe.Pointer(&cs[0])), C.int(len(paths)), -1, &p, C.int(streams), C.int(readers),
+		C.uint64_t(chunkRecords), 1, &st)
+	out := PipelineStats{uint64(st.records), uint64(st.bases), uint64(st.tuples), uint64(st.chunks), uint64(st.checksum),
+		float64(st.seconds), float64(st.reader_seconds), float64(st.reader_wait_seconds),
+		float64(st.h2d_pack_seconds), float64(st.kernel_seconds), float64(st.fetch_seconds),
+		int(st.n_streams), int(st.reader_threads), uint64(st.reparsed_pieces), float64(st.pin_seconds)}
+	if rc != C.BSK_OK {
+		return out, fmt.Errorf("bsk_pipeline_fastx_files: %s", C.GoString(C.bsk_err_name(rc)))
+	}
+	return out, nil
+}
