@@ -1054,7 +1054,12 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.ring_w = (u32)nh;
         }
     } else if (p->kind == BSK_PROT_HASH) {
-        if (fast_prot_hash_supported(p->k) && !getenv("BSK_FORCE_GENERIC")) {
+        if (b->alphabet == BSK_ALPHA_DNA) {  // the fused plan (sketch_impl checked that it applies)
+            pl.which = K_PROT_HASH_FAST;
+            pl.fused_dna = true;
+            pl.fast_k = p->k;
+            per_cu = fast_prot_hash_dna_blocks_per_cu(p->k);
+        } else if (fast_prot_hash_supported(p->k) && !getenv("BSK_FORCE_GENERIC")) {
             pl.which = K_PROT_HASH_FAST;
             pl.fast_k = p->k;
             per_cu = fast_prot_hash_blocks_per_cu(p->k);
@@ -1279,7 +1284,7 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
         case K_PROT_MIN: snprintf(b, sizeof b, "k_prot_minimizer"); break;
         case K_SYN_FAST: snprintf(b, sizeof b, "k_syncmer_fast<%d>", pl.fast_w); break;
         case K_PROT_MIN_FAST: snprintf(b, sizeof b, "k_prot_minimizer_fast<%d,%d,%s>", pl.fast_w, pl.fast_k, pl.fused_dna ? "true" : "false"); break;
-        case K_PROT_HASH_FAST: snprintf(b, sizeof b, "k_prot_hash_fast<%d>", pl.fast_k); break;
+        case K_PROT_HASH_FAST: snprintf(b, sizeof b, "k_prot_hash_fast<%d%s>", pl.fast_k, pl.fused_dna ? ",true" : ""); break;
         case K_SIM_FAST:
             snprintf(b, sizeof b, "k_simhash_fast<%d,%d>", pl.fast_w, pl.fast_k == 1 ? BSK_SIM_SHORT_WORDS : pl.fast_k == 2 ? BSK_SIM_MID_WORDS : BSK_NT_FAST_WORDS);
             break;
@@ -1362,7 +1367,15 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
                 fast_prot_launch(pl.fast_w, pl.fast_k, pl.grid, ctx->stream, a);
             }
             break;
-        case K_PROT_HASH_FAST: fast_prot_hash_launch(pl.fast_k, pl.grid, ctx->stream, a); break;
+        case K_PROT_HASH_FAST:
+            if (pl.fused_dna) {
+                a.frame = p->frame;
+                a.lut = ctx->d_lut;
+                fast_prot_hash_dna_launch(pl.fast_k, pl.grid, ctx->stream, a);
+            } else {
+                fast_prot_hash_launch(pl.fast_k, pl.grid, ctx->stream, a);
+            }
+            break;
         case K_SIM_FAST:
             if (pl.fast_k == 1) {
                 if (pl.fast_w == 5) hipLaunchKernelGGL((k_simhash_fast<5, BSK_SIM_SHORT_WORDS>), dim3(pl.grid), dim3(64), 0, ctx->stream, a);
@@ -1410,6 +1423,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
 // with the exact size
 static u64 estimate_cap_n(const bsk_params *p, u64 bases, u64 nreads);
 static u64 estimate_cap(const bsk_batch *b, const bsk_params *p, int circ_ext) {
+    if (p->kind == BSK_PROT_HASH && b->alphabet == BSK_ALPHA_DNA) return estimate_cap_n(p, b->n_bases / 3 + b->n, b->n);  // fused: residues
     return estimate_cap_n(p, b->n_bases + b->n * (u64)circ_ext, b->n);
 }
 static u64 estimate_cap_n(const bsk_params *p, u64 bases, u64 nreads) {
@@ -1868,6 +1882,10 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
         fused = p->kind == BSK_PROT_MINIMIZER && batch->desc && batch->n_nonacgt == 0 && fast_prot_supported(p->w, p->k) &&
                 translated_len(batch->maxlen, 1) < 65536u && !getenv("BSK_FORCE_GENERIC") && !getenv("BSK_NO_FUSED_TRANSLATE") && !ctx->no_prot_fast &&
                 slab_budget_ok(batch, (u64)translated_len(batch->maxlen, 1));
+        // the hash stream likewise (k = 9..16; translations longer than the tile threshold take the tiled two-step path)
+        if (p->kind == BSK_PROT_HASH)
+            fused = batch->desc && batch->n_nonacgt == 0 && fast_prot_hash_supported(p->k) && translated_len(batch->maxlen, 1) <= 4096u &&
+                    !getenv("BSK_FORCE_GENERIC") && !getenv("BSK_NO_FUSED_TRANSLATE");
         if (fused) {
             rc = ensure_lut(ctx, p->codon_table);
             if (rc != BSK_OK) return rc;

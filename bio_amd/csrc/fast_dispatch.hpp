@@ -37,4 +37,6 @@ void fast_prot_dna_launch(int w, int k, int grid, hipStream_t stream, const KArg
 bool fast_prot_hash_supported(int k);
 int fast_prot_hash_blocks_per_cu(int k);
 void fast_prot_hash_launch(int k, int grid, hipStream_t stream, const KArgs &a);
+int fast_prot_hash_dna_blocks_per_cu(int k);
+void fast_prot_hash_dna_launch(int k, int grid, hipStream_t stream, const KArgs &a);  // 2-bit DNA batch, translation fused in
 }  // namespace bsk

@@ -138,6 +138,38 @@ struct FastProt {
 // with the reverse-complemented codons for the minus frames, which walk the sequence downwards).  ~5 instructions per residue
 // on top of ~60 for its hash and window; no translated copy of the batch ever exists.
 typedef u64 u64_a4 __attribute__((aligned(4)));
+// Residues of a 2-bit DNA sequence, four at a time, translated where they are fetched (the fused DNA-fed protein kernels).
+// Residue dword jd = residues 4jd .. 4jd+3 = 12 bases = one 24-bit field F of the packed stream, lowest base `lo`.
+// Plus frames: residue t is F's bits [6t, 6t+6).  Minus frames walk downwards: residue t's codon ends 3t bases below the
+// field's top base Lnt + frame - 12 jd, so it is bits [18-6t, 24-6t) (complemented and reversed by the table); a field
+// that starts before base 0 (the sequence's last residues) is shifted up instead of moved.
+// aat: 64-entry LDS table, amino acid of the codon whose three bases, lowest position first, are the 2-bit codes of the index.
+struct DnaResidues {
+    const u32 *wseq;
+    u32 Lnt;
+    int frame;
+    const LDSQ u8 *aat;
+    static __device__ __forceinline__ void build_table(u8 *tab, const u8 *lut, int frame, int lane) {
+        const u32 six = (u32)lane, b0 = six & 3, b1 = (six >> 2) & 3, b2 = six >> 4;
+        const u32 idx = frame > 0 ? (b0 << 4) | (b1 << 2) | b2 : ((b2 ^ 3) << 4) | ((b1 ^ 3) << 2) | (b0 ^ 3);
+        tab[lane] = lut[4096 + 256 + idx];
+    }
+    __device__ __forceinline__ int lo_of(u32 jd) const { return frame > 0 ? (frame - 1) + 12 * (int)jd : (int)Lnt + frame - 12 * (int)jd - 11; }
+    __device__ __forceinline__ u64 issue(u32 jd) const {  // the two packed words that hold the field (request them early)
+        int lo = lo_of(jd);
+        lo = lo < 0 ? 0 : (lo > (int)Lnt ? (int)Lnt : lo);  // (fields wholly past the end are never hashed; stay inside the buffer)
+        return *reinterpret_cast<const GLBQ u64_a4 *>((size_t)(wseq + ((u32)lo >> 4)));
+    }
+    __device__ __forceinline__ u32 finish(u64 two, u32 jd) const {
+        const int lo = lo_of(jd);
+        u32 F;
+        if (lo < 0) F = (u32)(two << (2u * (u32)(lo < -12 ? 12 : -lo)));
+        else F = (u32)(two >> (((u32)(lo > (int)Lnt ? (int)Lnt : lo) & 15u) * 2u));
+        if (frame > 0) return (u32)aat[F & 63u] | ((u32)aat[(F >> 6) & 63u] << 8) | ((u32)aat[(F >> 12) & 63u] << 16) | ((u32)aat[(F >> 18) & 63u] << 24);
+        return (u32)aat[(F >> 18) & 63u] | ((u32)aat[(F >> 12) & 63u] << 8) | ((u32)aat[(F >> 6) & 63u] << 16) | ((u32)aat[F & 63u] << 24);
+    }
+};
+
 template <int W, int K, bool DNA = false>
 __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
     typedef FastProt<W, K> FP;
@@ -147,10 +179,8 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
     LDSQ char *const ldsq = (LDSQ char *)lds;
     const int lane = lane_id();
     const int frame = a.frame;
-    if (DNA) {  // amino acid of the codon whose three bases, lowest position first, are the 2-bit codes b0 b1 b2 of `six`
-        const u32 six = (u32)lane, b0 = six & 3, b1 = (six >> 2) & 3, b2 = six >> 4;
-        const u32 idx = frame > 0 ? (b0 << 4) | (b1 << 2) | b2 : ((b2 ^ 3) << 4) | ((b1 ^ 3) << 2) | (b0 ^ 3);
-        reinterpret_cast<u8 *>(lds + LY::TOTAL)[lane] = a.lut[4096 + 256 + idx];
+    if (DNA) {
+        DnaResidues::build_table(reinterpret_cast<u8 *>(lds + LY::TOTAL), a.lut, frame, lane);
         __syncthreads();
     }
     const u64 slab_read = a.slab_read;  // tuples reserved per sequence
@@ -193,26 +223,9 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
             // 6 wavefronts per CU walking 64 sequences each, the 48 KB of lines do not stay in the 32 KB L1.
             const u8 *p0 = a.ascii + off;
             const size_t gp0 = (size_t)p0;
-            const u32 *const wseq = a.words + off;
-            const LDSQ u8 *const aat = reinterpret_cast<const LDSQ u8 *>(ldsq + LY::TOTAL);
-            // DNA: residue dword jd = residues 4jd .. 4jd+3 = 12 bases = one 24-bit field F of the packed stream, lowest base `lo`.
-            // Plus frames: residue t is F's bits [6t, 6t+6).  Minus frames walk downwards: residue t's codon ends 3t bases below the
-            // field's top base Lnt + frame - 12 jd, so it is bits [18-6t, 24-6t) (complemented and reversed by the table); a field
-            // that starts before base 0 (the sequence's last residues) is shifted up instead of moved.
-            auto dna_lo = [&](u32 jd) -> int { return frame > 0 ? (frame - 1) + 12 * (int)jd : (int)Lnt + frame - 12 * (int)jd - 11; };
-            auto dna_issue = [&](u32 jd) -> u64 {  // the two packed words that hold the field (requested early: see the block loop)
-                int lo = dna_lo(jd);
-                lo = lo < 0 ? 0 : (lo > (int)Lnt ? (int)Lnt : lo);  // (fields wholly past the end are never hashed; stay inside the buffer)
-                return *reinterpret_cast<const GLBQ u64_a4 *>((size_t)(wseq + ((u32)lo >> 4)));
-            };
-            auto dna_finish = [&](u64 two, u32 jd) -> u32 {
-                int lo = dna_lo(jd);
-                u32 F;
-                if (lo < 0) F = (u32)(two << (2u * (u32)(lo < -12 ? 12 : -lo)));
-                else F = (u32)(two >> (((u32)(lo > (int)Lnt ? (int)Lnt : lo) & 15u) * 2u));
-                if (frame > 0) return (u32)aat[F & 63u] | ((u32)aat[(F >> 6) & 63u] << 8) | ((u32)aat[(F >> 12) & 63u] << 16) | ((u32)aat[(F >> 18) & 63u] << 24);
-                return (u32)aat[(F >> 18) & 63u] | ((u32)aat[(F >> 12) & 63u] << 8) | ((u32)aat[(F >> 6) & 63u] << 16) | ((u32)aat[F & 63u] << 24);
-            };
+            const DnaResidues dr{a.words + off, Lnt, frame, reinterpret_cast<const LDSQ u8 *>(ldsq + LY::TOTAL)};  // (DNA only)
+            auto dna_issue = [&](u32 jd) -> u64 { return dr.issue(jd); };
+            auto dna_finish = [&](u64 two, u32 jd) -> u32 { return dr.finish(two, jd); };
             auto load_dwords = [&](u32 *dst, int ndw, u32 j) {  // dwords j .. j+ndw-1 of the sequence (bytes 4j ..)
                 int g = 0;
                 if (DNA) {
@@ -373,14 +386,16 @@ __device__ __forceinline__ void stage_chunks(LDSQ char *reg0, const u8 *A, u64 w
     }
 }
 
-template <int K>
+// DNA = true: the batch is 2-bit DNA and every residue dword is translated where it is fetched (DnaResidues above): no translated
+// copy of the batch, no staged residue regions (the tile is the kernel's only LDS: more waves per CU).
+template <int K, bool DNA = false>
 __global__ __launch_bounds__(64) void k_prot_hash_fast(KArgs a) {
     typedef FastProt<1, K> FP;
     constexpr int TL = 18;
     constexpr int RS = BSK_PH_CHUNK / 4 + 4;  // dwords per staged region: 16 positions look at 8 dwords
     static_assert((RS % 4) == 0 && ((RS / 4) & 1), "region stride must be 4*odd dwords");
     constexpr int SW_OFF = 64 * TL * 8;
-    __shared__ __attribute__((aligned(16))) char lds[SW_OFF + RS * 64 * 4];
+    __shared__ __attribute__((aligned(16))) char lds[SW_OFF + (DNA ? 64 : RS * 64 * 4)];
     LDSQ char *const lq = (LDSQ char *)lds;
     LDSQ char *const reg0 = lq + SW_OFF;
     u64 *const s_off = reinterpret_cast<u64 *>(lds);        // unit prologue only: aliases the tile
@@ -388,6 +403,28 @@ __global__ __launch_bounds__(64) void k_prot_hash_fast(KArgs a) {
     const int lane = lane_id();
     FP fp;  // only hashK() is used
     __shared__ u64 s_base[4];
+    const int frame = a.frame;
+    if (DNA) {
+        DnaResidues::build_table(reinterpret_cast<u8 *>(lds + SW_OFF), a.lut, frame, lane);
+        __syncthreads();
+    }
+    // sequence r: where it starts, its length in residues, and whether the constructor accepts it (iterator-protein.go:50: the
+    // check is on the INPUT length, nucleotides for a DNA batch)
+    auto span = [&](u64 r, u64 &off_, u64 &L_, u32 &Lnt_) -> bool {
+        off_ = 0;
+        L_ = 0;
+        Lnt_ = 0;
+        if (r >= a.n) return false;
+        if (DNA) {
+            const u64 d = a.desc[r];
+            off_ = d >> 24;
+            Lnt_ = (u32)(d & 0xffffffULL);
+            L_ = translated_len((u64)Lnt_, frame);  // codon_tables.go:224,256
+            return (u64)Lnt_ >= (u64)K * 3;
+        }
+        ascii_span(a, r, off_, L_);
+        return prot_len_ok(a, r, L_, (u64)K * 3);
+    };
     for (;;) {
       const u32 u0 = next_ticket(a.ticket, lane) * 4u;
       if (u0 >= a.nunits) break;
@@ -396,10 +433,9 @@ __global__ __launch_bounds__(64) void k_prot_hash_fast(KArgs a) {
           u64 run = 0;
           for (u32 unit = u0; unit < u1; ++unit) {
               const u64 r = (u64)unit * 64 + lane;
-              u64 L = 0;
-              u64 off_ = 0;
-              if (r < a.n) ascii_span(a, r, off_, L);
-              const bool ok = r < a.n && prot_len_ok(a, r, L, (u64)K * 3);
+              u64 L = 0, off_ = 0;
+              u32 lnt_ = 0;
+              const bool ok = span(r, off_, L, lnt_);
               const u32 pk = (ok && L >= (u64)K) ? ((u32)(L - K + 1) + 15u) & ~15u : 0u;
               if (lane == 0) s_base[unit - u0] = run;
               run += wave_sum_u64((u64)pk);
@@ -412,10 +448,8 @@ __global__ __launch_bounds__(64) void k_prot_hash_fast(KArgs a) {
       for (u32 unit = u0; unit < u1; ++unit) {
         const u64 r = (u64)unit * 64 + lane;
         u64 off = 0, L = 0;
-        if (r < a.n) {
-            ascii_span(a, r, off, L);
-        }
-        const bool ok = r < a.n && prot_len_ok(a, r, L, (u64)K * 3);  // iterator-protein.go:50 (checked on the input length)
+        u32 Lnt = 0;
+        const bool ok = span(r, off, L, Lnt);
         const u32 nk = (ok && L >= (u64)K) ? (u32)(L - K + 1) : 0u;
         const u32 nk_max = wave_max_u32(nk);
         const u32 pk = (nk + 15u) & ~15u;
@@ -441,8 +475,56 @@ __global__ __launch_bounds__(64) void k_prot_hash_fast(KArgs a) {
             rnk[rr] = s_nk[rr * 8 + (lane >> 3)];
         }
         wave_sync_lds();
-        const u8 *p0 = a.ascii + off;
         LDSQ char *const myrow = lq + lane * (TL * 8);
+        // 16 hashes of the lane through the 64 x 16 tile, out as one aligned 128-byte line per sequence
+        auto hash16_and_flush = [&](const u32 (&R)[8], u32 i0) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int g = t >> 2;
+                u64 h;
+                switch (t & 3) {
+                    case 0: h = fp.template hashK<0>(R[g], R[g + 1], R[g + 2], R[g + 3], R[g + 4]); break;
+                    case 1: h = fp.template hashK<1>(R[g], R[g + 1], R[g + 2], R[g + 3], R[g + 4]); break;
+                    case 2: h = fp.template hashK<2>(R[g], R[g + 1], R[g + 2], R[g + 3], R[g + 4]); break;
+                    default: h = fp.template hashK<3>(R[g], R[g + 1], R[g + 2], R[g + 3], R[g + 4]); break;
+                }
+                *reinterpret_cast<LDSQ u64 *>(myrow + t * 8) = h;
+            }
+            wave_sync_lds();
+            u32x4 tv[8];
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr)
+                tv[rr] = *reinterpret_cast<LDSQ const u32x4 *>(lq + (rr * 8 + (lane >> 3)) * (TL * 8) + (lane & 7) * 16);
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                if (i0 + (u32)(lane & 7) * 2 < rnk[rr]) {
+                    u64x2_a8 vv;
+                    vv.a = ((u64)tv[rr].y << 32) | tv[rr].x;
+                    vv.b = ((u64)tv[rr].w << 32) | tv[rr].z;
+                    nt_store_u64x2(a.hash + roff[rr] + i0, vv.a, vv.b);
+                }
+            }
+            wave_sync_lds();
+        };
+        if (DNA) {
+            const DnaResidues dr{a.words + off, Lnt, frame, reinterpret_cast<const LDSQ u8 *>(lq + SW_OFF)};
+            u32 R[8];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) R[g] = dr.finish(dr.issue((u32)g), (u32)g);
+            for (u32 i0 = 0; i0 < nk_max; i0 += 16) {
+                u64 raw[4];  // the next step's four new dwords: requested before this step's hashing and stores
+#pragma unroll
+                for (int g = 0; g < 4; ++g) raw[g] = dr.issue(i0 / 4 + 8 + (u32)g);
+                hash16_and_flush(R, i0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    R[g] = R[g + 4];
+                    R[g + 4] = dr.finish(raw[g], i0 / 4 + 8 + (u32)g);
+                }
+            }
+            continue;
+        }
+        const u8 *p0 = a.ascii + off;
         LDSQ char *const myreg = reg0 + lane * (RS * 4);
         for (u32 c0 = 0; c0 < nk_max; c0 += BSK_PH_CHUNK) {
             const u32 cend = (c0 + BSK_PH_CHUNK < nk_max) ? c0 + BSK_PH_CHUNK : nk_max;
@@ -453,33 +535,7 @@ __global__ __launch_bounds__(64) void k_prot_hash_fast(KArgs a) {
                 const u32x4 ra = *reinterpret_cast<LDSQ const u32x4 *>(myreg + (i0 - c0));
                 const u32x4 rb = *reinterpret_cast<LDSQ const u32x4 *>(myreg + (i0 - c0) + 16);
                 const u32 R[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-#pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const int g = t >> 2;
-                    u64 h;
-                    switch (t & 3) {
-                        case 0: h = fp.template hashK<0>(R[g], R[g + 1], R[g + 2], R[g + 3], R[g + 4]); break;
-                        case 1: h = fp.template hashK<1>(R[g], R[g + 1], R[g + 2], R[g + 3], R[g + 4]); break;
-                        case 2: h = fp.template hashK<2>(R[g], R[g + 1], R[g + 2], R[g + 3], R[g + 4]); break;
-                        default: h = fp.template hashK<3>(R[g], R[g + 1], R[g + 2], R[g + 3], R[g + 4]); break;
-                    }
-                    *reinterpret_cast<LDSQ u64 *>(myrow + t * 8) = h;
-                }
-                wave_sync_lds();
-                u32x4 tv[8];
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr)
-                    tv[rr] = *reinterpret_cast<LDSQ const u32x4 *>(lq + (rr * 8 + (lane >> 3)) * (TL * 8) + (lane & 7) * 16);
-#pragma unroll
-                for (int rr = 0; rr < 8; ++rr) {
-                    if (i0 + (u32)(lane & 7) * 2 < rnk[rr]) {
-                        u64x2_a8 vv;
-                        vv.a = ((u64)tv[rr].y << 32) | tv[rr].x;
-                        vv.b = ((u64)tv[rr].w << 32) | tv[rr].z;
-                        nt_store_u64x2(a.hash + roff[rr] + i0, vv.a, vv.b);
-                    }
-                }
-                wave_sync_lds();
+                hash16_and_flush(R, i0);
             }
         }
       }
@@ -493,7 +549,7 @@ int fast_prot_hash_blocks_per_cu(int k) {
     int nb = 0;
     hipError_t e = hipErrorInvalidValue;
 #define X(KK) \
-    if (k == KK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_prot_hash_fast<KK>, 64, 0);
+    if (k == KK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_prot_hash_fast<KK, false>, 64, 0);
     BSK_PH_KS(X)
 #undef X
     if (e != hipSuccess || nb < 1) {
@@ -504,7 +560,26 @@ int fast_prot_hash_blocks_per_cu(int k) {
 }
 void fast_prot_hash_launch(int k, int grid, hipStream_t stream, const KArgs &a) {
 #define X(KK) \
-    if (k == KK) hipLaunchKernelGGL((k_prot_hash_fast<KK>), dim3(grid), dim3(64), 0, stream, a);
+    if (k == KK) hipLaunchKernelGGL((k_prot_hash_fast<KK, false>), dim3(grid), dim3(64), 0, stream, a);
+    BSK_PH_KS(X)
+#undef X
+}
+int fast_prot_hash_dna_blocks_per_cu(int k) {
+    int nb = 0;
+    hipError_t e = hipErrorInvalidValue;
+#define X(KK) \
+    if (k == KK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_prot_hash_fast<KK, true>, 64, 0);
+    BSK_PH_KS(X)
+#undef X
+    if (e != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        nb = 1;
+    }
+    return nb;
+}
+void fast_prot_hash_dna_launch(int k, int grid, hipStream_t stream, const KArgs &a) {  // 2-bit DNA in, translated on the fly
+#define X(KK) \
+    if (k == KK) hipLaunchKernelGGL((k_prot_hash_fast<KK, true>), dim3(grid), dim3(64), 0, stream, a);
     BSK_PH_KS(X)
 #undef X
 }
