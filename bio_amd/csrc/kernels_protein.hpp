@@ -168,6 +168,19 @@ struct DnaResidues {
         if (frame > 0) return (u32)aat[F & 63u] | ((u32)aat[(F >> 6) & 63u] << 8) | ((u32)aat[(F >> 12) & 63u] << 16) | ((u32)aat[(F >> 18) & 63u] << 24);
         return (u32)aat[(F >> 18) & 63u] | ((u32)aat[(F >> 12) & 63u] << 8) | ((u32)aat[(F >> 6) & 63u] << 16) | ((u32)aat[F & 63u] << 24);
     }
+    // Plus frames, four dwords at once: dwords jd0 .. jd0+3 (jd0 a multiple of 4) are 48 bases = three packed words starting at word
+    // 3 jd0 / 4, shifted by the frame's 0 / 2 / 4 bits -- the same wave-uniform alignment for every jd0, so ONE 16-byte load serves the
+    // four fields and each field is one v_alignbit with a scalar shift (no per-field address arithmetic, a quarter of the loads).
+    // (Reads up to maxlen / 16 + 4 words past a shorter sequence's end: inside the batch's slack, the residues are never stored.)
+    __device__ __forceinline__ u32x4 issue4(u32 jd0) const { return *reinterpret_cast<const GLBQ u32x4_u *>((size_t)(wseq + 3u * (jd0 >> 2))); }
+    __device__ __forceinline__ void finish4(const u32x4 &w4, u32 (&out)[4]) const {
+        const u32 d = 2u * (u32)(frame - 1);
+        const u32 F[4] = {__builtin_amdgcn_alignbit(w4.y, w4.x, d), __builtin_amdgcn_alignbit(w4.y, w4.x, 24u + d),
+                          __builtin_amdgcn_alignbit(w4.z, w4.y, 16u + d), __builtin_amdgcn_alignbit(w4.w, w4.z, 8u + d)};
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            out[g] = (u32)aat[F[g] & 63u] | ((u32)aat[(F[g] >> 6) & 63u] << 8) | ((u32)aat[(F[g] >> 12) & 63u] << 16) | ((u32)aat[(F[g] >> 18) & 63u] << 24);
+    }
 };
 
 template <int W, int K, bool DNA = false>
@@ -509,6 +522,28 @@ __global__ __launch_bounds__(64) void k_prot_hash_fast(KArgs a) {
         if (DNA) {
             const DnaResidues dr{a.words + off, Lnt, frame, reinterpret_cast<const LDSQ u8 *>(lq + SW_OFF)};
             u32 R[8];
+            if (frame > 0) {  // wave-uniform: the aligned four-dwords-per-load form
+                u32 lo4[4], hi4[4];
+                dr.finish4(dr.issue4(0), lo4);
+                dr.finish4(dr.issue4(4), hi4);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    R[g] = lo4[g];
+                    R[g + 4] = hi4[g];
+                }
+                for (u32 i0 = 0; i0 < nk_max; i0 += 16) {
+                    const u32x4 raw4 = dr.issue4(i0 / 4 + 8);  // the next step's four new dwords: requested before this step's hashing and stores
+                    hash16_and_flush(R, i0);
+                    u32 nx[4];
+                    dr.finish4(raw4, nx);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        R[g] = R[g + 4];
+                        R[g + 4] = nx[g];
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int g = 0; g < 8; ++g) R[g] = dr.finish(dr.issue((u32)g), (u32)g);
             for (u32 i0 = 0; i0 < nk_max; i0 += 16) {
