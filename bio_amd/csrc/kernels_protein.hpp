@@ -181,6 +181,32 @@ struct DnaResidues {
         for (int g = 0; g < 4; ++g)
             out[g] = (u32)aat[F[g] & 63u] | ((u32)aat[(F[g] >> 6) & 63u] << 8) | ((u32)aat[(F[g] >> 12) & 63u] << 16) | ((u32)aat[(F[g] >> 18) & 63u] << 24);
     }
+    // Minus frames, four dwords at once: the fields of dwords jd0 .. jd0+3 descend from the sequence's END, so their alignment is the
+    // lane's own -- but it is the same for every jd0 (48 bases = three words per step): with A = lowest base of the four fields,
+    // a = A & 15 is a per-lane constant, field g sits 2a + 24(3-g) bits into the window of four words at word A >> 4, i.e. in one of
+    // two word pairs chosen by a (three per-lane masks) and at a per-lane shift.  Near the sequence's start A is negative: the window
+    // then begins in the PREVIOUS sequence's words, whose bits only reach residues past the end of this translation (never stored);
+    // only the batch's very first sequence has nothing before it (first_word + A >> 4 < 0): such a lane says so and takes finish().
+    __device__ __forceinline__ int low_base4(u32 jd0) const { return (int)Lnt + frame - 12 * (int)(jd0 + 3) - 11; }
+    __device__ __forceinline__ u32x4 issue4m(u32 jd0, long long first_word, bool &before_batch) const {
+        const int A = low_base4(jd0);
+        long long w0 = (long long)(A >> 4);  // floor
+        before_batch = first_word + w0 < 0;
+        if (before_batch) w0 = -first_word;
+        return *reinterpret_cast<const GLBQ u32x4_u *>((size_t)(wseq + w0));
+    }
+    __device__ __forceinline__ void finish4m(const u32x4 &w4, u32 jd0, u32 (&out)[4]) const {
+        const u32 a = (u32)low_base4(jd0) & 15u;
+        const u32 s3 = 2u * a, s2 = (24u + 2u * a) & 31u, s1 = (48u + 2u * a) & 31u, s0 = (72u + 2u * a) & 31u;
+        const bool u2 = a >= 4u, u1 = a >= 8u, u0 = a >= 12u;  // the field starts one word higher
+        const u32 F[4] = {__builtin_amdgcn_alignbit(u0 ? w4.w : w4.w, u0 ? w4.w : w4.z, s0),  // (u0: the field lies inside word 3: bits 8..)
+                          __builtin_amdgcn_alignbit(u1 ? w4.w : w4.z, u1 ? w4.z : w4.y, s1),
+                          __builtin_amdgcn_alignbit(u2 ? w4.z : w4.y, u2 ? w4.y : w4.x, s2),
+                          __builtin_amdgcn_alignbit(w4.y, w4.x, s3)};
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            out[g] = (u32)aat[(F[g] >> 18) & 63u] | ((u32)aat[(F[g] >> 12) & 63u] << 8) | ((u32)aat[(F[g] >> 6) & 63u] << 16) | ((u32)aat[F[g] & 63u] << 24);
+    }
 };
 
 template <int W, int K, bool DNA = false>
@@ -546,15 +572,30 @@ __global__ __launch_bounds__(64) void k_prot_hash_fast(KArgs a) {
             }
 #pragma unroll
             for (int g = 0; g < 8; ++g) R[g] = dr.finish(dr.issue((u32)g), (u32)g);
-            for (u32 i0 = 0; i0 < nk_max; i0 += 16) {
-                u64 raw[4];  // the next step's four new dwords: requested before this step's hashing and stores
+            for (u32 i0 = 0; i0 < nk_max; i0 += 16) {  // minus frames: the window of four fields, aligned to the lane's own end
+                const u32 jn = i0 / 4 + 8;
+                bool bb;
+                const u32x4 raw4 = dr.issue4m(jn, (long long)off, bb);
+                const bool any_bb = __builtin_amdgcn_ballot_w64(bb) != 0;  // (only the wave of the batch's first sequence, near its start)
+                u64 rawg[4] = {0, 0, 0, 0};
+                if (any_bb) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) raw[g] = dr.issue(i0 / 4 + 8 + (u32)g);
+                    for (int g = 0; g < 4; ++g) rawg[g] = dr.issue(jn + (u32)g);
+                }
                 hash16_and_flush(R, i0);
+                u32 nx[4];
+                dr.finish4m(raw4, jn, nx);
+                if (any_bb) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const u32 t = dr.finish(rawg[g], jn + (u32)g);
+                        nx[g] = bb ? t : nx[g];
+                    }
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     R[g] = R[g + 4];
-                    R[g + 4] = dr.finish(raw[g], i0 / 4 + 8 + (u32)g);
+                    R[g + 4] = nx[g];
                 }
             }
             continue;
