@@ -646,11 +646,19 @@ void par_worker(bsk_fastx_par *p) {
         pc->idx = idx;
         uint64_t lo, hi;
         piece_range(p, idx, lo, hi);
-        const int64_t s = idx == 0 ? (int64_t)p->first : find_start(p, &rd.cursor, lo, hi, tmp);
-        if (s >= 0) {
-            parse_span(&rd, p, (uint64_t)s, hi, pc);
-        } else {
-            pc->start = -1;
+        try {
+            const int64_t s = idx == 0 ? (int64_t)p->first : find_start(p, &rd.cursor, lo, hi, tmp);
+            if (s >= 0) {
+                parse_span(&rd, p, (uint64_t)s, hi, pc);
+            } else {
+                pc->start = -1;
+                pc->seq.clear();
+                pc->off.assign(1, 0);
+                pc->err = BSK_OK;
+                pc->file_done = false;
+            }
+        } catch (const std::bad_alloc &) {  // no exception leaves a thread (or crosses the C ABI): the consumer re-parses the piece
+            pc->start = -1;                 // serially and meets the same condition in its own thread
             pc->seq.clear();
             pc->off.assign(1, 0);
             pc->err = BSK_OK;
@@ -803,7 +811,14 @@ extern "C" int bsk_fastx_par_next(bsk_fastx_par *p, bsk_fastx_piece **piece) {
         }
         if (pc->start != (int64_t)p->cur) {  // no guess or a wrong one: the records of [cur, hi), serially
             p->reparsed++;
-            parse_span(&p->serial, p, p->cur, hi, pc);
+            try {
+                parse_span(&p->serial, p, p->cur, hi, pc);
+            } catch (const std::bad_alloc &) {
+                p->err = "fastx: out of memory";
+                p->finished = true;
+                bsk_fastx_piece_release(p, pc);
+                return BSK_ERR_NOMEM;
+            }
         }
         if (pc->file_done) p->finished = true;
         else p->cur = pc->end;
