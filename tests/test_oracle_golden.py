@@ -228,3 +228,18 @@ def test_reference_protein_tests_feed_dna(oracle):
     assert len(oracle.protein_hashes_nt(dna, k, 1, 1)) == len(dna) // 3 - k + 1
     h, p, _ = oracle.protein_minimizer_nt(dna, k, 3, 1, 1)
     assert 1 <= len(h) <= len(dna) // 3 - k + 1 and list(p) == sorted(set(int(x) for x in p))
+
+
+def test_two_strand_kmer_codes_pair_letters_by_alphabet_hand_derived():
+    """NextKmer, canonical=false (iterator.go:713-723): the second strand is RevComInplace of the Seq, whose Alphabet decides which
+    letters pair (seq/alphabet.go:353-383) -- worked out by hand for ACGUUNRT, k = 3 (A0 C1 G2 T/U3; N, R -> 0; Y -> 1):
+      forward ACG CGU GUU UUN UNR NRT = 6 27 47 60 48 3 for every alphabet;
+      RNA          : T, R stay, N -> N, U -> A, G <-> C, A -> U : TRNAACGU -> TRN RNA NAA AAC ACG CGU = 48 0 0 1 6 27
+      DNAredundant : T -> A, R -> Y, U stays               : AYNUUCGT -> AYN YNU NUU UUC UCG CGT = 4 19 15 61 54 27
+      Unlimit      : reversed, not complemented            : TRNUUGCA -> TRN RNU NUU UUG UGC GCA = 48 3 15 62 57 36"""
+    fwd = [6, 27, 47, 60, 48, 3]
+    for alphabet, second in ((3, [48, 0, 0, 1, 6, 27]), (0, [4, 19, 15, 61, 54, 27]), (5, [48, 3, 15, 62, 57, 36])):
+        assert list(oracle.kmer_codes("ACGUUNRT", 3, False, False, alphabet)) == fwd + second, alphabet
+    # plain DNA pairs acgt only (T -> A, R / N / U stay): ARNUUCGT; RNAredundant: T stays, R -> Y, U -> A: TYNAACGU
+    assert list(oracle.kmer_codes("ACGUUNRT", 3, False, False, 2))[6:] == [0, 3, 15, 61, 54, 27]
+    assert list(oracle.kmer_codes("ACGUUNRT", 3, False, False, 4))[6:] == [52, 16, 0, 1, 6, 27]
