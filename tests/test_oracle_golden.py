@@ -230,7 +230,7 @@ def test_reference_protein_tests_feed_dna(oracle):
     assert 1 <= len(h) <= len(dna) // 3 - k + 1 and list(p) == sorted(set(int(x) for x in p))
 
 
-def test_two_strand_kmer_codes_pair_letters_by_alphabet_hand_derived():
+def test_two_strand_kmer_codes_pair_letters_by_alphabet_hand_derived(oracle):
     """NextKmer, canonical=false (iterator.go:713-723): the second strand is RevComInplace of the Seq, whose Alphabet decides which
     letters pair (seq/alphabet.go:353-383) -- worked out by hand for ACGUUNRT, k = 3 (A0 C1 G2 T/U3; N, R -> 0; Y -> 1):
       forward ACG CGU GUU UUN UNR NRT = 6 27 47 60 48 3 for every alphabet;
