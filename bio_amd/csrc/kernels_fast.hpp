@@ -443,10 +443,14 @@ __device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 e
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const u32 t = t0 + 64 * j + lane;
+#ifdef BSK_FAST_NOSTORE  // dev: the copy-out's LDS chains without its stores (keeps the values alive)
+            asm volatile("" ::"v"(hv[j]), "v"(pv[j]));
+#else
             if (t < T) {
                 __builtin_nontemporal_store(hv[j], &a.hash[base + t]);  // write-once output (see flush_rows)
                 __builtin_nontemporal_store(POS16 ? (pv[j] & 0x80007fffu) : pv[j], &a.pos[base + t]);
             }
+#endif
         }
     }
     wave_sync_lds();
@@ -524,8 +528,10 @@ __global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs 
         u64 base = (u64)unit * slab;
         if (!any_over) {
             // copy-out rows in flight: what keeps the kernel within 256 VGPRs (two waves per SIMD)
+#ifndef BSK_FAST_NOCOPYOUT
             if (PAIR) fast_copyout<LY, POS16, LY::NHEADS - 1, (W <= 11 ? 4 : W <= 15 ? 2 : 1), true>(lds, lane, cnt, excl, T, base, a);
             else fast_copyout<LY, POS16, CAP>(lds, lane, cnt, excl, T, base, a);
+#endif  // (dev: timing without the copy-out)
         } else {
             // rare (0.6 % of units at k=21 w=11 CAP=32): a lane selected more than CAP tuples.  The unit may not
             // fit its slab: take T tuples from the overflow region and recompute, storing straight to HBM.
