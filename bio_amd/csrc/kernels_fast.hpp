@@ -23,6 +23,7 @@
 // HBM traffic is the packed bases in and the selected (hash, pos|strand) tuples
 // plus one 8-byte reference per read out; tuples leave LDS as whole 512-/256-byte rows.
 #pragma once
+#include <type_traits>
 #include "fast_dispatch.hpp"
 
 namespace bsk {
@@ -140,7 +141,8 @@ struct PLds {
     static constexpr int NZ = HEADS + NHEADS * 8;                          // u8 [64]
     static constexpr int EXCL = SH + R * ROW * 8;                          // u32 [64] in the spare row (free once the pass is over)
     static constexpr int TAB2 = NZ + 64;                                   // 16 x uint4: warm-up table of two bases (build_xtab2)
-    static constexpr int TOTAL = TAB2 + 256;
+    static constexpr int CTAB = TAB2 + 256;                                // u64 [64]: fast_copyout's owner table
+    static constexpr int TOTAL = CTAB + 512;                               // 20 400 B: eight waves per CU use 163 200 of the 163 840 B
 };
 template <bool PAIR, int CAP, bool POS16, int PR>
 struct MinLds {
@@ -389,56 +391,73 @@ struct FastMin {
 };
 
 // LDS -> HBM copy-out of one unit's staged tuples in read order (shared by the fast kernels).
-// owner of output t = lane whose run [excl, excl+cnt) holds t: one head bit per non-empty lane,
-// popcount below the bit -> rank among non-empty lanes -> lane (no per-output map in LDS).
+// Owner of output t = the lane whose run [excl, excl + cnt) holds t: one head bit per non-empty lane (s_heads, one 64-bit word per
+// row of 64 outputs), population count up to the output's bit -> rank among the non-empty lanes -> that lane's table entry
+// {A, S}: the byte offset of output t inside the staged hashes is A + S t (S = one row up or -- the high lane of a paired column --
+// down).  Per row of 64 outputs: two mbcnt on the (scalar) head word, one 8-byte table read, one 24-bit multiply-add, the two
+// staged reads and the two stores; the first version (head word -> rank -> lane -> its first output -> row and column arithmetic
+// per output, a quarter-rate 32-bit multiply among it, a bound check on every output) was 13 % of the minimizer kernel's time.
 // PAIR: the staging of PLds (row = e for the low lane of a column, R-1-e for the high one); CAP is then the last head word.
 template <class LY, bool POS16, int CAP, int U = 4, bool PAIR = false>
 __device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 excl, u32 T, u64 base, const KArgs &a) {
-    u32 *s_excl = reinterpret_cast<u32 *>(lds + LY::EXCL);
     u64 *s_heads = reinterpret_cast<u64 *>(lds + LY::HEADS);
-    u8 *s_nz = reinterpret_cast<u8 *>(lds + LY::NZ);
+    // the table: {A, S} (8 bytes, PLds::CTAB) for paired columns; private columns all step upwards, S is a constant and the entry is A
+    // alone (4 bytes, in the 256 bytes that held the exclusive offsets: SynLds has no room for more at eight waves per CU)
+    u64 *s_tab64 = nullptr;
+    if constexpr (PAIR) s_tab64 = reinterpret_cast<u64 *>(lds + LY::CTAB);
+    u32 *s_tab32 = reinterpret_cast<u32 *>(lds + LY::EXCL);
     const u64 nzmask = __builtin_amdgcn_ballot_w64(cnt > 0);
-    s_excl[lane] = excl;
     if (lane <= CAP) s_heads[lane] = 0;
     wave_sync_lds();
     if (cnt > 0) {
-        s_nz[__builtin_amdgcn_mbcnt_hi((u32)(nzmask >> 32), __builtin_amdgcn_mbcnt_lo((u32)nzmask, 0))] = (u8)lane;
+        constexpr int RB = LY::ROW * 8;  // bytes from one row of staged hashes to the next
+        int A, S;
+        if (PAIR) {
+            const int col8 = (lane & 31) * 8;
+            S = lane < 32 ? RB : -RB;
+            A = lane < 32 ? col8 - (int)excl * RB : col8 + ((int)(BSK_PAIR_ROWS - 1) + (int)excl) * RB;
+        } else {
+            S = RB;
+            A = lane * 8 - (int)excl * RB;
+        }
+        const u32 rk = __builtin_amdgcn_mbcnt_hi((u32)(nzmask >> 32), __builtin_amdgcn_mbcnt_lo((u32)nzmask, 0));
+        if (PAIR) s_tab64[rk] = ((u64)(u32)S << 32) | (u32)A;
+        else s_tab32[rk] = (u32)A;
         atomicOr(&s_heads[excl >> 6], 1ULL << (excl & 63));
     }
     wave_sync_lds();
-    // U rows of 64 outputs per trip: each output costs a chain of four dependent LDS reads (head word -> owner rank ->
-    // owner's first output -> staged tuple), so the chains of U rows are issued together and their latencies overlap
-    // (minimizer k=21 w=11: 21.7 -> 21.0 ms with U = 4; kernels at the register limit keep U = 1).
-    u32 heads_before = 0;
-    const u64 *sh = reinterpret_cast<const u64 *>(lds + LY::SH);
-    for (u32 t0 = 0; t0 < T; t0 += 64 * U) {
-        u32 rank[U], owner[U], ex[U], sl[U];
+    u32 heads_before = 0;  // wave-uniform: the head words are made scalar, their population count is SALU work
+    const char *sh = lds + LY::SH, *sp = lds + LY::SP;
+    // CHECK: the trip may reach beyond output T (the unit's last trip); every other trip runs without the per-output bound.
+    // U rows per trip: their dependent LDS reads (head word -> table entry -> staged tuple) are issued together.
+    auto trip = [&](u32 t0, auto check) {
+        constexpr bool CHECK = decltype(check)::value;
+        u32 rank[U], so[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const u32 c = (t0 >> 6) + j;
-            const u64 M = s_heads[c < (u32)CAP ? c : (u32)CAP];  // word CAP is never set: rows beyond the unit see no heads
-            const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(M >> 32), __builtin_amdgcn_mbcnt_lo((u32)M, 0));
-            rank[j] = heads_before + below + (u32)((M >> lane) & 1) - 1;
+            const u64 Mv = s_heads[c < (u32)CAP ? c : (u32)CAP];  // word CAP is never set: rows beyond the unit see no heads
+            const u32 mlo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)Mv), mhi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(Mv >> 32));
+            const u64 M = ((u64)mhi << 32) | mlo;
+            // heads at outputs <= this lane's = bits 1 .. lane of M (mbcnt of M >> 1 counts exactly those) + bit 0
+            const u64 M1 = M >> 1;
+            const u32 sbase = heads_before + (mlo & 1u) - 1u;  // scalar
+            rank[j] = __builtin_amdgcn_mbcnt_hi((u32)(M1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)M1, sbase));
             heads_before += (u32)__builtin_popcountll(M);
         }
+        u64 ent[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) owner[j] = s_nz[rank[j]];
-#pragma unroll
-        for (int j = 0; j < U; ++j) ex[j] = s_excl[owner[j]];
+        for (int j = 0; j < U; ++j) ent[j] = PAIR ? s_tab64[rank[j] & 63u] : (((u64)(u32)(LY::ROW * 8) << 32) | s_tab32[rank[j] & 63u]);
         u64 hv[U];
         u32 pv[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const u32 t = t0 + 64 * j + lane;
-            if (PAIR) {
-                const u32 e = t - ex[j];
-                sl[j] = t < T ? (owner[j] < 32u ? e : (u32)(BSK_PAIR_ROWS - 1) - e) * LY::ROW + (owner[j] & 31u) : 0u;
-            } else {
-                sl[j] = t < T ? (t - ex[j]) * LY::ROW + owner[j] : 0u;
-            }
-            hv[j] = sh[sl[j]];
-            if (POS16) pv[j] = (u32)(int)*reinterpret_cast<const short *>(lds + LY::SP + sl[j] * 2);  // sign-extending read: the strand bit lands in bit 31
-            else pv[j] = *reinterpret_cast<const u32 *>(lds + LY::SP + sl[j] * 4);
+            const int off = __mul24((int)t, (int)(u32)(ent[j] >> 32)) + (int)(u32)ent[j];  // v_mad_i32_i24
+            so[j] = (!CHECK || t < T) ? (u32)off : 0u;
+            hv[j] = *reinterpret_cast<const u64 *>(sh + so[j]);
+            if (POS16) pv[j] = (u32)(int)*reinterpret_cast<const short *>(sp + (so[j] >> 2));  // sign-extending read: the strand bit lands in bit 31
+            else pv[j] = *reinterpret_cast<const u32 *>(sp + (so[j] >> 1));
         }
 #pragma unroll
         for (int j = 0; j < U; ++j) {
@@ -446,13 +465,16 @@ __device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 e
 #ifdef BSK_FAST_NOSTORE  // dev: the copy-out's LDS chains without its stores (keeps the values alive)
             asm volatile("" ::"v"(hv[j]), "v"(pv[j]));
 #else
-            if (t < T) {
+            if (!CHECK || t < T) {
                 __builtin_nontemporal_store(hv[j], &a.hash[base + t]);  // write-once output (see flush_rows)
                 __builtin_nontemporal_store(POS16 ? (pv[j] & 0x80007fffu) : pv[j], &a.pos[base + t]);
             }
 #endif
         }
-    }
+    };
+    u32 t0 = 0;
+    for (; t0 + 64 * U <= T; t0 += 64 * U) trip(t0, std::false_type{});
+    if (t0 < T) trip(t0, std::true_type{});
     wave_sync_lds();
 }
 
