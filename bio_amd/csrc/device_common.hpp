@@ -81,12 +81,19 @@ __device__ __forceinline__ void wave_sync_lds() {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// Wave-wide scans / reductions of 32-bit values on DPP moves (row_shr 1, 2, 4, 8 inside the rows of 16 lanes, then row_bcast:15 into
+// rows 1 and 3 and row_bcast:31 into rows 2 and 3): six VALU instructions and no LDS.  The ds_bpermute (__shfl_up) form was six
+// DEPENDENT trips through the LDS crossbar -- the flush of the per-read-slab kernels scans once per round (every ten steps of the
+// protein minimizer), and the scan alone was a third of a round.
+#define BSK_DPP0(v, ctrl, rmask) ((u32)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), (rmask), 0xf, false))
 __device__ __forceinline__ u32 wave_incl_scan_u32(u32 v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
+    (void)lane;
+    v += BSK_DPP0(v, 0x111, 0xf);  // row_shr:1 (lanes without a source add 0)
+    v += BSK_DPP0(v, 0x112, 0xf);
+    v += BSK_DPP0(v, 0x114, 0xf);
+    v += BSK_DPP0(v, 0x118, 0xf);
+    v += BSK_DPP0(v, 0x142, 0xa);  // row_bcast:15 -> rows 1, 3
+    v += BSK_DPP0(v, 0x143, 0xc);  // row_bcast:31 -> rows 2, 3
     return v;
 }
 __device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, int lane) {
@@ -102,15 +109,17 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
     for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d, 64);
     return v;
 }
-__device__ __forceinline__ u32 wave_max_u32(u32 v) {
-#pragma unroll
-    for (int d = 32; d; d >>= 1) {
-        u32 t = __shfl_xor(v, d, 64);
-        v = t > v ? t : v;
-    }
-    return v;
+__device__ __forceinline__ u32 wave_max_u32(u32 v) {  // the same ladder with max (0 is the identity of an unsigned maximum), read from lane 63
+    u32 t;
+    t = BSK_DPP0(v, 0x111, 0xf); v = t > v ? t : v;
+    t = BSK_DPP0(v, 0x112, 0xf); v = t > v ? t : v;
+    t = BSK_DPP0(v, 0x114, 0xf); v = t > v ? t : v;
+    t = BSK_DPP0(v, 0x118, 0xf); v = t > v ? t : v;
+    t = BSK_DPP0(v, 0x142, 0xa); v = t > v ? t : v;
+    t = BSK_DPP0(v, 0x143, 0xc); v = t > v ? t : v;
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
-__device__ __forceinline__ u32 wave_bcast_u32(u32 v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ u32 wave_bcast_u32(u32 v, int src) { return (u32)__builtin_amdgcn_readlane((int)v, src); }  // src is wave-uniform
 __device__ __forceinline__ u64 wave_bcast_u64(u64 v, int src) { return __shfl(v, src, 64); }
 
 // ---- work distribution: persistent waves pull units (64 reads) from a ticket ----

@@ -665,6 +665,77 @@ __device__ __forceinline__ void flush_rows(char *lds, int lane, u32 cnt, bool la
     wave_sync_lds();
 }
 
+// The regular flush round of the per-read-slab kernels: every lane sends its whole groups of 1 << GL staged tuples (a group = one
+// 128-byte line of hashes) to its own slab.  A work unit is ONE group, so the owner of an output needs no bitmap: unit u = t >> GL is
+// entry u of a 4-byte table {owner lane : 6, first ring row of the group : 6, its tuple index inside the owner's slab : 20} that the
+// owners fill (one or two entries each); an output then costs one broadcast table read, the ring wrap, one 24-bit multiply-add each
+// for the staged slot and the destination, the two staged reads and the two stores, and the rows of a round (three or four) go as
+// one batch.  flush_rows -- head bitmap built with LDS atomics, rank by population count, owner, its offset / destination / ring
+// head from three more arrays, a 32-bit multiply, one row at a time behind two hand-offs -- ran this round every ten steps of the
+// protein minimizer and was 47 % of that kernel (33.2 ms with it, 17.4 ms with the flushes compiled out).
+template <class LY, bool STRAND16, int GL, int RING>
+__device__ __forceinline__ void flush_groups(char *lds, int lane, u32 cnt, u32 done, u64 slab_read, u64 ubase, const KArgs &a, u32 head) {
+    constexpr u32 GM = (1u << GL) - 1u;
+    u32 *s_tab = reinterpret_cast<u32 *>(lds + LY::DST);  // 128 entries: a lane holds fewer than 2 << GL + ... staged tuples (RING <= 2 << GL + GM)
+    static_assert(RING <= 64 && ((RING - 1) >> GL) <= 2, "a lane flushes at most two groups per round");
+    const u32 units = cnt >> GL;
+    const u32 incl = wave_incl_scan_u32(units, lane);
+    const u32 excl = incl - units;
+    const u32 U = wave_bcast_u32(incl, 63);
+    if (U == 0) return;
+    const bool fits = (u64)done + ((u64)units << GL) <= slab_read && (u64)done + ((u64)units << GL) < (1u << 20);
+    if (__builtin_amdgcn_ballot_w64(!fits) && lane == 0) atomicOr(&a.ticket[1], 1u);  // slab too small: host falls back
+    if (units > 0) {
+        u32 row0 = head, doff = fits ? done : 0xfffffu;
+        s_tab[excl] = ((u32)lane << 26) | (row0 << 20) | doff;
+        if (units > 1) {
+            row0 += (1u << GL);
+            row0 = row0 >= (u32)RING ? row0 - (u32)RING : row0;
+            s_tab[excl + 1] = ((u32)lane << 26) | (row0 << 20) | (fits ? done + (1u << GL) : 0xfffffu);
+        }
+    }
+    wave_sync_lds();
+    const u32 T = U << GL;
+    const u32 slab24 = (u32)slab_read;  // < 2^24 (the kernels' callers bound the sequence length)
+    constexpr int UR = 4;               // rows of 64 outputs per trip: their table and staged reads are issued together
+    for (u32 t0 = 0; t0 < T; t0 += 64 * UR) {
+        u32 ent[UR];
+#pragma unroll
+        for (int j = 0; j < UR; ++j) {
+            const u32 t = t0 + 64 * j + lane;
+            ent[j] = s_tab[(t < T ? t : T - 1) >> GL];
+        }
+        u64 hv[UR];
+        u32 pv[UR], di[UR];
+        bool ok[UR];
+#pragma unroll
+        for (int j = 0; j < UR; ++j) {
+            const u32 t = t0 + 64 * j + lane;
+            const u32 owner = ent[j] >> 26, sub = t & GM, doff = ent[j] & 0xfffffu;
+            u32 row = ((ent[j] >> 20) & 63u) + sub;
+            row = row < row - (u32)RING ? row : row - (u32)RING;  // ring wrap: row - RING wraps to a huge value when row < RING
+            const u32 sl = __umul24(row, (u32)LY::ROW) + owner;
+            ok[j] = t < T && doff != 0xfffffu;
+            di[j] = __umul24(owner, slab24) + doff + sub;
+            hv[j] = *reinterpret_cast<const u64 *>(lds + LY::SH + sl * 8);
+            pv[j] = *reinterpret_cast<const u16 *>(lds + LY::SP + sl * 2);
+        }
+#pragma unroll
+        for (int j = 0; j < UR; ++j) {
+#ifdef BSK_FLUSH_NOSTORE  // dev: the flush's work without its stores
+            asm volatile("" ::"v"(hv[j]), "v"(pv[j]), "v"(di[j]), "v"((u32)ok[j]));
+#else
+            if (ok[j]) {
+                const u32 pp = STRAND16 ? (pv[j] & 0x7fffu) | ((pv[j] & 0x8000u) << 16) : pv[j];
+                __builtin_nontemporal_store(hv[j], &a.hash[ubase + di[j]]);  // write-once output (see flush_rows)
+                __builtin_nontemporal_store(pp, &a.pos[ubase + di[j]]);
+            }
+#endif
+        }
+    }
+    wave_sync_lds();
+}
+
 // ---------------------------------------------------------------------------------------
 // Dense minimizers (small w): a 150-bp read at w = 5 selects ~43 positions, more than the 32 k_minimizer_fast stages per
 // read, so almost every unit took its recompute-and-store-directly path (w = 5: 250 Gbases/s against 620 at w = 10).
@@ -761,7 +832,8 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
                     // the lane's rows are a ring starting at `head` (moving the left-over down after every flush cost more than the wrap test)
                     const u32 wrow = (fm.slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);
                     const u32 cnt = wrow >= head ? wrow - head : wrow + (u32)(CAP + 1) - head;  // staged: left-over < 16 + NB*W new
-                    flush_rows<LY, true, GL, CAP + 1>(lds, lane, cnt, last, done, slab_read, ubase, a, head);
+                    if (last) flush_rows<LY, true, GL, CAP + 1>(lds, lane, cnt, last, done, slab_read, ubase, a, head);
+                    else flush_groups<LY, true, GL, CAP + 1>(lds, lane, cnt, done, slab_read, ubase, a, head);
                     const u32 nfl = last ? cnt : (cnt & ~(u32)(G - 1));
                     head += nfl;
                     head = head >= (u32)(CAP + 1) ? head - (u32)(CAP + 1) : head;
