@@ -115,7 +115,7 @@ struct FLds {
     static constexpr int EXCL = SP + (((CAP + 1) * ROW * PB + 15) & ~15);   // u32 [64]
     static constexpr int HEADS = EXCL + 256;  // u64 [CAP+1]: bit j of word c: a lane's run starts at output 64c+j
     static constexpr int NZ = HEADS + (CAP + 1) * 8;  // u8 [64]: rank among non-empty lanes -> lane
-    static constexpr int DST = NZ + 64;               // u32 [64] + u32 [64] ring heads: flush_rows (kernels with per-read slabs)
+    static constexpr int DST = NZ + 64;               // 512 bytes: the owner table of flush_groups / flush_last (kernels with per-read slabs)
     static constexpr int ROWS = CAP + 1;
     static constexpr int TAB2 = DST + 512;            // 16 x uint4: warm-up table of two bases (build_xtab2)
     static constexpr int TOTAL = TAB2 + 256;
@@ -466,7 +466,7 @@ __device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 e
             asm volatile("" ::"v"(hv[j]), "v"(pv[j]));
 #else
             if (!CHECK || t < T) {
-                __builtin_nontemporal_store(hv[j], &a.hash[base + t]);  // write-once output (see flush_rows)
+                __builtin_nontemporal_store(hv[j], &a.hash[base + t]);  // write-once output: non-temporal, so that the tuples streaming out do not push the sequences' lines out of the L2
                 __builtin_nontemporal_store(POS16 ? (pv[j] & 0x80007fffu) : pv[j], &a.pos[base + t]);
             }
 #endif
@@ -596,81 +596,14 @@ __global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs 
 // per lane staged; groups of 8 (aligned 64-byte pieces) need 8 rows less -- two more waves per CU, protein minimizer w=5
 // 366 -> 424 G residues/s -- but every half-line write is a read-modify-write in HBM (traffic 1.3x -> 2.2x the algorithmic
 // bytes).  The kernels therefore keep GL = 4 and flush more often instead (fewer new rows between two flushes).
-// RING > 0: the lane's rows are a ring of RING rows starting at row `head` (no left-over moves; LY::HEAD0 holds the heads).
-template <class LY, bool STRAND16, int GL, int RING = 0>
-__device__ __forceinline__ void flush_rows(char *lds, int lane, u32 cnt, bool last, u32 done, u64 slab_read, u64 ubase,
-                                           const KArgs &a, u32 head = 0) {
-    u32 *s_excl = reinterpret_cast<u32 *>(lds + LY::EXCL);
-    u64 *s_heads = reinterpret_cast<u64 *>(lds + LY::HEADS);
-    u8 *s_nz = reinterpret_cast<u8 *>(lds + LY::NZ);
-    u32 *s_dst = reinterpret_cast<u32 *>(lds + LY::DST);
-    // unit of work: a group of 1 << GL tuples (regular round) or a single tuple (final round)
-    const u32 units = last ? cnt : (cnt >> GL);
-    const u32 ushift = last ? 0u : (u32)GL;
-    const u32 incl = wave_incl_scan_u32(units, lane);
-    const u32 excl = incl - units;
-    const u32 U = wave_bcast_u32(incl, 63);
-    if (U == 0) return;
-    const u64 nzmask = __builtin_amdgcn_ballot_w64(units > 0);
-    const bool fits = (u64)done + ((u64)units << ushift) <= slab_read;
-    if (__builtin_amdgcn_ballot_w64(!fits) && lane == 0) atomicOr(&a.ticket[1], 1u);  // slab too small: host falls back
-    s_excl[lane] = excl;
-    s_dst[lane] = fits ? (u32)(lane * slab_read + done) : 0xffffffffu;
-    if (RING) reinterpret_cast<u32 *>(lds + LY::DST)[64 + lane] = head;
-    if (lane < LY::ROWS) s_heads[lane] = 0;
-    wave_sync_lds();
-    if (units > 0) {
-        s_nz[__builtin_amdgcn_mbcnt_hi((u32)(nzmask >> 32), __builtin_amdgcn_mbcnt_lo((u32)nzmask, 0))] = (u8)lane;
-        atomicOr(&s_heads[excl >> 6], 1ULL << (excl & 63));
-    }
-    wave_sync_lds();
-    const u32 T = U << ushift;  // tuples to move
-    u32 heads_before = 0, word = 0xffffffffu;
-    u64 M = 0;
-    for (u32 t0 = 0; t0 < T; t0 += 64) {
-        const u32 t = t0 + lane;
-        const u32 ui = t >> ushift;  // work-unit index of this lane's tuple
-        if ((t0 >> ushift >> 6) != word) {  // next 64 work units: next head word (wave-uniform)
-            heads_before += (u32)__builtin_popcountll(M);
-            word = t0 >> ushift >> 6;
-            M = s_heads[word];
-        }
-        if (t < T) {
-            const u32 bit = ui & 63;
-            const u32 upto = (u32)__builtin_popcountll(M & (bit == 63 ? ~0ULL : ((2ULL << bit) - 1)));
-            const u32 owner = s_nz[heads_before + upto - 1];
-            const u32 e = ((ui - s_excl[owner]) << ushift) | (t & ((1u << ushift) - 1));
-            u32 row = e;
-            if (RING) {
-                row += reinterpret_cast<const u32 *>(lds + LY::DST)[64 + owner];
-                row = row >= (u32)RING ? row - (u32)RING : row;
-            }
-            const u32 sl = row * LY::ROW + owner;
-            const u32 d = s_dst[owner];
-            if (d != 0xffffffffu) {
-                // write-once output: non-temporal stores, so that the tuples streaming out do not push the sequences'
-                // lines (re-read every round by per-lane loads) out of the L2
-                u32 p = *reinterpret_cast<const u16 *>(lds + LY::SP + sl * 2);
-                if (STRAND16) p = (p & 0x7fffu) | ((p & 0x8000u) << 16);
-#ifndef BSK_FLUSH_PLAIN  // (dev switch: plain stores, for the write-combining experiments of DESIGN.md 3.1)
-                __builtin_nontemporal_store(*reinterpret_cast<const u64 *>(lds + LY::SH + sl * 8), &a.hash[ubase + d + e]);
-                __builtin_nontemporal_store(p, &a.pos[ubase + d + e]);
-#else
-                a.hash[ubase + d + e] = *reinterpret_cast<const u64 *>(lds + LY::SH + sl * 8);
-                a.pos[ubase + d + e] = p;
-#endif
-            }
-        }
-    }
-    wave_sync_lds();
-}
-
+// RING: the lane's rows are a ring of RING rows starting at row `head` (no left-over moves).
+//
 // The regular flush round of the per-read-slab kernels: every lane sends its whole groups of 1 << GL staged tuples (a group = one
 // 128-byte line of hashes) to its own slab.  A work unit is ONE group, so the owner of an output needs no bitmap: unit u = t >> GL is
 // entry u of a 4-byte table {owner lane : 6, first ring row of the group : 6, its tuple index inside the owner's slab : 20} that the
 // owners fill (one or two entries each); an output then costs one broadcast table read, the ring wrap, one 24-bit multiply-add each
 // for the staged slot and the destination, the two staged reads and the two stores, and the rows of a round (three or four) go as
-// one batch.  flush_rows -- head bitmap built with LDS atomics, rank by population count, owner, its offset / destination / ring
+// one batch.  The first version (flush_rows) -- head bitmap built with LDS atomics, rank by population count, owner, its offset / destination / ring
 // head from three more arrays, a 32-bit multiply, one row at a time behind two hand-offs -- ran this round every ten steps of the
 // protein minimizer and was 47 % of that kernel (33.2 ms with it, 17.4 ms with the flushes compiled out).
 template <class LY, bool STRAND16, int GL, int RING>
@@ -727,10 +660,74 @@ __device__ __forceinline__ void flush_groups(char *lds, int lane, u32 cnt, u32 d
 #else
             if (ok[j]) {
                 const u32 pp = STRAND16 ? (pv[j] & 0x7fffu) | ((pv[j] & 0x8000u) << 16) : pv[j];
-                __builtin_nontemporal_store(hv[j], &a.hash[ubase + di[j]]);  // write-once output (see flush_rows)
+                __builtin_nontemporal_store(hv[j], &a.hash[ubase + di[j]]);  // write-once output: non-temporal, so that the tuples streaming out do not push the sequences' lines out of the L2
                 __builtin_nontemporal_store(pp, &a.pos[ubase + di[j]]);
             }
 #endif
+        }
+    }
+    wave_sync_lds();
+}
+
+// The last round of a sequence: whole groups as above, then every lane's left-over (fewer than a group) as ONE partial group -- the
+// same table with the lane's count beside the entry, outputs beyond the count masked.  (Sixteen rows of 64 outputs instead of the
+// seven or eight dense ones of the first version, but four at a time and without its chain of five dependent LDS reads per row.)
+template <class LY, bool STRAND16, int GL, int RING>
+__device__ __forceinline__ void flush_last(char *lds, int lane, u32 cnt, u32 done, u64 slab_read, u64 ubase, const KArgs &a, u32 head) {
+    constexpr u32 GM = (1u << GL) - 1u;
+    flush_groups<LY, STRAND16, GL, RING>(lds, lane, cnt, done, slab_read, ubase, a, head);
+    const u32 g = cnt & ~GM;
+    head += g;
+    head = head >= (u32)RING ? head - (u32)RING : head;
+    head = head >= (u32)RING ? head - (u32)RING : head;
+    done += g;
+    const u32 c = cnt - g;  // < 1 << GL
+    u32 *s_tab = reinterpret_cast<u32 *>(lds + LY::DST);  // 64 entries of {owner, row, destination} + 64 counts
+    const u32 unit = c ? 1u : 0u;
+    const u32 incl = wave_incl_scan_u32(unit, lane);
+    const u32 U = wave_bcast_u32(incl, 63);
+    if (U == 0) return;
+    const bool fits = (u64)done + c <= slab_read && (u64)done + c < (1u << 20);
+    if (__builtin_amdgcn_ballot_w64(!fits) && lane == 0) atomicOr(&a.ticket[1], 1u);
+    if (c) {
+        s_tab[incl - 1] = ((u32)lane << 26) | (head << 20) | (fits ? done : 0xfffffu);
+        s_tab[64 + incl - 1] = c;
+    }
+    wave_sync_lds();
+    const u32 T = U << GL;
+    const u32 slab24 = (u32)slab_read;
+    constexpr int UR = 4;
+    for (u32 t0 = 0; t0 < T; t0 += 64 * UR) {
+        u32 ent[UR], cn[UR];
+#pragma unroll
+        for (int j = 0; j < UR; ++j) {
+            const u32 t = t0 + 64 * j + lane;
+            const u32 u = (t < T ? t : T - 1) >> GL;
+            ent[j] = s_tab[u];
+            cn[j] = s_tab[64 + u];
+        }
+        u64 hv[UR];
+        u32 pv[UR], di[UR];
+        bool ok[UR];
+#pragma unroll
+        for (int j = 0; j < UR; ++j) {
+            const u32 t = t0 + 64 * j + lane;
+            const u32 owner = ent[j] >> 26, sub = t & GM, doff = ent[j] & 0xfffffu;
+            u32 row = ((ent[j] >> 20) & 63u) + sub;
+            row = row < row - (u32)RING ? row : row - (u32)RING;
+            ok[j] = t < T && sub < cn[j] && doff != 0xfffffu;
+            const u32 sl = ok[j] ? __umul24(row, (u32)LY::ROW) + owner : 0u;
+            di[j] = __umul24(owner, slab24) + doff + sub;
+            hv[j] = *reinterpret_cast<const u64 *>(lds + LY::SH + sl * 8);
+            pv[j] = *reinterpret_cast<const u16 *>(lds + LY::SP + sl * 2);
+        }
+#pragma unroll
+        for (int j = 0; j < UR; ++j) {
+            if (ok[j]) {
+                const u32 pp = STRAND16 ? (pv[j] & 0x7fffu) | ((pv[j] & 0x8000u) << 16) : pv[j];
+                __builtin_nontemporal_store(hv[j], &a.hash[ubase + di[j]]);
+                __builtin_nontemporal_store(pp, &a.pos[ubase + di[j]]);
+            }
         }
     }
     wave_sync_lds();
@@ -740,7 +737,7 @@ __device__ __forceinline__ void flush_groups(char *lds, int lane, u32 cnt, u32 d
 // Dense minimizers (small w): a 150-bp read at w = 5 selects ~43 positions, more than the 32 k_minimizer_fast stages per
 // read, so almost every unit took its recompute-and-store-directly path (w = 5: 250 Gbases/s against 620 at w = 10).
 // Here every read owns a slab of `slab_read` tuples (as the protein minimizer does) and the wavefront flushes its staging
-// every NB blocks in whole groups of 16 tuples per read (flush_rows); fewer than 16 stay staged until the next round.
+// every NB blocks in whole groups of 16 tuples per read (flush_groups); fewer than 16 stay staged until the next round.
 // ---------------------------------------------------------------------------------------
 template <int W>
 struct DenseCfg {
@@ -832,7 +829,7 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
                     // the lane's rows are a ring starting at `head` (moving the left-over down after every flush cost more than the wrap test)
                     const u32 wrow = (fm.slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);
                     const u32 cnt = wrow >= head ? wrow - head : wrow + (u32)(CAP + 1) - head;  // staged: left-over < 16 + NB*W new
-                    if (last) flush_rows<LY, true, GL, CAP + 1>(lds, lane, cnt, last, done, slab_read, ubase, a, head);
+                    if (last) flush_last<LY, true, GL, CAP + 1>(lds, lane, cnt, done, slab_read, ubase, a, head);
                     else flush_groups<LY, true, GL, CAP + 1>(lds, lane, cnt, done, slab_read, ubase, a, head);
                     const u32 nfl = last ? cnt : (cnt & ~(u32)(G - 1));
                     head += nfl;

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
             auto flush = [&](bool last) {  // last: everything that is staged
                 const u32 wrow = (fp.slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);  // row of the next write
                 const u32 cnt = wrow >= head ? wrow - head : wrow + (u32)LY::ROWS - head;  // staged (< ROWS: left-over < 16, new <= HS)
-                if (last) flush_rows<LY, false, GL, LY::ROWS>(lds, lane, cnt, last, done, slab_read, ubase, a, head);
+                if (last) flush_last<LY, false, GL, LY::ROWS>(lds, lane, cnt, done, slab_read, ubase, a, head);
                 else flush_groups<LY, false, GL, LY::ROWS>(lds, lane, cnt, done, slab_read, ubase, a, head);
                 const u32 nfl = last ? cnt : (cnt & ~(u32)(G - 1));
                 head += nfl;
