@@ -630,38 +630,45 @@ __device__ __forceinline__ void flush_groups(char *lds, int lane, u32 cnt, u32 d
     wave_sync_lds();
     const u32 T = U << GL;
     const u32 slab24 = (u32)slab_read;  // < 2^24 (the kernels' callers bound the sequence length)
-    constexpr int UR = 4;               // rows of 64 outputs per trip: their table and staged reads are issued together
-    for (u32 t0 = 0; t0 < T; t0 += 64 * UR) {
+    // A lane moves TWO consecutive tuples (same group, hence same owner): one table read, one 16-byte store of hashes and one
+    // 8-byte store of positions per pair.  UR rows of 128 outputs per trip: their table and staged reads are issued together.
+    constexpr int UR = 2;
+    for (u32 t0 = 0; t0 < T; t0 += 128 * UR) {
         u32 ent[UR];
 #pragma unroll
         for (int j = 0; j < UR; ++j) {
-            const u32 t = t0 + 64 * j + lane;
+            const u32 t = t0 + 128 * j + 2 * (u32)lane;
             ent[j] = s_tab[(t < T ? t : T - 1) >> GL];
         }
-        u64 hv[UR];
-        u32 pv[UR], di[UR];
+        u64 h0[UR], h1[UR];
+        u32 p0[UR], p1[UR], di[UR];
         bool ok[UR];
 #pragma unroll
         for (int j = 0; j < UR; ++j) {
-            const u32 t = t0 + 64 * j + lane;
+            const u32 t = t0 + 128 * j + 2 * (u32)lane;
             const u32 owner = ent[j] >> 26, sub = t & GM, doff = ent[j] & 0xfffffu;
-            u32 row = ((ent[j] >> 20) & 63u) + sub;
-            row = row < row - (u32)RING ? row : row - (u32)RING;  // ring wrap: row - RING wraps to a huge value when row < RING
-            const u32 sl = __umul24(row, (u32)LY::ROW) + owner;
+            u32 r0 = ((ent[j] >> 20) & 63u) + sub, r1 = r0 + 1;
+            r0 = r0 < r0 - (u32)RING ? r0 : r0 - (u32)RING;  // ring wrap: r - RING wraps to a huge value when r < RING
+            r1 = r1 < r1 - (u32)RING ? r1 : r1 - (u32)RING;
+            const u32 s0 = __umul24(r0, (u32)LY::ROW) + owner, s1 = __umul24(r1, (u32)LY::ROW) + owner;
             ok[j] = t < T && doff != 0xfffffu;
             di[j] = __umul24(owner, slab24) + doff + sub;
-            hv[j] = *reinterpret_cast<const u64 *>(lds + LY::SH + sl * 8);
-            pv[j] = *reinterpret_cast<const u16 *>(lds + LY::SP + sl * 2);
+            h0[j] = *reinterpret_cast<const u64 *>(lds + LY::SH + s0 * 8);
+            h1[j] = *reinterpret_cast<const u64 *>(lds + LY::SH + s1 * 8);
+            p0[j] = *reinterpret_cast<const u16 *>(lds + LY::SP + s0 * 2);
+            p1[j] = *reinterpret_cast<const u16 *>(lds + LY::SP + s1 * 2);
         }
 #pragma unroll
         for (int j = 0; j < UR; ++j) {
 #ifdef BSK_FLUSH_NOSTORE  // dev: the flush's work without its stores
-            asm volatile("" ::"v"(hv[j]), "v"(pv[j]), "v"(di[j]), "v"((u32)ok[j]));
+            asm volatile("" ::"v"(h0[j]), "v"(h1[j]), "v"(p0[j]), "v"(p1[j]), "v"(di[j]), "v"((u32)ok[j]));
 #else
             if (ok[j]) {
-                const u32 pp = STRAND16 ? (pv[j] & 0x7fffu) | ((pv[j] & 0x8000u) << 16) : pv[j];
-                __builtin_nontemporal_store(hv[j], &a.hash[ubase + di[j]]);  // write-once output: non-temporal, so that the tuples streaming out do not push the sequences' lines out of the L2
-                __builtin_nontemporal_store(pp, &a.pos[ubase + di[j]]);
+                const u32 q0 = STRAND16 ? (p0[j] & 0x7fffu) | ((p0[j] & 0x8000u) << 16) : p0[j];
+                const u32 q1 = STRAND16 ? (p1[j] & 0x7fffu) | ((p1[j] & 0x8000u) << 16) : p1[j];
+                // write-once output: non-temporal, so that the tuples streaming out do not push the sequences' lines out of the L2
+                nt_store_u64x2(a.hash + ubase + di[j], h0[j], h1[j]);
+                __builtin_nontemporal_store(((u64)q1 << 32) | q0, reinterpret_cast<u64 *>(a.pos + ubase + di[j]));
             }
 #endif
         }
