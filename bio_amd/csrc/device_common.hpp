@@ -96,18 +96,28 @@ __device__ __forceinline__ u32 wave_incl_scan_u32(u32 v, int lane) {
     v += BSK_DPP0(v, 0x143, 0xc);  // row_bcast:31 -> rows 2, 3
     return v;
 }
-__device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u64 t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
+__device__ __forceinline__ u64 wave_incl_scan_u64(u64 v, int lane) {  // the same ladder on two words with the carry between them
+    (void)lane;
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+#define BSK_SCAN64_STEP(ctrl, rmask)                      \
+    {                                                     \
+        const u32 dl = BSK_DPP0(lo, ctrl, rmask), dh = BSK_DPP0(hi, ctrl, rmask); \
+        const u32 nl = lo + dl;                           \
+        hi += dh + (nl < lo ? 1u : 0u);                   \
+        lo = nl;                                          \
     }
-    return v;
+    BSK_SCAN64_STEP(0x111, 0xf)
+    BSK_SCAN64_STEP(0x112, 0xf)
+    BSK_SCAN64_STEP(0x114, 0xf)
+    BSK_SCAN64_STEP(0x118, 0xf)
+    BSK_SCAN64_STEP(0x142, 0xa)
+    BSK_SCAN64_STEP(0x143, 0xc)
+#undef BSK_SCAN64_STEP
+    return ((u64)hi << 32) | lo;
 }
-__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
-#pragma unroll
-    for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {  // lane 63 of the scan, in every lane
+    const u64 s = wave_incl_scan_u64(v, 0);
+    return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(s >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)s, 63);
 }
 __device__ __forceinline__ u32 wave_max_u32(u32 v) {  // the same ladder with max (0 is the identity of an unsigned maximum), read from lane 63
     u32 t;
@@ -120,7 +130,9 @@ __device__ __forceinline__ u32 wave_max_u32(u32 v) {  // the same ladder with ma
     return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ u32 wave_bcast_u32(u32 v, int src) { return (u32)__builtin_amdgcn_readlane((int)v, src); }  // src is wave-uniform
-__device__ __forceinline__ u64 wave_bcast_u64(u64 v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ u64 wave_bcast_u64(u64 v, int src) {
+    return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), src) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, src);
+}
 
 // ---- work distribution: persistent waves pull units (64 reads) from a ticket ----
 // Tickets are handed out in program order of the atomic, so every unit with a
