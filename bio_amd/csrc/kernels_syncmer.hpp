@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves p
         const bool any_over = __builtin_amdgcn_ballot_w64(cnt > (u32)CAP) != 0;
         u64 base = (u64)unit * slab;
         if (!any_over) {
-            fast_copyout<LY, true, CAP, (W >= 10 ? 1 : 4)>(lds, lane, cnt, excl, T, base, a);
+            fast_copyout<LY, true, CAP, 4>(lds, lane, cnt, excl, T, base, a);
         } else {
             u64 ob = 0;
             if (lane == 0) ob = atomicAdd(a.total + 1, (u64)T);
