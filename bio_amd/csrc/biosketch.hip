@@ -1284,7 +1284,7 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
         case K_PROT_MIN: snprintf(b, sizeof b, "k_prot_minimizer"); break;
         case K_SYN_FAST: snprintf(b, sizeof b, "k_syncmer_fast<%d>", pl.fast_w); break;
         case K_PROT_MIN_FAST: snprintf(b, sizeof b, "k_prot_minimizer_fast<%d,%d,%s>", pl.fast_w, pl.fast_k, pl.fused_dna ? "true" : "false"); break;
-        case K_PROT_HASH_FAST: snprintf(b, sizeof b, "k_prot_hash_fast<%d%s>", pl.fast_k, pl.fused_dna ? ",true" : ""); break;
+        case K_PROT_HASH_FAST: snprintf(b, sizeof b, "k_prot_hash_fast<%d,%s>", pl.fast_k, pl.fused_dna ? "true" : "false"); break;
         case K_SIM_FAST:
             snprintf(b, sizeof b, "k_simhash_fast<%d,%d>", pl.fast_w, pl.fast_k == 1 ? BSK_SIM_SHORT_WORDS : pl.fast_k == 2 ? BSK_SIM_MID_WORDS : BSK_NT_FAST_WORDS);
             break;
