@@ -42,12 +42,13 @@ __device__ __forceinline__ void seq_span(const u64 *refs, const u64 *wfirst, con
 // they sort to the end of their segment
 __global__ void k_gather_values(const u64 *hash, const u64 *refs, const u64 *wfirst, const u64 *wcount, const u64 *dst, u64 n, u64 maxhash,
                                 u64 *out) {
-    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
-    for (u64 r = wave; r < n; r += nw) {
+    // a group of 16 lanes per sequence (short reads hold two dozen values: a whole wavefront per sequence left most lanes idle)
+    const u64 grp = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ng = ((u64)gridDim.x * blockDim.x) >> 4;
+    for (u64 r = grp; r < n; r += ng) {
         u64 f, c;
         seq_span(refs, wfirst, wcount, r, f, c);
         const u64 d = dst[r];
-        for (u64 t = threadIdx.x & 63; t < c; t += 64) {
+        for (u64 t = threadIdx.x & 15; t < c; t += 16) {
             const u64 h = hash[f + t];
             out[d + t] = h > maxhash ? ~0ULL : h;
         }
@@ -449,7 +450,7 @@ extern "C" int bsk_result_sets(bsk_ctx *ctx, const bsk_result *r, int scope, int
     }
     SCHK(pool(2, N * 8, (void **)&vin));  // (all temporaries are pooled: in a process that has already cycled ~100 GB of batches a
     SCHK(pool(5, N * 8, (void **)&vsorted));  //  hipMalloc / hipFree of these buffers cost 70-200 ms per call against 10-18 ms of kernels)
-    hipLaunchKernelGGL(k_gather_values, dim3(grid_of(ctx, n * 64, 256)), dim3(256), 0, st, r->hash, r->refs, r->wfirst, r->wcount, offs, n,
+    hipLaunchKernelGGL(k_gather_values, dim3(grid_of(ctx, n * 16, 256)), dim3(256), 0, st, r->hash, r->refs, r->wfirst, r->wcount, offs, n,
                        maxhash, vin);
     SCHK(hipGetLastError());
     // 2. sort inside every set
