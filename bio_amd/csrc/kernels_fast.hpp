@@ -364,27 +364,15 @@ struct FastMin {
         }
     }
 
-    template <bool UNI>
+    // One first block and ONE steady block variant (per-lane bound check, bounded staging store).  The uniform-wave and
+    // unguarded variants each saved an instruction or two per step but made the kernel 65 KB of code against a 64 KB
+    // instruction cache shared by two CUs: with the single variant (22 KB) the whole kernel runs 4 % faster.
     __device__ __forceinline__ void run(u32 nk_max) {
         begin();
         const u32 col8 = (u32)(lane & 31) * 8u;
         const bool up = lane < 32;
-        block<true, UNI, false>(0);
-        // slot value from which a block could overrun the lane's rows (PAIR: the whole column, counted from the lane's end)
-        const u32 guard_from = PAIR ? (u32)((PR - W) * LY::ROW * 8) + col8 : (u32)((CAP - W) * LY::ROW + lane) * 8u;
-        for (u32 i0 = W; i0 < nk_max; i0 += W) {
-            // a lane stages at most W tuples per block: the bounded store is only needed near the cap
-            const u32 filled = (PAIR && !up) ? slim + col8 - slot : slot;  // = (rows used * ROW) * 8 + col8
-            const bool guard = !DIRECT && __builtin_amdgcn_ballot_w64(filled > guard_from) != 0;
-            if (i0 + W > nk_max) {  // partial last block: per-lane bound check even when the wave is uniform
-                if (guard) block<false, false, true>(i0);
-                else block<false, false, false>(i0);
-            } else if (guard) {
-                block<false, UNI, true>(i0);
-            } else {
-                block<false, UNI, false>(i0);
-            }
-        }
+        block<true, false, false>(0);  // a lane stages at most W <= CAP tuples in its first block
+        for (u32 i0 = W; i0 < nk_max; i0 += W) block<false, false, !DIRECT>(i0);
         if (PAIR) cnt = ((up ? slot : slim + col8 - slot)) / (u32)(LY::ROW * 8);  // col8 < ROW*8: the quotient is the row count
         else cnt = (slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);
     }
@@ -523,7 +511,6 @@ __global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs 
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
         const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
         const u32 nk_max = wave_max_u32(nk);
-        const bool uni = __builtin_amdgcn_ballot_w64(nk != nk_max) == 0;
         u32 cnt = 0, tie = 0;
         if (nk_max) {
             FastMin<W, CAP, POS16, false, PAIR> fm;
@@ -533,8 +520,7 @@ __global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs 
             fm.k = a.k;
             fm.lane = lane;
             fm.nk = nk;
-            if (uni) fm.template run<true>(nk_max);
-            else fm.template run<false>(nk_max);
+            fm.run(nk_max);
             cnt = fm.cnt;
             tie = fm.tie;
         }
@@ -572,7 +558,7 @@ __global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs 
                 fm.ghash = a.hash;
                 fm.gpos = a.pos;
                 fm.gbase = base + excl;
-                fm.template run<false>(nk_max);
+                fm.run(nk_max);
             } else {
                 cnt = 0;  // result buffers too small: flagged, the host re-runs with a larger overflow region
                 if (lane == 0) atomicOr(&a.ticket[1], 1u);
@@ -785,7 +771,6 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
         const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
         const u32 nk_max = wave_max_u32(nk);
-        const bool uni = __builtin_amdgcn_ballot_w64(nk != nk_max) == 0;
         const u64 ubase = (u64)unit * 64 * slab_read;
         u32 done = 0, tie = 0;
         if (nk_max) {
@@ -822,14 +807,8 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
             int inround = 0;
             u32 head = 0;
             for (u32 i0 = 0; i0 < nk_max; i0 += W) {
-                if (i0 == 0) {
-                    if (uni) fm.template block<true, true, false>(0);
-                    else fm.template block<true, false, false>(0);
-                } else if (i0 + W > nk_max || !uni) {
-                    fm.template block<false, false, false>(i0);
-                } else {
-                    fm.template block<false, true, false>(i0);
-                }
+                if (i0 == 0) fm.template block<true, false, false>(0);  // one first, one steady variant: see FastMin::run
+                else fm.template block<false, false, false>(i0);
                 const bool last = i0 + W >= nk_max;
                 if (++inround == NB || last) {
                     inround = 0;

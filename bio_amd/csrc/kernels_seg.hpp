@@ -143,7 +143,6 @@ __global__ __launch_bounds__(64, 3) void k_minimizer_seg(KArgs a) {
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
         const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
         const u32 nk_max = wave_max_u32(nk);
-        const bool uni = __builtin_amdgcn_ballot_w64(nk != nk_max) == 0;
         const u64 ubase = (u64)unit * 64 * slab_read;
         u32 done = 0, tie = 0;
         bool over = false;  // wave-uniform: some lane outgrew its slab, or a pair of lanes its column
@@ -156,8 +155,7 @@ __global__ __launch_bounds__(64, 3) void k_minimizer_seg(KArgs a) {
             fm.lane = lane;
             fm.nk = nk;
             fm.begin();
-            if (uni) fm.template block<true, true, false>(0);
-            else fm.template block<true, false, false>(0);
+            fm.template block<true, false, false>(0);  // one first, one steady variant: see FastMin::run
             int inseg = 1;
             for (u32 i0 = W;; i0 += W) {
                 const bool fin = i0 >= nk_max;
@@ -175,8 +173,7 @@ __global__ __launch_bounds__(64, 3) void k_minimizer_seg(KArgs a) {
                     fm.slot = slot0;
                 }
                 if (fin) break;
-                if (i0 + W > nk_max || !uni) fm.template block<false, false, false>(i0);
-                else fm.template block<false, true, false>(i0);
+                fm.template block<false, false, false>(i0);
                 ++inseg;
             }
             tie = fm.tie;
@@ -203,7 +200,7 @@ __global__ __launch_bounds__(64, 3) void k_minimizer_seg(KArgs a) {
                 fd.ghash = a.hash;
                 fd.gpos = a.pos;
                 fd.gbase = first;
-                fd.template run<false>(nk_max);
+                fd.run(nk_max);
             } else {
                 done = 0;  // result buffers too small: flagged, the host re-runs with a larger overflow region
                 if (lane == 0) atomicOr(&a.ticket[1], 1u);
