@@ -213,9 +213,8 @@ struct FastMin {
         rh_ = d ^ x.w;
     }
 
-    // UNI: every lane of the wave has the same number of k-mers (no per-lane bound check)
     // GUARD: some lane may reach CAP staged tuples inside this block (store must be bounded)
-    template <bool FIRST, bool UNI, bool GUARD>
+    template <bool FIRST, bool GUARD>
     __device__ __forceinline__ void block(u32 i0) {
         const u32 t0 = i0 + (u32)k - 1;
         const u32 cinb = __builtin_amdgcn_alignbit(in_hi, in_lo, (t0 & 15) * 2);  // code of slot o at bits [2o, 2o+2)
@@ -269,7 +268,7 @@ struct FastMin {
                 HV m = P;
                 if (o != W - 1) m = selv(lt64(P.lo, P.hi, S[o + 1].lo, S[o + 1].hi), P, S[o + 1]);
                 lmask e = __builtin_amdgcn_ballot_w64(m.p != prev);
-                if (!UNI) e &= __builtin_amdgcn_ballot_w64(vi < nk);
+                e &= __builtin_amdgcn_ballot_w64(vi < nk);  // per-lane bound check (a wave-uniform variant without it did not pay for its code)
                 prev = m.p;
                 if (!DIRECT) {
                     // branch-free: every candidate is stored to the lane's next slot; the slot only advances when the
@@ -371,8 +370,8 @@ struct FastMin {
         begin();
         const u32 col8 = (u32)(lane & 31) * 8u;
         const bool up = lane < 32;
-        block<true, false, false>(0);  // a lane stages at most W <= CAP tuples in its first block
-        for (u32 i0 = W; i0 < nk_max; i0 += W) block<false, false, !DIRECT>(i0);
+        block<true, false>(0);  // a lane stages at most W <= CAP tuples in its first block
+        for (u32 i0 = W; i0 < nk_max; i0 += W) block<false, !DIRECT>(i0);
         if (PAIR) cnt = ((up ? slot : slim + col8 - slot)) / (u32)(LY::ROW * 8);  // col8 < ROW*8: the quotient is the row count
         else cnt = (slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);
     }
@@ -807,8 +806,8 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
             int inround = 0;
             u32 head = 0;
             for (u32 i0 = 0; i0 < nk_max; i0 += W) {
-                if (i0 == 0) fm.template block<true, false, false>(0);  // one first, one steady variant: see FastMin::run
-                else fm.template block<false, false, false>(i0);
+                if (i0 == 0) fm.template block<true, false>(0);  // one first, one steady variant: see FastMin::run
+                else fm.template block<false, false>(i0);
                 const bool last = i0 + W >= nk_max;
                 if (++inround == NB || last) {
                     inround = 0;

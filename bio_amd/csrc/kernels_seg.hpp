@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64, 3) void k_minimizer_seg(KArgs a) {
             fm.lane = lane;
             fm.nk = nk;
             fm.begin();
-            fm.template block<true, false, false>(0);  // one first, one steady variant: see FastMin::run
+            fm.template block<true, false>(0);  // one first, one steady variant: see FastMin::run
             int inseg = 1;
             for (u32 i0 = W;; i0 += W) {
                 const bool fin = i0 >= nk_max;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64, 3) void k_minimizer_seg(KArgs a) {
                     fm.slot = slot0;
                 }
                 if (fin) break;
-                fm.template block<false, false, false>(i0);
+                fm.template block<false, false>(i0);
                 ++inseg;
             }
             tie = fm.tie;
