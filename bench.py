@@ -141,7 +141,9 @@ def end_to_end(kind: str, p, batch, read_len: int, n_streams: int = 3):
     out["from_memory"] = {"value": round(st["bases"] / st["seconds"] / 1e9, 3), "unit": "Gresidues/s" if alpha else "Gbases/s",
                           "reads": st["records"], "seconds": round(st["seconds"], 4),
                           "stage_seconds_summed_over_streams": {k: round(st[k], 4) for k in ("reader_seconds", "reader_wait_seconds", "h2d_pack_seconds", "kernel_seconds", "fetch_seconds")},
-                          "bound": "PCIe: %.0f B/read in + %.0f B/read of tuples out" % (read_len + 8, (12.0 if kind not in STREAM else 8.0) * st["tuples"] / max(st["records"], 1) + 9)}
+                          "bound": "the stream workers' host side (copy into pinned memory, the D2H wait, one pass over the fetched tuples), not the link: "
+                                   "%.0f B/read in + %.0f B/read of tuples out is well under the 48 + 48 GB/s the box's PCIe moves both ways at once "
+                                   "(scripts/ubench/pcie.py; DESIGN.md 4)" % (read_len + 8, (12.0 if kind not in STREAM else 8.0) * st["tuples"] / max(st["records"], 1) + 9)}
     # the same reads as files: fixed-width names, constant qualities
     rec = 12 + read_len + (3 + read_len if not alpha else 0)
     import shutil

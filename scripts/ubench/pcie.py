@@ -1,0 +1,23 @@
+"""dev helper: what the box's PCIe link gives pinned hipMemcpyAsync, one direction and both at once (the end-to-end pipeline's ceiling)."""
+import time, torch
+n = 1 << 28  # 256 MiB
+h_in = torch.empty(n, dtype=torch.uint8).pin_memory()
+h_out = torch.empty(n, dtype=torch.uint8).pin_memory()
+d_in = torch.empty(n, dtype=torch.uint8, device="cuda")
+d_out = torch.empty(n, dtype=torch.uint8, device="cuda")
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+def run(h2d, d2h, reps=8):
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(reps):
+        if h2d:
+            with torch.cuda.stream(s1):
+                d_in.copy_(h_in, non_blocking=True)
+        if d2h:
+            with torch.cuda.stream(s2):
+                h_out.copy_(d_out, non_blocking=True)
+    torch.cuda.synchronize()
+    dt = time.time() - t
+    return reps * n / dt / 1e9
+for _ in range(2):
+    print("H2D alone %.1f GB/s   D2H alone %.1f GB/s   both at once %.1f + %.1f GB/s" % (run(1, 0), run(0, 1), run(1, 1), run(1, 1)))
