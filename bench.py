@@ -137,8 +137,14 @@ def end_to_end(kind: str, p, batch, read_len: int, n_streams: int = 3):
     alpha = 1 if kind in PROTEIN else 0
     out = {"n_streams": n_streams, "chunk_records": 1 << 18,
            "what": "host ASCII -> pinned chunks -> H2D + 2-bit pack -> kernel -> every tuple back in pinned host memory; stages of different chunks overlap"}
+    S.Engine.pipeline_trim()
+    st0 = S.Engine.pipeline_memory(data, offs, p, n_streams=n_streams, chunk_records=1 << 18, repeat=2, fetch=True, alphabet=alpha)
+    # the second call of the process: the pinned buffers come from the library's pool (a long-lived host pins once, not per file)
     st = S.Engine.pipeline_memory(data, offs, p, n_streams=n_streams, chunk_records=1 << 18, repeat=2, fetch=True, alphabet=alpha)
-    out["from_memory"] = {"value": round(st["bases"] / st["seconds"] / 1e9, 3), "unit": "Gresidues/s" if alpha else "Gbases/s",
+    out["pinned_buffers"] = ("pooled by the library between pipeline calls; from_memory.first_call is the process's first run (it pins "
+                             "%.2f s summed over its threads), every figure below ran with the pool warm" % st0["pin_seconds"])
+    out["from_memory"] = {"first_call": {"value": round(st0["bases"] / st0["seconds"] / 1e9, 3), "seconds": round(st0["seconds"], 4), "pin_seconds": round(st0["pin_seconds"], 4)},
+                          "value": round(st["bases"] / st["seconds"] / 1e9, 3), "unit": "Gresidues/s" if alpha else "Gbases/s",
                           "reads": st["records"], "seconds": round(st["seconds"], 4),
                           "stage_seconds_summed_over_streams": {k: round(st[k], 4) for k in ("reader_seconds", "reader_wait_seconds", "h2d_pack_seconds", "kernel_seconds", "fetch_seconds")},
                           "bound": "the stream workers' host side (copy into pinned memory, the D2H wait, one pass over the fetched tuples), not the link: "
@@ -210,6 +216,7 @@ def end_to_end(kind: str, p, batch, read_len: int, n_streams: int = 3):
         out["from_8_gzip_files"] = {"value": round(st["bases"] / st["seconds"] / 1e9, 3), "unit": "Gresidues/s" if alpha else "Gbases/s",
                                     "reads": st["records"], "seconds": round(st["seconds"], 4), "readers": 8,
                                     "reader": "one serial record reader (zlib stream) per file, eight files at once"}
+    S.Engine.pipeline_trim()
     return out
 
 

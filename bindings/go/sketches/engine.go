@@ -327,3 +327,6 @@ func SketchFiles(device int, paths []string, p C.bsk_params, streams, readers in
 	}
 	return out, nil
 }
+
+// PipelineTrim returns the pinned host buffers SketchFiles keeps pooled between calls (bsk_pipeline_trim).
+func PipelineTrim() { C.bsk_pipeline_trim() }

@@ -28,25 +28,79 @@ inline double secs(clk::time_point a, clk::time_point b) { return std::chrono::d
 
 std::atomic<uint64_t> g_pin_ns{0};  // time spent pinning / unpinning host memory (all threads), for the statistics
 
+// Pinned buffers outlive a pipeline call: pinning costs ~0.35 ms per MB (0.2 s for the buffers of one three-stream run), so a
+// finished run parks its buffers in a process-wide pool (per device, best fit, bounded) and the next run -- the next file of a
+// long-lived host -- takes them from there.  bsk_pipeline_trim() gives the memory back.
+struct PinPool {
+    struct Blk {
+        void *p;
+        size_t cap;
+        int dev;
+    };
+    std::mutex m;
+    std::vector<Blk> blocks;
+    size_t bytes = 0;
+    static constexpr size_t LIMIT = (size_t)8 << 30;
+    void *take(int dev, size_t want, size_t *cap) {
+        std::lock_guard<std::mutex> l(m);
+        int best = -1;
+        for (size_t i = 0; i < blocks.size(); ++i)
+            if (blocks[i].dev == dev && blocks[i].cap >= want && (best < 0 || blocks[i].cap < blocks[(size_t)best].cap)) best = (int)i;
+        if (best < 0 || blocks[(size_t)best].cap > 2 * want + (1u << 20)) return nullptr;  // do not burn a large block on a small request
+        Blk b = blocks[(size_t)best];
+        blocks.erase(blocks.begin() + best);
+        bytes -= b.cap;
+        *cap = b.cap;
+        return b.p;
+    }
+    bool give(int dev, void *p, size_t cap) {
+        std::lock_guard<std::mutex> l(m);
+        if (bytes + cap > LIMIT) return false;
+        blocks.push_back({p, cap, dev});
+        bytes += cap;
+        return true;
+    }
+    void trim() {
+        std::vector<Blk> old;
+        {
+            std::lock_guard<std::mutex> l(m);
+            old.swap(blocks);
+            bytes = 0;
+        }
+        for (auto &b : old) (void)hipHostFree(b.p);
+    }
+};
+PinPool &pin_pool() {
+    static PinPool *pool = new PinPool;  // never destroyed: the HIP runtime may be gone by the time static destructors run
+    return *pool;
+}
+
 struct PinBuf {  // grow-only pinned host buffer
     void *p = nullptr;
     size_t cap = 0;
+    int dev = 0;
+    void release() {
+        if (p && !pin_pool().give(dev, p, cap)) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
     bool ensure(size_t bytes) {
         if (cap >= bytes) return true;
         const auto t0 = clk::now();
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
+        release();
+        (void)hipGetDevice(&dev);
         const size_t want = bytes + bytes / 4 + 4096;
-        const bool ok = hipHostMalloc(&p, want) == hipSuccess;
+        bool ok = true;
+        p = pin_pool().take(dev, want, &cap);
+        if (!p) {
+            ok = hipHostMalloc(&p, want) == hipSuccess;
+            cap = ok ? want : 0;
+            if (!ok) p = nullptr;
+        }
         g_pin_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count();
-        if (!ok) return false;
-        cap = want;
-        return true;
+        return ok;
     }
-    ~PinBuf() {
-        if (p) (void)hipHostFree(p);
-    }
+    ~PinBuf() { release(); }
 };
 
 struct Chunk {
@@ -524,3 +578,5 @@ extern "C" int bsk_pipeline_fastx_files(int device, const char *const *paths, in
     }
     return rc;
 }
+
+extern "C" void bsk_pipeline_trim(void) { pin_pool().trim(); }

@@ -258,6 +258,11 @@ class Engine:
         return st.asdict()
 
     @staticmethod
+    def pipeline_trim() -> None:
+        """Return the pinned host buffers the pipelines pool between calls (bsk_pipeline_trim)."""
+        L.load().bsk_pipeline_trim()
+
+    @staticmethod
     def pipeline_fastx_files(paths, params, n_streams: int = 3, n_readers: int = 0, chunk_records: int = 1 << 18, fetch: bool = True,
                              alphabet: int = -1, device: int = 0):
         """Several FASTA/FASTQ files (plain or gzip) through one pipeline, n_readers of them read at once."""

@@ -295,7 +295,7 @@ typedef struct bsk_pipeline_stats {
     int32_t n_streams;
     int32_t reader_threads;      /* bsk_pipeline_fastx on a plain file: parser threads of the block-parallel reader (0: serial reader) */
     uint64_t reparsed_pieces;    /* ... and the pieces whose guessed record start was wrong (parsed again, serially) */
-    double pin_seconds;          /* summed over all threads: hipHostMalloc / hipHostFree of the chunk and result buffers (start-up cost) */
+    double pin_seconds;          /* summed over all threads: getting the pinned chunk and result buffers (hipHostMalloc, or the pool of earlier runs) */
 } bsk_pipeline_stats;
 int bsk_pipeline_fastx(int device, const char *path, int alphabet /* -1: guess from the first record */, const bsk_params *p, int n_streams,
                        uint64_t chunk_records, int fetch_tuples, bsk_pipeline_stats *stats);
@@ -306,6 +306,10 @@ int bsk_pipeline_memory(int device, const uint8_t *bytes, const uint64_t *offset
  * A file is closed as soon as its last chunk is on the device.  The statistics are those of the whole job. */
 int bsk_pipeline_fastx_files(int device, const char *const *paths, int n_paths, int alphabet, const bsk_params *p, int n_streams, int n_readers,
                              uint64_t chunk_records, int fetch_tuples, bsk_pipeline_stats *stats);
+
+/* The pipelines keep their pinned host buffers in a process-wide pool between calls (pinning is the start-up cost of a run:
+ * pin_seconds); this returns the pooled memory to the system.  Safe at any time; buffers of a running pipeline are not affected. */
+void bsk_pipeline_trim(void);
 
 /* ---- multi-GPU: the one collective of the path ----------------------------
  * Reads shard by record; no tuple ever crosses GPUs.  What a job gathers at its end is a handful of u64 counters per GPU

@@ -174,3 +174,20 @@ def test_pipeline_over_several_files(engine, tmp_path):
         assert (st["records"], st["tuples"], st["checksum"]) == (want["records"], want["tuples"], want["checksum"]), (readers, streams, chunk)
     with pytest.raises(S.DeviceError):
         S.Engine.pipeline_fastx_files(paths + [str(tmp_path / "missing.fq")], p)
+
+
+def test_pinned_buffers_are_pooled_between_runs(engine):
+    """A finished run parks its pinned buffers in the process-wide pool: the next run of the same shape pins (almost) nothing,
+    and bsk_pipeline_trim() empties the pool again.  Results do not depend on where the buffers came from."""
+    n = 400_000
+    data, offs = make_reads(n, 11, with_n=False)
+    p = engine.params(L.MINIMIZER, k=21, w=11)
+    S.Engine.pipeline_trim()
+    first = S.Engine.pipeline_memory(data, offs, p, n_streams=2, chunk_records=100_000, fetch=True)
+    again = S.Engine.pipeline_memory(data, offs, p, n_streams=2, chunk_records=100_000, fetch=True)
+    S.Engine.pipeline_trim()
+    fresh = S.Engine.pipeline_memory(data, offs, p, n_streams=2, chunk_records=100_000, fetch=True)
+    S.Engine.pipeline_trim()
+    assert first["checksum"] == again["checksum"] == fresh["checksum"] and first["tuples"] == again["tuples"] == fresh["tuples"]
+    assert again["pin_seconds"] < 0.25 * first["pin_seconds"], (first["pin_seconds"], again["pin_seconds"])
+    assert fresh["pin_seconds"] > 2 * again["pin_seconds"], (fresh["pin_seconds"], again["pin_seconds"])
