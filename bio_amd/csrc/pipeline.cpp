@@ -404,7 +404,8 @@ int run_pipeline(int device, SourceSet &set, int n_producers, const bsk_params *
                     if (!o_off.ensure((nr + 1) * 8) || !o_st.ensure(nr + 1) || !o_hash.ensure((nt + 1) * 8) || (hp && !o_pos.ensure((nt + 1) * 4))) rc = BSK_ERR_NOMEM;
                     if (rc == BSK_OK)
                         rc = bsk_result_fetch(ctx, res, 0, nr, (uint64_t *)o_off.p, (uint8_t *)o_st.p, (uint64_t *)o_hash.p, hp ? (uint32_t *)o_pos.p : nullptr, nt + 1);
-                    if (rc == BSK_OK) {  // the caller's consumer would start here; the statistics keep an order-independent digest
+                    static const bool nodigest = getenv("BSK_PIPE_NO_DIGEST") != nullptr;  // dev: the run without the consumer stand-in (checksum stays 0)
+                    if (rc == BSK_OK && !nodigest) {  // the caller's consumer would start here; the statistics keep an order-independent digest
                         const uint64_t *h = (const uint64_t *)o_hash.p, *oo = (const uint64_t *)o_off.p;
                         const uint32_t *ps = (const uint32_t *)o_pos.p;
                         uint64_t sum = 0;

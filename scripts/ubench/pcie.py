@@ -21,3 +21,23 @@ def run(h2d, d2h, reps=8):
     return reps * n / dt / 1e9
 for _ in range(2):
     print("H2D alone %.1f GB/s   D2H alone %.1f GB/s   both at once %.1f + %.1f GB/s" % (run(1, 0), run(0, 1), run(1, 1), run(1, 1)))
+# the pipeline's copy sizes: 39 MB up, 46 + 23 MB down per chunk, several streams at once
+def sized(nst, reps=40):
+    up = [torch.empty(39 << 20, dtype=torch.uint8).pin_memory() for _ in range(nst)]
+    dn = [torch.empty(69 << 20, dtype=torch.uint8).pin_memory() for _ in range(nst)]
+    dup = [torch.empty(39 << 20, dtype=torch.uint8, device="cuda") for _ in range(nst)]
+    ddn = [torch.empty(69 << 20, dtype=torch.uint8, device="cuda") for _ in range(nst)]
+    ss = [torch.cuda.Stream() for _ in range(nst)]
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(reps):
+        for i in range(nst):
+            with torch.cuda.stream(ss[i]):
+                dup[i].copy_(up[i], non_blocking=True)
+                dn[i][: 46 << 20].copy_(ddn[i][: 46 << 20], non_blocking=True)
+                dn[i][46 << 20:].copy_(ddn[i][46 << 20:], non_blocking=True)
+    torch.cuda.synchronize()
+    dt = time.time() - t
+    print("%d streams, 39 MB up + 46 + 23 MB down per turn: %.1f GB/s up + %.1f GB/s down" % (nst, reps * nst * 39 * 2**20 / dt / 1e9, reps * nst * 69 * 2**20 / dt / 1e9))
+for nst in (1, 3, 5):
+    sized(nst)
