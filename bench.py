@@ -148,8 +148,8 @@ def end_to_end(kind: str, p, batch, read_len: int, n_streams: int = 5):
                           "reads": st["records"], "seconds": round(st["seconds"], 4),
                           "stage_seconds_summed_over_streams": {k: round(st[k], 4) for k in ("reader_seconds", "reader_wait_seconds", "h2d_pack_seconds", "kernel_seconds", "fetch_seconds")},
                           "bound": "on 3 streams the workers' host side (copy into pinned memory, the D2H wait, one pass over the fetched tuples); from 5 streams "
-                                   "on the copy pattern itself: %.0f B/read in + %.0f B/read of tuples out as 39 MB up / 46 + 23 MB down per stream moves "
-                                   "17 + 31 GB/s (3 streams) to 23 + 41 GB/s (5) on this link, against 48 + 48 with one large-copy stream per direction "
+                                   "on the copy pattern itself: %.0f B/read in + %.0f B/read of tuples out as 39 MB up / 46 + 23 MB down per stream moved "
+                                   "17 + 31 to 24 + 43 GB/s on this link in the micro-benchmark, against 48 + 48 with one large-copy stream per direction "
                                    "(scripts/ubench/pcie.py; DESIGN.md 4)" % (read_len + 8, (12.0 if kind not in STREAM else 8.0) * st["tuples"] / max(st["records"], 1) + 9)}
     # the same reads as files: fixed-width names, constant qualities
     rec = 12 + read_len + (3 + read_len if not alpha else 0)

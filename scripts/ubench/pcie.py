@@ -41,3 +41,25 @@ def sized(nst, reps=40):
     print("%d streams, 39 MB up + 46 + 23 MB down per turn: %.1f GB/s up + %.1f GB/s down" % (nst, reps * nst * 39 * 2**20 / dt / 1e9, reps * nst * 69 * 2**20 / dt / 1e9))
 for nst in (1, 3, 5):
     sized(nst)
+# the same sizes with the two directions on separate streams (n up-streams + n down-streams)
+def sized_split(nst, reps=40):
+    up = [torch.empty(39 << 20, dtype=torch.uint8).pin_memory() for _ in range(nst)]
+    dn = [torch.empty(69 << 20, dtype=torch.uint8).pin_memory() for _ in range(nst)]
+    dup = [torch.empty(39 << 20, dtype=torch.uint8, device="cuda") for _ in range(nst)]
+    ddn = [torch.empty(69 << 20, dtype=torch.uint8, device="cuda") for _ in range(nst)]
+    sa = [torch.cuda.Stream() for _ in range(nst)]
+    sb = [torch.cuda.Stream() for _ in range(nst)]
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(reps):
+        for i in range(nst):
+            with torch.cuda.stream(sa[i]):
+                dup[i].copy_(up[i], non_blocking=True)
+            with torch.cuda.stream(sb[i]):
+                dn[i][: 46 << 20].copy_(ddn[i][: 46 << 20], non_blocking=True)
+                dn[i][46 << 20:].copy_(ddn[i][46 << 20:], non_blocking=True)
+    torch.cuda.synchronize()
+    dt = time.time() - t
+    print("%d + %d streams, directions apart: %.1f GB/s up + %.1f GB/s down" % (nst, nst, reps * nst * 39 * 2**20 / dt / 1e9, reps * nst * 69 * 2**20 / dt / 1e9))
+for nst in (1, 3, 5):
+    sized_split(nst)
