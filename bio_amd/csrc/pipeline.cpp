@@ -79,6 +79,9 @@ struct PinBuf {  // grow-only pinned host buffer
     void *p = nullptr;
     size_t cap = 0;
     int dev = 0;
+    PinBuf() = default;
+    PinBuf(const PinBuf &) = delete;  // a copy would hand the same block to the pool twice
+    PinBuf &operator=(const PinBuf &) = delete;
     void release() {
         if (p && !pin_pool().give(dev, p, cap)) (void)hipHostFree(p);
         p = nullptr;
