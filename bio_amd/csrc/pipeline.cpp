@@ -412,8 +412,13 @@ int run_pipeline(int device, SourceSet &set, int n_producers, const bsk_params *
                         const uint64_t *h = (const uint64_t *)o_hash.p, *oo = (const uint64_t *)o_off.p;
                         const uint32_t *ps = (const uint32_t *)o_pos.p;
                         uint64_t sum = 0;
-                        for (uint64_t r = 0; r < nr; ++r)
-                            for (uint64_t j = oo[r]; j < oo[r + 1]; ++j) sum += h[j] * (2 * (uint64_t)(hp ? (ps[j] & BSK_POS_MASK) : j - oo[r]) + 1);
+                        if (hp) {  // explicit positions: one flat pass (the term does not depend on the read)
+                            const uint64_t T = oo[nr];
+                            for (uint64_t j = 0; j < T; ++j) sum += h[j] * (2 * (uint64_t)(ps[j] & BSK_POS_MASK) + 1);
+                        } else {
+                            for (uint64_t r = 0; r < nr; ++r)
+                                for (uint64_t j = oo[r]; j < oo[r + 1]; ++j) sum += h[j] * (2 * (j - oo[r]) + 1);
+                        }
                         loc.checksum += sum;
                     }
                 } else if (rc == BSK_OK) {
