@@ -92,8 +92,12 @@ __device__ __forceinline__ void suffix_min_pass(HV (&S)[W], lmask &tm) {
     for (int q = W - 2; q >= 0; --q) {
         const lmask lt = lt64(S[q + 1].lo, S[q + 1].hi, S[q].lo, S[q].hi);
         if (FIRST) {
-            dup = eq64(S[q + 1].lo, S[q + 1].hi, S[q].lo, S[q].hi) | (lt & dup);  // equal: twice; S[q] smaller: unique so far
-            tm |= dup;
+            // dup = eq | (lt & dup)  (equal: twice; S[q] smaller: unique so far);  tm |= dup.  One asm block per element, like
+            // or_eq64: otherwise all W - 1 equality masks are computed first and live in spilled SGPR pairs (110 spills at w = 32)
+            lmask t;
+            asm("v_cmp_eq_u64_e64 %2, %3, %4\n\ts_and_b64 %0, %5, %0\n\ts_or_b64 %0, %2, %0\n\ts_or_b64 %1, %1, %0"
+                : "+s"(dup), "+s"(tm), "=&s"(t)
+                : "v"(((u64)S[q + 1].hi << 32) | S[q + 1].lo), "v"(((u64)S[q].hi << 32) | S[q].lo), "s"(lt));
         }
         S[q] = selv(lt, S[q + 1], S[q]);
     }
