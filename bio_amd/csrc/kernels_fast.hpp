@@ -61,7 +61,7 @@ __device__ __forceinline__ u32 sel01(lmask m) {  // m ? 1 : 0 (both operands inl
 // first-window tie test first and spills their SGPR pairs to VGPR lanes (v_writelane + s_nop + v_readlane for every pair).
 __device__ __forceinline__ void or_eq64(lmask &tm, u64 a, u64 b) {
     lmask t;
-    asm("v_cmp_eq_u64_e64 %1, %2, %3\n\ts_or_b64 %0, %0, %1" : "+s"(tm), "=&s"(t) : "v"(a), "v"(b));
+    asm("v_cmp_eq_u64_e64 %1, %2, %3\n\ts_or_b64 %0, %0, %1" : "+s"(tm), "=&s"(t) : "v"(a), "v"(b) : "scc");  // s_or writes SCC
 }
 
 __device__ __forceinline__ lmask eq64(u32 alo, u32 ahi, u32 blo, u32 bhi) {
@@ -97,7 +97,8 @@ __device__ __forceinline__ void suffix_min_pass(HV (&S)[W], lmask &tm) {
             lmask t;
             asm("v_cmp_eq_u64_e64 %2, %3, %4\n\ts_and_b64 %0, %5, %0\n\ts_or_b64 %0, %2, %0\n\ts_or_b64 %1, %1, %0"
                 : "+s"(dup), "+s"(tm), "=&s"(t)
-                : "v"(((u64)S[q + 1].hi << 32) | S[q + 1].lo), "v"(((u64)S[q].hi << 32) | S[q].lo), "s"(lt));
+                : "v"(((u64)S[q + 1].hi << 32) | S[q + 1].lo), "v"(((u64)S[q].hi << 32) | S[q].lo), "s"(lt)
+                : "scc");  // s_and / s_or write SCC
         }
         S[q] = selv(lt, S[q + 1], S[q]);
     }
@@ -181,6 +182,7 @@ struct FastMin {
     u32 send;                          // RING: slot offset one row past the lane's last row
     u32 in_lo, in_hi, out_lo, out_hi;  // packed words of the current block
     u32 in_h2, out_h2;                 // W > 16: a block spans up to three words
+    u32 nku;                           // run(): the wave's largest window count (wave-uniform)
     u32x4 pw;                          // run(): the read's first four words, loaded by the caller (one unit ahead)
 
     __device__ __forceinline__ u32 first_word(u32 i) const {  // i is wave-uniform
@@ -253,6 +255,11 @@ struct FastMin {
         const u32 spare = PAIR ? sspare : (u32)(CAP * LY::ROW + lane) * 8u;
 #pragma unroll
         for (int o = 0; o < W; ++o) {
+            if (XC < W && !FIRST && o && o % XC == 0) {
+                // wide windows: the wave's last block ends at the chunk boundary past its last window (a 150-base read has 130
+                // windows: five blocks of 32 would run 160 steps).  No block follows, so the suffix pass goes too.
+                if (i0 + (u32)o >= nku) return;
+            }
             if (XC < W && o && o % XC == 0 && o + XC < W) {
                 __builtin_amdgcn_sched_barrier(0);  // keep the next chunk's reads here (hoisted, they are all live at once again)
                 fetch(o + XC);
@@ -312,6 +319,7 @@ struct FastMin {
         fl = fh_ = rl = rh_ = 0;
         prev = 0xffffffffu;
         tie = 0;
+        nku = 0xffffffffu;  // callers that drive block() themselves never leave a block early
         slot = (u32)lane * 8u;
         const u32 col8 = (u32)(lane & 31) * 8u;
         const bool up = lane < 32;
@@ -374,6 +382,7 @@ struct FastMin {
         begin();
         const u32 col8 = (u32)(lane & 31) * 8u;
         const bool up = lane < 32;
+        nku = nk_max;
         block<true, false>(0);  // a lane stages at most W <= CAP tuples in its first block
         for (u32 i0 = W; i0 < nk_max; i0 += W) block<false, !DIRECT>(i0);
         if (PAIR) cnt = ((up ? slot : slim + col8 - slot)) / (u32)(LY::ROW * 8);  // col8 < ROW*8: the quotient is the row count
@@ -787,6 +796,7 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
             fm.fl = fm.fh_ = fm.rl = fm.rh_ = 0;
             fm.prev = 0xffffffffu;
             fm.tie = 0;
+            fm.nku = 0xffffffffu;
             fm.slot = (u32)lane * 8u;
             for (int t0 = 0; t0 < a.k - 1; t0 += 16) {  // warm-up: bases 0..k-2 enter, nothing leaves
                 const u32 word = fm.w[t0 >> 4];
