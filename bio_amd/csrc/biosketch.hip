@@ -257,7 +257,7 @@ extern "C" int bsk_ctx_create(int device, bsk_ctx **out) {
     }
     ctx->cus = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&ctx->d_ticket, 4 * sizeof(u32)) != hipSuccess || hipMalloc(&ctx->d_total, 8 * sizeof(u64)) != hipSuccess ||
+        hipMalloc(&ctx->d_ticket, 8 * sizeof(u32)) != hipSuccess || hipMalloc(&ctx->d_total, 8 * sizeof(u64)) != hipSuccess ||
         hipHostMalloc(&ctx->h_pinned, 8 * sizeof(u64)) != hipSuccess) {
         bsk_ctx_destroy(ctx);
         return BSK_ERR_DEVICE;
@@ -323,7 +323,7 @@ extern "C" void bsk_batch_destroy(bsk_batch *b) {
     delete b;
 }
 
-static u64 pad_words(u32 maxlen) { return (u64)maxlen / 16 + 8; }
+static u64 pad_words(u32 maxlen) { return (u64)maxlen / 16 + 12; }  // DnaResidues::issue4 reaches first_word + 3*floor((nk_max-1)/16) + 10 words (one past maxlen/16 + 8 in the worst case)
 static u32 env_u32(const char *name, u32 dflt) {
     const char *v = getenv(name);
     return v && *v ? (u32)strtoul(v, nullptr, 10) : dflt;
@@ -888,7 +888,7 @@ static int blocks_per_cu(K kernel) {
 
 // Which kernel runs a (batch, params) pair, on how many workgroups, and how the tuple arrays are organised.
 enum Which { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST, K_NT_FAST, K_SYN_P, K_SYN_A, K_KMER_P, K_KMER_A, K_SIM_P, K_SIM_A,
-             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST, K_MIN_DENSE, K_MIN_SEG, K_MIN_WPR };
+             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST, K_MIN_DENSE, K_MIN_SEG, K_MIN_WPR, K_MIN_PK };
 struct Plan {
     Which which = K_MIN_GEN_P;
     int grid = 1;
@@ -919,7 +919,7 @@ static bool slab_budget_ok(const bsk_batch *b, u64 slab_read) {
 #define BSK_REPLAN_UNFUSED (-1000)  // internal: the fused DNA -> protein plan gave up, run the two-step path
 
 static bool which_is_fast(Which w) {
-    return w == K_MIN_FAST || w == K_NT_FAST || w == K_SYN_FAST || w == K_SIM_FAST || w == K_MIN_DENSE || w == K_MIN_SEG || w == K_MIN_WPR;
+    return w == K_MIN_FAST || w == K_NT_FAST || w == K_SYN_FAST || w == K_SIM_FAST || w == K_MIN_DENSE || w == K_MIN_SEG || w == K_MIN_WPR || w == K_MIN_PK;
 }
 
 static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan &pl, bool use_ascii);
@@ -993,6 +993,13 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.slab_unit = 64 * pl.slab_read;
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
             per_cu = dense_minimizer_blocks_per_cu(p->w);
+        } else if (!use_ascii && pk_minimizer_supported(p->w) && b->maxlen < 32768u && !getenv("BSK_FORCE_GENERIC") && !getenv("BSK_NO_PK")) {
+            pl.which = K_MIN_PK;  // w <= 16: packed 32-bit window machine (kernels_pk.hpp)
+            pl.fast_w = p->w;
+            pl.slab = true;
+            pl.slab_unit = (u64)64 * BSK_FAST_CAP;
+            pl.slab_total = (u64)pl.nunits * pl.slab_unit;
+            per_cu = pk_minimizer_blocks_per_cu(p->w);
         } else if (!use_ascii && fast_minimizer_supported(p->w) && b->maxlen < 32768u && !getenv("BSK_FORCE_GENERIC")) {
             pl.which = K_MIN_FAST;
             pl.fast_w = p->w;
@@ -1270,6 +1277,7 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
         case K_NT_P: snprintf(b, sizeof b, "k_nthash_stream<0>"); break;
         case K_NT_A: snprintf(b, sizeof b, "k_nthash_stream<1>"); break;
         case K_MIN_FAST: snprintf(b, sizeof b, "k_minimizer_fast<%d,%d,true>", pl.fast_w, BSK_FAST_CAP); break;
+        case K_MIN_PK: snprintf(b, sizeof b, "k_minimizer_pk<%d>", pl.fast_w); break;
         case K_MIN_DENSE: snprintf(b, sizeof b, "k_minimizer_dense<%d>", pl.fast_w); break;
         case K_MIN_SEG: snprintf(b, sizeof b, "k_minimizer_seg<%d>", pl.fast_w); break;
         case K_MIN_WPR: snprintf(b, sizeof b, "k_minimizer_wpr<%d>", pl.fast_w); break;
@@ -1331,12 +1339,13 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     a.ticket = ctx->d_ticket;
     a.total = ctx->d_total;
     a.ring_w = pl.ring_w;
-    int rc = ensure_scratch(ctx, std::max<u32>(pl.slab ? 1 : pl.nunits, pl.mixed ? pl.side_nunits : 0), pl.ring_entries);
+    int rc = ensure_scratch(ctx, std::max<u32>(pl.which == K_MIN_PK ? 2 * pl.nunits : pl.slab ? 1 : pl.nunits, pl.mixed ? pl.side_nunits : 0), pl.ring_entries);
     if (rc != BSK_OK) return rc;
     a.lookback = ctx->d_lookback;
+    a.fixlist = ctx->d_lookback;  // K_MIN_PK (a slab kernel: no look-back) keeps its list of unfinished units there
     a.ring_h = ctx->d_ring_h;
     a.ring_p = ctx->d_ring_p;
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket, 0, 4 * sizeof(u32), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket, 0, 8 * sizeof(u32), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, 4 * sizeof(u64), ctx->stream));
     if (!pl.slab) HIPCHK(ctx, hipMemsetAsync(ctx->d_lookback, 0, (size_t)pl.nunits * sizeof(u64), ctx->stream));
     if (ev0) HIPCHK(ctx, hipEventRecord(ev0, ctx->stream));
@@ -1346,6 +1355,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_NT_P: hipLaunchKernelGGL(k_nthash_stream<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_NT_A: hipLaunchKernelGGL(k_nthash_stream<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_MIN_FAST: fast_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
+        case K_MIN_PK: pk_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_MIN_DENSE: dense_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_MIN_SEG: seg_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_MIN_WPR: wpr_minimizer_launch(pl.grid, ctx->stream, a); break;

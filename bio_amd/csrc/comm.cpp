@@ -32,12 +32,14 @@ Rccl *rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        const char *why = nullptr;  // dlerror() clears its state when read: call it once, right after the failing dlopen
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.h) break;
+            why = dlerror();
         }
         if (!r.h) {
-            r.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
+            r.err = std::string("librccl not found: ") + (why ? why : "");
             return;
         }
         auto sym = [&](const char *n) {

@@ -18,6 +18,10 @@ bool dense_minimizer_supported(int w);  // per-read slabs + mid-read flushes: wi
 int dense_minimizer_blocks_per_cu(int w);
 void dense_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a);
 
+bool pk_minimizer_supported(int w);  // packed 32-bit window machine, w <= 16 (kernels_pk.hpp)
+int pk_minimizer_blocks_per_cu(int w);
+void pk_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a);
+
 bool seg_minimizer_supported(int w);  // per-read slabs + a flush of everything staged every few blocks: three wavefronts per SIMD
 int seg_minimizer_blocks_per_cu(int w);
 void seg_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a);

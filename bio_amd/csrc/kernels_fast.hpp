@@ -304,7 +304,7 @@ struct FastMin {
             S[o] = v;
             vi += 1;
         }
-        if (FIRST && !DIRECT) {
+        if (FIRST) {  // (DIRECT too: k_minimizer_pk's exact re-run of a unit takes the flag from here)
             lmask tm = 0;
             suffix_min_pass<W, true>(S, tm);
             tie = (u32)((tm >> lane) & 1);

@@ -35,7 +35,8 @@ struct KArgs {
     u32 *pos;
     u64 cap;  // capacity of hash[]/pos[] in tuples
     // synchronisation / scratch
-    u32 *ticket;    // [0] unit ticket, [1] overflow flag
+    u32 *ticket;    // [0] unit ticket, [1] overflow flag, [2..3] the same for a side launch, [4] units listed for k_minimizer_pk_fix, [5] its ticket
+    u64 *fixlist;   // [2 * nunits]: {unit | flags, lane mask} of the lanes the packed minimizer kernel left to its fix pass (kernels_pk.hpp)
     u64 *lookback;  // [nunits]
     u64 *total;     // [0] tuples written by the dense (look-back) kernels, [1] overflow-region cursor (slab kernels)
     u64 *ring_h;    // runtime-w ring: per workgroup ring_w*64 entries

@@ -1,0 +1,521 @@
+// kernels_pk.hpp -- k_minimizer_pk<W>: the minimizer kernel for W <= 16 and 2-bit reads shorter than 32 768 bases.
+//
+// Same mapping, rolling hash, paired LDS staging columns and slab output as k_minimizer_fast (kernels_fast.hpp).  What differs is
+// the window machine (NextMinimizer, sketches/sketch.go:205-309 -- closed form: leftmost argmin of every window, emitted when it
+// changes):
+//   * an element of the window is ONE 32-bit word  key | idx : the upper 27 bits of the canonical hash and a 5-bit slot number
+//     (block parity * 16 + offset in the block).  Prefix minimum, suffix minimum and their combination are then one full-rate
+//     v_min_u32 each instead of a 64-bit compare and three v_cndmask (hash lo, hash hi, position): 3 VOP2 against 12 VOP3 per step.
+//   * what a window selected is recorded as a bit: bm |= 1 << idx (one v_lshl_or_b32; setting a bit twice IS the reference's
+//     "emit only when the position changed").  Slot o of the previous block is final when step o of the current block begins, so
+//     the staging store of a step writes STATIC registers (that slot's hash pair and strand) and the staging pointer advances by
+//     bit o of bm (v_bfe + v_mad_i24) -- no selects, no position compare, no running position register.
+//   * exactness.  The 64-bit leftmost minimum of a window is the packed minimum unless two elements of the window share the
+//     minimal 27-bit key.  Every such pair meets in one of the three min operations (both in the current block: when the later one
+//     meets the prefix minimum; both in the previous block: in the suffix pass at the earlier one; one in each: where prefix and
+//     suffix minima are combined -- DESIGN.md), and a key tie there is (a ^ b) < 32: the kernel keeps the minimum of those
+//     xors (two full-rate ops per min operation).  A unit in which any lane saw one (6e-4 of the units on random reads) is simply
+//     re-run by the exact 64-bit machine (FastMin, DIRECT), as a unit whose staging column overflowed is.  Reads with real 64-bit
+//     ties (a k-mer and its reverse complement in one window, homopolymers) therefore take the exact path, which also evaluates
+//     BSK_ST_FIRST_WINDOW_TIE; everywhere else no tie exists and the flag is 0.
+// LDS layout (paired columns, 16-bit positions, 8 waves per CU) and copy-out are k_minimizer_fast's (PLds, fast_copyout).
+// (Tried first: byte positions + the copy-out's tables laid over the hash tables = 17.7 KB, nine waves per CU under a 168-VGPR cap.
+// The ninth wave was worth 3-4.7 %; the cap cost spills, the byte positions a wrap rule in the copy-out and a read-length limit.)
+#pragma once
+#include "kernels_fast.hpp"
+
+namespace bsk {
+
+typedef PLds<BSK_PAIR_ROWS, true> PkLds;
+
+template <int W>
+struct PkCfg {
+    static constexpr int XC = W > 12 ? 4 : W;  // table rows fetched per chunk (all up front for W <= 12)
+};
+
+// the packed window machine + staging of one read per lane
+template <int W>
+struct PkMin {
+    typedef PkLds LY;
+    const u32 *__restrict__ w;
+    LDSQ char *lds;
+    int k, lane;
+    u32 nk;
+    u32 fl, fh_, rl, rh_;
+    u32 S[W];   // packed suffix minima of the previous block (then raw packed values of the current one)
+    u64 H[W];   // canonical hashes of the previous block, slot by slot replaced by the current block's
+    u32 SB[W];  // strand << 15 of the same slots
+    u32 P, bm, tmin;
+    u32 slot, spare;
+    int sstep;
+    u32 in_lo, in_hi, out_lo, out_hi;
+    u32x4 pw;
+
+    __device__ __forceinline__ u32 first_word(u32 i) const {
+        if (i < 4) return i == 0 ? pw.x : i == 1 ? pw.y : i == 2 ? pw.z : pw.w;
+        return w[i];
+    }
+    __device__ __forceinline__ void load_block_words(u32 i0) {
+        const u32 t0 = i0 + (u32)k - 1;
+        in_lo = w[t0 >> 4];
+        in_hi = w[(t0 >> 4) + 1];
+        const u32 p0 = i0 ? i0 - 1 : 0;
+        out_lo = w[p0 >> 4];
+        out_hi = w[(p0 >> 4) + 1];
+    }
+    __device__ __forceinline__ void roll(u32x4 x) {
+        const u32 a = __builtin_amdgcn_alignbit(fl, fh_, 31), b = __builtin_amdgcn_alignbit(fh_, fl, 31);
+        const u32 c = __builtin_amdgcn_alignbit(rh_, rl, 1), d = __builtin_amdgcn_alignbit(rl, rh_, 1);
+        fl = a ^ x.x;
+        fh_ = b ^ x.y;
+        rl = c ^ x.z;
+        rh_ = d ^ x.w;
+    }
+    __device__ __forceinline__ void roll2(u32x4 x) {
+        const u32 a = __builtin_amdgcn_alignbit(fl, fh_, 30), b = __builtin_amdgcn_alignbit(fh_, fl, 30);
+        const u32 c = __builtin_amdgcn_alignbit(rh_, rl, 2), d = __builtin_amdgcn_alignbit(rl, rh_, 2);
+        fl = a ^ x.x;
+        fh_ = b ^ x.y;
+        rl = c ^ x.z;
+        rh_ = d ^ x.w;
+    }
+
+    // one staging step: slot o of the block whose slots are idx base IB, at position ppos (wave-uniform)
+    __device__ __forceinline__ void emit(int idx, int o, u32 ppos) {
+        const u32 b = (bm >> idx) & 1u;                // v_bfe_u32
+        const u32 addr = slot < spare ? slot : spare;  // v_min_u32: a full column scribbles on the spare row
+#ifndef PK_NOSTAGE  // (dev knock-outs, timing only: PK_NOSTAGE, PK_NOTIE, PK_NOTAB, PK_NOCOPY)
+        *reinterpret_cast<LDSQ u64 *>(lds + LY::SH + addr) = H[o];
+        *reinterpret_cast<LDSQ u16 *>(lds + LY::SP + (addr >> 2)) = (u16)(SB[o] | ppos);
+#else
+        asm volatile("" ::"v"(H[o]), "v"(SB[o] | ppos), "v"(addr));
+#endif
+        slot = (u32)(__mul24((int)b, sstep) + (int)slot);  // v_mad_i32_i24
+    }
+
+    // FIRST: block 0 (nothing leaves at slot 0, no window is complete before its last step, nothing to emit; okbit = 0 for lanes
+    //        without a read)
+    // RAG:   windows end per lane (ragged batch, or the wave's last, partial block)
+    // PAR:   parity of the block: its slots are idx PAR*16 + o, the previous block's (1-PAR)*16 + o
+    // SUFFIX: another block follows (the suffix minima are needed)
+    template <bool FIRST, bool RAG, int PAR>
+    __device__ __forceinline__ void block(u32 i0, u32 okbit, bool suffix) {
+        constexpr int CB = PAR * 16, PB = (1 - PAR) * 16;
+        constexpr int XC = PkCfg<W>::XC;
+        const u32 t0 = i0 + (u32)k - 1;
+        const u32 cinb = __builtin_amdgcn_alignbit(in_hi, in_lo, (t0 & 15) * 2);  // code of slot o at bits [2o, 2o+2)
+        u32 coutb;
+        if (FIRST) coutb = out_lo << 2;  // slot 0: nothing leaves; slot o >= 1 sees base o-1
+        else coutb = __builtin_amdgcn_alignbit(out_hi, out_lo, ((i0 - 1) & 15) * 2);
+        // table offsets: nibble j of E / O = (out << 2 | in) of slot 2j / 2j+1, so a slot's row offset is (word >> n) & 0xF0
+        const u32 E = (cinb & 0x33333333u) | ((coutb & 0x33333333u) << 2);
+        const u32 O = ((cinb >> 2) & 0x33333333u) | (coutb & 0xCCCCCCCCu);
+        u32x4 xs[W];
+        auto fetch = [&](int o0) {
+#pragma unroll
+            for (int o = o0; o < o0 + XC && o < W; ++o) {
+                const int j = o >> 1;
+                const u32 src = (o & 1) ? O : E;
+                u32 a = (j >= 1 ? (src >> (4 * j - 4)) : (src << 4)) & 0xF0u;
+                if (FIRST && o == 0) a = 0x100u | (a & 0x30u);  // row "nothing leaves"
+#ifndef PK_NOTAB
+                xs[o] = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB + a);
+#else
+                xs[o] = (u32x4){a, a ^ E, a + O, a ^ cinb};
+#endif
+            }
+        };
+        fetch(0);
+        if (XC < W) fetch(XC);
+        load_block_words(i0 + W);
+        u32 vb = 0;
+        if (RAG && !FIRST) {  // bit o: the window ending at slot o exists for this lane
+            const int left = (int)nk - (int)i0;
+            const u32 nv = (u32)(left < 0 ? 0 : left > W ? W : left);
+            vb = (1u << nv) - 1u;
+        }
+#pragma unroll
+        for (int o = 0; o < W; ++o) {
+            if (XC < W && o && o % XC == 0 && o + XC < W) {
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(o + XC);
+            }
+            roll(xs[o]);
+            const lmask rev = lt64(rl, rh_, fl, fh_);
+            if (!FIRST) emit(PB + o, o, i0 - (u32)W + (u32)o);  // the previous block's slot o, before its registers are re-used
+            const u32 hl = sel(rev, rl, fl), hh = sel(rev, rh_, fh_);
+            H[o] = ((u64)hh << 32) | hl;
+            SB[o] = sel01(rev) << 15;
+            const u32 pk = (hh & 0xffffffe0u) | (u32)(CB + o);  // v_and_or_b32
+            if (o == 0) {
+                P = pk;
+            } else {
+#ifndef PK_NOTIE
+                const u32 d = pk ^ P;
+                tmin = tmin < d ? tmin : d;
+#endif
+                P = P < pk ? P : pk;
+            }
+            if (!FIRST || o == W - 1) {
+                u32 m = P;
+                if (o != W - 1) {
+#ifndef PK_NOTIE
+                    const u32 d = P ^ S[o + 1];
+                    tmin = tmin < d ? tmin : d;
+#endif
+                    m = P < S[o + 1] ? P : S[o + 1];
+                }
+                u32 one = 1u;
+                if (FIRST) one = okbit;
+                else if (RAG) one = (vb >> o) & 1u;
+                bm |= one << (m & 31u);  // v_lshl_or_b32
+            }
+            S[o] = pk;
+        }
+        if (suffix) {
+#pragma unroll
+            for (int q = W - 2; q >= 0; --q) {
+#ifndef PK_NOTIE
+                const u32 d = S[q] ^ S[q + 1];
+                tmin = tmin < d ? tmin : d;
+#endif
+                S[q] = S[q] < S[q + 1] ? S[q] : S[q + 1];
+            }
+        }
+        if (!FIRST) bm &= PAR ? 0xffff0000u : 0x0000ffffu;  // the previous block's slots are all emitted
+    }
+
+    // the last block's own slots
+    template <int PAR>
+    __device__ __forceinline__ void drain(u32 i0) {
+#pragma unroll
+        for (int o = 0; o < W; ++o) emit(PAR * 16 + o, o, i0 + (u32)o);
+    }
+
+    // state reset, warm-up over the first k-1 bases, and the words of block 0 (as FastMin::begin)
+    // slot0 / step: the lane's first staging slot and its signed row stride (step 0 and slot0 = the spare slot: the lane does not stage)
+    __device__ __forceinline__ void begin(u32 slot0, int step, u32 col8) {
+        fl = fh_ = rl = rh_ = 0;
+        bm = 0;
+        tmin = 0xffffffffu;
+        spare = (u32)(LY::PR * LY::ROW * 8) + col8;  // the column's slot in the spare row
+        slot = slot0;
+        sstep = step;
+        for (int t0 = 0; t0 < k - 1; t0 += 16) {
+            const u32 word = first_word((u32)t0 >> 4);
+            const int nb = (k - 1 - t0) < 16 ? (k - 1 - t0) : 16;
+            int j = 0;
+            for (; j + 8 <= nb; j += 8) {  // eight bases = four rows of the two-base table in flight
+                const u32 sub = word >> (2 * j);
+                const u32x4 x0 = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB2 + ((sub & 0xf) << 4));
+                const u32x4 x1 = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB2 + (sub & 0xf0));
+                const u32x4 x2 = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB2 + ((sub & 0xf00) >> 4));
+                const u32x4 x3 = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB2 + ((sub & 0xf000) >> 8));
+                roll2(x0);
+                roll2(x1);
+                roll2(x2);
+                roll2(x3);
+            }
+            for (; j + 2 <= nb; j += 2) roll2(*reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB2 + (((word >> (2 * j)) & 0xf) << 4)));
+            for (; j < nb; ++j) roll(*reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB + 256 + (((word >> (2 * j)) & 3) << 4)));
+        }
+        const u32 wi = ((u32)k - 1) >> 4;
+        in_lo = first_word(wi);
+        in_hi = first_word(wi + 1);
+        out_lo = pw.x;
+        out_hi = pw.y;
+    }
+
+    // uniform: every lane with a read has nk == nk_max (fixed-length batch): full blocks need no per-lane window test
+    __device__ __forceinline__ void run(u32 nk_max, bool ok, bool uniform, u32 slot0, int step, u32 col8) {
+        begin(slot0, step, col8);
+        block<true, false, 0>(0, ok ? 1u : 0u, nk_max > (u32)W);
+        u32 i0 = W;
+        int last_par = 0;
+        for (;;) {
+            if (i0 >= nk_max) break;
+            // odd block
+            {
+                const bool more = i0 + W < nk_max;
+                if (uniform && i0 + W <= nk_max) block<false, false, 1>(i0, 1u, more);
+                else block<false, true, 1>(i0, 1u, more);
+            }
+            i0 += W;
+            last_par = 1;
+            if (i0 >= nk_max) break;
+            // even block
+            {
+                const bool more = i0 + W < nk_max;
+                if (uniform && i0 + W <= nk_max) block<false, false, 0>(i0, 1u, more);
+                else block<false, true, 0>(i0, 1u, more);
+            }
+            i0 += W;
+            last_par = 0;
+        }
+        if (last_par) drain<1>(i0 - W);
+        else drain<0>(i0 - W);
+    }
+};
+
+__device__ __forceinline__ void pk_tables(char *lds, int k, int lane) {
+    typedef PkLds LY;
+    build_xtab(reinterpret_cast<uint4 *>(lds + LY::TAB), k, lane);
+    if (lane < 16) {  // two-base warm-up table: entry (c0 | c1 << 2), c0 entering first, nothing leaving
+        const unsigned c0 = (unsigned)lane & 3u, c1 = (unsigned)lane >> 2;
+        const u64 f = rol64(seed_fwd_code(c0), 1) ^ seed_fwd_code(c1);
+        const u64 r = ror64(rol64(seed_rev_code(c0), (unsigned)(k - 1)), 1) ^ rol64(seed_rev_code(c1), (unsigned)(k - 1));
+        reinterpret_cast<uint4 *>(lds + LY::TAB2)[lane] = make_uint4((u32)f, (u32)(f >> 32), (u32)r, (u32)(r >> 32));
+    }
+    __syncthreads();
+}
+
+// Lanes the main kernel could not finish go to a list (a.fixlist: {unit | flags, lane mask} per entry, count in a.ticket[4]):
+//   * the two lanes of a staging column that filled up (cnt(l) + cnt(l+32) >= 56 rows: 1.3e-3 of the columns, 4 % of the units at
+//     k=21 w=11, 150 bp).  The unit's other lanes leave normally; k_minimizer_pk_fix hashes the unit once more with only the listed
+//     lanes staging, each alone in a column of its own, and sends their tuples to the overflow region;
+//   * all lanes of a unit in which two equal 27-bit keys met in a min operation (2e-4 of the units): the exact 64-bit machine.
+// Kept out of the main kernel on purpose: with the re-run loop and the exact machine inlined there the same main loop ran 5 % slower
+// (registers, code), as a noinline call 20 % slower; and re-running such units with every tuple stored straight to HBM, as
+// k_minimizer_fast does, costs nine units' time each (2 800 partial-line writes).
+#define BSK_PK_FIX_TIE 0x80000000u
+template <int W>
+__global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves per SIMD (the LDS staging allows eight per CU): up to 256 VGPRs
+    typedef PkLds LY;
+    __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
+    LDSQ char *const ldsq = (LDSQ char *)lds;
+    const int lane = lane_id();
+    pk_tables(lds, a.k, lane);
+    const u64 slab = (u64)64 * BSK_FAST_CAP;
+    const bool uniform = a.uniform_len != 0;
+    const u32 col8 = (u32)(lane & 31) * 8u;
+    constexpr u32 RB = (u32)(LY::ROW * 8);
+    const u32 top = (u32)(LY::PR - 1) * RB + col8;  // the high lane's first slot
+    u64 d_next = 0;
+    u32x4 pw_next = {0, 0, 0, 0};
+    bool pre = false;
+    for (u32 unit = next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; unit < a.nunits; ++unit, ({
+             if (unit == uend) {
+                 unit = next_ticket(a.ticket, lane) * 8u;
+                 uend = unit + 8u;
+             }
+         })) {
+        const u64 r = (u64)unit * 64 + lane;
+        // the descriptor and the first four words of a unit are loaded one unit ahead (k_minimizer_fast has the reason)
+        u64 d;
+        u32x4 pw;
+        if (pre) {
+            d = d_next;
+            pw = pw_next;
+        } else {
+            d = r < a.n ? a.desc[r] : 0;
+            pw = *reinterpret_cast<const GLBQ u32x4_u *>((size_t)(a.words + (d >> 24)));
+        }
+        const u64 off = d >> 24, L = d & 0xffffffULL;
+        const bool nxt = unit + 1 != uend && unit + 1 < a.nunits;
+        if (nxt) d_next = r + 64 < a.n ? a.desc[r + 64] : 0;
+        const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
+        const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
+        const u32 nk_max = wave_max_u32(nk);
+        u32 cnt = 0;
+        bool any_tie = false;
+        if (nk_max) {
+            PkMin<W> pm;
+            pm.w = a.words + off;
+            pm.pw = pw;
+            pm.lds = ldsq;
+            pm.k = a.k;
+            pm.lane = lane;
+            pm.nk = nk;
+            // lanes l and l+32 share column l & 31, the low lane filling it from row 0 upwards, the high lane from the last row downwards;
+            // a lane without a read is parked on the spare row
+            const u32 spare = (u32)LY::PR * RB + col8;
+            pm.run(nk_max, ok, uniform, !ok ? spare : lane < 32 ? col8 : top, !ok ? 0 : lane < 32 ? (int)RB : -(int)RB, col8);
+            if (ok) cnt = (lane < 32 ? pm.slot - col8 : top - pm.slot) / RB;
+            any_tie = __builtin_amdgcn_ballot_w64(ok && pm.tmin < 32u) != 0;
+        }
+        if (nxt) pw_next = *reinterpret_cast<const GLBQ u32x4_u *>((size_t)(a.words + (d_next >> 24)));  // ahead of the copy-out stores
+        pre = nxt;
+        const u32 cnt_pair = cnt + (u32)__builtin_amdgcn_ds_bpermute((lane ^ 32) * 4, (int)cnt);
+        u64 bad = __builtin_amdgcn_ballot_w64(cnt_pair >= (u32)LY::PR);  // the column's last free row takes the unselected candidates
+#if defined(PK_NOSTAGE) || defined(PK_NOTIE) || defined(PK_NOTAB) || defined(PK_NOCOPY) || defined(PK_NOSTORE) || defined(PK_NOFB)
+        bad = 0;
+        any_tie = false;
+#endif
+        if (any_tie) bad = ~0ULL;
+        if (bad) {
+            if (lane == 0) {
+                const u32 i = atomicAdd(&a.ticket[4], 1u);
+                a.fixlist[2 * (u64)i] = unit | (any_tie ? BSK_PK_FIX_TIE : 0u);
+                a.fixlist[2 * (u64)i + 1] = bad;
+            }
+            if ((bad >> lane) & 1) cnt = 0;  // k_minimizer_pk_fix writes these lanes' reference words
+        }
+        const u32 incl = wave_incl_scan_u32(cnt, lane);
+        const u32 excl = incl - cnt;
+        const u32 T = wave_bcast_u32(incl, 63);
+        const u64 base = (u64)unit * slab;
+#ifndef PK_NOCOPY
+        if (T) fast_copyout<LY, true, LY::NHEADS - 1, (W <= 11 ? 4 : W <= 15 ? 2 : 1), true>(lds, lane, cnt, excl, T, base, a);
+#endif
+        if (r < a.n) {
+            a.refs[r] = ((base + excl) << 24) | cnt;
+            u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
+            if (ok && a.rflags) sbyte |= a.rflags[r];
+            a.status[r] = sbyte;
+        }
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(64, 2) void k_minimizer_pk_fix(KArgs a) {
+    typedef PkLds LY;
+    __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
+    LDSQ char *const ldsq = (LDSQ char *)lds;
+    const int lane = lane_id();
+    const u32 nfix = a.ticket[4];
+    if (nfix == 0) return;
+    pk_tables(lds, a.k, lane);
+    constexpr u32 RB = (u32)(LY::ROW * 8);
+    for (;;) {
+        const u32 t = next_ticket(a.ticket + 5, lane);
+        if (t >= nfix) break;
+        const u64 e = a.fixlist[2 * (u64)t];
+        u64 bad = a.fixlist[2 * (u64)t + 1];
+        const u32 unit = (u32)e & ~BSK_PK_FIX_TIE;
+        const u64 r = (u64)unit * 64 + lane;
+        const u64 d = r < a.n ? a.desc[r] : 0;
+        const u32x4 pw = *reinterpret_cast<const GLBQ u32x4_u *>((size_t)(a.words + (d >> 24)));
+        const u64 off = d >> 24, L = d & 0xffffffULL;
+        const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
+        const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
+        const u32 nk_max = wave_max_u32(nk);
+        const bool mine = (bad >> lane) & 1;
+        u64 myref = 0;
+        u32 tie = 0;
+        bool exact = ((u32)e & BSK_PK_FIX_TIE) != 0;
+        if (!exact) {
+            // the listed lanes (at most 32 of them stage at a time) take the columns 0, 1, ... by their rank, each alone in its column
+            for (u64 todo = bad; todo && !exact;) {
+                const u32 rk = __builtin_amdgcn_mbcnt_hi((u32)(todo >> 32), __builtin_amdgcn_mbcnt_lo((u32)todo, 0));  // listed lanes below this one
+                const bool act = ok && ((todo >> lane) & 1) && rk < 32u;
+                const u32 c8 = (rk & 31u) * 8u, spare = (u32)LY::PR * RB + (u32)(lane & 31) * 8u;
+                PkMin<W> pm;
+                pm.w = a.words + off;
+                pm.pw = pw;
+                pm.lds = ldsq;
+                pm.k = a.k;
+                pm.lane = lane;
+                pm.nk = nk;
+                pm.run(nk_max, act, a.uniform_len != 0, act ? c8 : spare, act ? (int)RB : 0, act ? c8 : (u32)(lane & 31) * 8u);
+                const u32 cnt = act ? (pm.slot - c8) / RB : 0u;
+                if (__builtin_amdgcn_ballot_w64(cnt > (u32)LY::PR) != 0) {  // one read alone selected more than a column holds
+                    exact = true;
+                    break;
+                }
+                const u32 incl = wave_incl_scan_u32(cnt, lane);
+                const u32 excl = incl - cnt;
+                const u32 T = wave_bcast_u32(incl, 63);
+                u64 ob = 0;
+                if (lane == 0) ob = atomicAdd(a.total + 1, (u64)T);
+                ob = wave_bcast_u64(ob, 0);
+                const bool fits = ob + T <= a.ovf_cap;
+                if (!fits && lane == 0) atomicOr(&a.ticket[1], 1u);  // result buffers too small: the host re-runs with a larger overflow region
+                wave_sync_lds();
+                // copy-out, one staging lane at a time: its run of cnt <= 56 tuples is one contiguous piece of the output
+                const u64 actm = __builtin_amdgcn_ballot_w64(act);
+                for (u64 m = actm; m && fits; m &= m - 1) {
+                    const int src = __builtin_ctzll(m);
+                    const u32 sc = wave_bcast_u32(cnt, src), se = wave_bcast_u32(excl, src), sc8 = wave_bcast_u32(c8, src);
+                    if ((u32)lane < sc) {
+                        const u32 so = (u32)lane * RB + sc8;
+                        const u64 hv = *reinterpret_cast<const u64 *>(lds + LY::SH + so);
+                        const u32 pv = (u32)(int)*reinterpret_cast<const short *>(lds + LY::SP + (so >> 2));  // sign-extending read: the strand bit lands in bit 31
+                        a.hash[a.ovf_base + ob + se + lane] = hv;
+                        a.pos[a.ovf_base + ob + se + lane] = pv & 0x80007fffu;
+                    }
+                }
+                wave_sync_lds();
+                if (act) myref = fits ? ((a.ovf_base + ob + excl) << 24) | cnt : 0;
+                // (more than 32 listed lanes: the next 32)
+                u64 done = 0;
+                {
+                    const u64 first32 = __builtin_amdgcn_ballot_w64(((todo >> lane) & 1) && rk < 32u);
+                    done = first32;
+                }
+                todo &= ~done;
+            }
+            if (exact) bad = ~0ULL;
+        }
+        if (exact) {
+            // two equal 27-bit keys met in a min operation, or one read alone overflowed a column: the exact 64-bit machine over the
+            // whole unit, every tuple stored straight to the overflow region.  A key tie may have mis-selected, so the packed pass's
+            // counts are not trusted: the unit takes one tuple per window.
+            FastMin<W, BSK_FAST_CAP, true, true, false, false, BSK_PAIR_ROWS, 4> fm;
+            const u32 nwin = ok ? nk - (u32)W + 1u : 0u;
+            const u32 wincl = wave_incl_scan_u32(nwin, lane);
+            const u32 myoff = wincl - nwin, need = wave_bcast_u32(wincl, 63);
+            u64 ob = 0;
+            if (lane == 0) ob = atomicAdd(a.total + 1, (u64)need);
+            ob = wave_bcast_u64(ob, 0);
+            myref = 0;
+            if (ob + need <= a.ovf_cap) {
+                fm.w = a.words + off;
+                fm.pw = pw;
+                fm.lds = ldsq;
+                fm.k = a.k;
+                fm.lane = lane;
+                fm.nk = nk;
+                fm.ghash = a.hash;
+                fm.gpos = a.pos;
+                fm.gbase = a.ovf_base + ob + myoff;
+                fm.run(nk_max);
+                tie = fm.tie;
+                myref = ((a.ovf_base + ob + myoff) << 24) | fm.cnt;
+            } else if (lane == 0) {
+                atomicOr(&a.ticket[1], 1u);
+            }
+        }
+        if (r < a.n && ((bad >> lane) & 1)) {
+            a.refs[r] = myref;
+            if (tie && ok) a.status[r] |= BSK_ST_FIRST_WINDOW_TIE;
+        }
+        (void)mine;
+    }
+}
+
+#ifdef BSK_IMPL_PK
+#ifndef BSK_PK_WS
+#define BSK_PK_WS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#endif
+bool pk_minimizer_supported(int w) { return w >= 2 && w <= 16; }
+int pk_minimizer_blocks_per_cu(int w) {
+    int nb = 0;
+    hipError_t e = hipErrorInvalidValue;
+    switch (w) {
+#define X(WW) \
+    case WW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_minimizer_pk<WW>, 64, 0); break;
+        BSK_PK_WS(X)
+#undef X
+        default: break;
+    }
+    if (e != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        nb = 1;
+    }
+    return nb;
+}
+void pk_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a) {
+    switch (w) {
+#define X(WW) \
+    case WW:                                                                                  \
+        hipLaunchKernelGGL((k_minimizer_pk<WW>), dim3(grid), dim3(64), 0, stream, a);         \
+        hipLaunchKernelGGL((k_minimizer_pk_fix<WW>), dim3(grid), dim3(64), 0, stream, a);     \
+        break;
+        BSK_PK_WS(X)
+#undef X
+        default: break;
+    }
+}
+#endif  // BSK_IMPL_PK
+
+}  // namespace bsk

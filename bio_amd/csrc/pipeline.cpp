@@ -175,7 +175,7 @@ struct FastxSource : Source {
         if (want_alpha < 0) {
             int isq = 0, a = -1;
             bsk_fastx_info(f, &isq, &a);
-            alphabet = a < 0 ? BSK_ALPHA_DNA : a;  // the guessed alphabet (a nucleotide flavour or protein); "Unlimit" files run as nucleotides
+            alphabet = a < 0 ? BSK_ALPHA_UNLIMIT : a;  // the guessed alphabet (a nucleotide flavour or protein); "Unlimit" (-1) keeps its own pairing (seq.go:381-383: reversed, not complemented)
         } else {
             alphabet = want_alpha;
         }
@@ -216,7 +216,7 @@ struct ParFastxSource : Source {
         if (want_alpha < 0) {
             int a = -1;
             bsk_fastx_par_info(f, nullptr, &a, nullptr);
-            alphabet = a < 0 ? BSK_ALPHA_DNA : a;
+            alphabet = a < 0 ? BSK_ALPHA_UNLIMIT : a;
         } else {
             alphabet = want_alpha;
         }

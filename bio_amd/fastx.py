@@ -20,7 +20,7 @@ from typing import Iterator, Optional
 import numpy as np
 
 from . import _lib as L
-from .sketches import DNA, Protein, Seq
+from .sketches import DNA, DNAredundant, RNA, RNAredundant, Protein, Unlimit, Seq
 
 
 class FastxError(Exception):
@@ -176,7 +176,10 @@ class Reader:
             if c is None and self._err is None:
                 self._err = EOF
             if c is not None:
-                ab = Protein if c.alphabet == L.ALPHA_PROTEIN else DNA
+                # the reader hands out the guessed alphabet itself (reader.go:430-435): the two-strand k-mer mode pairs
+                # letters with the sequence's own alphabet, so DNAredundant / RNA / RNAredundant / Unlimit must not become DNA
+                ab = {L.ALPHA_DNA_PLAIN: DNA, L.ALPHA_DNA: DNAredundant, L.ALPHA_RNA: RNA, L.ALPHA_RNA_REDUNDANT: RNAredundant,
+                      L.ALPHA_PROTEIN: Protein}.get(c.alphabet, Unlimit)
                 self._pending = [Record(c.name(i), c.sequence(i), c.quality(i), ab) for i in range(len(c))][::-1]
         if self._pending:
             return self._pending.pop(), None
