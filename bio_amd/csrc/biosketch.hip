@@ -323,7 +323,7 @@ extern "C" void bsk_batch_destroy(bsk_batch *b) {
     delete b;
 }
 
-static u64 pad_words(u32 maxlen) { return (u64)maxlen / 16 + 12; }  // DnaResidues::issue4 reaches first_word + 3*floor((nk_max-1)/16) + 10 words (one past maxlen/16 + 8 in the worst case)
+static u64 pad_words(u32 maxlen) { return (u64)maxlen / 16 + 17; }  // slack behind the packed words: k_minimizer_pk loads 16 words from every read's first (also a zero-length last read's); DnaResidues::issue4 reaches maxlen/16 + 10
 static u32 env_u32(const char *name, u32 dflt) {
     const char *v = getenv(name);
     return v && *v ? (u32)strtoul(v, nullptr, 10) : dflt;
@@ -996,6 +996,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         } else if (!use_ascii && pk_minimizer_supported(p->w) && b->maxlen < 32768u && !getenv("BSK_FORCE_GENERIC") && !getenv("BSK_NO_PK")) {
             pl.which = K_MIN_PK;  // w <= 16: packed 32-bit window machine (kernels_pk.hpp)
             pl.fast_w = p->w;
+            pl.fast_k = b->maxlen > pk_minimizer_short_bases() ? 1 : 0;  // (the kernel's LONG argument, for plan_name)
             pl.slab = true;
             pl.slab_unit = (u64)64 * BSK_FAST_CAP;
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
@@ -1277,7 +1278,7 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
         case K_NT_P: snprintf(b, sizeof b, "k_nthash_stream<0>"); break;
         case K_NT_A: snprintf(b, sizeof b, "k_nthash_stream<1>"); break;
         case K_MIN_FAST: snprintf(b, sizeof b, "k_minimizer_fast<%d,%d,true>", pl.fast_w, BSK_FAST_CAP); break;
-        case K_MIN_PK: snprintf(b, sizeof b, "k_minimizer_pk<%d>", pl.fast_w); break;
+        case K_MIN_PK: snprintf(b, sizeof b, "k_minimizer_pk<%d,%s>", pl.fast_w, pl.fast_k ? "true" : "false"); break;
         case K_MIN_DENSE: snprintf(b, sizeof b, "k_minimizer_dense<%d>", pl.fast_w); break;
         case K_MIN_SEG: snprintf(b, sizeof b, "k_minimizer_seg<%d>", pl.fast_w); break;
         case K_MIN_WPR: snprintf(b, sizeof b, "k_minimizer_wpr<%d>", pl.fast_w); break;
@@ -1355,7 +1356,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_NT_P: hipLaunchKernelGGL(k_nthash_stream<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_NT_A: hipLaunchKernelGGL(k_nthash_stream<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_MIN_FAST: fast_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
-        case K_MIN_PK: pk_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
+        case K_MIN_PK: pk_minimizer_launch(pl.fast_w, b->maxlen > pk_minimizer_short_bases(), pl.grid, ctx->stream, a); break;
         case K_MIN_DENSE: dense_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_MIN_SEG: seg_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_MIN_WPR: wpr_minimizer_launch(pl.grid, ctx->stream, a); break;

@@ -20,7 +20,8 @@ void dense_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a)
 
 bool pk_minimizer_supported(int w);  // packed 32-bit window machine, w <= 16 (kernels_pk.hpp)
 int pk_minimizer_blocks_per_cu(int w);
-void pk_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a);
+u32 pk_minimizer_short_bases();
+void pk_minimizer_launch(int w, bool long_reads, int grid, hipStream_t stream, const KArgs &a);
 
 bool seg_minimizer_supported(int w);  // per-read slabs + a flush of everything staged every few blocks: three wavefronts per SIMD
 int seg_minimizer_blocks_per_cu(int w);

@@ -22,9 +22,22 @@
 // (Tried first: byte positions + the copy-out's tables laid over the hash tables = 17.7 KB, nine waves per CU under a 168-VGPR cap.
 // The ninth wave was worth 3-4.7 %; the cap cost spills, the byte positions a wrap rule in the copy-out and a read-length limit.)
 #pragma once
+#include <utility>
+
 #include "kernels_fast.hpp"
 
 namespace bsk {
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): an unrolled loop whose counter is a constant expression
+// (inline-asm immediates)
+template <int... Is, class F>
+__device__ __forceinline__ void pk_unroll_impl(std::integer_sequence<int, Is...>, F &&f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void pk_unroll(F &&f) {
+    pk_unroll_impl(std::make_integer_sequence<int, N>{}, f);
+}
 
 typedef PLds<BSK_PAIR_ROWS, true> PkLds;
 
@@ -33,8 +46,35 @@ struct PkCfg {
     static constexpr int XC = W > 12 ? 4 : W;  // table rows fetched per chunk (all up front for W <= 12)
 };
 
+#define PKNW 16
+typedef u32 u32x16 __attribute__((ext_vector_type(16)));
+struct PkWords {
+    u32x4 a, b, c, d;  // the first PKNW packed words of a read
+};
+// Loads the s_waitcnt pass does not see (see PkMin::word2): the caller waits with pk_wait_loads() before the first use.
+__device__ __forceinline__ PkWords pk_load_words(const u32 *p) {
+    PkWords r;
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
+                 : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c), "=&v"(r.d)
+                 : "v"(p));
+    return r;
+}
+__device__ __forceinline__ u64 pk_load_u64(const u64 *p) {
+    u64 r;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(r) : "v"(p));
+    return r;
+}
+// The wait "produces" the loaded values: anything computed from them is thereby ordered behind it (a bare asm volatile is not a
+// barrier for the arithmetic on its neighbours' results -- the address of the words was computed from the descriptor ahead of it).
+__device__ __forceinline__ void pk_wait_loads(u64 &d0, u64 &d1) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(d0), "+v"(d1)::"memory"); }
+__device__ __forceinline__ void pk_wait_loads(PkWords &p) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(p.a), "+v"(p.b), "+v"(p.c), "+v"(p.d)::"memory"); }
+__device__ __forceinline__ void pk_wait_loads(PkWords &p, u64 &d0) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(p.a), "+v"(p.b), "+v"(p.c), "+v"(p.d), "+v"(d0)::"memory");
+}
 // the packed window machine + staging of one read per lane
-template <int W>
+// LONG: reads of more than 16 (PKNW - 1) bases (their further words are loaded inside the k-mer loop)
+template <int W, bool LONG>
 struct PkMin {
     typedef PkLds LY;
     const u32 *__restrict__ w;
@@ -48,20 +88,30 @@ struct PkMin {
     u32 P, bm, tmin;
     u32 slot, spare;
     int sstep;
-    u32 in_lo, in_hi, out_lo, out_hi;
-    u32x4 pw;
+    // The read's first PKNW packed words (240 bases) live in registers, loaded one unit ahead, BEFORE the previous unit's copy-out
+    // stores: gfx9 counts loads and stores in one in-order vmcnt, so a load issued inside the k-mer loop waits for every copy-out
+    // store queued before it.  A word is picked by its wave-uniform index (s_set_gpr_idx + v_mov); longer reads load the rest.
+    u32x16 wr;
 
-    __device__ __forceinline__ u32 first_word(u32 i) const {
-        if (i < 4) return i == 0 ? pw.x : i == 1 ? pw.y : i == 2 ? pw.z : pw.w;
-        return w[i];
+    __device__ __forceinline__ void set_words(const PkWords &p) {
+        wr = (u32x16){p.a.x, p.a.y, p.a.z, p.a.w, p.b.x, p.b.y, p.b.z, p.b.w, p.c.x, p.c.y, p.c.z, p.c.w, p.d.x, p.d.y, p.d.z, p.d.w};
     }
-    __device__ __forceinline__ void load_block_words(u32 i0) {
-        const u32 t0 = i0 + (u32)k - 1;
-        in_lo = w[t0 >> 4];
-        in_hi = w[(t0 >> 4) + 1];
-        const u32 p0 = i0 ? i0 - 1 : 0;
-        out_lo = w[p0 >> 4];
-        out_hi = w[(p0 >> 4) + 1];
+    // Words i and i + 1 of the read, i wave-uniform: register-indexed moves (s_set_gpr_idx + v_mov).  (One branch per index with static
+    // register reads instead: 7 % slower -- the branches cut the block's head into pieces.)  The compiler's s_waitcnt pass cannot tell
+    // which register such a move reads and waits for EVERY load it knows to be in flight: the loads of the next unit's words are
+    // therefore issued from inline asm, which it does not see (pk_load_words), and waited for by hand.
+    __device__ __forceinline__ void word2(u32 i, u32 &lo, u32 &hi) const {
+        const u32 iu = (u32)__builtin_amdgcn_readfirstlane((int)i);
+        if (!LONG || iu + 1 < (u32)PKNW) {
+            lo = wr[iu], hi = wr[iu + 1];
+        } else {
+            lo = w[iu], hi = w[iu + 1];
+        }
+    }
+    __device__ __forceinline__ u32 word(u32 i) const {
+        const u32 iu = (u32)__builtin_amdgcn_readfirstlane((int)i);
+        if (!LONG || iu < (u32)PKNW) return wr[iu];
+        return w[iu];
     }
     __device__ __forceinline__ void roll(u32x4 x) {
         const u32 a = __builtin_amdgcn_alignbit(fl, fh_, 31), b = __builtin_amdgcn_alignbit(fh_, fl, 31);
@@ -81,8 +131,9 @@ struct PkMin {
     }
 
     // one staging step: slot o of the block whose slots are idx base IB, at position ppos (wave-uniform)
-    __device__ __forceinline__ void emit(int idx, int o, u32 ppos) {
-        const u32 b = (bm >> idx) & 1u;                // v_bfe_u32
+    template <int IDX>
+    __device__ __forceinline__ void emit(int o, u32 ppos) {
+        const u32 b = (bm >> IDX) & 1u;  // v_bfe_u32
         const u32 addr = slot < spare ? slot : spare;  // v_min_u32: a full column scribbles on the spare row
 #ifndef PK_NOSTAGE  // (dev knock-outs, timing only: PK_NOSTAGE, PK_NOTIE, PK_NOTAB, PK_NOCOPY)
         *reinterpret_cast<LDSQ u64 *>(lds + LY::SH + addr) = H[o];
@@ -90,7 +141,7 @@ struct PkMin {
 #else
         asm volatile("" ::"v"(H[o]), "v"(SB[o] | ppos), "v"(addr));
 #endif
-        slot = (u32)(__mul24((int)b, sstep) + (int)slot);  // v_mad_i32_i24
+        asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(slot) : "v"(b), "v"(sstep));  // (the compiler's bfe_i32 + and + add is one instruction more)
     }
 
     // FIRST: block 0 (nothing leaves at slot 0, no window is complete before its last step, nothing to emit; okbit = 0 for lanes
@@ -102,11 +153,14 @@ struct PkMin {
     __device__ __forceinline__ void block(u32 i0, u32 okbit, bool suffix) {
         constexpr int CB = PAR * 16, PB = (1 - PAR) * 16;
         constexpr int XC = PkCfg<W>::XC;
-        const u32 t0 = i0 + (u32)k - 1;
+        const u32 t0 = i0 + (u32)k - 1, p0 = FIRST ? 0u : i0 - 1u;
+        u32 in_lo, in_hi, out_lo, out_hi;
+        word2(t0 >> 4, in_lo, in_hi);
+        word2(p0 >> 4, out_lo, out_hi);
         const u32 cinb = __builtin_amdgcn_alignbit(in_hi, in_lo, (t0 & 15) * 2);  // code of slot o at bits [2o, 2o+2)
         u32 coutb;
         if (FIRST) coutb = out_lo << 2;  // slot 0: nothing leaves; slot o >= 1 sees base o-1
-        else coutb = __builtin_amdgcn_alignbit(out_hi, out_lo, ((i0 - 1) & 15) * 2);
+        else coutb = __builtin_amdgcn_alignbit(out_hi, out_lo, (p0 & 15) * 2);
         // table offsets: nibble j of E / O = (out << 2 | in) of slot 2j / 2j+1, so a slot's row offset is (word >> n) & 0xF0
         const u32 E = (cinb & 0x33333333u) | ((coutb & 0x33333333u) << 2);
         const u32 O = ((cinb >> 2) & 0x33333333u) | (coutb & 0xCCCCCCCCu);
@@ -127,26 +181,26 @@ struct PkMin {
         };
         fetch(0);
         if (XC < W) fetch(XC);
-        load_block_words(i0 + W);
         u32 vb = 0;
         if (RAG && !FIRST) {  // bit o: the window ending at slot o exists for this lane
             const int left = (int)nk - (int)i0;
             const u32 nv = (u32)(left < 0 ? 0 : left > W ? W : left);
             vb = (1u << nv) - 1u;
         }
-#pragma unroll
-        for (int o = 0; o < W; ++o) {
+        pk_unroll<W>([&](auto oc) {
+            constexpr int o = decltype(oc)::value;
             if (XC < W && o && o % XC == 0 && o + XC < W) {
                 __builtin_amdgcn_sched_barrier(0);
                 fetch(o + XC);
             }
             roll(xs[o]);
             const lmask rev = lt64(rl, rh_, fl, fh_);
-            if (!FIRST) emit(PB + o, o, i0 - (u32)W + (u32)o);  // the previous block's slot o, before its registers are re-used
+            if (!FIRST) this->template emit<PB + o>(o, i0 - (u32)W + (u32)o);  // the previous block's slot o, before its registers are re-used
             const u32 hl = sel(rev, rl, fl), hh = sel(rev, rh_, fh_);
             H[o] = ((u64)hh << 32) | hl;
             SB[o] = sel01(rev) << 15;
-            const u32 pk = (hh & 0xffffffe0u) | (u32)(CB + o);  // v_and_or_b32
+            u32 pk;  // (hh & ~31) | idx: one v_and_or_b32 with the mask in an SGPR (VOP3 takes no literal on gfx9: the compiler's form is and + or)
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(pk) : "v"(hh), "s"(0xffffffe0u), "n"(CB + o));
             if (o == 0) {
                 P = pk;
             } else {
@@ -171,7 +225,7 @@ struct PkMin {
                 bm |= one << (m & 31u);  // v_lshl_or_b32
             }
             S[o] = pk;
-        }
+        });
         if (suffix) {
 #pragma unroll
             for (int q = W - 2; q >= 0; --q) {
@@ -188,8 +242,10 @@ struct PkMin {
     // the last block's own slots
     template <int PAR>
     __device__ __forceinline__ void drain(u32 i0) {
-#pragma unroll
-        for (int o = 0; o < W; ++o) emit(PAR * 16 + o, o, i0 + (u32)o);
+        pk_unroll<W>([&](auto oc) {
+            constexpr int o = decltype(oc)::value;
+            this->template emit<PAR * 16 + o>(o, i0 + (u32)o);
+        });
     }
 
     // state reset, warm-up over the first k-1 bases, and the words of block 0 (as FastMin::begin)
@@ -202,7 +258,7 @@ struct PkMin {
         slot = slot0;
         sstep = step;
         for (int t0 = 0; t0 < k - 1; t0 += 16) {
-            const u32 word = first_word((u32)t0 >> 4);
+            const u32 word = this->word((u32)t0 >> 4);
             const int nb = (k - 1 - t0) < 16 ? (k - 1 - t0) : 16;
             int j = 0;
             for (; j + 8 <= nb; j += 8) {  // eight bases = four rows of the two-base table in flight
@@ -219,11 +275,6 @@ struct PkMin {
             for (; j + 2 <= nb; j += 2) roll2(*reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB2 + (((word >> (2 * j)) & 0xf) << 4)));
             for (; j < nb; ++j) roll(*reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB + 256 + (((word >> (2 * j)) & 3) << 4)));
         }
-        const u32 wi = ((u32)k - 1) >> 4;
-        in_lo = first_word(wi);
-        in_hi = first_word(wi + 1);
-        out_lo = pw.x;
-        out_hi = pw.y;
     }
 
     // uniform: every lane with a read has nk == nk_max (fixed-length batch): full blocks need no per-lane window test
@@ -257,6 +308,90 @@ struct PkMin {
     }
 };
 
+// LDS -> HBM copy-out of one unit's staged tuples in read order (PLds staging; the arithmetic of fast_copyout, kernels_fast.hpp: owner
+// of output t = the non-empty lane with the rank-th head at or before t, its table entry {A, S} puts output t at byte A + S t of the
+// staged hashes).  Re-cut for latency -- the copy-out was 10 000 cycles per unit, a fifth of the kernel, for 600 instructions: three
+// dependent LDS round trips per trip of four rows, 5.5 trips per unit.  Here the head words are read ONCE (lane c keeps word c, a row
+// takes its word with v_readlane: no LDS), and a trip is U = 8 rows, so a unit is three trips of two round trips (table entries, then
+// the staged tuples).
+template <int U>
+__device__ __forceinline__ void pk_copyout(char *lds, int lane, u32 cnt, u32 excl, u32 T, u64 base, const KArgs &a) {
+    typedef PkLds LY;
+    constexpr int NH = LY::NHEADS;
+    u64 *s_heads = reinterpret_cast<u64 *>(lds + LY::HEADS);
+    u64 *s_tab64 = reinterpret_cast<u64 *>(lds + LY::CTAB);
+    const u64 nzmask = __builtin_amdgcn_ballot_w64(cnt > 0);
+    if (lane < NH) s_heads[lane] = 0;
+    wave_sync_lds();
+    if (cnt > 0) {
+        constexpr int RB = LY::ROW * 8;  // bytes from one row of staged hashes to the next
+        const int col8 = (lane & 31) * 8;
+        const int S = lane < 32 ? RB : -RB;
+        const int A = lane < 32 ? col8 - (int)excl * RB : col8 + ((int)(LY::PR - 1) + (int)excl) * RB;
+        const u32 rk = __builtin_amdgcn_mbcnt_hi((u32)(nzmask >> 32), __builtin_amdgcn_mbcnt_lo((u32)nzmask, 0));
+        s_tab64[rk] = ((u64)(u32)S << 32) | (u32)A;
+        atomicOr(&s_heads[excl >> 6], 1ULL << (excl & 63));
+    }
+    wave_sync_lds();
+    const u64 hw = lane < NH ? s_heads[lane] : 0ULL;  // word c: bit j = a lane's run starts at output 64 c + j
+    const u32 hw_lo = (u32)hw, hw_hi = (u32)(hw >> 32);
+    u32 heads_before = 0;  // wave-uniform
+    const char *sh = lds + LY::SH, *sp = lds + LY::SP;
+    u64 *const gh = a.hash + base;
+    u32 *const gp = a.pos + base;
+    auto trip = [&](u32 t0, auto check) {
+        constexpr bool CHECK = decltype(check)::value;
+        u32 rank[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const u32 c = (t0 >> 6) + j;  // < 64; words from NH on read as 0: rows beyond the unit see no heads
+            const u32 mlo = (u32)__builtin_amdgcn_readlane((int)hw_lo, (int)c), mhi = (u32)__builtin_amdgcn_readlane((int)hw_hi, (int)c);
+            const u64 M = ((u64)mhi << 32) | mlo;
+            const u64 M1 = M >> 1;  // heads at outputs <= this lane's = bits 1 .. lane of M (mbcnt of M >> 1) + bit 0
+            const u32 sbase = heads_before + (mlo & 1u) - 1u;
+            rank[j] = __builtin_amdgcn_mbcnt_hi((u32)(M1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)M1, sbase));
+            heads_before += (u32)__builtin_popcountll(M);
+        }
+        u64 ent[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) ent[j] = s_tab64[rank[j] & 63u];
+        u64 hv[U];
+        u32 pv[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const u32 t = t0 + 64 * j + lane;
+            const int off = __mul24((int)t, (int)(u32)(ent[j] >> 32)) + (int)(u32)ent[j];  // v_mad_i32_i24
+            const u32 so = (!CHECK || t < T) ? (u32)off : 0u;
+            hv[j] = *reinterpret_cast<const u64 *>(sh + so);
+            pv[j] = (u32)(int)*reinterpret_cast<const short *>(sp + (so >> 2));  // sign-extending read: the strand bit lands in bit 31
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const u32 t = t0 + 64 * j + lane;
+#ifdef PK_NOSTORE  // dev: the copy-out's LDS chains without its stores
+            asm volatile("" ::"v"(hv[j]), "v"(pv[j]));
+#else
+            if (!CHECK || t < T) {
+#ifndef PK_NOHASHST
+                __builtin_nontemporal_store(hv[j], &gh[t]);  // write-once output: non-temporal, the tuples streaming out do not push the sequences' lines out of the L2
+#else
+                asm volatile("" ::"v"(hv[j]));
+#endif
+#ifndef PK_NOPOSST
+                __builtin_nontemporal_store(pv[j] & 0x80007fffu, &gp[t]);
+#else
+                asm volatile("" ::"v"(pv[j]));
+#endif
+            }
+#endif
+        }
+    };
+    u32 t0 = 0;
+    for (; t0 + 64 * U <= T; t0 += 64 * U) trip(t0, std::false_type{});
+    if (t0 < T) trip(t0, std::true_type{});
+    wave_sync_lds();
+}
+
 __device__ __forceinline__ void pk_tables(char *lds, int k, int lane) {
     typedef PkLds LY;
     build_xtab(reinterpret_cast<uint4 *>(lds + LY::TAB), k, lane);
@@ -278,7 +413,10 @@ __device__ __forceinline__ void pk_tables(char *lds, int k, int lane) {
 // (registers, code), as a noinline call 20 % slower; and re-running such units with every tuple stored straight to HBM, as
 // k_minimizer_fast does, costs nine units' time each (2 800 partial-line writes).
 #define BSK_PK_FIX_TIE 0x80000000u
-template <int W>
+#ifndef PK_TICKET
+#define PK_TICKET 8u  // units per ticket
+#endif
+template <int W, bool LONG>
 __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves per SIMD (the LDS staging allows eight per CU): up to 256 VGPRs
     typedef PkLds LY;
     __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
@@ -290,38 +428,47 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
     const u32 col8 = (u32)(lane & 31) * 8u;
     constexpr u32 RB = (u32)(LY::ROW * 8);
     const u32 top = (u32)(LY::PR - 1) * RB + col8;  // the high lane's first slot
-    u64 d_next = 0;
-    u32x4 pw_next = {0, 0, 0, 0};
-    bool pre = false;
-    for (u32 unit = next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; unit < a.nunits; ++unit, ({
+    // Loads and stores share ONE in-order counter on gfx9 (vmcnt), and the copy-out's store count is not a compile-time constant, so
+    // any load waited for AFTER a copy-out waits for every store of that copy-out to reach memory -- 3 ms of the kernel when the
+    // next unit's words were requested just ahead of the stores.  Here everything a unit reads is requested at the START of the
+    // previous unit's hashing (words of unit N+1, descriptor of unit N+2) and waited for before that unit's copy-out begins, when it
+    // has long arrived: after the stores nothing is waited for but LDS.
+    u64 d_n1 = 0, d_cur = 0;
+    PkWords pw_cur = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    bool have = false;
+    for (u32 unit = next_ticket(a.ticket, lane) * PK_TICKET, uend = unit + PK_TICKET; unit < a.nunits; ++unit, ({
              if (unit == uend) {
-                 unit = next_ticket(a.ticket, lane) * 8u;
-                 uend = unit + 8u;
+                 unit = next_ticket(a.ticket, lane) * PK_TICKET;
+                 uend = unit + PK_TICKET;
              }
          })) {
         const u64 r = (u64)unit * 64 + lane;
-        // the descriptor and the first four words of a unit are loaded one unit ahead (k_minimizer_fast has the reason)
-        u64 d;
-        u32x4 pw;
-        if (pre) {
-            d = d_next;
-            pw = pw_next;
-        } else {
-            d = r < a.n ? a.desc[r] : 0;
-            pw = *reinterpret_cast<const GLBQ u32x4_u *>((size_t)(a.words + (d >> 24)));
+        const bool nxt = unit + 1 != uend && unit + 1 < a.nunits;  // the next unit is this wave's too: its words and descriptor are on the way
+        // Every load below is unconditional (indices beyond the batch are clamped to its last read; what such a load returns is never
+        // used): a value defined on one path only would reach its wait through a copy made BEFORE the wait, i.e. from registers whose
+        // load the compiler does not know to be in flight.
+        const u64 rmax = a.n - 1;
+        if (!have) {  // first unit of a ticket: nothing was requested ahead
+            d_cur = pk_load_u64(a.desc + (r < rmax ? r : rmax));
+            d_n1 = pk_load_u64(a.desc + (r + 64 < rmax ? r + 64 : rmax));
+            pk_wait_loads(d_cur, d_n1);
+            pw_cur = pk_load_words(a.words + (d_cur >> 24));
+            pk_wait_loads(pw_cur);
         }
+        PkWords pw_n1 = pk_load_words(a.words + (d_n1 >> 24));
+        u64 d_n2 = pk_load_u64(a.desc + (r + 128 < rmax ? r + 128 : rmax));
+        const u64 d = d_cur;
+        const PkWords pw = pw_cur;
         const u64 off = d >> 24, L = d & 0xffffffULL;
-        const bool nxt = unit + 1 != uend && unit + 1 < a.nunits;
-        if (nxt) d_next = r + 64 < a.n ? a.desc[r + 64] : 0;
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
         const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
         const u32 nk_max = wave_max_u32(nk);
         u32 cnt = 0;
         bool any_tie = false;
         if (nk_max) {
-            PkMin<W> pm;
+            PkMin<W, LONG> pm;
             pm.w = a.words + off;
-            pm.pw = pw;
+            pm.set_words(pw);
             pm.lds = ldsq;
             pm.k = a.k;
             pm.lane = lane;
@@ -333,8 +480,11 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
             if (ok) cnt = (lane < 32 ? pm.slot - col8 : top - pm.slot) / RB;
             any_tie = __builtin_amdgcn_ballot_w64(ok && pm.tmin < 32u) != 0;
         }
-        if (nxt) pw_next = *reinterpret_cast<const GLBQ u32x4_u *>((size_t)(a.words + (d_next >> 24)));  // ahead of the copy-out stores
-        pre = nxt;
+        pk_wait_loads(pw_n1, d_n2);  // the next unit's words and descriptor, requested a whole hashing phase ago, are in
+        d_cur = d_n1;
+        pw_cur = pw_n1;
+        d_n1 = d_n2;
+        have = nxt;
         const u32 cnt_pair = cnt + (u32)__builtin_amdgcn_ds_bpermute((lane ^ 32) * 4, (int)cnt);
         u64 bad = __builtin_amdgcn_ballot_w64(cnt_pair >= (u32)LY::PR);  // the column's last free row takes the unselected candidates
 #if defined(PK_NOSTAGE) || defined(PK_NOTIE) || defined(PK_NOTAB) || defined(PK_NOCOPY) || defined(PK_NOSTORE) || defined(PK_NOFB)
@@ -355,7 +505,14 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
         const u32 T = wave_bcast_u32(incl, 63);
         const u64 base = (u64)unit * slab;
 #ifndef PK_NOCOPY
+#ifdef PK_OLDCOPY
         if (T) fast_copyout<LY, true, LY::NHEADS - 1, (W <= 11 ? 4 : W <= 15 ? 2 : 1), true>(lds, lane, cnt, excl, T, base, a);
+#else
+#ifndef PK_CU
+#define PK_CU 8
+#endif
+        if (T) pk_copyout<PK_CU>(lds, lane, cnt, excl, T, base, a);
+#endif
 #endif
         if (r < a.n) {
             a.refs[r] = ((base + excl) << 24) | cnt;
@@ -366,7 +523,7 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
     }
 }
 
-template <int W>
+template <int W, bool LONG>
 __global__ __launch_bounds__(64, 2) void k_minimizer_pk_fix(KArgs a) {
     typedef PkLds LY;
     __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
@@ -384,7 +541,8 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk_fix(KArgs a) {
         const u32 unit = (u32)e & ~BSK_PK_FIX_TIE;
         const u64 r = (u64)unit * 64 + lane;
         const u64 d = r < a.n ? a.desc[r] : 0;
-        const u32x4 pw = *reinterpret_cast<const GLBQ u32x4_u *>((size_t)(a.words + (d >> 24)));
+        PkWords pw = pk_load_words(a.words + (d >> 24));
+        pk_wait_loads(pw);
         const u64 off = d >> 24, L = d & 0xffffffULL;
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
         const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
@@ -399,9 +557,9 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk_fix(KArgs a) {
                 const u32 rk = __builtin_amdgcn_mbcnt_hi((u32)(todo >> 32), __builtin_amdgcn_mbcnt_lo((u32)todo, 0));  // listed lanes below this one
                 const bool act = ok && ((todo >> lane) & 1) && rk < 32u;
                 const u32 c8 = (rk & 31u) * 8u, spare = (u32)LY::PR * RB + (u32)(lane & 31) * 8u;
-                PkMin<W> pm;
+                PkMin<W, LONG> pm;
                 pm.w = a.words + off;
-                pm.pw = pw;
+                pm.set_words(pw);
                 pm.lds = ldsq;
                 pm.k = a.k;
                 pm.lane = lane;
@@ -460,7 +618,7 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk_fix(KArgs a) {
             myref = 0;
             if (ob + need <= a.ovf_cap) {
                 fm.w = a.words + off;
-                fm.pw = pw;
+                fm.pw = pw.a;
                 fm.lds = ldsq;
                 fm.k = a.k;
                 fm.lane = lane;
@@ -488,12 +646,13 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk_fix(KArgs a) {
 #define BSK_PK_WS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
 #endif
 bool pk_minimizer_supported(int w) { return w >= 2 && w <= 16; }
+u32 pk_minimizer_short_bases() { return 16u * (PKNW - 1); }  // reads up to this length never load inside the k-mer loop
 int pk_minimizer_blocks_per_cu(int w) {
     int nb = 0;
     hipError_t e = hipErrorInvalidValue;
     switch (w) {
 #define X(WW) \
-    case WW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_minimizer_pk<WW>, 64, 0); break;
+    case WW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_minimizer_pk<WW, false>, 64, 0); break;
         BSK_PK_WS(X)
 #undef X
         default: break;
@@ -504,12 +663,17 @@ int pk_minimizer_blocks_per_cu(int w) {
     }
     return nb;
 }
-void pk_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a) {
+void pk_minimizer_launch(int w, bool long_reads, int grid, hipStream_t stream, const KArgs &a) {
     switch (w) {
-#define X(WW) \
-    case WW:                                                                                  \
-        hipLaunchKernelGGL((k_minimizer_pk<WW>), dim3(grid), dim3(64), 0, stream, a);         \
-        hipLaunchKernelGGL((k_minimizer_pk_fix<WW>), dim3(grid), dim3(64), 0, stream, a);     \
+#define X(WW)                                                                                               \
+    case WW:                                                                                                \
+        if (long_reads) {                                                                                   \
+            hipLaunchKernelGGL((k_minimizer_pk<WW, true>), dim3(grid), dim3(64), 0, stream, a);             \
+            hipLaunchKernelGGL((k_minimizer_pk_fix<WW, true>), dim3(grid), dim3(64), 0, stream, a);         \
+        } else {                                                                                            \
+            hipLaunchKernelGGL((k_minimizer_pk<WW, false>), dim3(grid), dim3(64), 0, stream, a);            \
+            hipLaunchKernelGGL((k_minimizer_pk_fix<WW, false>), dim3(grid), dim3(64), 0, stream, a);        \
+        }                                                                                                   \
         break;
         BSK_PK_WS(X)
 #undef X
