@@ -39,7 +39,58 @@ __device__ __forceinline__ void pk_unroll(F &&f) {
     pk_unroll_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-typedef PLds<BSK_PAIR_ROWS, true> PkLds;
+// LDS plan of one wavefront.  Paired columns as PLds (kernels_fast.hpp), but 58 rows instead of 56: a column fills up when its two
+// reads select 58 tuples together -- 0.8 % of the units at k=21 w=11, 150 bp, against 4.1 % with 56 rows (measured: the tail is
+// heavier than normal), and every such unit costs a pass of k_minimizer_pk_fix.  The room comes from laying the copy-out's tables
+// (head words, owner table) over the two hash-phase tables, which a wavefront keeps in four VGPRs and writes back at the start of
+// every unit (PkTabs).  20 248 B: still eight waves per CU.
+#ifndef BSK_PK_ROWS
+#define BSK_PK_ROWS 58
+#endif
+struct PkLds {
+    static constexpr int PR = BSK_PK_ROWS;
+    static constexpr int ROW = 33;      // 32 columns + 1: consecutive rows of a column rotate through the banks
+    static constexpr int TAB = 0;       // 20 x uint4 update table           } hash phase
+    static constexpr int TAB2 = 320;    // 16 x uint4 two-base warm-up table }
+    static constexpr int NHEADS = (32 * (PR - 1)) / 64 + 2;
+    static constexpr int HEADS = 0;     // u64 [NHEADS]            } copy-out
+    static constexpr int CTAB = 256;    // u64 [64]: owner table   }
+    static constexpr int SH = 768;                                          // u64 [(PR+1)*33]
+    static constexpr int SP = SH + (PR + 1) * ROW * 8;                      // u16 [(PR+1)*33]
+    static constexpr int TOTAL = (SP + (PR + 1) * ROW * 2 + 15) & ~15;
+    static_assert(NHEADS * 8 <= CTAB && CTAB + 512 <= SH && TAB2 + 256 <= SH && TOTAL <= 20480, "PkLds");
+};
+
+// the two hash-phase tables, one row per lane (lanes 0..19: update table, lanes 32..47: two-base warm-up table)
+struct PkTabs {
+    u32x4 row;
+    u32 at;  // LDS offset of the lane's row, or ~0
+    __device__ __forceinline__ void init(int k, int lane) {
+        row = (u32x4){0, 0, 0, 0};
+        at = 0xffffffffu;
+        if (lane < 20) {  // build_xtab's rows
+            const unsigned out = (unsigned)lane >> 2, in = (unsigned)lane & 3u;
+            u64 f = seed_fwd_code(in);
+            u64 r = rol64(seed_rev_code(in), (unsigned)(k - 1));
+            if (out < 4) {
+                f ^= rol64(seed_fwd_code(out), (unsigned)k);
+                r ^= ror64(seed_rev_code(out), 1);
+            }
+            row = (u32x4){(u32)f, (u32)(f >> 32), (u32)r, (u32)(r >> 32)};
+            at = (u32)(PkLds::TAB + lane * 16);
+        } else if (lane >= 32 && lane < 48) {  // entry (c0 | c1 << 2), c0 entering first, nothing leaving
+            const unsigned c0 = (unsigned)lane & 3u, c1 = ((unsigned)lane >> 2) & 3u;
+            const u64 f = rol64(seed_fwd_code(c0), 1) ^ seed_fwd_code(c1);
+            const u64 r = ror64(rol64(seed_rev_code(c0), (unsigned)(k - 1)), 1) ^ rol64(seed_rev_code(c1), (unsigned)(k - 1));
+            row = (u32x4){(u32)f, (u32)(f >> 32), (u32)r, (u32)(r >> 32)};
+            at = (u32)(PkLds::TAB2 + (lane - 32) * 16);
+        }
+    }
+    __device__ __forceinline__ void write(LDSQ char *ldsq) const {
+        if (at != 0xffffffffu) *reinterpret_cast<LDSQ u32x4 *>(ldsq + at) = row;
+        wave_sync_lds();
+    }
+};
 
 template <int W>
 struct PkCfg {
@@ -392,20 +443,8 @@ __device__ __forceinline__ void pk_copyout(char *lds, int lane, u32 cnt, u32 exc
     wave_sync_lds();
 }
 
-__device__ __forceinline__ void pk_tables(char *lds, int k, int lane) {
-    typedef PkLds LY;
-    build_xtab(reinterpret_cast<uint4 *>(lds + LY::TAB), k, lane);
-    if (lane < 16) {  // two-base warm-up table: entry (c0 | c1 << 2), c0 entering first, nothing leaving
-        const unsigned c0 = (unsigned)lane & 3u, c1 = (unsigned)lane >> 2;
-        const u64 f = rol64(seed_fwd_code(c0), 1) ^ seed_fwd_code(c1);
-        const u64 r = ror64(rol64(seed_rev_code(c0), (unsigned)(k - 1)), 1) ^ rol64(seed_rev_code(c1), (unsigned)(k - 1));
-        reinterpret_cast<uint4 *>(lds + LY::TAB2)[lane] = make_uint4((u32)f, (u32)(f >> 32), (u32)r, (u32)(r >> 32));
-    }
-    __syncthreads();
-}
-
 // Lanes the main kernel could not finish go to a list (a.fixlist: {unit | flags, lane mask} per entry, count in a.ticket[4]):
-//   * the two lanes of a staging column that filled up (cnt(l) + cnt(l+32) >= 56 rows: 1.3e-3 of the columns, 4 % of the units at
+//   * the two lanes of a staging column that filled up (cnt(l) + cnt(l+32) >= 58 rows: 2.5e-4 of the columns, 0.8 % of the units at
 //     k=21 w=11, 150 bp).  The unit's other lanes leave normally; k_minimizer_pk_fix hashes the unit once more with only the listed
 //     lanes staging, each alone in a column of its own, and sends their tuples to the overflow region;
 //   * all lanes of a unit in which two equal 27-bit keys met in a min operation (2e-4 of the units): the exact 64-bit machine.
@@ -422,7 +461,8 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
     __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
     LDSQ char *const ldsq = (LDSQ char *)lds;
     const int lane = lane_id();
-    pk_tables(lds, a.k, lane);
+    PkTabs tabs;
+    tabs.init(a.k, lane);
     const u64 slab = (u64)64 * BSK_FAST_CAP;
     const bool uniform = a.uniform_len != 0;
     const u32 col8 = (u32)(lane & 31) * 8u;
@@ -466,6 +506,7 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
         u32 cnt = 0;
         bool any_tie = false;
         if (nk_max) {
+            tabs.write(ldsq);  // the previous copy-out's tables took their place
             PkMin<W, LONG> pm;
             pm.w = a.words + off;
             pm.set_words(pw);
@@ -505,14 +546,10 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
         const u32 T = wave_bcast_u32(incl, 63);
         const u64 base = (u64)unit * slab;
 #ifndef PK_NOCOPY
-#ifdef PK_OLDCOPY
-        if (T) fast_copyout<LY, true, LY::NHEADS - 1, (W <= 11 ? 4 : W <= 15 ? 2 : 1), true>(lds, lane, cnt, excl, T, base, a);
-#else
 #ifndef PK_CU
 #define PK_CU 8
 #endif
         if (T) pk_copyout<PK_CU>(lds, lane, cnt, excl, T, base, a);
-#endif
 #endif
         if (r < a.n) {
             a.refs[r] = ((base + excl) << 24) | cnt;
@@ -531,7 +568,9 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk_fix(KArgs a) {
     const int lane = lane_id();
     const u32 nfix = a.ticket[4];
     if (nfix == 0) return;
-    pk_tables(lds, a.k, lane);
+    PkTabs tabs;
+    tabs.init(a.k, lane);
+    tabs.write(ldsq);  // (this kernel's copy-outs use no table: written once)
     constexpr u32 RB = (u32)(LY::ROW * 8);
     for (;;) {
         const u32 t = next_ticket(a.ticket + 5, lane);
