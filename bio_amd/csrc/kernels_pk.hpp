@@ -1,4 +1,4 @@
-// kernels_pk.hpp -- k_minimizer_pk<W>: the minimizer kernel for W <= 16 and 2-bit reads shorter than 32 768 bases.
+// kernels_pk.hpp -- k_minimizer_pk<W>: the minimizer kernel for W <= 13 and 2-bit reads shorter than 32 768 bases.
 //
 // Same mapping, rolling hash, paired LDS staging columns and slab output as k_minimizer_fast (kernels_fast.hpp).  What differs is
 // the window machine (NextMinimizer, sketches/sketch.go:205-309 -- closed form: leftmost argmin of every window, emitted when it
@@ -682,9 +682,11 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk_fix(KArgs a) {
 
 #ifdef BSK_IMPL_PK
 #ifndef BSK_PK_WS
-#define BSK_PK_WS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#define BSK_PK_WS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13)
 #endif
-bool pk_minimizer_supported(int w) { return w >= 2 && w <= 16; }
+// (w = 14..16 would fit the 5-bit slot numbers, but need 250..256+ VGPRs: w = 15, 16 spill -- among others registers whose asm load is
+// still in flight, scripts/check_asm.py -- so they stay with k_minimizer_fast)
+bool pk_minimizer_supported(int w) { return w >= 2 && w <= 13; }
 u32 pk_minimizer_short_bases() { return 16u * (PKNW - 1); }  // reads up to this length never load inside the k-mer loop
 int pk_minimizer_blocks_per_cu(int w) {
     int nb = 0;

@@ -114,3 +114,13 @@ def test_codon_tables_of_the_library_equal_the_reference_matrix(oracle):
             assert lut[4096 + b] == want_set, (tid, b)
     assert lib.bsk_codon_lut(7, np.zeros(4416, np.uint8).ctypes.data, 4416) != 0      # no such genetic code
     assert lib.bsk_codon_lut(1, np.zeros(16, np.uint8).ctypes.data, 16) != 0          # buffer too small
+
+
+def test_hand_written_asm_is_safe():
+    """scripts/check_asm.py: every inline-asm block with an SCC-writing SALU op names the clobber (the round-2 bug class), and in
+    k_minimizer_pk's ISA nothing touches the registers of a hidden (inline-asm) load before the hand-written wait."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_asm.py"), "2", "11", "13"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
