@@ -274,15 +274,19 @@ def main():
             raise SystemExit("bench.py needs a GPU: the sketch engine has no CPU fallback")
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # BSK_BENCH_FORCE_COMM=1: take the multi-rank path -- torch `nccl` process group alive, bsk_comm_unique_id -> bsk_comm_init_rank ->
+    # bsk_gather_counts -- at world size 1 too (tests/test_gpu_comm.py: the only way to run that path on a one-GPU box)
+    force_comm = bool(os.environ.get("BSK_BENCH_FORCE_COMM")) and not args.plumbing_only
+    if world > 1 or force_comm:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_comm:
             dist.barrier()
         if dev is not None:
             torch.cuda.synchronize()
@@ -306,7 +310,7 @@ def main():
         seed = 0x5EED0000 + 3 + 0x1000000 * rank  # each rank hashes its own shard of the synthetic stream
         eng = S.Engine(local_rank)
         gather_via = "bsk_gather_counts (RCCL)"
-        if world > 1:  # the communicator of the one collective: RCCL behind the C ABI; the id travels over the launcher's store
+        if world > 1 or force_comm:  # the communicator of the one collective: RCCL behind the C ABI; the id travels over the launcher's store
             try:
                 uid = [eng.comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(uid, src=0)
@@ -335,7 +339,7 @@ def main():
         mine = [int(dt * 1e9), n_reads * read_len, int(res.info()["n_tuples"]), int(dg["first_window_tie"]), int(dg["has_non_acgt"])]
 
     # whole-job numbers: MAX time over ranks, SUM of units over ranks -- ONE all_gather of five u64 counters per rank
-    if world == 1:
+    if world == 1 and not force_comm:
         rows = [mine]
     elif args.plumbing_only:
         t = torch.tensor(mine, dtype=torch.int64)
@@ -380,7 +384,7 @@ def main():
                        "first_window_tie_reads": int(sum(r[3] for r in rows)), "non_acgt_reads": int(sum(r[4] for r in rows)),
                        "per_rank_seconds": [round(r[0] / 1e9, 6) for r in rows],
                        "parallelism": f"reads sharded by record over {world} GPU(s), no data-path collective; counters gathered by "
-                                      + (gather_via if world > 1 and not args.plumbing_only else "torch gloo (plumbing-only)" if world > 1 else "nothing (1 GPU)"),
+                                      + (gather_via if (world > 1 or force_comm) and not args.plumbing_only else "torch gloo (plumbing-only)" if world > 1 else "nothing (1 GPU)"),
                        "input": ("residues (1 B each)" if kind in PROTEIN else "2-bit packed reads") + " resident in HBM",
                        "output": ("hash u64 per position" if kind in STREAM else "hash u64 + pos|strand u32") + " + u64 index per read, in HBM"},
         }
@@ -415,7 +419,7 @@ def main():
             except Exception as e:  # never let the side measurement cost the line
                 out["end_to_end"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_comm:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -45,3 +45,23 @@ def test_gather_counts_all_world1_and_errors():
     assert lib.bsk_gather_counts(eng.ctx, mine.ctypes.data, 17, out.ctypes.data) == L.ERR_ARG  # more than BSK_MAX_COUNTERS
     lib.bsk_comm_destroy(eng.ctx)
     assert lib.bsk_gather_counts(eng.ctx, mine.ctypes.data, 3, out.ctypes.data) == L.ERR_ARG
+
+
+def test_bench_multi_rank_path_with_torch_rccl_alive():
+    """bench.py's N > 1 branch -- bsk_comm_unique_id -> bsk_comm_init_rank -> bsk_gather_counts INSIDE a process that has torch's own
+    RCCL process group alive -- run at world size 1 under torchrun (BSK_BENCH_FORCE_COMM=1): the first 8-GPU scaling run must not be
+    the first time this code executes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BSK_BENCH_FORCE_COMM="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--reads", "1e6", "--no-cpu-baseline", "--no-end-to-end"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert "counters gathered by bsk_gather_counts (RCCL)" in out["config"]["parallelism"], out["config"]["parallelism"]
+    assert out["n_gpus"] == 1 and out["value"] > 0
