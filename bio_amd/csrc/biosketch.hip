@@ -256,6 +256,7 @@ extern "C" int bsk_ctx_create(int device, bsk_ctx **out) {
         return BSK_ERR_DEVICE;
     }
     ctx->cus = prop.multiProcessorCount;
+    ctx->opt.load();  // the developer switches: once per context
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc(&ctx->d_ticket, 8 * sizeof(u32)) != hipSuccess || hipMalloc(&ctx->d_total, 8 * sizeof(u64)) != hipSuccess ||
         hipHostMalloc(&ctx->h_pinned, 8 * sizeof(u64)) != hipSuccess) {
@@ -327,6 +328,29 @@ static u64 pad_words(u32 maxlen) { return (u64)maxlen / 16 + 17; }  // slack beh
 static u32 env_u32(const char *name, u32 dflt) {
     const char *v = getenv(name);
     return v && *v ? (u32)strtoul(v, nullptr, 10) : dflt;
+}
+void BskOpts::load() {
+    auto on = [](const char *n) { return getenv(n) != nullptr; };
+    force_generic = on("BSK_FORCE_GENERIC");
+    no_mixed = on("BSK_NO_MIXED");
+    no_dense = on("BSK_NO_DENSE");
+    no_pk = on("BSK_NO_PK");
+    no_tiles = on("BSK_NO_TILES");
+    no_tile_cache = on("BSK_NO_TILE_CACHE");
+    timing = on("BSK_TIMING");
+    no_fused_translate = on("BSK_NO_FUSED_TRANSLATE");
+    sets_no_small = on("BSK_SETS_NO_SMALL");
+    wpr = env_u32("BSK_WPR", 0);
+    seg = env_u32("BSK_SEG", 0);
+    dense_min = env_u32("BSK_DENSE_MIN", 21);
+    waves_per_cu = env_u32("BSK_WAVES_PER_CU", 0);
+    tile_min = env_u32("BSK_TILE_MIN", 0);
+    tile_pos = env_u32("BSK_TILE_POS", 0);
+}
+extern "C" int bsk_ctx_reload_options(bsk_ctx *ctx) {
+    if (!ctx) return BSK_ERR_ARG;
+    ctx->opt.load();
+    return BSK_OK;
 }
 static int build_subset(bsk_ctx *ctx, bsk_batch *b);
 
@@ -430,7 +454,7 @@ static int batch_from_ascii_impl(bsk_ctx *ctx, const uint8_t *bytes, const uint6
         BCHK(hipMemsetAsync(b->rflags, 0, n ? n : 1, ctx->stream));
         if (n) BCHK(hipMemcpyAsync(wide ? b->fw : b->desc, desc.data(), n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
         BCHK(hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream));
-        if (maxlen > env_u32("BSK_TILE_MIN", 16u * (BSK_NT_FAST_WORDS - 2)) && w) {  // this batch may be tiled: remember which words hold non-ACGT letters
+        if (maxlen > (ctx->opt.tile_min ? ctx->opt.tile_min : 16u * (BSK_NT_FAST_WORDS - 2)) && w) {  // this batch may be tiled: remember which words hold non-ACGT letters
             BCHK(hipMalloc(&b->wbits, ((w + 31) / 32) * sizeof(u32)));
             BCHK(hipMemsetAsync(b->wbits, 0, ((w + 31) / 32) * sizeof(u32), ctx->stream));
         }
@@ -929,7 +953,7 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
     // reads with a non-ACGT letter (up to 90 %: the side launch costs flagged/60 against 1/690 Gbases/s for the fast kernel, so this wins
     // almost always): plan the batch as 2-bit; if that lands on a fast kernel, the flagged reads are
     // re-done by the general ASCII kernel in a side launch.  Otherwise the whole batch runs on the ASCII kernels.
-    if (has_n && b->subset && b->nsub * 10 <= b->n * 9 && !getenv("BSK_NO_MIXED")) {
+    if (has_n && b->subset && b->nsub * 10 <= b->n * 9 && !ctx->opt.no_mixed) {
         Plan t;
         int rc = make_plan_enc(ctx, b, p, t, false);
         if (rc != BSK_OK) return rc;
@@ -963,8 +987,8 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         // k_minimizer_seg: per-read slabs of the expected count + 30 % + 4 (150 bp, w = 11: 32 tuples), rounded to 64-byte pieces
         const double exp_sel = std::max(nwin, 0.0) * 2.0 / (p->w + 1.0) + 1.0;
         const u64 seg_slab = (std::min<u64>((u64)std::max(nwin, 1.0), (u64)(exp_sel * 1.3) + 4) + 7) & ~(u64)7;
-        if (!use_ascii && p->w == 11 && p->k + p->w <= 65 && b->maxlen < 32768u && nwin >= 1.0 && env_u32("BSK_WPR", 0) && !ctx->no_dense && slab_budget_ok(b, seg_slab) &&
-            !getenv("BSK_FORCE_GENERIC")) {
+        if (!use_ascii && p->w == 11 && p->k + p->w <= 65 && b->maxlen < 32768u && nwin >= 1.0 && ctx->opt.wpr && !ctx->no_dense && slab_budget_ok(b, seg_slab) &&
+            !ctx->opt.force_generic) {
             pl.which = K_MIN_WPR;  // the A/B experiment: one read per wavefront (kernels_wpr.hpp); a ticket is 64 reads
             pl.fast_w = p->w;
             pl.slab = true;
@@ -973,8 +997,8 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
             per_cu = wpr_minimizer_blocks_per_cu();
         } else
-        if (!use_ascii && seg_minimizer_supported(p->w) && b->maxlen < 32768u && nwin >= 1.0 && env_u32("BSK_SEG", 0) && !ctx->no_dense && slab_budget_ok(b, seg_slab) &&
-            !getenv("BSK_FORCE_GENERIC")) {
+        if (!use_ascii && seg_minimizer_supported(p->w) && b->maxlen < 32768u && nwin >= 1.0 && ctx->opt.seg && !ctx->no_dense && slab_budget_ok(b, seg_slab) &&
+            !ctx->opt.force_generic) {
             pl.which = K_MIN_SEG;
             pl.fast_w = p->w;
             pl.slab = true;
@@ -983,8 +1007,8 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
             per_cu = seg_minimizer_blocks_per_cu(p->w);
         } else
-        if (!use_ascii && dense_minimizer_supported(p->w) && b->maxlen < 32768u && nwin * 2.0 / (p->w + 1.0) > (double)env_u32("BSK_DENSE_MIN", 21) && !ctx->no_dense && slab_budget_ok(b, dense_slab) &&
-            !getenv("BSK_FORCE_GENERIC") && !getenv("BSK_NO_DENSE")) {
+        if (!use_ascii && dense_minimizer_supported(p->w) && b->maxlen < 32768u && nwin * 2.0 / (p->w + 1.0) > (double)ctx->opt.dense_min && !ctx->no_dense && slab_budget_ok(b, dense_slab) &&
+            !ctx->opt.force_generic && !ctx->opt.no_dense) {
             pl.which = K_MIN_DENSE;
             pl.fast_w = p->w;
             pl.slab = true;
@@ -993,7 +1017,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.slab_unit = 64 * pl.slab_read;
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
             per_cu = dense_minimizer_blocks_per_cu(p->w);
-        } else if (!use_ascii && pk_minimizer_supported(p->w) && b->maxlen < 32768u && !getenv("BSK_FORCE_GENERIC") && !getenv("BSK_NO_PK")) {
+        } else if (!use_ascii && pk_minimizer_supported(p->w) && b->maxlen < 32768u && !ctx->opt.force_generic && !ctx->opt.no_pk) {
             pl.which = K_MIN_PK;  // w <= 16: packed 32-bit window machine (kernels_pk.hpp)
             pl.fast_w = p->w;
             pl.fast_k = b->maxlen > pk_minimizer_short_bases() ? 1 : 0;  // (the kernel's LONG argument, for plan_name)
@@ -1001,7 +1025,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.slab_unit = (u64)64 * BSK_FAST_CAP;
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
             per_cu = pk_minimizer_blocks_per_cu(p->w);
-        } else if (!use_ascii && fast_minimizer_supported(p->w) && b->maxlen < 32768u && !getenv("BSK_FORCE_GENERIC")) {
+        } else if (!use_ascii && fast_minimizer_supported(p->w) && b->maxlen < 32768u && !ctx->opt.force_generic) {
             pl.which = K_MIN_FAST;
             pl.fast_w = p->w;
             pl.slab = true;
@@ -1014,7 +1038,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.ring_w = (u32)p->w;
         }
     } else if (p->kind == BSK_NTHASH) {
-        if (!use_ascii && b->maxlen + (u32)(p->circular ? p->k : 0) <= 16u * (BSK_NT_FAST_WORDS - 2) && !getenv("BSK_FORCE_GENERIC")) {
+        if (!use_ascii && b->maxlen + (u32)(p->circular ? p->k : 0) <= 16u * (BSK_NT_FAST_WORDS - 2) && !ctx->opt.force_generic) {
             pl.which = K_NT_FAST;
             // write-bound kernel: measured fastest at 4 waves/CU (more concurrent 128-byte write streams per XCD
             // thrash the L2 write-combining: 3.65 ms vs 5.27 ms at 15 waves/CU for 10M reads)
@@ -1024,7 +1048,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             per_cu = use_ascii ? blocks_per_cu(k_nthash_stream<1>) : blocks_per_cu(k_nthash_stream<0>);
         }
     } else if (p->kind == BSK_SYNCMER) {
-        if (!use_ascii && fast_syncmer_supported(p->k, p->s) && b->maxlen < 32768u && !getenv("BSK_FORCE_GENERIC")) {
+        if (!use_ascii && fast_syncmer_supported(p->k, p->s) && b->maxlen < 32768u && !ctx->opt.force_generic) {
             pl.which = K_SYN_FAST;
             pl.fast_w = p->k - p->s;
             pl.slab = true;
@@ -1038,7 +1062,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         }
     } else if (p->kind == BSK_KMER) {
         if (!use_ascii && p->canonical > 0 && b->maxlen + (u32)(p->circular ? p->k : 0) <= 16u * (BSK_NT_FAST_WORDS - 2) &&
-            !getenv("BSK_FORCE_GENERIC")) {
+            !ctx->opt.force_generic) {
             pl.which = K_NT_FAST;  // same streaming kernel, MODE 2
             per_cu = blocks_per_cu(k_nthash_fast<2>);
         } else {
@@ -1048,7 +1072,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
     } else if (p->kind == BSK_SIMHASH) {
         const int nh = p->k - p->m + 1;
         if (!use_ascii && nh <= 63 && b->maxlen + (u32)(p->circular ? p->k : 0) <= 16u * (BSK_NT_FAST_WORDS - 2) &&
-            !getenv("BSK_FORCE_GENERIC")) {
+            !ctx->opt.force_generic) {
             pl.which = K_SIM_FAST;  // bit-sliced counters: 5 planes count to 31, 6 to 63
             pl.fast_w = nh <= 31 ? 5 : 6;
             const u32 ext_len = b->maxlen + (u32)(p->circular ? p->k : 0);
@@ -1067,7 +1091,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.fused_dna = true;
             pl.fast_k = p->k;
             per_cu = fast_prot_hash_dna_blocks_per_cu(p->k);
-        } else if (fast_prot_hash_supported(p->k) && !getenv("BSK_FORCE_GENERIC")) {
+        } else if (fast_prot_hash_supported(p->k) && !ctx->opt.force_generic) {
             pl.which = K_PROT_HASH_FAST;
             pl.fast_k = p->k;
             per_cu = fast_prot_hash_blocks_per_cu(p->k);
@@ -1079,7 +1103,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         // a DNA batch here means the fused plan (sketch_impl checked that it applies): lengths in residues
         const u32 plen = b->alphabet == BSK_ALPHA_DNA ? (u32)translated_len(b->maxlen, 1) : b->maxlen;
         if (b->alphabet == BSK_ALPHA_DNA && ctx->no_prot_fast) return BSK_REPLAN_UNFUSED;  // slabs too small / too large: sketch_impl translates first
-        if (b->alphabet == BSK_ALPHA_DNA || (fast_prot_supported(p->w, p->k) && b->maxlen < 65536u && b->maxlen >= (u32)(p->k + p->w) && !getenv("BSK_FORCE_GENERIC") &&
+        if (b->alphabet == BSK_ALPHA_DNA || (fast_prot_supported(p->w, p->k) && b->maxlen < 65536u && b->maxlen >= (u32)(p->k + p->w) && !ctx->opt.force_generic &&
             !ctx->no_prot_fast && slab_budget_ok(b, (u64)b->maxlen))) {
             pl.which = K_PROT_MIN_FAST;
             pl.fused_dna = b->alphabet == BSK_ALPHA_DNA;
@@ -1101,7 +1125,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         ctx->err = "unknown kind";
         return BSK_ERR_ARG;
     }
-    if (getenv("BSK_WAVES_PER_CU")) per_cu = std::max(1, atoi(getenv("BSK_WAVES_PER_CU")));  // dev: occupancy experiments
+    if (ctx->opt.waves_per_cu) per_cu = (int)ctx->opt.waves_per_cu;  // dev: occupancy experiments
     pl.grid = (int)std::max<u64>(1, std::min<u64>((u64)ctx->cus * per_cu, pl.nunits));
     pl.ring_entries = (size_t)pl.grid * pl.ring_w * 64;
     return BSK_OK;
@@ -1606,13 +1630,13 @@ static bool kind_tiles(const bsk_params *p) {
 }
 
 // positions one tile owns: about 22 tuples per tile (the kernels stage 32 per lane; 16 for syncmers), a multiple of 16
-static u32 tile_positions(const bsk_params *p) {
+static u32 tile_positions(const bsk_ctx *ctx, const bsk_params *p) {
     u32 tp;
     if (p->kind == BSK_MINIMIZER || p->kind == BSK_PROT_MINIMIZER) tp = 16u * std::max<u32>(2, (u32)(22.0 * (p->w + 1.0) / 2.0 / 16.0));
     else if (p->kind == BSK_SYNCMER) tp = 16u * std::max<u32>(2, (u32)(11.0 * (p->k - p->s + 1.0) / 2.0 / 16.0));
     else tp = 256;
     tp = std::min<u32>(tp, 8192);
-    const u32 forced = env_u32("BSK_TILE_POS", 0);  // tests: exercise the tile seams
+    const u32 forced = ctx->opt.tile_pos;  // tests: exercise the tile seams
     if (forced) tp = std::max<u32>(16, (forced + 15) & ~15u);
     return tp;
 }
@@ -1637,7 +1661,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     geo.k = p->k;
     geo.w = p->kind == BSK_SYNCMER ? p->k - p->s : p->w;
     geo.s = p->s;
-    geo.tp = tile_positions(p);
+    geo.tp = tile_positions(ctx, p);
     geo.circ_ext = circ_ext;
     geo.syn_all = syn_all ? 1 : 0;
     const bool stream = !kind_has_pos(p->kind);
@@ -1670,7 +1694,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
             bsk_batch_destroy(tb);
         }
         if (code != BSK_OK && fin) bsk_result_release(fin);
-        if (getenv("BSK_NO_TILE_CACHE") && ctx->tile_res) {  // dev switch
+        if (ctx->opt.no_tile_cache && ctx->tile_res) {  // dev switch
             bsk_result_release(ctx->tile_res);
             ctx->tile_res = nullptr;
         }
@@ -1682,7 +1706,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
         hipError_t e__ = (call);                                    \
         if (e__ != hipSuccess) return done(fail_hip(ctx, e__, #call)); \
     } while (0)
-    const bool timing = getenv("BSK_TIMING") != nullptr;  // dev: wall time of the phases of a tiled call, to stderr
+    const bool timing = ctx->opt.timing;  // dev: wall time of the phases of a tiled call, to stderr
     auto t_prev = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!timing) return;
@@ -1891,12 +1915,12 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
         }
         // pure-ACGT 2-bit batches and a compiled (w, k): the protein minimizer kernel translates on the fly (no translated copy)
         fused = p->kind == BSK_PROT_MINIMIZER && batch->desc && batch->n_nonacgt == 0 && fast_prot_supported(p->w, p->k) &&
-                translated_len(batch->maxlen, 1) < 65536u && !getenv("BSK_FORCE_GENERIC") && !getenv("BSK_NO_FUSED_TRANSLATE") && !ctx->no_prot_fast &&
+                translated_len(batch->maxlen, 1) < 65536u && !ctx->opt.force_generic && !ctx->opt.no_fused_translate && !ctx->no_prot_fast &&
                 slab_budget_ok(batch, (u64)translated_len(batch->maxlen, 1));
         // the hash stream likewise (k = 9..16; translations longer than the tile threshold take the tiled two-step path)
         if (p->kind == BSK_PROT_HASH)
             fused = batch->desc && batch->n_nonacgt == 0 && fast_prot_hash_supported(p->k) && translated_len(batch->maxlen, 1) <= 4096u &&
-                    !getenv("BSK_FORCE_GENERIC") && !getenv("BSK_NO_FUSED_TRANSLATE");
+                    !ctx->opt.force_generic && !ctx->opt.no_fused_translate;
         if (fused) {
             rc = ensure_lut(ctx, p->codon_table);
             if (rc != BSK_OK) return rc;
@@ -1914,7 +1938,7 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
     }
     // the two-strand k-mer mode (iterator.go:713-723) yields 2(L-k+1) values per read: without tiles (dev switch) a read's count must
     // fit the 24-bit field of its reference word
-    if (p->kind == BSK_KMER && !p->canonical && getenv("BSK_NO_TILES") && (u64)b->maxlen >= (1ull << 23) + (u64)p->k - 1) {
+    if (p->kind == BSK_KMER && !p->canonical && ctx->opt.no_tiles && (u64)b->maxlen >= (1ull << 23) + (u64)p->k - 1) {
         if (tmp) bsk_batch_destroy(tmp);
         ctx->err = "two-strand k-mer codes: sequences of 2^23 k-mers or more need the tiled path";
         return BSK_ERR_UNSUPPORTED;
@@ -1931,9 +1955,9 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
     }
     // long sequences run as tiles; protein: only when really long (the protein kernels take any length per lane, slowly)
     const bool is_dna = b->alphabet == BSK_ALPHA_DNA;
-    const u32 tile_min = env_u32("BSK_TILE_MIN", (!is_dna || kind_has_pos(p->kind)) ? 4096u : 16u * (BSK_NT_FAST_WORDS - 2));
+    const u32 tile_min = ctx->opt.tile_min ? ctx->opt.tile_min : ((!is_dna || kind_has_pos(p->kind)) ? 4096u : 16u * (BSK_NT_FAST_WORDS - 2));
     const bool outlier = !is_dna && p->kind == BSK_PROT_MINIMIZER && b->maxlen > 512 && !slab_budget_ok(b, (u64)b->maxlen);  // tiles are uniform: small slabs
-    const bool tiled = kind_tiles(p) && (is_dna != prot_kind) && !getenv("BSK_NO_TILES") && ((is_dna && !b->desc) || b->maxlen > tile_min || outlier);
+    const bool tiled = kind_tiles(p) && (is_dna != prot_kind) && !ctx->opt.no_tiles && ((is_dna && !b->desc) || b->maxlen > tile_min || outlier);
     rc = tiled ? sketch_tiled(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms)
                : run_planned(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms);
     if (rc == BSK_REPLAN_UNFUSED && fused) {  // unusual density (a sequence outgrew its slab) or slabs that do not fit: translate, then sketch
@@ -1941,7 +1965,7 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
         const u64 need = (u64)p->k * 3 + (u64)p->w - 1;
         rc = translate_batch(ctx, batch, p->codon_table, p->frame, need, &tmp);
         if (rc != BSK_OK) return rc;
-        const bool tiled2 = kind_tiles(p) && !getenv("BSK_NO_TILES") && tmp->maxlen > tile_min;
+        const bool tiled2 = kind_tiles(p) && !ctx->opt.no_tiles && tmp->maxlen > tile_min;
         rc = tiled2 ? sketch_tiled(ctx, tmp, p, 0, result, warmup, iters, kernel_ms) : run_planned(ctx, tmp, p, 0, result, warmup, iters, kernel_ms);
     }
     if (tmp) bsk_batch_destroy(tmp);

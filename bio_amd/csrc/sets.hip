@@ -429,7 +429,7 @@ extern "C" int bsk_result_sets(bsk_ctx *ctx, const bsk_result *r, int scope, int
         *out = res;
         return done(BSK_OK);
     }
-    if (scope == BSK_SETS_PER_SEQUENCE && max_count <= SMALL_CAP && !getenv("BSK_SETS_NO_SMALL")) {
+    if (scope == BSK_SETS_PER_SEQUENCE && max_count <= SMALL_CAP && !ctx->opt.sets_no_small) {
         // short reads: one sequence per row of 16 lanes, bitonic network over DPP moves (k_sets_rows)
         u64 *ucount = nullptr, *dense = nullptr;
         SCHK(pool(2, N * 8, (void **)&dense));          // the sequences' distinct values at their input offsets

@@ -24,6 +24,7 @@ or CPU implementation here.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Iterable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -168,6 +169,7 @@ class BatchResult:
         """Sorted distinct hash values per sequence (or of the whole batch), optionally FracMinHash-filtered
         (bsk_result_sets) -> (offsets[n_sets+1], values)."""
         h = C.c_void_p()
+        self.eng._opts()
         self.eng._chk(self.eng.lib.bsk_result_sets(self.eng.ctx, self.h, L.SETS_WHOLE_BATCH if whole_batch else L.SETS_PER_SEQUENCE, scale,
                                                    C.byref(h)))
         try:
@@ -220,6 +222,19 @@ class Engine:
         if rc != L.OK:
             raise DeviceError(f"bsk_ctx_create({device}) failed: {self.lib.bsk_err_name(rc).decode()}")
         self.ctx = h
+        self._opts_seen = self._opts_env()
+
+    @staticmethod
+    def _opts_env():
+        return tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("BSK_")))
+
+    def _opts(self):
+        """The library reads its developer switches (BSK_*) once per context; the test suite flips them inside one process, so this
+        mirror reloads them (bsk_ctx_reload_options) when the environment changed since the last call."""
+        now = self._opts_env()
+        if now != self._opts_seen:
+            self._opts_seen = now
+            self.lib.bsk_ctx_reload_options(self.ctx)
 
     def _chk(self, rc: int):
         if rc == L.OK:
@@ -301,6 +316,7 @@ class Engine:
         data = np.ascontiguousarray(data, np.uint8)
         offsets = np.ascontiguousarray(offsets, np.uint64)
         h = C.c_void_p()
+        self._opts()
         self._chk(self.lib.bsk_batch_from_ascii(self.ctx, data.ctypes.data, offsets.ctypes.data, len(offsets) - 1,
                                                 alphabet, C.byref(h)))
         return Batch(self, h)
@@ -309,6 +325,7 @@ class Engine:
         words = np.ascontiguousarray(words, np.uint32)
         desc = np.ascontiguousarray(desc, np.uint64)
         h = C.c_void_p()
+        self._opts()
         self._chk(self.lib.bsk_batch_from_packed(self.ctx, words.ctypes.data, len(words), desc.ctypes.data, len(desc),
                                                  C.byref(h)))
         return Batch(self, h)
@@ -318,11 +335,13 @@ class Engine:
         alphabet < 0: the reader's guess from its first record, as the reference does."""
         h = C.c_void_p()
         n = C.c_uint64()
+        self._opts()
         self._chk(self.lib.bsk_batch_from_fastx(self.ctx, reader.h, max_records, max_bytes, alphabet, C.byref(h), C.byref(n)))
         return (Batch(self, h) if n.value else None), n.value
 
     def synth(self, alphabet: int, n: int, length: int, seed: int) -> Batch:
         h = C.c_void_p()
+        self._opts()
         self._chk(self.lib.bsk_batch_synth(self.ctx, alphabet, n, length, seed, C.byref(h)))
         return Batch(self, h)
 
@@ -333,6 +352,7 @@ class Engine:
 
     def run(self, batch: Batch, p: L.Params, reuse: Optional[BatchResult] = None) -> BatchResult:
         h = reuse.h if reuse is not None else C.c_void_p()
+        self._opts()
         self._chk(self.lib.bsk_sketch(self.ctx, batch.h, C.byref(p), C.byref(h)))
         if reuse is not None:
             reuse.h, reuse.params, reuse._host = h, p, None
@@ -342,6 +362,7 @@ class Engine:
     def run_timed(self, batch: Batch, p: L.Params, warmup: int, iters: int, reuse: Optional[BatchResult] = None):
         h = reuse.h if reuse is not None else C.c_void_p()
         ms = (C.c_float * max(iters, 1))()
+        self._opts()
         self._chk(self.lib.bsk_sketch_timed(self.ctx, batch.h, C.byref(p), C.byref(h), warmup, iters, ms))
         res = reuse if reuse is not None else BatchResult(self, h, p)
         res.h, res.params, res._host = h, p, None

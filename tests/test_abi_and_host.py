@@ -124,3 +124,16 @@ def test_hand_written_asm_is_safe():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_asm.py"), "2", "11", "13"], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout + p.stderr
+
+
+def test_developer_switches_are_read_once_per_context():
+    """No getenv on the bsk_sketch path: biosketch.hip / sets.hip read the BSK_* switches only in BskOpts::load (bsk_ctx_create,
+    bsk_ctx_reload_options)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for fn in ("biosketch.hip", "sets.hip", "comm.cpp"):
+        text = open(os.path.join(root, "bio_amd", "csrc", fn)).read()
+        body = text
+        if fn == "biosketch.hip":  # the two functions that may call getenv
+            a, b = text.index("static u32 env_u32("), text.index('extern "C" int bsk_ctx_reload_options')
+            body = text[:a] + text[b:]
+        assert "getenv" not in body, fn
