@@ -912,7 +912,7 @@ static int blocks_per_cu(K kernel) {
 
 // Which kernel runs a (batch, params) pair, on how many workgroups, and how the tuple arrays are organised.
 enum Which { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST, K_NT_FAST, K_SYN_P, K_SYN_A, K_KMER_P, K_KMER_A, K_SIM_P, K_SIM_A,
-             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST, K_MIN_DENSE, K_MIN_SEG, K_MIN_WPR, K_MIN_PK };
+             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST, K_MIN_DENSE, K_MIN_SEG, K_MIN_WPR, K_MIN_PK, K_SYN_PK };
 struct Plan {
     Which which = K_MIN_GEN_P;
     int grid = 1;
@@ -943,7 +943,7 @@ static bool slab_budget_ok(const bsk_batch *b, u64 slab_read) {
 #define BSK_REPLAN_UNFUSED (-1000)  // internal: the fused DNA -> protein plan gave up, run the two-step path
 
 static bool which_is_fast(Which w) {
-    return w == K_MIN_FAST || w == K_NT_FAST || w == K_SYN_FAST || w == K_SIM_FAST || w == K_MIN_DENSE || w == K_MIN_SEG || w == K_MIN_WPR || w == K_MIN_PK;
+    return w == K_MIN_FAST || w == K_NT_FAST || w == K_SYN_FAST || w == K_SIM_FAST || w == K_MIN_DENSE || w == K_MIN_SEG || w == K_MIN_WPR || w == K_MIN_PK || w == K_SYN_PK;
 }
 
 static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan &pl, bool use_ascii);
@@ -1048,7 +1048,18 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             per_cu = use_ascii ? blocks_per_cu(k_nthash_stream<1>) : blocks_per_cu(k_nthash_stream<0>);
         }
     } else if (p->kind == BSK_SYNCMER) {
-        if (!use_ascii && fast_syncmer_supported(p->k, p->s) && b->maxlen < 32768u && !ctx->opt.force_generic) {
+        // packed machine: reads whose words fit a lane's registers, and few enough selections that a pair of reads stages in the
+        // kernel's short columns (expected 1.5 / (k-s+1) of the windows: 7.1 of 101 at k=31 s=11, 150 bp, measured)
+        const double syn_nwin = (double)b->maxlen - 2.0 * p->k + p->s + 2.0;
+        if (!use_ascii && pk_syncmer_supported(p->k - p->s) && fast_syncmer_supported(p->k, p->s) && b->maxlen <= pk_syncmer_max_bases() &&
+            2.0 * (syn_nwin * 1.5 / (p->k - p->s + 1.0) + 0.5) + 6.0 <= (double)pk_syncmer_pair_rows() && !ctx->opt.force_generic && !ctx->opt.no_pk && !ctx->no_syn_pk) {
+            pl.which = K_SYN_PK;
+            pl.fast_w = p->k - p->s;
+            pl.slab = true;
+            pl.slab_unit = (u64)64 * BSK_SYN_CAP;
+            pl.slab_total = (u64)pl.nunits * pl.slab_unit;
+            per_cu = pk_syncmer_blocks_per_cu(pl.fast_w);
+        } else if (!use_ascii && fast_syncmer_supported(p->k, p->s) && b->maxlen < 32768u && !ctx->opt.force_generic) {
             pl.which = K_SYN_FAST;
             pl.fast_w = p->k - p->s;
             pl.slab = true;
@@ -1316,6 +1327,7 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
         case K_PROT_HASH: snprintf(b, sizeof b, "k_prot_hash"); break;
         case K_PROT_MIN: snprintf(b, sizeof b, "k_prot_minimizer"); break;
         case K_SYN_FAST: snprintf(b, sizeof b, "k_syncmer_fast<%d>", pl.fast_w); break;
+        case K_SYN_PK: snprintf(b, sizeof b, "k_syncmer_pk<%d>", pl.fast_w); break;
         case K_PROT_MIN_FAST: snprintf(b, sizeof b, "k_prot_minimizer_fast<%d,%d,%s>", pl.fast_w, pl.fast_k, pl.fused_dna ? "true" : "false"); break;
         case K_PROT_HASH_FAST: snprintf(b, sizeof b, "k_prot_hash_fast<%d,%s>", pl.fast_k, pl.fused_dna ? "true" : "false"); break;
         case K_SIM_FAST:
@@ -1327,6 +1339,9 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
     res->plan_grid = pl.grid;
     res->plan_per_cu = cus > 0 ? (pl.grid + cus - 1) / cus : 0;
 }
+
+// k_syncmer_pk's list of reads for the exact machine: room for a quarter of the batch (a batch with more falls back to k_syncmer_fast)
+static u64 syn_pk_fixcap(u64 n) { return std::max<u64>(65536, (n / 4 + 1) & ~(u64)1); }
 
 // One launch of the planned kernel into res.  ev0/ev1 (optional) bracket the kernel itself.
 static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_result *res, int circ_ext, const Plan &pl,
@@ -1364,10 +1379,11 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     a.ticket = ctx->d_ticket;
     a.total = ctx->d_total;
     a.ring_w = pl.ring_w;
-    int rc = ensure_scratch(ctx, std::max<u32>(pl.which == K_MIN_PK ? 2 * pl.nunits : pl.slab ? 1 : pl.nunits, pl.mixed ? pl.side_nunits : 0), pl.ring_entries);
+    int rc = ensure_scratch(ctx, std::max<u32>(pl.which == K_MIN_PK ? 2 * pl.nunits : pl.which == K_SYN_PK ? (u32)(syn_pk_fixcap(b->n) / 2) : pl.slab ? 1 : pl.nunits, pl.mixed ? pl.side_nunits : 0), pl.ring_entries);
     if (rc != BSK_OK) return rc;
     a.lookback = ctx->d_lookback;
-    a.fixlist = ctx->d_lookback;  // K_MIN_PK (a slab kernel: no look-back) keeps its list of unfinished units there
+    a.fixlist = ctx->d_lookback;
+    a.fixcap = pl.which == K_SYN_PK ? (u32)syn_pk_fixcap(b->n) : 0u;  // K_MIN_PK (a slab kernel: no look-back) keeps its list of unfinished units there
     a.ring_h = ctx->d_ring_h;
     a.ring_p = ctx->d_ring_p;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket, 0, 8 * sizeof(u32), ctx->stream));
@@ -1393,6 +1409,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_PROT_HASH: hipLaunchKernelGGL(k_prot_hash, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_PROT_MIN: hipLaunchKernelGGL(k_prot_minimizer, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_SYN_FAST: fast_syncmer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
+        case K_SYN_PK: pk_syncmer_launch(pl.fast_w, pl.grid, std::min(pl.grid, ctx->cus * 8), ctx->stream, a); break;
         case K_PROT_MIN_FAST:
             if (pl.fused_dna) {
                 a.frame = p->frame;
@@ -1554,13 +1571,15 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
             ctx->err = "result capacity overflow after exact re-size";
             return cleanup(BSK_ERR_DEVICE);
         }
-        if (pl.which == K_PROT_MIN_FAST || pl.which == K_MIN_DENSE) {  // a sequence outgrew its slab (unusual density): re-plan without that kernel
+        if (pl.which == K_PROT_MIN_FAST || pl.which == K_MIN_DENSE || (pl.which == K_SYN_PK && (ovf & 2u))) {  // a sequence outgrew its slab (unusual density), or too many reads with key ties: re-plan without that kernel
             ctx->no_prot_fast = true;
             ctx->no_dense = true;
+            ctx->no_syn_pk = true;
             pl = Plan();  // not just `which`: the slab fields of the abandoned plan must go too (they size the look-back scratch)
             rc = make_plan(ctx, b, p, pl);
             ctx->no_prot_fast = false;
             ctx->no_dense = false;
+            ctx->no_syn_pk = false;
             if (rc != BSK_OK) return cleanup(rc);
             cap = pl.slab ? pl.slab_total + std::max<u64>(65536, pl.slab_total / 50) : estimate_cap(b, p, circ_ext);
             continue;

@@ -34,6 +34,12 @@ bool fast_syncmer_supported(int k, int s);
 int fast_syncmer_blocks_per_cu(int w);
 void fast_syncmer_launch(int w, int grid, hipStream_t stream, const KArgs &a);
 
+bool pk_syncmer_supported(int w);  // packed window machine, three waves per SIMD (kernels_syncmer_pk.hpp)
+u32 pk_syncmer_max_bases();
+u32 pk_syncmer_pair_rows();
+int pk_syncmer_blocks_per_cu(int w);
+void pk_syncmer_launch(int w, int grid, int fix_grid, hipStream_t stream, const KArgs &a);
+
 bool fast_prot_supported(int w, int k);
 int fast_prot_blocks_per_cu(int w, int k);
 void fast_prot_launch(int w, int k, int grid, hipStream_t stream, const KArgs &a);

@@ -365,9 +365,8 @@ struct PkMin {
 // dependent LDS round trips per trip of four rows, 5.5 trips per unit.  Here the head words are read ONCE (lane c keeps word c, a row
 // takes its word with v_readlane: no LDS), and a trip is U = 8 rows, so a unit is three trips of two round trips (table entries, then
 // the staged tuples).
-template <int U>
+template <int U, class LY = PkLds>
 __device__ __forceinline__ void pk_copyout(char *lds, int lane, u32 cnt, u32 excl, u32 T, u64 base, const KArgs &a) {
-    typedef PkLds LY;
     constexpr int NH = LY::NHEADS;
     u64 *s_heads = reinterpret_cast<u64 *>(lds + LY::HEADS);
     u64 *s_tab64 = reinterpret_cast<u64 *>(lds + LY::CTAB);

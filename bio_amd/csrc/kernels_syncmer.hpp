@@ -297,7 +297,10 @@ struct FastSyn {
 };
 
 
-template <int W>
+// LIST: the READS k_syncmer_pk listed in a.fixlist (u32 read numbers; count in a.ticket[4], ticket counter a.ticket[5]) -- reads in
+// which two equal 27-bit s-mer keys met in a min operation, or whose staging column filled up -- 64 per wavefront, on this kernel's
+// 64-bit machine; their tuples go to the overflow region.
+template <int W, bool LIST = false>
 __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves per SIMD: at most 256 VGPRs.  One wave with 512 registers
                                                                     // removes the W >= 13 spills but runs 1.5x slower (432 -> 284 Gbases/s at W = 20)
     constexpr int CAP = BSK_SYN_CAP;
@@ -311,17 +314,22 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves p
     const u64 slab = (u64)64 * CAP;
     u64 d_next = 0;
     bool pre = false;
-    for (u32 unit = next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; unit < a.nunits; ++unit, ({
-             if (unit == uend) {
+    const u32 nlist = LIST ? (a.ticket[4] < a.fixcap ? a.ticket[4] : a.fixcap) : 0u;
+    const u32 *const rlist = reinterpret_cast<const u32 *>(a.fixlist);
+    for (u32 unit = LIST ? next_ticket(a.ticket + 5, lane) : next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; LIST ? unit < (nlist + 63u) / 64u : unit < a.nunits; ++unit, ({
+             if (LIST) {
+                 unit = next_ticket(a.ticket + 5, lane);
+             } else if (unit == uend) {
                  unit = next_ticket(a.ticket, lane) * 8u;
                  uend = unit + 8u;
              }
          })) {
-        const u64 r = (u64)unit * 64 + lane;
+        u64 r = (u64)unit * 64 + lane;
+        if (LIST) r = r < nlist ? (u64)rlist[r] : ~0ULL;
         // the next unit's descriptors are loaded one unit ahead (a load issued here waits for the copy-out stores to drain)
-        const u64 d = pre ? d_next : (r < a.n ? a.desc[r] : 0);
+        const u64 d = (pre && !LIST) ? d_next : (r < a.n ? a.desc[r] : 0);
         const u64 off = d >> 24, L = d & 0xffffffULL;
-        pre = unit + 1 != uend && unit + 1 < a.nunits;
+        pre = !LIST && unit + 1 != uend && unit + 1 < a.nunits;
         if (pre) d_next = r + 64 < a.n ? a.desc[r + 64] : 0;
         const long long Lorig = (long long)L - a.circ_ext;
         const bool ok = r < a.n && Lorig >= 0 && Lorig >= 2LL * a.k - a.s - 1 && L >= (u64)a.k;  // sketch.go:149
@@ -346,12 +354,15 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves p
         const u32 T = wave_bcast_u32(incl, 63);
         const bool any_over = __builtin_amdgcn_ballot_w64(cnt > (u32)CAP) != 0;
         u64 base = (u64)unit * slab;
-        if (!any_over) {
-            fast_copyout<LY, true, CAP, 4>(lds, lane, cnt, excl, T, base, a);
-        } else {
-            u64 ob = 0;
+        u64 ob = 0;
+        if (LIST || any_over) {
             if (lane == 0) ob = atomicAdd(a.total + 1, (u64)T);
             ob = wave_bcast_u64(ob, 0);
+        }
+        if (LIST && ob + T <= a.ovf_cap) base = a.ovf_base + ob;
+        if (!any_over && (!LIST || ob + T <= a.ovf_cap)) {
+            fast_copyout<LY, true, CAP, 4>(lds, lane, cnt, excl, T, base, a);
+        } else {
             if (ob + T <= a.ovf_cap) {
                 base = a.ovf_base + ob;
                 FastSyn<W, CAP, true> fs;

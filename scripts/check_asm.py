@@ -4,7 +4,7 @@
 1. Every inline-asm block that contains an SALU instruction writing SCC (s_and/s_or/s_xor/s_add/s_sub/s_lshl/s_lshr/s_bcnt/s_cmp ...)
    names "scc" in its clobber list.  (Round 2: a tie chain without the clobber lost whole reads' tuples in 6 % of the fuzz cases --
    the compiler kept a loop condition in SCC across the block.)
-2. The loads k_minimizer_pk issues from inline asm are invisible to the compiler's s_waitcnt pass (on purpose, kernels_pk.hpp).  In the
+2. The loads k_minimizer_pk / k_syncmer_pk issue from inline asm are invisible to the compiler's s_waitcnt pass (on purpose, kernels_pk.hpp).  In the
    generated ISA, between such a load and the hand-written `s_waitcnt vmcnt(0)` that follows it in the text, no instruction may
    mention the load's destination registers: a copy or a use placed there would read registers whose data has not arrived.
    (A linear scan of the text: conservative, it knows nothing of the control flow.)
@@ -51,11 +51,11 @@ def regs(operand_text):
     return out
 
 
-def check_hidden_loads(ws=("11",)):
+def check_hidden_loads(ws=("11",), unit="k_minimizer_pk", macro="BSK_PK_WS"):
     bad = []
     for w in ws:
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(CSRC, "..", "..", "include"),
-               f"-DBSK_PK_WS(X)=X({w})", "-S", "--cuda-device-only", "-o", "-", os.path.join(CSRC, "k_minimizer_pk.hip")]
+               f"-D{macro}(X)=X({w})", "-S", "--cuda-device-only", "-o", "-", os.path.join(CSRC, unit + ".hip")]
         p = subprocess.run(cmd, capture_output=True, text=True)
         if p.returncode != 0:
             return [f"hipcc failed for w={w}: {p.stderr[-400:]}"]
@@ -74,7 +74,7 @@ def check_hidden_loads(ws=("11",)):
                 continue
             code = s.split(";")[0]
             if in_asm:
-                if code.startswith("global_load"):
+                if code.startswith("global_load") and not code.startswith("global_load_lds"):  # (LDS-DMA has no VGPR destination)
                     dst = code.split()[1].rstrip(",")
                     for r in regs(dst):
                         pending[r] = n
@@ -92,6 +92,6 @@ def check_hidden_loads(ws=("11",)):
 
 
 if __name__ == "__main__":
-    errs = check_scc() + check_hidden_loads(tuple(sys.argv[1:]) or ("11",))
+    errs = check_scc() + check_hidden_loads(tuple(sys.argv[1:]) or ("11",)) + check_hidden_loads(("20",), "k_syncmer_pk", "BSK_SYNPK_WS")
     print("\n".join(errs) if errs else "asm checks: ok")
     sys.exit(1 if errs else 0)
