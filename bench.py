@@ -404,12 +404,15 @@ def main():
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "frac_of_6.29TBps_copy_ceiling": round(achieved / HBM_COPY_GBS, 4),
                 "read_only_frac": round(in_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "valu_util": prof.get("valu_util") if prof else None,
+                "valu": prof.get("valu") if prof else None,
+                "binding_ceiling": (("valu-issue" if (prof.get("valu") or {}).get("frac", 0) > achieved / HBM_PEAK_GBS else "hbm") if prof and prof.get("valu") else None),
                 "profile": ({"dir": "profiles/" + prof["profile"], "kernel": prof.get("kernel"),
                              "kernel_matches_this_run": prof.get("kernel", "").split("<")[0] == kern.split("<")[0] and (prof.get("kernel", "") in kern or kern in prof.get("kernel", ""))}
                             if prof else None),
                 "note": NOTES[kind] + "; frac is vs the 8 TB/s spec peak; read_only_frac = input bytes alone over the same peak "
-                                      "(north_star's 'HBM-read roofline'); valu_util = SQ_ACTIVE_INST_VALU*4/SQ_BUSY_CU_CYCLES of the committed PMC pass",
+                                      "(north_star's 'HBM-read roofline'); `bound`/`achieved`/`peak` are the HBM roofline of the contract; `valu` is the VALU-issue "
+                                      "roofline of the committed PMC pass (SQ_INSTS_VALU x the mean issue cost of the kernel's inner-loop instruction mix, "
+                                      "scripts/valu_model.py, over the dispatch's SIMD-cycles) and `binding_ceiling` names the larger of the two fractions",
             }
         if world == 1 and not args.no_cpu_baseline and not args.plumbing_only:
             out["cpu_baseline"] = cpu_baseline(kind, k, x, read_len, batch)

@@ -13,10 +13,15 @@ import bench  # noqa: E402  (WORKLOADS table)
 
 # the sketch kernel family each workload's plan lands on (only used to pick that kernel's rows out of the CSVs; the full
 # instantiated name is read from the rows themselves)
-FAMILY = {"min": "k_minimizer_", "nt": "k_nthash_fast", "syn": "k_syncmer_fast", "pmin": "k_prot_minimizer_fast", "kmer": "k_nthash_fast",
+FAMILY = {"min": "k_minimizer_pk<", "nt": "k_nthash_fast", "syn": "k_syncmer_pk<", "pmin": "k_prot_minimizer_fast", "kmer": "k_nthash_fast",
           "phash": "k_prot_hash_fast", "sim": "k_simhash_fast"}
 
 out_dir, workloads = sys.argv[1], sys.argv[2].split()
+VALU_MODEL = {}
+for cand in (os.path.join(out_dir, "valu_model.json"), os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "valu_model.json")):
+    if os.path.exists(cand):
+        VALU_MODEL = json.load(open(cand)).get("kernels", {})
+        break
 entries = []
 for w in workloads:
     kind, n_reads = bench.WORKLOADS[w][0], bench.WORKLOADS[w][1]
@@ -47,9 +52,20 @@ for w in workloads:
     # VALU utilisation: wave-instructions issued to the VALU (one quad-cycle each) over the SIMD-cycles of the dispatch
     # (256 CUs x 4 SIMDs x the shader clock cycles GRBM_GUI_ACTIVE counts per XCD; 8 XCDs are summed in the CSV)
     sqp = os.path.join(out_dir, f"bench_{w}_pmc_sq.csv")
-    va, gui = mean_counter(sqp, "SQ_ACTIVE_INST_VALU"), mean_counter(sqp, "GRBM_GUI_ACTIVE")
-    valu_util = round(va * 4 / (gui / 8 * 1024), 4) if va and gui else None
-    entries.append({"workload": w, "reads_per_gpu": n_reads, "kernel": full["name"], "valu_util": valu_util,
+    va, gui, vi = mean_counter(sqp, "SQ_ACTIVE_INST_VALU"), mean_counter(sqp, "GRBM_GUI_ACTIVE"), mean_counter(sqp, "SQ_INSTS_VALU")
+    # VALU-issue roofline: wave-instructions issued (SQ_INSTS_VALU) x the mean issue cost of the kernel's inner-loop instruction mix
+    # (scripts/valu_model.py: 2.0 cycles for VOP1/VOP2/v_bitop3, 3.5 for VOP3 forms, 4.0 for 64-bit / multiplier ops -- the rates
+    # measured in scripts/ubench) over the SIMD-cycles of the dispatch (1024 SIMDs x the shader cycles GRBM_GUI_ACTIVE counts per XCD)
+    valu = None
+    vm = VALU_MODEL.get(w, {})
+    if vi and gui and "cycles_per_inst" in vm:
+        simd_cycles = gui / 8 * 1024
+        units = n_reads * bench.WORKLOADS[w][2]
+        valu = {"wave_insts": vi, "cycles_per_inst": vm["cycles_per_inst"], "vop3_frac": vm["vop3_frac"], "issue_cycles": vi * vm["cycles_per_inst"],
+                "simd_cycles": simd_cycles, "frac": round(vi * vm["cycles_per_inst"] / simd_cycles, 4),
+                "issue_cycles_per_unit": round(vi * vm["cycles_per_inst"] / units, 5), "insts_per_unit": round(vi / units, 4),
+                "shader_clock_GHz": round(gui / 8 / (kms * 1e-3) / 1e9, 3) if kms else None}
+    entries.append({"workload": w, "reads_per_gpu": n_reads, "kernel": full["name"], "valu": valu,
                     "SQ_ACTIVE_INST_VALU": va, "GRBM_GUI_ACTIVE_sum_over_xcds": gui, "FETCH_SIZE_KiB_mean": round(f), "WRITE_SIZE_KiB_mean": round(wr),
                     "fetch_bytes_corrected": int(f * 1024 * 2), "write_bytes": int(wr * 1024), "hbm_bytes_per_launch": int(f * 2048 + wr * 1024),
                     "rocprof_kernel_ms_avg": kms})
