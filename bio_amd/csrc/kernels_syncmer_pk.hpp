@@ -186,9 +186,11 @@ struct SynPk {
             vb = nv >= 32u ? 0xffffffffu : (1u << nv) - 1u;
         }
         // table rows: XC steps' worth (both tables) are requested one chunk ahead of their use -- a row requested where it is rolled in
-        // exposes the LDS latency twice per step (measured: 570 Gbases/s at twelve waves per CU against 697 for k_syncmer_fast at eight)
+        // exposes the LDS latency twice per step.  One step ahead is enough at twelve waves per CU, and the registers matter more:
+        // chunks of 4 / 3 / 2 / 1 steps spill 172 / 128 / 72 / 12 bytes under the 168-VGPR cap and run 846 / 934 / 939 / 968 Gbases/s
+        // (spills inside the block loop are HBM traffic: 43 GB per launch against 17 GB algorithmic with chunks of 4)
 #ifndef SYNPK_XC
-#define SYNPK_XC 4
+#define SYNPK_XC 1
 #endif
         constexpr int XC = SYNPK_XC;
         u32x4 xs[W], xk[W];
