@@ -306,9 +306,15 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
             };
             for (u32 i0 = 0; i0 < nk_max; i0 += MB) {
                 u64 raw[MB / 4];  // DNA: the next macro block's packed words are requested here, a whole block of hashing ahead of their use
+                u32 nextR[MB / 4];  // protein: the same for the next macro block's residues (round 3: they were requested after the
+                                    // block and waited for at once -- an exposed L2 / HBM round trip every MB steps)
                 if (DNA) {
 #pragma unroll
                     for (int g = 0; g < MB / 4; ++g) raw[g] = dna_issue(dj + (u32)g);
+                } else {
+#ifndef PROT_NO_AHEAD
+                    load_dwords(nextR, MB / 4, dj);
+#endif
                 }
                 if (HS < MB) {
                     if (i0 == 0) fp.template macro<true, 0, HS>(i0);
@@ -328,7 +334,12 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
 #pragma unroll
                     for (int g = 0; g < MB / 4; ++g) fp.R[5 + g] = dna_finish(raw[g], dj + (u32)g);
                 } else {
+#ifndef PROT_NO_AHEAD
+#pragma unroll
+                    for (int g = 0; g < MB / 4; ++g) fp.R[5 + g] = nextR[g];
+#else
                     load_dwords(fp.R + 5, MB / 4, dj);
+#endif
                 }
                 dj += MB / 4;
 #pragma unroll

@@ -22,6 +22,9 @@
 #include "host_types.hpp"
 
 namespace {
+std::mutex g_h2d_mutex[16], g_d2h_mutex[16];  // per device: one copy per direction at a time (run_pipeline)
+const bool g_copy_locks = getenv("BSK_PIPE_NO_COPY_LOCKS") == nullptr;  // dev: A/B without them
+
 
 using clk = std::chrono::steady_clock;
 inline double secs(clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); }
@@ -390,7 +393,14 @@ int run_pipeline(int device, SourceSet &set, int n_producers, const bsk_params *
                 auto t0 = clk::now();
                 Slot *sl = c->slot;
                 int rc = sl->src->materialize(c);
-                if (rc == BSK_OK) rc = bsk_batch_refill_ascii(ctx, &batch, (const uint8_t *)c->bytes.p, (const uint64_t *)c->offs.p, c->n, c->alphabet);
+                if (rc == BSK_OK) {
+                    // ONE host-to-device copy in flight per device, and one device-to-host (below): the link moves 48 + 48 GB/s with one
+                    // large-copy stream per direction and 17 + 31 .. 24 + 43 when n streams interleave 39-MB and 46 + 23-MB copies both
+                    // ways (scripts/ubench/pcie.py).  The kernels and the host-side work of other chunks still overlap the copies.
+                    std::unique_lock<std::mutex> lk(g_h2d_mutex[device & 15], std::defer_lock);
+                    if (g_copy_locks) lk.lock();
+                    rc = bsk_batch_refill_ascii(ctx, &batch, (const uint8_t *)c->bytes.p, (const uint64_t *)c->offs.p, c->n, c->alphabet);
+                }
                 c->slot = nullptr;
                 if (--sl->inflight == 0 && sl->finished.load()) close_once(sl);
                 const uint64_t n = c->n, nb = c->nbytes;
@@ -405,8 +415,11 @@ int run_pipeline(int device, SourceSet &set, int n_producers, const bsk_params *
                 if (rc == BSK_OK) rc = bsk_result_info(res, &nr, &nt, &hp);
                 if (rc == BSK_OK && fetch) {
                     if (!o_off.ensure((nr + 1) * 8) || !o_st.ensure(nr + 1) || !o_hash.ensure((nt + 1) * 8) || (hp && !o_pos.ensure((nt + 1) * 4))) rc = BSK_ERR_NOMEM;
-                    if (rc == BSK_OK)
+                    if (rc == BSK_OK) {
+                        std::unique_lock<std::mutex> lk(g_d2h_mutex[device & 15], std::defer_lock);
+                        if (g_copy_locks) lk.lock();
                         rc = bsk_result_fetch(ctx, res, 0, nr, (uint64_t *)o_off.p, (uint8_t *)o_st.p, (uint64_t *)o_hash.p, hp ? (uint32_t *)o_pos.p : nullptr, nt + 1);
+                    }
                     static const bool nodigest = getenv("BSK_PIPE_NO_DIGEST") != nullptr;  // dev: the run without the consumer stand-in (checksum stays 0)
                     if (rc == BSK_OK && !nodigest) {  // the caller's consumer would start here; the statistics keep an order-independent digest
                         const uint64_t *h = (const uint64_t *)o_hash.p, *oo = (const uint64_t *)o_off.p;
