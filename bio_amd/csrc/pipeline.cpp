@@ -23,7 +23,10 @@
 
 namespace {
 std::mutex g_h2d_mutex[16], g_d2h_mutex[16];  // per device: one copy per direction at a time (run_pipeline)
-const bool g_copy_locks = getenv("BSK_PIPE_NO_COPY_LOCKS") == nullptr;  // dev: A/B without them
+// Measured (scripts/perf_e2e.py, 3.2e7 reads from host memory, 3 / 5 / 8 streams x chunks of 2^18..2^20 records): 12.0 / 12.6 / 10.4 Gbases/s
+// with the locks, 13.5 / 12.1 / 10.6 without -- the workers are bound by their own host-side work (the copy into pinned memory, the
+// pass over the fetched tuples), not by interleaved copies.  Off unless BSK_PIPE_COPY_LOCKS is set.
+const bool g_copy_locks = getenv("BSK_PIPE_COPY_LOCKS") != nullptr;
 
 
 using clk = std::chrono::steady_clock;
