@@ -80,3 +80,37 @@ def test_reference_fastq_and_protein_fasta(engine, oracle, tmp_path):
     for i in range(2):
         _, h, _ = res.read(i)
         assert np.array_equal(h, oracle.protein_hashes(want[i][1], 9))
+
+
+def test_read_hands_out_the_guessed_alphabet(engine, oracle, tmp_path):
+    """Reader.Read() (reader.go:233, :430-435): the record's Seq carries the alphabet GUESSED from the file's first sequence -- the
+    two-strand k-mer mode pairs letters with it (iterator.go:719), so a DNAredundant / RNA / RNAredundant file must not come out as
+    plain DNA ('R' pairs with 'Y' in DNAredundant and stays 'R' in DNA)."""
+    from bio_amd import sketches as S
+    cases = {"dnar.fa": (b">a\nACGTRYACGTNNACGTKMACGTACGTAC\n>b\nACGTACGTACGTRACGTACGTYACG\n", S.DNAredundant, L.ALPHA_DNA),
+             "rna.fa": (b">a\nACGUACGUACGUACGUACGUACGU\n>b\nUUUACGACGACGUUUACGACG\n", S.RNA, L.ALPHA_RNA),
+             "rnar.fa": (b">a\nACGURYACGUNNACGUKMACGUACGUAC\n>b\nACGUACGUACGURACGUACGUYACG\n", S.RNAredundant, L.ALPHA_RNA_REDUNDANT),
+             "dna.fa": (b">a\nACGTACGTACGTACGTACGTACGT\n>b\nTTTACGACGACGTTTACGACG\n", S.DNA, L.ALPHA_DNA_PLAIN)}
+    for name, (text, want_alpha, code) in cases.items():
+        p = tmp_path / name
+        p.write_bytes(text)
+        rd = fastx.Reader(str(p))
+        recs = []
+        while True:
+            rec, err = rd.Read()
+            if rec is None:
+                break
+            recs.append(rec)
+        assert len(recs) == 2
+        for rec in recs:
+            assert rec.Seq.Alphabet is want_alpha, (name, rec.Seq.Alphabet)
+            it, err = S.NewKmerIterator(rec.Seq, 7, False, False, engine)
+            assert err is None
+            got = []
+            while True:
+                c, ok, e = it.NextKmer()
+                if not ok:
+                    break
+                got.append(c)
+            want = oracle.kmer_codes(bytes(rec.Seq.Seq).decode(), 7, False, False, code)
+            assert got == [int(x) for x in want], name
