@@ -1017,7 +1017,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.slab_unit = 64 * pl.slab_read;
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
             per_cu = dense_minimizer_blocks_per_cu(p->w);
-        } else if (!use_ascii && pk_minimizer_supported(p->w) && b->maxlen < 32768u && !ctx->opt.force_generic && !ctx->opt.no_pk) {
+        } else if (!use_ascii && pk_minimizer_supported(p->w) && b->maxlen < 32768u && !ctx->opt.force_generic && !ctx->opt.no_pk && !ctx->no_syn_pk) {
             pl.which = K_MIN_PK;  // w <= 16: packed 32-bit window machine (kernels_pk.hpp)
             pl.fast_w = p->w;
             pl.fast_k = b->maxlen > pk_minimizer_short_bases() ? 1 : 0;  // (the kernel's LONG argument, for plan_name)
@@ -1340,7 +1340,8 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
     res->plan_per_cu = cus > 0 ? (pl.grid + cus - 1) / cus : 0;
 }
 
-// k_syncmer_pk's list of reads for the exact machine: room for a quarter of the batch (a batch with more falls back to k_syncmer_fast)
+// k_syncmer_pk's / k_minimizer_pk's list of reads for the exact machine: room for a quarter of the batch (a batch with more falls back
+// to k_syncmer_fast / k_minimizer_fast)
 static u64 syn_pk_fixcap(u64 n) { return std::max<u64>(65536, (n / 4 + 1) & ~(u64)1); }
 
 // One launch of the planned kernel into res.  ev0/ev1 (optional) bracket the kernel itself.
@@ -1379,11 +1380,16 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     a.ticket = ctx->d_ticket;
     a.total = ctx->d_total;
     a.ring_w = pl.ring_w;
-    int rc = ensure_scratch(ctx, std::max<u32>(pl.which == K_MIN_PK ? 2 * pl.nunits : pl.which == K_SYN_PK ? (u32)(syn_pk_fixcap(b->n) / 2) : pl.slab ? 1 : pl.nunits, pl.mixed ? pl.side_nunits : 0), pl.ring_entries);
+    int rc = ensure_scratch(ctx, std::max<u32>(pl.which == K_MIN_PK ? 2 * pl.nunits + (u32)(syn_pk_fixcap(b->n) / 2) : pl.which == K_SYN_PK ? (u32)(syn_pk_fixcap(b->n) / 2) : pl.slab ? 1 : pl.nunits, pl.mixed ? pl.side_nunits : 0), pl.ring_entries);
     if (rc != BSK_OK) return rc;
     a.lookback = ctx->d_lookback;
     a.fixlist = ctx->d_lookback;
-    a.fixcap = pl.which == K_SYN_PK ? (u32)syn_pk_fixcap(b->n) : 0u;  // K_MIN_PK (a slab kernel: no look-back) keeps its list of unfinished units there
+    a.fixcap = (pl.which == K_SYN_PK || pl.which == K_MIN_PK) ? (u32)syn_pk_fixcap(b->n) : 0u;
+    a.rlist = reinterpret_cast<u32 *>(ctx->d_lookback + 2 * (size_t)pl.nunits);  // K_MIN_PK: behind its {unit, lane mask} entries
+    if (pl.which == K_MIN_PK) {  // slab of a listed read (k_minimizer_dense<W, true>): one tuple per window, whole 128-byte lines
+        const u64 nwin_max = b->maxlen + 2 > (u32)(p->k + p->w) ? (u64)b->maxlen - p->k - p->w + 2 : 1;
+        a.slab_read = (nwin_max + 15) & ~(u64)15;
+    }  // K_MIN_PK (a slab kernel: no look-back) keeps its list of unfinished units there
     a.ring_h = ctx->d_ring_h;
     a.ring_p = ctx->d_ring_p;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket, 0, 8 * sizeof(u32), ctx->stream));
@@ -1571,7 +1577,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
             ctx->err = "result capacity overflow after exact re-size";
             return cleanup(BSK_ERR_DEVICE);
         }
-        if (pl.which == K_PROT_MIN_FAST || pl.which == K_MIN_DENSE || (pl.which == K_SYN_PK && (ovf & 2u))) {  // a sequence outgrew its slab (unusual density), or too many reads with key ties: re-plan without that kernel
+        if (pl.which == K_PROT_MIN_FAST || pl.which == K_MIN_DENSE || ((pl.which == K_SYN_PK || pl.which == K_MIN_PK) && (ovf & 2u))) {  // a sequence outgrew its slab (unusual density), or too many reads with key ties: re-plan without that kernel
             ctx->no_prot_fast = true;
             ctx->no_dense = true;
             ctx->no_syn_pk = true;

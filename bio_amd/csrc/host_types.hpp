@@ -46,7 +46,7 @@ struct bsk_ctx {
     void *comm = nullptr;  // ncclComm_t
     int comm_rank = 0, comm_world = 0;
     u64 *d_comm = nullptr;  // [(world + 1) * BSK_MAX_COUNTERS] device staging of bsk_gather_counts
-    bool no_syn_pk = false;     // set while a call falls back from k_syncmer_pk (its list of reads for the exact machine filled up)
+    bool no_syn_pk = false;     // set while a call falls back from k_syncmer_pk / k_minimizer_pk (the list of reads for the exact machine filled up)
     bool no_prot_fast = false;
     bool no_dense = false;      // same for the dense-minimizer kernel (per-read slabs)  // set while a call falls back from the per-sequence-slab protein kernel
 };

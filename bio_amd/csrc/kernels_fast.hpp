@@ -478,7 +478,10 @@ __device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 e
     wave_sync_lds();
 }
 
-template <int W, int CAP, bool POS16>
+// LIST: the READS k_minimizer_pk listed in a.rlist (u32 read numbers, count in a.ticket[6], ticket counter a.ticket[7]) -- reads in
+// which two equal 27-bit keys met in a min operation (real ties among them: low-complexity reads) -- 64 per wavefront, on this
+// kernel's 64-bit machine; their tuples go to the overflow region.
+template <int W, int CAP, bool POS16, bool LIST = false>
 __global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs a) {  // W >= 16: capped at 256 VGPRs (two waves per SIMD)
     constexpr bool PAIR = POS16;  // paired staging columns (8 waves per CU); 32-bit positions keep the private columns
     typedef typename MinLds<PAIR, CAP, POS16, BSK_PAIR_ROWS>::type LY;
@@ -498,13 +501,20 @@ __global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs 
     u32x4 pw_next = {0, 0, 0, 0};
     bool pre = false;
     // work distribution: a wave takes 8 consecutive units per ticket (one atomic per 512 reads)
-    for (u32 unit = next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; unit < a.nunits; ++unit, ({
-             if (unit == uend) {
+    const u32 nlist = LIST ? (a.ticket[6] < a.fixcap ? a.ticket[6] : a.fixcap) : 0u;
+    for (u32 unit = LIST ? next_ticket(a.ticket + 7, lane) : next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; LIST ? unit < (nlist + 63u) / 64u : unit < a.nunits; ++unit, ({
+             if (LIST) {
+                 unit = next_ticket(a.ticket + 7, lane);
+             } else if (unit == uend) {
                  unit = next_ticket(a.ticket, lane) * 8u;
                  uend = unit + 8u;
              }
          })) {
-        const u64 r = (u64)unit * 64 + lane;
+        u64 r = (u64)unit * 64 + lane;
+        if (LIST) {
+            r = r < nlist ? (u64)a.rlist[r] : ~0ULL;
+            pre = false;  // (no look-ahead over a list)
+        }
         // The descriptor and the first four words of a unit are loaded one unit ahead (within a ticket): a load issued at
         // the unit's start returns only after the previous unit's copy-out stores have drained (loads and stores share the
         // in-order vmcnt) and then costs two dependent memory latencies before the first base can be hashed.
@@ -518,7 +528,7 @@ __global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs 
             pw = *reinterpret_cast<const GLBQ u32x4_u *>((size_t)(a.words + (d >> 24)));
         }
         const u64 off = d >> 24, L = d & 0xffffffULL;
-        const bool nxt = unit + 1 != uend && unit + 1 < a.nunits;
+        const bool nxt = !LIST && unit + 1 != uend && unit + 1 < a.nunits;
         if (nxt) d_next = r + 64 < a.n ? a.desc[r + 64] : 0;
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
         const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
@@ -546,7 +556,18 @@ __global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs 
         const u32 cnt_pair = PAIR ? cnt + (u32)__builtin_amdgcn_ds_bpermute((lane ^ 32) * 4, (int)cnt) : 0u;
         const bool any_over = PAIR ? __builtin_amdgcn_ballot_w64(cnt_pair >= (u32)BSK_PAIR_ROWS) != 0 : __builtin_amdgcn_ballot_w64(cnt > (u32)CAP) != 0;
         u64 base = (u64)unit * slab;
-        if (!any_over) {
+        bool list_fits = true;
+        if (LIST && !any_over) {  // listed reads leave through the overflow region
+            u64 ob = 0;
+            if (lane == 0) ob = atomicAdd(a.total + 1, (u64)T);
+            ob = wave_bcast_u64(ob, 0);
+            list_fits = ob + T <= a.ovf_cap;
+            if (list_fits) base = a.ovf_base + ob;
+            else if (lane == 0) atomicOr(&a.ticket[1], 1u);
+            if (!list_fits) cnt = 0;
+        }
+        if (!any_over && !list_fits) {
+        } else if (!any_over) {
             // copy-out rows in flight: what keeps the kernel within 256 VGPRs (two waves per SIMD)
 #ifndef BSK_FAST_NOCOPYOUT
             if (PAIR) fast_copyout<LY, POS16, LY::NHEADS - 1, (W <= 11 ? 4 : W <= 15 ? 2 : 1), true>(lds, lane, cnt, excl, T, base, a);
@@ -757,23 +778,33 @@ struct DenseCfg {
     static constexpr int CAP = NB * W + G - 1;              // rows = CAP + 1: the left-over of a group + NB*W new + the scribble row
 };
 
-template <int W>
+// LIST: the READS k_minimizer_pk listed in a.rlist (u32 read numbers, count in a.ticket[6], ticket counter a.ticket[7]) -- reads in
+// which two equal 27-bit keys met in a min operation.  Real ties are most of them on real data: low-complexity reads (poly-A / poly-G
+// tails, repeats), and a homopolymer selects EVERY position -- which is this kernel's case (per-read slabs, mid-read flushes), not
+// k_minimizer_fast's, whose staging columns such reads overflow.  64 listed reads per wavefront; every read gets a slab of
+// a.slab_read tuples (the caller passes the largest possible count) in the overflow region.
+template <int W, bool LIST = false>
 __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
     constexpr int CAP = DenseCfg<W>::CAP, NB = DenseCfg<W>::NB, GL = DenseCfg<W>::GL, G = DenseCfg<W>::G;
     typedef FLds<CAP, true> LY;
     __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
     LDSQ char *const ldsq = (LDSQ char *)lds;
     const int lane = lane_id();
+    const u32 nlist = LIST ? (a.ticket[6] < a.fixcap ? a.ticket[6] : a.fixcap) : 0u;
+    if (LIST && nlist == 0) return;
     build_xtab(reinterpret_cast<uint4 *>(lds + LY::TAB), a.k, lane);
     __syncthreads();
     const u64 slab_read = a.slab_read;
-    for (u32 unit = next_ticket(a.ticket, lane) * 4u, uend = unit + 4u; unit < a.nunits; ++unit, ({
-             if (unit == uend) {
+    for (u32 unit = LIST ? next_ticket(a.ticket + 7, lane) : next_ticket(a.ticket, lane) * 4u, uend = unit + 4u; LIST ? unit < (nlist + 63u) / 64u : unit < a.nunits; ++unit, ({
+             if (LIST) {
+                 unit = next_ticket(a.ticket + 7, lane);
+             } else if (unit == uend) {
                  unit = next_ticket(a.ticket, lane) * 4u;
                  uend = unit + 4u;
              }
          })) {
-        const u64 r = (u64)unit * 64 + lane;
+        u64 r = (u64)unit * 64 + lane;
+        if (LIST) r = r < nlist ? (u64)a.rlist[r] : ~0ULL;
         u64 off = 0, L = 0;
         if (r < a.n) {
             const u64 d = a.desc[r];
@@ -783,9 +814,18 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
         const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
         const u32 nk_max = wave_max_u32(nk);
-        const u64 ubase = (u64)unit * 64 * slab_read;
+        u64 ubase = (u64)unit * 64 * slab_read;
+        bool room = true;
+        if (LIST) {  // 64 slabs from the overflow region
+            u64 ob = 0;
+            if (lane == 0) ob = atomicAdd(a.total + 1, 64 * slab_read);
+            ob = wave_bcast_u64(ob, 0);
+            room = ob + 64 * slab_read <= a.ovf_cap;
+            if (!room && lane == 0) atomicOr(&a.ticket[1], 1u);  // the host re-runs with a larger overflow region
+            ubase = a.ovf_base + ob;
+        }
         u32 done = 0, tie = 0;
-        if (nk_max) {
+        if (nk_max && room) {
             FastMin<W, CAP, true, false, false, true> fm;
             fm.w = a.words + off;
             fm.send = (u32)((CAP + 1) * LY::ROW + lane) * 8u;

@@ -36,7 +36,8 @@ struct KArgs {
     u64 cap;  // capacity of hash[]/pos[] in tuples
     // synchronisation / scratch
     u32 *ticket;    // [0] unit ticket, [1] overflow flag, [2..3] the same for a side launch, [4] units listed for k_minimizer_pk_fix, [5] its ticket
-    u32 fixcap;     // k_syncmer_pk: entries (reads) fixlist holds
+    u32 fixcap;     // entries (reads) of the read list: k_syncmer_pk's fixlist, k_minimizer_pk's rlist
+    u32 *rlist;     // k_minimizer_pk: reads for the exact machine (k_minimizer_fast<.., LIST>), count in ticket[6], its ticket in ticket[7]
     u64 *fixlist;   // [2 * nunits]: {unit | flags, lane mask} of the lanes the packed minimizer kernel left to its fix pass (kernels_pk.hpp)
     u64 *lookback;  // [nunits]
     u64 *total;     // [0] tuples written by the dense (look-back) kernels, [1] overflow-region cursor (slab kernels)

@@ -41,7 +41,7 @@ __device__ __forceinline__ void pk_unroll(F &&f) {
 
 // LDS plan of one wavefront.  Paired columns as PLds (kernels_fast.hpp), but 58 rows instead of 56: a column fills up when its two
 // reads select 58 tuples together -- 0.8 % of the units at k=21 w=11, 150 bp, against 4.1 % with 56 rows (measured: the tail is
-// heavier than normal), and every such unit costs a pass of k_minimizer_pk_fix.  The room comes from laying the copy-out's tables
+// heavier than normal), and both reads of such a column go to the exact machine afterwards.  The room comes from laying the copy-out's tables
 // (head words, owner table) over the two hash-phase tables, which a wavefront keeps in four VGPRs and writes back at the start of
 // every unit (PkTabs).  20 248 B: still eight waves per CU.
 #ifndef BSK_PK_ROWS
@@ -442,15 +442,12 @@ __device__ __forceinline__ void pk_copyout(char *lds, int lane, u32 cnt, u32 exc
     wave_sync_lds();
 }
 
-// Lanes the main kernel could not finish go to a list (a.fixlist: {unit | flags, lane mask} per entry, count in a.ticket[4]):
-//   * the two lanes of a staging column that filled up (cnt(l) + cnt(l+32) >= 58 rows: 2.5e-4 of the columns, 0.8 % of the units at
-//     k=21 w=11, 150 bp).  The unit's other lanes leave normally; k_minimizer_pk_fix hashes the unit once more with only the listed
-//     lanes staging, each alone in a column of its own, and sends their tuples to the overflow region;
-//   * all lanes of a unit in which two equal 27-bit keys met in a min operation (2e-4 of the units): the exact 64-bit machine.
-// Kept out of the main kernel on purpose: with the re-run loop and the exact machine inlined there the same main loop ran 5 % slower
-// (registers, code), as a noinline call 20 % slower; and re-running such units with every tuple stored straight to HBM, as
-// k_minimizer_fast does, costs nine units' time each (2 800 partial-line writes).
-#define BSK_PK_FIX_TIE 0x80000000u
+// Reads the main kernel cannot finish -- a 27-bit key tie in one of their min operations, or a staging column that filled up -- go
+// to a list of READS (a.rlist, count in a.ticket[6]) and k_minimizer_dense<W, true>, the exact 64-bit machine with per-read slabs,
+// runs them afterwards, 64 per wavefront.  History (profiles/NOTEBOOK.md): the exact machine inlined here cost the main loop 5 %
+// (registers, code), as a noinline call 20 %; re-running a unit with every tuple stored straight to HBM, as k_minimizer_fast does,
+// costs nine units' time (2 800 partial-line writes); a per-UNIT second pass cost a whole pass for every unit with one low-complexity
+// read (2 % of the reads with a poly-A tail = 72 % of the units: 830 -> 650 Gbases/s).
 #ifndef PK_TICKET
 #define PK_TICKET 8u  // units per ticket
 #endif
@@ -502,8 +499,7 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
         const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
         const u32 nk_max = wave_max_u32(nk);
-        u32 cnt = 0;
-        bool any_tie = false;
+        u32 cnt = 0, tmin_lane = 0xffffffffu;
         if (nk_max) {
             tabs.write(ldsq);  // the previous copy-out's tables took their place
             PkMin<W, LONG> pm;
@@ -518,7 +514,7 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
             const u32 spare = (u32)LY::PR * RB + col8;
             pm.run(nk_max, ok, uniform, !ok ? spare : lane < 32 ? col8 : top, !ok ? 0 : lane < 32 ? (int)RB : -(int)RB, col8);
             if (ok) cnt = (lane < 32 ? pm.slot - col8 : top - pm.slot) / RB;
-            any_tie = __builtin_amdgcn_ballot_w64(ok && pm.tmin < 32u) != 0;
+            tmin_lane = pm.tmin;
         }
         pk_wait_loads(pw_n1, d_n2);  // the next unit's words and descriptor, requested a whole hashing phase ago, are in
         d_cur = d_n1;
@@ -527,18 +523,27 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
         have = nxt;
         const u32 cnt_pair = cnt + (u32)__builtin_amdgcn_ds_bpermute((lane ^ 32) * 4, (int)cnt);
         u64 bad = __builtin_amdgcn_ballot_w64(cnt_pair >= (u32)LY::PR);  // the column's last free row takes the unselected candidates
+        u64 tied = __builtin_amdgcn_ballot_w64(ok && tmin_lane < 32u);
 #if defined(PK_NOSTAGE) || defined(PK_NOTIE) || defined(PK_NOTAB) || defined(PK_NOCOPY) || defined(PK_NOSTORE) || defined(PK_NOFB)
         bad = 0;
-        any_tie = false;
+        tied = 0;
 #endif
-        if (any_tie) bad = ~0ULL;
-        if (bad) {
-            if (lane == 0) {
-                const u32 i = atomicAdd(&a.ticket[4], 1u);
-                a.fixlist[2 * (u64)i] = unit | (any_tie ? BSK_PK_FIX_TIE : 0u);
-                a.fixlist[2 * (u64)i + 1] = bad;
+        const u64 redo = bad | tied;
+        if (redo) {
+            // Reads this kernel cannot finish go to a list of READS for the exact 64-bit machine (k_minimizer_dense<W, true> gathers 64 per
+            // wavefront; per-read slabs, so it also takes reads that select every position): the reads with a key tie -- on real data
+            // mostly low-complexity reads (poly-A / poly-G tails: every k-mer the same hash), per cent of the reads, i.e. in most units,
+            // which is why the list is per read and not per unit -- and both reads of a column that filled up (0.8 % of the units on
+            // random reads; next to a homopolymer tail, always).  The unit's other lanes leave normally.
+            const u32 nr = (u32)__builtin_popcountll(redo);
+            u32 at = 0;
+            if (lane == 0) at = atomicAdd(&a.ticket[6], nr);
+            at = wave_bcast_u32(at, 0) + __builtin_amdgcn_mbcnt_hi((u32)(redo >> 32), __builtin_amdgcn_mbcnt_lo((u32)redo, 0));
+            if ((redo >> lane) & 1) {
+                if (at < a.fixcap) a.rlist[at] = (u32)r;
+                else atomicOr(&a.ticket[1], 2u);  // the list is full: the host runs the batch on k_minimizer_fast instead
+                cnt = 0;  // the list pass writes this read's reference word
             }
-            if ((bad >> lane) & 1) cnt = 0;  // k_minimizer_pk_fix writes these lanes' reference words
         }
         const u32 incl = wave_incl_scan_u32(cnt, lane);
         const u32 excl = incl - cnt;
@@ -551,131 +556,11 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
         if (T) pk_copyout<PK_CU>(lds, lane, cnt, excl, T, base, a);
 #endif
         if (r < a.n) {
-            a.refs[r] = ((base + excl) << 24) | cnt;
+            if (!((redo >> lane) & 1)) a.refs[r] = ((base + excl) << 24) | cnt;  // (listed reads: the list pass writes theirs)
             u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
             if (ok && a.rflags) sbyte |= a.rflags[r];
             a.status[r] = sbyte;
         }
-    }
-}
-
-template <int W, bool LONG>
-__global__ __launch_bounds__(64, 2) void k_minimizer_pk_fix(KArgs a) {
-    typedef PkLds LY;
-    __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
-    LDSQ char *const ldsq = (LDSQ char *)lds;
-    const int lane = lane_id();
-    const u32 nfix = a.ticket[4];
-    if (nfix == 0) return;
-    PkTabs tabs;
-    tabs.init(a.k, lane);
-    tabs.write(ldsq);  // (this kernel's copy-outs use no table: written once)
-    constexpr u32 RB = (u32)(LY::ROW * 8);
-    for (;;) {
-        const u32 t = next_ticket(a.ticket + 5, lane);
-        if (t >= nfix) break;
-        const u64 e = a.fixlist[2 * (u64)t];
-        u64 bad = a.fixlist[2 * (u64)t + 1];
-        const u32 unit = (u32)e & ~BSK_PK_FIX_TIE;
-        const u64 r = (u64)unit * 64 + lane;
-        const u64 d = r < a.n ? a.desc[r] : 0;
-        PkWords pw = pk_load_words(a.words + (d >> 24));
-        pk_wait_loads(pw);
-        const u64 off = d >> 24, L = d & 0xffffffULL;
-        const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
-        const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
-        const u32 nk_max = wave_max_u32(nk);
-        const bool mine = (bad >> lane) & 1;
-        u64 myref = 0;
-        u32 tie = 0;
-        bool exact = ((u32)e & BSK_PK_FIX_TIE) != 0;
-        if (!exact) {
-            // the listed lanes (at most 32 of them stage at a time) take the columns 0, 1, ... by their rank, each alone in its column
-            for (u64 todo = bad; todo && !exact;) {
-                const u32 rk = __builtin_amdgcn_mbcnt_hi((u32)(todo >> 32), __builtin_amdgcn_mbcnt_lo((u32)todo, 0));  // listed lanes below this one
-                const bool act = ok && ((todo >> lane) & 1) && rk < 32u;
-                const u32 c8 = (rk & 31u) * 8u, spare = (u32)LY::PR * RB + (u32)(lane & 31) * 8u;
-                PkMin<W, LONG> pm;
-                pm.w = a.words + off;
-                pm.set_words(pw);
-                pm.lds = ldsq;
-                pm.k = a.k;
-                pm.lane = lane;
-                pm.nk = nk;
-                pm.run(nk_max, act, a.uniform_len != 0, act ? c8 : spare, act ? (int)RB : 0, act ? c8 : (u32)(lane & 31) * 8u);
-                const u32 cnt = act ? (pm.slot - c8) / RB : 0u;
-                if (__builtin_amdgcn_ballot_w64(cnt > (u32)LY::PR) != 0) {  // one read alone selected more than a column holds
-                    exact = true;
-                    break;
-                }
-                const u32 incl = wave_incl_scan_u32(cnt, lane);
-                const u32 excl = incl - cnt;
-                const u32 T = wave_bcast_u32(incl, 63);
-                u64 ob = 0;
-                if (lane == 0) ob = atomicAdd(a.total + 1, (u64)T);
-                ob = wave_bcast_u64(ob, 0);
-                const bool fits = ob + T <= a.ovf_cap;
-                if (!fits && lane == 0) atomicOr(&a.ticket[1], 1u);  // result buffers too small: the host re-runs with a larger overflow region
-                wave_sync_lds();
-                // copy-out, one staging lane at a time: its run of cnt <= 56 tuples is one contiguous piece of the output
-                const u64 actm = __builtin_amdgcn_ballot_w64(act);
-                for (u64 m = actm; m && fits; m &= m - 1) {
-                    const int src = __builtin_ctzll(m);
-                    const u32 sc = wave_bcast_u32(cnt, src), se = wave_bcast_u32(excl, src), sc8 = wave_bcast_u32(c8, src);
-                    if ((u32)lane < sc) {
-                        const u32 so = (u32)lane * RB + sc8;
-                        const u64 hv = *reinterpret_cast<const u64 *>(lds + LY::SH + so);
-                        const u32 pv = (u32)(int)*reinterpret_cast<const short *>(lds + LY::SP + (so >> 2));  // sign-extending read: the strand bit lands in bit 31
-                        a.hash[a.ovf_base + ob + se + lane] = hv;
-                        a.pos[a.ovf_base + ob + se + lane] = pv & 0x80007fffu;
-                    }
-                }
-                wave_sync_lds();
-                if (act) myref = fits ? ((a.ovf_base + ob + excl) << 24) | cnt : 0;
-                // (more than 32 listed lanes: the next 32)
-                u64 done = 0;
-                {
-                    const u64 first32 = __builtin_amdgcn_ballot_w64(((todo >> lane) & 1) && rk < 32u);
-                    done = first32;
-                }
-                todo &= ~done;
-            }
-            if (exact) bad = ~0ULL;
-        }
-        if (exact) {
-            // two equal 27-bit keys met in a min operation, or one read alone overflowed a column: the exact 64-bit machine over the
-            // whole unit, every tuple stored straight to the overflow region.  A key tie may have mis-selected, so the packed pass's
-            // counts are not trusted: the unit takes one tuple per window.
-            FastMin<W, BSK_FAST_CAP, true, true, false, false, BSK_PAIR_ROWS, 4> fm;
-            const u32 nwin = ok ? nk - (u32)W + 1u : 0u;
-            const u32 wincl = wave_incl_scan_u32(nwin, lane);
-            const u32 myoff = wincl - nwin, need = wave_bcast_u32(wincl, 63);
-            u64 ob = 0;
-            if (lane == 0) ob = atomicAdd(a.total + 1, (u64)need);
-            ob = wave_bcast_u64(ob, 0);
-            myref = 0;
-            if (ob + need <= a.ovf_cap) {
-                fm.w = a.words + off;
-                fm.pw = pw.a;
-                fm.lds = ldsq;
-                fm.k = a.k;
-                fm.lane = lane;
-                fm.nk = nk;
-                fm.ghash = a.hash;
-                fm.gpos = a.pos;
-                fm.gbase = a.ovf_base + ob + myoff;
-                fm.run(nk_max);
-                tie = fm.tie;
-                myref = ((a.ovf_base + ob + myoff) << 24) | fm.cnt;
-            } else if (lane == 0) {
-                atomicOr(&a.ticket[1], 1u);
-            }
-        }
-        if (r < a.n && ((bad >> lane) & 1)) {
-            a.refs[r] = myref;
-            if (tie && ok) a.status[r] |= BSK_ST_FIRST_WINDOW_TIE;
-        }
-        (void)mine;
     }
 }
 
@@ -709,11 +594,10 @@ void pk_minimizer_launch(int w, bool long_reads, int grid, hipStream_t stream, c
     case WW:                                                                                                \
         if (long_reads) {                                                                                   \
             hipLaunchKernelGGL((k_minimizer_pk<WW, true>), dim3(grid), dim3(64), 0, stream, a);             \
-            hipLaunchKernelGGL((k_minimizer_pk_fix<WW, true>), dim3(grid), dim3(64), 0, stream, a);         \
         } else {                                                                                            \
             hipLaunchKernelGGL((k_minimizer_pk<WW, false>), dim3(grid), dim3(64), 0, stream, a);            \
-            hipLaunchKernelGGL((k_minimizer_pk_fix<WW, false>), dim3(grid), dim3(64), 0, stream, a);        \
         }                                                                                                   \
+        hipLaunchKernelGGL((k_minimizer_dense<WW, true>), dim3(grid), dim3(64), 0, stream, a);              \
         break;
         BSK_PK_WS(X)
 #undef X

@@ -240,3 +240,28 @@ def test_timed_entry_point_on_every_plan(engine):
             assert res.digest() == want, (kind, pk)
             res2, _ = engine.run_timed(b, p, 0, 1, reuse=res)   # the bench's pattern: repeat on the sized result
             assert res2.digest() == want, (kind, pk)
+
+
+def test_minimizer_low_complexity_reads_take_the_exact_list(engine, oracle):
+    """k_minimizer_pk sends READS with a 27-bit key tie to a list for the exact machine (per read, not per unit): batches where a
+    third of the reads have poly-A / poly-G tails, dinucleotide repeats or are reverse-complement palindromes (real 64-bit ties),
+    mixed with random reads in the same units, ragged lengths, several (k, w)."""
+    rng = random.Random(77)
+    seqs = []
+    for i in range(700):
+        L_ = rng.randint(60, 260)
+        kind = i % 6
+        if kind == 0:
+            s = rand_dna(rng, L_ // 2) + "A" * (L_ - L_ // 2)
+        elif kind == 1:
+            s = "G" * (L_ // 3) + rand_dna(rng, L_ - L_ // 3)
+        elif kind == 2:
+            s = ("AC" * L_)[:L_]
+        elif kind == 3:
+            h = rand_dna(rng, L_ // 2)
+            s = h + h[::-1].translate(str.maketrans("ACGT", "TGCA"))  # its own reverse complement
+        else:
+            s = rand_dna(rng, L_)
+        seqs.append(s)
+    for k, w in ((21, 11), (15, 10), (9, 5), (31, 13)):
+        check_minimizer(engine, oracle, seqs, k, w)
