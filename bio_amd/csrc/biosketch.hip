@@ -396,6 +396,7 @@ static int batch_from_ascii_impl(bsk_ctx *ctx, const uint8_t *bytes, const uint6
     const u64 nbytes = n ? offsets[n] : 0;
     b->n_bases = nbytes;
     u32 maxlen = 0;
+    bool uniform = true;
     for (u64 r = 0; r < n; ++r) {
         if (offsets[r + 1] < offsets[r]) {
             delete b;
@@ -408,8 +409,10 @@ static int batch_from_ascii_impl(bsk_ctx *ctx, const uint8_t *bytes, const uint6
             return BSK_ERR_UNSUPPORTED;
         }
         maxlen = std::max<u32>(maxlen, (u32)L);
+        if (L != offsets[1] - offsets[0]) uniform = false;
     }
     b->maxlen = maxlen;
+    b->uniform_len = (n && uniform) ? maxlen : 0;  // fixed-length batches (most FASTQ files): closed-form output offsets, no per-lane window test
     int rc = BSK_OK;
     auto bail = [&](int code) {
         bsk_batch_destroy(b);
@@ -512,11 +515,13 @@ extern "C" int bsk_batch_from_packed(bsk_ctx *ctx, const uint32_t *words, uint64
     HIPCHK(ctx, hipSetDevice(ctx->device));
     u32 maxlen = 0;
     u64 nb = 0;
+    bool uniform = true;
     for (u64 r = 0; r < n; ++r) {
         u64 L = desc[r] & 0xffffffULL, w0 = desc[r] >> 24;
         if (w0 + (L + 15) / 16 > n_words) return fail_arg(ctx, "desc points outside words[]");
         maxlen = std::max<u32>(maxlen, (u32)L);
         nb += L;
+        if (L != (desc[0] & 0xffffffULL)) uniform = false;
     }
     bsk_batch *b = new (std::nothrow) bsk_batch();
     if (!b) return BSK_ERR_NOMEM;
@@ -526,6 +531,7 @@ extern "C" int bsk_batch_from_packed(bsk_ctx *ctx, const uint32_t *words, uint64
     b->n_bases = nb;
     b->n_words = n_words;
     b->maxlen = maxlen;
+    b->uniform_len = (n && uniform) ? maxlen : 0;
     const u64 alloc_words = n_words + pad_words(maxlen);
     hipError_t e;
     if ((e = hipMalloc(&b->words, alloc_words * 4)) != hipSuccess || (e = hipMalloc(&b->desc, (n ? n : 1) * 8)) != hipSuccess ||

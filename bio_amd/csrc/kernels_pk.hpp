@@ -120,8 +120,13 @@ __device__ __forceinline__ u64 pk_load_u64(const u64 *p) {
 // barrier for the arithmetic on its neighbours' results -- the address of the words was computed from the descriptor ahead of it).
 __device__ __forceinline__ void pk_wait_loads(u64 &d0, u64 &d1) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(d0), "+v"(d1)::"memory"); }
 __device__ __forceinline__ void pk_wait_loads(PkWords &p) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(p.a), "+v"(p.b), "+v"(p.c), "+v"(p.d)::"memory"); }
-__device__ __forceinline__ void pk_wait_loads(PkWords &p, u64 &d0) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(p.a), "+v"(p.b), "+v"(p.c), "+v"(p.d), "+v"(d0)::"memory");
+__device__ __forceinline__ void pk_wait_loads(PkWords &p, u64 &d0, u32 &f) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(p.a), "+v"(p.b), "+v"(p.c), "+v"(p.d), "+v"(d0), "+v"(f)::"memory");
+}
+__device__ __forceinline__ u32 pk_load_u8(const u8 *p) {
+    u32 r;
+    asm volatile("global_load_ubyte %0, %1, off" : "=&v"(r) : "v"(p));
+    return r;
 }
 // the packed window machine + staging of one read per lane
 // LONG: reads of more than 16 (PKNW - 1) bases (their further words are loaded inside the k-mer loop)
@@ -493,6 +498,8 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
         }
         PkWords pw_n1 = pk_load_words(a.words + (d_n1 >> 24));
         u64 d_n2 = pk_load_u64(a.desc + (r + 128 < rmax ? r + 128 : rmax));
+        // the read's input flags (batches packed from ASCII have them): a load after the copy-out would wait for its stores
+        u32 rfl = pk_load_u8(a.rflags ? a.rflags + (r < rmax ? r : rmax) : reinterpret_cast<const u8 *>(a.desc));
         const u64 d = d_cur;
         const PkWords pw = pw_cur;
         const u64 off = d >> 24, L = d & 0xffffffULL;
@@ -516,7 +523,7 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
             if (ok) cnt = (lane < 32 ? pm.slot - col8 : top - pm.slot) / RB;
             tmin_lane = pm.tmin;
         }
-        pk_wait_loads(pw_n1, d_n2);  // the next unit's words and descriptor, requested a whole hashing phase ago, are in
+        pk_wait_loads(pw_n1, d_n2, rfl);  // the next unit's words and descriptor, requested a whole hashing phase ago, are in
         d_cur = d_n1;
         pw_cur = pw_n1;
         d_n1 = d_n2;
@@ -558,7 +565,7 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
         if (r < a.n) {
             if (!((redo >> lane) & 1)) a.refs[r] = ((base + excl) << 24) | cnt;  // (listed reads: the list pass writes theirs)
             u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
-            if (ok && a.rflags) sbyte |= a.rflags[r];
+            if (ok && a.rflags) sbyte |= (u8)rfl;
             a.status[r] = sbyte;
         }
     }

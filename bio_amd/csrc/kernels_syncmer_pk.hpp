@@ -389,6 +389,8 @@ __global__ __launch_bounds__(64, SYNPK_LB) void k_syncmer_pk(KArgs a) {  // thre
         }
         synpk_dma_words(a.words + (d_n1 >> 24), wbuf);
         synpk_dma_desc(a.desc + (r + 128 < rmax ? r + 128 : rmax), dbuf);
+        // the read's input flags (batches packed from ASCII have them): a load after the copy-out would wait for its stores
+        u32 rfl = pk_load_u8(a.rflags ? a.rflags + (r < rmax ? r : rmax) : reinterpret_cast<const u8 *>(a.desc));
         const u64 L = d & 0xffffffULL;
         const long long Lorig = (long long)L - a.circ_ext;
         const bool ok = r < a.n && Lorig >= 0 && Lorig >= 2LL * a.k - a.s - 1 && L >= (u64)a.k;  // sketch.go:149
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(64, SYNPK_LB) void k_syncmer_pk(KArgs a) {  // thre
             if (ok) cnt = (lane < 32 ? sp.slot - col8 : top - sp.slot) / RB;
             tmin_lane = sp.tmin;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next unit's words and the descriptors after them are in LDS
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rfl)::"memory");  // the next unit's words and the descriptors after them are in LDS
         d_cur = d_n1;
         have = nxt;
         // reads the exact machine must run: two equal 27-bit keys met in one of their min operations (a few per cent of the reads at
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(64, SYNPK_LB) void k_syncmer_pk(KArgs a) {  // thre
         if (r < a.n && !((redo >> lane) & 1)) {
             a.refs[r] = ((base + excl) << 24) | cnt;
             u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
-            if (ok && a.rflags) sbyte |= a.rflags[r];
+            if (ok && a.rflags) sbyte |= (u8)rfl;
             a.status[r] = sbyte;
         }
     }
