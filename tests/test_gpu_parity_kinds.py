@@ -43,15 +43,19 @@ def test_syncmer(engine, oracle, k, s, circular):
         assert (st & 0xF0) == fl, (i, q, st, fl)
 
 
-def test_syncmer_matches_state_machine_too(engine, oracle):
-    rng = random.Random(77)
-    seqs = [rand_seq(rng, 150) for _ in range(100)]
+@pytest.mark.parametrize("k,s,n,lens", [(31, 11, 3000, (150,)), (31, 16, 1500, (150, 100, 224)), (21, 10, 1500, (150, 90, 61)),
+                                        (15, 4, 1500, (80, 150)), (31, 7, 1000, (150, 300, 500)), (40, 23, 600, (250, 2000))])
+def test_syncmer_matches_state_machine_too(engine, oracle, k, s, n, lens):
+    """The kernels implement the closed form; this pins them to the line-by-line restatement of the reference's state machine
+    (sorted buffer, binary-search insert, pending queue: sketch.go:312-477) on thousands of reads per shape, ragged batches included."""
+    rng = random.Random(77 * k + s)
+    seqs = [rand_seq(rng, rng.choice(lens) + (rng.randint(0, 9) if len(lens) > 1 else 0)) for _ in range(n)]
     b = engine.batch(seqs)
-    res = engine.run(b, engine.params(L.SYNCMER, 31, s=11))
+    res = engine.run(b, engine.params(L.SYNCMER, k, s=s))
     for i, q in enumerate(seqs):
         _, h, p = res.read(i)
-        eh, ep, _, _ = oracle.syncmer(q, 31, 11)  # line-by-line restatement of sketch.go:312-477
-        assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep)
+        eh, ep, _, _ = oracle.syncmer(q, k, s)  # closed=False: the state machine
+        assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep), (i, k, s, len(q))
 
 
 def test_syncmer_invalid_s(engine):
