@@ -143,6 +143,7 @@ struct PkMin {
     u32 SB[W];  // strand << 15 of the same slots
     u32 P, bm, tmin;
     u32 slot, spare;
+    u32 glo, gspan;  // guard(): the lane's staging pointer may start a block in [glo, glo + gspan]
     int sstep;
     // The read's first PKNW packed words (240 bases) live in registers, loaded one unit ahead, BEFORE the previous unit's copy-out
     // stores: gfx9 counts loads and stores in one in-order vmcnt, so a load issued inside the k-mer loop waits for every copy-out
@@ -186,16 +187,26 @@ struct PkMin {
         rh_ = d ^ x.w;
     }
 
-    // one staging step: slot o of the block whose slots are idx base IB, at position ppos (wave-uniform)
-    template <int IDX>
-    __device__ __forceinline__ void emit(int o, u32 ppos) {
+    // Before the W staging steps of a block: a lane whose pointer could leave its column during them (a low lane within W - 1 rows of
+    // the spare row, a high lane within W - 1 rows of row 0: alone more tuples than a column holds with its partner's) is parked on the
+    // spare row for the rest of the unit -- its count then reads as a full column and both reads of the column go to the list.  Four
+    // instructions per block instead of a clamp (v_min_u32) in every staging step.
+    __device__ __forceinline__ void guard() {
+        const bool in = slot - glo <= gspan;
+        slot = in ? slot : spare;
+        sstep = in ? sstep : 0;
+    }
+    // one staging step: slot o of the block whose slot 0 is k-mer pbase (wave-uniform)
+    template <int IDX, int O>
+    __device__ __forceinline__ void emit(u32 pbase) {
         const u32 b = (bm >> IDX) & 1u;  // v_bfe_u32
-        const u32 addr = slot < spare ? slot : spare;  // v_min_u32: a full column scribbles on the spare row
+        u32 pv;  // strand << 15 | position: one v_add3_u32 (scalar base, inline slot number); as C it is an s_add per step and a v_or
+        asm("v_add3_u32 %0, %1, %2, %3" : "=v"(pv) : "v"(SB[O]), "s"(pbase), "n"(O));
 #ifndef PK_NOSTAGE  // (dev knock-outs, timing only: PK_NOSTAGE, PK_NOTIE, PK_NOTAB, PK_NOCOPY)
-        *reinterpret_cast<LDSQ u64 *>(lds + LY::SH + addr) = H[o];
-        *reinterpret_cast<LDSQ u16 *>(lds + LY::SP + (addr >> 2)) = (u16)(SB[o] | ppos);
+        *reinterpret_cast<LDSQ u64 *>(lds + LY::SH + slot) = H[O];
+        *reinterpret_cast<LDSQ u16 *>(lds + LY::SP + (slot >> 2)) = (u16)pv;
 #else
-        asm volatile("" ::"v"(H[o]), "v"(SB[o] | ppos), "v"(addr));
+        asm volatile("" ::"v"(H[O]), "v"(pv), "v"(slot));
 #endif
         asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(slot) : "v"(b), "v"(sstep));  // (the compiler's bfe_i32 + and + add is one instruction more)
     }
@@ -220,13 +231,22 @@ struct PkMin {
         // table offsets: nibble j of E / O = (out << 2 | in) of slot 2j / 2j+1, so a slot's row offset is (word >> n) & 0xF0
         const u32 E = (cinb & 0x33333333u) | ((coutb & 0x33333333u) << 2);
         const u32 O = ((cinb >> 2) & 0x33333333u) | (coutb & 0xCCCCCCCCu);
+        // nibble j times 16 = the high nibble of byte (j - 1) / 2 of the word (j odd) or of byte j / 2 of the word << 4 (j even): ONE
+        // v_and_b32_sdwa with a byte select instead of a shift and an and per slot
+        const u32 E4 = E << 4, O4 = O << 4;
         u32x4 xs[W];
         auto fetch = [&](int o0) {
 #pragma unroll
             for (int o = o0; o < o0 + XC && o < W; ++o) {
                 const int j = o >> 1;
-                const u32 src = (o & 1) ? O : E;
-                u32 a = (j >= 1 ? (src >> (4 * j - 4)) : (src << 4)) & 0xF0u;
+                const u32 src = (j & 1) ? ((o & 1) ? O : E) : ((o & 1) ? O4 : E4);
+                u32 a;
+                switch (j >> 1) {
+                    case 0: asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(a) : "v"(src), "s"(0xF0u)); break;
+                    case 1: asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(a) : "v"(src), "s"(0xF0u)); break;
+                    case 2: asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(a) : "v"(src), "s"(0xF0u)); break;
+                    default: asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(a) : "v"(src), "s"(0xF0u)); break;
+                }
                 if (FIRST && o == 0) a = 0x100u | (a & 0x30u);  // row "nothing leaves"
 #ifndef PK_NOTAB
                 xs[o] = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB + a);
@@ -237,6 +257,8 @@ struct PkMin {
         };
         fetch(0);
         if (XC < W) fetch(XC);
+        const u32 pbase = (u32)__builtin_amdgcn_readfirstlane((int)(i0 - (u32)W));
+        if (!FIRST) guard();
         u32 vb = 0;
         if (RAG && !FIRST) {  // bit o: the window ending at slot o exists for this lane
             const int left = (int)nk - (int)i0;
@@ -251,7 +273,7 @@ struct PkMin {
             }
             roll(xs[o]);
             const lmask rev = lt64(rl, rh_, fl, fh_);
-            if (!FIRST) this->template emit<PB + o>(o, i0 - (u32)W + (u32)o);  // the previous block's slot o, before its registers are re-used
+            if (!FIRST) this->template emit<PB + o, o>(pbase);  // the previous block's slot o, before its registers are re-used
             const u32 hl = sel(rev, rl, fl), hh = sel(rev, rh_, fh_);
             H[o] = ((u64)hh << 32) | hl;
             SB[o] = sel01(rev) << 15;
@@ -298,9 +320,11 @@ struct PkMin {
     // the last block's own slots
     template <int PAR>
     __device__ __forceinline__ void drain(u32 i0) {
+        const u32 pbase = (u32)__builtin_amdgcn_readfirstlane((int)i0);
+        guard();
         pk_unroll<W>([&](auto oc) {
             constexpr int o = decltype(oc)::value;
-            this->template emit<PAR * 16 + o>(o, i0 + (u32)o);
+            this->template emit<PAR * 16 + o, o>(pbase);
         });
     }
 
@@ -313,6 +337,11 @@ struct PkMin {
         spare = (u32)(LY::PR * LY::ROW * 8) + col8;  // the column's slot in the spare row
         slot = slot0;
         sstep = step;
+        {  // W staging writes from `slot` on stay in rows 0 .. PR (the spare row may be scribbled on)
+            constexpr u32 RB = (u32)(LY::ROW * 8);
+            glo = step < 0 ? col8 + (u32)(W - 1) * RB : col8;
+            gspan = (u32)(LY::PR - W) * RB + (step < 0 ? 0u : RB);  // low lane: up to row PR - W + 1; high lane: rows W - 1 .. PR - 1
+        }
         for (int t0 = 0; t0 < k - 1; t0 += 16) {
             const u32 word = this->word((u32)t0 >> 4);
             const int nb = (k - 1 - t0) < 16 ? (k - 1 - t0) : 16;
