@@ -144,6 +144,7 @@ struct PkMin {
     u32 P, bm, tmin;
     u32 slot, spare;
     u32 glo, gspan;  // guard(): the lane's staging pointer may start a block in [glo, glo + gspan]
+    u32 c8000;
     int sstep;
     // The read's first PKNW packed words (240 bases) live in registers, loaded one unit ahead, BEFORE the previous unit's copy-out
     // stores: gfx9 counts loads and stores in one in-order vmcnt, so a load issued inside the k-mer loop waits for every copy-out
@@ -276,7 +277,7 @@ struct PkMin {
             if (!FIRST) this->template emit<PB + o, o>(pbase);  // the previous block's slot o, before its registers are re-used
             const u32 hl = sel(rev, rl, fl), hh = sel(rev, rh_, fh_);
             H[o] = ((u64)hh << 32) | hl;
-            SB[o] = sel01(rev) << 15;
+            asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(SB[o]) : "v"(c8000), "s"(rev));  // strand << 15 in one select (0x8000 kept in a VGPR: VOP3 takes no literal)
             u32 pk;  // (hh & ~31) | idx: one v_and_or_b32 with the mask in an SGPR (VOP3 takes no literal on gfx9: the compiler's form is and + or)
             asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(pk) : "v"(hh), "s"(0xffffffe0u), "n"(CB + o));
             if (o == 0) {
@@ -333,6 +334,8 @@ struct PkMin {
     __device__ __forceinline__ void begin(u32 slot0, int step, u32 col8) {
         fl = fh_ = rl = rh_ = 0;
         bm = 0;
+        c8000 = 0x8000u;
+        asm volatile("" : "+v"(c8000));  // (stays a register: as a known constant the compiler re-materialises it, or goes back to select + shift)
         tmin = 0xffffffffu;
         spare = (u32)(LY::PR * LY::ROW * 8) + col8;  // the column's slot in the spare row
         slot = slot0;
