@@ -417,10 +417,12 @@ __device__ __forceinline__ void pk_copyout(char *lds, int lane, u32 cnt, u32 exc
         const int A = lane < 32 ? col8 - (int)excl * RB : col8 + ((int)(LY::PR - 1) + (int)excl) * RB;
         const u32 rk = __builtin_amdgcn_mbcnt_hi((u32)(nzmask >> 32), __builtin_amdgcn_mbcnt_lo((u32)nzmask, 0));
         s_tab64[rk] = ((u64)(u32)S << 32) | (u32)A;
-        atomicOr(&s_heads[excl >> 6], 1ULL << (excl & 63));
+        // bit e - 1 for a run that starts at output e >= 1 (the first run is owner 0 without a bit): the owner of output t is then the number
+        // of bits below t -- a running popcount over the words before t's and one exclusive v_mbcnt in its own, nothing to shift or patch
+        if (excl) atomicOr(&s_heads[(excl - 1u) >> 6], 1ULL << ((excl - 1u) & 63u));
     }
     wave_sync_lds();
-    const u64 hw = lane < NH ? s_heads[lane] : 0ULL;  // word c: bit j = a lane's run starts at output 64 c + j
+    const u64 hw = lane < NH ? s_heads[lane] : 0ULL;  // word c: bit j = a lane's run starts at output 64 c + j + 1
     const u32 hw_lo = (u32)hw, hw_hi = (u32)(hw >> 32);
     u32 heads_before = 0;  // wave-uniform
     const char *sh = lds + LY::SH, *sp = lds + LY::SP;
@@ -433,15 +435,15 @@ __device__ __forceinline__ void pk_copyout(char *lds, int lane, u32 cnt, u32 exc
         for (int j = 0; j < U; ++j) {
             const u32 c = (t0 >> 6) + j;  // < 64; words from NH on read as 0: rows beyond the unit see no heads
             const u32 mlo = (u32)__builtin_amdgcn_readlane((int)hw_lo, (int)c), mhi = (u32)__builtin_amdgcn_readlane((int)hw_hi, (int)c);
-            const u64 M = ((u64)mhi << 32) | mlo;
-            const u64 M1 = M >> 1;  // heads at outputs <= this lane's = bits 1 .. lane of M (mbcnt of M >> 1) + bit 0
-            const u32 sbase = heads_before + (mlo & 1u) - 1u;
-            rank[j] = __builtin_amdgcn_mbcnt_hi((u32)(M1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)M1, sbase));
-            heads_before += (u32)__builtin_popcountll(M);
+            rank[j] = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, heads_before));
+            heads_before += (u32)__builtin_popcount(mlo) + (u32)__builtin_popcount(mhi);
         }
         u64 ent[U];
 #pragma unroll
         for (int j = 0; j < U; ++j) ent[j] = s_tab64[rank[j] & 63u];
+        // (one wait for the whole trip: left alone the compiler waits before every first use -- 22 s_waitcnt per trip, each an issue slot)
+        if constexpr (U == 8)
+            asm volatile("" ::"v"(ent[0]), "v"(ent[1]), "v"(ent[2]), "v"(ent[3]), "v"(ent[4]), "v"(ent[5]), "v"(ent[6]), "v"(ent[7]));
         u64 hv[U];
         u32 pv[U];
 #pragma unroll
@@ -452,6 +454,9 @@ __device__ __forceinline__ void pk_copyout(char *lds, int lane, u32 cnt, u32 exc
             hv[j] = *reinterpret_cast<const u64 *>(sh + so);
             pv[j] = (u32)(int)*reinterpret_cast<const short *>(sp + (so >> 2));  // sign-extending read: the strand bit lands in bit 31
         }
+        if constexpr (U == 8)
+            asm volatile("" ::"v"(hv[0]), "v"(hv[1]), "v"(hv[2]), "v"(hv[3]), "v"(hv[4]), "v"(hv[5]), "v"(hv[6]), "v"(hv[7]), "v"(pv[0]), "v"(pv[1]),
+                         "v"(pv[2]), "v"(pv[3]), "v"(pv[4]), "v"(pv[5]), "v"(pv[6]), "v"(pv[7]));
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const u32 t = t0 + 64 * j + lane;
