@@ -435,15 +435,20 @@ __device__ __forceinline__ void pk_copyout(char *lds, int lane, u32 cnt, u32 exc
         for (int j = 0; j < U; ++j) {
             const u32 c = (t0 >> 6) + j;  // < 64; words from NH on read as 0: rows beyond the unit see no heads
             const u32 mlo = (u32)__builtin_amdgcn_readlane((int)hw_lo, (int)c), mhi = (u32)__builtin_amdgcn_readlane((int)hw_hi, (int)c);
-            rank[j] = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, heads_before));
-            heads_before += (u32)__builtin_popcount(mlo) + (u32)__builtin_popcount(mhi);
+            // byte offset of the owner's table entry: (bits below this lane << 3) + 8 * (bits of the words before): one v_lshl_add_u32 with
+            // the scalar part as its third operand (as an initial value of v_mbcnt the scalar count costs a v_mov per row)
+            rank[j] = (__builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u)) << 3) + (heads_before << 3);
+            heads_before += (u32)__builtin_popcountll(((u64)mhi << 32) | mlo);
         }
         u64 ent[U];
 #pragma unroll
-        for (int j = 0; j < U; ++j) ent[j] = s_tab64[rank[j] & 63u];
+        for (int j = 0; j < U; ++j) ent[j] = *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(s_tab64) + rank[j]);  // (< 64 entries: at most 63 bits are set)
         // (one wait for the whole trip: left alone the compiler waits before every first use -- 22 s_waitcnt per trip, each an issue slot)
-        if constexpr (U == 8)
+        if constexpr (U == 8) {
+            __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::"v"(ent[0]), "v"(ent[1]), "v"(ent[2]), "v"(ent[3]), "v"(ent[4]), "v"(ent[5]), "v"(ent[6]), "v"(ent[7]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
         u64 hv[U];
         u32 pv[U];
 #pragma unroll
@@ -454,9 +459,12 @@ __device__ __forceinline__ void pk_copyout(char *lds, int lane, u32 cnt, u32 exc
             hv[j] = *reinterpret_cast<const u64 *>(sh + so);
             pv[j] = (u32)(int)*reinterpret_cast<const short *>(sp + (so >> 2));  // sign-extending read: the strand bit lands in bit 31
         }
-        if constexpr (U == 8)
+        if constexpr (U == 8) {
+            __builtin_amdgcn_sched_barrier(0);
             asm volatile("" ::"v"(hv[0]), "v"(hv[1]), "v"(hv[2]), "v"(hv[3]), "v"(hv[4]), "v"(hv[5]), "v"(hv[6]), "v"(hv[7]), "v"(pv[0]), "v"(pv[1]),
                          "v"(pv[2]), "v"(pv[3]), "v"(pv[4]), "v"(pv[5]), "v"(pv[6]), "v"(pv[7]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const u32 t = t0 + 64 * j + lane;
