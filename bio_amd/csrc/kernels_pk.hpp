@@ -14,11 +14,13 @@
 //     minimal 27-bit key.  Every such pair meets in one of the three min operations (both in the current block: when the later one
 //     meets the prefix minimum; both in the previous block: in the suffix pass at the earlier one; one in each: where prefix and
 //     suffix minima are combined -- DESIGN.md), and a key tie there is (a ^ b) < 32: the kernel keeps the minimum of those
-//     xors (two full-rate ops per min operation).  A unit in which any lane saw one (6e-4 of the units on random reads) is simply
-//     re-run by the exact 64-bit machine (FastMin, DIRECT), as a unit whose staging column overflowed is.  Reads with real 64-bit
-//     ties (a k-mer and its reverse complement in one window, homopolymers) therefore take the exact path, which also evaluates
-//     BSK_ST_FIRST_WINDOW_TIE; everywhere else no tie exists and the flag is 0.
-// LDS layout (paired columns, 16-bit positions, 8 waves per CU) and copy-out are k_minimizer_fast's (PLds, fast_copyout).
+//     xors (two full-rate ops per min operation).  A READ that saw one -- accidental key ties are 6e-4 of the units on random reads;
+//     reads with real 64-bit ties (a k-mer and its reverse complement in one window, homopolymers) always -- is appended to a list
+//     and run afterwards by the exact 64-bit machine (k_minimizer_dense<W, true>), which also evaluates BSK_ST_FIRST_WINDOW_TIE;
+//     everywhere else no tie exists and the flag is 0.
+// LDS layout: paired columns (lanes l and l + 32 fill one column from both ends) and 16-bit positions as in k_minimizer_fast, 58 rows,
+// eight waves per CU (PkLds); the copy-out is pk_copyout below.  The kernel is bound by what two waves per SIMD issue in order: what
+// pays is removing instructions of any kind, not cheaper encodings (profiles/NOTEBOOK.md, round 3).
 // (Tried first: byte positions + the copy-out's tables laid over the hash tables = 17.7 KB, nine waves per CU under a 168-VGPR cap.
 // The ninth wave was worth 3-4.7 %; the cap cost spills, the byte positions a wrap rule in the copy-out and a read-length limit.)
 #pragma once
