@@ -46,7 +46,7 @@ WORKLOADS = {
     "simhash": ("sim", 20_000_000, 150, 21, 5, "20M x 150 bp reads, SimHash k=21 m=5 scale=5"),
 }
 NOTES = {
-    "min": "integer-VALU / issue bound, not HBM bound (DESIGN.md 3.1)",
+    "min": "bound by the in-order instruction issue of two waves per SIMD (eight waves per CU: LDS staging), not by HBM; the VALU pipe is ~0.6 full (DESIGN.md 3.1)",
     "nt": "HBM-write bound (DESIGN.md 3.2); a plain 16 B/lane fill kernel reaches 5.2-5.9 TB/s on this part",
     "syn": "integer-VALU bound (two rolling hashes + a 2(k-s) window per base; DESIGN.md 3.3)",
     "pmin": "integer-VALU bound (wyhash from scratch per residue: 8 v_mad_u64_u32; DESIGN.md 3.4)",
