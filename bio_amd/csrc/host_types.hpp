@@ -37,8 +37,8 @@ struct bsk_ctx {
     u8 *d_lut = nullptr;      // codon tables of `lut_table` (kernels_translate.hpp layout)
     int lut_table = 0;
     // tiled calls: grow-only temporaries (hipMalloc / hipFree of ten buffers per call cost more than the kernels)
-    void *tmp[16] = {};      // 0-9: tiled calls, 12-14: bsk_result_fetch
-    size_t tmp_cap[16] = {};
+    void *tmp[20] = {};      // 0-9: tiled calls / sets, 12-14: bsk_result_fetch, 16-19: bsk_result_compact
+    size_t tmp_cap[20] = {};
     u64 *h_refs = nullptr;   // pinned staging of bsk_result_fetch (refs down, offsets up), grow-only
     size_t h_refs_cap = 0;
     struct bsk_result *tile_res = nullptr;  // tile-level result of the previous tiled call, reused

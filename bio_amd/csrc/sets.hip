@@ -355,6 +355,68 @@ int grid_of(bsk_ctx *ctx, u64 items, int block) {
 
 }  // namespace
 
+// Dense device copy of a result's tuples: the sketch kernels leave gaps between the 64-sequence units' slabs, a device-side consumer
+// wants CSR.  Offsets by the scan above, tuples by one wavefront per sequence; everything in the context's grow-only pool.
+namespace {
+__global__ void k_compact(const u64 *hash, const u32 *pos, const u64 *refs, const u64 *wfirst, const u64 *wcount, const u64 *dstoff, u64 n,
+                          u64 *ohash, u32 *opos) {
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 r = wave; r < n; r += nw) {
+        u64 b, cnt;
+        seq_span(refs, wfirst, wcount, r, b, cnt);
+        const u64 d = dstoff[r];
+        for (u64 t = threadIdx.x & 63; t < cnt; t += 64) {
+            ohash[d + t] = hash[b + t];
+            if (opos) opos[d + t] = pos[b + t];
+        }
+    }
+}
+}  // namespace
+
+extern "C" int bsk_result_compact(bsk_ctx *ctx, const bsk_result *r, const uint64_t **offsets, const uint64_t **hash, const uint32_t **pos,
+                                  uint64_t *n_tuples) {
+    if (!ctx || !r || !offsets || !hash) return fail_arg(ctx, "bsk_result_compact: null argument");
+    if (r->ctx != ctx) return fail_arg(ctx, "bsk_result_compact: result belongs to another context");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const u64 n = r->n;
+    auto pool = [&](int slot, size_t bytes, void **outp) -> hipError_t {
+        if (ctx->tmp_cap[slot] < bytes) {
+            (void)hipFree(ctx->tmp[slot]);
+            ctx->tmp[slot] = nullptr;
+            ctx->tmp_cap[slot] = 0;
+            const size_t want = bytes + bytes / 4 + 256;
+            const hipError_t e = hipMalloc(&ctx->tmp[slot], want);
+            if (e != hipSuccess) return e;
+            ctx->tmp_cap[slot] = want;
+        }
+        *outp = ctx->tmp[slot];
+        return hipSuccess;
+    };
+    u64 *offs = nullptr, *part = nullptr, *oh = nullptr;
+    u32 *op = nullptr;
+    HIPCHK(ctx, pool(16, (n + 2) * 8, (void **)&offs));
+    HIPCHK(ctx, pool(17, ((n + SCAN_CHUNK - 1) / SCAN_CHUNK + 2) * 8, (void **)&part));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, 16, st));
+    HIPCHK(ctx, scan_counts(st, CountOf{r->refs, r->wfirst, r->wcount}, n, part, offs, ctx->d_total + 1, (u64 *)nullptr));
+    u64 T = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&T, ctx->d_total + 1, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, pool(18, (T + 1) * 8, (void **)&oh));
+    if (r->pos) HIPCHK(ctx, pool(19, (T + 1) * 4, (void **)&op));
+    if (T) {
+        hipLaunchKernelGGL(k_compact, dim3(grid_of(ctx, n * 64, 256)), dim3(256), 0, st, r->hash, r->pos, r->refs, r->wfirst, r->wcount, offs, n, oh,
+                           r->pos ? op : nullptr);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(st));
+    }
+    *offsets = (const uint64_t *)offs;
+    *hash = (const uint64_t *)oh;
+    if (pos) *pos = r->pos ? op : nullptr;
+    if (n_tuples) *n_tuples = T;
+    return BSK_OK;
+}
+
 extern "C" void bsk_sets_release(bsk_sets *s) {
     if (!s) return;
     if (s->ctx) (void)hipSetDevice(s->ctx->device);

@@ -182,6 +182,14 @@ class BatchResult:
         finally:
             self.eng.lib.bsk_sets_release(h)
 
+    def compact(self):
+        """bsk_result_compact: dense CSR copy left ON THE DEVICE -> (offsets_ptr, hash_ptr, pos_ptr or None, n_tuples); the arrays belong
+        to the engine's context until its next compact()."""
+        po, ph, pp = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nt = C.c_uint64()
+        self.eng._chk(self.eng.lib.bsk_result_compact(self.eng.ctx, self.h, C.byref(po), C.byref(ph), C.byref(pp), C.byref(nt)))
+        return po.value, ph.value, pp.value, int(nt.value)
+
     def digest(self):
         ck, nt = C.c_uint64(), C.c_uint64()
         sc = (C.c_uint64 * 4)()

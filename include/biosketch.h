@@ -253,6 +253,12 @@ int bsk_result_plan(const bsk_result *r, const char **kernel, int *grid, int *wa
 int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t first, uint64_t count,
                      uint64_t *offsets, uint8_t *status, uint64_t *hash, uint32_t *pos,
                      uint64_t tuple_cap);
+/* Dense device copy for device-side consumers (CSR: what bsk_result_fetch delivers to the host, left on the device): offsets[n+1]
+ * (u64, offsets[n] = *n_tuples), hash[*n_tuples], pos[*n_tuples] (*pos = NULL for the kinds with implicit positions; pos may be NULL).
+ * The arrays belong to the context and stay valid until the next bsk_result_compact on it (or bsk_ctx_destroy).  The reference has no
+ * counterpart: its callers collect Next() values into a slice (e.g. sketches/sketch_test.go:93-104). */
+int bsk_result_compact(bsk_ctx *ctx, const bsk_result *r, const uint64_t **offsets, const uint64_t **hash, const uint32_t **pos,
+                       uint64_t *n_tuples);
 /* Device pointers (valid until release / next bsk_sketch on this result); refs[] as described above.
  * Long sequences: when a DNA batch holds a sequence longer than the tile threshold (4096 bases, 512 for the every-position kinds; always from 2^24
  * bases on) the engine cuts the sequences into overlapping tiles, runs the same kernels over the tiles and stitches

@@ -111,3 +111,36 @@ def test_sets_empty_result(engine):
     assert list(offs) == [0, 0, 0, 0] and len(vals) == 0
     offs, vals = res.sets(whole_batch=True)
     assert list(offs) == [0, 0] and len(vals) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["min", "nt", "long"])
+def test_compact_device_copy_equals_fetch(engine, kind):
+    """bsk_result_compact leaves on the device exactly what bsk_result_fetch brings to the host (slab gaps squeezed out; wide results too)."""
+    import ctypes as C
+    rng = random.Random(31)
+    if kind == "long":
+        seqs = ["".join(rng.choice("ACGT") for _ in range(n)) for n in (70000, 150, 9000, 0, 33000)]
+        p = engine.params(L.MINIMIZER, 21, w=11)
+    else:
+        seqs = ["".join(rng.choice("ACGT") for _ in range(rng.choice([150, 150, 90, 20, 251]))) for _ in range(700)]
+        p = engine.params(L.MINIMIZER, 21, w=11) if kind == "min" else engine.params(L.NTHASH, 21)
+    res = engine.run(engine.batch(seqs), p)
+    offs, _, h, pos = res.fetch()
+    po, ph, pp, nt = res.compact()
+    assert nt == len(h) == int(offs[-1])
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def d2h(ptr, n, dt):
+        a = np.empty(n, dt)
+        if n:
+            assert hip.hipMemcpy(a.ctypes.data, ptr, a.nbytes, 2) == 0
+        return a
+
+    assert np.array_equal(d2h(po, len(seqs) + 1, np.uint64), offs)
+    assert np.array_equal(d2h(ph, nt, np.uint64), h)
+    if pos is None:
+        assert pp is None
+    else:
+        assert np.array_equal(d2h(pp, nt, np.uint32), pos)
