@@ -145,8 +145,8 @@ __global__ void k_digest(const u64 *hash, const u32 *pos, const u64 *refs, const
                          u64 *out /*[0] checksum [1] tuples*/) {
     u64 s = 0, c = 0;
     for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) {
-        const u64 b = refs ? refs[r] >> 24 : wfirst[r], cnt = refs ? refs[r] & 0xffffffULL : wcount[r];
-        for (u64 t = 0; t < cnt; ++t) s += hash[b + t] * (2ULL * (pos ? (u64)(pos[b + t] & BSK_POS_MASK) : t) + 1ULL);
+        const u64 b = refs ? BSK_REF_FIRST(refs[r]) : wfirst[r], cnt = refs ? BSK_REF_COUNT(refs[r]) : wcount[r], st = refs ? BSK_REF_STRIDE(refs[r]) : 1;
+        for (u64 t = 0; t < cnt; ++t) s += hash[b + t * st] * (2ULL * (pos ? (u64)(pos[b + t * st] & BSK_POS_MASK) : t) + 1ULL);
         c += cnt;
     }
     s = wave_sum_u64(s);
@@ -167,10 +167,11 @@ __global__ void k_gather(const u64 *hash, const u32 *pos, const u64 *refs, const
                          u64 count, u64 *ohash, u32 *opos) {
     const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
     for (u64 r = wave; r < count; r += nw) {
-        const u64 b = refs ? refs[r] >> 24 : wfirst[r], cnt = refs ? refs[r] & 0xffffffULL : wcount[r], d = dstoff[r];
+        const u64 b = refs ? BSK_REF_FIRST(refs[r]) : wfirst[r], cnt = refs ? BSK_REF_COUNT(refs[r]) : wcount[r], d = dstoff[r];
+        const u64 st = refs ? BSK_REF_STRIDE(refs[r]) : 1;
         for (u64 t = threadIdx.x & 63; t < cnt; t += 64) {
-            if (ohash) ohash[d + t] = hash[b + t];
-            if (opos) opos[d + t] = pos[b + t];
+            if (ohash) ohash[d + t] = hash[b + t * st];
+            if (opos) opos[d + t] = pos[b + t * st];
         }
     }
 }
@@ -335,6 +336,9 @@ void BskOpts::load() {
     no_mixed = on("BSK_NO_MIXED");
     no_dense = on("BSK_NO_DENSE");
     no_pk = on("BSK_NO_PK");
+    no_ring = on("BSK_NO_RING");
+    ring = on("BSK_RING");
+    ring_max = env_u32("BSK_RING_MAX", 60);
     no_tiles = on("BSK_NO_TILES");
     no_tile_cache = on("BSK_NO_TILE_CACHE");
     timing = on("BSK_TIMING");
@@ -918,7 +922,7 @@ static int blocks_per_cu(K kernel) {
 
 // Which kernel runs a (batch, params) pair, on how many workgroups, and how the tuple arrays are organised.
 enum Which { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST, K_NT_FAST, K_SYN_P, K_SYN_A, K_KMER_P, K_KMER_A, K_SIM_P, K_SIM_A,
-             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST, K_MIN_DENSE, K_MIN_SEG, K_MIN_WPR, K_MIN_PK, K_SYN_PK };
+             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST, K_MIN_DENSE, K_MIN_SEG, K_MIN_WPR, K_MIN_PK, K_SYN_PK, K_MIN_RING };
 struct Plan {
     Which which = K_MIN_GEN_P;
     int grid = 1;
@@ -946,10 +950,17 @@ static bool slab_budget_ok(const bsk_batch *b, u64 slab_read) {
     return (double)b->maxlen <= 4.0 * mean + 64.0 || (double)b->n * (double)slab_read * 12.0 < 256.0 * 1024 * 1024;
 }
 
+// rows of 64 tuples in a unit's slab (kernels_ring.hpp): a read selects 2 / (w + 1) of its windows; + 30 % + 6, in whole groups of four
+// rows (150 bp, w = 11: 32 rows).  A read with more goes to the exact machine's list.
+static u64 ring_rows(double nwin, int w) {
+    const double nw = std::max(nwin, 1.0);
+    return ((u64)std::min(nw, std::ceil(nw * 2.6 / (w + 1.0)) + 6.0) + 3) & ~(u64)3;
+}
+
 #define BSK_REPLAN_UNFUSED (-1000)  // internal: the fused DNA -> protein plan gave up, run the two-step path
 
 static bool which_is_fast(Which w) {
-    return w == K_MIN_FAST || w == K_NT_FAST || w == K_SYN_FAST || w == K_SIM_FAST || w == K_MIN_DENSE || w == K_MIN_SEG || w == K_MIN_WPR || w == K_MIN_PK || w == K_SYN_PK;
+    return w == K_MIN_FAST || w == K_NT_FAST || w == K_SYN_FAST || w == K_SIM_FAST || w == K_MIN_DENSE || w == K_MIN_SEG || w == K_MIN_WPR || w == K_MIN_PK || w == K_SYN_PK || w == K_MIN_RING;
 }
 
 static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan &pl, bool use_ascii);
@@ -993,6 +1004,10 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         // k_minimizer_seg: per-read slabs of the expected count + 30 % + 4 (150 bp, w = 11: 32 tuples), rounded to 64-byte pieces
         const double exp_sel = std::max(nwin, 0.0) * 2.0 / (p->w + 1.0) + 1.0;
         const u64 seg_slab = (std::min<u64>((u64)std::max(nwin, 1.0), (u64)(exp_sel * 1.3) + 4) + 7) & ~(u64)7;
+        // unit rows through a ring (kernels_ring.hpp): reads that select more tuples than k_minimizer_pk stages (longer than ~156 bases at
+        // w = 11) up to the length where the lanes of a unit drift too far apart for a ring of 16 rows (measured: DESIGN.md 3.2)
+        const double exp_tuples = nwin * 2.0 / (p->w + 1.0);
+        const bool ring_wins = ctx->opt.ring ? true : exp_tuples > (double)ctx->opt.dense_min && exp_tuples <= (double)ctx->opt.ring_max;
         if (!use_ascii && p->w == 11 && p->k + p->w <= 65 && b->maxlen < 32768u && nwin >= 1.0 && ctx->opt.wpr && !ctx->no_dense && slab_budget_ok(b, seg_slab) &&
             !ctx->opt.force_generic) {
             pl.which = K_MIN_WPR;  // the A/B experiment: one read per wavefront (kernels_wpr.hpp); a ticket is 64 reads
@@ -1012,6 +1027,16 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.slab_unit = 64 * pl.slab_read;
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
             per_cu = seg_minimizer_blocks_per_cu(p->w);
+        } else
+        if (!use_ascii && ring_minimizer_supported(p->w) && !b->alias && nwin >= 1.0 && nwin < 262144.0 && ring_wins && !ctx->opt.force_generic && !ctx->opt.no_ring &&
+            !ctx->no_syn_pk && slab_budget_ok(b, ring_rows(nwin, p->w))) {
+            pl.which = K_MIN_RING;  // w <= 13: packed window machine, unit rows through a ring of staged rows (kernels_ring.hpp)
+            pl.fast_w = p->w;
+            pl.fast_k = b->maxlen > ring_minimizer_short_bases() ? 1 : 0;  // (the kernel's LONG argument, for plan_name)
+            pl.slab = true;
+            pl.slab_unit = (u64)64 * ring_rows(nwin, p->w);
+            pl.slab_total = (u64)pl.nunits * pl.slab_unit;
+            per_cu = ring_minimizer_blocks_per_cu(p->w);
         } else
         if (!use_ascii && dense_minimizer_supported(p->w) && b->maxlen < 32768u && nwin * 2.0 / (p->w + 1.0) > (double)ctx->opt.dense_min && !ctx->no_dense && slab_budget_ok(b, dense_slab) &&
             !ctx->opt.force_generic && !ctx->opt.no_dense) {
@@ -1320,6 +1345,7 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
         case K_NT_A: snprintf(b, sizeof b, "k_nthash_stream<1>"); break;
         case K_MIN_FAST: snprintf(b, sizeof b, "k_minimizer_fast<%d,%d,true>", pl.fast_w, BSK_FAST_CAP); break;
         case K_MIN_PK: snprintf(b, sizeof b, "k_minimizer_pk<%d,%s>", pl.fast_w, pl.fast_k ? "true" : "false"); break;
+        case K_MIN_RING: snprintf(b, sizeof b, "k_minimizer_ring<%d,%s>", pl.fast_w, pl.fast_k ? "true" : "false"); break;
         case K_MIN_DENSE: snprintf(b, sizeof b, "k_minimizer_dense<%d>", pl.fast_w); break;
         case K_MIN_SEG: snprintf(b, sizeof b, "k_minimizer_seg<%d>", pl.fast_w); break;
         case K_MIN_WPR: snprintf(b, sizeof b, "k_minimizer_wpr<%d>", pl.fast_w); break;
@@ -1386,13 +1412,14 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     a.ticket = ctx->d_ticket;
     a.total = ctx->d_total;
     a.ring_w = pl.ring_w;
-    int rc = ensure_scratch(ctx, std::max<u32>(pl.which == K_MIN_PK ? 2 * pl.nunits + (u32)(syn_pk_fixcap(b->n) / 2) : pl.which == K_SYN_PK ? (u32)(syn_pk_fixcap(b->n) / 2) : pl.slab ? 1 : pl.nunits, pl.mixed ? pl.side_nunits : 0), pl.ring_entries);
+    int rc = ensure_scratch(ctx, std::max<u32>(pl.which == K_MIN_PK ? 2 * pl.nunits + (u32)(syn_pk_fixcap(b->n) / 2) : (pl.which == K_SYN_PK || pl.which == K_MIN_RING) ? (u32)(syn_pk_fixcap(b->n) / 2) : pl.slab ? 1 : pl.nunits, pl.mixed ? pl.side_nunits : 0), pl.ring_entries);
     if (rc != BSK_OK) return rc;
     a.lookback = ctx->d_lookback;
     a.fixlist = ctx->d_lookback;
-    a.fixcap = (pl.which == K_SYN_PK || pl.which == K_MIN_PK) ? (u32)syn_pk_fixcap(b->n) : 0u;
-    a.rlist = reinterpret_cast<u32 *>(ctx->d_lookback + 2 * (size_t)pl.nunits);  // K_MIN_PK: behind its {unit, lane mask} entries
-    if (pl.which == K_MIN_PK) {  // slab of a listed read (k_minimizer_dense<W, true>): one tuple per window, whole 128-byte lines
+    a.fixcap = (pl.which == K_SYN_PK || pl.which == K_MIN_PK || pl.which == K_MIN_RING) ? (u32)syn_pk_fixcap(b->n) : 0u;
+    a.rlist = reinterpret_cast<u32 *>(ctx->d_lookback + (pl.which == K_MIN_RING ? 0 : 2 * (size_t)pl.nunits));  // K_MIN_PK: behind its {unit, lane mask} entries
+    a.unit_rows = (u32)(pl.slab_unit / 64);
+    if (pl.which == K_MIN_PK || pl.which == K_MIN_RING) {  // slab of a listed read (k_minimizer_dense<W, true>): one tuple per window, whole 128-byte lines
         const u64 nwin_max = b->maxlen + 2 > (u32)(p->k + p->w) ? (u64)b->maxlen - p->k - p->w + 2 : 1;
         a.slab_read = (nwin_max + 15) & ~(u64)15;
     }  // K_MIN_PK (a slab kernel: no look-back) keeps its list of unfinished units there
@@ -1409,6 +1436,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_NT_A: hipLaunchKernelGGL(k_nthash_stream<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_MIN_FAST: fast_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_MIN_PK: pk_minimizer_launch(pl.fast_w, b->maxlen > pk_minimizer_short_bases(), pl.grid, ctx->stream, a); break;
+        case K_MIN_RING: ring_minimizer_launch(pl.fast_w, b->maxlen > ring_minimizer_short_bases(), pl.grid, ctx->stream, a); break;
         case K_MIN_DENSE: dense_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_MIN_SEG: seg_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_MIN_WPR: wpr_minimizer_launch(pl.grid, ctx->stream, a); break;
@@ -1583,7 +1611,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
             ctx->err = "result capacity overflow after exact re-size";
             return cleanup(BSK_ERR_DEVICE);
         }
-        if (pl.which == K_PROT_MIN_FAST || pl.which == K_MIN_DENSE || ((pl.which == K_SYN_PK || pl.which == K_MIN_PK) && (ovf & 2u))) {  // a sequence outgrew its slab (unusual density), or too many reads with key ties: re-plan without that kernel
+        if (pl.which == K_PROT_MIN_FAST || pl.which == K_MIN_DENSE || ((pl.which == K_SYN_PK || pl.which == K_MIN_PK || pl.which == K_MIN_RING) && (ovf & 2u))) {  // a sequence outgrew its slab (unusual density), or too many reads with key ties: re-plan without that kernel
             ctx->no_prot_fast = true;
             ctx->no_dense = true;
             ctx->no_syn_pk = true;

@@ -23,6 +23,11 @@ int pk_minimizer_blocks_per_cu(int w);
 u32 pk_minimizer_short_bases();
 void pk_minimizer_launch(int w, bool long_reads, int grid, hipStream_t stream, const KArgs &a);
 
+bool ring_minimizer_supported(int w);  // packed window machine, unit rows through a ring of 16 staged rows: three waves per SIMD (kernels_ring.hpp)
+int ring_minimizer_blocks_per_cu(int w);
+u32 ring_minimizer_short_bases();
+void ring_minimizer_launch(int w, bool long_reads, int grid, hipStream_t stream, const KArgs &a);
+
 bool seg_minimizer_supported(int w);  // per-read slabs + a flush of everything staged every few blocks: three wavefronts per SIMD
 int seg_minimizer_blocks_per_cu(int w);
 void seg_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a);

@@ -29,7 +29,7 @@ struct KArgs {
     // parameters
     int kind, k, w, s, canonical, circ_ext, m, scale;
     // output
-    u64 *refs;     // per read: (first_tuple << 24) | n_tuples
+    u64 *refs;     // per read: (first_tuple << 24) | n_tuples, bit 63 (BSK_REF_ROWS): the tuples are 64 apart
     u8 *status;
     u64 *hash;
     u32 *pos;
@@ -46,6 +46,7 @@ struct KArgs {
     u32 ring_w;
     u32 uniform_len;  // != 0: every read has exactly this many bases (synthetic / fixed-length batches)
     u64 slab_read;  // per-sequence slab kernels (protein): tuples reserved per sequence
+    u32 unit_rows;  // unit-row kernels (kernels_ring.hpp): rows of 64 tuples in a unit's slab
     u64 ovf_base;   // slab kernels: first tuple index of the overflow region, and its size
     u64 ovf_cap;
     // side launch over a subset of the reads (the reads with a non-ACGT letter of an otherwise 2-bit batch): unit u holds

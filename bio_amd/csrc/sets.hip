@@ -28,13 +28,16 @@ struct bsk_sets {
 namespace {
 
 // where the values of sequence r are: packed reference word or the wide arrays (host_types.hpp)
-__device__ __forceinline__ void seq_span(const u64 *refs, const u64 *wfirst, const u64 *wcount, u64 r, u64 &first, u64 &cnt) {
+// stride: 1, or 64 for a read of a unit written as rows (BSK_REF_ROWS, kernels_ring.hpp)
+__device__ __forceinline__ void seq_span(const u64 *refs, const u64 *wfirst, const u64 *wcount, u64 r, u64 &first, u64 &cnt, u64 &stride) {
     if (refs) {
-        first = refs[r] >> 24;
-        cnt = refs[r] & 0xffffffULL;
+        first = BSK_REF_FIRST(refs[r]);
+        cnt = BSK_REF_COUNT(refs[r]);
+        stride = BSK_REF_STRIDE(refs[r]);
     } else {
         first = wfirst[r];
         cnt = wcount[r];
+        stride = 1;
     }
 }
 
@@ -45,11 +48,11 @@ __global__ void k_gather_values(const u64 *hash, const u64 *refs, const u64 *wfi
     // a group of 16 lanes per sequence (short reads hold two dozen values: a whole wavefront per sequence left most lanes idle)
     const u64 grp = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 4, ng = ((u64)gridDim.x * blockDim.x) >> 4;
     for (u64 r = grp; r < n; r += ng) {
-        u64 f, c;
-        seq_span(refs, wfirst, wcount, r, f, c);
+        u64 f, c, st;
+        seq_span(refs, wfirst, wcount, r, f, c, st);
         const u64 d = dst[r];
         for (u64 t = threadIdx.x & 15; t < c; t += 16) {
-            const u64 h = hash[f + t];
+            const u64 h = hash[f + t * st];
             out[d + t] = h > maxhash ? ~0ULL : h;
         }
     }
@@ -161,7 +164,7 @@ __device__ __forceinline__ void sort_rows(u64 (&v)[E], int l) {
 // load, filter, sort and flag the distinct values of the row's sequence: keep[reg] / rank rk[reg] of element reg * 16 + l among
 // the kept ones; returns their number (the same in all 16 lanes of the row)
 template <int E>
-__device__ __forceinline__ u32 row_set(const u64 *src, u32 c, u64 maxhash, int l, int row, u64 (&v)[E], bool (&keep)[E], u32 (&rk)[E]) {
+__device__ __forceinline__ u32 row_set(const u64 *src, u32 stride, u32 c, u64 maxhash, int l, int row, u64 (&v)[E], bool (&keep)[E], u32 (&rk)[E]) {
     u32 nvalid = 0;
 #pragma unroll
     for (int reg = 0; reg < E; ++reg) {
@@ -169,7 +172,7 @@ __device__ __forceinline__ u32 row_set(const u64 *src, u32 c, u64 maxhash, int l
         u64 x = ~0ULL;
         bool valid = false;
         if (e < c) {
-            x = src[e];
+            x = src[(size_t)e * stride];
             valid = x <= maxhash;
             if (!valid) x = ~0ULL;  // filtered values sort to the end with the padding
         }
@@ -193,11 +196,11 @@ __device__ __forceinline__ u32 row_set(const u64 *src, u32 c, u64 maxhash, int l
 }
 
 template <int E>
-__device__ __forceinline__ u32 rows_store(const u64 *src, u32 c, u64 maxhash, int l, int row, u64 *dst) {
+__device__ __forceinline__ u32 rows_store(const u64 *src, u32 stride, u32 c, u64 maxhash, int l, int row, u64 *dst) {
     u64 v[E];
     bool keep[E];
     u32 rk[E];
-    const u32 u = row_set<E>(src, c, maxhash, l, row, v, keep, rk);
+    const u32 u = row_set<E>(src, stride, c, maxhash, l, row, v, keep, rk);
 #pragma unroll
     for (int reg = 0; reg < E; ++reg)
         if (keep[reg]) dst[rk[reg]] = v[reg];
@@ -210,15 +213,15 @@ __global__ __launch_bounds__(256) void k_sets_rows(const u64 *hash, const u64 *r
     const u64 nit = (n + 3) / 4;  // wave iterations: four sequences each
     for (u64 it = wave; it < nit; it += nw) {
         const u64 r = it * 4 + (u64)row;
-        u64 first = 0, c = 0, d = 0;
+        u64 first = 0, c = 0, d = 0, st = 1;
         if (r < n) {
-            seq_span(refs, wfirst, wcount, r, first, c);
+            seq_span(refs, wfirst, wcount, r, first, c, st);
             d = offs[r];
         }
         u32 u;
-        if (__ballot(c > 32)) u = rows_store<4>(hash + first, (u32)c, maxhash, l, row, tmp + d);
-        else if (__ballot(c > 16)) u = rows_store<2>(hash + first, (u32)c, maxhash, l, row, tmp + d);
-        else u = rows_store<1>(hash + first, (u32)c, maxhash, l, row, tmp + d);
+        if (__ballot(c > 32)) u = rows_store<4>(hash + first, (u32)st, (u32)c, maxhash, l, row, tmp + d);
+        else if (__ballot(c > 16)) u = rows_store<2>(hash + first, (u32)st, (u32)c, maxhash, l, row, tmp + d);
+        else u = rows_store<1>(hash + first, (u32)st, (u32)c, maxhash, l, row, tmp + d);
         if (l == 0 && r < n) ucount[r] = u;
     }
 }
@@ -228,8 +231,8 @@ __global__ __launch_bounds__(256) void k_sets_rows(const u64 *hash, const u64 *r
 struct CountOf {
     const u64 *refs, *wfirst, *wcount;
     __device__ __forceinline__ u64 operator()(u64 r) const {
-        u64 f, c;
-        seq_span(refs, wfirst, wcount, r, f, c);
+        u64 f, c, st;
+        seq_span(refs, wfirst, wcount, r, f, c, st);
         return c;
     }
 };
@@ -362,12 +365,12 @@ __global__ void k_compact(const u64 *hash, const u32 *pos, const u64 *refs, cons
                           u64 *ohash, u32 *opos) {
     const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
     for (u64 r = wave; r < n; r += nw) {
-        u64 b, cnt;
-        seq_span(refs, wfirst, wcount, r, b, cnt);
+        u64 b, cnt, st;
+        seq_span(refs, wfirst, wcount, r, b, cnt, st);
         const u64 d = dstoff[r];
         for (u64 t = threadIdx.x & 63; t < cnt; t += 64) {
-            ohash[d + t] = hash[b + t];
-            if (opos) opos[d + t] = pos[b + t];
+            ohash[d + t] = hash[b + t * st];
+            if (opos) opos[d + t] = pos[b + t * st];
         }
     }
 }

@@ -105,6 +105,12 @@ typedef enum bsk_alphabet {
 #define BSK_ST_HAS_NON_ACGT 0x20      /* a byte outside ACGTacgt was hashed (ntHash seed table for such
                                          bytes is unpinned upstream) */
 
+/* reference words of a result (bsk_result_device): (first_tuple << 24) | n_tuples, bit 63 = the read's tuples are 64 apart */
+#define BSK_REF_ROWS (1ULL << 63)
+#define BSK_REF_FIRST(ref) (((ref) & ~BSK_REF_ROWS) >> 24)
+#define BSK_REF_COUNT(ref) ((ref) & 0xffffffULL)
+#define BSK_REF_STRIDE(ref) (((ref) & BSK_REF_ROWS) ? 64ULL : 1ULL)
+
 #define BSK_POS_STRAND_BIT 0x80000000u /* pos[] bit 31: 1 iff the reverse-strand hash was the canonical one */
 #define BSK_POS_MASK 0x7fffffffu
 
@@ -226,10 +232,14 @@ void bsk_fastx_par_close(bsk_fastx_par *f);
  * *result == NULL: a result is allocated; otherwise it is reused (bench loops).
  * Output layout (device, SoA, deterministic):
  *   refs[n] u64 = (first_tuple << 24) | n_tuples ; status[n] u8 ; hash[] u64 ; pos[] u32 (bit 31 strand)
- * read r owns tuples [first_tuple, first_tuple + n_tuples) in position order -- exactly
- * the sequence of (Next*() value, Index()) pairs the reference iterator yields.
- * (The tuple arrays may contain gaps between reads of different 64-read units; use
- * bsk_result_fetch for a dense, rebased CSR copy on the host.)
+ * read r owns tuples first_tuple + j * stride, j = 0 .. n_tuples - 1, in position order -- exactly
+ * the sequence of (Next*() value, Index()) pairs the reference iterator yields.  stride is 1, or 64
+ * when bit 63 of the reference word (BSK_REF_ROWS) is set: the minimizer / syncmer kernels for short
+ * reads write a 64-read unit as ROWS (row j = the j-th tuple of each of the unit's 64 reads), which
+ * lets whole rows leave the chip while the reads are still being hashed.
+ * BSK_REF_FIRST / BSK_REF_COUNT / BSK_REF_STRIDE decode a reference word.
+ * (The tuple arrays contain gaps; use bsk_result_fetch for a dense, rebased CSR copy on the host,
+ * bsk_result_compact for one on the device.)
  * KMER / NTHASH / SIMHASH / PROT_HASH emit every position, so pos[] is implicit
  * (NULL): tuple j of read r is position j. */
 int bsk_sketch(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, bsk_result **result);

@@ -51,11 +51,11 @@ def regs(operand_text):
     return out
 
 
-def check_hidden_loads(ws=("11",), unit="k_minimizer_pk", macro="BSK_PK_WS"):
+def check_hidden_loads(ws=("11",), unit="k_minimizer_pk", macro="BSK_PK_WS", extra=()):
     bad = []
     for w in ws:
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(CSRC, "..", "..", "include"),
-               f"-D{macro}(X)=X({w})", "-S", "--cuda-device-only", "-o", "-", os.path.join(CSRC, unit + ".hip")]
+               f"-D{macro}(X)=X({w})", *extra, "-S", "--cuda-device-only", "-o", "-", os.path.join(CSRC, unit + ".hip")]
         p = subprocess.run(cmd, capture_output=True, text=True)
         if p.returncode != 0:
             return [f"hipcc failed for w={w}: {p.stderr[-400:]}"]
@@ -91,7 +91,37 @@ def check_hidden_loads(ws=("11",), unit="k_minimizer_pk", macro="BSK_PK_WS"):
     return bad
 
 
+def check_reserved(ws=("11",), unit="k_minimizer_ring", macro="BSK_RING_WS", first=144, func_filter="k_minimizer_ring"):
+    """3. k_minimizer_ring keeps v144.. out of the register allocator's hands (amdgpu_num_vgpr) and loads into them from inline asm:
+    outside asm blocks no instruction of those kernels may name such a register."""
+    bad = []
+    for w in ws:
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(CSRC, "..", "..", "include"),
+               f"-D{macro}(X)=X({w})", "-S", "--cuda-device-only", "-o", "-", os.path.join(CSRC, unit + ".hip")]
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        if p.returncode != 0:
+            return [f"hipcc failed for w={w}: {p.stderr[-400:]}"]
+        in_asm, func = False, "?"
+        for n, line in enumerate(p.stdout.splitlines(), 1):
+            s = line.strip()
+            if re.match(r"^_Z\w+:", s):
+                func = s.split(":")[0]
+            if s.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if s.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if in_asm or func_filter not in func or not s or s.startswith((";", ".")) or s.endswith(":"):
+                continue
+            hit = [r for r in regs(s.split(";")[0]) if r >= first]
+            if hit:
+                bad.append(f"w={w} {func} line {n}: `{s.split(';')[0].strip()}` names reserved v{sorted(hit)}")
+    return bad
+
+
 if __name__ == "__main__":
-    errs = check_scc() + check_hidden_loads(tuple(sys.argv[1:]) or ("11",)) + check_hidden_loads(("20",), "k_syncmer_pk", "BSK_SYNPK_WS")
+    errs = (check_scc() + check_hidden_loads(tuple(sys.argv[1:]) or ("11",)) + check_hidden_loads(("20",), "k_syncmer_pk", "BSK_SYNPK_WS") +
+            check_hidden_loads(("11",), "k_minimizer_ring", "BSK_RING_WS") + check_reserved(("11",)))
     print("\n".join(errs) if errs else "asm checks: ok")
     sys.exit(1 if errs else 0)
