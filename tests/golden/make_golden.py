@@ -84,6 +84,31 @@ def main():
             g["cases"].append({"name": name, "seq": s, "fn": "protein_minimizer", "k": k, "w": w,
                                "out": entry(O.protein_minimizer, s, k, w)})
         g["cases"].append({"name": name, "seq": s, "fn": "protein_hashes", "k": 9, "out": entry(O.protein_hashes, s, 9)})
+    # wyhash (github.com/zeebo/wyhash v0.0.1, seed 1 as at iterator-protein.go:87) on its own: every length class of the algorithm
+    for n in (0, 1, 3, 4, 7, 8, 9, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64, 65, 100):
+        data = "".join(rng.choice("ACDEFGHIKLMNPQRSTVWY") for _ in range(n))
+        for seed in (1, 0):
+            g["cases"].append({"name": "wyhash_len%d" % n, "seq": data, "fn": "wyhash", "seed": seed, "out": [O.wyhash(data, seed)]})
+    # ties inside the first sorted window (sorts.Quicksort is unstable, sketch.go:236,351): random short-alphabet strings whose oracle
+    # result carries BSK_ST_FIRST_WINDOW_TIE (0x10) -- the pin harness says what upstream really yields for them
+    found = 0
+    for trial in range(20000):
+        s_ = "".join(rng.choice("AC") for _ in range(rng.randint(24, 60)))
+        k, w = rng.choice([(4, 6), (5, 4), (3, 8), (6, 5)])
+        r = O.minimizer(s_, k, w)
+        if r[3] & 0x10 and len(set(s_)) > 1:
+            g["cases"].append({"name": "first_window_tie_%d" % found, "seq": s_, "fn": "minimizer", "k": k, "w": w, "out": entry(O.minimizer, s_, k, w)})
+            ks, ss = rng.choice([(6, 3), (7, 4), (5, 2)])
+            g["cases"].append({"name": "first_window_tie_%d" % found, "seq": s_, "fn": "syncmer", "k": ks, "s": ss, "out": entry(O.syncmer, s_, ks, ss)})
+            found += 1
+            if found == 8:
+                break
+    # k > 64 (Go's << by 64 or more yields 0: does nthash v0.4.0 rotate modulo 64?)
+    long_ = "".join(rng.choice("ACGT") for _ in range(200))
+    for k in (64, 65, 70, 100):
+        g["cases"].append({"name": "k_over_64", "seq": long_, "fn": "nthash", "k": k, "canonical": True, "circular": False,
+                           "out": entry(O.nthash, long_, k, True, False)})
+        g["cases"].append({"name": "k_over_64", "seq": long_, "fn": "minimizer", "k": k, "w": 5, "out": entry(O.minimizer, long_, k, 5)})
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sketches_golden.json")
     with open(out, "w") as f:
         json.dump(g, f, separators=(",", ":"))

@@ -54,6 +54,8 @@ def _run(oracle, c):
             r = oracle.protein_minimizer(s, c["k"], c["w"])
         elif fn == "protein_hashes":
             r = oracle.protein_hashes(s, c["k"])
+        elif fn == "wyhash":
+            r = [oracle.wyhash(s, c["seed"])]
         else:
             raise AssertionError(fn)
     except oracle.OracleError as e:
