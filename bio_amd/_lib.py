@@ -54,6 +54,7 @@ SYMBOLS = [
     ("bsk_ctx_destroy", None, [_vp]),
     ("bsk_ctx_sync", C.c_int, [_vp]),
     ("bsk_ctx_reload_options", C.c_int, [_vp]),
+    ("bsk_build_has_experiments", C.c_int, []),
     ("bsk_last_error", C.c_char_p, [_vp]),
     ("bsk_err_name", C.c_char_p, [C.c_int]),
     ("bsk_batch_from_ascii", C.c_int, [_vp, _vp, _vp, C.c_uint64, C.c_int, _pp]),

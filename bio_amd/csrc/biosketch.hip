@@ -351,6 +351,13 @@ void BskOpts::load() {
     tile_min = env_u32("BSK_TILE_MIN", 0);
     tile_pos = env_u32("BSK_TILE_POS", 0);
 }
+extern "C" int bsk_build_has_experiments(void) {
+#ifdef BSK_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
 extern "C" int bsk_ctx_reload_options(bsk_ctx *ctx) {
     if (!ctx) return BSK_ERR_ARG;
     ctx->opt.load();
@@ -1008,6 +1015,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         // w = 11) up to the length where the lanes of a unit drift too far apart for a ring of 16 rows (measured: DESIGN.md 3.2)
         const double exp_tuples = nwin * 2.0 / (p->w + 1.0);
         const bool ring_wins = ctx->opt.ring ? true : exp_tuples > (double)ctx->opt.dense_min && exp_tuples <= (double)ctx->opt.ring_max;
+#ifdef BSK_EXPERIMENTS  // the two measured-and-rejected minimizer kernels (make EXPERIMENTS=1; NOTEBOOK round 2): never planned without their switch
         if (!use_ascii && p->w == 11 && p->k + p->w <= 65 && b->maxlen < 32768u && nwin >= 1.0 && ctx->opt.wpr && !ctx->no_dense && slab_budget_ok(b, seg_slab) &&
             !ctx->opt.force_generic) {
             pl.which = K_MIN_WPR;  // the A/B experiment: one read per wavefront (kernels_wpr.hpp); a ticket is 64 reads
@@ -1028,6 +1036,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
             per_cu = seg_minimizer_blocks_per_cu(p->w);
         } else
+#endif
         if (!use_ascii && ring_minimizer_supported(p->w) && !b->alias && nwin >= 1.0 && nwin < 262144.0 && ring_wins && !ctx->opt.force_generic && !ctx->opt.no_ring &&
             !ctx->no_syn_pk && slab_budget_ok(b, ring_rows(nwin, p->w))) {
             pl.which = K_MIN_RING;  // w <= 13: packed window machine, unit rows through a ring of staged rows (kernels_ring.hpp)
@@ -1438,8 +1447,13 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_MIN_PK: pk_minimizer_launch(pl.fast_w, b->maxlen > pk_minimizer_short_bases(), pl.grid, ctx->stream, a); break;
         case K_MIN_RING: ring_minimizer_launch(pl.fast_w, b->maxlen > ring_minimizer_short_bases(), pl.grid, ctx->stream, a); break;
         case K_MIN_DENSE: dense_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
+#ifdef BSK_EXPERIMENTS
         case K_MIN_SEG: seg_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_MIN_WPR: wpr_minimizer_launch(pl.grid, ctx->stream, a); break;
+#else
+        case K_MIN_SEG:
+        case K_MIN_WPR: break;
+#endif
         case K_SYN_P: hipLaunchKernelGGL(k_syncmer<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_SYN_A: hipLaunchKernelGGL(k_syncmer<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_KMER_P: hipLaunchKernelGGL(k_kmer<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;

@@ -141,6 +141,7 @@ int bsk_ctx_sync(bsk_ctx *ctx);                    /* wait for the context's str
 /* The library's developer switches (environment variables BSK_*, DESIGN.md "Switches") are read ONCE, by bsk_ctx_create -- never on
  * the bsk_sketch path.  A process that changes them afterwards (the test suite does) calls this to have the context read them again. */
 int bsk_ctx_reload_options(bsk_ctx *ctx);
+int bsk_build_has_experiments(void);               /* 1 iff built with `make EXPERIMENTS=1`: the measured-and-rejected kernels behind BSK_SEG / BSK_WPR are in */
 const char *bsk_last_error(const bsk_ctx *ctx);    /* text of the last BSK_ERR_DEVICE/ARG on this ctx */
 const char *bsk_err_name(int err);                 /* "ErrShortSeq", ... (the reference's names) */
 

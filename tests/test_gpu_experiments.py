@@ -12,6 +12,11 @@ from bio_amd import _lib as L
 pytestmark = pytest.mark.gpu
 
 
+def _built():
+    from bio_amd import _lib
+    return bool(_lib.load().bsk_build_has_experiments())
+
+
 def ragged_batch(rng, n, lo, hi, frac_n=0.0):
     lens = rng.integers(lo, hi, n)
     lens[::5] = 150
@@ -26,6 +31,8 @@ def ragged_batch(rng, n, lo, hi, frac_n=0.0):
 @pytest.mark.parametrize("switch,k,w", [("BSK_SEG", 21, 11), ("BSK_SEG", 15, 5), ("BSK_SEG", 31, 15), ("BSK_WPR", 21, 11), ("BSK_WPR", 5, 11),
                                         ("BSK_WPR", 54, 11), ("BSK_WPR", 33, 11)])
 def test_experimental_kernels_equal_the_planned_one(engine, oracle, switch, k, w):
+    if not _built():
+        pytest.skip("libbiosketch.so was built without the experiments (make -C bio_amd/csrc EXPERIMENTS=1)")
     rng = np.random.default_rng(k * 100 + w)
     for n, lo, hi, fn in ((3000, 20, 400, 0.0), (777, 140, 160, 0.02), (64, 1000, 4000, 0.0), (5, 10, 30, 0.0)):
         data, offs = ragged_batch(rng, n, lo, hi, fn)
