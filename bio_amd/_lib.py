@@ -84,6 +84,8 @@ SYMBOLS = [
     ("bsk_pipeline_fastx", C.c_int, [C.c_int, C.c_char_p, C.c_int, _vp, C.c_int, C.c_uint64, C.c_int, _vp]),
     ("bsk_pipeline_memory", C.c_int, [C.c_int, _vp, _vp, C.c_uint64, C.c_int, _vp, C.c_int, C.c_uint64, C.c_int, C.c_int, _vp]),
     ("bsk_pipeline_fastx_files", C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_uint64, C.c_int, _vp]),
+    ("bsk_pipeline_fastx_multi", C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int, _vp, C.c_int, C.c_uint64, C.c_int, _vp]),
+    ("bsk_pipeline_memory_multi", C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, C.c_int, _vp, C.c_int, C.c_uint64, C.c_int, C.c_int, _vp]),
     ("bsk_pipeline_trim", None, []),
     ("bsk_comm_unique_id", C.c_int, [_vp]),
     ("bsk_comm_init_rank", C.c_int, [_vp, _vp, C.c_int, C.c_int]),

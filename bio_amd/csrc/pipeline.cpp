@@ -301,11 +301,17 @@ struct OneSource : SourceSet {
     void close(Source *) override {}
 };
 
-int run_pipeline(int device, SourceSet &set, int n_producers, const bsk_params *p, int n_streams, uint64_t chunk_records, int fetch, bsk_pipeline_stats *st) {
-    if (!p || !st || n_streams < 1 || n_streams > 16 || n_producers < 1 || n_producers > 64) return BSK_ERR_ARG;
+// devices[n_dev]: the GPUs of the run.  Every device gets n_streams workers (a context = a HIP stream each); all workers take chunks from the one
+// queue the producers fill, so a node's GPUs share one input the way the reference's workers share ChunkChan (seqio/fastx/reader.go:562-608) --
+// reads are independent, nothing is exchanged between devices, and the order-independent digest of the statistics is the whole job's.
+int run_pipeline(const int *devices, int n_dev, SourceSet &set, int n_producers, const bsk_params *p, int n_streams, uint64_t chunk_records, int fetch, bsk_pipeline_stats *st) {
+    if (!p || !st || !devices || n_dev < 1 || n_dev > 64 || n_streams < 1 || n_streams > 16 || n_producers < 1 || n_producers > 64) return BSK_ERR_ARG;
     memset(st, 0, sizeof *st);
-    if (hipSetDevice(device) != hipSuccess) return BSK_ERR_NO_DEVICE;
-    const int nchunks = 2 * n_streams + n_producers;  // double buffering per stream + the one every producer is filling
+    for (int d = 0; d < n_dev; ++d)
+        if (hipSetDevice(devices[d]) != hipSuccess) return BSK_ERR_NO_DEVICE;
+    const int device = devices[0];  // (the producers' pinned buffers)
+    const int n_workers = n_dev * n_streams;
+    const int nchunks = 2 * n_workers + n_producers;  // double buffering per stream + the one every producer is filling
     std::vector<Chunk> chunks(nchunks);
     Queue free_q, full_q;
     for (auto &c : chunks) free_q.push(&c);
@@ -377,9 +383,9 @@ int run_pipeline(int device, SourceSet &set, int n_producers, const bsk_params *
         });
     }
     std::vector<std::thread> workers;
-    for (int w = 0; w < n_streams; ++w) {
+    for (int w = 0; w < n_workers; ++w) {
         workers.emplace_back([&, w] {
-            (void)w;
+            const int device = devices[w % n_dev];  // (shadows the producers' device: the copy locks below are per device)
             bsk_ctx *ctx = nullptr;
             if (bsk_ctx_create(device, &ctx) != BSK_OK) {
                 fail(BSK_ERR_NO_DEVICE, "bsk_ctx_create");
@@ -475,27 +481,27 @@ int run_pipeline(int device, SourceSet &set, int n_producers, const bsk_params *
     st->seconds = secs(t_start, clk::now());
     st->reader_seconds = reader_s;
     st->reader_wait_seconds = reader_wait_s;
-    st->n_streams = n_streams;
+    st->n_streams = n_workers;
     st->pin_seconds = (double)(g_pin_ns.load() - pin0) * 1e-9;
     return error.load();
 }
 
 }  // namespace
 
-extern "C" int bsk_pipeline_fastx(int device, const char *path, int alphabet, const bsk_params *p, int n_streams, uint64_t chunk_records,
-                                  int fetch_tuples, bsk_pipeline_stats *stats) {
-    if (!path) return BSK_ERR_ARG;
+extern "C" int bsk_pipeline_fastx_multi(const int *devices, int n_devices, const char *path, int alphabet, const bsk_params *p, int n_streams,
+                                        uint64_t chunk_records, int fetch_tuples, bsk_pipeline_stats *stats) {
+    if (!path || !devices || n_devices < 1) return BSK_ERR_ARG;
     // a plain file: block-parallel parsing (the serial record reader delivers ~0.8 Gbases/s, a third of what ONE stream sketches)
     if (!getenv("BSK_FASTX_SERIAL")) {
         ParFastxSource ps;
         ps.want_alpha = alphabet;
         const char *tv = getenv("BSK_FASTX_THREADS");
-        int nt = tv && atoi(tv) > 0 ? atoi(tv) : (int)std::thread::hardware_concurrency() - n_streams - 1;
+        int nt = tv && atoi(tv) > 0 ? atoi(tv) : (int)std::thread::hardware_concurrency() - n_streams * n_devices - 1;
         nt = std::max(1, std::min(nt, 12));
         const int orc = bsk_fastx_par_open(path, nt, 0, &ps.f);
         if (orc == BSK_OK) {
             OneSource one(&ps);
-            const int rc = run_pipeline(device, one, 1, p, n_streams, chunk_records, fetch_tuples, stats);
+            const int rc = run_pipeline(devices, n_devices, one, 1, p, n_streams, chunk_records, fetch_tuples, stats);
             uint64_t rep = 0;
             bsk_fastx_par_info(ps.f, nullptr, nullptr, &rep);
             if (stats) stats->reader_threads = nt, stats->reparsed_pieces = rep;
@@ -509,14 +515,18 @@ extern "C" int bsk_pipeline_fastx(int device, const char *path, int alphabet, co
     int rc = bsk_fastx_open(path, &src.f);
     if (rc != BSK_OK) return rc;
     OneSource one(&src);
-    rc = run_pipeline(device, one, 1, p, n_streams, chunk_records, fetch_tuples, stats);
+    rc = run_pipeline(devices, n_devices, one, 1, p, n_streams, chunk_records, fetch_tuples, stats);
     bsk_fastx_close(src.f);
     return rc;
 }
+extern "C" int bsk_pipeline_fastx(int device, const char *path, int alphabet, const bsk_params *p, int n_streams, uint64_t chunk_records,
+                                  int fetch_tuples, bsk_pipeline_stats *stats) {
+    return bsk_pipeline_fastx_multi(&device, 1, path, alphabet, p, n_streams, chunk_records, fetch_tuples, stats);
+}
 
-extern "C" int bsk_pipeline_memory(int device, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet, const bsk_params *p,
-                                   int n_streams, uint64_t chunk_records, int repeat, int fetch_tuples, bsk_pipeline_stats *stats) {
-    if (!bytes || !offsets || !n || repeat < 1) return BSK_ERR_ARG;
+extern "C" int bsk_pipeline_memory_multi(const int *devices, int n_devices, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet,
+                                         const bsk_params *p, int n_streams, uint64_t chunk_records, int repeat, int fetch_tuples, bsk_pipeline_stats *stats) {
+    if (!bytes || !offsets || !n || repeat < 1 || !devices || n_devices < 1) return BSK_ERR_ARG;
     MemorySource src;
     src.bytes = bytes;
     src.offsets = offsets;
@@ -524,7 +534,11 @@ extern "C" int bsk_pipeline_memory(int device, const uint8_t *bytes, const uint6
     src.repeat = repeat;
     src.alphabet = alphabet;
     OneSource one(&src);
-    return run_pipeline(device, one, 1, p, n_streams, chunk_records, fetch_tuples, stats);
+    return run_pipeline(devices, n_devices, one, 1, p, n_streams, chunk_records, fetch_tuples, stats);
+}
+extern "C" int bsk_pipeline_memory(int device, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet, const bsk_params *p,
+                                   int n_streams, uint64_t chunk_records, int repeat, int fetch_tuples, bsk_pipeline_stats *stats) {
+    return bsk_pipeline_memory_multi(&device, 1, bytes, offsets, n, alphabet, p, n_streams, chunk_records, repeat, fetch_tuples, stats);
 }
 
 // several files, n_readers of them read at once (each by its own producer thread: the block-parallel reader for a plain file, the serial
@@ -596,7 +610,7 @@ extern "C" int bsk_pipeline_fastx_files(int device, const char *const *paths, in
     const char *tv = getenv("BSK_FASTX_THREADS");
     const int budget = tv && atoi(tv) > 0 ? atoi(tv) : std::max(1, (int)std::thread::hardware_concurrency() - n_streams - n_readers);
     set.threads_per_file = std::max(1, std::min(budget, 12) / n_readers);
-    const int rc = run_pipeline(device, set, n_readers, p, n_streams, chunk_records, fetch_tuples, stats);
+    const int rc = run_pipeline(&device, 1, set, n_readers, p, n_streams, chunk_records, fetch_tuples, stats);
     if (stats) {
         stats->reader_threads = set.par_files ? set.threads_per_file : 0;
         stats->reparsed_pieces = set.reparsed;

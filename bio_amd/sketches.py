@@ -281,6 +281,31 @@ class Engine:
         return st.asdict()
 
     @staticmethod
+    def pipeline_memory_multi(devices, data: np.ndarray, offsets: np.ndarray, params, n_streams: int = 2, chunk_records: int = 1 << 18,
+                              repeat: int = 1, fetch: bool = True, alphabet: int = L.ALPHA_DNA):
+        """bsk_pipeline_memory over several GPUs of the node (a device may be named more than once): one chunk queue, n_streams workers per device."""
+        lib = L.load()
+        data = np.ascontiguousarray(data, np.uint8)
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        dev = (C.c_int * len(devices))(*devices)
+        st = L.PipelineStats()
+        rc = lib.bsk_pipeline_memory_multi(dev, len(devices), data.ctypes.data, offsets.ctypes.data, len(offsets) - 1, alphabet, C.byref(params),
+                                           n_streams, chunk_records, repeat, 1 if fetch else 0, C.byref(st))
+        if rc != L.OK:
+            raise _SENTINELS.get(rc) or DeviceError(f"bsk_pipeline_memory_multi: {lib.bsk_err_name(rc).decode()}")
+        return st.asdict()
+
+    @staticmethod
+    def pipeline_fastx_multi(devices, path: str, params, n_streams: int = 2, chunk_records: int = 1 << 18, fetch: bool = True, alphabet: int = -1):
+        lib = L.load()
+        dev = (C.c_int * len(devices))(*devices)
+        st = L.PipelineStats()
+        rc = lib.bsk_pipeline_fastx_multi(dev, len(devices), path.encode(), alphabet, C.byref(params), n_streams, chunk_records, 1 if fetch else 0, C.byref(st))
+        if rc != L.OK:
+            raise _SENTINELS.get(rc) or DeviceError(f"bsk_pipeline_fastx_multi: {lib.bsk_err_name(rc).decode()}")
+        return st.asdict()
+
+    @staticmethod
     def pipeline_trim() -> None:
         """Return the pinned host buffers the pipelines pool between calls (bsk_pipeline_trim)."""
         L.load().bsk_pipeline_trim()

@@ -321,6 +321,14 @@ int bsk_pipeline_fastx(int device, const char *path, int alphabet /* -1: guess f
                        uint64_t chunk_records, int fetch_tuples, bsk_pipeline_stats *stats);
 int bsk_pipeline_memory(int device, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet, const bsk_params *p,
                         int n_streams, uint64_t chunk_records, int repeat, int fetch_tuples, bsk_pipeline_stats *stats);
+/* The same over SEVERAL GPUs of one node (devices[n_devices]; a device may be named more than once): one producer side, n_streams workers
+ * per device, every worker takes the next chunk from the one queue -- the role of ChunkChan feeding W workers
+ * (seqio/fastx/reader.go:562-608) with the workers spread over the node's GPUs.  Reads are independent: nothing crosses between devices,
+ * and the statistics (records, tuples, the order-independent checksum) are the whole job's. */
+int bsk_pipeline_fastx_multi(const int *devices, int n_devices, const char *path, int alphabet, const bsk_params *p, int n_streams,
+                             uint64_t chunk_records, int fetch_tuples, bsk_pipeline_stats *stats);
+int bsk_pipeline_memory_multi(const int *devices, int n_devices, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet,
+                              const bsk_params *p, int n_streams, uint64_t chunk_records, int repeat, int fetch_tuples, bsk_pipeline_stats *stats);
 /* Several files through ONE pipeline, n_readers of them (0: min(n_paths, 8)) read at the same time, each by its own producer thread --
  * the block-parallel reader for a plain file, the serial one for a gzip file (one zlib stream per file is how gzip input scales).
  * A file is closed as soon as its last chunk is on the device.  The statistics are those of the whole job. */
