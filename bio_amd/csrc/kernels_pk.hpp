@@ -511,6 +511,9 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
     const int lane = lane_id();
     PkTabs tabs;
     tabs.init(a.k, lane);
+#ifdef PK_STAGGER  // dev: workgroups start up to PK_STAGGER x ~1 us apart
+    for (u32 i = (((blockIdx.x * 2654435761u) >> 24) * (u32)PK_STAGGER) >> 8; i; --i) __builtin_amdgcn_s_sleep(32);
+#endif
     const u64 slab = (u64)64 * BSK_FAST_CAP;
     const bool uniform = a.uniform_len != 0;
     const u32 col8 = (u32)(lane & 31) * 8u;

@@ -181,6 +181,29 @@ __device__ __forceinline__ void rg_group(u32 va, u32 voh, u32 vop, const u64 *sh
 #define RG_ST(j, o8, o4) "v_alignbit_b32 %[p" #j "], %[p" #j "], %[p" #j "], 1\n\tglobal_store_dwordx2 %[voh], %[h" #j "], %[sh] offset:" #o8 " nt\n\tglobal_store_dword %[vop], %[p" #j "], %[sp] offset:" #o4 " nt\n\t"
 #endif
 #define RG_OUT [h0] "=&v"(h0), [h1] "=&v"(h1), [h2] "=&v"(h2), [h3] "=&v"(h3), [p0] "=&v"(p0), [p1] "=&v"(p1), [p2] "=&v"(p2), [p3] "=&v"(p3)
+#ifdef RG_X4TEST  // dev (timing only, results wrong): a group leaves as three 16-byte stores per lane
+    {
+        u32x4 H01, H23, PP;
+        const u32 voh2 = voh + (voh & 511u) * 3u, vop2 = vop + (vop & 255u) * 3u;  // 32 lane + 2048 (tg / 4), 16 lane + 1024 (tg / 4)
+        if constexpr (MODE == 0) {
+            asm volatile("ds_read_b128 %[a], %[va] offset:768\n\tds_read_b128 %[b], %[va] offset:784\n\tds_read_b128 %[c], %[va] offset:800\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\tglobal_store_dwordx4 %[voh], %[a], %[sh] nt\n\tglobal_store_dwordx4 %[voh], %[b], %[sh] offset:16 nt\n\t"
+                         "global_store_dwordx4 %[vop], %[c], %[sp] nt"
+                         : [a] "=&v"(H01), [b] "=&v"(H23), [c] "=&v"(PP)
+                         : [va] "v"(va & ~15u), [voh] "v"(voh2), [vop] "v"(vop2), [sh] "s"(sh), [sp] "s"(sp)
+                         : "memory");
+        } else {
+            asm volatile("ds_read_b128 %[a], %[va] offset:768\n\tds_read_b128 %[b], %[va] offset:784\n\tds_read_b128 %[c], %[va] offset:800\n\t"
+                         "s_mov_b64 %[sv], exec\n\tv_cmpx_lt_i32 0, %[hi]\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\tglobal_store_dwordx4 %[voh], %[a], %[sh] nt\n\tglobal_store_dwordx4 %[voh], %[b], %[sh] offset:16 nt\n\t"
+                         "global_store_dwordx4 %[vop], %[c], %[sp] nt\n\ts_mov_b64 exec, %[sv]"
+                         : [a] "=&v"(H01), [b] "=&v"(H23), [c] "=&v"(PP), [sv] "=&s"(sv)
+                         : [va] "v"(va & ~15u), [voh] "v"(voh2), [vop] "v"(vop2), [sh] "s"(sh), [sp] "s"(sp), [hi] "v"(hi - lo * (MODE == 2 ? 1 : 0))
+                         : "memory", "vcc");
+        }
+        return;
+    }
+#endif
     if constexpr (MODE == 0) {
         asm volatile(RG_READS "s_waitcnt lgkmcnt(4)\n\t" RG_ST(0, 0, 0) RG_ST(1, 512, 256) "s_waitcnt lgkmcnt(0)\n\t" RG_ST(2, 1024, 512) RG_ST(3, 1536, 768)
                      : RG_OUT
@@ -481,6 +504,9 @@ __global__ __launch_bounds__(64, BSK_RING_WAVES) RG_KERNEL_ATTR void k_minimizer
         tabs.init(a.k, lane);
         tabs.write(ldsq);
     }
+#ifdef RG_STAGGER  // dev: workgroups start up to RG_STAGGER x ~1 us apart (are the waves' store bursts in phase?)
+    for (u32 i = (((blockIdx.x * 2654435761u) >> 24) * (u32)RG_STAGGER) >> 8; i; --i) __builtin_amdgcn_s_sleep(32);
+#endif
     const u32 rows = a.unit_rows;  // rows of a unit's slab
     const u64 slab = (u64)64 * rows;
     const bool uniform_batch = a.uniform_len != 0;
