@@ -80,6 +80,7 @@ SYMBOLS = [
     ("bsk_batch_from_fastx", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_int, _pp, _u64p]),
     ("bsk_sketch", C.c_int, [_vp, _vp, C.POINTER(Params), _pp]),
     ("bsk_sketch_timed", C.c_int, [_vp, _vp, C.POINTER(Params), _pp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    ("bsk_batch_prepare", C.c_int, [_vp, _vp, C.POINTER(Params), C.POINTER(C.c_float)]),
     ("bsk_batch_refill_ascii", C.c_int, [_vp, _pp, _vp, _vp, C.c_uint64, C.c_int]),
     ("bsk_pipeline_fastx", C.c_int, [C.c_int, C.c_char_p, C.c_int, _vp, C.c_int, C.c_uint64, C.c_int, _vp]),
     ("bsk_pipeline_memory", C.c_int, [C.c_int, _vp, _vp, C.c_uint64, C.c_int, _vp, C.c_int, C.c_uint64, C.c_int, C.c_int, _vp]),

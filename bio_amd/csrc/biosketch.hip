@@ -196,6 +196,82 @@ __global__ void k_digest_status(const u8 *status, u64 n, u64 *out4) {
     }
 }
 
+// Length binning (KArgs::binned).  The packed minimizer / syncmer kernels walk the 64 reads of a unit in lock-step, so a unit costs its
+// LONGEST read: trimmed reads (lengths 60..150) ran at 0.64-0.73 of the fixed-length rate.  Here the reads of every chunk of 4096 -- 64
+// units -- are stably ordered by length class, so that the reads of a unit end together.  The class is the number of `gran`-wide steps
+// the kernel takes over the read: ceil((bases - lo) / gran) (lo = k - 1, gran = a multiple of the kernel's block of w k-mers; at most
+// 64 classes; slots beyond the batch sort last).  bdesc[4096 c + j] = the descriptor of chunk c's j-th read in that order | the read's
+// own place in the chunk << 12 (batches of reads shorter than 4096 bases: bits 12..23 of a descriptor are free); bflags follows rflags.
+// The kernels write the reference word and status byte of a read at its own place (out_index, kernels_generic.hpp): the permutation
+// never leaves a chunk, i.e. 32 KB of reference words written by a few wavefronts at about the same time.
+// One workgroup of 512 per chunk: wave v takes rows 8 v .. 8 v + 7 (a row = 64 consecutive reads); stable ranks inside a row come from
+// ballots, class by class; cnt[row][class] is scanned over the rows by 65 threads and the class totals by one wavefront.
+__global__ __launch_bounds__(512) void k_bin_desc(const u64 *desc, const u8 *rflags, u64 n, u32 lo, u32 gran, u64 *bdesc, u8 *bflags) {
+    __shared__ u32 cnt[64][66];  // reads of the class in the row, then the first place of that run inside its class
+    __shared__ u32 tot[66];      // reads of the class in the chunk, then the class's first place in the chunk
+    const u32 tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const u64 nchunks = (n + 4095) / 4096;
+    for (u64 c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        for (u32 i = tid; i < 64 * 66; i += 512) (&cnt[0][0])[i] = 0;
+        __syncthreads();
+        u64 d[8];
+        u32 cls[8], rank[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const u32 row = wave * 8 + j;
+            const u64 i = c * 4096 + row * 64 + lane;
+            d[j] = i < n ? desc[i] : 0;
+            u32 cl = 64;
+            if (i < n) {
+                const u32 L = (u32)(d[j] & 0xffffffULL);
+                cl = L > lo ? (L - lo + gran - 1) / gran : 0u;
+                cl = cl < 63u ? cl : 63u;
+            }
+            u32 rk = 0;
+            for (u64 todo = ~0ULL; todo;) {
+                const int first = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+                const u32 cc = (u32)__builtin_amdgcn_readlane((int)cl, first);
+                const u64 m = __builtin_amdgcn_ballot_w64(cl == cc);
+                if (cl == cc) rk = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0));
+                if ((int)lane == first) cnt[row][cc] = (u32)__builtin_popcountll(m);
+                todo &= ~m;
+            }
+            cls[j] = cl;
+            rank[j] = rk;
+        }
+        __syncthreads();
+        if (tid < 65) {
+            u32 run = 0;
+#pragma unroll 8
+            for (int r = 0; r < 64; ++r) {
+                const u32 t = cnt[r][tid];
+                cnt[r][tid] = run;
+                run += t;
+            }
+            tot[tid] = run;
+        }
+        __syncthreads();
+        if (tid < 64) {  // (class 64 = the slots beyond the batch: behind everything else)
+            const u32 t = tot[tid];
+            const u32 inc = wave_incl_scan_u32(t, (int)lane);
+            tot[tid] = inc - t;
+            if (tid == 63) tot[64] = inc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const u32 row = wave * 8 + j;
+            const u64 i = c * 4096 + row * 64 + lane;
+            if (i < n) {
+                const u64 dest = c * 4096 + tot[cls[j]] + cnt[row][cls[j]] + rank[j];
+                bdesc[dest] = d[j] | ((u64)(row * 64 + lane) << 12);
+                if (rflags) bflags[dest] = rflags[i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------
@@ -319,6 +395,8 @@ extern "C" void bsk_batch_destroy(bsk_batch *b) {
     (void)hipFree(b->subset);
     (void)hipFree(b->wbits);
     (void)hipFree(b->rflags);
+    (void)hipFree(b->bdesc);
+    (void)hipFree(b->bflags);
     (void)hipFree(b->aoff);
     (void)hipFree(b->spare_ascii);
     (void)hipFree(b->spare_aoff);
@@ -337,8 +415,10 @@ void BskOpts::load() {
     no_dense = on("BSK_NO_DENSE");
     no_pk = on("BSK_NO_PK");
     no_ring = on("BSK_NO_RING");
+    no_bin = on("BSK_NO_BIN");
     ring = on("BSK_RING");
     ring_max = env_u32("BSK_RING_MAX", 60);
+    bin_min = env_u32("BSK_BIN_MIN", 1024);
     no_tiles = on("BSK_NO_TILES");
     no_tile_cache = on("BSK_NO_TILE_CACHE");
     timing = on("BSK_TIMING");
@@ -404,6 +484,12 @@ static int batch_from_ascii_impl(bsk_ctx *ctx, const uint8_t *bytes, const uint6
     b->alphabet = alphabet;
     b->pairs = pairs;
     b->n = n;
+    if (donor) {  // the buffers of the donor's length-binned view (its contents are the donor's: bin_gran stays 0)
+        std::swap(b->bdesc, donor->bdesc);
+        std::swap(b->c_bdesc, donor->c_bdesc);
+        std::swap(b->bflags, donor->bflags);
+        std::swap(b->c_bflags, donor->c_bflags);
+    }
     const u64 nbytes = n ? offsets[n] : 0;
     b->n_bases = nbytes;
     u32 maxlen = 0;
@@ -942,6 +1028,7 @@ struct Plan {
     size_t ring_entries = 0;
     u64 slab_read = 0;     // per-sequence slabs (protein fast path)
     int fast_k = 0;
+    u32 bin_gran = 0;      // != 0: the kernel runs over the batch's length-binned descriptors (ensure_binned), classes of this many bases
     bool fused_dna = false;  // protein minimizer of a 2-bit DNA batch: the kernel translates where it fetches its residues
     // mixed batch: the fast 2-bit kernel over all reads + the general ASCII kernel over the reads with a non-ACGT letter
     bool mixed = false;
@@ -955,6 +1042,44 @@ struct Plan {
 static bool slab_budget_ok(const bsk_batch *b, u64 slab_read) {
     const double mean = b->n ? (double)b->n_bases / (double)b->n : 0.0;
     return (double)b->maxlen <= 4.0 * mean + 64.0 || (double)b->n * (double)slab_read * 12.0 < 256.0 * 1024 * 1024;
+}
+
+// Length binning pays when the reads of a unit end more than half a block of `step` k-mers apart (KArgs::binned, k_bin_desc): ragged
+// batches of short reads on the lock-step kernels.  Returns the bases per length class (a multiple of step, at most 63 classes), 0: no.
+static u32 bin_gran_for(const bsk_ctx *ctx, const bsk_batch *b, int step) {
+    if (ctx->opt.no_bin || b->uniform_len || !b->desc || b->alias || b->maxlen >= 4096u || b->n < (u64)ctx->opt.bin_min || step < 1) return 0;
+    const double mean = (double)b->n_bases / (double)b->n;
+    if (((double)b->maxlen - mean) * 2.0 < (double)step) return 0;
+    u32 g = (u32)step;
+    while (b->maxlen / g > 61u) g += (u32)step;
+    return g;
+}
+// the batch's length-binned descriptors for classes of `gran` bases above `lo`, built on the context's stream on first use and kept
+// with the batch
+static int ensure_binned(bsk_ctx *ctx, const bsk_batch *b, u32 lo, u32 gran) {
+    if (b->bin_gran == gran && b->bin_lo == lo && b->bdesc) return BSK_OK;
+    const size_t need_d = (size_t)b->n * sizeof(u64), need_f = b->rflags ? (size_t)b->n : 0;
+    if (b->c_bdesc < need_d) {
+        (void)hipFree(b->bdesc);
+        b->bdesc = nullptr;
+        b->c_bdesc = 0;
+        HIPCHK(ctx, hipMalloc(&b->bdesc, need_d + need_d / 8));
+        b->c_bdesc = need_d + need_d / 8;
+    }
+    if (b->c_bflags < need_f) {
+        (void)hipFree(b->bflags);
+        b->bflags = nullptr;
+        b->c_bflags = 0;
+        HIPCHK(ctx, hipMalloc(&b->bflags, need_f + need_f / 8));
+        b->c_bflags = need_f + need_f / 8;
+    }
+    const u64 nchunks = (b->n + 4095) / 4096;
+    hipLaunchKernelGGL(k_bin_desc, dim3((unsigned)std::min<u64>(nchunks, (u64)ctx->cus * 4)), dim3(512), 0, ctx->stream, b->desc, b->rflags, b->n, lo, gran,
+                       b->bdesc, b->rflags ? b->bflags : nullptr);
+    HIPCHK(ctx, hipGetLastError());
+    b->bin_gran = gran;
+    b->bin_lo = lo;
+    return BSK_OK;
 }
 
 // rows of 64 tuples in a unit's slab (kernels_ring.hpp): a read selects 2 / (w + 1) of its windows; + 30 % + 6, in whole groups of four
@@ -1045,6 +1170,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.slab = true;
             pl.slab_unit = (u64)64 * ring_rows(nwin, p->w);
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
+            pl.bin_gran = bin_gran_for(ctx, b, p->w);
             per_cu = ring_minimizer_blocks_per_cu(p->w);
         } else
         if (!use_ascii && dense_minimizer_supported(p->w) && b->maxlen < 32768u && nwin * 2.0 / (p->w + 1.0) > (double)ctx->opt.dense_min && !ctx->no_dense && slab_budget_ok(b, dense_slab) &&
@@ -1056,6 +1182,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.slab_read = (pl.slab_read + 15) & ~(u64)15;  // whole 128-byte lines of hashes per read
             pl.slab_unit = 64 * pl.slab_read;
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
+            pl.bin_gran = bin_gran_for(ctx, b, p->w);
             per_cu = dense_minimizer_blocks_per_cu(p->w);
         } else if (!use_ascii && pk_minimizer_supported(p->w) && b->maxlen < 32768u && !ctx->opt.force_generic && !ctx->opt.no_pk && !ctx->no_syn_pk) {
             pl.which = K_MIN_PK;  // w <= 16: packed 32-bit window machine (kernels_pk.hpp)
@@ -1064,6 +1191,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.slab = true;
             pl.slab_unit = (u64)64 * BSK_FAST_CAP;
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
+            pl.bin_gran = bin_gran_for(ctx, b, p->w);
             per_cu = pk_minimizer_blocks_per_cu(p->w);
         } else if (!use_ascii && fast_minimizer_supported(p->w) && b->maxlen < 32768u && !ctx->opt.force_generic) {
             pl.which = K_MIN_FAST;
@@ -1376,7 +1504,7 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
             break;
         default: snprintf(b, sizeof b, "?"); break;
     }
-    snprintf(res->plan, sizeof res->plan, "%s%s%s", b, pl.mixed ? " + ASCII side launch" : "", tiled ? " (over tiles)" : "");
+    snprintf(res->plan, sizeof res->plan, "%s%s%s%s", b, pl.bin_gran ? " (length-binned units)" : "", pl.mixed ? " + ASCII side launch" : "", tiled ? " (over tiles)" : "");
     res->plan_grid = pl.grid;
     res->plan_per_cu = cus > 0 ? (pl.grid + cus - 1) / cus : 0;
 }
@@ -1421,6 +1549,15 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     a.ticket = ctx->d_ticket;
     a.total = ctx->d_total;
     a.ring_w = pl.ring_w;
+    a.len_mask = 0xffffffu;
+    if (pl.bin_gran) {  // ragged short reads on a lock-step kernel: units of reads that end together (k_bin_desc)
+        const int brc = ensure_binned(ctx, b, (u32)(p->k - 1), pl.bin_gran);
+        if (brc != BSK_OK) return brc;
+        a.desc = b->bdesc;
+        a.rflags = b->rflags ? b->bflags : nullptr;
+        a.len_mask = 0xfffu;
+        a.binned = 1;
+    }
     int rc = ensure_scratch(ctx, std::max<u32>(pl.which == K_MIN_PK ? 2 * pl.nunits + (u32)(syn_pk_fixcap(b->n) / 2) : (pl.which == K_SYN_PK || pl.which == K_MIN_RING) ? (u32)(syn_pk_fixcap(b->n) / 2) : pl.slab ? 1 : pl.nunits, pl.mixed ? pl.side_nunits : 0), pl.ring_entries);
     if (rc != BSK_OK) return rc;
     a.lookback = ctx->d_lookback;
@@ -1500,6 +1637,10 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     }
     if (pl.mixed) {  // the reads with a non-ACGT letter again, from their ASCII bytes, into [main_cap, cap)
         KArgs sd = a;
+        sd.desc = b->desc;  // (the side launch names its reads by their batch positions)
+        sd.rflags = b->rflags;
+        sd.len_mask = 0xffffffu;
+        sd.binned = 0;
         sd.subset = b->subset;
         sd.nsub = b->nsub;
         sd.nunits = pl.side_nunits;
@@ -1963,6 +2104,33 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     const int rcd = done(BSK_OK);
     lap("free temporaries");
     return rcd;
+}
+
+extern "C" int bsk_batch_prepare(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, float *ms) {
+    if (ms) *ms = 0.0f;
+    if (!ctx || !batch || !p) return fail_arg(ctx, "bsk_batch_prepare: null argument");
+    if (batch->ctx != ctx) return fail_arg(ctx, "bsk_batch_prepare: the batch belongs to another context");
+    if (batch->n == 0 || p->circular || !batch->desc) return BSK_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Plan pl;
+    int rc = make_plan(ctx, batch, p, pl);
+    if (rc != BSK_OK || !pl.bin_gran) return rc == BSK_OK ? BSK_OK : BSK_OK;  // (parameters bsk_sketch would refuse are its to report)
+    hipEvent_t e0, e1;
+    HIPCHK(ctx, hipEventCreate(&e0));
+    HIPCHK(ctx, hipEventCreate(&e1));
+    batch->bin_gran = 0;  // build (again): the call is also the way to time the pass
+    hipError_t e = hipEventRecord(e0, ctx->stream);
+    rc = ensure_binned(ctx, batch, (u32)(p->k - 1), pl.bin_gran);
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float t = 0.0f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc != BSK_OK) return rc;
+    if (e != hipSuccess) return fail_hip(ctx, e, "bsk_batch_prepare");
+    if (ms) *ms = t;
+    return BSK_OK;
 }
 
 static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, bsk_result **result, int warmup, int iters,

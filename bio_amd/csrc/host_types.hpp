@@ -13,9 +13,9 @@
 // Developer switches (DESIGN.md "Switches"): read from the environment ONCE, when the context is created, or again on
 // bsk_ctx_reload_options (the test suite flips them inside one process) -- never on the bsk_sketch path.
 struct BskOpts {
-    bool force_generic = false, no_mixed = false, no_dense = false, no_pk = false, no_ring = false, ring = false, no_tiles = false, no_tile_cache = false, timing = false,
+    bool force_generic = false, no_mixed = false, no_dense = false, no_pk = false, no_ring = false, ring = false, no_bin = false, no_tiles = false, no_tile_cache = false, timing = false,
          no_fused_translate = false, sets_no_small = false;
-    u32 wpr = 0, seg = 0, dense_min = 21, ring_max = 60, waves_per_cu = 0, tile_min = 0, tile_pos = 0;  // tile_min 0: the kind's default
+    u32 wpr = 0, seg = 0, dense_min = 21, ring_max = 60, bin_min = 1024, waves_per_cu = 0, tile_min = 0, tile_pos = 0;  // tile_min 0: the kind's default
     void load();  // biosketch.hip
 };
 
@@ -68,6 +68,11 @@ struct bsk_batch {
     u32 *subset = nullptr; // reads with a non-ACGT letter, ascending (side launch of the ASCII kernels); nsub = n_nonacgt
     u64 nsub = 0;
     u8 *rflags = nullptr;
+    // length-binned view of desc / rflags (ensure_binned, biosketch.hip): built on the first sketch call that plans it, kept with the batch
+    mutable u64 *bdesc = nullptr;
+    mutable u8 *bflags = nullptr;
+    mutable u32 bin_gran = 0, bin_lo = 0;  // bases per length class (above bin_lo) the view was built with (0: not built)
+    mutable size_t c_bdesc = 0, c_bflags = 0;
     u8 *ascii = nullptr;  // DNA: kept only when some read has a non-ACGT byte; protein: always
     u64 *aoff = nullptr;
     u64 device_bytes = 0;

@@ -805,11 +805,12 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
          })) {
         u64 r = (u64)unit * 64 + lane;
         if (LIST) r = r < nlist ? (u64)a.rlist[r] : ~0ULL;
-        u64 off = 0, L = 0;
+        u64 off = 0, L = 0, ro = r;
         if (r < a.n) {
             const u64 d = a.desc[r];
             off = d >> 24;
-            L = d & 0xffffffULL;
+            L = desc_len(a, d);
+            ro = out_index(a, r, d);  // (length-binned batches: the read's own place in its chunk)
         }
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
         const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
@@ -879,11 +880,11 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
             tie = fm.tie;
         }
         if (r < a.n) {
-            a.refs[r] = ((ubase + (u64)lane * slab_read) << 24) | done;
+            a.refs[ro] = ((ubase + (u64)lane * slab_read) << 24) | done;
             u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
             if (tie && ok) sbyte |= BSK_ST_FIRST_WINDOW_TIE;
             if (ok && a.rflags) sbyte |= a.rflags[r];
-            a.status[r] = sbyte;
+            a.status[ro] = sbyte;
         }
     }
 }

@@ -35,10 +35,10 @@ struct KArgs {
     u32 *pos;
     u64 cap;  // capacity of hash[]/pos[] in tuples
     // synchronisation / scratch
-    u32 *ticket;    // [0] unit ticket, [1] overflow flag, [2..3] the same for a side launch, [4] units listed for k_minimizer_pk_fix, [5] its ticket
+    u32 *ticket;    // [0] unit ticket, [1] overflow flag, [2..3] the same for a side launch, [4] reads listed by k_syncmer_pk, [5] the list pass's ticket, [6] / [7] the same for k_minimizer_pk / k_minimizer_ring
     u32 fixcap;     // entries (reads) of the read list: k_syncmer_pk's fixlist, k_minimizer_pk's rlist
-    u32 *rlist;     // k_minimizer_pk: reads for the exact machine (k_minimizer_fast<.., LIST>), count in ticket[6], its ticket in ticket[7]
-    u64 *fixlist;   // [2 * nunits]: {unit | flags, lane mask} of the lanes the packed minimizer kernel left to its fix pass (kernels_pk.hpp)
+    u32 *rlist;     // k_minimizer_pk / k_minimizer_ring: reads for the exact machine (k_minimizer_dense<W, true>), count in ticket[6], its ticket in ticket[7]
+    u64 *fixlist;   // k_syncmer_pk: the same list as u32 read numbers (count in ticket[4], the list pass's ticket in ticket[5])
     u64 *lookback;  // [nunits]
     u64 *total;     // [0] tuples written by the dense (look-back) kernels, [1] overflow-region cursor (slab kernels)
     u64 *ring_h;    // runtime-w ring: per workgroup ring_w*64 entries
@@ -60,7 +60,17 @@ struct KArgs {
     const u8 *lut;   // device codon tables of the context (kernels_translate.hpp layout)
     int pairs;       // KMER, canonical = 0: the alphabet whose PairLetter builds the second strand (bsk_alphabet; 0 = DNAredundant)
     int one_strand;  // KMER, canonical = 0, over tiles: forward codes only (k_two_strand appends the second strand per sequence)
+    // length-binned descriptors (bsk_batch::bdesc, k_bin_desc in biosketch.hip): the reads of every chunk of 4096 (64 units) are ordered
+    // by length class, so that the 64 reads of a unit end together; a binned descriptor carries the read's place in its chunk in bits
+    // 12..23 (such batches hold reads of < 4096 bases), and the reference word / status byte of the read a lane holds belong at
+    // out_index(), not at unit * 64 + lane
+    u32 len_mask;    // 0xffffff, or 0xfff for binned descriptors
+    u32 binned;
 };
+
+__device__ __forceinline__ u64 desc_len(const KArgs &a, u64 d) { return d & (u64)a.len_mask; }
+// where the outputs of the read in slot r (descriptor d) go: r itself, or the read's own place in its chunk of 4096
+__device__ __forceinline__ u64 out_index(const KArgs &a, u64 r, u64 d) { return a.binned ? ((r & ~4095ULL) | ((d >> 12) & 4095ULL)) : r; }
 
 // read handled by (unit, lane): the batch position, or the subset entry of a side launch (~0 = no read)
 __device__ __forceinline__ u64 read_index(const KArgs &a, u32 unit, int lane) {

@@ -552,7 +552,8 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
         u32 rfl = pk_load_u8(a.rflags ? a.rflags + (r < rmax ? r : rmax) : reinterpret_cast<const u8 *>(a.desc));
         const u64 d = d_cur;
         const PkWords pw = pw_cur;
-        const u64 off = d >> 24, L = d & 0xffffffULL;
+        const u64 off = d >> 24, L = desc_len(a, d);
+        const u64 ro = out_index(a, r, d);  // (length-binned batches: the read's own place in its chunk)
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
         const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
         const u32 nk_max = wave_max_u32(nk);
@@ -613,10 +614,10 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
         if (T) pk_copyout<PK_CU>(lds, lane, cnt, excl, T, base, a);
 #endif
         if (r < a.n) {
-            if (!((redo >> lane) & 1)) a.refs[r] = ((base + excl) << 24) | cnt;  // (listed reads: the list pass writes theirs)
+            if (!((redo >> lane) & 1)) a.refs[ro] = ((base + excl) << 24) | cnt;  // (listed reads: the list pass writes theirs)
             u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
             if (ok && a.rflags) sbyte |= (u8)rfl;
-            a.status[r] = sbyte;
+            a.status[ro] = sbyte;
         }
     }
 }

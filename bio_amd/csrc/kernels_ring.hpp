@@ -547,7 +547,8 @@ __global__ __launch_bounds__(64, BSK_RING_WAVES) RG_KERNEL_ATTR void k_minimizer
         u32 rfl = pk_load_u8(a.rflags ? a.rflags + (r < rmax ? r : rmax) : reinterpret_cast<const u8 *>(a.desc));
 #endif
         const u64 d = d_cur;
-        const u64 off = d >> 24, L = d & 0xffffffULL;
+        const u64 off = d >> 24, L = desc_len(a, d);
+        const u64 ro = out_index(a, r, d);  // (length-binned batches: the read's own place in its chunk)
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
         const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
         const u32 nk_max = wave_max_u32(nk);
@@ -695,10 +696,10 @@ __global__ __launch_bounds__(64, BSK_RING_WAVES) RG_KERNEL_ATTR void k_minimizer
         d_n1 = d_n2;
         have = nxt;
         if (r < a.n) {
-            if (!((redo >> lane) & 1)) a.refs[r] = BSK_REF_ROWS | ((base + (u64)lane) << 24) | cnt;  // (listed reads: the list pass writes theirs)
+            if (!((redo >> lane) & 1)) a.refs[ro] = BSK_REF_ROWS | ((base + (u64)lane) << 24) | cnt;  // (listed reads: the list pass writes theirs)
             u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
             if (ok && a.rflags) sbyte |= (u8)rfl;
-            a.status[r] = sbyte;
+            a.status[ro] = sbyte;
         }
     }
 }

@@ -401,6 +401,14 @@ class Engine:
         res.h, res.params, res._host = h, p, None
         return res, [ms[i] for i in range(iters)]
 
+    def prepare(self, batch: Batch, p: L.Params) -> float:
+        """Per-batch preparation a sketch with these parameters would do on its first call (length-binned units of a ragged batch),
+        done now; returns the device milliseconds of the pass (0.0: the plan needs none).  bsk_batch_prepare."""
+        ms = C.c_float(0.0)
+        self._opts()
+        self._chk(self.lib.bsk_batch_prepare(self.ctx, batch.h, C.byref(p), C.byref(ms)))
+        return float(ms.value)
+
     def sync(self):
         self._chk(self.lib.bsk_ctx_sync(self.ctx))
 

@@ -254,6 +254,13 @@ int bsk_sketch(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, bsk_re
 int bsk_sketch_timed(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, bsk_result **result,
                      int warmup, int iters, float *kernel_ms);
 
+/* Per-batch preparation a sketch with these parameters would do on its first call, done now (optional; bsk_sketch does it itself and
+ * keeps it with the batch): today the LENGTH-BINNED view of a ragged batch of short reads -- the kernels walk the 64 reads of a unit
+ * in lock-step, so the reads of every chunk of 4096 are grouped by length before units are formed (reference words and status bytes
+ * stay at the reads' own positions).  *ms (may be NULL) receives the device time of the pass, 0 when the plan needs none.  The
+ * reference has no counterpart: its cost is per base of one sequence at a time (sketches/sketch.go:46). */
+int bsk_batch_prepare(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, float *ms);
+
 int bsk_result_info(const bsk_result *r, uint64_t *n_reads, uint64_t *n_tuples, int *has_pos);
 /* What ran: the name of the kernel the planner launched for this result, as a profiler shows it
  * ("k_minimizer_fast<11,32,true>", "k_syncmer<1>", "... (over tiles)"), its grid and the workgroups (= wavefronts) per CU

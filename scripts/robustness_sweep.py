@@ -1,0 +1,74 @@
+"""GPU: the minimizer path off its headline point -- one JSON line per case.
+
+  uniform read lengths 100 / 150 / 151 / 200 / 250 / 300, a ragged batch (lengths uniform in 60..150: trimmed reads) with and
+  without length-binned units, 2 % / 10 % of the reads ending in a 50-base poly-A tail.  k = 21, w = 11, ~3e9 bases per case,
+  inputs and outputs resident in HBM, min / median of 5 launches (HIP events around the kernels, bsk_sketch_timed).
+usage: python scripts/robustness_sweep.py [bases] > profiles/r04/robustness.jsonl"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from bio_amd import sketches as S, _lib as L
+
+BASES = float(sys.argv[1]) if len(sys.argv) > 1 else 3e9
+K, W = 21, 11
+eng = S.Engine(0)
+rng = np.random.default_rng(12)
+
+
+def run(case, b, nbases, extra=None):
+    p = eng.params(L.MINIMIZER, K, w=W)
+    prep_first = eng.prepare(b, p)  # (allocates the view's buffers: a streaming caller re-uses them, bsk_batch_refill_ascii)
+    prep = min(eng.prepare(b, p) for _ in range(3)) if prep_first else 0.0
+    res, ms = eng.run_timed(b, p, 2, 5)
+    ms = sorted(ms)
+    inf, plan = res.info(), res.plan()
+    dg = res.digest()
+    out = dict(case=case, kernel=plan["kernel"], waves_per_cu=plan["waves_per_cu"], reads=inf["n_reads"], bases=int(nbases), tuples=inf["n_tuples"],
+               kernel_ms_min=round(ms[0], 4), kernel_ms_median=round(ms[len(ms) // 2], 4), gbases_per_s=round(nbases / ms[0] / 1e6, 1),
+               gbases_per_s_median=round(nbases / ms[len(ms) // 2] / 1e6, 1), prepare_ms=round(prep, 4), prepare_first_ms=round(prep_first, 4),
+               gbases_per_s_with_prepare=round(nbases / (ms[0] + prep) / 1e6, 1), checksum=dg["checksum"], first_window_tie_reads=dg.get("first_window_tie", None))
+    if extra:
+        out.update(extra)
+    print(json.dumps(out), flush=True)
+    res.close()
+    return out
+
+
+def ragged(lo, hi, n):
+    lens = rng.integers(lo, hi + 1, n, dtype=np.uint64)
+    offs = np.zeros(n + 1, np.uint64)
+    np.cumsum(lens, out=offs[1:])
+    data = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(offs[-1]), dtype=np.uint8)]
+    return data, offs
+
+
+base = None
+for rl in (100, 150, 151, 200, 250, 300):
+    n = int(BASES / rl)
+    b = eng.synth(L.ALPHA_DNA, n, rl, 0x5EED0003)
+    o = run("uniform %d bp" % rl, b, n * rl)
+    if rl == 150:
+        base = o["gbases_per_s"]
+    b.close()
+
+n = int(BASES / 105 / 1.5)  # (host-generated: two thirds of the bases)
+data, offs = ragged(60, 150, n)
+b = eng.batch_from_arrays(data, offs)
+r1 = run("ragged 60..150 bp, length-binned units", b, int(offs[-1]), dict(vs_uniform_150=None))
+os.environ["BSK_NO_BIN"] = "1"
+r2 = run("ragged 60..150 bp, units in batch order (BSK_NO_BIN)", b, int(offs[-1]))
+del os.environ["BSK_NO_BIN"]
+b.close()
+assert r1["checksum"] == r2["checksum"], "binned and unbinned digests differ"
+del data, offs
+
+n, rl = int(BASES / 150 / 1.5), 150
+for frac in (0.02, 0.10):
+    d = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n * rl, dtype=np.uint8)].copy().reshape(n, rl)
+    d[rng.random(n) < frac, 100:] = ord("A")
+    b = eng.batch_from_arrays(d.reshape(-1), np.arange(n + 1, dtype=np.uint64) * rl)
+    run("%d %% of the reads end in a 50-base poly-A tail" % round(frac * 100), b, n * rl)
+    b.close()
+print(json.dumps(dict(case="summary", uniform_150=base, ragged_binned_over_uniform_150=round(r1["gbases_per_s"] / base, 3),
+                      ragged_binned_with_prepare_over_uniform_150=round(r1["gbases_per_s_with_prepare"] / base, 3),
+                      ragged_unbinned_over_uniform_150=round(r2["gbases_per_s"] / base, 3))))
