@@ -244,6 +244,54 @@ def plumbing_counters(rank: int):
     return [int((1.0 + 0.5 * rank) * 1e9), 15_000_000_000 + rank, 2_211_224_063 + 7 * rank, 88 + rank, 0]
 
 
+def power_probe(eng, batch, p, res, k_ms, device, bases_per_launch, seconds=2.5):
+    """Board power and shader clock while the SAME launch loops for a few seconds (outside the timed region): rocm-smi samples from a
+    side thread.  The sketch kernels run against the board's power limit, not against a pipe: this is the evidence."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    samples, stop = [], threading.Event()
+
+    def sample():
+        while not stop.is_set():
+            try:
+                o = subprocess.run([smi, "-d", str(device), "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5).stdout
+                pw = re.search(r"Package Power \(W\):\s*([0-9.]+)", o)
+                sc = re.search(r"sclk clock level:\s*\S+\s*\((\d+)Mhz\)", o)
+                if pw and sc:
+                    samples.append((float(pw.group(1)), int(sc.group(1))))
+            except Exception:
+                pass
+            stop.wait(0.15)
+
+    cap = None
+    try:
+        o = subprocess.run([smi, "-d", str(device), "--showmaxpower"], capture_output=True, text=True, timeout=5).stdout
+        m = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", o)
+        cap = float(m.group(1)) if m else None
+    except Exception:
+        pass
+    iters = max(8, int(seconds * 1e3 / max(k_ms, 0.05)))
+    eng.run_timed(batch, p, 0, max(4, iters // 5), reuse=res)  # the board warms up before the first sample
+    th = threading.Thread(target=sample, daemon=True)
+    th.start()
+    _, ms = eng.run_timed(batch, p, 0, iters, reuse=res)
+    stop.set()
+    th.join(timeout=6)
+    busy = [x for x in samples if x[1] > 500]  # (a sample taken before / after the loop shows the idle clock)
+    if not busy:
+        return None
+    pw = statistics.median(x[0] for x in busy)
+    rate = bases_per_launch / (sum(ms) / len(ms) * 1e-3)
+    return {"board_power_w": pw, "power_cap_w": cap, "sclk_mhz": statistics.median(x[1] for x in busy), "samples": len(busy),
+            "loop_seconds": round(sum(ms) / 1e3, 2), "units_per_s_in_loop": round(rate / 1e9, 1), "nj_per_unit": round(pw / rate * 1e9, 4),
+            "note": "rocm-smi samples while the same launch loops (untimed, after the measurement); nj_per_unit = board power / bases (residues) per second"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -253,6 +301,7 @@ def main():
     ap.add_argument("--reads", type=float, default=0, help="override reads per GPU (dev)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the file/host-memory -> host-tuples side measurement")
+    ap.add_argument("--no-power-probe", action="store_true", help="skip the rocm-smi power / clock samples taken while the launch loops after the measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the rendezvous / barriers")
     ap.add_argument("--plumbing-only", action="store_true", help="tests: N>1 control flow with stand-in counters, no GPU, no kernel")
     args = ap.parse_args()
@@ -414,6 +463,11 @@ def main():
                                       "roofline of the committed PMC pass (SQ_INSTS_VALU x the mean issue cost of the kernel's inner-loop instruction mix, "
                                       "scripts/valu_model.py, over the dispatch's SIMD-cycles) and `binding_ceiling` names the larger of the two fractions",
             }
+        if kernel_ms and not args.no_power_probe and not args.plumbing_only:
+            try:
+                out["roofline"]["power"] = power_probe(eng, batch, p, res, sum(kernel_ms) / len(kernel_ms), local_rank, n_reads * read_len)
+            except Exception as e:
+                out["roofline"]["power"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and not args.plumbing_only:
             out["cpu_baseline"] = cpu_baseline(kind, k, x, read_len, batch)
         if world == 1 and not args.no_end_to_end and not args.plumbing_only:

@@ -417,7 +417,7 @@ void BskOpts::load() {
     no_ring = on("BSK_NO_RING");
     no_bin = on("BSK_NO_BIN");
     ring = on("BSK_RING");
-    ring_max = env_u32("BSK_RING_MAX", 60);
+    ring_max = env_u32("BSK_RING_MAX", 42);
     bin_min = env_u32("BSK_BIN_MIN", 1024);
     no_tiles = on("BSK_NO_TILES");
     no_tile_cache = on("BSK_NO_TILE_CACHE");
@@ -1716,6 +1716,12 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
     rc = make_plan(ctx, b, p, pl);
     if (rc != BSK_OK) return cleanup(rc);
     u64 ovf_cap = pl.slab ? std::max<u64>(65536, pl.slab_total / 50) : 0;
+    if (pl.which == K_MIN_PK || pl.which == K_MIN_RING) {
+        // the list pass gives every listed read a slab of one tuple per window out of this region (a wavefront claims 64 of them): room
+        // for 1.5 % of the reads -- low-complexity tails are per cent of real reads -- before the call has to be sized again
+        const u64 nwin_max = b->maxlen + 2 > (u32)(p->k + p->w) ? (u64)b->maxlen - p->k - p->w + 2 : 1;
+        ovf_cap += (b->n / 64 + 64) * ((nwin_max + 15) & ~(u64)15);
+    }
     if (pl.slab && *result && (*result)->ovf_cap > ovf_cap) ovf_cap = (*result)->ovf_cap;
     u64 cap = pl.slab ? pl.slab_total + ovf_cap : estimate_cap(b, p, circ_ext);
     u64 side_cap = (pl.mixed && kind_has_pos(p->kind)) ? estimate_cap_n(p, b->nsub * (u64)b->maxlen, b->nsub) : 0;  // maxlen already includes a circular extension
