@@ -416,6 +416,7 @@ void BskOpts::load() {
     no_pk = on("BSK_NO_PK");
     no_ring = on("BSK_NO_RING");
     no_bin = on("BSK_NO_BIN");
+    compact = on("BSK_COMPACT");
     ring = on("BSK_RING");
     ring_max = env_u32("BSK_RING_MAX", 42);
     bin_min = env_u32("BSK_BIN_MIN", 1024);
@@ -1028,6 +1029,7 @@ struct Plan {
     size_t ring_entries = 0;
     u64 slab_read = 0;     // per-sequence slabs (protein fast path)
     int fast_k = 0;
+    bool compact = false;  // stream kernels, fixed-length batch: runs without padding (k_nthash_fast<MODE, true>)
     u32 bin_gran = 0;      // != 0: the kernel runs over the batch's length-binned descriptors (ensure_binned), classes of this many bases
     bool fused_dna = false;  // protein minimizer of a 2-bit DNA batch: the kernel translates where it fetches its residues
     // mixed batch: the fast 2-bit kernel over all reads + the general ASCII kernel over the reads with a non-ACGT letter
@@ -1125,6 +1127,22 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
     return make_plan_enc(ctx, b, p, pl, has_n);
 }
 
+// k_nthash_fast<MODE, true>: a fixed-length batch of reads with at least 32 values each leaves without any padding (a line shared by
+// two reads is assembled at the end of the unit); batches with non-ACGT reads (the ASCII side launch rewrites runs in place) and tile
+// batches keep the line-padded runs
+// MEASURED AND REJECTED (round 4, NOTEBOOK): 11 % fewer bytes written, and 10 % slower -- the kernel is not bound by the bytes it writes
+// (without the shared lines, i.e. 12 % fewer lines, it takes exactly the padded kernel's time), and assembling the shared lines costs
+// what it costs.  Built only with make EXPERIMENTS=1 and chosen only with BSK_COMPACT=1 (tests/test_gpu_compact_streams.py).
+static bool stream_compact_ok(const bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p) {
+#ifdef BSK_EXPERIMENTS
+    if (!ctx->opt.compact || !b->uniform_len || b->alias || b->n_nonacgt || p->circular) return false;
+    return b->uniform_len >= (u32)p->k + 31u;
+#else
+    (void)ctx, (void)b, (void)p;
+    return false;
+#endif
+}
+
 static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan &pl, bool use_ascii) {
     pl.nunits = (u32)((b->n + 63) / 64);
     int per_cu = 1;
@@ -1210,7 +1228,11 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.which = K_NT_FAST;
             // write-bound kernel: measured fastest at 4 waves/CU (more concurrent 128-byte write streams per XCD
             // thrash the L2 write-combining: 3.65 ms vs 5.27 ms at 15 waves/CU for 10M reads)
+            pl.compact = stream_compact_ok(ctx, b, p);
             per_cu = p->canonical ? blocks_per_cu(k_nthash_fast<1>) : blocks_per_cu(k_nthash_fast<0>);
+#ifdef BSK_EXPERIMENTS
+            if (pl.compact) per_cu = p->canonical ? blocks_per_cu(k_nthash_fast<1, true>) : blocks_per_cu(k_nthash_fast<0, true>);
+#endif
         } else {
             pl.which = use_ascii ? K_NT_A : K_NT_P;
             per_cu = use_ascii ? blocks_per_cu(k_nthash_stream<1>) : blocks_per_cu(k_nthash_stream<0>);
@@ -1243,7 +1265,11 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         if (!use_ascii && p->canonical > 0 && b->maxlen + (u32)(p->circular ? p->k : 0) <= 16u * (BSK_NT_FAST_WORDS - 2) &&
             !ctx->opt.force_generic) {
             pl.which = K_NT_FAST;  // same streaming kernel, MODE 2
+            pl.compact = stream_compact_ok(ctx, b, p);
             per_cu = blocks_per_cu(k_nthash_fast<2>);
+#ifdef BSK_EXPERIMENTS
+            if (pl.compact) per_cu = blocks_per_cu(k_nthash_fast<2, true>);
+#endif
         } else {
             pl.which = use_ascii ? K_KMER_A : K_KMER_P;
             per_cu = use_ascii ? blocks_per_cu(k_kmer<1>) : blocks_per_cu(k_kmer<0>);
@@ -1486,7 +1512,7 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
         case K_MIN_DENSE: snprintf(b, sizeof b, "k_minimizer_dense<%d>", pl.fast_w); break;
         case K_MIN_SEG: snprintf(b, sizeof b, "k_minimizer_seg<%d>", pl.fast_w); break;
         case K_MIN_WPR: snprintf(b, sizeof b, "k_minimizer_wpr<%d>", pl.fast_w); break;
-        case K_NT_FAST: snprintf(b, sizeof b, "k_nthash_fast<%d>", p->kind == BSK_KMER ? 2 : p->canonical ? 1 : 0); break;
+        case K_NT_FAST: snprintf(b, sizeof b, pl.compact ? "k_nthash_fast<%d,true>" : "k_nthash_fast<%d>", p->kind == BSK_KMER ? 2 : p->canonical ? 1 : 0); break;
         case K_SYN_P: snprintf(b, sizeof b, "k_syncmer<0>"); break;
         case K_SYN_A: snprintf(b, sizeof b, "k_syncmer<1>"); break;
         case K_KMER_P: snprintf(b, sizeof b, "k_kmer<0>"); break;
@@ -1630,6 +1656,13 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
             else hipLaunchKernelGGL(k_simhash_fast<6>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             break;
         case K_NT_FAST:
+#ifdef BSK_EXPERIMENTS
+            if (pl.compact) {
+                if (a.kind == BSK_KMER) hipLaunchKernelGGL((k_nthash_fast<2, true>), dim3(pl.grid), dim3(64), 0, ctx->stream, a);
+                else if (a.canonical) hipLaunchKernelGGL((k_nthash_fast<1, true>), dim3(pl.grid), dim3(64), 0, ctx->stream, a);
+                else hipLaunchKernelGGL((k_nthash_fast<0, true>), dim3(pl.grid), dim3(64), 0, ctx->stream, a);
+            } else
+#endif
             if (a.kind == BSK_KMER) hipLaunchKernelGGL(k_nthash_fast<2>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             else if (a.canonical) hipLaunchKernelGGL(k_nthash_fast<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             else hipLaunchKernelGGL(k_nthash_fast<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);

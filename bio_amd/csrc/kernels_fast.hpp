@@ -898,11 +898,20 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
 // ---------------------------------------------------------------------------------------
 #define BSK_NT_FAST_WORDS 34  // reads of up to 32*16 = 512 bases (+2 words of look-ahead)
 // MODE 0: ntHash forward strand, 1: canonical ntHash, 2: canonical 2-bit k-mer code (NextKmer, iterator.go:708-759, k <= 32)
-template <int MODE>
+// CP ("compact runs", fixed-length batches of reads with >= 32 values; an EXPERIMENT -- measured and rejected, see stream_compact_ok in
+// biosketch.hip -- instantiated only with make EXPERIMENTS=1): no padding at all.  Read l of a unit starts at
+//   unit base + l * nk  (the unit's 64 nk values are one run; 64 nk is a multiple of 16, so units start on lines)
+// and the 128-byte lines are written WHOLE all the same: the tile row is a ring of the last 32 values of a read; after block b a
+// read's line b -- values [16 b - e, 16 b + 16 - e), e = the read's start modulo 16 -- leaves if it lies inside the read, and the
+// lines that hold the tail of one read and the head of the next (one per read) leave at the end of the unit, assembled from the
+// ring and from the heads, which every lane keeps in registers since block 0.  Padded runs cost 144 values written for 130
+// (k = 21, 150 bases): 11 % of the write traffic of a write-bound kernel.
+template <int MODE, bool CP = false>
 __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
-    constexpr int TL = 18;  // u64 per tile row (16 + 2 pad: 144-byte rows keep 16-byte alignment, 2-way conflicts at most)
+    constexpr int TL = CP ? 34 : 18;  // u64 per tile row (16 + 2 pad: 144-byte rows keep 16-byte alignment, 2-way conflicts at most; CP: a ring of 32 + 2)
     constexpr int NWL = BSK_NT_FAST_WORDS;          // packed words of a read staged in LDS
     constexpr int SW_OFF = 512 + 64 * TL * 8;
+    static_assert(!CP || NWL * 64 * 4 >= 64 * 17 * 8, "the heads of a unit take the words' place");
     __shared__ __attribute__((aligned(16))) char lds[SW_OFF + NWL * 64 * 4];
     __shared__ u64 s_off[64];
     __shared__ u32 s_nk[64];
@@ -912,6 +921,15 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
     __syncthreads();
     const int k = a.k;
     __shared__ u64 s_base[8];
+    u32 wa0[CP ? 16 : 1], wa1[CP ? 16 : 1];  // CP: LDS addresses of this lane's 16 values of an even / odd block
+    if constexpr (CP) {
+        const u32 e = ((u32)lane * (a.uniform_len - (u32)k + 1u)) & 15u;  // the read's start modulo 16 (reads of a unit are nk apart)
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            wa0[o] = 512u + (u32)lane * (u32)(TL * 8) + (((u32)o + e) & 31u) * 8u;
+            wa1[o] = 512u + (u32)lane * (u32)(TL * 8) + ((16u + (u32)o + e) & 31u) * 8u;
+        }
+    }
     for (;;) {
       const u32 u0 = next_ticket(a.ticket, lane) * 8u;
       if (u0 >= a.nunits) break;
@@ -949,11 +967,11 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
         const u32 nk_max = wave_max_u32(nk);
         // every read's run starts on a 128-byte line and is padded to whole lines (16 values): each 16-step flush
         // then writes full, aligned lines (measured WRITE_SIZE 1.24x -> ~1.0x of the algorithmic bytes)
-        const u32 pk = (nk + 15u) & ~15u;
+        const u32 pk = CP ? nk : (nk + 15u) & ~15u;
         const u64 incl = wave_incl_scan_u64((u64)pk, lane);
         const u64 T = wave_bcast_u64(incl, 63);
-        const u64 base = a.uniform_len ? (u64)unit * 64 * ((nk_max + 15u) & ~15u) : s_base[unit - u0];
-        const bool ovf = base + T > a.cap;
+        const u64 base = CP ? (u64)unit * 64 * nk_max : a.uniform_len ? (u64)unit * 64 * ((nk_max + 15u) & ~15u) : s_base[unit - u0];
+        const bool ovf = base + ((T + 15u) & ~(u64)15) > a.cap;  // (CP: the last line of a partial unit is written whole)
         if (ovf && lane == 0) atomicOr(&a.ticket[1], 1u);
         if (r < a.n) {
             a.refs[r] = ((base + incl - pk) << 24) | nk;
@@ -974,6 +992,15 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
             roff[rr] = s_off[rr * 8 + (lane >> 3)] + (u32)(lane & 7) * 2;
             rnk[rr] = s_nk[rr * 8 + (lane >> 3)];
         }
+        u32 re[8];  // CP: the served row's start modulo 16 (its line b begins e values before its block b)
+        if (CP) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                re[rr] = ((u32)(rr * 8 + (lane >> 3)) * nk_max) & 15u;
+                roff[rr] -= re[rr];
+            }
+        }
+        u64 hv[CP ? 16 : 1];  // CP: the read's first 16 values
         // the read's packed words go to LDS once ([word][lane]: conflict-free): the k-mer loop then has no global loads,
         // so its flush stores stay in flight across blocks (with loads in the loop the compiler's s_waitcnt vmcnt(0)
         // made every block wait for the previous flush to reach memory)
@@ -1007,8 +1034,11 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
                 }
             }
         }
-        LDSQ char *const myrow = lq + 512 + lane * (TL * 8);
-        for (u32 i0 = 0; i0 < nk_max; i0 += 16) {
+        LDSQ char *const myrow0 = lq + 512 + lane * (TL * 8);
+        // one block of 16 values + its flush.  CP: the row is a ring of two blocks, PAR = which half this block's values go to -- shifted by
+        // the read's start modulo 16 (wa0 / wa1), so that the ring columns [16 PAR, 16 PAR + 16) hold exactly line b of the row
+        auto blockfn = [&](auto parc, const u32 i0) {
+            constexpr int PAR = decltype(parc)::value;
             const u32 t0 = i0 + (u32)k - 1, p0 = i0 ? i0 - 1 : 0;
             const u32 cinb = __builtin_amdgcn_alignbit(sw[((t0 >> 4) + 1) * 64 + lane], sw[(t0 >> 4) * 64 + lane], (t0 & 15) * 2);
             const u32 olo = sw[(p0 >> 4) * 64 + lane], ohi = sw[((p0 >> 4) + 1) * 64 + lane];
@@ -1043,11 +1073,37 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
                         hh = sel(rev, rh_, fh_);
                     }
                 }
-                *reinterpret_cast<LDSQ u64 *>(myrow + o * 8) = ((u64)hh << 32) | hl;
+                if constexpr (CP) *reinterpret_cast<LDSQ u64 *>(lq + (PAR ? wa1[o] : wa0[o])) = ((u64)hh << 32) | hl;
+                else *reinterpret_cast<LDSQ u64 *>(myrow0 + o * 8) = ((u64)hh << 32) | hl;
             }
             wave_sync_lds();
             // flush: 8 x (16 bytes per lane = 128 bytes per read); runs are padded to whole lines, so a lane either
             // stores its full 16 bytes or nothing (the padding receives whatever the tile holds)
+            if constexpr (CP) {
+#ifndef NTCP_NOBOUNDARY
+                if (i0 == 0) {
+#pragma unroll
+                    for (int o = 0; o < 16; ++o) hv[o] = *reinterpret_cast<LDSQ const u64 *>(lq + wa0[o]);
+                }
+#endif
+                u32x4 tv[8];
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr)
+                    tv[rr] = *reinterpret_cast<LDSQ const u32x4 *>(lq + 512 + (rr * 8 + (lane >> 3)) * (TL * 8) + PAR * 128 + (lane & 7) * 16);
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {  // the line leaves if it lies inside the read (its first and its last line wait for the neighbours)
+#ifdef NTCP_ALLSTORE  // dev (timing only)
+                    if (rnk[rr]) {
+#else
+                    if (rnk[rr] && i0 >= re[rr] && i0 - re[rr] + 16u <= rnk[rr]) {
+#endif
+                        u64x2_a8 vv;
+                        vv.a = ((u64)tv[rr].y << 32) | tv[rr].x;
+                        vv.b = ((u64)tv[rr].w << 32) | tv[rr].z;
+                        nt_store_u64x2(a.hash + roff[rr] + i0, vv.a, vv.b);
+                    }
+                }
+            } else {
             u32x4 tv[8];
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr)
@@ -1061,8 +1117,48 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
                     nt_store_u64x2(a.hash + roff[rr] + i0, vv.a, vv.b);
                 }
             }
+            }
+            wave_sync_lds();
+        };
+        if constexpr (CP) {
+            for (u32 i0 = 0; i0 < nk_max; i0 += 32) {
+                blockfn(std::integral_constant<int, 0>{}, i0);
+                if (i0 + 16 < nk_max) blockfn(std::integral_constant<int, 1>{}, i0 + 16);
+            }
+        } else {
+            for (u32 i0 = 0; i0 < nk_max; i0 += 16) blockfn(std::integral_constant<int, 0>{}, i0);
+        }
+#ifndef NTCP_NOBOUNDARY  // dev (timing only)
+        if constexpr (CP) {
+            // the lines shared by two reads: tail of row (from its ring) + head of row + 1 (from the heads, which take the words' place)
+            LDSQ char *const hd = lq + SW_OFF;
+#pragma unroll
+            for (int o = 0; o < 16; ++o) *reinterpret_cast<LDSQ u64 *>(hd + (lane * 17 + o) * 8) = hv[o];
+            wave_sync_lds();
+            const u32 NK = nk_max;
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const u32 row = (u32)(rr * 8 + (lane >> 3));
+                const u32 end = (row + 1u) * NK;              // unit-relative index one past the row's last value
+                const u32 ls = (end - 1u) & ~15u;             // the line that holds that value
+                const u32 g = ls + (u32)(lane & 7) * 2;       // this lane's two values of it
+                u64 v[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const u32 gi = g + (u32)q;
+                    const bool tail = gi < end;
+                    const u32 tcol = (gi - row * NK + re[rr]) & 31u;              // (ring column = value index + the row's shift; the line begins inside the row: NK >= 32)
+                    const u32 hcol = tail ? 0u : (gi - end);                      // < 16
+                    const u32 hrow = row + 1u < 64u ? row + 1u : 63u;
+                    const u64 tv_ = *reinterpret_cast<LDSQ const u64 *>(lq + 512 + row * (TL * 8) + tcol * 8u);
+                    const u64 hv_ = *reinterpret_cast<LDSQ const u64 *>(hd + (hrow * 17u + hcol) * 8u);
+                    v[q] = tail ? tv_ : hv_;
+                }
+                if (rnk[rr] && (end & 15u)) nt_store_u64x2(a.hash + base + g, v[0], v[1]);
+            }
             wave_sync_lds();
         }
+#endif
       }
     }
 }
