@@ -97,6 +97,7 @@ SYMBOLS = [
     ("bsk_result_plan", C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("bsk_result_info", C.c_int, [_vp, _u64p, _u64p, C.POINTER(C.c_int)]),
     ("bsk_result_fetch", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp, C.c_uint64]),
+    ("bsk_result_fetch_narrow", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp, C.c_uint64, _u64p]),
     ("bsk_result_device", C.c_int, [_vp, _pp, _pp, _pp, _pp]),
     ("bsk_result_compact", C.c_int, [_vp, _vp, _pp, _pp, _pp, _u64p]),
     ("bsk_result_device_wide", C.c_int, [_vp, _pp, _pp]),

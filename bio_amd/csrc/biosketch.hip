@@ -533,7 +533,18 @@ static int batch_from_ascii_impl(bsk_ctx *ctx, const uint8_t *bytes, const uint6
     b->device_bytes = nbytes + 64 + (n + 1) * 8;
     if (alphabet == BSK_ALPHA_DNA) {
         const bool wide = maxlen >= (1u << 24);  // desc cannot hold such a length: sequences are located by fw + llen
-        std::vector<u64> desc(n ? n : 1), llen(wide ? n : 0);
+        // (descriptors are built in the context's pinned staging words: a pageable std::vector made the 2 MB copy of every streamed
+        // chunk a staged, synchronous one)
+        if (ctx->h_refs_cap < n + 1) {
+            if (ctx->h_refs) (void)hipHostFree(ctx->h_refs);
+            ctx->h_refs = nullptr;
+            ctx->h_refs_cap = 0;
+            const size_t want = (n + 1) + (n + 1) / 4 + 64;
+            BCHK(hipHostMalloc(&ctx->h_refs, want * 8));
+            ctx->h_refs_cap = want;
+        }
+        u64 *const desc = ctx->h_refs;
+        std::vector<u64> llen(wide ? n : 0);
         u64 w = 0;
         for (u64 r = 0; r < n; ++r) {
             u64 L = offsets[r + 1] - offsets[r];
@@ -553,7 +564,7 @@ static int batch_from_ascii_impl(bsk_ctx *ctx, const uint8_t *bytes, const uint6
         BCHK(take((void **)&b->rflags, &b->c_rflags, n ? n : 1, donor ? (void **)&donor->rflags : nullptr, donor ? &donor->c_rflags : nullptr));
         BCHK(hipMemsetAsync(b->words, 0, alloc_words * sizeof(u32), ctx->stream));
         BCHK(hipMemsetAsync(b->rflags, 0, n ? n : 1, ctx->stream));
-        if (n) BCHK(hipMemcpyAsync(wide ? b->fw : b->desc, desc.data(), n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        if (n) BCHK(hipMemcpyAsync(wide ? b->fw : b->desc, desc, n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
         BCHK(hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream));
         if (maxlen > (ctx->opt.tile_min ? ctx->opt.tile_min : 16u * (BSK_NT_FAST_WORDS - 2)) && w) {  // this batch may be tiled: remember which words hold non-ACGT letters
             BCHK(hipMalloc(&b->wbits, ((w + 31) / 32) * sizeof(u32)));

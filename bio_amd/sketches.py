@@ -165,6 +165,22 @@ class BatchResult:
                                                     pos.ctypes.data if pos is not None else None, max(T, 1)))
         return offs, status[:count], hash_[:T], (pos[:T] if pos is not None else None)
 
+    def fetch_narrow(self, first: int = 0, count: Optional[int] = None):
+        """bsk_result_fetch_narrow -> (offsets[count+1] u32, status[count], hash[T], pos[T] u16 (bit 15 = strand) or None)"""
+        inf = self.info()
+        if count is None:
+            count = inf["n_reads"] - first
+        offs = np.zeros(count + 1, np.uint32)
+        status = np.zeros(max(count, 1), np.uint8)
+        cap = max(int(inf["n_tuples"]), 1)
+        hash_ = np.zeros(cap, np.uint64)
+        pos = np.zeros(cap, np.uint16) if inf["has_pos"] else None
+        nt = C.c_uint64()
+        self.eng._chk(self.eng.lib.bsk_result_fetch_narrow(self.eng.ctx, self.h, first, count, offs.ctypes.data, status.ctypes.data, hash_.ctypes.data,
+                                                           pos.ctypes.data if pos is not None else None, cap, C.byref(nt)))
+        T = int(nt.value)
+        return offs, status[:count], hash_[:T], (pos[:T] if pos is not None else None)
+
     def sets(self, whole_batch: bool = False, scale: int = 1):
         """Sorted distinct hash values per sequence (or of the whole batch), optionally FracMinHash-filtered
         (bsk_result_sets) -> (offsets[n_sets+1], values)."""

@@ -271,6 +271,14 @@ int bsk_result_plan(const bsk_result *r, const char **kernel, int *grid, int *wa
 int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t first, uint64_t count,
                      uint64_t *offsets, uint8_t *status, uint64_t *hash, uint32_t *pos,
                      uint64_t tuple_cap);
+/* The same with narrow side arrays, for streaming callers that move every tuple over the link (bsk_pipeline_*): offsets[count+1] as
+ * u32 (scanned on the device: no round trip for the reference words), positions as u16 -- 15 bits + the strand in bit 15
+ * (BSK_POS16_STRAND_BIT) -- i.e. 10 bytes per tuple + 5 per read instead of 12 + 17.  BSK_ERR_UNSUPPORTED when a position needs
+ * more than 15 bits (reads of 32 768 bases or more) or the range holds 2^32 tuples; *n_tuples (may be NULL) receives the count. */
+#define BSK_POS16_STRAND_BIT 0x8000u
+#define BSK_POS16_MASK 0x7fffu
+int bsk_result_fetch_narrow(bsk_ctx *ctx, const bsk_result *r, uint64_t first, uint64_t count, uint32_t *offsets, uint8_t *status,
+                            uint64_t *hash, uint16_t *pos, uint64_t tuple_cap, uint64_t *n_tuples);
 /* Dense device copy for device-side consumers (CSR: what bsk_result_fetch delivers to the host, left on the device): offsets[n+1]
  * (u64, offsets[n] = *n_tuples), hash[*n_tuples], pos[*n_tuples] (*pos = NULL for the kinds with implicit positions; pos may be NULL).
  * The arrays belong to the context and stay valid until the next bsk_result_compact on it (or bsk_ctx_destroy).  The reference has no

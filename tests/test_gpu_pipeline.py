@@ -191,3 +191,36 @@ def test_pinned_buffers_are_pooled_between_runs(engine):
     assert first["checksum"] == again["checksum"] == fresh["checksum"] and first["tuples"] == again["tuples"] == fresh["tuples"]
     assert again["pin_seconds"] < 0.5 * first["pin_seconds"], (first["pin_seconds"], again["pin_seconds"])
     assert fresh["pin_seconds"] > again["pin_seconds"], (fresh["pin_seconds"], again["pin_seconds"])
+
+
+def test_narrow_fetch_equals_wide_fetch(engine):
+    """bsk_result_fetch_narrow (u32 offsets scanned on the device, u16 positions) against bsk_result_fetch: whole results and ranges,
+    slab (k_minimizer_pk), unit-row (k_minimizer_ring) and per-read-slab layouts, a stream kind; a read too long for 15-bit positions."""
+    import random
+    from bio_amd import _lib as L
+    from bio_amd import sketches as S
+    rng = random.Random(4)
+    for rl, k, w in ((150, 21, 11), (250, 21, 11), (150, 15, 3)):
+        b = engine.synth(L.ALPHA_DNA, 20_000, rl, 0x5EED0003)
+        res = engine.run(b, engine.params(L.MINIMIZER, k, w=w))
+        for first, count in ((0, None), (5_000, 7_777), (19_999, 1), (3, 0)):
+            o, st, h, p = res.fetch(first, count)
+            o2, st2, h2, p2 = res.fetch_narrow(first, count)
+            assert np.array_equal(o, o2.astype(np.uint64)) and np.array_equal(st, st2) and np.array_equal(h, h2)
+            assert np.array_equal(p & L.POS_MASK, (p2 & 0x7FFF).astype(np.uint32)) and np.array_equal(p >> 31, (p2 >> 15).astype(np.uint32))
+        res.close()
+        b.close()
+    b = engine.synth(L.ALPHA_DNA, 3_000, 150, 0x5EED0003)
+    res = engine.run(b, engine.params(L.NTHASH, 21))
+    o, st, h, p = res.fetch()
+    o2, st2, h2, p2 = res.fetch_narrow()
+    assert p is None and p2 is None and np.array_equal(o, o2.astype(np.uint64)) and np.array_equal(h, h2)
+    res.close()
+    b.close()
+    long_read = "".join(rng.choice("ACGT") for _ in range(40_000))
+    b = engine.batch([long_read, long_read[:100]])
+    res = engine.run(b, engine.params(L.MINIMIZER, 21, w=11))
+    with pytest.raises(S.DeviceError):
+        res.fetch_narrow()
+    res.close()
+    b.close()
