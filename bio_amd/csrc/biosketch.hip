@@ -1259,6 +1259,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.slab = true;
             pl.slab_unit = (u64)64 * BSK_SYN_CAP;
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
+            pl.bin_gran = bin_gran_for(ctx, b, p->k - p->s);
             per_cu = pk_syncmer_blocks_per_cu(pl.fast_w);
         } else if (!use_ascii && fast_syncmer_supported(p->k, p->s) && b->maxlen < 32768u && !ctx->opt.force_generic) {
             pl.which = K_SYN_FAST;
@@ -1266,6 +1267,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.slab = true;
             pl.slab_unit = (u64)64 * BSK_SYN_CAP;
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
+            pl.bin_gran = bin_gran_for(ctx, b, p->k - p->s);
             per_cu = fast_syncmer_blocks_per_cu(pl.fast_w);
         } else {
             pl.which = use_ascii ? K_SYN_A : K_SYN_P;
@@ -1588,7 +1590,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     a.ring_w = pl.ring_w;
     a.len_mask = 0xffffffu;
     if (pl.bin_gran) {  // ragged short reads on a lock-step kernel: units of reads that end together (k_bin_desc)
-        const int brc = ensure_binned(ctx, b, (u32)(p->k - 1), pl.bin_gran);
+        const int brc = ensure_binned(ctx, b, (u32)((p->kind == BSK_SYNCMER ? p->s : p->k) - 1), pl.bin_gran);  // (the kernels step over k-mers / s-mers)
         if (brc != BSK_OK) return brc;
         a.desc = b->bdesc;
         a.rflags = b->rflags ? b->bflags : nullptr;
@@ -2170,7 +2172,7 @@ extern "C" int bsk_batch_prepare(bsk_ctx *ctx, const bsk_batch *batch, const bsk
     HIPCHK(ctx, hipEventCreate(&e1));
     batch->bin_gran = 0;  // build (again): the call is also the way to time the pass
     hipError_t e = hipEventRecord(e0, ctx->stream);
-    rc = ensure_binned(ctx, batch, (u32)(p->k - 1), pl.bin_gran);
+    rc = ensure_binned(ctx, batch, (u32)((p->kind == BSK_SYNCMER ? p->s : p->k) - 1), pl.bin_gran);
     if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     float t = 0.0f;

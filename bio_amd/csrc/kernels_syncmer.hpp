@@ -328,7 +328,8 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves p
         if (LIST) r = r < nlist ? (u64)rlist[r] : ~0ULL;
         // the next unit's descriptors are loaded one unit ahead (a load issued here waits for the copy-out stores to drain)
         const u64 d = (pre && !LIST) ? d_next : (r < a.n ? a.desc[r] : 0);
-        const u64 off = d >> 24, L = d & 0xffffffULL;
+        const u64 off = d >> 24, L = desc_len(a, d);
+        const u64 ro = out_index(a, r, d);  // (length-binned batches: the read's own place in its chunk)
         pre = !LIST && unit + 1 != uend && unit + 1 < a.nunits;
         if (pre) d_next = r + 64 < a.n ? a.desc[r + 64] : 0;
         const long long Lorig = (long long)L - a.circ_ext;
@@ -382,11 +383,11 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves p
             }
         }
         if (r < a.n) {
-            a.refs[r] = ((base + excl) << 24) | cnt;
+            a.refs[ro] = ((base + excl) << 24) | cnt;
             u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
             if (tie && ok) sbyte |= BSK_ST_FIRST_WINDOW_TIE;
             if (ok && a.rflags) sbyte |= a.rflags[r];
-            a.status[r] = sbyte;
+            a.status[ro] = sbyte;
         }
     }
 }

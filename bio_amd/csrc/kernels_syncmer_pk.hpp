@@ -391,7 +391,8 @@ __global__ __launch_bounds__(64, SYNPK_LB) void k_syncmer_pk(KArgs a) {  // thre
         synpk_dma_desc(a.desc + (r + 128 < rmax ? r + 128 : rmax), dbuf);
         // the read's input flags (batches packed from ASCII have them): a load after the copy-out would wait for its stores
         u32 rfl = pk_load_u8(a.rflags ? a.rflags + (r < rmax ? r : rmax) : reinterpret_cast<const u8 *>(a.desc));
-        const u64 L = d & 0xffffffULL;
+        const u64 L = desc_len(a, d);
+        const u64 ro = out_index(a, r, d);  // (length-binned batches: the read's own place in its chunk)
         const long long Lorig = (long long)L - a.circ_ext;
         const bool ok = r < a.n && Lorig >= 0 && Lorig >= 2LL * a.k - a.s - 1 && L >= (u64)a.k;  // sketch.go:149
         const u32 nwin = ok ? (u32)(L - 2 * (u64)a.k + a.s + 2) : 0u;                             // end + 1
@@ -444,10 +445,10 @@ __global__ __launch_bounds__(64, SYNPK_LB) void k_syncmer_pk(KArgs a) {  // thre
         if (T) pk_copyout<4, LY>(lds, lane, cnt, excl, T, base, a);
 #endif
         if (r < a.n && !((redo >> lane) & 1)) {
-            a.refs[r] = ((base + excl) << 24) | cnt;
+            a.refs[ro] = ((base + excl) << 24) | cnt;
             u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
             if (ok && a.rflags) sbyte |= (u8)rfl;
-            a.status[r] = sbyte;
+            a.status[ro] = sbyte;
         }
     }
 }

@@ -111,3 +111,25 @@ def test_binned_view_is_rebuilt_per_window_and_after_refill(engine, oracle):
         check_reads(res, oracle, seqs, k, w, range(0, len(seqs), 7))
         res.close()
     b.close()
+
+
+@pytest.mark.parametrize("k,s,lo,hi", [(31, 11, 40, 150), (21, 11, 30, 224), (15, 9, 20, 400)])
+def test_binned_units_syncmers(engine, oracle, k, s, lo, hi):
+    """The syncmer kernels (k_syncmer_pk + its list pass, k_syncmer_fast for the longer reads) over length-binned units."""
+    rng = random.Random(k * 100 + s)
+    n = 9000 + rng.randint(0, 500)
+    seqs = [rand_dna(rng, rng.randint(lo, hi)) for _ in range(n)]
+    b = engine.batch(seqs)
+    res = engine.run(b, engine.params(L.SYNCMER, k, s=s))
+    assert "length-binned" in res.plan()["kernel"], res.plan()
+    for i in range(0, n, 3):
+        st, h, p = res.read(i)
+        try:
+            eh, ep, es, fl = oracle.syncmer(seqs[i], k, s, False, closed=True)
+        except oracle.OracleError as e:
+            assert e.name == "ErrShortSeq" and (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0, (i, len(seqs[i]))
+            continue
+        assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep) and np.array_equal(p >> 31, es), (i, len(seqs[i]), k, s)
+        assert (st & 0xF0) == fl, (i, st, fl)
+    res.close()
+    b.close()
