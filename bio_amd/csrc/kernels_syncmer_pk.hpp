@@ -15,7 +15,7 @@
 //   * exactness as in kernels_pk.hpp: the packed minimum is the 64-bit leftmost minimum unless two s-mers with equal 27-bit keys met
 //     in a min operation (now four per step); such a unit, or one with a full staging column, goes to a list and k_syncmer_fast's
 //     exact machine runs it afterwards (k_syncmer_fix), which also evaluates BSK_ST_FIRST_WINDOW_TIE.
-// Reads of up to 16 (PKNW - 3) bases; words, descriptors and waits as in k_minimizer_pk.
+// Reads of up to 16 (PKNW - 2) = 224 bases (pk_syncmer_max_bases); words, descriptors and waits as in k_minimizer_pk.
 #pragma once
 #include "kernels_pk.hpp"
 #include "kernels_syncmer.hpp"

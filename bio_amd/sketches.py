@@ -254,11 +254,21 @@ class Engine:
 
     def _opts(self):
         """The library reads its developer switches (BSK_*) once per context; the test suite flips them inside one process, so this
-        mirror reloads them (bsk_ctx_reload_options) when the environment changed since the last call."""
+        mirror reloads them (bsk_ctx_reload_options) when the environment changed since the last call.  Only when BSK_PY_WATCH_ENV
+        is set (tests/conftest.py sets it): a production caller pays no scan of its environment per call and uses reload_options()."""
+        if not Engine._watch_env:
+            return
         now = self._opts_env()
         if now != self._opts_seen:
             self._opts_seen = now
             self.lib.bsk_ctx_reload_options(self.ctx)
+
+    _watch_env = bool(os.environ.get("BSK_PY_WATCH_ENV"))
+
+    def reload_options(self):
+        """Re-read the BSK_* developer switches from the environment now (bsk_ctx_reload_options)."""
+        self._opts_seen = self._opts_env()
+        self.lib.bsk_ctx_reload_options(self.ctx)
 
     def _chk(self, rc: int):
         if rc == L.OK:

@@ -120,8 +120,29 @@ def check_reserved(ws=("11",), unit="k_minimizer_ring", macro="BSK_RING_WS", fir
     return bad
 
 
+PK_WS = tuple(str(w) for w in range(2, 14))       # BSK_PK_WS, BSK_RING_WS
+SYNPK_WS = tuple(str(w) for w in range(4, 21))    # BSK_SYNPK_WS
+
+
+def run_all(pk_ws, syn_ws, ring_ws, jobs=None):
+    """Every (kernel family, width) is one hipcc -S run: in parallel."""
+    from concurrent.futures import ThreadPoolExecutor
+    tasks = [lambda w=w: check_hidden_loads((w,)) for w in pk_ws]
+    tasks += [lambda w=w: check_hidden_loads((w,), "k_syncmer_pk", "BSK_SYNPK_WS") for w in syn_ws]
+    tasks += [lambda w=w: check_hidden_loads((w,), "k_minimizer_ring", "BSK_RING_WS") + check_reserved((w,)) for w in ring_ws]
+    with ThreadPoolExecutor(max_workers=jobs or max(2, (os.cpu_count() or 4))) as ex:
+        res = list(ex.map(lambda f: f(), tasks))
+    return [e for r in res for e in r]
+
+
 if __name__ == "__main__":
-    errs = (check_scc() + check_hidden_loads(tuple(sys.argv[1:]) or ("11",)) + check_hidden_loads(("20",), "k_syncmer_pk", "BSK_SYNPK_WS") +
-            check_hidden_loads(("11",), "k_minimizer_ring", "BSK_RING_WS") + check_reserved(("11",)))
-    print("\n".join(errs) if errs else "asm checks: ok")
+    # usage: check_asm.py            -> w = 11 (pk, ring), k - s = 20 (syncmer)
+    #        check_asm.py 2 11 13    -> those pk widths (+ ring 11, syncmer 20)
+    #        check_asm.py all        -> every instantiation the library ships (pk / ring 2..13, syncmer 4..20)
+    args = sys.argv[1:]
+    if args == ["all"]:
+        errs = check_scc() + run_all(PK_WS, SYNPK_WS, PK_WS)
+    else:
+        errs = check_scc() + run_all(tuple(args) or ("11",), ("20",), ("11",))
+    print("\n".join(errs) if errs else "asm checks: ok (%s)" % (" ".join(args) or "default widths"))
     sys.exit(1 if errs else 0)

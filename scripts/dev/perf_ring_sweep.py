@@ -1,5 +1,6 @@
 """dev (GPU): k_minimizer_ring (BSK_RING=1) against the planner's other choice over window sizes and read lengths."""
 import sys, os
+os.environ.setdefault("BSK_PY_WATCH_ENV", "1")  # this script flips BSK_* switches between runs
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bio_amd import sketches as S, _lib as L
 eng = S.Engine(0)

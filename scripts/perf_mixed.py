@@ -1,5 +1,6 @@
 """dev helper: a batch where 1 % of the reads carry an N -- mixed plan vs whole-batch ASCII kernels."""
 import os, sys, time
+os.environ.setdefault("BSK_PY_WATCH_ENV", "1")  # this script flips BSK_* switches between runs
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bio_amd import sketches as S, _lib as L

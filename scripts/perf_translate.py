@@ -1,5 +1,6 @@
 """dev helper: time bsk_batch_translate (wall clock incl. allocation + sync) and the DNA-fed protein sketch."""
 import sys, time, os
+os.environ.setdefault("BSK_PY_WATCH_ENV", "1")  # this script flips BSK_* switches between runs
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bio_amd import sketches as S, _lib as L
 

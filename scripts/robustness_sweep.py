@@ -5,6 +5,7 @@
   inputs and outputs resident in HBM, min / median of 5 launches (HIP events around the kernels, bsk_sketch_timed).
 usage: python scripts/robustness_sweep.py [bases] > profiles/r04/robustness.jsonl"""
 import json, os, sys
+os.environ.setdefault("BSK_PY_WATCH_ENV", "1")  # this script flips BSK_* switches between runs
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from bio_amd import sketches as S, _lib as L

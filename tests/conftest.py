@@ -4,6 +4,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("BSK_PY_WATCH_ENV", "1")  # the tests flip BSK_* switches inside one process: bio_amd.sketches.Engine re-reads them when they change
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

@@ -58,6 +58,25 @@ def test_syncmer_matches_state_machine_too(engine, oracle, k, s, n, lens):
         assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep), (i, k, s, len(q))
 
 
+def test_syncmer_packed_kernel_at_its_length_limit(engine, oracle):
+    """k_syncmer_pk takes reads of up to 224 bases (its words live in 16 registers, the last two are look-ahead): lengths 208..224
+    without jitter, so that the batch really is planned on that kernel and the clamped word index of its last blocks is exercised."""
+    rng = random.Random(2240)
+    seqs = [rand_seq(rng, rng.randint(208, 224)) for _ in range(2500)]
+    b = engine.batch(seqs)
+    # (the kernel's short staging columns admit such long reads only when they select few positions: large k)
+    for k, s in ((100, 80), (104, 85), (110, 92)):
+        res = engine.run(b, engine.params(L.SYNCMER, k, s=s))
+        assert "k_syncmer_pk" in res.plan()["kernel"], res.plan()
+        for i, q in enumerate(seqs):
+            st, h, p = res.read(i)
+            eh, ep, es, fl = oracle.syncmer(q, k, s, False, closed=True)
+            assert (st & L.ST_CODE_MASK) == L.ST_OK and np.array_equal(h, eh), (i, k, s, len(q))
+            assert np.array_equal(p & L.POS_MASK, ep) and np.array_equal(p >> 31, es) and (st & 0xF0) == fl, (i, k, s, len(q))
+        res.close()
+    b.close()
+
+
 def test_syncmer_invalid_s(engine):
     from bio_amd import sketches as S
     seq, _ = S.NewSeq(S.DNA, "ACGT" * 20)
