@@ -69,6 +69,8 @@ def env_switches(rng):
         env["BSK_NO_MIXED"] = "1"
     elif r < 0.5:
         env["BSK_NO_TILES"] = "1"
+    if rng.random() < 0.5:
+        env["BSK_BIN_MIN"] = "1"  # length-binned units on these small batches too (round 4)
     return env
 
 
@@ -76,7 +78,7 @@ def run_case(engine, oracle, seed):
     rng = random.Random(seed)
     kind = rng.choice([L.MINIMIZER, L.MINIMIZER, L.SYNCMER, L.NTHASH, L.KMER, L.SIMHASH, L.PROT_HASH, L.PROT_MINIMIZER])
     env = env_switches(rng)
-    old = {k: os.environ.get(k) for k in ("BSK_TILE_MIN", "BSK_TILE_POS", "BSK_FORCE_GENERIC", "BSK_NO_MIXED", "BSK_NO_TILES")}
+    old = {k: os.environ.get(k) for k in ("BSK_TILE_MIN", "BSK_TILE_POS", "BSK_FORCE_GENERIC", "BSK_NO_MIXED", "BSK_NO_TILES", "BSK_BIN_MIN")}
     for k in old:
         os.environ.pop(k, None)
     os.environ.update(env)
