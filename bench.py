@@ -44,9 +44,13 @@ WORKLOADS = {
     "kmer": ("kmer", 10_000_000, 150, 21, 0, "10M x 150 bp reads, canonical 2-bit k-mer codes k=21"),
     "prothash": ("phash", 20_000_000, 300, 9, 0, "20M x 300 aa, protein k-mer hashes k=9"),
     "simhash": ("sim", 20_000_000, 150, 21, 5, "20M x 150 bp reads, SimHash k=21 m=5 scale=5"),
+    # off the headline point (the same 1.5e10 bases): the unit-row kernel's length range (scripts/robustness_sweep.py has the rest)
+    "minimizer250": ("min", 60_000_000, 250, 21, 11, "60M x 250 bp reads, minimizer sketch k=21 w=11 (the configs[2] parameters on longer reads)"),
 }
 NOTES = {
-    "min": "bound by the in-order instruction issue of two waves per SIMD (eight waves per CU: LDS staging), not by HBM; the VALU pipe is ~0.6 full (DESIGN.md 3.1)",
+    "min": "bound by the in-order instruction issue of two waves per SIMD (eight waves per CU: LDS staging) with the board's power cap as a second ceiling 5-8 % "
+           "above it -- the three-wave kernel (k_minimizer_ring) needs 8 % fewer cycles and is clocked 9 % lower; `power` holds this run's board watts and clock "
+           "(every kernel of the library draws 1.26-1.38 kW of the 1.4 kW cap; DESIGN.md 3.1) -- not by HBM; the VALU pipe is ~0.6 full",
     "nt": "HBM-write bound (DESIGN.md 3.2); a plain 16 B/lane fill kernel reaches 5.2-5.9 TB/s on this part",
     "syn": "integer-VALU bound (two rolling hashes + a 2(k-s) window per base; DESIGN.md 3.3)",
     "pmin": "integer-VALU bound (wyhash from scratch per residue: 8 v_mad_u64_u32; DESIGN.md 3.4)",

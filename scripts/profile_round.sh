@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out/$ROUND
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for w in $WORKLOADS; do
-  CMD="python $REPO/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end"
+  CMD="python $REPO/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-end-to-end --no-power-probe"
   rm -rf /tmp/prof_$w
   # the timing pass runs more launches: the first ones after a start are cold and the judge compares the AVERAGE with bench.py's live figure
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$w/stats -- ${CMD/--steps 3 --warmup 1/--steps 16 --warmup 4} > /tmp/prof_$w.log 2>&1
