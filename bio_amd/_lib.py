@@ -82,6 +82,7 @@ SYMBOLS = [
     ("bsk_sketch_timed", C.c_int, [_vp, _vp, C.POINTER(Params), _pp, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     ("bsk_batch_prepare", C.c_int, [_vp, _vp, C.POINTER(Params), C.POINTER(C.c_float)]),
     ("bsk_batch_refill_ascii", C.c_int, [_vp, _pp, _vp, _vp, C.c_uint64, C.c_int]),
+    ("bsk_batch_refill_packed", C.c_int, [_vp, _pp, _vp, C.c_uint64, _vp, C.c_uint64]),
     ("bsk_pipeline_fastx", C.c_int, [C.c_int, C.c_char_p, C.c_int, _vp, C.c_int, C.c_uint64, C.c_int, _vp]),
     ("bsk_pipeline_memory", C.c_int, [C.c_int, _vp, _vp, C.c_uint64, C.c_int, _vp, C.c_int, C.c_uint64, C.c_int, C.c_int, _vp]),
     ("bsk_pipeline_fastx_files", C.c_int, [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_uint64, C.c_int, _vp]),

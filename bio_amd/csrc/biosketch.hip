@@ -617,8 +617,13 @@ extern "C" int bsk_batch_refill_ascii(bsk_ctx *ctx, bsk_batch **batch, const uin
     return batch_from_ascii_impl(ctx, bytes, offsets, n, alphabet, old, batch);
 }
 
-extern "C" int bsk_batch_from_packed(bsk_ctx *ctx, const uint32_t *words, uint64_t n_words, const uint64_t *desc, uint64_t n,
-                                     bsk_batch **out) {
+// donor: a batch whose device buffers may be taken over (bsk_batch_refill_packed); it is consumed
+static int batch_from_packed_impl(bsk_ctx *ctx, const uint32_t *words, uint64_t n_words, const uint64_t *desc, uint64_t n, bsk_batch *donor,
+                                  bsk_batch **out) {
+    struct DonorGuard {
+        bsk_batch *d;
+        ~DonorGuard() { if (d) bsk_batch_destroy(d); }
+    } donor_guard{donor};
     if (!ctx || !out || (n && !desc) || (n_words && !words)) return fail_arg(ctx, "bsk_batch_from_packed: null argument");
     *out = nullptr;
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -642,10 +647,43 @@ extern "C" int bsk_batch_from_packed(bsk_ctx *ctx, const uint32_t *words, uint64
     b->maxlen = maxlen;
     b->uniform_len = (n && uniform) ? maxlen : 0;
     const u64 alloc_words = n_words + pad_words(maxlen);
+    // device buffer of at least `need` bytes: the donor's if it is large enough (a streaming caller refills one batch object per
+    // stream: hipFree / hipMalloc per chunk would synchronise the device), else a fresh one with 1/8 of slack
+    auto take = [&](void **dst, size_t *cap_dst, size_t need, void **src, size_t *cap_src) -> hipError_t {
+        if (donor && *src && *cap_src >= need) {
+            *dst = *src;
+            *cap_dst = *cap_src;
+            *src = nullptr;
+            *cap_src = 0;
+            return hipSuccess;
+        }
+        const size_t want = donor ? need + need / 8 + 256 : need;
+        const hipError_t e2 = hipMalloc(dst, want ? want : 1);
+        if (e2 == hipSuccess) *cap_dst = want;
+        return e2;
+    };
+    if (donor) {
+        std::swap(b->bdesc, donor->bdesc);
+        std::swap(b->c_bdesc, donor->c_bdesc);
+        std::swap(b->bflags, donor->bflags);
+        std::swap(b->c_bflags, donor->c_bflags);
+        // (an ASCII-refilled donor parks its ASCII buffers: they stay with the batch object for a later ASCII refill)
+        std::swap(b->spare_ascii, donor->spare_ascii);
+        std::swap(b->spare_aoff, donor->spare_aoff);
+        if (donor->ascii && !b->spare_ascii) {
+            b->spare_ascii = donor->ascii;
+            b->spare_aoff = donor->aoff;
+            donor->ascii = nullptr;
+            donor->aoff = nullptr;
+        }
+        b->c_ascii = donor->c_ascii;
+        b->c_aoff = donor->c_aoff;
+    }
     hipError_t e;
-    if ((e = hipMalloc(&b->words, alloc_words * 4)) != hipSuccess || (e = hipMalloc(&b->desc, (n ? n : 1) * 8)) != hipSuccess ||
-        (e = hipMalloc(&b->rflags, n ? n : 1)) != hipSuccess ||
-        (e = hipMemsetAsync(b->words, 0, alloc_words * 4, ctx->stream)) != hipSuccess ||
+    if ((e = take((void **)&b->words, &b->c_words, alloc_words * 4, donor ? (void **)&donor->words : nullptr, donor ? &donor->c_words : nullptr)) != hipSuccess ||
+        (e = take((void **)&b->desc, &b->c_desc, (n ? n : 1) * 8, donor ? (void **)&donor->desc : nullptr, donor ? &donor->c_desc : nullptr)) != hipSuccess ||
+        (e = take((void **)&b->rflags, &b->c_rflags, n ? n : 1, donor ? (void **)&donor->rflags : nullptr, donor ? &donor->c_rflags : nullptr)) != hipSuccess ||
+        (e = hipMemsetAsync(b->words + n_words, 0, (alloc_words - n_words) * 4, ctx->stream)) != hipSuccess ||
         (e = hipMemsetAsync(b->rflags, 0, n ? n : 1, ctx->stream)) != hipSuccess ||
         (n_words && (e = hipMemcpyAsync(b->words, words, n_words * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) ||
         (n && (e = hipMemcpyAsync(b->desc, desc, n * 8, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) ||
@@ -656,6 +694,19 @@ extern "C" int bsk_batch_from_packed(bsk_ctx *ctx, const uint32_t *words, uint64
     b->device_bytes = alloc_words * 4 + n * 9;
     *out = b;
     return BSK_OK;
+}
+
+extern "C" int bsk_batch_from_packed(bsk_ctx *ctx, const uint32_t *words, uint64_t n_words, const uint64_t *desc, uint64_t n,
+                                     bsk_batch **out) {
+    return batch_from_packed_impl(ctx, words, n_words, desc, n, nullptr, out);
+}
+
+extern "C" int bsk_batch_refill_packed(bsk_ctx *ctx, bsk_batch **batch, const uint32_t *words, uint64_t n_words, const uint64_t *desc, uint64_t n) {
+    if (!ctx || !batch) return fail_arg(ctx, "bsk_batch_refill_packed: null argument");
+    bsk_batch *old = *batch;
+    if (old && (old->ctx != ctx || old->alias)) return fail_arg(ctx, "bsk_batch_refill_packed: the batch belongs to another context");
+    *batch = nullptr;  // consumed whatever happens
+    return batch_from_packed_impl(ctx, words, n_words, desc, n, old, batch);
 }
 
 extern "C" int bsk_batch_synth(bsk_ctx *ctx, int alphabet, uint64_t n, uint32_t len, uint64_t seed, bsk_batch **out) {

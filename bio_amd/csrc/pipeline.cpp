@@ -112,6 +112,87 @@ struct PinBuf {  // grow-only pinned host buffer
     ~PinBuf() { release(); }
 };
 
+// ---- 2-bit packing on the host (memory source): a chunk of pure ACGT reads crosses the link as 38 + 8 bytes per 150-base read instead
+// of 150 + 8, and the device-side pack kernel is not needed.  A = 0, C = 1, G = 2, T = 3 (upper or lower case), 16 bases per u32, base i
+// of a word at bits [2i, 2i + 2), every read on a word boundary: the layout of k_pack (biosketch.hip).  Any other byte: the chunk goes the
+// ASCII way (the device keeps the ASCII of such reads for the side launch).
+static inline int code_of(uint8_t c) {
+    switch (c & 0xDF) {
+        case 'A': return 0;
+        case 'C': return 1;
+        case 'G': return 2;
+        case 'T': return 3;
+        default: return -1;
+    }
+}
+static bool pack_read_scalar(const uint8_t *src, uint64_t len, uint32_t *dst) {
+    const uint64_t nw = (len + 15) / 16;
+    for (uint64_t w = 0; w < nw; ++w) {
+        uint32_t v = 0;
+        const uint64_t i0 = w * 16, m = std::min<uint64_t>(16, len - i0);
+        for (uint64_t j = 0; j < m; ++j) {
+            const int c = code_of(src[i0 + j]);
+            if (c < 0) return false;
+            v |= (uint32_t)c << (2 * j);
+        }
+        dst[w] = v;
+    }
+    return true;
+}
+#if defined(__x86_64__)
+#include <immintrin.h>
+// 32 bases per step; `safe` = bytes that may be read from src (the caller guarantees len <= safe; the vector loop reads whole 32-byte
+// blocks only while they lie inside it).  Writes ceil(len / 16) words, possibly one more zero word behind them (the next read's first).
+__attribute__((target("avx2"))) static bool pack_read_avx2(const uint8_t *src, uint64_t len, uint64_t safe, uint32_t *dst) {
+    const __m256i up = _mm256_set1_epi8((char)0xDF), three = _mm256_set1_epi8(3);
+    const __m256i cA = _mm256_set1_epi8('A'), cC = _mm256_set1_epi8('C'), cG = _mm256_set1_epi8('G'), cT = _mm256_set1_epi8('T');
+    const __m256i idx = _mm256_setr_epi8(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31);
+    const __m256i m1 = _mm256_set1_epi16(0x0401), m2 = _mm256_set1_epi32(0x00100001);
+    const __m256i pick = _mm256_setr_epi8(0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 0, 4, 8, 12, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1);
+    uint64_t i = 0;
+    for (; i < len && i + 32 <= safe; i += 32) {
+        const __m256i v = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(src + i));
+        const __m256i u = _mm256_and_si256(v, up);
+        const __m256i ok = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(u, cA), _mm256_cmpeq_epi8(u, cC)), _mm256_or_si256(_mm256_cmpeq_epi8(u, cG), _mm256_cmpeq_epi8(u, cT)));
+        const uint64_t rem = len - i;
+        __m256i inside = _mm256_set1_epi8((char)0xFF);
+        if (rem < 32) inside = _mm256_cmpgt_epi8(_mm256_set1_epi8((char)rem), idx);  // lanes < rem
+        if ((uint32_t)_mm256_movemask_epi8(_mm256_or_si256(ok, _mm256_andnot_si256(inside, _mm256_set1_epi8((char)0xFF)))) != 0xFFFFFFFFu) return false;
+        __m256i c = _mm256_and_si256(_mm256_xor_si256(_mm256_srli_epi16(v, 1), _mm256_srli_epi16(v, 2)), three);
+        c = _mm256_and_si256(c, inside);
+        const __m256i q = _mm256_madd_epi16(_mm256_maddubs_epi16(c, m1), m2);  // every 32-bit lane: one packed byte (four bases)
+        const __m256i g = _mm256_shuffle_epi8(q, pick);
+        dst[i / 16] = (uint32_t)_mm256_extract_epi32(g, 0);
+        if (rem > 16) dst[i / 16 + 1] = (uint32_t)_mm256_extract_epi32(g, 4);
+    }
+    if (i < len) return pack_read_scalar(src + i, len - i, dst + i / 16);  // (the last bytes of the source: no room for a whole block)
+    return true;
+}
+static bool have_avx2() {
+    static const bool v = __builtin_cpu_supports("avx2");
+    return v;
+}
+#endif
+// reads [a, a + m) of (bytes, offsets) -> words / descriptors; false: a byte outside ACGTacgt (nothing usable was written)
+static bool pack_chunk(const uint8_t *bytes, const uint64_t *offsets, uint64_t a, uint64_t m, uint64_t total_bytes, uint32_t *words, uint64_t *desc, uint64_t *n_words) {
+    uint64_t w = 0;
+    for (uint64_t r = 0; r < m; ++r) {
+        const uint64_t b0 = offsets[a + r], len = offsets[a + r + 1] - b0;
+        if (len >= (1ull << 24)) return false;
+        bool ok;
+#if defined(__x86_64__)
+        if (have_avx2()) ok = pack_read_avx2(bytes + b0, len, total_bytes - b0, words + w);
+        else
+#endif
+            ok = pack_read_scalar(bytes + b0, len, words + w);
+        if (!ok) return false;
+        desc[r] = (w << 24) | len;
+        w += (len + 15) / 16;
+    }
+    *n_words = w;
+    return true;
+}
+
 struct Chunk {
     PinBuf bytes, offs;
     uint64_t n = 0, nbytes = 0;
@@ -119,6 +200,8 @@ struct Chunk {
     std::vector<bsk_fastx_piece *> parts;  // block-parallel file source: the parsed pieces of the chunk (copied by the worker)
     struct Slot *slot = nullptr;           // where the chunk came from (several files can be in flight)
     int alphabet = BSK_ALPHA_DNA;
+    bool packed = false;   // bytes holds 2-bit packed words (16 bases per u32, every read on a word boundary), offs the descriptors
+    uint64_t n_words = 0;
 };
 
 struct Queue {  // chunks handed from the producer to the workers, and back
@@ -277,6 +360,16 @@ struct MemorySource : Source {
     }
     int materialize(Chunk *c) override {
         const uint64_t a = c->src_at, m = c->n, b0 = offsets[a], nb = c->nbytes;
+        c->packed = false;
+        static const bool no_pack = getenv("BSK_PIPE_NO_HOST_PACK") != nullptr;  // dev: every chunk the ASCII way
+        if (c->alphabet == BSK_ALPHA_DNA && !no_pack && m) {  // DNA: 2-bit words straight into the pinned buffer (a quarter of the bytes); other alphabets keep their own pairing rules with the batch
+            const uint64_t max_words = nb / 16 + m + 2;
+            if (!c->bytes.ensure(max_words * 4 + 64) || !c->offs.ensure((m + 1) * 8)) return BSK_ERR_NOMEM;
+            if (pack_chunk(bytes, offsets, a, m, offsets[n], (uint32_t *)c->bytes.p, (uint64_t *)c->offs.p, &c->n_words)) {
+                c->packed = true;
+                return BSK_OK;
+            }
+        }
         if (!c->bytes.ensure(nb + 1) || !c->offs.ensure((m + 1) * 8)) return BSK_ERR_NOMEM;
         memcpy(c->bytes.p, bytes + b0, nb);
         uint64_t *o = (uint64_t *)c->offs.p;
@@ -408,7 +501,8 @@ int run_pipeline(const int *devices, int n_dev, SourceSet &set, int n_producers,
                     // ways (scripts/ubench/pcie.py).  The kernels and the host-side work of other chunks still overlap the copies.
                     std::unique_lock<std::mutex> lk(g_h2d_mutex[device & 15], std::defer_lock);
                     if (g_copy_locks) lk.lock();
-                    rc = bsk_batch_refill_ascii(ctx, &batch, (const uint8_t *)c->bytes.p, (const uint64_t *)c->offs.p, c->n, c->alphabet);
+                    if (c->packed) rc = bsk_batch_refill_packed(ctx, &batch, (const uint32_t *)c->bytes.p, c->n_words, (const uint64_t *)c->offs.p, c->n);
+                    else rc = bsk_batch_refill_ascii(ctx, &batch, (const uint8_t *)c->bytes.p, (const uint64_t *)c->offs.p, c->n, c->alphabet);
                 }
                 c->slot = nullptr;
                 if (--sl->inflight == 0 && sl->finished.load()) close_once(sl);

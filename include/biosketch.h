@@ -321,6 +321,9 @@ void bsk_result_release(bsk_result *r);
  * first read to the last tuple; the per-stage seconds are summed over the workers (they overlap, so they add up to more
  * than `seconds`); checksum is the digest of bsk_result_digest summed over the chunks (positions are per sequence). */
 int bsk_batch_refill_ascii(bsk_ctx *ctx, bsk_batch **batch, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet);
+/* bsk_batch_refill_packed: the same for bsk_batch_from_packed (2-bit words + descriptors prepared on the host: a quarter of the bytes
+ * over the link, no pack kernel).  bsk_pipeline_memory packs chunks of pure ACGT reads this way on its worker threads. */
+int bsk_batch_refill_packed(bsk_ctx *ctx, bsk_batch **batch, const uint32_t *words, uint64_t n_words, const uint64_t *desc, uint64_t n);
 typedef struct bsk_pipeline_stats {
     uint64_t records, bases, tuples, chunks, checksum;
     double seconds;              /* wall */

@@ -224,3 +224,56 @@ def test_narrow_fetch_equals_wide_fetch(engine):
         res.fetch_narrow()
     res.close()
     b.close()
+
+
+def test_host_packed_chunks_equal_ascii_chunks(engine, monkeypatch):
+    """bsk_pipeline_memory packs chunks of pure ACGT reads to 2-bit words on its worker threads (bsk_batch_refill_packed) and sends the
+    others as ASCII: mixed case, chunks with and without an N, reads whose length is not a multiple of 16 or 32, the last read of the
+    source (no room for a whole vector block), zero-length reads -- all against one batch, and against BSK_PIPE_NO_HOST_PACK."""
+    rng = np.random.default_rng(21)
+    n = 50_000
+    lens = rng.integers(0, 200, n).astype(np.uint64)
+    lens[::5] = 150
+    lens[-1] = 37
+    offs = np.zeros(n + 1, np.uint64)
+    offs[1:] = np.cumsum(lens)
+    data = np.frombuffer(b"ACGTacgt", np.uint8)[rng.integers(0, 8, int(offs[-1]))].copy()
+    for with_n in (False, True):
+        d = data.copy()
+        if with_n:
+            d[int(offs[12_345]) + 3] = ord("N")      # one chunk of several goes the ASCII way
+            d[int(offs[40_000]) + 1] = ord("-")
+        p = engine.params(L.MINIMIZER, 21, w=11)
+        want = engine.run(engine.batch_from_arrays(d, offs), p).digest()
+        for fetch in (True, False):
+            st = S.Engine.pipeline_memory(d, offs, p, n_streams=3, chunk_records=6000, fetch=fetch)
+            assert (st["records"], st["tuples"], st["checksum"]) == (n, want["n_tuples"], want["checksum"]), (with_n, fetch)
+        monkeypatch.setenv("BSK_PIPE_NO_HOST_PACK", "1")
+        st2 = S.Engine.pipeline_memory(d, offs, p, n_streams=2, chunk_records=6000, fetch=True)
+        monkeypatch.delenv("BSK_PIPE_NO_HOST_PACK")
+        assert (st2["tuples"], st2["checksum"]) == (want["n_tuples"], want["checksum"])
+    # refill through ONE batch object, packed and ASCII chunks in turn
+    lib, h = engine.lib, C.c_void_p()
+    p = engine.params(L.MINIMIZER, 15, w=7)
+    for i, packed in enumerate([True, False, True, True, False]):
+        m = [3000, 500, 7000, 10, 4000][i]
+        dd, oo = data[: int(offs[m])], offs[: m + 1]
+        if packed:
+            words, desc = [], np.zeros(m, np.uint64)
+            w = 0
+            for r in range(m):
+                s = dd[int(oo[r]):int(oo[r + 1])]
+                codes = (((s >> 1) ^ (s >> 2)) & 3).astype(np.uint64)
+                nw = (len(s) + 15) // 16
+                pad = np.zeros(nw * 16, np.uint64)
+                pad[: len(s)] = codes
+                words.append((pad.reshape(nw, 16) << (2 * np.arange(16, dtype=np.uint64))).sum(axis=1).astype(np.uint32))
+                desc[r] = (w << 24) | len(s)
+                w += nw
+            words = np.concatenate(words) if words else np.zeros(1, np.uint32)
+            engine._chk(lib.bsk_batch_refill_packed(engine.ctx, C.byref(h), words.ctypes.data, w, desc.ctypes.data, m))
+        else:
+            engine._chk(lib.bsk_batch_refill_ascii(engine.ctx, C.byref(h), dd.ctypes.data, oo.ctypes.data, m, L.ALPHA_DNA))
+        got = S.BatchResult(engine, *_run(engine, h, p)).digest()
+        assert got == engine.run(engine.batch_from_arrays(dd, oo), p).digest(), (i, packed)
+    lib.bsk_batch_destroy(h)
