@@ -139,22 +139,25 @@ def end_to_end(kind: str, p, batch, read_len: int, n_streams: int = 5):
     n_mem = min(n_have, int(16_000_000 * scale))
     data, offs = batch.fetch_ascii(0, n_mem)
     alpha = 1 if kind in PROTEIN else 0
-    out = {"n_streams": n_streams, "chunk_records": 1 << 18,
-           "what": "host ASCII -> pinned chunks -> H2D + 2-bit pack -> kernel -> every tuple back in pinned host memory; stages of different chunks overlap"}
+    n_mem_streams = int(os.environ.get("BSK_BENCH_MEM_STREAMS", str(max(n_streams, 8))))  # (the memory path has no parser threads to share the 16 CPUs with)
+    out = {"n_streams": n_streams, "n_streams_from_memory": n_mem_streams, "chunk_records": 1 << 18,
+           "what": "host ASCII -> 2-bit packed into pinned chunks on the worker threads (protein / reads with another byte: ASCII + pack kernel) -> H2D -> kernel -> "
+                   "every tuple back in pinned host memory (u32 offsets, u16 positions); stages of different chunks overlap"}
     S.Engine.pipeline_trim()
-    st0 = S.Engine.pipeline_memory(data, offs, p, n_streams=n_streams, chunk_records=1 << 18, repeat=2, fetch=True, alphabet=alpha)
+    st0 = S.Engine.pipeline_memory(data, offs, p, n_streams=n_mem_streams, chunk_records=1 << 18, repeat=2, fetch=True, alphabet=alpha)
     # the second call of the process: the pinned buffers come from the library's pool (a long-lived host pins once, not per file)
-    st = S.Engine.pipeline_memory(data, offs, p, n_streams=n_streams, chunk_records=1 << 18, repeat=2, fetch=True, alphabet=alpha)
+    st = S.Engine.pipeline_memory(data, offs, p, n_streams=n_mem_streams, chunk_records=1 << 18, repeat=2, fetch=True, alphabet=alpha)
     out["pinned_buffers"] = ("pooled by the library between pipeline calls; from_memory.first_call is the process's first run (it pins "
                              "%.2f s summed over its threads), every figure below ran with the pool warm" % st0["pin_seconds"])
     out["from_memory"] = {"first_call": {"value": round(st0["bases"] / st0["seconds"] / 1e9, 3), "seconds": round(st0["seconds"], 4), "pin_seconds": round(st0["pin_seconds"], 4)},
                           "value": round(st["bases"] / st["seconds"] / 1e9, 3), "unit": "Gresidues/s" if alpha else "Gbases/s",
                           "reads": st["records"], "seconds": round(st["seconds"], 4),
                           "stage_seconds_summed_over_streams": {k: round(st[k], 4) for k in ("reader_seconds", "reader_wait_seconds", "h2d_pack_seconds", "kernel_seconds", "fetch_seconds")},
-                          "bound": "on 3 streams the workers' host side (copy into pinned memory, the D2H wait, one pass over the fetched tuples); from 5 streams "
-                                   "on the copy pattern itself: %.0f B/read in + %.0f B/read of tuples out as 39 MB up / 46 + 23 MB down per stream moved "
-                                   "17 + 31 to 24 + 43 GB/s on this link in the micro-benchmark, against 48 + 48 with one large-copy stream per direction "
-                                   "(scripts/ubench/pcie.py; DESIGN.md 4)" % (read_len + 8, (12.0 if kind not in STREAM else 8.0) * st["tuples"] / max(st["records"], 1) + 9)}
+                          "bound": "the workers' host passes (2-bit pack into pinned memory, one pass over the fetched tuples) and the D2H copies: "
+                                   "%.0f B/read up (packed words + descriptor; ASCII chunks %.0f) + %.0f B/read of tuples down "
+                                   "(DESIGN.md 4; r03 moved 158 + 282 and reached 16.7 Gbases/s)" % (
+                                       (read_len + 3) // 4 + 8 if not alpha else read_len + 8, read_len + 8,
+                                       ((10.0 if kind not in STREAM else 8.0) * st["tuples"] / max(st["records"], 1) + 5))}
     # the same reads as files: fixed-width names, constant qualities
     rec = 12 + read_len + (3 + read_len if not alpha else 0)
     import shutil
