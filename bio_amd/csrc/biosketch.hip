@@ -418,7 +418,7 @@ void BskOpts::load() {
     no_bin = on("BSK_NO_BIN");
     compact = on("BSK_COMPACT");
     ring = on("BSK_RING");
-    ring_max = env_u32("BSK_RING_MAX", 42);
+    ring_max = env_u32("BSK_RING_MAX", 40);
     bin_min = env_u32("BSK_BIN_MIN", 1024);
     no_tiles = on("BSK_NO_TILES");
     no_tile_cache = on("BSK_NO_TILE_CACHE");
