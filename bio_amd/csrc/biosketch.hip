@@ -418,7 +418,7 @@ void BskOpts::load() {
     no_bin = on("BSK_NO_BIN");
     compact = on("BSK_COMPACT");
     ring = on("BSK_RING");
-    ring_max = env_u32("BSK_RING_MAX", 40);
+    ring_max = env_u32("BSK_RING_MAX", 0);
     bin_min = env_u32("BSK_BIN_MIN", 1024);
     no_tiles = on("BSK_NO_TILES");
     no_tile_cache = on("BSK_NO_TILE_CACHE");
@@ -1219,7 +1219,10 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         // unit rows through a ring (kernels_ring.hpp): reads that select more tuples than k_minimizer_pk stages (longer than ~156 bases at
         // w = 11) up to the length where the lanes of a unit drift too far apart for a ring of 16 rows (measured: DESIGN.md 3.2)
         const double exp_tuples = nwin * 2.0 / (p->w + 1.0);
-        const bool ring_wins = ctx->opt.ring ? true : exp_tuples > (double)ctx->opt.dense_min && exp_tuples <= (double)ctx->opt.ring_max;
+        // (measured, profiles/r04/ring_window_sweep.txt: w = 4..13 x 150..350 bases against k_minimizer_dense / k_minimizer_pk -- the wider the
+        // window, the longer the unit-row kernel stays ahead: 34 + 2 w expected tuples; BSK_RING_MAX overrides)
+        const double ring_cap = ctx->opt.ring_max ? (double)ctx->opt.ring_max : 34.0 + 2.0 * p->w;
+        const bool ring_wins = ctx->opt.ring ? true : exp_tuples > (double)ctx->opt.dense_min && exp_tuples <= ring_cap;
 #ifdef BSK_EXPERIMENTS  // the two measured-and-rejected minimizer kernels (make EXPERIMENTS=1; NOTEBOOK round 2): never planned without their switch
         if (!use_ascii && p->w == 11 && p->k + p->w <= 65 && b->maxlen < 32768u && nwin >= 1.0 && ctx->opt.wpr && !ctx->no_dense && slab_budget_ok(b, seg_slab) &&
             !ctx->opt.force_generic) {

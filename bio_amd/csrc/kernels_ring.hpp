@@ -64,14 +64,21 @@ struct RgLds {
     static constexpr int RING = 768;    // (a multiple of 256: the planes are reached with ds_*2st64 offsets)
     static constexpr int TOTAL = RING + R * ROWB;
     static constexpr int G = 4;         // rows leave in aligned groups of four
-#ifndef BSK_RING_PRESS
-#define BSK_RING_PRESS 12
+    // a lane this many rows ahead of the frontier makes the frontier's group leave under a lane mask.  Measured (round 4, 3e9 bases, one box):
+    //   PRESS        12     13     14     15     16          a masked group costs what a full one costs (a store instruction's
+    //   150 bases  1 062  1 071  1 055    959    920          price does not depend on its lane mask), so the later the better --
+    //   200 bases    879    943    936    933    897          until lanes run a whole ring (16 rows) ahead of what they have sent
+    //   250 bases    754    849    900    876    858          and go to the list of reads for the exact machine
+    //   300 bases    643    712    767    813    806
+#ifdef BSK_RING_PRESS
+    static constexpr int PRESS_SHORT = BSK_RING_PRESS, PRESS_LONG = BSK_RING_PRESS;
+#else
+    static constexpr int PRESS_SHORT = 13, PRESS_LONG = 14;  // (reads up to / beyond ring_minimizer_short_bases())
 #endif
-    static constexpr int PRESS = BSK_RING_PRESS;
 #ifndef BSK_RING_LAZY
 #define BSK_RING_LAZY 6
 #endif
-    static constexpr int LAZY = BSK_RING_LAZY;  // a lane behind the frontier catches up once it has this many tuples waiting    // a lane this many rows ahead of the frontier makes the frontier's group leave under a lane mask
+    static constexpr int LAZY = BSK_RING_LAZY;  // a lane behind the frontier catches up once it has this many tuples waiting
     static_assert(TOTAL <= 13312, "twelve waves per CU");
 };
 
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(64, BSK_RING_WAVES) RG_KERNEL_ATTR void k_minimizer
             for (;;) {
                 if (T + (u32)LY::G > rows) break;
                 const lmask behind = act & __builtin_amdgcn_ballot_w64(pm.c < T + (u32)LY::G);
-                if (behind && !__builtin_amdgcn_ballot_w64(pm.c >= T + (u32)LY::PRESS)) break;
+                if (behind && !__builtin_amdgcn_ballot_w64(pm.c >= T + (u32)(LONG ? LY::PRESS_LONG : LY::PRESS_SHORT))) break;
                 if (!behind && !lag && uniform) group(T, std::integral_constant<int, 0>{}, 0, 0);
                 else group(T, std::integral_constant<int, 1>{}, lagging ? 0 : (int)(pm.c - T), 0);
                 T += (u32)LY::G;

@@ -1,6 +1,6 @@
 """GPU: the minimizer path off its headline point -- one JSON line per case.
 
-  uniform read lengths 100 / 150 / 151 / 200 / 250 / 300, a ragged batch (lengths uniform in 60..150: trimmed reads) with and
+  uniform read lengths 100 / 150 / 151 / 200 / 250 / 300 / 350, a ragged batch (lengths uniform in 60..150: trimmed reads) with and
   without length-binned units, 2 % / 10 % of the reads ending in a 50-base poly-A tail.  k = 21, w = 11, ~3e9 bases per case,
   inputs and outputs resident in HBM, min / median of 5 launches (HIP events around the kernels, bsk_sketch_timed).
 usage: python scripts/robustness_sweep.py [bases] > profiles/r04/robustness.jsonl"""
@@ -44,7 +44,7 @@ def ragged(lo, hi, n):
 
 
 base = None
-for rl in (100, 150, 151, 200, 250, 300):
+for rl in (100, 150, 151, 200, 250, 300, 350):
     n = int(BASES / rl)
     b = eng.synth(L.ALPHA_DNA, n, rl, 0x5EED0003)
     o = run("uniform %d bp" % rl, b, n * rl)
