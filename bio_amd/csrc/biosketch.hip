@@ -1604,7 +1604,9 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
 
 // k_syncmer_pk's / k_minimizer_pk's list of reads for the exact machine: room for a quarter of the batch (a batch with more falls back
 // to k_syncmer_fast / k_minimizer_fast)
-static u64 syn_pk_fixcap(u64 n) { return std::max<u64>(65536, (n / 4 + 1) & ~(u64)1); }
+// (list_append, kernels_generic.hpp: one segment per workgroup of the launch -- at least 1 024 entries each, so that a small batch of
+// nothing but low-complexity reads still fits its segments)
+static u64 syn_pk_fixcap(u64 n, int grid) { return std::max<u64>((u64)grid * 1024, (n / 4 + (u64)grid) / (u64)grid * (u64)grid); }
 
 // One launch of the planned kernel into res.  ev0/ev1 (optional) bracket the kernel itself.
 static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_result *res, int circ_ext, const Plan &pl,
@@ -1651,17 +1653,20 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         a.len_mask = 0xfffu;
         a.binned = 1;
     }
-    int rc = ensure_scratch(ctx, std::max<u32>(pl.which == K_MIN_PK ? 2 * pl.nunits + (u32)(syn_pk_fixcap(b->n) / 2) : (pl.which == K_SYN_PK || pl.which == K_MIN_RING) ? (u32)(syn_pk_fixcap(b->n) / 2) : pl.slab ? 1 : pl.nunits, pl.mixed ? pl.side_nunits : 0), pl.ring_entries);
+    const bool lists = pl.which == K_SYN_PK || pl.which == K_MIN_PK || pl.which == K_MIN_RING;
+    const u64 fixcap = lists ? syn_pk_fixcap(b->n, pl.grid) : 0;  // u32 entries, behind one u32 count per workgroup
+    int rc = ensure_scratch(ctx, std::max<u32>(lists ? (u32)((fixcap + (u64)pl.grid) / 2 + 2) : pl.slab ? 1 : pl.nunits, pl.mixed ? pl.side_nunits : 0), pl.ring_entries);
     if (rc != BSK_OK) return rc;
     a.lookback = ctx->d_lookback;
     a.fixlist = ctx->d_lookback;
-    a.fixcap = (pl.which == K_SYN_PK || pl.which == K_MIN_PK || pl.which == K_MIN_RING) ? (u32)syn_pk_fixcap(b->n) : 0u;
-    a.rlist = reinterpret_cast<u32 *>(ctx->d_lookback + (pl.which == K_MIN_RING ? 0 : 2 * (size_t)pl.nunits));  // K_MIN_PK: behind its {unit, lane mask} entries
+    a.fixcap = (u32)fixcap;
+    a.list_grid = (u32)pl.grid;
+    a.rlist = reinterpret_cast<u32 *>(ctx->d_lookback);  // (the slab kernels use no look-back words: the list of reads lives there)
     a.unit_rows = (u32)(pl.slab_unit / 64);
     if (pl.which == K_MIN_PK || pl.which == K_MIN_RING) {  // slab of a listed read (k_minimizer_dense<W, true>): one tuple per window, whole 128-byte lines
         const u64 nwin_max = b->maxlen + 2 > (u32)(p->k + p->w) ? (u64)b->maxlen - p->k - p->w + 2 : 1;
         a.slab_read = (nwin_max + 15) & ~(u64)15;
-    }  // K_MIN_PK (a slab kernel: no look-back) keeps its list of unfinished units there
+    }
     a.ring_h = ctx->d_ring_h;
     a.ring_p = ctx->d_ring_p;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket, 0, 8 * sizeof(u32), ctx->stream));

@@ -790,21 +790,27 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
     LDSQ char *const ldsq = (LDSQ char *)lds;
     const int lane = lane_id();
-    const u32 nlist = LIST ? (a.ticket[6] < a.fixcap ? a.ticket[6] : a.fixcap) : 0u;
-    if (LIST && nlist == 0) return;
+    // LIST: this workgroup's segment of the list (list_append, kernels_generic.hpp)
+    const u32 lseg = LIST ? a.fixcap / a.list_grid : 0u;
+    if (LIST) {  // (nothing listed in any of this workgroup's segments: leave before the table is built)
+        u32 any = 0;
+        for (u32 sg = blockIdx.x; sg < a.list_grid; sg += gridDim.x) any |= a.rlist[sg];
+        if (!any) return;
+    }
     build_xtab(reinterpret_cast<uint4 *>(lds + LY::TAB), a.k, lane);
     __syncthreads();
     const u64 slab_read = a.slab_read;
-    for (u32 unit = LIST ? next_ticket(a.ticket + 7, lane) : next_ticket(a.ticket, lane) * 4u, uend = unit + 4u; LIST ? unit < (nlist + 63u) / 64u : unit < a.nunits; ++unit, ({
-             if (LIST) {
-                 unit = next_ticket(a.ticket + 7, lane);
-             } else if (unit == uend) {
+    for (u32 sg = LIST ? blockIdx.x : 0u; sg < (LIST ? a.list_grid : 1u); sg += LIST ? gridDim.x : 1u) {
+    const u32 nlist = LIST ? (a.rlist[sg] < lseg ? a.rlist[sg] : lseg) : 0u;
+    const u32 *const mylist = LIST ? a.rlist + a.list_grid + sg * lseg : nullptr;
+    for (u32 unit = LIST ? 0u : next_ticket(a.ticket, lane) * 4u, uend = unit + 4u; LIST ? unit < (nlist + 63u) / 64u : unit < a.nunits; ++unit, ({
+             if (!LIST && unit == uend) {
                  unit = next_ticket(a.ticket, lane) * 4u;
                  uend = unit + 4u;
              }
          })) {
         u64 r = (u64)unit * 64 + lane;
-        if (LIST) r = r < nlist ? (u64)a.rlist[r] : ~0ULL;
+        if (LIST) r = r < nlist ? (u64)mylist[r] : ~0ULL;
         u64 off = 0, L = 0, ro = r;
         if (r < a.n) {
             const u64 d = a.desc[r];
@@ -886,6 +892,7 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
             if (ok && a.rflags) sbyte |= a.rflags[r];
             a.status[ro] = sbyte;
         }
+    }
     }
 }
 

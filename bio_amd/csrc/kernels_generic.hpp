@@ -36,7 +36,7 @@ struct KArgs {
     u64 cap;  // capacity of hash[]/pos[] in tuples
     // synchronisation / scratch
     u32 *ticket;    // [0] unit ticket, [1] overflow flag, [2..3] the same for a side launch, [4] reads listed by k_syncmer_pk, [5] the list pass's ticket, [6] / [7] the same for k_minimizer_pk / k_minimizer_ring
-    u32 fixcap;     // entries (reads) of the read list: k_syncmer_pk's fixlist, k_minimizer_pk's rlist
+    u32 fixcap;     // entries (reads) of the read list over all segments (list_append): k_syncmer_pk's fixlist, k_minimizer_pk's rlist
     u32 *rlist;     // k_minimizer_pk / k_minimizer_ring: reads for the exact machine (k_minimizer_dense<W, true>), count in ticket[6], its ticket in ticket[7]
     u64 *fixlist;   // k_syncmer_pk: the same list as u32 read numbers (count in ticket[4], the list pass's ticket in ticket[5])
     u64 *lookback;  // [nunits]
@@ -64,9 +64,29 @@ struct KArgs {
     // by length class, so that the 64 reads of a unit end together; a binned descriptor carries the read's place in its chunk in bits
     // 12..23 (such batches hold reads of < 4096 bases), and the reference word / status byte of the read a lane holds belong at
     // out_index(), not at unit * 64 + lane
+    u32 list_grid;   // workgroups of the main launch = segments of the list of reads (list_append); the list pass may run with fewer
     u32 len_mask;    // 0xffffff, or 0xfff for binned descriptors
     u32 binned;
 };
+
+// The list of READS a packed kernel leaves to the exact machine (k_minimizer_pk / _ring -> k_minimizer_dense<W, true>; k_syncmer_pk ->
+// k_syncmer_fast<W, true>).  Every workgroup (= wavefront) of the main kernel owns ONE SEGMENT of it -- list[list_grid + b * seg .. + seg),
+// seg = fixcap / list_grid -- filled through a cursor in a register and closed with one store of its count to list[b]: no atomic with
+// a return value in the unit loop.  (An `atomicAdd` per unit with a listed read was a load to wait for, and gfx9 counts loads and
+// stores in one in-order vmcnt: every such unit waited for the previous copy-out's stores to reach memory -- a batch where 10 % of the
+// reads end in a poly-A tail ran the MAIN kernel 59 % slower than a clean one, and k = 31 s = 11 syncmers list a read in half of the
+// units.)  The list pass takes the segments (KArgs::list_grid of them) round-robin over its workgroups, 64 reads at a time.
+__device__ __forceinline__ void list_append(const KArgs &a, u32 *list, u32 seg, u32 &cur, u64 redo, int lane, u64 r) {
+    const u32 at = cur + __builtin_amdgcn_mbcnt_hi((u32)(redo >> 32), __builtin_amdgcn_mbcnt_lo((u32)redo, 0));
+    if ((redo >> lane) & 1) {
+        if (at < seg) list[a.list_grid + blockIdx.x * seg + at] = (u32)r;
+        else atomicOr(&a.ticket[1], 2u);  // the segment is full: the host runs the batch on the 64-bit kernel instead
+    }
+    cur += (u32)__builtin_popcountll(redo);
+}
+__device__ __forceinline__ void list_close(u32 *list, u32 seg, u32 cur, int lane) {
+    if (lane == 0) list[blockIdx.x] = cur < seg ? cur : seg;
+}
 
 __device__ __forceinline__ u64 desc_len(const KArgs &a, u64 d) { return d & (u64)a.len_mask; }
 // where the outputs of the read in slot r (descriptor d) go: r itself, or the read's own place in its chunk of 4096

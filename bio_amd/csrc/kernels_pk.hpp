@@ -527,6 +527,8 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
     u64 d_n1 = 0, d_cur = 0;
     PkWords pw_cur = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     bool have = false;
+    const u32 lseg = a.fixcap / a.list_grid;  // this workgroup's segment of the list of reads for the exact machine (list_append)
+    u32 lcur = 0;
     for (u32 unit = next_ticket(a.ticket, lane) * PK_TICKET, uend = unit + PK_TICKET; unit < a.nunits; ++unit, ({
              if (unit == uend) {
                  unit = next_ticket(a.ticket, lane) * PK_TICKET;
@@ -593,15 +595,8 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
             // mostly low-complexity reads (poly-A / poly-G tails: every k-mer the same hash), per cent of the reads, i.e. in most units,
             // which is why the list is per read and not per unit -- and both reads of a column that filled up (0.8 % of the units on
             // random reads; next to a homopolymer tail, always).  The unit's other lanes leave normally.
-            const u32 nr = (u32)__builtin_popcountll(redo);
-            u32 at = 0;
-            if (lane == 0) at = atomicAdd(&a.ticket[6], nr);
-            at = wave_bcast_u32(at, 0) + __builtin_amdgcn_mbcnt_hi((u32)(redo >> 32), __builtin_amdgcn_mbcnt_lo((u32)redo, 0));
-            if ((redo >> lane) & 1) {
-                if (at < a.fixcap) a.rlist[at] = (u32)r;
-                else atomicOr(&a.ticket[1], 2u);  // the list is full: the host runs the batch on k_minimizer_fast instead
-                cnt = 0;  // the list pass writes this read's reference word
-            }
+            list_append(a, a.rlist, lseg, lcur, redo, lane, r);
+            if ((redo >> lane) & 1) cnt = 0;  // the list pass writes this read's reference word
         }
         const u32 incl = wave_incl_scan_u32(cnt, lane);
         const u32 excl = incl - cnt;
@@ -620,6 +615,7 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
             a.status[ro] = sbyte;
         }
     }
+    list_close(a.rlist, lseg, lcur, lane);
 }
 
 #ifdef BSK_IMPL_PK

@@ -523,6 +523,8 @@ __global__ __launch_bounds__(64, BSK_RING_WAVES) RG_KERNEL_ATTR void k_minimizer
 #pragma unroll
     for (int j = 0; j < NQ; ++j) pw_cur.q[j] = (u32x4){0, 0, 0, 0};
     bool have = false;
+    const u32 lseg = a.fixcap / a.list_grid;  // this workgroup's segment of the list of reads for the exact machine (list_append)
+    u32 lcur = 0;
     for (u32 unit = next_ticket(a.ticket, lane) * RG_TICKET, uend = unit + RG_TICKET; unit < a.nunits; ++unit, ({
              if (unit == uend) {
                  unit = next_ticket(a.ticket, lane) * RG_TICKET;
@@ -683,14 +685,7 @@ __global__ __launch_bounds__(64, BSK_RING_WAVES) RG_KERNEL_ATTR void k_minimizer
             for (; T < cmax; T += (u32)LY::G) group(T, std::integral_constant<int, 1>{}, (int)(lim - T), 0);
         }
         if (redo) {
-            const u32 nr = (u32)__builtin_popcountll(redo);
-            u32 at = 0;
-            if (lane == 0) at = atomicAdd(&a.ticket[6], nr);
-            at = wave_bcast_u32(at, 0) + __builtin_amdgcn_mbcnt_hi((u32)(redo >> 32), __builtin_amdgcn_mbcnt_lo((u32)redo, 0));
-            if ((redo >> lane) & 1) {
-                if (at < a.fixcap) a.rlist[at] = (u32)r;
-                else atomicOr(&a.ticket[1], 2u);  // the list is full: the host runs the batch on k_minimizer_fast instead
-            }
+            list_append(a, a.rlist, lseg, lcur, redo, lane, r);
         }
 #if BSK_RING_WAVES >= 3
         RgWords<NQ> pw_n1;
@@ -709,6 +704,7 @@ __global__ __launch_bounds__(64, BSK_RING_WAVES) RG_KERNEL_ATTR void k_minimizer
             a.status[ro] = sbyte;
         }
     }
+    list_close(a.rlist, lseg, lcur, lane);
 }
 
 #ifdef BSK_IMPL_RING

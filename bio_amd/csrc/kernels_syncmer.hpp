@@ -314,11 +314,14 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves p
     const u64 slab = (u64)64 * CAP;
     u64 d_next = 0;
     bool pre = false;
-    const u32 nlist = LIST ? (a.ticket[4] < a.fixcap ? a.ticket[4] : a.fixcap) : 0u;
-    const u32 *const rlist = reinterpret_cast<const u32 *>(a.fixlist);
-    for (u32 unit = LIST ? next_ticket(a.ticket + 5, lane) : next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; LIST ? unit < (nlist + 63u) / 64u : unit < a.nunits; ++unit, ({
+    // LIST: this workgroup's segment of the list (list_append, kernels_generic.hpp)
+    const u32 lseg = LIST ? a.fixcap / a.list_grid : 0u;
+    const u32 *const flist = reinterpret_cast<const u32 *>(a.fixlist);
+    for (u32 sg = LIST ? blockIdx.x : 0u; sg < (LIST ? a.list_grid : 1u); sg += LIST ? gridDim.x : 1u) {
+    const u32 nlist = LIST ? (flist[sg] < lseg ? flist[sg] : lseg) : 0u;
+    const u32 *const rlist = LIST ? flist + a.list_grid + sg * lseg : nullptr;
+    for (u32 unit = LIST ? 0u : next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; LIST ? unit < (nlist + 63u) / 64u : unit < a.nunits; ++unit, ({
              if (LIST) {
-                 unit = next_ticket(a.ticket + 5, lane);
              } else if (unit == uend) {
                  unit = next_ticket(a.ticket, lane) * 8u;
                  uend = unit + 8u;
@@ -389,6 +392,7 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves p
             if (ok && a.rflags) sbyte |= a.rflags[r];
             a.status[ro] = sbyte;
         }
+    }
     }
 }
 

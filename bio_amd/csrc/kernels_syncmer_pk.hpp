@@ -356,6 +356,8 @@ __global__ __launch_bounds__(64, SYNPK_LB) void k_syncmer_pk(KArgs a) {  // thre
     const u32 top = (u32)(LY::PR - 1) * RB + col8;  // the high lane's first slot
     u64 d_cur = 0;
     bool have = false;
+    const u32 lseg = a.fixcap / a.list_grid;  // this workgroup's segment of the list of reads for the exact machine (list_append)
+    u32 lcur = 0;
     const u32 wbuf = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(size_t)(ldsq + LY::WBUF));  // LDS byte addresses of the two buffers
     const u32 dbuf = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(size_t)(ldsq + LY::DBUF));
     for (u32 unit = next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; unit < a.nunits; ++unit, ({
@@ -427,15 +429,8 @@ __global__ __launch_bounds__(64, SYNPK_LB) void k_syncmer_pk(KArgs a) {  // thre
         redo = 0;
 #endif
         if (redo) {
-            const u32 nr = (u32)__builtin_popcountll(redo);
-            u32 at = 0;
-            if (lane == 0) at = atomicAdd(&a.ticket[4], nr);
-            at = wave_bcast_u32(at, 0) + __builtin_amdgcn_mbcnt_hi((u32)(redo >> 32), __builtin_amdgcn_mbcnt_lo((u32)redo, 0));
-            if ((redo >> lane) & 1) {
-                if (at < a.fixcap) reinterpret_cast<u32 *>(a.fixlist)[at] = (u32)r;
-                else atomicOr(&a.ticket[1], 2u);  // the list is full: the host runs the batch on k_syncmer_fast instead
-                cnt = 0;
-            }
+            list_append(a, reinterpret_cast<u32 *>(a.fixlist), lseg, lcur, redo, lane, r);
+            if ((redo >> lane) & 1) cnt = 0;
         }
         const u32 incl = wave_incl_scan_u32(cnt, lane);
         const u32 excl = incl - cnt;
@@ -451,6 +446,7 @@ __global__ __launch_bounds__(64, SYNPK_LB) void k_syncmer_pk(KArgs a) {  // thre
             a.status[ro] = sbyte;
         }
     }
+    list_close(reinterpret_cast<u32 *>(a.fixlist), lseg, lcur, lane);
 }
 
 #ifdef BSK_IMPL_SYNPK
