@@ -478,10 +478,7 @@ __device__ __forceinline__ void fast_copyout(char *lds, int lane, u32 cnt, u32 e
     wave_sync_lds();
 }
 
-// LIST: the READS k_minimizer_pk listed in a.rlist (u32 read numbers, count in a.ticket[6], ticket counter a.ticket[7]) -- reads in
-// which two equal 27-bit keys met in a min operation (real ties among them: low-complexity reads) -- 64 per wavefront, on this
-// kernel's 64-bit machine; their tuples go to the overflow region.
-template <int W, int CAP, bool POS16, bool LIST = false>
+template <int W, int CAP, bool POS16>
 __global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs a) {  // W >= 16: capped at 256 VGPRs (two waves per SIMD)
     constexpr bool PAIR = POS16;  // paired staging columns (8 waves per CU); 32-bit positions keep the private columns
     typedef typename MinLds<PAIR, CAP, POS16, BSK_PAIR_ROWS>::type LY;
@@ -501,20 +498,13 @@ __global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs 
     u32x4 pw_next = {0, 0, 0, 0};
     bool pre = false;
     // work distribution: a wave takes 8 consecutive units per ticket (one atomic per 512 reads)
-    const u32 nlist = LIST ? (a.ticket[6] < a.fixcap ? a.ticket[6] : a.fixcap) : 0u;
-    for (u32 unit = LIST ? next_ticket(a.ticket + 7, lane) : next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; LIST ? unit < (nlist + 63u) / 64u : unit < a.nunits; ++unit, ({
-             if (LIST) {
-                 unit = next_ticket(a.ticket + 7, lane);
-             } else if (unit == uend) {
+    for (u32 unit = next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; unit < a.nunits; ++unit, ({
+             if (unit == uend) {
                  unit = next_ticket(a.ticket, lane) * 8u;
                  uend = unit + 8u;
              }
          })) {
-        u64 r = (u64)unit * 64 + lane;
-        if (LIST) {
-            r = r < nlist ? (u64)a.rlist[r] : ~0ULL;
-            pre = false;  // (no look-ahead over a list)
-        }
+        const u64 r = (u64)unit * 64 + lane;
         // The descriptor and the first four words of a unit are loaded one unit ahead (within a ticket): a load issued at
         // the unit's start returns only after the previous unit's copy-out stores have drained (loads and stores share the
         // in-order vmcnt) and then costs two dependent memory latencies before the first base can be hashed.
@@ -528,7 +518,7 @@ __global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs 
             pw = *reinterpret_cast<const GLBQ u32x4_u *>((size_t)(a.words + (d >> 24)));
         }
         const u64 off = d >> 24, L = d & 0xffffffULL;
-        const bool nxt = !LIST && unit + 1 != uend && unit + 1 < a.nunits;
+        const bool nxt = unit + 1 != uend && unit + 1 < a.nunits;
         if (nxt) d_next = r + 64 < a.n ? a.desc[r + 64] : 0;
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
         const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
@@ -556,18 +546,7 @@ __global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs 
         const u32 cnt_pair = PAIR ? cnt + (u32)__builtin_amdgcn_ds_bpermute((lane ^ 32) * 4, (int)cnt) : 0u;
         const bool any_over = PAIR ? __builtin_amdgcn_ballot_w64(cnt_pair >= (u32)BSK_PAIR_ROWS) != 0 : __builtin_amdgcn_ballot_w64(cnt > (u32)CAP) != 0;
         u64 base = (u64)unit * slab;
-        bool list_fits = true;
-        if (LIST && !any_over) {  // listed reads leave through the overflow region
-            u64 ob = 0;
-            if (lane == 0) ob = atomicAdd(a.total + 1, (u64)T);
-            ob = wave_bcast_u64(ob, 0);
-            list_fits = ob + T <= a.ovf_cap;
-            if (list_fits) base = a.ovf_base + ob;
-            else if (lane == 0) atomicOr(&a.ticket[1], 1u);
-            if (!list_fits) cnt = 0;
-        }
-        if (!any_over && !list_fits) {
-        } else if (!any_over) {
+        if (!any_over) {
             // copy-out rows in flight: what keeps the kernel within 256 VGPRs (two waves per SIMD)
 #ifndef BSK_FAST_NOCOPYOUT
             if (PAIR) fast_copyout<LY, POS16, LY::NHEADS - 1, (W <= 11 ? 4 : W <= 15 ? 2 : 1), true>(lds, lane, cnt, excl, T, base, a);
@@ -778,7 +757,7 @@ struct DenseCfg {
     static constexpr int CAP = NB * W + G - 1;              // rows = CAP + 1: the left-over of a group + NB*W new + the scribble row
 };
 
-// LIST: the READS k_minimizer_pk listed in a.rlist (u32 read numbers, count in a.ticket[6], ticket counter a.ticket[7]) -- reads in
+// LIST: the READS k_minimizer_pk / k_minimizer_ring listed (list_append, kernels_generic.hpp: one segment of a.rlist per workgroup of the main launch) -- reads in
 // which two equal 27-bit keys met in a min operation.  Real ties are most of them on real data: low-complexity reads (poly-A / poly-G
 // tails, repeats), and a homopolymer selects EVERY position -- which is this kernel's case (per-read slabs, mid-read flushes), not
 // k_minimizer_fast's, whose staging columns such reads overflow.  64 listed reads per wavefront; every read gets a slab of
