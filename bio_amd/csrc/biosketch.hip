@@ -420,6 +420,7 @@ void BskOpts::load() {
     ring = on("BSK_RING");
     ring_max = env_u32("BSK_RING_MAX", 0);
     bin_min = env_u32("BSK_BIN_MIN", 1024);
+    syn_margin = (int)env_u32("BSK_SYN_MARGIN", 2 + 64) - 64;  // dev: rows of slack the planner wants in k_syncmer_pk's columns (BSK_SYN_MARGIN = 64 + margin)
     no_tiles = on("BSK_NO_TILES");
     no_tile_cache = on("BSK_NO_TILE_CACHE");
     timing = on("BSK_TIMING");
@@ -1304,10 +1305,12 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         }
     } else if (p->kind == BSK_SYNCMER) {
         // packed machine: reads whose words fit a lane's registers, and few enough selections that a pair of reads stages in the
-        // kernel's short columns (expected 1.5 / (k-s+1) of the windows: 7.1 of 101 at k=31 s=11, 150 bp, measured)
+        // kernel's short columns (expected 1.5 / (k-s+1) of the windows: 7.1 of 101 at k=31 s=11, 150 bp, measured).  Two rows of slack
+        // (round 4, scripts/dev/perf_syn_len.py: with six, reads of 165..188 bases ran on k_syncmer_fast at 640 instead of 800-850
+        // Gbases/s; with none, 195-base reads fill their columns, list a quarter of the batch and fall back after a wasted run)
         const double syn_nwin = (double)b->maxlen - 2.0 * p->k + p->s + 2.0;
         if (!use_ascii && pk_syncmer_supported(p->k - p->s) && fast_syncmer_supported(p->k, p->s) && b->maxlen <= pk_syncmer_max_bases() &&
-            2.0 * (syn_nwin * 1.5 / (p->k - p->s + 1.0) + 0.5) + 6.0 <= (double)pk_syncmer_pair_rows() && !ctx->opt.force_generic && !ctx->opt.no_pk && !ctx->no_syn_pk) {
+            2.0 * (syn_nwin * 1.5 / (p->k - p->s + 1.0) + 0.5) + (double)ctx->opt.syn_margin <= (double)pk_syncmer_pair_rows() && !ctx->opt.force_generic && !ctx->opt.no_pk && !ctx->no_syn_pk) {
             pl.which = K_SYN_PK;
             pl.fast_w = p->k - p->s;
             pl.slab = true;
