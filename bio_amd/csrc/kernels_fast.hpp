@@ -851,6 +851,12 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
                 const bool last = i0 + W >= nk_max;
                 if (++inround == NB || last) {
                     inround = 0;
+#ifndef BSK_DENSE_LATE_WAIT
+                    // the next block's words (requested a block of hashing ago) are waited for HERE, before the flush's stores are issued:
+                    // vmcnt is one in-order counter, and a wait behind the stores -- where the compiler puts it, at the words' first
+                    // use -- waits for every one of them to reach memory
+                    asm volatile("" : "+v"(fm.in_lo), "+v"(fm.in_hi), "+v"(fm.out_lo), "+v"(fm.out_hi));
+#endif
                     // the lane's rows are a ring starting at `head` (moving the left-over down after every flush cost more than the wrap test)
                     const u32 wrow = (fm.slot - (u32)lane * 8u) / (u32)(LY::ROW * 8);
                     const u32 cnt = wrow >= head ? wrow - head : wrow + (u32)(CAP + 1) - head;  // staged: left-over < 16 + NB*W new
