@@ -35,10 +35,10 @@ struct KArgs {
     u32 *pos;
     u64 cap;  // capacity of hash[]/pos[] in tuples
     // synchronisation / scratch
-    u32 *ticket;    // [0] unit ticket, [1] overflow flag, [2..3] the same for a side launch, [4] reads listed by k_syncmer_pk, [5] the list pass's ticket, [6] / [7] the same for k_minimizer_pk / k_minimizer_ring
+    u32 *ticket;    // [0] unit ticket, [1] overflow flag, [2..3] the same for a side launch, [4..7] unused since the lists of reads are per workgroup (list_append)
     u32 fixcap;     // entries (reads) of the read list over all segments (list_append): k_syncmer_pk's fixlist, k_minimizer_pk's rlist
-    u32 *rlist;     // k_minimizer_pk / k_minimizer_ring: reads for the exact machine (k_minimizer_dense<W, true>), count in ticket[6], its ticket in ticket[7]
-    u64 *fixlist;   // k_syncmer_pk: the same list as u32 read numbers (count in ticket[4], the list pass's ticket in ticket[5])
+    u32 *rlist;     // k_minimizer_pk / k_minimizer_ring: reads for the exact machine (k_minimizer_dense<W, true>): [list_grid] counts, then list_grid segments (list_append)
+    u64 *fixlist;   // k_syncmer_pk: the same list (u32 entries) for k_syncmer_fast<W, true>
     u64 *lookback;  // [nunits]
     u64 *total;     // [0] tuples written by the dense (look-back) kernels, [1] overflow-region cursor (slab kernels)
     u64 *ring_h;    // runtime-w ring: per workgroup ring_w*64 entries

@@ -495,7 +495,7 @@ __device__ __forceinline__ void pk_copyout(char *lds, int lane, u32 cnt, u32 exc
 }
 
 // Reads the main kernel cannot finish -- a 27-bit key tie in one of their min operations, or a staging column that filled up -- go
-// to a list of READS (a.rlist, count in a.ticket[6]) and k_minimizer_dense<W, true>, the exact 64-bit machine with per-read slabs,
+// to a list of READS (a.rlist: one segment per workgroup, list_append) and k_minimizer_dense<W, true>, the exact 64-bit machine with per-read slabs,
 // runs them afterwards, 64 per wavefront.  History (profiles/NOTEBOOK.md): the exact machine inlined here cost the main loop 5 %
 // (registers, code), as a noinline call 20 %; re-running a unit with every tuple stored straight to HBM, as k_minimizer_fast does,
 // costs nine units' time (2 800 partial-line writes); a per-UNIT second pass cost a whole pass for every unit with one low-complexity

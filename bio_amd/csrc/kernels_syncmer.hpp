@@ -297,7 +297,7 @@ struct FastSyn {
 };
 
 
-// LIST: the READS k_syncmer_pk listed in a.fixlist (u32 read numbers; count in a.ticket[4], ticket counter a.ticket[5]) -- reads in
+// LIST: the READS k_syncmer_pk listed in a.fixlist (u32 read numbers, one segment per workgroup of the main launch: list_append) -- reads in
 // which two equal 27-bit s-mer keys met in a min operation, or whose staging column filled up -- 64 per wavefront, on this kernel's
 // 64-bit machine; their tuples go to the overflow region.
 template <int W, bool LIST = false>
