@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -420,6 +421,7 @@ void BskOpts::load() {
     ring = on("BSK_RING");
     ring_max = env_u32("BSK_RING_MAX", 0);
     bin_min = env_u32("BSK_BIN_MIN", 1024);
+    no_syn_long = on("BSK_NO_SYN_LONG");  // dev: reads beyond k_syncmer_pk's limits go to k_syncmer_fast as before round 4
     syn_margin = (int)env_u32("BSK_SYN_MARGIN", 2 + 64) - 64;  // dev: rows of slack the planner wants in k_syncmer_pk's columns (BSK_SYN_MARGIN = 64 + margin)
     no_tiles = on("BSK_NO_TILES");
     no_tile_cache = on("BSK_NO_TILE_CACHE");
@@ -1084,6 +1086,7 @@ struct Plan {
     Which which = K_MIN_GEN_P;
     int grid = 1;
     int fast_w = 0;
+    bool syn_long = false;  // K_SYN_PK: k_syncmer_pkl (longer columns, more words in registers, two waves per SIMD)
     bool slab = false;     // true: unit u owns tuples [u*slab_unit, (u+1)*slab_unit) (+ overflow region); no look-back
     u64 slab_unit = 0;     // tuples per unit slab
     u64 slab_total = 0;    // nunits * slab_unit
@@ -1309,15 +1312,27 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         // (round 4, scripts/dev/perf_syn_len.py: with six, reads of 165..188 bases ran on k_syncmer_fast at 640 instead of 800-850
         // Gbases/s; with none, 195-base reads fill their columns, list a quarter of the batch and fall back after a wasted run)
         const double syn_nwin = (double)b->maxlen - 2.0 * p->k + p->s + 2.0;
-        if (!use_ascii && pk_syncmer_supported(p->k - p->s) && fast_syncmer_supported(p->k, p->s) && b->maxlen <= pk_syncmer_max_bases() &&
-            2.0 * (syn_nwin * 1.5 / (p->k - p->s + 1.0) + 0.5) + (double)ctx->opt.syn_margin <= (double)pk_syncmer_pair_rows() && !ctx->opt.force_generic && !ctx->opt.no_pk && !ctx->no_syn_pk) {
+        const double syn_rows = 2.0 * (syn_nwin * 1.5 / (p->k - p->s + 1.0) + 0.5) + (double)ctx->opt.syn_margin;
+        auto syn_pk_fits = [&](bool lng) {
+            // (the long plan's columns fill later in relative terms -- a pair's count spreads with its square root -- but two rows of
+            // slack are not enough there: a fifth more than expected, measured with scripts/dev/perf_syn_len.py)
+            const double want = lng ? syn_rows + 0.12 * (syn_rows - (double)ctx->opt.syn_margin) : syn_rows;
+            return pk_syncmer_supported(p->k - p->s, lng) && b->maxlen <= pk_syncmer_max_bases(lng) && want <= (double)pk_syncmer_pair_rows(lng);
+        };
+        const bool syn_short = syn_pk_fits(false), syn_lng = !syn_short && !ctx->opt.no_syn_long && syn_pk_fits(true);
+        // small s: equal s-mers inside one 2w window are the rule (s = 7: 8 192 canonical values, half of the 150-base reads hold such a
+        // pair), every such read is the exact machine's, the list (a quarter of the batch) fills up and the call falls back after a
+        // wasted run.  Expected pairs per read = windows x 2w x 2 / 4^s; beyond 0.2 the packed kernels are not planned.
+        const bool syn_ties = std::max(syn_nwin, 0.0) * 4.0 * (p->k - p->s) / std::pow(4.0, (double)std::min(p->s, 24)) > 0.2;
+        if (!use_ascii && fast_syncmer_supported(p->k, p->s) && (syn_short || syn_lng) && !syn_ties && !ctx->opt.force_generic && !ctx->opt.no_pk && !ctx->no_syn_pk) {
+            pl.syn_long = syn_lng;
             pl.which = K_SYN_PK;
             pl.fast_w = p->k - p->s;
             pl.slab = true;
             pl.slab_unit = (u64)64 * BSK_SYN_CAP;
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
             pl.bin_gran = bin_gran_for(ctx, b, p->k - p->s);
-            per_cu = pk_syncmer_blocks_per_cu(pl.fast_w);
+            per_cu = pk_syncmer_blocks_per_cu(pl.fast_w, pl.syn_long);
         } else if (!use_ascii && fast_syncmer_supported(p->k, p->s) && b->maxlen < 32768u && !ctx->opt.force_generic) {
             pl.which = K_SYN_FAST;
             pl.fast_w = p->k - p->s;
@@ -1592,7 +1607,7 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
         case K_PROT_HASH: snprintf(b, sizeof b, "k_prot_hash"); break;
         case K_PROT_MIN: snprintf(b, sizeof b, "k_prot_minimizer"); break;
         case K_SYN_FAST: snprintf(b, sizeof b, "k_syncmer_fast<%d>", pl.fast_w); break;
-        case K_SYN_PK: snprintf(b, sizeof b, "k_syncmer_pk<%d>", pl.fast_w); break;
+        case K_SYN_PK: snprintf(b, sizeof b, pl.syn_long ? "k_syncmer_pkl<%d>" : "k_syncmer_pk<%d>", pl.fast_w); break;
         case K_PROT_MIN_FAST: snprintf(b, sizeof b, "k_prot_minimizer_fast<%d,%d,%s>", pl.fast_w, pl.fast_k, pl.fused_dna ? "true" : "false"); break;
         case K_PROT_HASH_FAST: snprintf(b, sizeof b, "k_prot_hash_fast<%d,%s>", pl.fast_k, pl.fused_dna ? "true" : "false"); break;
         case K_SIM_FAST:
@@ -1701,7 +1716,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_PROT_HASH: hipLaunchKernelGGL(k_prot_hash, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_PROT_MIN: hipLaunchKernelGGL(k_prot_minimizer, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_SYN_FAST: fast_syncmer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
-        case K_SYN_PK: pk_syncmer_launch(pl.fast_w, pl.grid, std::min(pl.grid, ctx->cus * 8), ctx->stream, a); break;
+        case K_SYN_PK: pk_syncmer_launch(pl.fast_w, pl.syn_long, pl.grid, std::min(pl.grid, ctx->cus * 8), ctx->stream, a); break;
         case K_PROT_MIN_FAST:
             if (pl.fused_dna) {
                 a.frame = p->frame;

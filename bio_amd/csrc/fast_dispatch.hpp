@@ -39,11 +39,13 @@ bool fast_syncmer_supported(int k, int s);
 int fast_syncmer_blocks_per_cu(int w);
 void fast_syncmer_launch(int w, int grid, hipStream_t stream, const KArgs &a);
 
-bool pk_syncmer_supported(int w);  // packed window machine, three waves per SIMD (kernels_syncmer_pk.hpp)
-u32 pk_syncmer_max_bases();
-u32 pk_syncmer_pair_rows();
-int pk_syncmer_blocks_per_cu(int w);
-void pk_syncmer_launch(int w, int grid, int fix_grid, hipStream_t stream, const KArgs &a);
+// packed window machine (kernels_syncmer_pk.hpp).  lng = false: k_syncmer_pk, three waves per SIMD, reads up to 224 bases in 23-row
+// columns; lng = true: k_syncmer_pkl, two waves per SIMD, reads up to 352 bases in longer columns, k - s up to 24
+bool pk_syncmer_supported(int w, bool lng);
+u32 pk_syncmer_max_bases(bool lng);
+u32 pk_syncmer_pair_rows(bool lng);
+int pk_syncmer_blocks_per_cu(int w, bool lng);
+void pk_syncmer_launch(int w, bool lng, int grid, int fix_grid, hipStream_t stream, const KArgs &a);
 
 bool fast_prot_supported(int w, int k);
 int fast_prot_blocks_per_cu(int w, int k);

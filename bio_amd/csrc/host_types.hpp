@@ -16,6 +16,7 @@ struct BskOpts {
     bool force_generic = false, no_mixed = false, no_dense = false, no_pk = false, no_ring = false, ring = false, no_bin = false, compact = false, no_tiles = false, no_tile_cache = false, timing = false,
          no_fused_translate = false, sets_no_small = false;
     int syn_margin = 2;
+    bool no_syn_long = false;
     u32 wpr = 0, seg = 0, dense_min = 21, ring_max = 0, bin_min = 1024, waves_per_cu = 0, tile_min = 0, tile_pos = 0;  // tile_min 0: the kind's default
     void load();  // biosketch.hip
 };

@@ -25,8 +25,17 @@ namespace bsk {
 #ifndef BSK_SYNPK_ROWS
 #define BSK_SYNPK_ROWS 23
 #endif
-struct SynPkLds {
-    static constexpr int PR = BSK_SYNPK_ROWS;
+#ifndef BSK_SYNPKL_ROWS
+#define BSK_SYNPKL_ROWS 38
+#endif
+#ifndef BSK_SYNPKL_NW
+#define BSK_SYNPKL_NW 24
+#endif
+// PR_: rows of a pair's staging column.  NW_: packed words of a read kept in registers.  LIM: the LDS a wavefront may take.
+template <int PR_, int NW_, int LIM>
+struct SynPkLdsT {
+    static constexpr int PR = PR_;
+    static constexpr int NW = NW_;
     static constexpr int ROW = 33;
     static constexpr int TABK = 0;      // 20 x uint4 k-mer update table } hash phase
     static constexpr int TABS = 320;    // 20 x uint4 s-mer update table }
@@ -35,19 +44,24 @@ struct SynPkLds {
     static constexpr int CTAB = 256;    // }
     static constexpr int SH = 768;
     static constexpr int SP = SH + (PR + 1) * ROW * 8;
-    static constexpr int WBUF = (SP + (PR + 1) * ROW * 2 + 15) & ~15;  // u32x4 [PKNW / 4][64]: the NEXT unit's packed words (LDS-DMA)
-    static constexpr int DBUF = WBUF + PKNW * 64 * 4;                  // u32 [2][64]: the next unit's descriptors, low and high words
-    static constexpr int TOTAL = DBUF + 512;                           // 13 296 B: twelve waves per CU
-    static_assert(NHEADS * 8 <= CTAB && CTAB + 512 <= SH && TABS + 320 <= SH && TOTAL <= 13312, "SynPkLds");
+    static constexpr int WBUF = (SP + (PR + 1) * ROW * 2 + 15) & ~15;  // u32x4 [NW / 4][64]: the NEXT unit's packed words (LDS-DMA)
+    static constexpr int DBUF = WBUF + NW * 64 * 4;                    // u32 [2][64]: the next unit's descriptors, low and high words
+    static constexpr int TOTAL = DBUF + 512;                           // short plan: 13 296 B, twelve waves per CU
+    static_assert(NHEADS * 8 <= CTAB && CTAB + 512 <= SH && TABS + 320 <= SH && TOTAL <= LIM && NW % 4 == 0, "SynPkLds");
 };
+typedef SynPkLdsT<BSK_SYNPK_ROWS, PKNW, 13312> SynPkLds;              // k_syncmer_pk: reads of up to 224 bases, twelve waves per CU
+// k_syncmer_pkl: reads of up to 352 bases and k - s up to 24 in longer columns, two waves per SIMD (round 4: until then reads that
+// select more than ~10 positions or are longer than 224 bases, and k - s = 21..24, ran on the 64-bit machine k_syncmer_fast)
+typedef SynPkLdsT<BSK_SYNPKL_ROWS, BSK_SYNPKL_NW, 32768> SynPkLdsL;  // (38 rows + 24 words: 20 304 B, eight waves per CU)
 
 // The next unit's packed words go global -> LDS directly (global_load_lds_dwordx4: lane i's 16 bytes land at base + 16 i), from inline
 // asm: no VGPR destination that the compiler could spill or copy while the load is in flight (under this kernel's 168-register cap
 // it did exactly that with k_minimizer_pk's register form), and no entry in its s_waitcnt bookkeeping (kernels_pk.hpp: PkMin::word2).
 // The caller waits with vmcnt(0) before the unit's copy-out; M0 (compiler-reserved) is saved and restored inside the statement.
+template <int NQ>
 __device__ __forceinline__ void synpk_dma_words(const u32 *gsrc, u32 lds_dst) {
 #pragma unroll
-    for (int j = 0; j < PKNW / 4; ++j) {
+    for (int j = 0; j < NQ; ++j) {
         u32 keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
@@ -110,13 +124,20 @@ struct Nib32 {
     }
 };
 
-template <int W>
+typedef u32 u32x32 __attribute__((ext_vector_type(32)));
+template <int N>
+struct SynVec {
+    static_assert(N == 16 || N == 24 || N == 32, "SynVec");
+    typedef typename std::conditional<N == 16, u32x16, u32x32>::type type;  // (no 24-register class: the tuple is 32 wide)
+};
+template <int W, class LY_ = SynPkLds>
 struct SynPk {
-    typedef SynPkLds LY;
+    typedef LY_ LY;
+    static constexpr int NW = LY::NW;
     LDSQ char *lds;
     int k, s, lane;
     u32 end_plus1;  // number of windows of this lane (end + 1), 0: the lane does not stage
-    u32x16 wr;      // the read's first 16 packed words
+    typename SynVec<NW>::type wr;  // the read's first NW packed words
     u32 kfl, kfh, krl, krh, sfl, sfh, srl, srh;
     u32 S[W], D[W], P;
     u32 selm, tmin, slot, spare, park0;
@@ -147,7 +168,7 @@ struct SynPk {
     // 32 codes from base position p0 (wave-uniform; positions beyond the 16 words read as the last words: never a valid step's)
     __device__ __forceinline__ Codes32 codes(u32 p0) const {
         u32 wi = (u32)__builtin_amdgcn_readfirstlane((int)(p0 >> 4));
-        wi = wi < (u32)(PKNW - 3) ? wi : (u32)(PKNW - 3);
+        wi = wi < (u32)(NW - 3) ? wi : (u32)(NW - 3);
         Codes32 c;
         const u32 w0 = wr[wi], w1 = wr[wi + 1], w2 = wr[wi + 2], sh = (p0 & 15) * 2;
         c.lo = __builtin_amdgcn_alignbit(w1, w0, sh);
@@ -342,10 +363,9 @@ struct SynPk {
 #ifndef SYNPK_LB
 #define SYNPK_LB 3
 #endif
-template <int W>
-__global__ __launch_bounds__(64, SYNPK_LB) void k_syncmer_pk(KArgs a) {  // three waves per SIMD: at most 168 VGPRs
-    typedef SynPkLds LY;
-    __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
+template <int W, class LY>
+__device__ __forceinline__ void synpk_body(const KArgs &a, char *lds) {
+    constexpr int NQ = LY::NW / 4;
     LDSQ char *const ldsq = (LDSQ char *)lds;
     const int lane = lane_id();
     SynPkTabs tabs;
@@ -373,23 +393,35 @@ __global__ __launch_bounds__(64, SYNPK_LB) void k_syncmer_pk(KArgs a) {  // thre
         const u64 rmax = a.n - 1;
         if (!have) {  // first unit of a ticket: nothing was requested ahead
             d_cur = a.desc[r < rmax ? r : rmax];
-            synpk_dma_words(a.words + (d_cur >> 24), wbuf);
+            synpk_dma_words<NQ>(a.words + (d_cur >> 24), wbuf);
             synpk_dma_desc(a.desc + (r + 64 < rmax ? r + 64 : rmax), dbuf);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         const u64 d = d_cur;
-        u32x16 wr;
+        typename SynVec<LY::NW>::type wr;
         u64 d_n1;
         {
             const LDSQ u32x4 *wb = reinterpret_cast<const LDSQ u32x4 *>(ldsq + LY::WBUF) + lane;
             const LDSQ u32 *db = reinterpret_cast<const LDSQ u32 *>(ldsq + LY::DBUF) + lane;
-            const u32x4 w0 = wb[0], w1 = wb[64], w2 = wb[128], w3 = wb[192];
+            u32x4 wq[NQ];
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) wq[j] = wb[64 * j];
             u32 dl = db[0], dh = db[64];
-            wr = (u32x16){w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wr), "+v"(dl), "+v"(dh)::"memory");  // both buffers are read before the next loads overwrite them
+            // both buffers are read before the next loads overwrite them
+            static_assert(NQ == 4 || NQ == 6 || NQ == 8, "synpk_body");
+            if constexpr (NQ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[0]), "+v"(wq[1]), "+v"(wq[2]), "+v"(wq[3]), "+v"(dl), "+v"(dh)::"memory");
+            else if constexpr (NQ == 6) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[0]), "+v"(wq[1]), "+v"(wq[2]), "+v"(wq[3]), "+v"(wq[4]), "+v"(wq[5]), "+v"(dl), "+v"(dh)::"memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[0]), "+v"(wq[1]), "+v"(wq[2]), "+v"(wq[3]), "+v"(wq[4]), "+v"(wq[5]), "+v"(wq[6]), "+v"(wq[7]), "+v"(dl), "+v"(dh)::"memory");
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                wr[4 * j] = wq[j].x;
+                wr[4 * j + 1] = wq[j].y;
+                wr[4 * j + 2] = wq[j].z;
+                wr[4 * j + 3] = wq[j].w;
+            }
             d_n1 = ((u64)dh << 32) | dl;
         }
-        synpk_dma_words(a.words + (d_n1 >> 24), wbuf);
+        synpk_dma_words<NQ>(a.words + (d_n1 >> 24), wbuf);
         synpk_dma_desc(a.desc + (r + 128 < rmax ? r + 128 : rmax), dbuf);
         // the read's input flags (batches packed from ASCII have them): a load after the copy-out would wait for its stores
         u32 rfl = pk_load_u8(a.rflags ? a.rflags + (r < rmax ? r : rmax) : reinterpret_cast<const u8 *>(a.desc));
@@ -404,7 +436,7 @@ __global__ __launch_bounds__(64, SYNPK_LB) void k_syncmer_pk(KArgs a) {  // thre
         u32 cnt = 0, tmin_lane = 0xffffffffu;
         if (ns_max) {
             tabs.write(ldsq);  // the previous copy-out's tables took their place
-            SynPk<W> sp;
+            SynPk<W, LY> sp;
             sp.lds = ldsq;
             sp.k = a.k;
             sp.s = a.s;
@@ -449,41 +481,72 @@ __global__ __launch_bounds__(64, SYNPK_LB) void k_syncmer_pk(KArgs a) {  // thre
     list_close(reinterpret_cast<u32 *>(a.fixlist), lseg, lcur, lane);
 }
 
+template <int W>
+__global__ __launch_bounds__(64, SYNPK_LB) void k_syncmer_pk(KArgs a) {  // three waves per SIMD: at most 168 VGPRs
+    __shared__ __attribute__((aligned(16))) char lds[SynPkLds::TOTAL];
+    synpk_body<W, SynPkLds>(a, lds);
+}
+// the same machine with room for longer reads: BSK_SYNPKL_NW words in registers (352 bases), BSK_SYNPKL_ROWS rows per pair of reads,
+// two waves per SIMD (up to 256 VGPRs), eight waves per CU; also k - s = 21..24 (their first-window test parks 2 x 12 rows)
+template <int W>
+__global__ __launch_bounds__(64, 2) void k_syncmer_pkl(KArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[SynPkLdsL::TOTAL];
+    synpk_body<W, SynPkLdsL>(a, lds);
+}
+
 #ifdef BSK_IMPL_SYNPK
 #ifndef BSK_SYNPK_WS
 #define BSK_SYNPK_WS(X) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20)
 #endif
-// (w <= 20: the first-window tie test parks W suffix minima in the lane's half of a 23-row staging column)
-bool pk_syncmer_supported(int w) { return w >= 4 && w <= 20; }
-u32 pk_syncmer_max_bases() { return 16u * (PKNW - 2); }  // the words a lane keeps in registers
-u32 pk_syncmer_pair_rows() { return (u32)SynPkLds::PR; }
-int pk_syncmer_blocks_per_cu(int w) {
+#ifndef BSK_SYNPKL_WS
+#define BSK_SYNPKL_WS(X) BSK_SYNPK_WS(X) X(21) X(22) X(23) X(24)
+#endif
+// short plan: w <= 20 (the first-window tie test parks W suffix minima in the lane's half of a 23-row staging column); long plan: w <= 24
+bool pk_syncmer_supported(int w, bool lng) {
+#define X(WW) \
+    if (w == WW) return true;
+    if (lng) {
+        BSK_SYNPKL_WS(X)
+    } else {
+        BSK_SYNPK_WS(X)
+    }
+#undef X
+    return false;
+}
+u32 pk_syncmer_max_bases(bool lng) { return 16u * (u32)((lng ? SynPkLdsL::NW : SynPkLds::NW) - 2); }  // the words a lane keeps in registers
+u32 pk_syncmer_pair_rows(bool lng) { return (u32)(lng ? SynPkLdsL::PR : SynPkLds::PR); }
+int pk_syncmer_blocks_per_cu(int w, bool lng) {
     int nb = 0;
     hipError_t e = hipErrorInvalidValue;
-    switch (w) {
 #define X(WW) \
-    case WW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_syncmer_pk<WW>, 64, 0); break;
-        BSK_SYNPK_WS(X)
+    if (w == WW && !lng) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_syncmer_pk<WW>, 64, 0);
+    BSK_SYNPK_WS(X)
 #undef X
-        default: break;
-    }
+#define X(WW) \
+    if (w == WW && lng) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_syncmer_pkl<WW>, 64, 0);
+    BSK_SYNPKL_WS(X)
+#undef X
     if (e != hipSuccess || nb < 1) {
         (void)hipGetLastError();
         nb = 1;
     }
     return nb;
 }
-void pk_syncmer_launch(int w, int grid, int fix_grid, hipStream_t stream, const KArgs &a) {
-    switch (w) {
-#define X(WW)                                                                                       \
-    case WW:                                                                                        \
-        hipLaunchKernelGGL((k_syncmer_pk<WW>), dim3(grid), dim3(64), 0, stream, a);                 \
-        hipLaunchKernelGGL((k_syncmer_fast<WW, true>), dim3(fix_grid), dim3(64), 0, stream, a);     \
-        break;
-        BSK_SYNPK_WS(X)
-#undef X
-        default: break;
+void pk_syncmer_launch(int w, bool lng, int grid, int fix_grid, hipStream_t stream, const KArgs &a) {
+#define X(WW)                                                                                   \
+    if (w == WW && !lng) {                                                                      \
+        hipLaunchKernelGGL((k_syncmer_pk<WW>), dim3(grid), dim3(64), 0, stream, a);             \
+        hipLaunchKernelGGL((k_syncmer_fast<WW, true>), dim3(fix_grid), dim3(64), 0, stream, a); \
     }
+    BSK_SYNPK_WS(X)
+#undef X
+#define X(WW)                                                                                   \
+    if (w == WW && lng) {                                                                       \
+        hipLaunchKernelGGL((k_syncmer_pkl<WW>), dim3(grid), dim3(64), 0, stream, a);            \
+        hipLaunchKernelGGL((k_syncmer_fast<WW, true>), dim3(fix_grid), dim3(64), 0, stream, a); \
+    }
+    BSK_SYNPKL_WS(X)
+#undef X
 }
 #endif  // BSK_IMPL_SYNPK
 

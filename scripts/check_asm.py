@@ -121,14 +121,14 @@ def check_reserved(ws=("11",), unit="k_minimizer_ring", macro="BSK_RING_WS", fir
 
 
 PK_WS = tuple(str(w) for w in range(2, 14))       # BSK_PK_WS, BSK_RING_WS
-SYNPK_WS = tuple(str(w) for w in range(4, 21))    # BSK_SYNPK_WS
+SYNPK_WS = tuple(str(w) for w in range(4, 25))    # BSK_SYNPK_WS (4..20: k_syncmer_pk and k_syncmer_pkl), BSK_SYNPKL_WS (21..24: k_syncmer_pkl only)
 
 
 def run_all(pk_ws, syn_ws, ring_ws, jobs=None):
     """Every (kernel family, width) is one hipcc -S run: in parallel."""
     from concurrent.futures import ThreadPoolExecutor
     tasks = [lambda w=w: check_hidden_loads((w,)) for w in pk_ws]
-    tasks += [lambda w=w: check_hidden_loads((w,), "k_syncmer_pk", "BSK_SYNPK_WS") for w in syn_ws]
+    tasks += [lambda w=w: check_hidden_loads((w,), "k_syncmer_pk", "BSK_SYNPKL_WS", ("-DBSK_SYNPK_WS(X)=" + ("X(%s)" % w if int(w) <= 20 else ""),)) for w in syn_ws]
     tasks += [lambda w=w: check_hidden_loads((w,), "k_minimizer_ring", "BSK_RING_WS") + check_reserved((w,)) for w in ring_ws]
     with ThreadPoolExecutor(max_workers=jobs or max(2, (os.cpu_count() or 4))) as ex:
         res = list(ex.map(lambda f: f(), tasks))
@@ -138,7 +138,7 @@ def run_all(pk_ws, syn_ws, ring_ws, jobs=None):
 if __name__ == "__main__":
     # usage: check_asm.py            -> w = 11 (pk, ring), k - s = 20 (syncmer)
     #        check_asm.py 2 11 13    -> those pk widths (+ ring 11, syncmer 20)
-    #        check_asm.py all        -> every instantiation the library ships (pk / ring 2..13, syncmer 4..20)
+    #        check_asm.py all        -> every instantiation the library ships (pk / ring 2..13, syncmer 4..24)
     args = sys.argv[1:]
     if args == ["all"]:
         errs = check_scc() + run_all(PK_WS, SYNPK_WS, PK_WS)

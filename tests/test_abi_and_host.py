@@ -118,9 +118,9 @@ def test_codon_tables_of_the_library_equal_the_reference_matrix(oracle):
 
 def test_hand_written_asm_is_safe():
     """scripts/check_asm.py: every inline-asm block with an SCC-writing SALU op names the clobber (the round-2 bug class), and in the
-    ISA of EVERY shipped instantiation of k_minimizer_pk / k_minimizer_ring (w = 2..13) and k_syncmer_pk (k - s = 4..20) nothing touches
+    ISA of EVERY shipped instantiation of k_minimizer_pk / k_minimizer_ring (w = 2..13) and k_syncmer_pk / k_syncmer_pkl (k - s = 4..20 / 4..24) nothing touches
     the registers of a hidden (inline-asm) load before the hand-written wait, nor a register the ring kernel reserves (w = 15, 16 of the
-    packed kernel once spilled in-flight registers: the check is width-dependent).  41 hipcc -S runs in parallel, ~30 s on 8 cores."""
+    packed kernel once spilled in-flight registers: the check is width-dependent).  45 hipcc -S runs in parallel, ~40 s on 8 cores."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

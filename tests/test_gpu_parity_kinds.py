@@ -77,6 +77,58 @@ def test_syncmer_packed_kernel_at_its_length_limit(engine, oracle):
     b.close()
 
 
+@pytest.mark.parametrize("k,s,lo,hi", [(31, 11, 225, 260), (31, 11, 180, 250), (120, 100, 330, 352), (31, 7, 120, 160), (33, 10, 140, 150),
+                                       (35, 13, 150, 151), (45, 21, 200, 300), (31, 11, 60, 250)])
+def test_syncmer_long_packed_kernel(engine, oracle, k, s, lo, hi):
+    """k_syncmer_pkl: the packed machine with 24 words of a read in registers (reads of up to 352 bases), longer staging columns and
+    k - s up to 24 (round 4; until then these batches ran on k_syncmer_fast).  Every read against the closed form AND the reference's
+    state machine; lengths up to the word limit so that the clamped word index of the last blocks is exercised; ragged batches
+    (length-binned units) included."""
+    rng = random.Random(1000 * k + s + hi)
+    seqs = [rand_seq(rng, rng.randint(lo, hi)) for _ in range(2200)]
+    seqs[7] = "A" * hi                      # every s-mer the same hash: a key tie in every min operation -> the exact machine
+    seqs[8] = rand_seq(rng, lo - 40) + "T" * 40  # a low-complexity tail
+    b = engine.batch(seqs)
+    res = engine.run(b, engine.params(L.SYNCMER, k, s=s))
+    assert "k_syncmer_pkl" in res.plan()["kernel"], res.plan()
+    for i, q in enumerate(seqs):
+        st, h, p = res.read(i)
+        if len(q) < 2 * k - s - 1:
+            assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0, (i, len(q))
+            continue
+        eh, ep, es, fl = oracle.syncmer(q, k, s, False, closed=True)
+        assert (st & L.ST_CODE_MASK) == L.ST_OK and np.array_equal(h, eh), (i, k, s, len(q))
+        assert np.array_equal(p & L.POS_MASK, ep) and np.array_equal(p >> 31, es) and (st & 0xF0) == fl, (i, k, s, len(q))
+        if i % 4 == 0:
+            mh, mp, _, _ = oracle.syncmer(q, k, s)  # the state machine
+            assert np.array_equal(h, mh) and np.array_equal(p & L.POS_MASK, mp), (i, k, s, len(q))
+    res.close()
+    b.close()
+
+
+def test_syncmer_long_plan_digest_equals_the_64_bit_kernels(engine):
+    """Same batch through k_syncmer_pkl and (BSK_NO_SYN_LONG) k_syncmer_fast: identical digests and flag counts."""
+    import os
+    b = engine.synth(L.ALPHA_DNA, 300000, 250, 0x5EED0250)
+    prm = engine.params(L.SYNCMER, 31, s=11)
+    res = engine.run(b, prm)
+    assert "k_syncmer_pkl" in res.plan()["kernel"], res.plan()
+    d1 = res.digest()
+    res.close()
+    os.environ["BSK_NO_SYN_LONG"] = "1"
+    try:
+        engine.reload_options()
+        res = engine.run(b, prm)
+        assert "k_syncmer_fast" in res.plan()["kernel"], res.plan()
+        d2 = res.digest()
+        res.close()
+    finally:
+        del os.environ["BSK_NO_SYN_LONG"]
+        engine.reload_options()
+    assert d1 == d2, (d1, d2)
+    b.close()
+
+
 def test_syncmer_invalid_s(engine):
     from bio_amd import sketches as S
     seq, _ = S.NewSeq(S.DNA, "ACGT" * 20)
