@@ -1314,8 +1314,9 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         const double syn_nwin = (double)b->maxlen - 2.0 * p->k + p->s + 2.0;
         const double syn_rows = 2.0 * (syn_nwin * 1.5 / (p->k - p->s + 1.0) + 0.5) + (double)ctx->opt.syn_margin;
         auto syn_pk_fits = [&](bool lng) {
-            // (the long plan's columns fill later in relative terms -- a pair's count spreads with its square root -- but two rows of
-            // slack are not enough there: a fifth more than expected, measured with scripts/dev/perf_syn_len.py)
+            // (the long plan: an eighth more than the short plan's rule, the spread of a pair's count grows with the count.  k=31 s=11,
+            // scripts/dev/perf_syn_long.py: 250 / 300 / 350 / 380-base reads 818 / 750 / 759 / 680 Gbases/s -- at 380 the columns begin
+            // to fill -- against 635 / 597 / 604 / 416 on k_syncmer_fast; 400-base reads want 59.3 of the 58 rows and stay there)
             const double want = lng ? syn_rows + 0.12 * (syn_rows - (double)ctx->opt.syn_margin) : syn_rows;
             return pk_syncmer_supported(p->k - p->s, lng) && b->maxlen <= pk_syncmer_max_bases(lng) && want <= (double)pk_syncmer_pair_rows(lng);
         };

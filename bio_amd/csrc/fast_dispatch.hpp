@@ -40,7 +40,7 @@ int fast_syncmer_blocks_per_cu(int w);
 void fast_syncmer_launch(int w, int grid, hipStream_t stream, const KArgs &a);
 
 // packed window machine (kernels_syncmer_pk.hpp).  lng = false: k_syncmer_pk, three waves per SIMD, reads up to 224 bases in 23-row
-// columns; lng = true: k_syncmer_pkl, two waves per SIMD, reads up to 352 bases in longer columns, k - s up to 24
+// columns; lng = true: k_syncmer_pkl, two waves per SIMD, reads up to 480 bases in 58-row columns, k - s up to 24
 bool pk_syncmer_supported(int w, bool lng);
 u32 pk_syncmer_max_bases(bool lng);
 u32 pk_syncmer_pair_rows(bool lng);

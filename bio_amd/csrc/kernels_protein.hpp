@@ -357,8 +357,10 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
 
 #ifdef BSK_IMPL_PROTEIN
 // every window 2..8 with every k 9..16 (the register wyhash covers 9..16 residues), protein-fed and DNA-fed
+#ifndef BSK_PROT_KW  // (dev builds narrow the list: -D'BSK_PROT_KW(X)=X(5,9)')
 #define BSK_PROT_K(X, WW) X(WW, 9) X(WW, 10) X(WW, 11) X(WW, 12) X(WW, 13) X(WW, 14) X(WW, 15) X(WW, 16)
 #define BSK_PROT_KW(X) BSK_PROT_K(X, 2) BSK_PROT_K(X, 3) BSK_PROT_K(X, 4) BSK_PROT_K(X, 5) BSK_PROT_K(X, 6) BSK_PROT_K(X, 7) BSK_PROT_K(X, 8)
+#endif
 bool fast_prot_supported(int w, int k) {
 #define X(WW, KK) \
     if (w == WW && k == KK) return true;

@@ -26,16 +26,18 @@ namespace bsk {
 #define BSK_SYNPK_ROWS 23
 #endif
 #ifndef BSK_SYNPKL_ROWS
-#define BSK_SYNPKL_ROWS 38
+#define BSK_SYNPKL_ROWS 58
 #endif
 #ifndef BSK_SYNPKL_NW
-#define BSK_SYNPKL_NW 24
+#define BSK_SYNPKL_NW 32
 #endif
 // PR_: rows of a pair's staging column.  NW_: packed words of a read kept in registers.  LIM: the LDS a wavefront may take.
-template <int PR_, int NW_, int LIM>
+// DMA_: the next unit's words and descriptors travel global -> LDS (buffers WBUF / DBUF); otherwise global -> registers
+template <int PR_, int NW_, int LIM, bool DMA_ = true>
 struct SynPkLdsT {
     static constexpr int PR = PR_;
     static constexpr int NW = NW_;
+    static constexpr bool DMA = DMA_;
     static constexpr int ROW = 33;
     static constexpr int TABK = 0;      // 20 x uint4 k-mer update table } hash phase
     static constexpr int TABS = 320;    // 20 x uint4 s-mer update table }
@@ -46,13 +48,18 @@ struct SynPkLdsT {
     static constexpr int SP = SH + (PR + 1) * ROW * 8;
     static constexpr int WBUF = (SP + (PR + 1) * ROW * 2 + 15) & ~15;  // u32x4 [NW / 4][64]: the NEXT unit's packed words (LDS-DMA)
     static constexpr int DBUF = WBUF + NW * 64 * 4;                    // u32 [2][64]: the next unit's descriptors, low and high words
-    static constexpr int TOTAL = DBUF + 512;                           // short plan: 13 296 B, twelve waves per CU
+    static constexpr int TOTAL = DMA ? DBUF + 512 : WBUF;              // short plan: 13 296 B, twelve waves per CU
     static_assert(NHEADS * 8 <= CTAB && CTAB + 512 <= SH && TABS + 320 <= SH && TOTAL <= LIM && NW % 4 == 0, "SynPkLds");
 };
 typedef SynPkLdsT<BSK_SYNPK_ROWS, PKNW, 13312> SynPkLds;              // k_syncmer_pk: reads of up to 224 bases, twelve waves per CU
-// k_syncmer_pkl: reads of up to 352 bases and k - s up to 24 in longer columns, two waves per SIMD (round 4: until then reads that
+// k_syncmer_pkl: reads of up to 480 bases and k - s up to 24 in 58-row columns, two waves per SIMD (round 4: until then reads that
 // select more than ~10 positions or are longer than 224 bases, and k - s = 21..24, ran on the 64-bit machine k_syncmer_fast)
-typedef SynPkLdsT<BSK_SYNPKL_ROWS, BSK_SYNPKL_NW, 32768> SynPkLdsL;  // (38 rows + 24 words: 20 304 B, eight waves per CU)
+// (two waves per SIMD have the registers to take the next unit's words as k_minimizer_pk does, and the LDS the two buffers would take
+// is 18 more rows at the same eight waves per CU -- seven ran 17 % slower, six 26 %: round 4, scripts/dev/perf_syn_long.py)
+#ifndef BSK_SYNPKL_DMA
+#define BSK_SYNPKL_DMA 0
+#endif
+typedef SynPkLdsT<BSK_SYNPKL_ROWS, BSK_SYNPKL_NW, 32768, BSK_SYNPKL_DMA != 0> SynPkLdsL;  // 58 rows: 20 240 B, eight waves per CU
 
 // The next unit's packed words go global -> LDS directly (global_load_lds_dwordx4: lane i's 16 bytes land at base + 16 i), from inline
 // asm: no VGPR destination that the compiler could spill or copy while the load is in flight (under this kernel's 168-register cap
@@ -79,6 +86,33 @@ __device__ __forceinline__ void synpk_dma_desc(const u64 *gsrc, u32 lds_dst) {  
                      : "v"(reinterpret_cast<const u32 *>(gsrc) + j), "s"(lds_dst + 256u * (u32)j)
                      : "memory");
     }
+}
+
+// register form of the prefetch (plans without the LDS buffers): NQ x 4 words by loads the s_waitcnt pass does not see (kernels_pk.hpp)
+template <int NQ>
+struct SynWords {
+    u32x4 q[NQ];
+};
+template <int NQ>
+__device__ __forceinline__ SynWords<NQ> syn_load_words(const u32 *p) {
+    SynWords<NQ> r;
+    static_assert(NQ == 4 || NQ == 6 || NQ == 8, "SynWords");
+    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32\n\tglobal_load_dwordx4 %3, %4, off offset:48"
+                 : "=&v"(r.q[0]), "=&v"(r.q[1]), "=&v"(r.q[2]), "=&v"(r.q[3])
+                 : "v"(p));
+    if constexpr (NQ >= 6) asm volatile("global_load_dwordx4 %0, %2, off offset:64\n\tglobal_load_dwordx4 %1, %2, off offset:80" : "=&v"(r.q[4]), "=&v"(r.q[5]) : "v"(p));
+    if constexpr (NQ >= 8) asm volatile("global_load_dwordx4 %0, %2, off offset:96\n\tglobal_load_dwordx4 %1, %2, off offset:112" : "=&v"(r.q[6]), "=&v"(r.q[7]) : "v"(p));
+    return r;
+}
+template <int NQ>
+__device__ __forceinline__ void syn_wait_loads(SynWords<NQ> &p, u64 &d0, u32 &f) {
+    if constexpr (NQ == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(p.q[0]), "+v"(p.q[1]), "+v"(p.q[2]), "+v"(p.q[3]), "+v"(d0), "+v"(f)::"memory");
+    else if constexpr (NQ == 6)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(p.q[0]), "+v"(p.q[1]), "+v"(p.q[2]), "+v"(p.q[3]), "+v"(p.q[4]), "+v"(p.q[5]), "+v"(d0), "+v"(f)::"memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(p.q[0]), "+v"(p.q[1]), "+v"(p.q[2]), "+v"(p.q[3]), "+v"(p.q[4]), "+v"(p.q[5]), "+v"(p.q[6]), "+v"(p.q[7]), "+v"(d0), "+v"(f)::"memory");
 }
 
 struct SynPkTabs {  // lanes 0..19: the k-mer table's row, lanes 32..51: the s-mer table's
@@ -213,7 +247,10 @@ struct SynPk {
 #ifndef SYNPK_XC
 #define SYNPK_XC 1
 #endif
-        constexpr int XC = SYNPK_XC;
+#ifndef SYNPKL_XC
+#define SYNPKL_XC 1
+#endif
+        constexpr int XC = LY::NW > PKNW ? SYNPKL_XC : SYNPK_XC;  // (the long plan has the registers for more)
         u32x4 xs[W], xk[W];
         auto fetch = [&](auto o0c) {
             constexpr int O0 = decltype(o0c)::value;
@@ -374,7 +411,10 @@ __device__ __forceinline__ void synpk_body(const KArgs &a, char *lds) {
     const u32 col8 = (u32)(lane & 31) * 8u;
     constexpr u32 RB = (u32)(LY::ROW * 8);
     const u32 top = (u32)(LY::PR - 1) * RB + col8;  // the high lane's first slot
-    u64 d_cur = 0;
+    u64 d_cur = 0, d_nx = 0;
+    SynWords<NQ> pw_cur;  // (register form of the prefetch)
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) pw_cur.q[j] = (u32x4){0, 0, 0, 0};
     bool have = false;
     const u32 lseg = a.fixcap / a.list_grid;  // this workgroup's segment of the list of reads for the exact machine (list_append)
     u32 lcur = 0;
@@ -391,15 +431,18 @@ __device__ __forceinline__ void synpk_body(const KArgs &a, char *lds) {
         // The next unit's words and descriptors travel global -> LDS while this unit is hashed (indices beyond the batch are clamped to
         // its last read; what such a load brings is never used) and are waited for before the copy-out.
         const u64 rmax = a.n - 1;
+        typename SynVec<LY::NW>::type wr;
+        u64 d_n1;
+        SynWords<NQ> pw_n1;  // (register form)
+        u64 d_n2 = 0;
+        u32 rfl;
+        if constexpr (LY::DMA) {
         if (!have) {  // first unit of a ticket: nothing was requested ahead
             d_cur = a.desc[r < rmax ? r : rmax];
             synpk_dma_words<NQ>(a.words + (d_cur >> 24), wbuf);
             synpk_dma_desc(a.desc + (r + 64 < rmax ? r + 64 : rmax), dbuf);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        const u64 d = d_cur;
-        typename SynVec<LY::NW>::type wr;
-        u64 d_n1;
         {
             const LDSQ u32x4 *wb = reinterpret_cast<const LDSQ u32x4 *>(ldsq + LY::WBUF) + lane;
             const LDSQ u32 *db = reinterpret_cast<const LDSQ u32 *>(ldsq + LY::DBUF) + lane;
@@ -424,7 +467,30 @@ __device__ __forceinline__ void synpk_body(const KArgs &a, char *lds) {
         synpk_dma_words<NQ>(a.words + (d_n1 >> 24), wbuf);
         synpk_dma_desc(a.desc + (r + 128 < rmax ? r + 128 : rmax), dbuf);
         // the read's input flags (batches packed from ASCII have them): a load after the copy-out would wait for its stores
-        u32 rfl = pk_load_u8(a.rflags ? a.rflags + (r < rmax ? r : rmax) : reinterpret_cast<const u8 *>(a.desc));
+        rfl = pk_load_u8(a.rflags ? a.rflags + (r < rmax ? r : rmax) : reinterpret_cast<const u8 *>(a.desc));
+        } else {  // register form, as k_minimizer_pk: every load unconditional, words of unit N+1 and descriptor of unit N+2 requested here
+            if (!have) {
+                d_cur = pk_load_u64(a.desc + (r < rmax ? r : rmax));
+                d_nx = pk_load_u64(a.desc + (r + 64 < rmax ? r + 64 : rmax));
+                pk_wait_loads(d_cur, d_nx);
+                pw_cur = syn_load_words<NQ>(a.words + (d_cur >> 24));
+                u64 dz = d_cur;
+                u32 fz = 0;
+                syn_wait_loads<NQ>(pw_cur, dz, fz);
+            }
+            d_n1 = d_nx;
+            pw_n1 = syn_load_words<NQ>(a.words + (d_n1 >> 24));
+            d_n2 = pk_load_u64(a.desc + (r + 128 < rmax ? r + 128 : rmax));
+            rfl = pk_load_u8(a.rflags ? a.rflags + (r < rmax ? r : rmax) : reinterpret_cast<const u8 *>(a.desc));
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                wr[4 * j] = pw_cur.q[j].x;
+                wr[4 * j + 1] = pw_cur.q[j].y;
+                wr[4 * j + 2] = pw_cur.q[j].z;
+                wr[4 * j + 3] = pw_cur.q[j].w;
+            }
+        }
+        const u64 d = d_cur;
         const u64 L = desc_len(a, d);
         const u64 ro = out_index(a, r, d);  // (length-binned batches: the read's own place in its chunk)
         const long long Lorig = (long long)L - a.circ_ext;
@@ -448,7 +514,13 @@ __device__ __forceinline__ void synpk_body(const KArgs &a, char *lds) {
             if (ok) cnt = (lane < 32 ? sp.slot - col8 : top - sp.slot) / RB;
             tmin_lane = sp.tmin;
         }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rfl)::"memory");  // the next unit's words and the descriptors after them are in LDS
+        if constexpr (LY::DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(rfl)::"memory");  // the next unit's words and the descriptors after them are in LDS
+        } else {
+            syn_wait_loads<NQ>(pw_n1, d_n2, rfl);  // the next unit's words and the descriptor after it, requested a whole hashing phase ago
+            pw_cur = pw_n1;
+            d_nx = d_n2;
+        }
         d_cur = d_n1;
         have = nxt;
         // reads the exact machine must run: two equal 27-bit keys met in one of their min operations (a few per cent of the reads at
@@ -486,7 +558,7 @@ __global__ __launch_bounds__(64, SYNPK_LB) void k_syncmer_pk(KArgs a) {  // thre
     __shared__ __attribute__((aligned(16))) char lds[SynPkLds::TOTAL];
     synpk_body<W, SynPkLds>(a, lds);
 }
-// the same machine with room for longer reads: BSK_SYNPKL_NW words in registers (352 bases), BSK_SYNPKL_ROWS rows per pair of reads,
+// the same machine with room for longer reads: BSK_SYNPKL_NW words in registers (480 bases), BSK_SYNPKL_ROWS rows per pair of reads,
 // two waves per SIMD (up to 256 VGPRs), eight waves per CU; also k - s = 21..24 (their first-window test parks 2 x 12 rows)
 template <int W>
 __global__ __launch_bounds__(64, 2) void k_syncmer_pkl(KArgs a) {

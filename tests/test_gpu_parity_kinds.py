@@ -77,10 +77,10 @@ def test_syncmer_packed_kernel_at_its_length_limit(engine, oracle):
     b.close()
 
 
-@pytest.mark.parametrize("k,s,lo,hi", [(31, 11, 225, 260), (31, 11, 180, 250), (120, 100, 330, 352), (31, 7, 120, 160), (33, 10, 140, 150),
+@pytest.mark.parametrize("k,s,lo,hi", [(31, 11, 225, 260), (31, 11, 180, 250), (120, 100, 330, 352), (35, 11, 120, 160), (31, 11, 300, 352), (150, 128, 440, 480), (33, 10, 140, 150),
                                        (35, 13, 150, 151), (45, 21, 200, 300), (31, 11, 60, 250)])
 def test_syncmer_long_packed_kernel(engine, oracle, k, s, lo, hi):
-    """k_syncmer_pkl: the packed machine with 24 words of a read in registers (reads of up to 352 bases), longer staging columns and
+    """k_syncmer_pkl: the packed machine with 32 words of a read in registers (reads of up to 480 bases), longer staging columns and
     k - s up to 24 (round 4; until then these batches ran on k_syncmer_fast).  Every read against the closed form AND the reference's
     state machine; lengths up to the word limit so that the clamped word index of the last blocks is exercised; ragged batches
     (length-binned units) included."""
@@ -102,6 +102,22 @@ def test_syncmer_long_packed_kernel(engine, oracle, k, s, lo, hi):
         if i % 4 == 0:
             mh, mp, _, _ = oracle.syncmer(q, k, s)  # the state machine
             assert np.array_equal(h, mh) and np.array_equal(p & L.POS_MASK, mp), (i, k, s, len(q))
+    res.close()
+    b.close()
+
+
+def test_syncmer_small_s_is_not_planned_on_the_packed_kernels(engine, oracle):
+    """s = 7: equal s-mers inside one 2w window are the rule, every such read is the exact machine's -- the planner keeps such
+    parameters off the packed kernels (their list would fill up and the call would fall back after a wasted run)."""
+    rng = random.Random(707)
+    seqs = [rand_seq(rng, 150) for _ in range(600)]
+    b = engine.batch(seqs)
+    res = engine.run(b, engine.params(L.SYNCMER, 31, s=7))
+    assert "k_syncmer_fast" in res.plan()["kernel"], res.plan()
+    for i, q in enumerate(seqs):
+        st, h, p = res.read(i)
+        eh, ep, es, fl = oracle.syncmer(q, 31, 7, False, closed=True)
+        assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep) and (st & 0xF0) == fl, i
     res.close()
     b.close()
 
