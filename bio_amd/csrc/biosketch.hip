@@ -1973,11 +1973,25 @@ static bool kind_tiles(const bsk_params *p) {
     }
 }
 
+// the planner would put fixed-length 2-bit reads of a fitting length on k_syncmer_pkl (make_plan, BSK_SYNCMER)
+static bool syn_long_plan_ok(const bsk_ctx *ctx, const bsk_params *p) {
+    return pk_syncmer_supported(p->k - p->s, true) && fast_syncmer_supported(p->k, p->s) && !ctx->opt.no_syn_long && !ctx->opt.no_pk && !ctx->opt.force_generic &&
+           p->s >= 9;  // (small s: equal s-mers inside a window are the rule and the packed kernels are not planned)
+}
+
 // positions one tile owns: about 22 tuples per tile (the kernels stage 32 per lane; 16 for syncmers), a multiple of 16
 static u32 tile_positions(const bsk_ctx *ctx, const bsk_params *p) {
     u32 tp;
     if (p->kind == BSK_MINIMIZER || p->kind == BSK_PROT_MINIMIZER) tp = 16u * std::max<u32>(2, (u32)(22.0 * (p->w + 1.0) / 2.0 / 16.0));
-    else if (p->kind == BSK_SYNCMER) tp = 16u * std::max<u32>(2, (u32)(11.0 * (p->k - p->s + 1.0) / 2.0 / 16.0));
+    else if (p->kind == BSK_SYNCMER) {
+        tp = 16u * std::max<u32>(2, (u32)(11.0 * (p->k - p->s + 1.0) / 2.0 / 16.0));
+        // round 4: k_syncmer_pkl takes tiles three times as long at 0.9 of the rate, and a tile carries 3k + 16 bases of overlap: at k=31
+        // s=11 tiles of 112 + 109 bases spend half of the kernel on overlaps, tiles of 224 + 109 a third (~21 expected selections
+        // per tile: where the long plan's rate is still flat, scripts/dev/perf_syn_long.py)
+        const int w = p->k - p->s;
+        const long long lt = std::min<long long>(480, 14LL * (w + 1) + 2LL * p->k - p->s - 2), over = 3LL * p->k + 16;
+        if (syn_long_plan_ok(ctx, p) && lt - over > (long long)tp) tp = (u32)(lt - over) & ~15u;
+    }
     else tp = 256;
     tp = std::min<u32>(tp, 8192);
     const u32 forced = ctx->opt.tile_pos;  // tests: exercise the tile seams
@@ -2326,7 +2340,11 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
     }
     // long sequences run as tiles; protein: only when really long (the protein kernels take any length per lane, slowly)
     const bool is_dna = b->alphabet == BSK_ALPHA_DNA;
-    const u32 tile_min = ctx->opt.tile_min ? ctx->opt.tile_min : ((!is_dna || kind_has_pos(p->kind)) ? 4096u : 16u * (BSK_NT_FAST_WORDS - 2));
+    // (syncmers: beyond the packed kernels' reach the per-read 64-bit kernel falls to 140-160 Gbases/s of wall time -- its 28-tuple slabs
+    // overflow -- and to 83 at 4 000 bases, where tiles run 170-210: scripts/dev/perf_midlen.py, round 4)
+    const u32 tile_min = ctx->opt.tile_min ? ctx->opt.tile_min
+                         : (is_dna && p->kind == BSK_SYNCMER && syn_long_plan_ok(ctx, p)) ? 448u
+                         : ((!is_dna || kind_has_pos(p->kind)) ? 4096u : 16u * (BSK_NT_FAST_WORDS - 2));
     const bool outlier = !is_dna && p->kind == BSK_PROT_MINIMIZER && b->maxlen > 512 && !slab_budget_ok(b, (u64)b->maxlen);  // tiles are uniform: small slabs
     const bool tiled = kind_tiles(p) && (is_dna != prot_kind) && !ctx->opt.no_tiles && ((is_dna && !b->desc) || b->maxlen > tile_min || outlier);
     rc = tiled ? sketch_tiled(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms)

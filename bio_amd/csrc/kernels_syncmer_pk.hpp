@@ -235,10 +235,21 @@ struct SynPk {
             nk.set(kin, z);
         }
         u32 vb = 0;
+        // MODE 3: s-mers beyond the lane's own end (the lane runs on to the wave's longest read) take made-up keys that differ from
+        // each other wherever two of them can meet in a min operation -- offset and block parity in the key's low bits, ones above:
+        // they lose against every real s-mer and never tie.  What lies behind a read are the padding bases of its last word (code 0 = A)
+        // and the next read: twelve or more padding bases are two or more IDENTICAL poly-A s-mers, a key tie by construction -- the read
+        // went to the list for nothing.  Length-binned units keep the overrun below a class width; tiles and batches in batch order do
+        // not: 450-base reads cut into tiles of 333 + 226 bases (14 padding bases) listed every second tile, the list filled up and
+        // the call fell back to k_syncmer_fast after a wasted run (round 4, scripts/dev/perf_midlen.py).
+        int nvs = W;          // s-mers of this block the lane has
+        u32 badkey = 0;
         if (MODE == 3) {  // bit o: window idx0 + o exists for this lane
             const int left = (int)end_plus1 - (int)idx0;
             const u32 nv = (u32)(left < 0 ? 0 : left > W ? W : left);
             vb = nv >= 32u ? 0xffffffffu : (1u << nv) - 1u;
+            nvs = end_plus1 ? (int)end_plus1 + (2 * W - 1) - (int)i0 : W;  // (ns = end + 1 + 2W - 1; lanes without a read are never listed)
+            badkey = 0xfffff000u | (((i0 / (u32)W) & 1u) << 10);
         }
         // table rows: XC steps' worth (both tables) are requested one chunk ahead of their use -- a row requested where it is rolled in
         // exposes the LDS latency twice per step.  One step ahead is enough at twelve waves per CU, and the registers matter more:
@@ -282,6 +293,7 @@ struct SynPk {
             const u32 sh_ = sel(srev, srh, sfh);
             u32 pk;
             asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(pk) : "v"(sh_), "s"(0xffffffe0u), "n"(O));
+            if (MODE == 3) pk = nvs > O ? pk : (badkey | (u32)(O << 5) | (u32)O);
             if (O == 0) {
                 P = pk;
             } else {

@@ -106,6 +106,28 @@ def test_syncmer_long_packed_kernel(engine, oracle, k, s, lo, hi):
     b.close()
 
 
+def test_syncmer_mid_length_reads_run_as_tiles(engine, oracle):
+    """Reads beyond the packed syncmer kernels' reach (449+ bases) run as tiles of 224 + 3k + 16 bases on k_syncmer_pkl instead of on the
+    per-read 64-bit kernel (whose 28-tuple slabs overflow there): same tuples, every read against the closed form, every fourth
+    against the state machine."""
+    rng = random.Random(4490)
+    seqs = [rand_seq(rng, rng.choice((449, 450, 557, 558, 700, 1500, 3000))) for _ in range(500)]
+    seqs[3] = "AC" * 400
+    b = engine.batch(seqs)
+    res = engine.run(b, engine.params(L.SYNCMER, 31, s=11))
+    assert "over tiles" in res.plan()["kernel"] and "k_syncmer_pkl" in res.plan()["kernel"], res.plan()
+    for i, q in enumerate(seqs):
+        st, h, p = res.read(i)
+        eh, ep, es, fl = oracle.syncmer(q, 31, 11, False, closed=True)
+        assert (st & L.ST_CODE_MASK) == L.ST_OK and np.array_equal(h, eh), (i, len(q))
+        assert np.array_equal(p & L.POS_MASK, ep) and np.array_equal(p >> 31, es), (i, len(q))
+        if i % 4 == 0:
+            mh, mp, _, _ = oracle.syncmer(q, 31, 11)
+            assert np.array_equal(h, mh) and np.array_equal(p & L.POS_MASK, mp), (i, len(q))
+    res.close()
+    b.close()
+
+
 def test_syncmer_small_s_is_not_planned_on_the_packed_kernels(engine, oracle):
     """s = 7: equal s-mers inside one 2w window are the rule, every such read is the exact machine's -- the planner keeps such
     parameters off the packed kernels (their list would fill up and the call would fall back after a wasted run)."""
