@@ -1,6 +1,6 @@
 """GPU: the minimizer path off its headline point -- one JSON line per case.
 
-  uniform read lengths 100 / 150 / 151 / 200 / 250 / 300 / 350, a ragged batch (lengths uniform in 60..150: trimmed reads) with and
+  uniform read lengths 100 / 150 / 151 / 200 / 250 / 300 / 350 (and 150..350 through the syncmer kernels, k = 31 s = 11), a ragged batch (lengths uniform in 60..150: trimmed reads) with and
   without length-binned units, 2 % / 10 % of the reads ending in a 50-base poly-A tail.  k = 21, w = 11, ~3e9 bases per case,
   inputs and outputs resident in HBM, min / median of 5 launches (HIP events around the kernels, bsk_sketch_timed).
 usage: python scripts/robustness_sweep.py [bases] > profiles/r04/robustness.jsonl"""
@@ -52,6 +52,13 @@ for rl in (100, 150, 151, 200, 250, 300, 350):
         base = o["gbases_per_s"]
     b.close()
 
+ps = eng.params(L.SYNCMER, 31, s=11)
+for rl in (150, 200, 250, 300, 350):  # syncmers k = 31 s = 11 over the read length: k_syncmer_pk, then k_syncmer_pkl (round 4; k_syncmer_fast before)
+    n = int(BASES / rl)
+    b = eng.synth(L.ALPHA_DNA, n, rl, 0x5EED0003)
+    run("syncmers k=31 s=11, uniform %d bp" % rl, b, n * rl, p=ps)
+    b.close()
+
 n = int(BASES / 105 / 1.5)  # (host-generated: two thirds of the bases)
 data, offs = ragged(60, 150, n)
 b = eng.batch_from_arrays(data, offs)
@@ -60,7 +67,7 @@ os.environ["BSK_NO_BIN"] = "1"
 r2 = run("ragged 60..150 bp, units in batch order (BSK_NO_BIN)", b, int(offs[-1]))
 del os.environ["BSK_NO_BIN"]
 assert r1["checksum"] == r2["checksum"], "binned and unbinned digests differ"
-ps = eng.params(L.SYNCMER, 31, s=11)  # the same trimmed reads through the syncmer kernels (k = 31, s = 11)
+# the same trimmed reads through the syncmer kernels (k = 31, s = 11)
 s1 = run("syncmers k=31 s=11, ragged 60..150 bp, length-binned units", b, int(offs[-1]), p=ps)
 os.environ["BSK_NO_BIN"] = "1"
 s2 = run("syncmers k=31 s=11, ragged 60..150 bp, units in batch order (BSK_NO_BIN)", b, int(offs[-1]), p=ps)
