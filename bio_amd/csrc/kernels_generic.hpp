@@ -90,7 +90,11 @@ __device__ __forceinline__ void list_close(u32 *list, u32 seg, u32 cur, int lane
 
 __device__ __forceinline__ u64 desc_len(const KArgs &a, u64 d) { return d & (u64)a.len_mask; }
 // where the outputs of the read in slot r (descriptor d) go: r itself, or the read's own place in its chunk of 4096
+#ifdef BSK_BIN_NOSCATTER  // dev, timing only: what the scattered reference words / status bytes of a binned batch cost
+__device__ __forceinline__ u64 out_index(const KArgs &, u64 r, u64) { return r; }
+#else
 __device__ __forceinline__ u64 out_index(const KArgs &a, u64 r, u64 d) { return a.binned ? ((r & ~4095ULL) | ((d >> 12) & 4095ULL)) : r; }
+#endif
 
 // read handled by (unit, lane): the batch position, or the subset entry of a side launch (~0 = no read)
 __device__ __forceinline__ u64 read_index(const KArgs &a, u32 unit, int lane) {

@@ -7,7 +7,8 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 rng = np.random.default_rng(5)
 eng = S.Engine(0)
 p = eng.params(L.MINIMIZER, 21, w=11)
-for lo in (150, 140, 100, 60):
+lows = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (150, 140, 100, 60)
+for lo in lows:
     lens = rng.integers(lo, 151, n, dtype=np.uint64)
     offs = np.zeros(n + 1, np.uint64)
     np.cumsum(lens, out=offs[1:])
