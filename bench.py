@@ -476,6 +476,25 @@ def main():
                 out["roofline"]["power"] = power_probe(eng, batch, p, res, sum(kernel_ms) / len(kernel_ms), local_rank, n_reads * read_len)
             except Exception as e:
                 out["roofline"]["power"] = {"error": repr(e)}
+        if world == 1 and kernel_ms and not args.plumbing_only:
+            # what a device-side consumer of the tuples pays on top of the sketch: bsk_result_compact (offsets scanned, the units'
+            # slabs squeezed into dense CSR arrays left in HBM; sets.hip, k_gather_groups) -- outside `value`, reported beside it
+            try:
+                ts = []
+                for _ in range(4):
+                    t0 = time.perf_counter()
+                    _, _, _, nt = res.compact()
+                    ts.append((time.perf_counter() - t0) * 1e3)
+                c_ms = min(ts[1:])
+                per = 12 if kind not in STREAM else 8
+                moved = nt * 2 * per + n_reads * 24
+                out["dense_copy"] = {"what": "bsk_result_compact: dense CSR copy of the result left on the device (wall time of the call, incl. its two synchronisations; "
+                                             "first call, which allocates the arrays, not counted)",
+                                     "ms": round(c_ms, 3), "first_call_ms": round(ts[0], 3), "tuples": int(nt), "bytes_moved": int(moved),
+                                     "GB_per_s": round(moved / c_ms / 1e6, 1),
+                                     "sketch_plus_dense_copy": round(n_reads * read_len / ((sum(kernel_ms) / len(kernel_ms)) + c_ms) / 1e6, 2), "unit": out["unit"]}
+            except Exception as e:
+                out["dense_copy"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline and not args.plumbing_only:
             out["cpu_baseline"] = cpu_baseline(kind, k, x, read_len, batch)
         if world == 1 and not args.no_end_to_end and not args.plumbing_only:

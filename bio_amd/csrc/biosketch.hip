@@ -425,6 +425,7 @@ void BskOpts::load() {
     syn_margin = (int)env_u32("BSK_SYN_MARGIN", 2 + 64) - 64;  // dev: rows of slack the planner wants in k_syncmer_pk's columns (BSK_SYN_MARGIN = 64 + margin)
     no_tiles = on("BSK_NO_TILES");
     no_tile_cache = on("BSK_NO_TILE_CACHE");
+    no_group_gather = on("BSK_NO_GROUP_GATHER");  // dev: bsk_result_compact / _fetch_narrow with one (part of a) wavefront per sequence, as before round 4
     timing = on("BSK_TIMING");
     no_fused_translate = on("BSK_NO_FUSED_TRANSLATE");
     sets_no_small = on("BSK_SETS_NO_SMALL");

@@ -3,6 +3,8 @@
 // downstream consumers of the reference's sketches keep on disk (kmcp / unikmer: sorted unique uint64 lists):
 // collecting Next() values into a slice, sort, de-duplicate.  Done on the device with rocPRIM (segmented radix sort,
 // scan) so that only the final sets cross PCIe.
+#include <chrono>
+#include <cstdio>
 #include <hip/hip_runtime.h>
 #include <string.h>
 
@@ -374,6 +376,129 @@ __global__ void k_compact(const u64 *hash, const u32 *pos, const u64 *refs, cons
         }
     }
 }
+
+// The same copy for results with packed reference words (every batch of reads): one wavefront per GROUP of 64 consecutive sequences.
+// The group's output range [dstoff[g*64], dstoff[g*64+64)) is contiguous, so the lanes take its elements in order -- whole lines of
+// coalesced stores, whatever the sequences' counts -- and find each element's sequence by a six-step search over the lanes' own
+// offsets (ds_bpermute: no LDS allocation, no table to build); two rows of 64 elements per trip, so that four loads are in flight.
+// (One wavefront per sequence kept 22 of 64 lanes busy on 150-base reads and ran at 1.9 TB/s: a dense copy cost 2.4 sketches.)
+// NARROW: bsk_result_fetch_narrow's outputs (u16 positions, u32 offsets, the 15-bit check).
+// ROWS (results of k_minimizer_ring, launched with one wavefront per workgroup): a group whose sequences are stored as unit rows
+// (element t of a sequence 64 tuples after element t - 1) is read ROW BY ROW -- the lanes are the sequences, one coalesced load per
+// row -- into a 32 KB LDS image of the group's output range, which then leaves in order; hashes first, positions through the same
+// image.  (Elements in output order are 512 bytes apart in such a slab: 64 lines per load instruction, 1.6 TB/s.)  Groups of more than
+// 4 096 tuples take the search below.
+#define BSK_GATHER_LCAP 4096
+template <bool NARROW, bool ROWS = false>
+__global__ __launch_bounds__(256) void k_gather_groups(const u64 *hash, const u32 *pos, const u64 *refs, const u64 *dstoff, u64 n, u64 *ohash,
+                                                       void *opos_, u32 *ooff, u32 *flag) {
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const u64 ngroups = (n + 64) / 64;  // (NARROW: entry n of the offsets is written by the group that holds slot n)
+    u32 wide = 0;
+    for (u64 g = wave; g < ngroups; g += nw) {
+        const u64 r = g * 64 + lane;
+        const u64 d = dstoff[r < n ? r : n];
+        u64 src = 0;
+        u32 cnt = 0;
+        if (r < n) {
+            const u64 ref = refs[r];
+            cnt = (u32)BSK_REF_COUNT(ref);
+            src = BSK_REF_FIRST(ref) | (BSK_REF_STRIDE(ref) > 1 ? 1ULL << 63 : 0);
+        }
+        if (NARROW && r <= n) ooff[r] = (u32)d;
+        const u64 d0 = wave_bcast_u64(d, 0);
+        const u32 dl = (u32)(d - d0);  // < 2^30: 64 sequences of < 2^24 tuples
+        const u32 T = (u32)__builtin_amdgcn_readlane((int)(dl + cnt), 63);
+        const u32 slo = (u32)src, shi = (u32)(src >> 32);
+        if (ROWS && T <= BSK_GATHER_LCAP) {
+            // (a listed read of such a unit lies elsewhere with stride 1 -- at 250 bases every second group holds one: the stride is
+            // the lane's own, only the group's size sends it to the search below)
+            constexpr int GU = 32;  // rows requested together
+            __shared__ u64 image[ROWS ? BSK_GATHER_LCAP : 1];
+            const u64 base = src & ~(1ULL << 63), step = (src >> 63) ? 64 : 1;
+            const u32 maxc = wave_max_u32(cnt);
+            for (u32 t0 = 0; t0 < maxc; t0 += GU) {
+                u64 v[GU];
+#pragma unroll
+                for (int i = 0; i < GU; ++i) v[i] = t0 + i < cnt ? hash[base + (u64)(t0 + i) * step] : 0;
+#pragma unroll
+                for (int i = 0; i < GU; ++i)
+                    if (t0 + i < cnt) image[dl + t0 + i] = v[i];
+            }
+            wave_sync_lds();
+            for (u32 j = (u32)lane; j < T; j += 64) ohash[d0 + j] = image[j];
+            if (pos) {
+                wave_sync_lds();
+                u32 *image32 = reinterpret_cast<u32 *>(image);
+                for (u32 t0 = 0; t0 < maxc; t0 += GU) {
+                    u32 v[GU];
+#pragma unroll
+                    for (int i = 0; i < GU; ++i) v[i] = t0 + i < cnt ? pos[base + (u64)(t0 + i) * step] : 0;
+#pragma unroll
+                    for (int i = 0; i < GU; ++i)
+                        if (t0 + i < cnt) image32[dl + t0 + i] = v[i];
+                }
+                wave_sync_lds();
+                for (u32 j = (u32)lane; j < T; j += 64) {
+                    const u32 q = image32[j];
+                    if (NARROW) {
+                        wide |= q & 0x7fff8000u;
+                        reinterpret_cast<u16 *>(opos_)[d0 + j] = (u16)((q & 0x7fffu) | ((q >> 16) & 0x8000u));
+                    } else {
+                        reinterpret_cast<u32 *>(opos_)[d0 + j] = q;
+                    }
+                }
+            }
+            wave_sync_lds();
+            continue;
+        }
+        for (u32 j0 = 0; j0 < T; j0 += 128) {
+            u32 j[2], own[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                j[q] = j0 + 64 * q + (u32)lane;
+                own[q] = 0;  // the largest lane whose offset is <= j (sequences without tuples share their successor's offset)
+            }
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const u32 probe = own[q] + (u32)s;
+                    const u32 v = (u32)__builtin_amdgcn_ds_bpermute((int)(probe << 2), (int)dl);
+                    own[q] = v <= j[q] ? probe : own[q];
+                }
+            }
+            u64 hv[2];
+            u32 pv[2];
+            bool ok[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int a = (int)(own[q] << 2);
+                const u32 t = j[q] - (u32)__builtin_amdgcn_ds_bpermute(a, (int)dl);
+                const u32 b0 = (u32)__builtin_amdgcn_ds_bpermute(a, (int)slo), b1 = (u32)__builtin_amdgcn_ds_bpermute(a, (int)shi);
+                const u64 at = (((u64)(b1 & 0x7fffffffu) << 32) | b0) + ((b1 >> 31) ? (u64)t * 64 : (u64)t);
+                ok[q] = j[q] < T;
+                hv[q] = ok[q] ? hash[at] : 0;
+                pv[q] = (ok[q] && pos) ? pos[at] : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                if (!ok[q]) continue;
+                ohash[d0 + j[q]] = hv[q];
+                if (pos) {
+                    if (NARROW) {
+                        wide |= pv[q] & 0x7fff8000u;
+                        reinterpret_cast<u16 *>(opos_)[d0 + j[q]] = (u16)((pv[q] & 0x7fffu) | ((pv[q] >> 16) & 0x8000u));
+                    } else {
+                        reinterpret_cast<u32 *>(opos_)[d0 + j[q]] = pv[q];
+                    }
+                }
+            }
+        }
+    }
+    if (NARROW && wide) atomicOr(flag, 1u);
+}
 }  // namespace
 
 extern "C" int bsk_result_compact(bsk_ctx *ctx, const bsk_result *r, const uint64_t **offsets, const uint64_t **hash, const uint32_t **pos,
@@ -398,6 +523,11 @@ extern "C" int bsk_result_compact(bsk_ctx *ctx, const bsk_result *r, const uint6
     };
     u64 *offs = nullptr, *part = nullptr, *oh = nullptr;
     u32 *op = nullptr;
+    const bool timing = ctx->opt.timing;  // dev: wall time of the phases, to stderr
+    const auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (timing) fprintf(stderr, "bsk_result_compact: %-18s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    };
     HIPCHK(ctx, pool(16, (n + 2) * 8, (void **)&offs));
     HIPCHK(ctx, pool(17, ((n + SCAN_CHUNK - 1) / SCAN_CHUNK + 2) * 8, (void **)&part));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, 16, st));
@@ -405,14 +535,24 @@ extern "C" int bsk_result_compact(bsk_ctx *ctx, const bsk_result *r, const uint6
     u64 T = 0;
     HIPCHK(ctx, hipMemcpyAsync(&T, ctx->d_total + 1, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    lap("offsets scanned");
     HIPCHK(ctx, pool(18, (T + 1) * 8, (void **)&oh));
     if (r->pos) HIPCHK(ctx, pool(19, (T + 1) * 4, (void **)&op));
+    lap("arrays");
     if (T) {
-        hipLaunchKernelGGL(k_compact, dim3(grid_of(ctx, n * 64, 256)), dim3(256), 0, st, r->hash, r->pos, r->refs, r->wfirst, r->wcount, offs, n, oh,
-                           r->pos ? op : nullptr);
+        if (r->refs && !ctx->opt.no_group_gather && strstr(r->plan, "k_minimizer_ring"))  // unit rows
+            hipLaunchKernelGGL((k_gather_groups<false, true>), dim3(grid_of(ctx, n + 64, 1)), dim3(64), 0, st, r->hash, r->pos, r->refs, offs, n, oh, (void *)op,
+                               (u32 *)nullptr, (u32 *)nullptr);
+        else if (r->refs && !ctx->opt.no_group_gather)
+            hipLaunchKernelGGL((k_gather_groups<false, false>), dim3(grid_of(ctx, n + 64, 256)), dim3(256), 0, st, r->hash, r->pos, r->refs, offs, n, oh, (void *)op,
+                               (u32 *)nullptr, (u32 *)nullptr);
+        else
+            hipLaunchKernelGGL(k_compact, dim3(grid_of(ctx, n * 64, 256)), dim3(256), 0, st, r->hash, r->pos, r->refs, r->wfirst, r->wcount, offs, n, oh,
+                               r->pos ? op : nullptr);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(st));
     }
+    lap("tuples gathered");
     *offsets = (const uint64_t *)offs;
     *hash = (const uint64_t *)oh;
     if (pos) *pos = r->pos ? op : nullptr;
@@ -489,9 +629,16 @@ extern "C" int bsk_result_fetch_narrow(bsk_ctx *ctx, const bsk_result *r, uint64
     if (T >= (1ULL << 32)) return fail_arg(ctx, "bsk_result_fetch_narrow: 2^32 tuples or more (fetch a smaller range)");
     HIPCHK(ctx, pool(13, (T + 1) * 8, (void **)&oh));
     if (pos) HIPCHK(ctx, pool(14, (T + 1) * 2, (void **)&op));
-    hipLaunchKernelGGL(k_gather_narrow, dim3(grid_of(ctx, (count + 1) * 16, 256)), dim3(256), 0, st, r->hash, pos ? r->pos : nullptr,
-                       r->refs ? r->refs + first : nullptr, r->refs ? nullptr : r->wfirst + first, r->refs ? nullptr : r->wcount + first, offs, count, oh, op, oo,
-                       reinterpret_cast<u32 *>(ctx->d_total + 3));
+    if (r->refs && !ctx->opt.no_group_gather && strstr(r->plan, "k_minimizer_ring"))  // unit rows
+        hipLaunchKernelGGL((k_gather_groups<true, true>), dim3(grid_of(ctx, count + 64, 1)), dim3(64), 0, st, r->hash, pos ? r->pos : nullptr, r->refs + first, offs,
+                           count, oh, (void *)op, oo, reinterpret_cast<u32 *>(ctx->d_total + 3));
+    else if (r->refs && !ctx->opt.no_group_gather)
+        hipLaunchKernelGGL((k_gather_groups<true, false>), dim3(grid_of(ctx, count + 64, 256)), dim3(256), 0, st, r->hash, pos ? r->pos : nullptr, r->refs + first, offs,
+                           count, oh, (void *)op, oo, reinterpret_cast<u32 *>(ctx->d_total + 3));
+    else
+        hipLaunchKernelGGL(k_gather_narrow, dim3(grid_of(ctx, (count + 1) * 16, 256)), dim3(256), 0, st, r->hash, pos ? r->pos : nullptr,
+                           r->refs ? r->refs + first : nullptr, r->refs ? nullptr : r->wfirst + first, r->refs ? nullptr : r->wcount + first, offs, count, oh, op, oo,
+                           reinterpret_cast<u32 *>(ctx->d_total + 3));
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(offsets, oo, (count + 1) * 4, hipMemcpyDeviceToHost, st));
     if (status && count) HIPCHK(ctx, hipMemcpyAsync(status, r->status + first, count, hipMemcpyDeviceToHost, st));

@@ -144,3 +144,54 @@ def test_compact_device_copy_equals_fetch(engine, kind):
         assert pp is None
     else:
         assert np.array_equal(d2h(pp, nt, np.uint32), pos)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lens,plan", [((200, 250, 330), "k_minimizer_ring"), ((150,), "k_minimizer_pk"), ((60, 100, 150), "k_minimizer_pk"), ((40, 900, 2500), "minimizer")])
+def test_group_gather_layouts_and_mixed_groups(engine, lens, plan):
+    """bsk_result_compact / bsk_result_fetch_narrow gather by GROUPS of 64 sequences (k_gather_groups: offsets searched with ds_bpermute,
+    unit rows through an LDS image): against bsk_result_fetch's own wavefront-per-sequence gather on slab, unit-row and per-read-slab
+    results, with listed reads (poly-A: stride 1 inside a unit of rows), sequences without tuples, a last group that is not full,
+    ranges that do not start on a group boundary -- and against the per-sequence kernels they replaced (BSK_NO_GROUP_GATHER)."""
+    import ctypes as C
+    rng = random.Random(len(lens) * 1000 + lens[0])
+    n = 64 * 37 + 29
+    seqs = ["".join(rng.choice("ACGT") for _ in range(rng.choice(lens))) for _ in range(n)]
+    for i in range(5, n, 97):
+        seqs[i] = "A" * len(seqs[i])          # listed: the exact machine writes it elsewhere, stride 1
+    for i in range(11, n, 131):
+        seqs[i] = seqs[i][:17]                # too short: no tuples
+    seqs[64], seqs[65], seqs[127] = "", "ACGT", ""
+    b = engine.batch(seqs)
+    res = engine.run(b, engine.params(L.MINIMIZER, 21, w=11))
+    assert plan in res.plan()["kernel"], res.plan()
+    offs, st, h, pos = res.fetch()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def d2h(ptr, m, dt):
+        a = np.empty(m, dt)
+        if m:
+            assert hip.hipMemcpy(a.ctypes.data, ptr, a.nbytes, 2) == 0
+        return a
+
+    def check():
+        po, ph, pp, nt = res.compact()
+        assert nt == len(h)
+        assert np.array_equal(d2h(po, n + 1, np.uint64), offs) and np.array_equal(d2h(ph, nt, np.uint64), h) and np.array_equal(d2h(pp, nt, np.uint32), pos)
+        for first, count in ((0, None), (1, 63), (63, 130), (64 * 20 + 7, 64 * 9 + 1), (n - 1, 1), (n - 30, 30), (9, 0)):
+            o, s1, hh, p = res.fetch(first, count)
+            o2, s2, h2, p2 = res.fetch_narrow(first, count)
+            assert np.array_equal(o, o2.astype(np.uint64)) and np.array_equal(s1, s2) and np.array_equal(hh, h2), (first, count)
+            assert np.array_equal(p & L.POS_MASK, (p2 & 0x7FFF).astype(np.uint32)) and np.array_equal(p >> 31, (p2 >> 15).astype(np.uint32)), (first, count)
+
+    check()
+    os.environ["BSK_NO_GROUP_GATHER"] = "1"
+    try:
+        engine.reload_options()
+        check()
+    finally:
+        del os.environ["BSK_NO_GROUP_GATHER"]
+        engine.reload_options()
+    res.close()
+    b.close()
