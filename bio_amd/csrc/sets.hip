@@ -353,6 +353,51 @@ __global__ void k_move_seqs(const u64 *tmp, const u64 *in_off, const u64 *out_of
         for (u64 i = gl; i < t; i += 32) out[d0 + i] = tmp[s0 + i];
     }
 }
+// the same placement by GROUPS of 64 sequences (see k_gather_groups below): the group's output range is contiguous, the lanes take
+// its elements in order and find each element's sequence by a six-step search over the lanes' output offsets (ds_bpermute)
+__global__ __launch_bounds__(256) void k_move_groups(const u64 *tmp, const u64 *in_off, const u64 *out_off, const u64 *ucount, u64 n, u64 *out) {
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((u64)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const u64 ngroups = (n + 63) / 64;
+    for (u64 g = wave; g < ngroups; g += nw) {
+        const u64 r = g * 64 + lane;
+        const u64 d = out_off[r < n ? r : n];
+        const u64 src = r < n ? in_off[r] : 0;
+        const u32 cnt = r < n ? (u32)ucount[r] : 0u;
+        const u64 d0 = wave_bcast_u64(d, 0);
+        const u32 dl = (u32)(d - d0);
+        const u32 T = (u32)__builtin_amdgcn_readlane((int)(dl + cnt), 63);
+        const u32 slo = (u32)src, shi = (u32)(src >> 32);
+        for (u32 j0 = 0; j0 < T; j0 += 128) {
+            u32 j[2], own[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                j[q] = j0 + 64 * q + (u32)lane;
+                own[q] = 0;
+            }
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const u32 probe = own[q] + (u32)s;
+                    const u32 v = (u32)__builtin_amdgcn_ds_bpermute((int)(probe << 2), (int)dl);
+                    own[q] = v <= j[q] ? probe : own[q];
+                }
+            }
+            u64 hv[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int a = (int)(own[q] << 2);
+                const u32 t = j[q] - (u32)__builtin_amdgcn_ds_bpermute(a, (int)dl);
+                const u32 b0 = (u32)__builtin_amdgcn_ds_bpermute(a, (int)slo), b1 = (u32)__builtin_amdgcn_ds_bpermute(a, (int)shi);
+                hv[q] = j[q] < T ? tmp[(((u64)b1 << 32) | b0) + t] : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (j[q] < T) out[d0 + j[q]] = hv[q];
+        }
+    }
+}
 int grid_of(bsk_ctx *ctx, u64 items, int block) {
     const u64 g = (items + block - 1) / block;
     return (int)std::max<u64>(1, std::min<u64>(g, (u64)ctx->cus * 16));
@@ -736,8 +781,12 @@ extern "C" int bsk_result_sets(bsk_ctx *ctx, const bsk_result *r, int scope, int
         hipLaunchKernelGGL(k_sets_rows, dim3(sgrid), dim3(256), 0, st, r->hash, r->refs, r->wfirst, r->wcount, offs, n, maxhash, dense, ucount);
         SCHK(hipGetLastError());
         SCHK(scan_counts(st, ArrayOf{ucount}, n, part, res->offsets, ctx->d_total + 1, (u64 *)nullptr));
-        hipLaunchKernelGGL(k_move_seqs, dim3((unsigned)std::max<u64>(1, std::min<u64>((n + 7) / 8, (u64)ctx->cus * 32))), dim3(256), 0, st, dense, offs, res->offsets,
-                           ucount, n, res->values);
+        if (!ctx->opt.no_group_gather)
+            hipLaunchKernelGGL(k_move_groups, dim3((unsigned)std::max<u64>(1, std::min<u64>((n + 255) / 256, (u64)ctx->cus * 16))), dim3(256), 0, st, dense, offs,
+                               res->offsets, ucount, n, res->values);
+        else
+            hipLaunchKernelGGL(k_move_seqs, dim3((unsigned)std::max<u64>(1, std::min<u64>((n + 7) / 8, (u64)ctx->cus * 32))), dim3(256), 0, st, dense, offs, res->offsets,
+                               ucount, n, res->values);
         SCHK(hipGetLastError());
         u64 M = 0;
         SCHK(hipMemcpyAsync(&M, ctx->d_total + 1, 8, hipMemcpyDeviceToHost, st));
