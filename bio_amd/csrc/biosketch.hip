@@ -141,18 +141,39 @@ __global__ void k_extend_ascii(const u8 *ascii, const u64 *aoff, const u64 *naof
     }
 }
 
-// digest: checksum = sum over tuples of hash*(2*position+1); one thread per read walks its tuples
+// digest: checksum = sum over tuples of hash*(2*position+1) -- a sum, so any traversal will do.  A wavefront takes 64 reads: when they
+// are stored as unit rows a lane walks its own read (row t of the unit is one coalesced load); otherwise (slabs, per-read runs: a
+// lane's tuples are contiguous and the lanes' runs 256 bytes or more apart -- 64 lines per load, 50 ms for configs[2]'s result) the
+// reads are taken four at a time by 16 lanes each, whole 128-byte pieces of a run per load.
 __global__ void k_digest(const u64 *hash, const u32 *pos, const u64 *refs, const u64 *wfirst, const u64 *wcount, u64 n,
                          u64 *out /*[0] checksum [1] tuples*/) {
     u64 s = 0, c = 0;
-    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) {
-        const u64 b = refs ? BSK_REF_FIRST(refs[r]) : wfirst[r], cnt = refs ? BSK_REF_COUNT(refs[r]) : wcount[r], st = refs ? BSK_REF_STRIDE(refs[r]) : 1;
-        for (u64 t = 0; t < cnt; ++t) s += hash[b + t * st] * (2ULL * (pos ? (u64)(pos[b + t * st] & BSK_POS_MASK) : t) + 1ULL);
+    const int lane = threadIdx.x & 63;
+    const u64 nblk = (n + 63) / 64;
+    for (u64 blk = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; blk < nblk; blk += ((u64)gridDim.x * blockDim.x) >> 6) {
+        const u64 r = blk * 64 + lane;
+        u64 b = 0, cnt = 0, st = 1;
+        if (r < n) {
+            b = refs ? BSK_REF_FIRST(refs[r]) : wfirst[r];
+            cnt = refs ? BSK_REF_COUNT(refs[r]) : wcount[r];
+            st = refs ? BSK_REF_STRIDE(refs[r]) : 1;
+        }
         c += cnt;
+        if (st != 1)  // unit rows (a listed read of such a unit lies elsewhere with stride 1 and is taken below)
+            for (u64 t = 0; t < cnt; ++t) s += hash[b + t * st] * (2ULL * (pos ? (u64)(pos[b + t * st] & BSK_POS_MASK) : t) + 1ULL);
+        if (__builtin_amdgcn_ballot_w64(cnt > 0 && st == 1) == 0) continue;
+        if (st != 1) cnt = 0;
+        for (int i = 0; i < 16; ++i) {
+            const int a = (i * 4 + (lane >> 4)) << 2;
+            const u64 bq = ((u64)(u32)__builtin_amdgcn_ds_bpermute(a, (int)(u32)(b >> 32)) << 32) | (u32)__builtin_amdgcn_ds_bpermute(a, (int)(u32)b);
+            const u64 cq = ((u64)(u32)__builtin_amdgcn_ds_bpermute(a, (int)(u32)(cnt >> 32)) << 32) | (u32)__builtin_amdgcn_ds_bpermute(a, (int)(u32)cnt);
+            const u64 sq = (u32)__builtin_amdgcn_ds_bpermute(a, (int)(u32)st);
+            for (u64 t = (u64)(lane & 15); t < cq; t += 16) s += hash[bq + t * sq] * (2ULL * (pos ? (u64)(pos[bq + t * sq] & BSK_POS_MASK) : t) + 1ULL);
+        }
     }
     s = wave_sum_u64(s);
     c = wave_sum_u64(c);
-    if ((threadIdx.x & 63) == 0) {
+    if (lane == 0) {
         atomicAdd(&out[0], s);
         atomicAdd(&out[1], c);
     }
@@ -972,7 +993,7 @@ extern "C" int bsk_result_digest(bsk_ctx *ctx, const bsk_result *r, uint64_t *ch
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, 8 * sizeof(u64), ctx->stream));
     if (r->n) {
-        hipLaunchKernelGGL(k_digest, dim3(grid_for(ctx, r->n, 256)), dim3(256), 0, ctx->stream, r->hash, r->pos, r->refs, r->wfirst,
+        hipLaunchKernelGGL(k_digest, dim3(grid_for(ctx, r->n * 8, 256)), dim3(256), 0, ctx->stream, r->hash, r->pos, r->refs, r->wfirst,
                            r->wcount, r->n, ctx->d_total);
         hipLaunchKernelGGL(k_digest_status, dim3(grid_for(ctx, r->n, 256)), dim3(256), 0, ctx->stream, r->status, r->n,
                            ctx->d_total + 2);
