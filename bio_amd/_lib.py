@@ -38,6 +38,26 @@ class PipelineStats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class PipelineConfig(C.Structure):
+    """bsk_pipeline_config (include/biosketch.h)"""
+    _fields_ = [("devices", C.POINTER(C.c_int)), ("n_devices", C.c_int32), ("n_streams", C.c_int32), ("chunk_records", C.c_uint64),
+                ("sink", C.c_int32), ("sets_scale", C.c_int32), ("alphabet", C.c_int32), ("host_checksum", C.c_int32),
+                ("n_readers", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Chunk(C.Structure):
+    """bsk_chunk (include/biosketch.h): one delivered chunk; the arrays are pinned host memory of the pipeline until release"""
+    _fields_ = [("sequence", C.c_uint64), ("source_index", C.c_int32), ("device", C.c_int32), ("first_record", C.c_uint64),
+                ("n_records", C.c_uint64), ("n_bases", C.c_uint64), ("n_tuples", C.c_uint64), ("n_values", C.c_uint64),
+                ("checksum", C.c_uint64), ("link_bytes", C.c_uint64), ("sink", C.c_int32), ("has_pos", C.c_int32),
+                ("offsets32", C.c_void_p), ("offsets64", C.c_void_p), ("status", C.c_void_p), ("hash", C.c_void_p),
+                ("pos16", C.c_void_p), ("pos32", C.c_void_p), ("opaque", C.c_void_p)]
+
+
+SINK_COUNTS, SINK_TUPLES, SINK_SETS = 0, 1, 2
+CHUNK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(Chunk))
+
+
 class Params(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("kind", "k", "w", "s", "m", "scale", "canonical", "circular", "codon_table", "frame")]
@@ -89,6 +109,16 @@ SYMBOLS = [
     ("bsk_pipeline_fastx_multi", C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int, _vp, C.c_int, C.c_uint64, C.c_int, _vp]),
     ("bsk_pipeline_memory_multi", C.c_int, [_vp, C.c_int, _vp, _vp, C.c_uint64, C.c_int, _vp, C.c_int, C.c_uint64, C.c_int, C.c_int, _vp]),
     ("bsk_pipeline_trim", None, []),
+    ("bsk_pipeline_open_fastx", C.c_int, [C.POINTER(PipelineConfig), C.POINTER(C.c_char_p), C.c_int, C.POINTER(Params), _pp]),
+    ("bsk_pipeline_open_memory", C.c_int, [C.POINTER(PipelineConfig), _vp, _vp, C.c_uint64, C.c_int, C.POINTER(Params), _pp]),
+    ("bsk_pipeline_next", C.c_int, [_vp, C.POINTER(C.POINTER(Chunk))]),
+    ("bsk_pipeline_release", C.c_int, [_vp, C.POINTER(Chunk)]),
+    ("bsk_pipeline_close", C.c_int, [_vp, _vp]),
+    ("bsk_pipeline_error", C.c_char_p, [_vp]),
+    ("bsk_pipeline_run", C.c_int, [_vp, CHUNK_FN, _vp, _vp]),
+    ("bsk_result_fetch_status", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp]),
+    ("bsk_result_sets_reuse", C.c_int, [_vp, _vp, C.c_int, C.c_int, _pp]),
+    ("bsk_sets_fetch_narrow", C.c_int, [_vp, _vp, _vp, _vp, C.c_uint64]),
     ("bsk_comm_unique_id", C.c_int, [_vp]),
     ("bsk_comm_init_rank", C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     ("bsk_comm_init_all", C.c_int, [_pp, C.c_int]),

@@ -425,11 +425,21 @@ extern "C" void bsk_batch_destroy(bsk_batch *b) {
     delete b;
 }
 
-static u64 pad_words(u32 maxlen) { return (u64)maxlen / 16 + 17; }  // slack behind the packed words: k_minimizer_pk loads 16 words from every read's first (also a zero-length last read's); DnaResidues::issue4 reaches maxlen/16 + 10
+// Slack behind the packed words.  Every prefetching kernel loads a fixed number of words from every read's FIRST word -- also the last
+// read's, a zero-length read's and a tile's that aliases the end of words[]: k_minimizer_pk / k_minimizer_ring / k_syncmer_pk 16 words,
+// k_syncmer_pkl BSK_SYNPKL_NW = 32 (register path, no LDS-DMA), DnaResidues::issue4 maxlen/16 + 10.  The pad is the WIDEST prefetch + 1,
+// whatever the batch's longest read (the long syncmer plan is reachable with a small maxlen: k-s = 21..24, dense selections).
+static constexpr u64 kMaxPrefetchWords = 32;  // >= SynPkLdsL::NW (static_assert beside pk_syncmer_max_bases, kernels_syncmer_pk.hpp)
+// The smallest read length any kind tiles from (sketch_impl's tile_min: syncmers on the long packed plan from 448 bases, stream kinds from
+// 16 (BSK_NT_FAST_WORDS - 2) = 512): batch creation keeps the non-ACGT word bits of every batch that MAY be tiled.
+static constexpr u32 kSynTileMin = 448;
+static u32 min_tile_min(const bsk_ctx *ctx);
+static u64 pad_words(u32 maxlen) { return (u64)maxlen / 16 + kMaxPrefetchWords + 1; }
 static u32 env_u32(const char *name, u32 dflt) {
     const char *v = getenv(name);
     return v && *v ? (u32)strtoul(v, nullptr, 10) : dflt;
 }
+static u32 min_tile_min(const bsk_ctx *ctx) { return ctx->opt.tile_min ? ctx->opt.tile_min : std::min<u32>(kSynTileMin, 16u * (BSK_NT_FAST_WORDS - 2)); }
 void BskOpts::load() {
     auto on = [](const char *n) { return getenv(n) != nullptr; };
     force_generic = on("BSK_FORCE_GENERIC");
@@ -591,7 +601,7 @@ static int batch_from_ascii_impl(bsk_ctx *ctx, const uint8_t *bytes, const uint6
         BCHK(hipMemsetAsync(b->rflags, 0, n ? n : 1, ctx->stream));
         if (n) BCHK(hipMemcpyAsync(wide ? b->fw : b->desc, desc, n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
         BCHK(hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream));
-        if (maxlen > (ctx->opt.tile_min ? ctx->opt.tile_min : 16u * (BSK_NT_FAST_WORDS - 2)) && w) {  // this batch may be tiled: remember which words hold non-ACGT letters
+        if (maxlen > min_tile_min(ctx) && w) {  // this batch may be tiled: remember which words hold non-ACGT letters
             BCHK(hipMalloc(&b->wbits, ((w + 31) / 32) * sizeof(u32)));
             BCHK(hipMemsetAsync(b->wbits, 0, ((w + 31) / 32) * sizeof(u32), ctx->stream));
         }
@@ -925,6 +935,18 @@ extern "C" int bsk_result_device_wide(const bsk_result *r, const uint64_t **firs
     return BSK_OK;
 }
 
+// the status bytes alone (a consumer of sketch SETS still needs every read's SHORT / ILLEGAL / tie flags)
+extern "C" int bsk_result_fetch_status(bsk_ctx *ctx, const bsk_result *r, uint64_t first, uint64_t count, uint8_t *status) {
+    if (!ctx || !r || !status) return fail_arg(ctx, "bsk_result_fetch_status: null argument");
+    if (first + count > r->n) return fail_arg(ctx, "bsk_result_fetch_status: range outside result");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (count) {
+        HIPCHK(ctx, hipMemcpyAsync(status, r->status + first, count, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return BSK_OK;
+}
+
 extern "C" int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t first, uint64_t count, uint64_t *offsets,
                                 uint8_t *status, uint64_t *hash, uint32_t *pos, uint64_t tuple_cap) {
     if (!ctx || !r || !offsets) return fail_arg(ctx, "bsk_result_fetch: null argument");
@@ -1126,6 +1148,24 @@ struct Plan {
     u32 side_nunits = 0, side_ring_w = 0;
     int side_grid = 1;
 };
+
+static_assert(sizeof(Plan) <= sizeof(((bsk_result *)nullptr)->plan_blob) && std::is_trivially_copyable<Plan>::value, "bsk_result::plan_blob holds a Plan");
+static void plan_record(bsk_result *res, const bsk_batch *b, const bsk_params *p, int circ_ext, const Plan &pl) {
+    memcpy(res->plan_blob, &pl, sizeof pl);
+    res->plan_params = *p;
+    res->plan_n = b->n;
+    res->plan_bases = b->n_bases;
+    res->plan_maxlen = b->maxlen;
+    res->plan_circ = circ_ext;
+    res->plan_valid = true;
+}
+static bool plan_recall(const bsk_result *res, const bsk_batch *b, const bsk_params *p, int circ_ext, Plan &pl) {
+    if (!res->plan_valid || res->plan_n != b->n || res->plan_bases != b->n_bases || res->plan_maxlen != b->maxlen || res->plan_circ != circ_ext ||
+        memcmp(&res->plan_params, p, sizeof *p) != 0)
+        return false;
+    memcpy(&pl, res->plan_blob, sizeof pl);
+    return true;
+}
 
 // per-read slabs are sized by the LONGEST read: acceptable only while that does not blow the result arrays up (a batch of
 // short reads with one long outlier would otherwise reserve the outlier's slab for every read)
@@ -1809,6 +1849,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     }
     if (ev1) HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
     HIPCHK(ctx, hipGetLastError());
+    res->unit_rows = pl.which == K_MIN_RING;  // what actually ran last (sets.hip picks its gather's shape on it, not on the plan string)
     return BSK_OK;
 }
 
@@ -1877,8 +1918,13 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
     } else if (*result && !pl.mixed && (*result)->cap > cap) {
         cap = (*result)->cap;
     }
-    // bsk_sketch always runs (and sizes) once; bsk_sketch_timed on an existing result only repeats the launch
+    // bsk_sketch always runs (and sizes) once; bsk_sketch_timed on an existing result only repeats the launch -- of the plan the result
+    // was sized for, on the batch it was sized for (anything else could write past `cap`)
     const bool sizing = *result == nullptr || warmup + iters == 0;
+    if (!sizing && !plan_recall(*result, b, p, circ_ext, pl)) {
+        ctx->err = "bsk_sketch_timed: the result was not sized for this batch and these parameters: call bsk_sketch first";
+        return cleanup(BSK_ERR_ARG);
+    }
     for (int attempt = 0; sizing && attempt < 3; ++attempt) {
         rc = result_prepare(ctx, result, b->n, p->kind, cap + side_cap);
         if (rc == BSK_ERR_NOMEM && (pl.which == K_MIN_DENSE || pl.which == K_MIN_SEG || pl.which == K_MIN_WPR || pl.which == K_PROT_MIN_FAST) && attempt < 2) {
@@ -1933,6 +1979,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         }
         cap = pl.slab ? pl.slab_total + ovf_used + ovf_used / 4 + 65536 : total + 64;  // size known now: re-run once
     }
+    if (sizing && *result) plan_record(*result, b, p, circ_ext, pl);
     if (sizing && (pl.mixed || pl.slab || pl.which == K_NT_FAST || pl.which == K_PROT_HASH_FAST || pl.which == K_SIM_FAST) && b->n) {  // slab / line-padded kernels: sum the per-read counts once
         HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, sizeof(u64), ctx->stream));
         hipLaunchKernelGGL(k_sum_counts, dim3(grid_for(ctx, b->n, 256)), dim3(256), 0, ctx->stream, (*result)->refs, b->n, ctx->d_total);
@@ -2281,9 +2328,15 @@ extern "C" int bsk_batch_prepare(bsk_ctx *ctx, const bsk_batch *batch, const bsk
     Plan pl;
     int rc = make_plan(ctx, batch, p, pl);
     if (rc != BSK_OK || !pl.bin_gran) return rc == BSK_OK ? BSK_OK : BSK_OK;  // (parameters bsk_sketch would refuse are its to report)
-    hipEvent_t e0, e1;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     HIPCHK(ctx, hipEventCreate(&e0));
-    HIPCHK(ctx, hipEventCreate(&e1));
+    {
+        const hipError_t ec = hipEventCreate(&e1);
+        if (ec != hipSuccess) {
+            (void)hipEventDestroy(e0);
+            return fail_hip(ctx, ec, "bsk_batch_prepare: hipEventCreate");
+        }
+    }
     batch->bin_gran = 0;  // build (again): the call is also the way to time the pass
     hipError_t e = hipEventRecord(e0, ctx->stream);
     rc = ensure_binned(ctx, batch, (u32)((p->kind == BSK_SYNCMER ? p->s : p->k) - 1), pl.bin_gran);
@@ -2365,7 +2418,7 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
     // (syncmers: beyond the packed kernels' reach the per-read 64-bit kernel falls to 140-160 Gbases/s of wall time -- its 28-tuple slabs
     // overflow -- and to 83 at 4 000 bases, where tiles run 170-210: scripts/dev/perf_midlen.py, round 4)
     const u32 tile_min = ctx->opt.tile_min ? ctx->opt.tile_min
-                         : (is_dna && p->kind == BSK_SYNCMER && syn_long_plan_ok(ctx, p)) ? 448u
+                         : (is_dna && p->kind == BSK_SYNCMER && syn_long_plan_ok(ctx, p) && p->k - p->s >= 16) ? kSynTileMin  // (measured at k-s = 20..24; small k-s: tiles of 32 positions + 61 bases of overlap were never measured)
                          : ((!is_dna || kind_has_pos(p->kind)) ? 4096u : 16u * (BSK_NT_FAST_WORDS - 2));
     const bool outlier = !is_dna && p->kind == BSK_PROT_MINIMIZER && b->maxlen > 512 && !slab_budget_ok(b, (u64)b->maxlen);  // tiles are uniform: small slabs
     const bool tiled = kind_tiles(p) && (is_dna != prot_kind) && !ctx->opt.no_tiles && ((is_dna && !b->desc) || b->maxlen > tile_min || outlier);

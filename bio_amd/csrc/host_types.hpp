@@ -39,8 +39,8 @@ struct bsk_ctx {
     u8 *d_lut = nullptr;      // codon tables of `lut_table` (kernels_translate.hpp layout)
     int lut_table = 0;
     // tiled calls: grow-only temporaries (hipMalloc / hipFree of ten buffers per call cost more than the kernels)
-    void *tmp[20] = {};      // 0-9: tiled calls / sets, 12-14: bsk_result_fetch, 16-19: bsk_result_compact
-    size_t tmp_cap[20] = {};
+    void *tmp[24] = {};      // 0-9: tiled calls / sets, 12-14: bsk_result_fetch, 16-19: bsk_result_compact, 20: bsk_sets_fetch_narrow, 21-23: class plans
+    size_t tmp_cap[24] = {};
     u64 *h_refs = nullptr;   // pinned staging of bsk_result_fetch (refs down, offsets up), grow-only
     size_t h_refs_cap = 0;
     struct bsk_result *tile_res = nullptr;  // tile-level result of the previous tiled call, reused
@@ -100,6 +100,15 @@ struct bsk_result {
     u32 *pos = nullptr;
     char plan[96] = "";   // what ran: kernel name of the last launch into this result (bsk_result_plan)
     int plan_grid = 0, plan_per_cu = 0;
+    // The plan the arrays were SIZED for (run_planned, biosketch.hip): bsk_sketch_timed on an existing result repeats exactly this plan --
+    // a fresh plan could want more rows per unit than `cap` holds (k_minimizer_ring after a fall-back to 32-row slabs) and write past it.
+    bool plan_valid = false;
+    bool unit_rows = false;  // the last launch wrote unit rows (BSK_REF_ROWS: k_minimizer_ring): what the group gathers of sets.hip dispatch on
+    u64 plan_n = 0, plan_bases = 0;
+    u32 plan_maxlen = 0;
+    int plan_circ = 0;
+    bsk_params plan_params = {};
+    alignas(8) unsigned char plan_blob[192] = {};
 };
 
 static inline int fail_hip(bsk_ctx *ctx, hipError_t e, const char *what) {

@@ -205,7 +205,14 @@ struct PkMin {
         const u32 b = (bm >> IDX) & 1u;  // v_bfe_u32
         u32 pv;  // strand << 15 | position: one v_add3_u32 (scalar base, inline slot number); as C it is an s_add per step and a v_or
         asm("v_add3_u32 %0, %1, %2, %3" : "=v"(pv) : "v"(SB[O]), "s"(pbase), "n"(O));
-#ifndef PK_NOSTAGE  // (dev knock-outs, timing only: PK_NOSTAGE, PK_NOTIE, PK_NOTAB, PK_NOCOPY)
+#if defined(PK_MASKST)  // dev: the staging writes under the selection bit's lane mask (about a sixth of the lanes), no branch
+        {
+            const u32 a0 = (u32)(uintptr_t)(lds + LY::SH) + slot, a1 = (u32)(uintptr_t)(lds + LY::SP) + (slot >> 2);
+            u64 sv;
+            asm volatile("v_cmp_ne_u32_e32 vcc, 0, %1\n\ts_and_saveexec_b64 %0, vcc\n\tds_write_b64 %2, %3\n\tds_write_b16 %4, %5\n\ts_mov_b64 exec, %0"
+                         : "=&s"(sv) : "v"(b), "v"(a0), "v"(H[O]), "v"(a1), "v"(pv) : "vcc", "memory");
+        }
+#elif !defined(PK_NOSTAGE)  // (dev knock-outs, timing only: PK_NOSTAGE, PK_NOTIE, PK_NOTAB, PK_NOCOPY)
         *reinterpret_cast<LDSQ u64 *>(lds + LY::SH + slot) = H[O];
         *reinterpret_cast<LDSQ u16 *>(lds + LY::SP + (slot >> 2)) = (u16)pv;
 #else

@@ -343,7 +343,14 @@ struct RgMin {
         u32 pv;  // 2 * position + strand (rg_group turns it round by one bit): 2 pbase in a register, 2 O inline, the strand as the carry in
         asm("v_addc_co_u32 %0, vcc, %1, %2, %3" : "=v"(pv) : "v"(pbase2), "n"(2 * O), "s"(RV[O]) : "vcc");
         const u32 at = __umulhi(phase, (u32)(LY::R * LY::ROWB));
-#ifndef RG_NOSTAGE
+#if defined(RG_MASKST)  // dev: the staging writes under the selection bit's lane mask, no branch
+        {
+            const u32 a0 = (u32)(uintptr_t)(lds + LY::RING) + at;
+            u64 sv;
+            asm volatile("v_cmp_ne_u32_e32 vcc, 0, %1\n\ts_and_saveexec_b64 %0, vcc\n\tds_write2st64_b32 %2, %3, %4 offset1:1\n\tds_write_b32 %2, %5 offset:512\n\ts_mov_b64 exec, %0"
+                         : "=&s"(sv) : "v"(b), "v"(a0), "v"(HL[O]), "v"(HH[O]), "v"(pv) : "vcc", "memory");
+        }
+#elif !defined(RG_NOSTAGE)
         LDSQ u32 *const e = reinterpret_cast<LDSQ u32 *>(lds + LY::RING + at);  // the three planes of the row: one ds_write2st64_b32 + one ds_write_b32
         e[0] = HL[O];
         e[64] = HH[O];

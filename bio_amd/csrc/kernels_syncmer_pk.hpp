@@ -597,6 +597,7 @@ bool pk_syncmer_supported(int w, bool lng) {
 #undef X
     return false;
 }
+static_assert(SynPkLdsL::NW <= 32 && SynPkLds::NW <= 32, "biosketch.hip: kMaxPrefetchWords (pad_words) must cover the widest register prefetch");
 u32 pk_syncmer_max_bases(bool lng) { return 16u * (u32)((lng ? SynPkLdsL::NW : SynPkLds::NW) - 2); }  // the words a lane keeps in registers
 u32 pk_syncmer_pair_rows(bool lng) { return (u32)(lng ? SynPkLdsL::PR : SynPkLds::PR); }
 int pk_syncmer_blocks_per_cu(int w, bool lng) {

@@ -14,6 +14,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -174,8 +175,10 @@ static bool have_avx2() {
 }
 #endif
 // reads [a, a + m) of (bytes, offsets) -> words / descriptors; false: a byte outside ACGTacgt (nothing usable was written)
-static bool pack_chunk(const uint8_t *bytes, const uint64_t *offsets, uint64_t a, uint64_t m, uint64_t total_bytes, uint32_t *words, uint64_t *desc, uint64_t *n_words) {
-    uint64_t w = 0;
+// (w0: the chunk's words before this piece -- descriptors count from the chunk's first word)
+static bool pack_chunk(const uint8_t *bytes, const uint64_t *offsets, uint64_t a, uint64_t m, uint64_t total_bytes, uint32_t *words, uint64_t *desc, uint64_t *n_words,
+                       uint64_t w0 = 0) {
+    uint64_t w = w0;
     for (uint64_t r = 0; r < m; ++r) {
         const uint64_t b0 = offsets[a + r], len = offsets[a + r + 1] - b0;
         if (len >= (1ull << 24)) return false;
@@ -200,6 +203,8 @@ struct Chunk {
     std::vector<bsk_fastx_piece *> parts;  // block-parallel file source: the parsed pieces of the chunk (copied by the worker)
     struct Slot *slot = nullptr;           // where the chunk came from (several files can be in flight)
     int alphabet = BSK_ALPHA_DNA;
+    uint64_t seq = 0, first_record = 0;  // place in the run's delivery order; index of the chunk's first record in its source
+    int source_index = 0;
     bool packed = false;   // bytes holds 2-bit packed words (16 bases per u32, every read on a word boundary), offs the descriptors
     uint64_t n_words = 0;
 };
@@ -313,6 +318,33 @@ struct ParFastxSource : Source {
     }
     int materialize(Chunk *c) override {
         int rc = BSK_OK;
+        c->packed = false;
+        static const bool no_pack = getenv("BSK_PIPE_NO_HOST_PACK") != nullptr;  // dev: every chunk the ASCII way
+        if (c->alphabet == BSK_ALPHA_DNA && !no_pack && c->n) {  // pure ACGT chunks cross the link as 2-bit words (as MemorySource)
+            const uint64_t max_words = c->nbytes / 16 + c->n + 2;
+            if (c->bytes.ensure(max_words * 4 + 64) && c->offs.ensure((c->n + 1) * 8)) {
+                uint64_t at = 0, w = 0;
+                bool ok = true;
+                for (auto *pc : c->parts) {
+                    uint64_t n = 0;
+                    const uint8_t *sb = nullptr;
+                    const uint64_t *so = nullptr;
+                    bsk_fastx_piece_data(pc, &n, &sb, &so);
+                    if (!pack_chunk(sb, so, 0, n, so[n], (uint32_t *)c->bytes.p, (uint64_t *)c->offs.p + at, &w, w)) {
+                        ok = false;
+                        break;
+                    }
+                    at += n;
+                }
+                if (ok) {
+                    for (auto *pc : c->parts) bsk_fastx_piece_release(f, pc);
+                    c->parts.clear();
+                    c->n_words = w;
+                    c->packed = true;
+                    return BSK_OK;
+                }
+            }
+        }
         if (!c->bytes.ensure(c->nbytes + 1) || !c->offs.ensure((c->n + 1) * 8)) rc = BSK_ERR_NOMEM;
         uint64_t *o = (uint64_t *)c->offs.p;
         uint64_t at = 0, nb = 0;
@@ -394,24 +426,87 @@ struct OneSource : SourceSet {
     void close(Source *) override {}
 };
 
+// ---- the pipeline object behind bsk_pipeline_open_* / _next / _release / _close (include/biosketch.h) -----------------------------
 // devices[n_dev]: the GPUs of the run.  Every device gets n_streams workers (a context = a HIP stream each); all workers take chunks from the one
 // queue the producers fill, so a node's GPUs share one input the way the reference's workers share ChunkChan (seqio/fastx/reader.go:562-608) --
-// reads are independent, nothing is exchanged between devices, and the order-independent digest of the statistics is the whole job's.
-int run_pipeline(const int *devices, int n_dev, SourceSet &set, int n_producers, const bsk_params *p, int n_streams, uint64_t chunk_records, int fetch, bsk_pipeline_stats *st) {
-    if (!p || !st || !devices || n_dev < 1 || n_dev > 64 || n_streams < 1 || n_streams > 16 || n_producers < 1 || n_producers > 64) return BSK_ERR_ARG;
-    memset(st, 0, sizeof *st);
-    for (int d = 0; d < n_dev; ++d)
-        if (hipSetDevice(devices[d]) != hipSuccess) return BSK_ERR_NO_DEVICE;
-    const int device = devices[0];  // (the producers' pinned buffers)
-    const int n_workers = n_dev * n_streams;
-    const int nchunks = 2 * n_workers + n_producers;  // double buffering per stream + the one every producer is filling
-    std::vector<Chunk> chunks(nchunks);
+// reads are independent, nothing is exchanged between devices.  What the reference's ChunkChan hands its consumer -- every chunk, in input
+// order -- is what bsk_pipeline_next hands out: a worker finishes its chunk into an OUTPUT BUFFER (pinned; a bounded pool), the buffers are
+// delivered in the order the chunks were queued, and the consumer gives each one back with bsk_pipeline_release.
+//   A worker takes its output buffer BEFORE it takes a chunk: chunks leave the queue in sequence order, so the lowest sequence number not
+//   yet delivered is always held by a worker that already owns a buffer -- the bounded pool cannot dead-lock the ordered delivery.
+template <class T>
+struct PQueue {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<T *> q;
+    bool closed = false;
+    void push(T *c) {
+        {
+            std::lock_guard<std::mutex> l(m);
+            q.push_back(c);
+        }
+        cv.notify_one();
+    }
+    T *pop() {
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return !q.empty() || closed; });
+        if (q.empty()) return nullptr;
+        T *c = q.front();
+        q.pop_front();
+        return c;
+    }
+    void close() {
+        {
+            std::lock_guard<std::mutex> l(m);
+            closed = true;
+        }
+        cv.notify_all();
+    }
+};
+
+struct OutBuf {
+    PinBuf off, st, hash, pos;
+    bsk_chunk pub;
+    uint64_t seq = 0;
+};
+
+}  // namespace
+
+struct bsk_pipeline {
+    std::vector<int> devices;
+    int n_streams = 1, n_producers = 1, sink = BSK_SINK_TUPLES, sets_scale = 1, host_checksum = 0;
+    uint64_t chunk_records = 0;
+    bsk_params params{};
+    std::unique_ptr<SourceSet> set;
+    std::unique_ptr<Source> own_src;  // the single source of a memory / one-file run (the set refers to it)
+    // machinery
+    std::vector<Chunk> chunks;
     Queue free_q, full_q;
-    for (auto &c : chunks) free_q.push(&c);
+    std::vector<std::unique_ptr<OutBuf>> outs;
+    PQueue<OutBuf> free_out;
+    std::mutex om;  // ordered delivery
+    std::condition_variable ocv;
+    std::map<uint64_t, OutBuf *> ready;
+    uint64_t next_seq = 0;
+    int workers_alive = 0;
+    std::mutex seqm;  // sequence numbers are given in queue order
+    uint64_t seq_counter = 0;
     std::atomic<int> error{0};
     std::mutex stm;
     std::string errtext;
-    auto fail = [&](int code, const std::string &text) {
+    std::unique_ptr<Slot[]> slots;
+    std::atomic<int> next_source{0}, producers_left{0};
+    std::vector<std::thread> producers, workers;
+    clk::time_point t_start, t_last;
+    uint64_t pin0 = 0;
+    double reader_s = 0, reader_wait_s = 0;
+    bsk_pipeline_stats acc{};
+    bool joined = false;
+    // the block-parallel reader's figures, filled in when its file closes
+    int reader_threads = 0;
+    uint64_t reparsed = 0;
+
+    void fail(int code, const std::string &text) {
         int z = 0;
         if (error.compare_exchange_strong(z, code)) {
             std::lock_guard<std::mutex> l(stm);
@@ -419,252 +514,412 @@ int run_pipeline(const int *devices, int n_dev, SourceSet &set, int n_producers,
         }
         full_q.close();
         free_q.close();
-    };
-    const auto t_start = clk::now();
-    const uint64_t pin0 = g_pin_ns.load();
-    double reader_s = 0, reader_wait_s = 0;
-    std::atomic<int> next_source{0}, producers_left{n_producers};
-    std::unique_ptr<Slot[]> slots(new Slot[(size_t)std::max(1, set.count())]);
-    auto close_once = [&](Slot *sl) {
-        if (!sl->closed.exchange(true)) set.close(sl->src);
-    };
-    std::vector<std::thread> producers;
-    for (int pi = 0; pi < n_producers; ++pi) {
-        producers.emplace_back([&] {
-            (void)hipSetDevice(device);
-            double rs = 0, ws = 0;
-            for (;;) {
-                const int si = next_source++;
-                if (si >= set.count() || error.load()) break;
-                int orc = BSK_OK;
-                std::string otext;
-                Source *src = set.open(si, &orc, &otext);
-                if (!src) {
-                    fail(orc, otext);
-                    break;
-                }
-                Slot *sl = &slots[si];
-                sl->src = src;
-                for (;;) {
-                    const auto w0 = clk::now();
-                    Chunk *c = free_q.pop();
-                    ws += secs(w0, clk::now());
-                    if (!c || error.load()) break;
-                    const auto r0 = clk::now();
-                    const int rc = src->next(c, chunk_records);
-                    rs += secs(r0, clk::now());
-                    if (rc <= 0) {
-                        if (rc < 0) fail(-rc, src->err);
-                        else free_q.push(c);  // the source is exhausted: the buffer goes back
-                        break;
-                    }
-                    c->slot = sl;
-                    c->alphabet = src->alphabet;
-                    sl->inflight++;
-                    full_q.push(c);
-                }
-                if (error.load()) break;
-                sl->finished = true;
-                if (sl->inflight.load() == 0) close_once(sl);
+        free_out.close();
+        {
+            std::lock_guard<std::mutex> l(om);
+        }
+        ocv.notify_all();
+    }
+    void close_once(Slot *sl) {
+        if (!sl->closed.exchange(true)) set->close(sl->src);
+    }
+    void producer_main();
+    void worker_main(int w);
+    int start();
+    void join_all();
+};
+
+namespace {
+inline uint64_t host_checksum_tuples(const bsk_chunk &c) {
+    uint64_t sum = 0;
+    const uint64_t *h = c.hash;
+    if (c.offsets32) {
+        const uint64_t T = c.offsets32[c.n_records];
+        if (c.pos16)
+            for (uint64_t j = 0; j < T; ++j) sum += h[j] * (2 * (uint64_t)(c.pos16[j] & BSK_POS16_MASK) + 1);
+        else
+            for (uint64_t r = 0; r < c.n_records; ++r)
+                for (uint64_t j = c.offsets32[r]; j < c.offsets32[r + 1]; ++j) sum += h[j] * (2 * (j - c.offsets32[r]) + 1);
+    } else {
+        const uint64_t *oo = c.offsets64;
+        if (c.pos32) {  // explicit positions: one flat pass (the term does not depend on the read)
+            const uint64_t T = oo[c.n_records];
+            for (uint64_t j = 0; j < T; ++j) sum += h[j] * (2 * (uint64_t)(c.pos32[j] & BSK_POS_MASK) + 1);
+        } else {
+            for (uint64_t r = 0; r < c.n_records; ++r)
+                for (uint64_t j = oo[r]; j < oo[r + 1]; ++j) sum += h[j] * (2 * (j - oo[r]) + 1);
+        }
+    }
+    return sum;
+}
+}  // namespace
+
+void bsk_pipeline::producer_main() {
+    (void)hipSetDevice(devices[0]);
+    double rs = 0, ws = 0;
+    for (;;) {
+        const int si = next_source++;
+        if (si >= set->count() || error.load()) break;
+        int orc = BSK_OK;
+        std::string otext;
+        Source *src = set->open(si, &orc, &otext);
+        if (!src) {
+            fail(orc, otext);
+            break;
+        }
+        Slot *sl = &slots[si];
+        sl->src = src;
+        uint64_t first_record = 0;
+        for (;;) {
+            const auto w0 = clk::now();
+            Chunk *c = free_q.pop();
+            ws += secs(w0, clk::now());
+            if (!c || error.load()) break;
+            const auto r0 = clk::now();
+            const int rc = src->next(c, chunk_records);
+            rs += secs(r0, clk::now());
+            if (rc <= 0) {
+                if (rc < 0) fail(-rc, src->err);
+                else free_q.push(c);  // the source is exhausted: the buffer goes back
+                break;
             }
+            c->slot = sl;
+            c->alphabet = src->alphabet;
+            c->source_index = si;
+            c->first_record = first_record;
+            first_record += c->n;
+            sl->inflight++;
             {
-                std::lock_guard<std::mutex> l(stm);
-                reader_s += rs;
-                reader_wait_s += ws;
+                std::lock_guard<std::mutex> l(seqm);  // number and queue in one step: the workers take chunks in sequence order
+                c->seq = seq_counter++;
+                full_q.push(c);
             }
-            if (--producers_left == 0) full_q.close();
-        });
+        }
+        if (error.load()) break;
+        sl->finished = true;
+        if (sl->inflight.load() == 0) close_once(sl);
     }
-    std::vector<std::thread> workers;
-    for (int w = 0; w < n_workers; ++w) {
-        workers.emplace_back([&, w] {
-            const int device = devices[w % n_dev];  // (shadows the producers' device: the copy locks below are per device)
-            bsk_ctx *ctx = nullptr;
-            if (bsk_ctx_create(device, &ctx) != BSK_OK) {
-                fail(BSK_ERR_NO_DEVICE, "bsk_ctx_create");
-                return;
+    {
+        std::lock_guard<std::mutex> l(stm);
+        reader_s += rs;
+        reader_wait_s += ws;
+    }
+    if (--producers_left == 0) full_q.close();
+}
+
+void bsk_pipeline::worker_main(int w) {
+    const int n_dev = (int)devices.size();
+    const int device = devices[(size_t)(w % n_dev)];
+    bsk_ctx *ctx = nullptr;
+    bsk_batch *batch = nullptr;
+    bsk_result *res = nullptr;
+    bsk_sets *sets = nullptr;
+    bsk_pipeline_stats loc;
+    memset(&loc, 0, sizeof loc);
+    const bsk_params *p = &params;
+    if (bsk_ctx_create(device, &ctx) != BSK_OK) {
+        fail(BSK_ERR_NO_DEVICE, "bsk_ctx_create");
+    } else {
+        for (;;) {
+            OutBuf *ob = free_out.pop();
+            if (!ob || error.load()) break;
+            Chunk *c = full_q.pop();
+            if (!c || error.load()) {
+                if (c) free_q.push(c);
+                free_out.push(ob);
+                break;
             }
-            bsk_batch *batch = nullptr;
-            bsk_result *res = nullptr;
-            PinBuf o_off, o_st, o_hash, o_pos;
-            bsk_pipeline_stats loc;
-            memset(&loc, 0, sizeof loc);
-            for (;;) {
-                Chunk *c = full_q.pop();
-                if (!c || error.load()) break;
-                auto t0 = clk::now();
-                Slot *sl = c->slot;
-                int rc = sl->src->materialize(c);
-                if (rc == BSK_OK) {
-                    // ONE host-to-device copy in flight per device, and one device-to-host (below): the link moves 48 + 48 GB/s with one
-                    // large-copy stream per direction and 17 + 31 .. 24 + 43 when n streams interleave 39-MB and 46 + 23-MB copies both
-                    // ways (scripts/ubench/pcie.py).  The kernels and the host-side work of other chunks still overlap the copies.
-                    std::unique_lock<std::mutex> lk(g_h2d_mutex[device & 15], std::defer_lock);
+            auto t0 = clk::now();
+            Slot *sl = c->slot;
+            int rc = sl->src->materialize(c);
+            if (rc == BSK_OK) {
+                // ONE host-to-device copy in flight per device, and one device-to-host (below): the link moves 48 + 48 GB/s with one
+                // large-copy stream per direction and 17 + 31 .. 24 + 43 when n streams interleave 39-MB and 46 + 23-MB copies both
+                // ways (scripts/ubench/pcie.py).  The kernels and the host-side work of other chunks still overlap the copies.
+                std::unique_lock<std::mutex> lk(g_h2d_mutex[device & 15], std::defer_lock);
+                if (g_copy_locks) lk.lock();
+                if (c->packed) rc = bsk_batch_refill_packed(ctx, &batch, (const uint32_t *)c->bytes.p, c->n_words, (const uint64_t *)c->offs.p, c->n);
+                else rc = bsk_batch_refill_ascii(ctx, &batch, (const uint8_t *)c->bytes.p, (const uint64_t *)c->offs.p, c->n, c->alphabet);
+            }
+            c->slot = nullptr;
+            if (--sl->inflight == 0 && sl->finished.load()) close_once(sl);
+            const uint64_t n = c->n, nb = c->nbytes;
+            bsk_chunk &pub = ob->pub;
+            memset(&pub, 0, sizeof pub);
+            ob->seq = c->seq;
+            pub.sequence = c->seq;
+            pub.source_index = c->source_index;
+            pub.first_record = c->first_record;
+            pub.n_records = n;
+            pub.n_bases = nb;
+            pub.device = device;
+            pub.sink = sink;
+            pub.opaque = ob;
+            free_q.push(c);  // the bytes are on the device: the producer may refill this buffer
+            auto t1 = clk::now();
+            loc.h2d_pack_seconds += secs(t0, t1);
+            if (rc == BSK_OK) rc = bsk_sketch(ctx, batch, p, &res);
+            auto t2 = clk::now();
+            loc.kernel_seconds += secs(t1, t2);
+            uint64_t nr = 0, nt = 0;
+            int hp = 0;
+            if (rc == BSK_OK) rc = bsk_result_info(res, &nr, &nt, &hp);
+            pub.n_tuples = nt;
+            pub.has_pos = hp;
+            if (rc == BSK_OK && sink == BSK_SINK_TUPLES) {
+                if (!ob->off.ensure((nr + 1) * 8) || !ob->st.ensure(nr + 1) || !ob->hash.ensure((nt + 1) * 8) || (hp && !ob->pos.ensure((nt + 1) * 4))) rc = BSK_ERR_NOMEM;
+                // kinds with explicit positions leave through the narrow fetch (u32 offsets scanned on the device, u16 positions: 10 bytes
+                // per tuple + 5 per read over the link instead of 12 + 17); reads of 32 768 bases or more fall back to the wide one
+                static const bool wide_only = getenv("BSK_PIPE_WIDE_FETCH") != nullptr;
+                bool narrow = hp && !wide_only && nt < (1ull << 32);
+                if (rc == BSK_OK && narrow) {
+                    std::unique_lock<std::mutex> lk(g_d2h_mutex[device & 15], std::defer_lock);
                     if (g_copy_locks) lk.lock();
-                    if (c->packed) rc = bsk_batch_refill_packed(ctx, &batch, (const uint32_t *)c->bytes.p, c->n_words, (const uint64_t *)c->offs.p, c->n);
-                    else rc = bsk_batch_refill_ascii(ctx, &batch, (const uint8_t *)c->bytes.p, (const uint64_t *)c->offs.p, c->n, c->alphabet);
-                }
-                c->slot = nullptr;
-                if (--sl->inflight == 0 && sl->finished.load()) close_once(sl);
-                const uint64_t n = c->n, nb = c->nbytes;
-                free_q.push(c);  // the bytes are on the device: the producer may refill this buffer
-                auto t1 = clk::now();
-                loc.h2d_pack_seconds += secs(t0, t1);
-                if (rc == BSK_OK) rc = bsk_sketch(ctx, batch, p, &res);
-                auto t2 = clk::now();
-                loc.kernel_seconds += secs(t1, t2);
-                uint64_t nr = 0, nt = 0;
-                int hp = 0;
-                if (rc == BSK_OK) rc = bsk_result_info(res, &nr, &nt, &hp);
-                if (rc == BSK_OK && fetch) {
-                    if (!o_off.ensure((nr + 1) * 8) || !o_st.ensure(nr + 1) || !o_hash.ensure((nt + 1) * 8) || (hp && !o_pos.ensure((nt + 1) * 4))) rc = BSK_ERR_NOMEM;
-                    // kinds with explicit positions leave through the narrow fetch (u32 offsets scanned on the device, u16 positions: 10 bytes
-                    // per tuple + 5 per read over the link instead of 12 + 17); reads of 32 768 bases or more fall back to the wide one
-                    static const bool wide_only = getenv("BSK_PIPE_WIDE_FETCH") != nullptr;
-                    bool narrow = hp && !wide_only && nt < (1ull << 32);
-                    if (rc == BSK_OK && narrow) {
-                        std::unique_lock<std::mutex> lk(g_d2h_mutex[device & 15], std::defer_lock);
-                        if (g_copy_locks) lk.lock();
-                        rc = bsk_result_fetch_narrow(ctx, res, 0, nr, (uint32_t *)o_off.p, (uint8_t *)o_st.p, (uint64_t *)o_hash.p, (uint16_t *)o_pos.p, nt + 1, nullptr);
-                        if (rc == BSK_ERR_UNSUPPORTED) {
-                            narrow = false;
-                            rc = BSK_OK;
-                        }
+                    rc = bsk_result_fetch_narrow(ctx, res, 0, nr, (uint32_t *)ob->off.p, (uint8_t *)ob->st.p, (uint64_t *)ob->hash.p, (uint16_t *)ob->pos.p, nt + 1, nullptr);
+                    if (rc == BSK_ERR_UNSUPPORTED) {
+                        narrow = false;
+                        rc = BSK_OK;
                     }
-                    if (rc == BSK_OK && !narrow) {
-                        std::unique_lock<std::mutex> lk(g_d2h_mutex[device & 15], std::defer_lock);
-                        if (g_copy_locks) lk.lock();
-                        rc = bsk_result_fetch(ctx, res, 0, nr, (uint64_t *)o_off.p, (uint8_t *)o_st.p, (uint64_t *)o_hash.p, hp ? (uint32_t *)o_pos.p : nullptr, nt + 1);
-                    }
-                    static const bool nodigest = getenv("BSK_PIPE_NO_DIGEST") != nullptr;  // dev: the run without the consumer stand-in (checksum stays 0)
-                    if (rc == BSK_OK && !nodigest && narrow) {
-                        const uint64_t *h = (const uint64_t *)o_hash.p;
-                        const uint16_t *ps = (const uint16_t *)o_pos.p;
-                        const uint64_t T = ((const uint32_t *)o_off.p)[nr];
-                        uint64_t sum = 0;
-                        for (uint64_t j = 0; j < T; ++j) sum += h[j] * (2 * (uint64_t)(ps[j] & BSK_POS16_MASK) + 1);
-                        loc.checksum += sum;
-                    } else
-                    if (rc == BSK_OK && !nodigest) {  // the caller's consumer would start here; the statistics keep an order-independent digest
-                        const uint64_t *h = (const uint64_t *)o_hash.p, *oo = (const uint64_t *)o_off.p;
-                        const uint32_t *ps = (const uint32_t *)o_pos.p;
-                        uint64_t sum = 0;
-                        if (hp) {  // explicit positions: one flat pass (the term does not depend on the read)
-                            const uint64_t T = oo[nr];
-                            for (uint64_t j = 0; j < T; ++j) sum += h[j] * (2 * (uint64_t)(ps[j] & BSK_POS_MASK) + 1);
-                        } else {
-                            for (uint64_t r = 0; r < nr; ++r)
-                                for (uint64_t j = oo[r]; j < oo[r + 1]; ++j) sum += h[j] * (2 * (j - oo[r]) + 1);
-                        }
-                        loc.checksum += sum;
-                    }
-                } else if (rc == BSK_OK) {
-                    uint64_t ck = 0, ntt = 0;
-                    rc = bsk_result_digest(ctx, res, &ck, &ntt, nullptr);
-                    loc.checksum += ck;
                 }
-                loc.fetch_seconds += secs(t2, clk::now());
-                if (rc != BSK_OK) {
-                    fail(rc, bsk_last_error(ctx));
-                    break;
+                if (rc == BSK_OK && !narrow) {
+                    std::unique_lock<std::mutex> lk(g_d2h_mutex[device & 15], std::defer_lock);
+                    if (g_copy_locks) lk.lock();
+                    rc = bsk_result_fetch(ctx, res, 0, nr, (uint64_t *)ob->off.p, (uint8_t *)ob->st.p, (uint64_t *)ob->hash.p, hp ? (uint32_t *)ob->pos.p : nullptr, nt + 1);
                 }
-                loc.records += n;
-                loc.bases += nb;
-                loc.tuples += nt;
-                loc.chunks += 1;
+                pub.status = (const uint8_t *)ob->st.p;
+                pub.hash = (const uint64_t *)ob->hash.p;
+                if (narrow) {
+                    pub.offsets32 = (const uint32_t *)ob->off.p;
+                    pub.pos16 = (const uint16_t *)ob->pos.p;
+                    pub.link_bytes = nr * 5 + nt * 10;
+                } else {
+                    pub.offsets64 = (const uint64_t *)ob->off.p;
+                    pub.pos32 = hp ? (const uint32_t *)ob->pos.p : nullptr;
+                    pub.link_bytes = nr * 9 + nt * (hp ? 12 : 8);
+                }
+                pub.n_values = nt;
+                static const bool nodigest = getenv("BSK_PIPE_NO_DIGEST") != nullptr;  // dev: the run without the consumer stand-in (checksum stays 0)
+                if (rc == BSK_OK && host_checksum && !nodigest) pub.checksum = host_checksum_tuples(pub);
+            } else if (rc == BSK_OK && sink == BSK_SINK_SETS) {
+                // the on-device reduction the reference's consumers do on the host (collect, sort, de-duplicate, FracMinHash filter:
+                // iterator.go:181-185): only the distinct values that pass cross the link
+                rc = bsk_result_sets_reuse(ctx, res, BSK_SETS_PER_SEQUENCE, sets_scale, &sets);
+                uint64_t ns = 0, nv = 0;
+                if (rc == BSK_OK) rc = bsk_sets_info(sets, &ns, &nv);
+                if (rc == BSK_OK && (!ob->off.ensure((ns + 1) * 4) || !ob->st.ensure(nr + 1) || !ob->hash.ensure((nv + 1) * 8))) rc = BSK_ERR_NOMEM;
+                if (rc == BSK_OK) {
+                    std::unique_lock<std::mutex> lk(g_d2h_mutex[device & 15], std::defer_lock);
+                    if (g_copy_locks) lk.lock();
+                    rc = bsk_sets_fetch_narrow(ctx, sets, (uint32_t *)ob->off.p, (uint64_t *)ob->hash.p, nv + 1);
+                    if (rc == BSK_OK) rc = bsk_result_fetch_status(ctx, res, 0, nr, (uint8_t *)ob->st.p);
+                }
+                pub.offsets32 = (const uint32_t *)ob->off.p;
+                pub.status = (const uint8_t *)ob->st.p;
+                pub.hash = (const uint64_t *)ob->hash.p;
+                pub.n_values = nv;
+                pub.link_bytes = nr * 5 + nv * 8;
+                if (rc == BSK_OK && host_checksum) {
+                    uint64_t sum = 0;
+                    for (uint64_t j = 0; j < nv; ++j) sum += pub.hash[j];
+                    pub.checksum = sum;
+                }
+            } else if (rc == BSK_OK) {  // BSK_SINK_COUNTS: nothing but counts and the device-side digest leave the device
+                uint64_t ck = 0, ntt = 0;
+                rc = bsk_result_digest(ctx, res, &ck, &ntt, nullptr);
+                pub.checksum = ck;
             }
-            bsk_result_release(res);
-            bsk_batch_destroy(batch);
-            bsk_ctx_destroy(ctx);
-            std::lock_guard<std::mutex> l(stm);
-            st->records += loc.records;
-            st->bases += loc.bases;
-            st->tuples += loc.tuples;
-            st->chunks += loc.chunks;
-            st->checksum += loc.checksum;
-            st->h2d_pack_seconds += loc.h2d_pack_seconds;
-            st->kernel_seconds += loc.kernel_seconds;
-            st->fetch_seconds += loc.fetch_seconds;
-        });
+            loc.fetch_seconds += secs(t2, clk::now());
+            if (rc != BSK_OK) {
+                fail(rc, bsk_last_error(ctx));
+                free_out.push(ob);
+                break;
+            }
+            loc.records += n;
+            loc.bases += nb;
+            loc.tuples += nt;
+            loc.chunks += 1;
+            loc.checksum += pub.checksum;
+            {
+                std::lock_guard<std::mutex> l(om);
+                ready[ob->seq] = ob;
+            }
+            ocv.notify_all();
+        }
     }
+    if (sets) bsk_sets_release(sets);
+    bsk_result_release(res);
+    bsk_batch_destroy(batch);
+    if (ctx) bsk_ctx_destroy(ctx);
+    {
+        std::lock_guard<std::mutex> l(stm);
+        acc.records += loc.records;
+        acc.bases += loc.bases;
+        acc.tuples += loc.tuples;
+        acc.chunks += loc.chunks;
+        acc.checksum += loc.checksum;
+        acc.h2d_pack_seconds += loc.h2d_pack_seconds;
+        acc.kernel_seconds += loc.kernel_seconds;
+        acc.fetch_seconds += loc.fetch_seconds;
+    }
+    {
+        std::lock_guard<std::mutex> l(om);
+        --workers_alive;
+    }
+    ocv.notify_all();
+}
+
+int bsk_pipeline::start() {
+    const int n_dev = (int)devices.size();
+    for (int d = 0; d < n_dev; ++d)
+        if (hipSetDevice(devices[(size_t)d]) != hipSuccess) return BSK_ERR_NO_DEVICE;
+    const int n_workers = n_dev * n_streams;
+    const int nchunks = 2 * n_workers + n_producers;  // double buffering per stream + the one every producer is filling
+    chunks = std::vector<Chunk>((size_t)nchunks);
+    for (auto &c : chunks) free_q.push(&c);
+    const int nouts = 2 * n_workers + 2;  // one in work per stream, one waiting for its turn or held by the consumer, two to spare
+    for (int i = 0; i < nouts; ++i) {
+        outs.emplace_back(new OutBuf());
+        free_out.push(outs.back().get());
+    }
+    slots.reset(new Slot[(size_t)std::max(1, set->count())]);
+    t_start = t_last = clk::now();
+    pin0 = g_pin_ns.load();
+    producers_left = n_producers;
+    workers_alive = n_workers;
+    for (int pi = 0; pi < n_producers; ++pi) producers.emplace_back([this] { producer_main(); });
+    for (int w = 0; w < n_workers; ++w) workers.emplace_back([this, w] { worker_main(w); });
+    return BSK_OK;
+}
+
+void bsk_pipeline::join_all() {
+    if (joined) return;
+    joined = true;
     for (auto &t : producers) t.join();
     for (auto &t : workers) t.join();
     for (auto &c : chunks)
         if (c.slot && !c.slot->closed.load()) c.slot->src->discard(&c);
-    for (int i = 0; i < set.count(); ++i)
+    for (int i = 0; i < set->count(); ++i)
         if (slots[i].src) close_once(&slots[i]);
-    st->seconds = secs(t_start, clk::now());
-    st->reader_seconds = reader_s;
-    st->reader_wait_seconds = reader_wait_s;
-    st->n_streams = n_workers;
-    st->pin_seconds = (double)(g_pin_ns.load() - pin0) * 1e-9;
-    return error.load();
 }
 
-}  // namespace
+extern "C" int bsk_pipeline_next(bsk_pipeline *pl, const bsk_chunk **chunk) {
+    if (!pl || !chunk) return BSK_ERR_ARG;
+    *chunk = nullptr;
+    std::unique_lock<std::mutex> l(pl->om);
+    pl->ocv.wait(l, [&] { return pl->ready.count(pl->next_seq) || pl->workers_alive == 0 || pl->error.load(); });
+    if (pl->error.load()) return pl->error.load();
+    auto it = pl->ready.find(pl->next_seq);
+    if (it == pl->ready.end()) return BSK_OK;  // every worker has left and nothing is waiting: the end
+    OutBuf *ob = it->second;
+    pl->ready.erase(it);
+    pl->next_seq++;
+    pl->t_last = clk::now();
+    *chunk = &ob->pub;
+    return BSK_OK;
+}
 
-extern "C" int bsk_pipeline_fastx_multi(const int *devices, int n_devices, const char *path, int alphabet, const bsk_params *p, int n_streams,
-                                        uint64_t chunk_records, int fetch_tuples, bsk_pipeline_stats *stats) {
-    if (!path || !devices || n_devices < 1) return BSK_ERR_ARG;
-    // a plain file: block-parallel parsing (the serial record reader delivers ~0.8 Gbases/s, a third of what ONE stream sketches)
-    if (!getenv("BSK_FASTX_SERIAL")) {
-        ParFastxSource ps;
-        ps.want_alpha = alphabet;
-        const char *tv = getenv("BSK_FASTX_THREADS");
-        int nt = tv && atoi(tv) > 0 ? atoi(tv) : (int)std::thread::hardware_concurrency() - n_streams * n_devices - 1;
-        nt = std::max(1, std::min(nt, 12));
-        const int orc = bsk_fastx_par_open(path, nt, 0, &ps.f);
-        if (orc == BSK_OK) {
-            OneSource one(&ps);
-            const int rc = run_pipeline(devices, n_devices, one, 1, p, n_streams, chunk_records, fetch_tuples, stats);
-            uint64_t rep = 0;
-            bsk_fastx_par_info(ps.f, nullptr, nullptr, &rep);
-            if (stats) stats->reader_threads = nt, stats->reparsed_pieces = rep;
-            bsk_fastx_par_close(ps.f);
-            return rc;
-        }
-        if (orc != BSK_ERR_UNSUPPORTED) return orc;  // gzip / stdin: the serial reader below
+extern "C" int bsk_pipeline_release(bsk_pipeline *pl, const bsk_chunk *chunk) {
+    if (!pl || !chunk || !chunk->opaque) return BSK_ERR_ARG;
+    pl->free_out.push(static_cast<OutBuf *>(chunk->opaque));
+    return BSK_OK;
+}
+
+extern "C" const char *bsk_pipeline_error(const bsk_pipeline *pl) {
+    if (!pl) return "null pipeline";
+    std::lock_guard<std::mutex> l(const_cast<bsk_pipeline *>(pl)->stm);
+    return pl->errtext.c_str();
+}
+
+extern "C" int bsk_pipeline_close(bsk_pipeline *pl, bsk_pipeline_stats *st) {
+    if (!pl) return BSK_ERR_ARG;
+    bool drained;
+    {
+        std::lock_guard<std::mutex> l(pl->om);
+        drained = pl->workers_alive == 0 && pl->ready.empty();
     }
-    FastxSource src;
-    src.want_alpha = alphabet;
-    int rc = bsk_fastx_open(path, &src.f);
-    if (rc != BSK_OK) return rc;
-    OneSource one(&src);
-    rc = run_pipeline(devices, n_devices, one, 1, p, n_streams, chunk_records, fetch_tuples, stats);
-    bsk_fastx_close(src.f);
+    int rc = pl->error.load();
+    if (!drained && !rc) {  // closed before the end: stop the threads (not an error of the run)
+        pl->full_q.close();
+        pl->free_q.close();
+        pl->free_out.close();
+        int z = 0;
+        pl->error.compare_exchange_strong(z, -1);
+    }
+    pl->join_all();
+    if (st) {
+        *st = pl->acc;
+        st->seconds = secs(pl->t_start, drained ? pl->t_last : clk::now());
+        st->reader_seconds = pl->reader_s;
+        st->reader_wait_seconds = pl->reader_wait_s;
+        st->n_streams = (int32_t)(pl->devices.size() * (size_t)pl->n_streams);
+        st->pin_seconds = (double)(g_pin_ns.load() - pl->pin0) * 1e-9;
+        st->reader_threads = pl->reader_threads;
+        st->reparsed_pieces = pl->reparsed;
+    }
+    pl->set.reset();
+    pl->own_src.reset();
+    delete pl;
     return rc;
 }
-extern "C" int bsk_pipeline_fastx(int device, const char *path, int alphabet, const bsk_params *p, int n_streams, uint64_t chunk_records,
-                                  int fetch_tuples, bsk_pipeline_stats *stats) {
-    return bsk_pipeline_fastx_multi(&device, 1, path, alphabet, p, n_streams, chunk_records, fetch_tuples, stats);
+
+extern "C" int bsk_pipeline_run(bsk_pipeline *pl, bsk_chunk_fn on_chunk, void *user, bsk_pipeline_stats *stats) {
+    if (!pl) return BSK_ERR_ARG;
+    int rc = BSK_OK, crc = 0;
+    for (;;) {
+        const bsk_chunk *c = nullptr;
+        rc = bsk_pipeline_next(pl, &c);
+        if (rc != BSK_OK || !c) break;
+        if (on_chunk) crc = on_chunk(user, c);
+        bsk_pipeline_release(pl, c);
+        if (crc) break;  // the consumer stops the run
+    }
+    const int close_rc = bsk_pipeline_close(pl, stats);
+    if (crc) return BSK_ERR_ARG;
+    return rc != BSK_OK ? rc : close_rc;
 }
 
-extern "C" int bsk_pipeline_memory_multi(const int *devices, int n_devices, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet,
-                                         const bsk_params *p, int n_streams, uint64_t chunk_records, int repeat, int fetch_tuples, bsk_pipeline_stats *stats) {
-    if (!bytes || !offsets || !n || repeat < 1 || !devices || n_devices < 1) return BSK_ERR_ARG;
-    MemorySource src;
-    src.bytes = bytes;
-    src.offsets = offsets;
-    src.n = n;
-    src.repeat = repeat;
-    src.alphabet = alphabet;
-    OneSource one(&src);
-    return run_pipeline(devices, n_devices, one, 1, p, n_streams, chunk_records, fetch_tuples, stats);
+namespace {
+int check_config(const bsk_pipeline_config *cfg, const bsk_params *p) {
+    if (!cfg || !p || !cfg->devices || cfg->n_devices < 1 || cfg->n_devices > 64 || cfg->n_streams < 1 || cfg->n_streams > 16) return BSK_ERR_ARG;
+    if (cfg->sink != BSK_SINK_COUNTS && cfg->sink != BSK_SINK_TUPLES && cfg->sink != BSK_SINK_SETS) return BSK_ERR_ARG;
+    if (cfg->sink == BSK_SINK_SETS && cfg->sets_scale < 0) return BSK_ERR_ARG;
+    return BSK_OK;
 }
-extern "C" int bsk_pipeline_memory(int device, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet, const bsk_params *p,
-                                   int n_streams, uint64_t chunk_records, int repeat, int fetch_tuples, bsk_pipeline_stats *stats) {
-    return bsk_pipeline_memory_multi(&device, 1, bytes, offsets, n, alphabet, p, n_streams, chunk_records, repeat, fetch_tuples, stats);
+bsk_pipeline *new_pipeline(const bsk_pipeline_config *cfg, const bsk_params *p) {
+    auto *pl = new bsk_pipeline();
+    pl->devices.assign(cfg->devices, cfg->devices + cfg->n_devices);
+    pl->n_streams = cfg->n_streams;
+    pl->chunk_records = cfg->chunk_records;
+    pl->sink = cfg->sink;
+    pl->sets_scale = cfg->sets_scale > 0 ? cfg->sets_scale : 1;
+    pl->host_checksum = cfg->host_checksum;
+    pl->params = *p;
+    return pl;
 }
+int start_or_drop(bsk_pipeline *pl, bsk_pipeline **out) {
+    const int rc = pl->start();
+    if (rc != BSK_OK) {
+        pl->set.reset();
+        pl->own_src.reset();
+        delete pl;
+        return rc;
+    }
+    *out = pl;
+    return BSK_OK;
+}
+
+// the statistics-only entry points of rounds 2-4, now one consumer loop over the pipeline object
+int run_pipeline(bsk_pipeline *pl, bsk_pipeline_stats *st) { return bsk_pipeline_run(pl, nullptr, nullptr, st); }
 
 // several files, n_readers of them read at once (each by its own producer thread: the block-parallel reader for a plain file, the serial
 // one for a gzip file -- which is how gzip input scales: one zlib stream per file, several files)
-namespace {
 struct FileSet : SourceSet {
     std::vector<std::string> paths;
     int want_alpha = -1, threads_per_file = 1;
     std::mutex m;
     uint64_t reparsed = 0;
     int par_files = 0;
+    bsk_pipeline *owner = nullptr;
     int count() const override { return (int)paths.size(); }
     Source *open(int i, int *rc, std::string *errtext) override {
         if (!getenv("BSK_FASTX_SERIAL")) {
@@ -677,7 +932,7 @@ struct FileSet : SourceSet {
                 return ps;
             }
             delete ps;
-            if (orc != BSK_ERR_UNSUPPORTED) {
+            if (orc != BSK_ERR_UNSUPPORTED) {  // (gzip / stdin: the serial reader below)
                 *rc = orc;
                 *errtext = "cannot read " + paths[i];
                 return nullptr;
@@ -701,6 +956,7 @@ struct FileSet : SourceSet {
             {
                 std::lock_guard<std::mutex> l(m);
                 reparsed += rep;
+                if (owner) owner->reparsed = reparsed, owner->reader_threads = threads_per_file;
             }
             bsk_fastx_par_close(ps->f);
         } else if (auto *fs = dynamic_cast<FastxSource *>(s)) {
@@ -711,26 +967,111 @@ struct FileSet : SourceSet {
 };
 }  // namespace
 
+extern "C" int bsk_pipeline_open_fastx(const bsk_pipeline_config *cfg, const char *const *paths, int n_paths, const bsk_params *p, bsk_pipeline **out) {
+    if (!out) return BSK_ERR_ARG;
+    *out = nullptr;
+    int rc = check_config(cfg, p);
+    if (rc != BSK_OK || !paths || n_paths < 1 || cfg->n_readers < 0) return BSK_ERR_ARG;
+    auto *set = new FileSet();
+    for (int i = 0; i < n_paths; ++i) {
+        if (!paths[i]) {
+            delete set;
+            return BSK_ERR_ARG;
+        }
+        set->paths.emplace_back(paths[i]);
+    }
+    set->want_alpha = cfg->alphabet;
+    int n_readers = cfg->n_readers ? cfg->n_readers : std::min(n_paths, 8);
+    n_readers = std::min(n_readers, std::min(n_paths, 64));
+    const int n_workers = cfg->n_streams * cfg->n_devices;
+    const char *tv = getenv("BSK_FASTX_THREADS");
+    const int budget = tv && atoi(tv) > 0 ? atoi(tv) : std::max(1, (int)std::thread::hardware_concurrency() - n_workers - n_readers);
+    set->threads_per_file = std::max(1, std::min(budget, 12) / n_readers);
+    bsk_pipeline *pl = new_pipeline(cfg, p);
+    set->owner = pl;
+    pl->set.reset(set);
+    pl->n_producers = n_readers;
+    return start_or_drop(pl, out);
+}
+
+extern "C" int bsk_pipeline_open_memory(const bsk_pipeline_config *cfg, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int repeat,
+                                        const bsk_params *p, bsk_pipeline **out) {
+    if (!out) return BSK_ERR_ARG;
+    *out = nullptr;
+    if (check_config(cfg, p) != BSK_OK || !bytes || !offsets || !n || repeat < 1) return BSK_ERR_ARG;
+    auto *src = new MemorySource();
+    src->bytes = bytes;
+    src->offsets = offsets;
+    src->n = n;
+    src->repeat = repeat;
+    src->alphabet = cfg->alphabet < 0 ? BSK_ALPHA_DNA : cfg->alphabet;
+    bsk_pipeline *pl = new_pipeline(cfg, p);
+    pl->own_src.reset(src);
+    pl->set.reset(new OneSource(src));
+    pl->n_producers = 1;
+    return start_or_drop(pl, out);
+}
+
+// ---- the statistics-only entry points (rounds 2-4): one consumer loop over the pipeline object, the digest folded by the workers ----
+static int stats_run_files(const int *devices, int n_devices, const char *const *paths, int n_paths, int alphabet, const bsk_params *p, int n_streams, int n_readers,
+                           uint64_t chunk_records, int fetch_tuples, bsk_pipeline_stats *stats) {
+    if (!stats) return BSK_ERR_ARG;
+    memset(stats, 0, sizeof *stats);
+    bsk_pipeline_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.devices = devices;
+    cfg.n_devices = n_devices;
+    cfg.n_streams = n_streams;
+    cfg.chunk_records = chunk_records;
+    cfg.sink = fetch_tuples == 2 ? BSK_SINK_SETS : fetch_tuples ? BSK_SINK_TUPLES : BSK_SINK_COUNTS;
+    cfg.sets_scale = 1;
+    cfg.alphabet = alphabet;
+    cfg.host_checksum = 1;
+    cfg.n_readers = n_readers;
+    bsk_pipeline *pl = nullptr;
+    const int rc = bsk_pipeline_open_fastx(&cfg, paths, n_paths, p, &pl);
+    if (rc != BSK_OK) return rc;
+    return run_pipeline(pl, stats);
+}
+
+extern "C" int bsk_pipeline_fastx_multi(const int *devices, int n_devices, const char *path, int alphabet, const bsk_params *p, int n_streams,
+                                        uint64_t chunk_records, int fetch_tuples, bsk_pipeline_stats *stats) {
+    if (!path || !devices || n_devices < 1) return BSK_ERR_ARG;
+    return stats_run_files(devices, n_devices, &path, 1, alphabet, p, n_streams, 1, chunk_records, fetch_tuples, stats);
+}
+extern "C" int bsk_pipeline_fastx(int device, const char *path, int alphabet, const bsk_params *p, int n_streams, uint64_t chunk_records,
+                                  int fetch_tuples, bsk_pipeline_stats *stats) {
+    return bsk_pipeline_fastx_multi(&device, 1, path, alphabet, p, n_streams, chunk_records, fetch_tuples, stats);
+}
+
+extern "C" int bsk_pipeline_memory_multi(const int *devices, int n_devices, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet,
+                                         const bsk_params *p, int n_streams, uint64_t chunk_records, int repeat, int fetch_tuples, bsk_pipeline_stats *stats) {
+    if (!bytes || !offsets || !n || repeat < 1 || !devices || n_devices < 1 || !stats) return BSK_ERR_ARG;
+    memset(stats, 0, sizeof *stats);
+    bsk_pipeline_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    cfg.devices = devices;
+    cfg.n_devices = n_devices;
+    cfg.n_streams = n_streams;
+    cfg.chunk_records = chunk_records;
+    cfg.sink = fetch_tuples == 2 ? BSK_SINK_SETS : fetch_tuples ? BSK_SINK_TUPLES : BSK_SINK_COUNTS;
+    cfg.sets_scale = 1;
+    cfg.alphabet = alphabet;
+    cfg.host_checksum = 1;
+    bsk_pipeline *pl = nullptr;
+    const int rc = bsk_pipeline_open_memory(&cfg, bytes, offsets, n, repeat, p, &pl);
+    if (rc != BSK_OK) return rc;
+    return run_pipeline(pl, stats);
+}
+extern "C" int bsk_pipeline_memory(int device, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int alphabet, const bsk_params *p,
+                                   int n_streams, uint64_t chunk_records, int repeat, int fetch_tuples, bsk_pipeline_stats *stats) {
+    return bsk_pipeline_memory_multi(&device, 1, bytes, offsets, n, alphabet, p, n_streams, chunk_records, repeat, fetch_tuples, stats);
+}
+
 extern "C" int bsk_pipeline_fastx_files(int device, const char *const *paths, int n_paths, int alphabet, const bsk_params *p, int n_streams, int n_readers,
                                         uint64_t chunk_records, int fetch_tuples, bsk_pipeline_stats *stats) {
     if (!paths || n_paths < 1 || n_readers < 0) return BSK_ERR_ARG;
-    FileSet set;
-    for (int i = 0; i < n_paths; ++i) {
-        if (!paths[i]) return BSK_ERR_ARG;
-        set.paths.emplace_back(paths[i]);
-    }
-    set.want_alpha = alphabet;
-    if (n_readers == 0) n_readers = std::min(n_paths, 8);
-    n_readers = std::min(n_readers, std::min(n_paths, 64));
-    const char *tv = getenv("BSK_FASTX_THREADS");
-    const int budget = tv && atoi(tv) > 0 ? atoi(tv) : std::max(1, (int)std::thread::hardware_concurrency() - n_streams - n_readers);
-    set.threads_per_file = std::max(1, std::min(budget, 12) / n_readers);
-    const int rc = run_pipeline(&device, 1, set, n_readers, p, n_streams, chunk_records, fetch_tuples, stats);
-    if (stats) {
-        stats->reader_threads = set.par_files ? set.threads_per_file : 0;
-        stats->reparsed_pieces = set.reparsed;
-    }
-    return rc;
+    return stats_run_files(&device, 1, paths, n_paths, alphabet, p, n_streams, n_readers, chunk_records, fetch_tuples, stats);
 }
 
 extern "C" void bsk_pipeline_trim(void) { pin_pool().trim(); }

@@ -25,6 +25,7 @@ struct bsk_sets {
     u64 n_sets = 0, n_values = 0;
     u64 *offsets = nullptr;  // [n_sets + 1]
     u64 *values = nullptr;   // [n_values] ascending inside a set
+    size_t c_offsets = 0, c_values = 0;  // bytes allocated (grow-only when the object is re-used: bsk_result_sets_reuse)
 };
 
 namespace {
@@ -585,7 +586,7 @@ extern "C" int bsk_result_compact(bsk_ctx *ctx, const bsk_result *r, const uint6
     if (r->pos) HIPCHK(ctx, pool(19, (T + 1) * 4, (void **)&op));
     lap("arrays");
     if (T) {
-        if (r->refs && !ctx->opt.no_group_gather && strstr(r->plan, "k_minimizer_ring"))  // unit rows
+        if (r->refs && !ctx->opt.no_group_gather && r->unit_rows)  // unit rows
             hipLaunchKernelGGL((k_gather_groups<false, true>), dim3(grid_of(ctx, n + 64, 1)), dim3(64), 0, st, r->hash, r->pos, r->refs, offs, n, oh, (void *)op,
                                (u32 *)nullptr, (u32 *)nullptr);
         else if (r->refs && !ctx->opt.no_group_gather)
@@ -674,7 +675,7 @@ extern "C" int bsk_result_fetch_narrow(bsk_ctx *ctx, const bsk_result *r, uint64
     if (T >= (1ULL << 32)) return fail_arg(ctx, "bsk_result_fetch_narrow: 2^32 tuples or more (fetch a smaller range)");
     HIPCHK(ctx, pool(13, (T + 1) * 8, (void **)&oh));
     if (pos) HIPCHK(ctx, pool(14, (T + 1) * 2, (void **)&op));
-    if (r->refs && !ctx->opt.no_group_gather && strstr(r->plan, "k_minimizer_ring"))  // unit rows
+    if (r->refs && !ctx->opt.no_group_gather && r->unit_rows)  // unit rows
         hipLaunchKernelGGL((k_gather_groups<true, true>), dim3(grid_of(ctx, count + 64, 1)), dim3(64), 0, st, r->hash, pos ? r->pos : nullptr, r->refs + first, offs,
                            count, oh, (void *)op, oo, reinterpret_cast<u32 *>(ctx->d_total + 3));
     else if (r->refs && !ctx->opt.no_group_gather)
@@ -706,13 +707,35 @@ extern "C" void bsk_sets_release(bsk_sets *s) {
     delete s;
 }
 
+static int sets_impl(bsk_ctx *ctx, const bsk_result *r, int scope, int scale, bsk_sets *reuse, bsk_sets **out);
 extern "C" int bsk_result_sets(bsk_ctx *ctx, const bsk_result *r, int scope, int scale, bsk_sets **out) {
-    if (!ctx || !r || !out) return fail_arg(ctx, "bsk_result_sets: null argument");
-    if (r->ctx != ctx) return fail_arg(ctx, "bsk_result_sets: result belongs to another context");
-    if (scope != BSK_SETS_PER_SEQUENCE && scope != BSK_SETS_WHOLE_BATCH) return fail_arg(ctx, "bsk_result_sets: bad scope");
-    if (scale < 0) return fail_arg(ctx, "bsk_result_sets: bad scale");
+    return sets_impl(ctx, r, scope, scale, nullptr, out);
+}
+// The same into an EXISTING sets object (*sets may be NULL the first time): its device arrays are kept and only grow, so a streaming
+// caller -- one chunk after the other through one object per stream -- allocates nothing in steady state (hipMalloc / hipFree
+// synchronise the whole device and would serialise the streams; bsk_batch_refill_ascii is the same idea for batches).  On error the
+// object is released and *sets is NULL.
+extern "C" int bsk_result_sets_reuse(bsk_ctx *ctx, const bsk_result *r, int scope, int scale, bsk_sets **sets) {
+    if (!sets) return fail_arg(ctx, "bsk_result_sets_reuse: null argument");
+    bsk_sets *old = *sets;
+    if (old && old->ctx != ctx) return fail_arg(ctx, "bsk_result_sets_reuse: the sets belong to another context");
+    *sets = nullptr;
+    return sets_impl(ctx, r, scope, scale, old, sets);
+}
+static int sets_impl(bsk_ctx *ctx, const bsk_result *r, int scope, int scale, bsk_sets *reuse, bsk_sets **out) {
+    if (!ctx || !r || !out) {
+        if (reuse) bsk_sets_release(reuse);
+        return fail_arg(ctx, "bsk_result_sets: null argument");
+    }
     *out = nullptr;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (r->ctx != ctx || (scope != BSK_SETS_PER_SEQUENCE && scope != BSK_SETS_WHOLE_BATCH) || scale < 0) {
+        if (reuse) bsk_sets_release(reuse);
+        return fail_arg(ctx, r->ctx != ctx ? "bsk_result_sets: result belongs to another context" : scale < 0 ? "bsk_result_sets: bad scale" : "bsk_result_sets: bad scope");
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        if (reuse) bsk_sets_release(reuse);
+        return fail_arg(ctx, "bsk_result_sets: hipSetDevice");
+    }
     const u64 n = r->n;
     const u64 maxhash = scale > 1 ? ~0ULL / (u64)scale : ~0ULL;
     const u64 n_sets = scope == BSK_SETS_WHOLE_BATCH ? 1 : n;
@@ -721,10 +744,20 @@ extern "C" int bsk_result_sets(bsk_ctx *ctx, const bsk_result *r, int scope, int
     u8 *head = nullptr;
     u32 *keep = nullptr;
     void *tmp = nullptr;
-    bsk_sets *res = nullptr;
+    bsk_sets *res = reuse;
     auto done = [&](int code) {
         if (code != BSK_OK && res) bsk_sets_release(res);
         return code;
+    };
+    auto grow = [&](u64 **p, size_t *cap, size_t bytes) -> hipError_t {  // the sets' own arrays: grow-only
+        if (*cap >= bytes && *p) return hipSuccess;
+        (void)hipFree(*p);
+        *p = nullptr;
+        *cap = 0;
+        const size_t want = reuse ? bytes + bytes / 4 + 256 : bytes;
+        const hipError_t e = hipMalloc(p, want);
+        if (e == hipSuccess) *cap = want;
+        return e;
     };
 #define SCHK(call)                                                  \
     do {                                                            \
@@ -760,12 +793,13 @@ extern "C" int bsk_result_sets(bsk_ctx *ctx, const bsk_result *r, int scope, int
         ctx->err = "bsk_result_sets: more than 2^32 values in one call (split the batch)";
         return done(BSK_ERR_UNSUPPORTED);
     }
-    res = new (std::nothrow) bsk_sets();
+    if (!res) res = new (std::nothrow) bsk_sets();
     if (!res) return done(BSK_ERR_NOMEM);
     res->ctx = ctx;
     res->n_sets = n_sets;
-    SCHK(hipMalloc(&res->offsets, (n_sets + 1) * 8));
-    SCHK(hipMalloc(&res->values, (N ? N : 1) * 8));
+    res->n_values = 0;
+    SCHK(grow(&res->offsets, &res->c_offsets, (n_sets + 1) * 8));
+    SCHK(grow(&res->values, &res->c_values, (N ? N : 1) * 8));
     if (N == 0) {
         SCHK(hipMemsetAsync(res->offsets, 0, (n_sets + 1) * 8, st));
         SCHK(hipStreamSynchronize(st));
@@ -853,6 +887,37 @@ extern "C" int bsk_sets_device(const bsk_sets *s, const uint64_t **offsets, cons
     if (!s) return BSK_ERR_ARG;
     if (offsets) *offsets = (const uint64_t *)s->offsets;
     if (values) *values = (const uint64_t *)s->values;
+    return BSK_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void k_offsets_u32(const u64 *in, u64 n1, u32 *out) {
+    for (u64 i = blockIdx.x * 256ull + threadIdx.x; i < n1; i += (u64)gridDim.x * 256ull) out[i] = (u32)in[i];
+}
+}  // namespace
+// All sets of `s` to the host in the narrow form of bsk_result_fetch_narrow: u32 offsets[n_sets + 1] (narrowed on the device; a call
+// holds fewer than 2^32 values) and the values, both copied on the context's stream straight into the caller's buffers -- pinned ones
+// make the copies asynchronous to the other streams of a pipeline.  4 bytes per set + 8 per value over the link.
+extern "C" int bsk_sets_fetch_narrow(bsk_ctx *ctx, const bsk_sets *s, uint32_t *offsets, uint64_t *values, uint64_t value_cap) {
+    if (!ctx || !s || !offsets) return fail_arg(ctx, "bsk_sets_fetch_narrow: null argument");
+    if (s->ctx != ctx) return fail_arg(ctx, "bsk_sets_fetch_narrow: the sets belong to another context");
+    if (values && s->n_values > value_cap) return fail_arg(ctx, "bsk_sets_fetch_narrow: value_cap too small");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t need = (s->n_sets + 1) * 4;
+    if (ctx->tmp_cap[20] < need) {
+        (void)hipFree(ctx->tmp[20]);
+        ctx->tmp[20] = nullptr;
+        ctx->tmp_cap[20] = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->tmp[20], need + need / 4 + 256));
+        ctx->tmp_cap[20] = need + need / 4 + 256;
+    }
+    u32 *o32 = (u32 *)ctx->tmp[20];
+    hipLaunchKernelGGL(k_offsets_u32, dim3((unsigned)std::max<u64>(1, std::min<u64>((s->n_sets + 256) / 256, (u64)ctx->cus * 8))), dim3(256), 0, ctx->stream, s->offsets,
+                       s->n_sets + 1, o32);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(offsets, o32, need, hipMemcpyDeviceToHost, ctx->stream));
+    if (values && s->n_values) HIPCHK(ctx, hipMemcpyAsync(values, s->values, s->n_values * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return BSK_OK;
 }
 

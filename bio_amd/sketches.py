@@ -256,7 +256,7 @@ class Engine:
         """The library reads its developer switches (BSK_*) once per context; the test suite flips them inside one process, so this
         mirror reloads them (bsk_ctx_reload_options) when the environment changed since the last call.  Only when BSK_PY_WATCH_ENV
         is set (tests/conftest.py sets it): a production caller pays no scan of its environment per call and uses reload_options()."""
-        if not Engine._watch_env:
+        if not (Engine._watch_env or os.environ.get("BSK_PY_WATCH_ENV")):  # (one dict lookup: set at any time, not only before import)
             return
         now = self._opts_env()
         if now != self._opts_seen:
@@ -330,6 +330,13 @@ class Engine:
         if rc != L.OK:
             raise _SENTINELS.get(rc) or DeviceError(f"bsk_pipeline_fastx_multi: {lib.bsk_err_name(rc).decode()}")
         return st.asdict()
+
+    @staticmethod
+    def pipeline_open(params, *, paths=None, data: np.ndarray = None, offsets: np.ndarray = None, devices=(0,), n_streams: int = 2,
+                      chunk_records: int = 1 << 18, sink: int = L.SINK_TUPLES, sets_scale: int = 1, alphabet: int = -1, repeat: int = 1,
+                      host_checksum: bool = False, n_readers: int = 0) -> "Pipeline":
+        """bsk_pipeline_open_fastx / _memory: the pipeline with a consumer (the role of fastx's ChunkChan, seqio/fastx/reader.go:562-608)."""
+        return Pipeline(params, paths, data, offsets, devices, n_streams, chunk_records, sink, sets_scale, alphabet, repeat, host_checksum, n_readers)
 
     @staticmethod
     def pipeline_trim() -> None:
@@ -538,6 +545,110 @@ class ProteinIterator(_Cursor):
 class ProteinMinimizerSketch(_Cursor):
     def Next(self):  # sketch-protein.go:106
         return self._next()
+
+
+class ChunkView:
+    """One chunk of a Pipeline: numpy views over the pipeline's pinned arrays, valid until the next chunk is taken (copy what you keep)."""
+
+    def __init__(self, c: L.Chunk):
+        self.sequence, self.source_index, self.device = c.sequence, c.source_index, c.device
+        self.first_record, self.n_records, self.n_bases, self.n_tuples, self.n_values = c.first_record, c.n_records, c.n_bases, c.n_tuples, c.n_values
+        self.checksum, self.link_bytes, self.sink, self.has_pos = c.checksum, c.link_bytes, c.sink, bool(c.has_pos)
+        n, nv = int(c.n_records), int(c.n_values)
+
+        def view(ptr, count, dtype):
+            if not ptr or count == 0:
+                return None if not ptr else np.empty(0, dtype)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(count,))
+
+        self.status = view(c.status, n, np.uint8)
+        if c.offsets32:
+            self.offsets = view(c.offsets32, n + 1, np.uint32)
+        else:
+            self.offsets = view(c.offsets64, n + 1, np.uint64)
+        self.hash = view(c.hash, nv, np.uint64) if c.hash else None
+        self.pos = None
+        self.strand = None
+        if c.pos16 and nv:
+            p16 = view(c.pos16, nv, np.uint16)
+            self.pos = (p16 & 0x7FFF).astype(np.uint32)
+            self.strand = (p16 >> 15).astype(np.uint8)
+        elif c.pos32 and nv:
+            p32 = view(c.pos32, nv, np.uint32)
+            self.pos = p32 & L.POS_MASK
+            self.strand = (p32 >> 31).astype(np.uint8)
+
+
+class Pipeline:
+    """bsk_pipeline: sketches of every chunk of the input, delivered in input order (include/biosketch.h, "the pipeline with a consumer").
+
+        with Engine.pipeline_open(params, paths=["reads.fq"], sink=L.SINK_SETS, sets_scale=100) as pl:
+            for chunk in pl.chunks():
+                ...chunk.offsets / chunk.hash / chunk.pos / chunk.status...
+        pl.stats
+    """
+
+    def __init__(self, params, paths, data, offsets, devices, n_streams, chunk_records, sink, sets_scale, alphabet, repeat, host_checksum, n_readers):
+        self.lib = L.load()
+        self._dev = (C.c_int * len(devices))(*devices)
+        cfg = L.PipelineConfig(self._dev, len(devices), n_streams, chunk_records, sink, sets_scale, alphabet, 1 if host_checksum else 0, n_readers, 0)
+        self.h = C.c_void_p()
+        self._keep = (data, offsets, params)
+        if paths is not None:
+            arr = (C.c_char_p * len(paths))(*[p.encode() for p in paths])
+            rc = self.lib.bsk_pipeline_open_fastx(C.byref(cfg), arr, len(paths), C.byref(params), C.byref(self.h))
+        else:
+            data = np.ascontiguousarray(data, dtype=np.uint8)
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+            self._keep = (data, offsets, params)
+            rc = self.lib.bsk_pipeline_open_memory(C.byref(cfg), data.ctypes.data, offsets.ctypes.data, len(offsets) - 1, repeat, C.byref(params), C.byref(self.h))
+        if rc != L.OK:
+            self.h = C.c_void_p()
+            raise _SENTINELS.get(rc) or DeviceError(f"bsk_pipeline_open: {self.lib.bsk_err_name(rc).decode()}")
+        self.stats = None
+        self._held = None
+
+    def next(self) -> Optional[ChunkView]:
+        """The next chunk in input order, None at the end.  Releases the chunk handed out before."""
+        self._release()
+        c = C.POINTER(L.Chunk)()
+        rc = self.lib.bsk_pipeline_next(self.h, C.byref(c))
+        if rc != L.OK:
+            msg = self.lib.bsk_pipeline_error(self.h).decode()
+            raise _SENTINELS.get(rc) or DeviceError(f"bsk_pipeline_next: {self.lib.bsk_err_name(rc).decode()}: {msg}")
+        if not c:
+            return None
+        self._held = c
+        return ChunkView(c.contents)
+
+    def _release(self):
+        if self._held is not None:
+            self.lib.bsk_pipeline_release(self.h, self._held)
+            self._held = None
+
+    def chunks(self):
+        while True:
+            c = self.next()
+            if c is None:
+                return
+            yield c
+
+    def close(self):
+        if self.h:
+            self._release()
+            st = L.PipelineStats()
+            rc = self.lib.bsk_pipeline_close(self.h, C.byref(st))
+            self.h = C.c_void_p()
+            self.stats = st.asdict()
+            if rc not in (L.OK, -1):
+                raise _SENTINELS.get(rc) or DeviceError(f"bsk_pipeline_close: {self.lib.bsk_err_name(rc).decode()}")
+        return self.stats
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 def _single(seq: Seq, p: L.Params, alphabet: int, eng: Optional[Engine]):

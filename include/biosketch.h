@@ -271,6 +271,8 @@ int bsk_result_plan(const bsk_result *r, const char **kernel, int *grid, int *wa
 int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t first, uint64_t count,
                      uint64_t *offsets, uint8_t *status, uint64_t *hash, uint32_t *pos,
                      uint64_t tuple_cap);
+/* The status bytes of reads [first, first+count) alone. */
+int bsk_result_fetch_status(bsk_ctx *ctx, const bsk_result *r, uint64_t first, uint64_t count, uint8_t *status);
 /* The same with narrow side arrays, for streaming callers that move every tuple over the link (bsk_pipeline_*): offsets[count+1] as
  * u32 (scanned on the device: no round trip for the reference words), positions as u16 -- 15 bits + the strand in bit 15
  * (BSK_POS16_STRAND_BIT) -- i.e. 10 bytes per tuple + 5 per read instead of 12 + 17.  BSK_ERR_UNSUPPORTED when a position needs
@@ -353,6 +355,65 @@ int bsk_pipeline_memory_multi(const int *devices, int n_devices, const uint8_t *
 int bsk_pipeline_fastx_files(int device, const char *const *paths, int n_paths, int alphabet, const bsk_params *p, int n_streams, int n_readers,
                              uint64_t chunk_records, int fetch_tuples, bsk_pipeline_stats *stats);
 
+/* ---- the pipeline with a consumer ----------------------------------------------------------------------------------------------
+ * What fastx's ChunkChan is to the reference's callers (seqio/fastx/reader.go:562-608: every chunk of records, in input order, handed to
+ * whoever ranges over the channel) with the sketching done on the way: open a pipeline over a source, then
+ *     for (;;) { bsk_pipeline_next(pl, &c); if (!c) break;  ... use c ...;  bsk_pipeline_release(pl, c); }   bsk_pipeline_close(pl, &stats);
+ * Chunks arrive in the order the producer queued them (= record order for one source); a chunk's arrays live in pinned host memory of the
+ * pipeline until the chunk is released (the pool of output buffers is bounded: a consumer that holds 2 * workers + 2 chunks stalls the run).
+ * sink selects what crosses the link for every chunk:
+ *   BSK_SINK_TUPLES  every tuple, as bsk_result_fetch_narrow delivers it (offsets32 / pos16; offsets64 / pos32 when a chunk holds a read
+ *                    of 32 768 bases or more, or 2^32 tuples) -- record i of the chunk owns hash[offsets[i] .. offsets[i+1]) in Next() order;
+ *   BSK_SINK_SETS    the on-device reduction of bsk_result_sets: per record the ascending distinct hash values with hash <= MaxUint64 /
+ *                    sets_scale (iterator.go:181-185; sets_scale <= 1: no filter) -- offsets32 + hash, n_values values;
+ *   BSK_SINK_COUNTS  nothing but the counts and the device-side digest (bsk_result_digest) in `checksum`.
+ * host_checksum != 0: the worker also folds what it fetched into `checksum` (tuples: the order-independent sum of bsk_result_digest; sets:
+ * the sum of the values) -- the statistics-only entry points bsk_pipeline_fastx / _memory use this.
+ * bsk_pipeline_next blocks until the next chunk is ready; *chunk == NULL with BSK_OK is the end of the input.  One consumer thread at a
+ * time.  bsk_pipeline_close may be called at any point (it stops the run) and frees the pipeline; stats may be NULL. */
+typedef struct bsk_pipeline bsk_pipeline;
+enum { BSK_SINK_COUNTS = 0, BSK_SINK_TUPLES = 1, BSK_SINK_SETS = 2 };
+typedef struct bsk_pipeline_config {
+    const int *devices;      /* the GPUs of the run (a device may be named more than once) */
+    int32_t n_devices;
+    int32_t n_streams;       /* workers (context + HIP stream) per device */
+    uint64_t chunk_records;  /* records per chunk (0: the reader's default) */
+    int32_t sink;            /* BSK_SINK_* */
+    int32_t sets_scale;      /* BSK_SINK_SETS: FracMinHash scale */
+    int32_t alphabet;        /* bsk_alphabet, -1: guess from the first record (files) */
+    int32_t host_checksum;
+    int32_t n_readers;       /* several files: how many are read at the same time (0: min(n_paths, 8); chunk order = queue order) */
+    int32_t reserved;
+} bsk_pipeline_config;
+typedef struct bsk_chunk {
+    uint64_t sequence;       /* 0, 1, 2 ...: the delivery order */
+    int32_t source_index;    /* which of the run's files */
+    int32_t device;          /* the GPU that sketched it */
+    uint64_t first_record;   /* index of the chunk's first record in its source */
+    uint64_t n_records, n_bases, n_tuples;
+    uint64_t n_values;       /* entries of hash[]: n_tuples (TUPLES), distinct filtered values (SETS), 0 (COUNTS) */
+    uint64_t checksum;
+    uint64_t link_bytes;     /* bytes this chunk's output moved device -> host */
+    int32_t sink, has_pos;
+    const uint32_t *offsets32; /* [n_records + 1], or NULL when offsets64 is set */
+    const uint64_t *offsets64;
+    const uint8_t *status;     /* [n_records] BSK_ST_* */
+    const uint64_t *hash;
+    const uint16_t *pos16;     /* TUPLES with positions: BSK_POS16_* encoding; NULL for implicit positions / SETS / when pos32 is set */
+    const uint32_t *pos32;
+    void *opaque;
+} bsk_chunk;
+int bsk_pipeline_open_fastx(const bsk_pipeline_config *cfg, const char *const *paths, int n_paths, const bsk_params *p, bsk_pipeline **out);
+int bsk_pipeline_open_memory(const bsk_pipeline_config *cfg, const uint8_t *bytes, const uint64_t *offsets, uint64_t n, int repeat,
+                             const bsk_params *p, bsk_pipeline **out);
+int bsk_pipeline_next(bsk_pipeline *pl, const bsk_chunk **chunk);
+int bsk_pipeline_release(bsk_pipeline *pl, const bsk_chunk *chunk);
+int bsk_pipeline_close(bsk_pipeline *pl, bsk_pipeline_stats *stats);
+const char *bsk_pipeline_error(const bsk_pipeline *pl);
+/* next / on_chunk / release until the end (or until on_chunk returns non-zero), then close: the callback form of the loop above. */
+typedef int (*bsk_chunk_fn)(void *user, const bsk_chunk *chunk);
+int bsk_pipeline_run(bsk_pipeline *pl, bsk_chunk_fn on_chunk, void *user, bsk_pipeline_stats *stats);
+
 /* The pipelines keep their pinned host buffers in a process-wide pool between calls (pinning is the start-up cost of a run:
  * pin_seconds); this returns the pooled memory to the system.  Safe at any time; buffers of a running pipeline are not affected. */
 void bsk_pipeline_trim(void);
@@ -386,6 +447,12 @@ void bsk_comm_destroy(bsk_ctx *ctx);
 typedef struct bsk_sets bsk_sets;
 enum { BSK_SETS_PER_SEQUENCE = 0, BSK_SETS_WHOLE_BATCH = 1 };
 int bsk_result_sets(bsk_ctx *ctx, const bsk_result *r, int scope, int scale, bsk_sets **out);
+/* The same into an existing object (*sets may be NULL the first time): the device arrays are kept and only grow -- a streaming caller
+ * allocates nothing in steady state.  On error the object is released and *sets is NULL. */
+int bsk_result_sets_reuse(bsk_ctx *ctx, const bsk_result *r, int scope, int scale, bsk_sets **sets);
+/* All sets to the host in narrow form: u32 offsets[n_sets + 1] (narrowed on the device) + the values, copied on the context's stream
+ * (4 bytes per set + 8 per value over the link). */
+int bsk_sets_fetch_narrow(bsk_ctx *ctx, const bsk_sets *s, uint32_t *offsets, uint64_t *values, uint64_t value_cap);
 int bsk_sets_info(const bsk_sets *s, uint64_t *n_sets, uint64_t *n_values);
 int bsk_sets_fetch(bsk_ctx *ctx, const bsk_sets *s, uint64_t first, uint64_t count, uint64_t *offsets, uint64_t *values,
                    uint64_t value_cap);

@@ -277,3 +277,152 @@ def test_host_packed_chunks_equal_ascii_chunks(engine, monkeypatch):
         got = S.BatchResult(engine, *_run(engine, h, p)).digest()
         assert got == engine.run(engine.batch_from_arrays(dd, oo), p).digest(), (i, packed)
     lib.bsk_batch_destroy(h)
+
+
+# ---- the pipeline with a consumer (bsk_pipeline_open_* / _next / _release / _close) ---------------------------------------------------
+def _all_devices():
+    n = C.c_int()
+    L.load().bsk_device_count(C.byref(n))
+    return list(range(max(1, n.value)))
+
+
+def _collect(pl):
+    """every chunk of the run, copied, in delivery order"""
+    out = []
+    for c in pl.chunks():
+        out.append(dict(seq=c.sequence, first=c.first_record, n=c.n_records, src=c.source_index, offsets=c.offsets.astype(np.uint64).copy(), status=c.status.copy(),
+                        hash=None if c.hash is None else c.hash.copy(), pos=None if c.pos is None else c.pos.copy(),
+                        strand=None if c.strand is None else c.strand.copy(), link=c.link_bytes, n_tuples=c.n_tuples, n_values=c.n_values))
+    return out
+
+
+@pytest.mark.parametrize("devices", ["one", "twice", "all"])
+@pytest.mark.parametrize("kind,pk", [(L.MINIMIZER, dict(k=21, w=11)), (L.SYNCMER, dict(k=31, s=11)), (L.NTHASH, dict(k=21))])
+def test_sink_delivers_every_tuple_in_record_order(engine, devices, kind, pk):
+    """What the sink hands out, chunk after chunk, is bsk_result_fetch of the same records of ONE big batch: same offsets, status bytes,
+    hashes, positions and strands, in input order -- on one device, on one device named twice (the n > 1 code on a 1-GPU box) and on all."""
+    devs = {"one": [0], "twice": [0, 0], "all": _all_devices()}[devices]
+    n = 40_000
+    data, offs = make_reads(n, 21)
+    p = engine.params(kind, **pk)
+    whole = engine.run(engine.batch_from_arrays(data, offs), p)
+    w_off, w_st, w_h, w_p = whole.fetch()
+    with S.Engine.pipeline_open(p, data=data, offsets=offs, devices=devs, n_streams=2, chunk_records=3001, sink=L.SINK_TUPLES, alphabet=L.ALPHA_DNA) as pl:
+        chunks = _collect(pl)
+    st = pl.stats
+    assert [c["seq"] for c in chunks] == list(range(len(chunks))) and len(chunks) == -(-n // 3001)
+    at = 0
+    for c in chunks:
+        assert c["first"] == at and c["src"] == 0
+        m = c["n"]
+        a, b = int(w_off[at]), int(w_off[at + m])
+        assert np.array_equal(c["offsets"], w_off[at:at + m + 1] - w_off[at]), c["seq"]
+        assert np.array_equal(c["status"], w_st[at:at + m])
+        assert np.array_equal(c["hash"], w_h[a:b])
+        if w_p is not None:
+            assert np.array_equal(c["pos"], w_p[a:b] & L.POS_MASK) and np.array_equal(c["strand"], (w_p[a:b] >> 31).astype(np.uint8))
+        else:
+            assert c["pos"] is None
+        at += m
+    assert at == n and st["records"] == n and st["tuples"] == int(w_off[-1]) and st["n_streams"] == 2 * len(devs)
+
+
+@pytest.mark.parametrize("scale", [1, 100])
+def test_sink_sets_mode_equals_result_sets(engine, scale):
+    """BSK_SINK_SETS: per record the ascending distinct values with hash <= MaxUint64 / scale (iterator.go:181-185) -- what bsk_result_sets
+    gives for one big batch, and what numpy gives from the fetched tuples."""
+    n = 30_000
+    data, offs = make_reads(n, 22)
+    p = engine.params(L.MINIMIZER, 21, w=11)
+    whole = engine.run(engine.batch_from_arrays(data, offs), p)
+    s_off, s_val = whole.sets(scale=scale)
+    w_off, _, w_h, _ = whole.fetch()
+    with S.Engine.pipeline_open(p, data=data, offsets=offs, devices=[0, 0], n_streams=2, chunk_records=4096, sink=L.SINK_SETS, sets_scale=scale, alphabet=L.ALPHA_DNA) as pl:
+        chunks = _collect(pl)
+    at = 0
+    link = 0
+    for c in chunks:
+        m = c["n"]
+        assert c["first"] == at
+        assert np.array_equal(c["offsets"], s_off[at:at + m + 1] - s_off[at])
+        assert np.array_equal(c["hash"], s_val[int(s_off[at]):int(s_off[at + m])])
+        assert c["n_values"] == int(s_off[at + m] - s_off[at]) and c["pos"] is None
+        link += c["link"]
+        at += m
+    assert at == n
+    lim = np.uint64(0xFFFFFFFFFFFFFFFF // scale)
+    for r in (0, 1, 77, n - 1):  # the definition itself, from the tuples
+        v = np.unique(w_h[int(w_off[r]):int(w_off[r + 1])])
+        assert np.array_equal(v[v <= lim], s_val[int(s_off[r]):int(s_off[r + 1])])
+    assert link == 5 * n + 8 * int(s_off[-1])  # what crossed the link: u32 offsets + status bytes + the surviving values
+    if scale == 100:  # the reduction is the point (window minima are small hashes: ~11 % of them pass hash <= max / 100, not 1 %)
+        assert link < 0.25 * (10 * int(w_off[-1]) + 5 * n)
+
+
+def test_sink_over_files_and_early_close(engine, tmp_path):
+    """Files (plain: host-packed chunks of the block-parallel reader; gzip: the serial reader) through the sink; a consumer that stops early
+    closes cleanly; the callback form (bsk_pipeline_run) sees the same chunks."""
+    n = 25_000
+    data, offs = make_reads(n, 23, with_n=False)
+    p = engine.params(L.MINIMIZER, 21, w=11)
+    whole = engine.run(engine.batch_from_arrays(data, offs), p)
+    w_off, w_st, w_h, w_p = whole.fetch()
+    paths = []
+    for gz in (False, True):
+        path = str(tmp_path / ("r.fq.gz" if gz else "r.fq"))
+        write_fastq(path, data, offs, gz)
+        paths.append(path)
+    for path in paths:
+        with S.Engine.pipeline_open(p, paths=[path], devices=[0], n_streams=3, chunk_records=2500, sink=L.SINK_TUPLES) as pl:
+            chunks = _collect(pl)
+        assert sum(c["n"] for c in chunks) == n
+        assert np.array_equal(np.concatenate([c["hash"] for c in chunks]), w_h[: int(w_off[-1])])
+        assert np.array_equal(np.concatenate([c["pos"] for c in chunks]), w_p[: int(w_off[-1])] & L.POS_MASK)
+        assert [c["first"] for c in chunks] == list(np.cumsum([0] + [c["n"] for c in chunks[:-1]]))
+    # two files, one reader: file 0's chunks, then file 1's, every file counted from its own record 0
+    with S.Engine.pipeline_open(p, paths=paths, devices=[0], n_streams=2, chunk_records=6000, sink=L.SINK_COUNTS, n_readers=1) as pl:
+        chunks = _collect(pl)
+    assert [c["src"] for c in chunks] == sorted(c["src"] for c in chunks) and {c["src"] for c in chunks} == {0, 1}
+    assert sum(c["n_tuples"] for c in chunks) == 2 * int(w_off[-1]) and all(c["hash"] is None for c in chunks)
+    # early close
+    pl = S.Engine.pipeline_open(p, data=data, offsets=offs, devices=[0], n_streams=2, chunk_records=1000, sink=L.SINK_TUPLES, alphabet=L.ALPHA_DNA, repeat=50)
+    first = pl.next()
+    assert first.sequence == 0 and first.n_records == 1000
+    st = pl.close()
+    assert st["seconds"] > 0
+    # the callback form
+    lib = L.load()
+    seen = []
+
+    def on_chunk(user, cptr):
+        c = cptr.contents
+        seen.append((c.sequence, c.first_record, c.n_records, c.n_tuples))
+        return 0
+
+    dev = (C.c_int * 1)(0)
+    cfg = L.PipelineConfig(dev, 1, 2, 5000, L.SINK_TUPLES, 1, L.ALPHA_DNA, 0, 0, 0)
+    h = C.c_void_p()
+    d8, o64 = np.ascontiguousarray(data, np.uint8), np.ascontiguousarray(offs, np.uint64)
+    assert lib.bsk_pipeline_open_memory(C.byref(cfg), d8.ctypes.data, o64.ctypes.data, n, 1, C.byref(p), C.byref(h)) == L.OK
+    stats = L.PipelineStats()
+    cb = L.CHUNK_FN(on_chunk)
+    assert lib.bsk_pipeline_run(h, cb, None, C.byref(stats)) == L.OK
+    assert [s[0] for s in seen] == list(range(5)) and sum(s[2] for s in seen) == n and sum(s[3] for s in seen) == int(w_off[-1]) == stats.tuples
+
+
+def test_timed_rerun_needs_the_sized_plan(engine):
+    """bsk_sketch_timed on an existing result repeats the plan the result was SIZED for -- and refuses another batch or other parameters
+    (a fresh plan could write past the arrays: ADVICE round 4)."""
+    b1 = engine.synth(L.ALPHA_DNA, 20_000, 150, 7)
+    b2 = engine.synth(L.ALPHA_DNA, 20_000, 250, 7)
+    p = engine.params(L.MINIMIZER, 21, w=11)
+    res, ms = engine.run_timed(b1, p, 1, 2)
+    want = res.digest()
+    ms2 = (C.c_float * 2)()
+    h = C.c_void_p(res.h.value if hasattr(res.h, "value") else res.h)
+    assert engine.lib.bsk_sketch_timed(engine.ctx, b1.h, C.byref(p), C.byref(h), 0, 2, ms2) == L.OK
+    assert res.digest() == want
+    assert engine.lib.bsk_sketch_timed(engine.ctx, b2.h, C.byref(p), C.byref(h), 0, 2, ms2) == L.ERR_ARG
+    p2 = engine.params(L.MINIMIZER, 21, w=9)
+    assert engine.lib.bsk_sketch_timed(engine.ctx, b1.h, C.byref(p2), C.byref(h), 0, 2, ms2) == L.ERR_ARG
+    assert res.digest() == want
