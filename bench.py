@@ -159,6 +159,40 @@ def end_to_end(kind: str, p, batch, read_len: int, n_streams: int = 5):
                                    "(DESIGN.md 4; r03 moved 158 + 282 and reached 16.7 Gbases/s)" % (
                                        (read_len + 3) // 4 + 8 if not alpha else read_len + 8, read_len + 8,
                                        ((10.0 if kind not in STREAM else 8.0) * st["tuples"] / max(st["records"], 1) + 5))}
+    # the pipeline WITH a consumer (bsk_pipeline_open_memory / _next / _release: every chunk delivered in record order, the role of fastx's
+    # ChunkChan, seqio/fastx/reader.go:562-608).  The consumer here touches every chunk's counts and one value per chunk -- a real one
+    # does its own work on its own thread while the workers run ahead (2 x workers + 2 output buffers).
+    def sink_run(sink, scale_):
+        import time as _t
+        t0 = _t.perf_counter()
+        seen = vals = link = recs = 0
+        order_ok = True
+        with S.Engine.pipeline_open(p, data=data, offsets=offs, devices=[0], n_streams=n_mem_streams, chunk_records=1 << 18, sink=sink, sets_scale=scale_,
+                                    alphabet=alpha, repeat=2) as pl:
+            for c in pl.chunks():
+                order_ok &= c.sequence == seen
+                seen += 1
+                recs += c.n_records
+                vals += c.n_values
+                link += c.link_bytes
+                if c.n_values:
+                    _ = int(c.hash[0]) + int(c.offsets[-1])
+        stx = pl.stats
+        return {"value": round(stx["bases"] / stx["seconds"] / 1e9, 3), "unit": "Gresidues/s" if alpha else "Gbases/s", "reads": recs, "chunks": seen,
+                "delivered_in_order": bool(order_ok), "values_delivered": vals, "d2h_bytes_per_read": round(link / max(recs, 1), 2),
+                "h2d_bytes_per_read": (read_len + 3) // 4 + 8 if not alpha else read_len + 8, "seconds": round(stx["seconds"], 4),
+                "stage_seconds_summed_over_streams": {k_: round(stx[k_], 4) for k_ in ("h2d_pack_seconds", "kernel_seconds", "fetch_seconds")}}
+    try:
+        from bio_amd import _lib as _L
+        out["from_memory_to_sink"] = {"what": "bsk_pipeline_open_memory + bsk_pipeline_next / _release: chunks delivered to the caller in record order",
+                                      "tuples": sink_run(_L.SINK_TUPLES, 1)}
+        if kind not in STREAM:
+            out["from_memory_to_sink"]["sets_scale_1"] = sink_run(_L.SINK_SETS, 1)
+            out["from_memory_to_sink"]["sets_scale_100"] = sink_run(_L.SINK_SETS, 100)
+            out["from_memory_to_sink"]["sets_note"] = ("BSK_SINK_SETS: per read the ascending distinct hashes with hash <= MaxUint64 / scale (iterator.go:181-185), reduced on "
+                                                       "the device; scale 1 still moves ~8 B per distinct value, scale 100 moves what a FracMinHash consumer keeps")
+    except Exception as e:  # the line must not be lost to this section
+        out["from_memory_to_sink"] = {"error": repr(e)}
     # the same reads as files: fixed-width names, constant qualities
     rec = 12 + read_len + (3 + read_len if not alpha else 0)
     import shutil

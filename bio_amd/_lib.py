@@ -126,6 +126,7 @@ SYMBOLS = [
     ("bsk_gather_counts_all", C.c_int, [_pp, C.c_int, _vp, C.c_int, _vp]),
     ("bsk_comm_destroy", None, [_vp]),
     ("bsk_result_plan", C.c_int, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("bsk_result_class_plan", C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     ("bsk_result_info", C.c_int, [_vp, _u64p, _u64p, C.POINTER(C.c_int)]),
     ("bsk_result_fetch", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp, C.c_uint64]),
     ("bsk_result_fetch_narrow", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, _vp, _vp, _vp, C.c_uint64, _u64p]),

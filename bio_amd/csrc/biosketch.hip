@@ -10,8 +10,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "biosketch.h"
@@ -106,6 +108,96 @@ __global__ __launch_bounds__(64) void k_compact_flags(const u8 *rflags, u64 n, u
         const u64 m = __ballot(f);
         const u64 base = lookback_exclusive(lookback, unit, (u64)__builtin_popcountll(m), lane);
         if (f) subset[base + __builtin_popcountll(m & ((1ULL << lane) - 1))] = (u32)r;
+    }
+}
+// Class plans (run_classed): ONE pass over the descriptors cuts the batch -- every read of a class other than the bulk is appended to its
+// class's list with its descriptor next to it (the class then runs as a batch of its own over the parent's words), and the BULK's view of
+// the batch is written: a read of another class keeps its place and its first word and PRETENDS the bulk's length -- `pretend` bases when
+// every read of the bulk has that length (the view stays a fixed-length batch: the kernels' fast paths; what the bulk's kernel makes of
+// such a read's first bases is overwritten by the part that owns it; reading past a shorter read stays inside words[]: pad_words), 0 bases
+// otherwise (an empty SHORT entry).  A ticket is 16 rows of 64 reads; a class's place in its list comes from ONE atomic per ticket and
+// class present (a decoupled look-back per class and ticket was latency-bound: 0.6-0.9 ms per class for 4 10^7 reads).  The lists are in
+// arrival order: which slab of a part a read gets may differ from run to run, what it holds does not.
+struct ClassCuts {
+    u32 hi[8];     // class c takes the lengths (hi[c-1], hi[c]]
+    u32 first[8];  // where class c's list starts in list[] / sdesc[] (exact counts are known on the host: LenHist)
+    u32 ncls, bulk, pretend, pad;
+};
+__device__ __forceinline__ u32 class_of(const ClassCuts &cc, u32 len) {
+    u32 c = 0;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) c += (q + 1 < (int)cc.ncls && len > cc.hi[q]) ? 1u : 0u;
+    return c;
+}
+__global__ __launch_bounds__(64) void k_class_cut(const u64 *desc, u64 n, u32 nblocks, ClassCuts cc, u32 *ticket, u32 *cursor, u32 *list, u64 *sdesc, u64 *view) {
+    constexpr int ROWS = 16;
+    const int lane = lane_id();
+    for (;;) {
+        const u32 blk = next_ticket(ticket, lane);
+        if (blk >= nblocks) break;
+        const u64 r0 = (u64)blk * ROWS * 64 + lane;
+        u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;  // reads per class in this ticket (wave-uniform)
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const u64 r = r0 + (u64)j * 64;
+            const u64 d = r < n ? desc[r] : 0;
+            const u32 c = r < n ? class_of(cc, (u32)(d & 0xffffffULL)) : cc.bulk;
+            if (r < n) view[r] = c == cc.bulk ? d : ((d & ~0xffffffULL) | cc.pretend);
+            if (__ballot(c != cc.bulk)) {  // (rare for outlier classes: most rows are all bulk)
+                any = true;
+                c0 += (u32)__builtin_popcountll(__ballot(c == 0u));
+                c1 += (u32)__builtin_popcountll(__ballot(c == 1u));
+                c2 += (u32)__builtin_popcountll(__ballot(c == 2u));
+                c3 += (u32)__builtin_popcountll(__ballot(c == 3u));
+                c4 += (u32)__builtin_popcountll(__ballot(c == 4u));
+                c5 += (u32)__builtin_popcountll(__ballot(c == 5u));
+                c6 += (u32)__builtin_popcountll(__ballot(c == 6u));
+                c7 += (u32)__builtin_popcountll(__ballot(c == 7u));
+            }
+        }
+        if (!any) continue;
+        // this ticket's place in every list it adds to: one atomic per class present (lane q asks for class q)
+        u32 mine = lane == 0 ? c0 : lane == 1 ? c1 : lane == 2 ? c2 : lane == 3 ? c3 : lane == 4 ? c4 : lane == 5 ? c5 : lane == 6 ? c6 : lane == 7 ? c7 : 0u;
+        if (lane >= 8 || (u32)lane == cc.bulk) mine = 0;
+        u32 at = 0;
+        if (mine) at = cc.first[lane & 7] + atomicAdd(&cursor[lane & 7], mine);
+        for (int j = 0; j < ROWS; ++j) {  // (the rows again, from the L2: nothing is kept across the two passes)
+            const u64 r = r0 + (u64)j * 64;
+            const u64 d = r < n ? desc[r] : 0;
+            const u32 c = r < n ? class_of(cc, (u32)(d & 0xffffffULL)) : cc.bulk;
+            u64 others = __ballot(c != cc.bulk);
+            while (others) {  // every class present in the row, lowest first
+                const int src = __builtin_ctzll(others);
+                const u32 q = (u32)__builtin_amdgcn_readlane((int)c, src);
+                const u64 m = __ballot(c == q);
+                const u32 base = (u32)__builtin_amdgcn_readlane((int)at, (int)q);
+                if (c == q) {
+                    const u32 i = base + (u32)__builtin_popcountll(m & ((1ULL << lane) - 1));
+                    list[i] = (u32)r;
+                    sdesc[i] = d;
+                }
+                if ((u32)lane == q) at += (u32)__builtin_popcountll(m);
+                others &= ~m;
+            }
+        }
+    }
+}
+// the reads of a part take their reference words (re-based into the parent's tail) and status bytes from the part's result
+__global__ void k_adopt_refs(const u32 *list, u64 n, const u64 *crefs, const u8 *cstatus, u64 base, u64 *refs, u8 *status) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 r = list[i], c = crefs[i];
+        const u64 first = (c & ~BSK_REF_ROWS) >> 24;
+        refs[r] = (c & BSK_REF_ROWS) | ((first + base) << 24) | (c & 0xffffffULL);
+        status[r] = cstatus[i];
+    }
+}
+// ... the same from a part that ran over tiles (a wide result: first / count per sequence)
+__global__ void k_adopt_wide(const u32 *list, u64 n, const u64 *wfirst, const u64 *wcount, const u8 *cstatus, u64 base, u64 *refs, u8 *status) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 r = list[i];
+        refs[r] = ((wfirst[i] + base) << 24) | (wcount[i] & 0xffffffULL);
+        status[r] = cstatus[i];
     }
 }
 // circular: read r' = read r + its first k-1 bases (iterator.go:642-646).  One thread per output word.
@@ -357,7 +449,7 @@ extern "C" int bsk_ctx_create(int device, bsk_ctx **out) {
     ctx->cus = prop.multiProcessorCount;
     ctx->opt.load();  // the developer switches: once per context
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&ctx->d_ticket, 8 * sizeof(u32)) != hipSuccess || hipMalloc(&ctx->d_total, 8 * sizeof(u64)) != hipSuccess ||
+        hipMalloc(&ctx->d_ticket, 16 * sizeof(u32)) != hipSuccess || hipMalloc(&ctx->d_total, 8 * sizeof(u64)) != hipSuccess ||
         hipHostMalloc(&ctx->h_pinned, 8 * sizeof(u64)) != hipSuccess) {
         bsk_ctx_destroy(ctx);
         return BSK_ERR_DEVICE;
@@ -406,6 +498,13 @@ static int grid_for(bsk_ctx *ctx, u64 items, int block) {
 extern "C" void bsk_batch_destroy(bsk_batch *b) {
     if (!b) return;
     if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    delete b->hist;
+    if (b->borrowed) {  // a view of another batch (class plans): its descriptors live in the context's pool, only the binned copies are its own
+        (void)hipFree(b->bdesc);
+        (void)hipFree(b->bflags);
+        delete b;
+        return;
+    }
     if (!b->alias) {
         (void)hipFree(b->words);
         (void)hipFree(b->ascii);
@@ -452,6 +551,10 @@ void BskOpts::load() {
     ring = on("BSK_RING");
     ring_max = env_u32("BSK_RING_MAX", 0);
     bin_min = env_u32("BSK_BIN_MIN", 1024);
+    no_class = on("BSK_NO_CLASS");
+    syn_sel = on("BSK_SYN_SEL");
+    class_min = env_u32("BSK_CLASS_MIN", 16384);
+    class_force = on("BSK_CLASS_FORCE");
     no_syn_long = on("BSK_NO_SYN_LONG");  // dev: reads beyond k_syncmer_pk's limits go to k_syncmer_fast as before round 4
     syn_margin = (int)env_u32("BSK_SYN_MARGIN", 2 + 64) - 64;  // dev: rows of slack the planner wants in k_syncmer_pk's columns (BSK_SYN_MARGIN = 64 + margin)
     no_tiles = on("BSK_NO_TILES");
@@ -581,12 +684,16 @@ static int batch_from_ascii_impl(bsk_ctx *ctx, const uint8_t *bytes, const uint6
         u64 *const desc = ctx->h_refs;
         std::vector<u64> llen(wide ? n : 0);
         u64 w = 0;
+        LenHist *hist = (!uniform && !wide && n) ? new (std::nothrow) LenHist() : nullptr;  // what the class plans are cut from (run_classed)
         for (u64 r = 0; r < n; ++r) {
             u64 L = offsets[r + 1] - offsets[r];
             desc[r] = wide ? w : ((w << 24) | L);
             if (wide) llen[r] = L;
+            if (hist) hist->add(L);
             w += (L + 15) / 16;
         }
+        delete b->hist;
+        b->hist = hist;
         b->n_words = w;
         const u64 alloc_words = w + pad_words(maxlen);
         BCHK(take((void **)&b->words, &b->c_words, alloc_words * sizeof(u32), donor ? (void **)&donor->words : nullptr, donor ? &donor->c_words : nullptr));
@@ -665,15 +772,27 @@ static int batch_from_packed_impl(bsk_ctx *ctx, const uint32_t *words, uint64_t 
     u32 maxlen = 0;
     u64 nb = 0;
     bool uniform = true;
+    std::unique_ptr<LenHist> hist;
     for (u64 r = 0; r < n; ++r) {
         u64 L = desc[r] & 0xffffffULL, w0 = desc[r] >> 24;
         if (w0 + (L + 15) / 16 > n_words) return fail_arg(ctx, "desc points outside words[]");
         maxlen = std::max<u32>(maxlen, (u32)L);
         nb += L;
-        if (L != (desc[0] & 0xffffffULL)) uniform = false;
+        if (L != (desc[0] & 0xffffffULL) && uniform) {  // the first read of another length: the histogram starts here (run_classed)
+            uniform = false;
+            hist.reset(new (std::nothrow) LenHist());
+            if (hist) {
+                hist->cnt[LenHist::bucket(desc[0] & 0xffffffULL)] = r;
+                hist->bases[LenHist::bucket(desc[0] & 0xffffffULL)] = r * (desc[0] & 0xffffffULL);
+                hist->hi[LenHist::bucket(desc[0] & 0xffffffULL)] = (u32)(desc[0] & 0xffffffULL);
+                hist->lo[LenHist::bucket(desc[0] & 0xffffffULL)] = (u32)(desc[0] & 0xffffffULL);
+            }
+        }
+        if (hist) hist->add(L);
     }
     bsk_batch *b = new (std::nothrow) bsk_batch();
     if (!b) return BSK_ERR_NOMEM;
+    b->hist = hist.release();
     b->ctx = ctx;
     b->alphabet = BSK_ALPHA_DNA;
     b->n = n;
@@ -845,21 +964,28 @@ extern "C" int bsk_batch_fetch_ascii(bsk_ctx *ctx, const bsk_batch *b, uint64_t 
 // ------------------------------------------------------------------------------------
 // results
 // ------------------------------------------------------------------------------------
+static void class_set_free(ClassSet *cs);
 extern "C" void bsk_result_release(bsk_result *r) {
     if (!r) return;
     if (r->ctx) (void)hipSetDevice(r->ctx->device);
+    if (r->classes) class_set_free(r->classes);
+    if (r->ctx && r->ctx->cls_owner == r) r->ctx->cls_owner = nullptr;
     (void)hipFree(r->refs);
     (void)hipFree(r->wfirst);
     (void)hipFree(r->wcount);
     (void)hipFree(r->status);
-    (void)hipFree(r->hash);
-    (void)hipFree(r->pos);
+    if (!r->arrays_borrowed) {
+        (void)hipFree(r->hash);
+        (void)hipFree(r->pos);
+    }
     delete r;
 }
 
 static bool kind_has_pos(int kind) { return kind == BSK_MINIMIZER || kind == BSK_SYNCMER || kind == BSK_PROT_MINIMIZER; }
 
-static int result_prepare(bsk_ctx *ctx, bsk_result **res, u64 n, int kind, u64 cap) {
+// tail: tuples reserved BEHIND the logical capacity `cap` (class plans: the slabs of the adopted parts live there; the kernels of the
+// result itself never see them)
+static int result_prepare(bsk_ctx *ctx, bsk_result **res, u64 n, int kind, u64 cap, u64 tail = 0) {
     bsk_result *r = *res;
     const int hp = kind_has_pos(kind) ? 1 : 0;
     if (r && (r->ctx != ctx || r->n_cap < n || !r->refs)) {  // too small (or a wide result): start over
@@ -888,17 +1014,23 @@ static int result_prepare(bsk_ctx *ctx, bsk_result **res, u64 n, int kind, u64 c
         (void)hipFree(r->pos);
         r->pos = nullptr;
     }
-    if (r->cap < cap || (hp && !r->pos)) {
-        (void)hipFree(r->hash);
-        (void)hipFree(r->pos);
+    if (r->alloc_cap < cap + tail || r->arrays_borrowed || (hp && !r->pos)) {
+        if (!r->arrays_borrowed) {
+            (void)hipFree(r->hash);
+            (void)hipFree(r->pos);
+        }
+        r->arrays_borrowed = false;
         r->hash = nullptr;
         r->pos = nullptr;
         r->cap = 0;
+        r->alloc_cap = 0;
         hipError_t e;
-        if ((e = hipMalloc(&r->hash, (cap + 2) * 8)) != hipSuccess) return fail_hip(ctx, e, "result hash alloc");
-        if (hp && (e = hipMalloc(&r->pos, (cap + 2) * 4)) != hipSuccess) return fail_hip(ctx, e, "result pos alloc");
-        r->cap = cap;
+        if ((e = hipMalloc(&r->hash, (cap + tail + 2) * 8)) != hipSuccess) return fail_hip(ctx, e, "result hash alloc");
+        if (hp && (e = hipMalloc(&r->pos, (cap + tail + 2) * 4)) != hipSuccess) return fail_hip(ctx, e, "result pos alloc");
+        r->alloc_cap = cap + tail;
     }
+    r->tail_cap = tail;
+    r->cap = r->alloc_cap - tail;  // (a re-used, larger allocation: the logical capacity grows with it, the tail stays at the end)
     return BSK_OK;
 }
 
@@ -1125,7 +1257,7 @@ static int blocks_per_cu(K kernel) {
 
 // Which kernel runs a (batch, params) pair, on how many workgroups, and how the tuple arrays are organised.
 enum Which { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST, K_NT_FAST, K_SYN_P, K_SYN_A, K_KMER_P, K_KMER_A, K_SIM_P, K_SIM_A,
-             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST, K_MIN_DENSE, K_MIN_SEG, K_MIN_WPR, K_MIN_PK, K_SYN_PK, K_MIN_RING };
+             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST, K_MIN_DENSE, K_MIN_SEG, K_MIN_WPR, K_MIN_PK, K_SYN_PK, K_MIN_RING, K_SYN_SEL };
 struct Plan {
     Which which = K_MIN_GEN_P;
     int grid = 1;
@@ -1222,7 +1354,7 @@ static u64 ring_rows(double nwin, int w) {
 #define BSK_REPLAN_UNFUSED (-1000)  // internal: the fused DNA -> protein plan gave up, run the two-step path
 
 static bool which_is_fast(Which w) {
-    return w == K_MIN_FAST || w == K_NT_FAST || w == K_SYN_FAST || w == K_SIM_FAST || w == K_MIN_DENSE || w == K_MIN_SEG || w == K_MIN_WPR || w == K_MIN_PK || w == K_SYN_PK || w == K_MIN_RING;
+    return w == K_MIN_FAST || w == K_NT_FAST || w == K_SYN_FAST || w == K_SIM_FAST || w == K_MIN_DENSE || w == K_MIN_SEG || w == K_MIN_WPR || w == K_MIN_PK || w == K_SYN_PK || w == K_MIN_RING || w == K_SYN_SEL;
 }
 
 static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan &pl, bool use_ascii);
@@ -1387,6 +1519,26 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         // pair), every such read is the exact machine's, the list (a quarter of the batch) fills up and the call falls back after a
         // wasted run.  Expected pairs per read = windows x 2w x 2 / 4^s; beyond 0.2 the packed kernels are not planned.
         const bool syn_ties = std::max(syn_nwin, 0.0) * 4.0 * (p->k - p->s) / std::pow(4.0, (double)std::min(p->s, 24)) > 0.2;
+#ifdef BSK_EXPERIMENTS
+        // the two-pass plan (kernels_syncmer_sel.hpp): selection by the packed s-mer machine, then ONLY the selected k-mers are hashed -- no
+        // staging columns, so neither the rows-per-pair rule above nor column overflows apply: any read whose words fit the registers.
+        // MEASURED AND NOT PLANNED (round 5, NOTEBOOK 5.4): the selection pass alone runs at 1 575 Gbases/s, but the second pass is bound by
+        // the latency of its loads behind its stores (72 % of its wave cycles wait) and the two together reach 870 against k_syncmer_pk's
+        // 950-966.  Built with make EXPERIMENTS=1, chosen with BSK_SYN_SEL=1 (tests/test_gpu_experiments.py keeps it exact).
+        if (!use_ascii && ctx->opt.syn_sel && fast_syncmer_supported(p->k, p->s) && sel_syncmer_supported(p->k - p->s) && b->maxlen <= sel_syncmer_max_bases() && p->k <= 64 && !syn_ties &&
+            !ctx->opt.force_generic && !ctx->opt.no_pk && !ctx->no_syn_pk && b->n < (1ULL << 32)) {
+            pl.which = K_SYN_SEL;
+            pl.fast_w = p->k - p->s;
+            pl.slab = true;   // (the slab plumbing: [0, slab_total) is the DENSE region of the unlisted reads, the overflow region behind it the listed reads')
+            pl.slab_unit = 0;
+            // expected 1.5 / (k - s + 1) of the windows (7.1 of 101 at k = 31, s = 11: measured) + 25 %; an undershoot is seen by pass 2 and the call is sized again
+            const double per_read = std::max(syn_nwin, 1.0) * 1.5 / (p->k - p->s + 1.0) * 1.25 + 2.0;
+            pl.slab_total = ((u64)((double)b->n * std::min(per_read, std::max(syn_nwin, 1.0))) + 4096 + 63) & ~(u64)63;
+            if (ctx->sel_need > pl.slab_total) pl.slab_total = (ctx->sel_need + 63) & ~(u64)63;  // (set while a call is being sized again)
+            pl.bin_gran = bin_gran_for(ctx, b, p->k - p->s);
+            per_cu = sel_syncmer_blocks_per_cu(pl.fast_w);
+        } else
+#endif
         if (!use_ascii && fast_syncmer_supported(p->k, p->s) && (syn_short || syn_lng) && !syn_ties && !ctx->opt.force_generic && !ctx->opt.no_pk && !ctx->no_syn_pk) {
             pl.syn_long = syn_lng;
             pl.which = K_SYN_PK;
@@ -1671,6 +1823,7 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
         case K_PROT_MIN: snprintf(b, sizeof b, "k_prot_minimizer"); break;
         case K_SYN_FAST: snprintf(b, sizeof b, "k_syncmer_fast<%d>", pl.fast_w); break;
         case K_SYN_PK: snprintf(b, sizeof b, pl.syn_long ? "k_syncmer_pkl<%d>" : "k_syncmer_pk<%d>", pl.fast_w); break;
+        case K_SYN_SEL: snprintf(b, sizeof b, "k_syncmer_sel<%d> + k_syncmer_emit", pl.fast_w); break;
         case K_PROT_MIN_FAST: snprintf(b, sizeof b, "k_prot_minimizer_fast<%d,%d,%s>", pl.fast_w, pl.fast_k, pl.fused_dna ? "true" : "false"); break;
         case K_PROT_HASH_FAST: snprintf(b, sizeof b, "k_prot_hash_fast<%d,%s>", pl.fast_k, pl.fused_dna ? "true" : "false"); break;
         case K_SIM_FAST:
@@ -1689,10 +1842,122 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
 // nothing but low-complexity reads still fits its segments)
 static u64 syn_pk_fixcap(u64 n, int grid) { return std::max<u64>((u64)grid * 1024, (n / 4 + (u64)grid) / (u64)grid * (u64)grid); }
 
-// One launch of the planned kernel into res.  ev0/ev1 (optional) bracket the kernel itself.
+// ------------------------------------------------------------------------------------
+// class plans: one plan per LENGTH CLASS of a batch instead of one plan per batch
+// ------------------------------------------------------------------------------------
+// The reference sketches one sequence at a time: a 5-kb contig costs 5 kb, whatever else is in the file (sketch.go:46, :85-94).  A batch
+// plan keyed on the longest read does not: one 400-base read moved 10^8 x 150 bases from k_minimizer_pk to k_minimizer_dense, one 5-kb
+// read moved them onto tiles.  A class plan cuts the batch by length at the points where the planner's choice changes (LenHist: known on
+// the host since the batch was created), runs the BULK class -- the one with most bases -- over a view of the batch in which every other
+// read has length 0, and every other class as a batch of its own (its descriptors gathered, the words shared) whose slabs live in the
+// TAIL of the parent's arrays; k_adopt_refs then points those reads' reference words there.  Callers see one result.
+struct ClassPart {
+    bsk_batch *sub = nullptr;   // borrowed view: desc = the class's descriptors (context pool), words = the parent's
+    bsk_result *res = nullptr;  // refs / status of its own; hash / pos = the parent's tail once the parent exists
+    u32 *list = nullptr;        // the class's reads (batch positions), ascending (context pool)
+    u64 n = 0, bases = 0, off = 0, extent = 0;
+    u32 lo = 0, hi = 0;
+    bool tiled = false;  // longer than the kind's tile threshold: the part runs over tiles (sketch_tiled), its result is wide and copied into the tail
+    bool fresh = false;  // ... and was just run by the sizing call (the parent's first launch does not run it again)
+};
+struct ClassSet {
+    std::vector<ClassPart> parts;
+    bsk_batch *view = nullptr;  // the bulk class's view of the batch
+    u64 tail = 0;
+    u64 n = 0, n_bases = 0;     // what it was cut from
+    u32 maxlen = 0, blo = 0, bhi = 0;
+    const u64 *desc = nullptr;
+    const u32 *words = nullptr;
+    float build_ms = 0.0f;
+};
+static void class_set_free(ClassSet *cs) {
+    if (!cs) return;
+    for (auto &pt : cs->parts) {
+        if (pt.res) bsk_result_release(pt.res);
+        if (pt.sub) bsk_batch_destroy(pt.sub);
+    }
+    if (cs->view) bsk_batch_destroy(cs->view);
+    delete cs;
+}
+extern "C" int bsk_result_class_plan(const bsk_result *r, int *n_parts, float *build_ms) {
+    if (!r) return BSK_ERR_ARG;
+    if (n_parts) *n_parts = r->classes ? (int)r->classes->parts.size() : 0;
+    if (build_ms) *build_ms = r->classes ? r->classes->build_ms : 0.0f;
+    return BSK_OK;
+}
+
+static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_result *res, int circ_ext, const Plan &pl, hipEvent_t ev0, hipEvent_t ev1);
+// the parts of a class plan into the tail of `res` (called from the parent's launch, before its own kernel)
+static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in, int circ_ext, bsk_result **result, int warmup, int iters, float *kernel_ms);
+static int launch_parts(bsk_ctx *ctx, ClassSet *cs, const bsk_params *p, bsk_result *res) {
+    for (auto &pt : cs->parts) {
+        const u64 base = res->cap + pt.off;
+        if (base + pt.extent > res->alloc_cap) {
+            ctx->err = "class plan: the parts do not fit the result's tail";
+            return BSK_ERR_DEVICE;
+        }
+        if (pt.tiled) {  // tiles + stitch into a result of its own, then one copy into the tail
+            if (!pt.fresh) {
+                const int trc = sketch_tiled(ctx, pt.sub, p, 0, &pt.res, 0, 0, nullptr);
+                if (trc != BSK_OK) return trc;
+            }
+            pt.fresh = false;
+            const u64 T = pt.res->n_tuples;
+            if (T > pt.extent) {
+                ctx->err = "class plan: a tiled part outgrew its place in the tail";
+                return BSK_ERR_DEVICE;
+            }
+            if (T) {
+                HIPCHK(ctx, hipMemcpyAsync(res->hash + base, pt.res->hash, T * 8, hipMemcpyDeviceToDevice, ctx->stream));
+                if (res->pos && pt.res->pos) HIPCHK(ctx, hipMemcpyAsync(res->pos + base, pt.res->pos, T * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            continue;
+        }
+        bsk_result *cr = pt.res;
+        if (!cr->arrays_borrowed) {  // first launch after the part was sized on arrays of its own
+            (void)hipFree(cr->hash);
+            (void)hipFree(cr->pos);
+        }
+        cr->hash = res->hash + base;
+        cr->pos = res->pos ? res->pos + base : nullptr;
+        cr->arrays_borrowed = true;
+        cr->cap = cr->alloc_cap = pt.extent;
+        Plan cpl;
+        if (!plan_recall(cr, pt.sub, p, 0, cpl)) {
+            ctx->err = "class plan: a part lost its plan";
+            return BSK_ERR_DEVICE;
+        }
+        const int rc = launch(ctx, pt.sub, p, cr, 0, cpl, nullptr, nullptr);
+        if (rc != BSK_OK) return rc;
+    }
+    return BSK_OK;
+}
+static int adopt_parts(bsk_ctx *ctx, ClassSet *cs, bsk_result *res) {
+    for (auto &pt : cs->parts) {
+        if (!pt.n) continue;
+        if (pt.tiled)
+            hipLaunchKernelGGL(k_adopt_wide, dim3(grid_for(ctx, pt.n, 256)), dim3(256), 0, ctx->stream, pt.list, pt.n, pt.res->wfirst, pt.res->wcount, pt.res->status,
+                               res->cap + pt.off, res->refs, res->status);
+        else
+            hipLaunchKernelGGL(k_adopt_refs, dim3(grid_for(ctx, pt.n, 256)), dim3(256), 0, ctx->stream, pt.list, pt.n, pt.res->refs, pt.res->status, res->cap + pt.off,
+                               res->refs, res->status);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return BSK_OK;
+}
+
+// One launch of the planned kernel into res.  ev0/ev1 (optional) bracket the kernel itself (with the parts of a class plan).
 static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_result *res, int circ_ext, const Plan &pl,
                   hipEvent_t ev0, hipEvent_t ev1) {
     if (pl.nunits == 0) return BSK_OK;
+    ClassSet *const cs = (ctx->cls && b == ctx->cls->view) ? ctx->cls : nullptr;
+    if (cs) {
+        if (ev0) HIPCHK(ctx, hipEventRecord(ev0, ctx->stream));
+        ctx->cls = nullptr;  // (the parts are plain launches)
+        const int prc = launch_parts(ctx, cs, p, res);
+        ctx->cls = cs;
+        if (prc != BSK_OK) return prc;
+    }
     KArgs a;
     memset(&a, 0, sizeof a);
     a.words = b->words;
@@ -1734,7 +1999,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         a.len_mask = 0xfffu;
         a.binned = 1;
     }
-    const bool lists = pl.which == K_SYN_PK || pl.which == K_MIN_PK || pl.which == K_MIN_RING;
+    const bool lists = pl.which == K_SYN_PK || pl.which == K_MIN_PK || pl.which == K_MIN_RING || pl.which == K_SYN_SEL;
     const u64 fixcap = lists ? syn_pk_fixcap(b->n, pl.grid) : 0;  // u32 entries, behind one u32 count per workgroup
     int rc = ensure_scratch(ctx, std::max<u32>(lists ? (u32)((fixcap + (u64)pl.grid) / 2 + 2) : pl.slab ? 1 : pl.nunits, pl.mixed ? pl.side_nunits : 0), pl.ring_entries);
     if (rc != BSK_OK) return rc;
@@ -1753,7 +2018,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket, 0, 8 * sizeof(u32), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, 4 * sizeof(u64), ctx->stream));
     if (!pl.slab) HIPCHK(ctx, hipMemsetAsync(ctx->d_lookback, 0, (size_t)pl.nunits * sizeof(u64), ctx->stream));
-    if (ev0) HIPCHK(ctx, hipEventRecord(ev0, ctx->stream));
+    if (ev0 && !cs) HIPCHK(ctx, hipEventRecord(ev0, ctx->stream));
     switch (pl.which) {
         case K_MIN_GEN_P: hipLaunchKernelGGL(k_minimizer_generic<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_MIN_GEN_A: hipLaunchKernelGGL(k_minimizer_generic<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
@@ -1780,6 +2045,38 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_PROT_MIN: hipLaunchKernelGGL(k_prot_minimizer, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_SYN_FAST: fast_syncmer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_SYN_PK: pk_syncmer_launch(pl.fast_w, pl.syn_long, pl.grid, std::min(pl.grid, ctx->cus * 8), ctx->stream, a); break;
+#ifndef BSK_EXPERIMENTS
+        case K_SYN_SEL: break;
+#else
+        case K_SYN_SEL: {
+            // scratch of the two passes (context pool, grow-only): selection words [unit][nb][64], per read offset | count, per unit total / base
+            const u32 ns_max = b->maxlen + 1 > (u32)p->s ? b->maxlen - (u32)p->s + 1 : 1;
+            const u32 nb = (ns_max + (u32)pl.fast_w - 1) / (u32)pl.fast_w;  // fused blocks: i0 = W, 2W, ... < ns_max (one spare)
+            const u32 nblocks = (pl.nunits + 1023u) / 1024u;
+            auto pool = [&](int slot, size_t bytes, void **outp) -> hipError_t {
+                if (ctx->tmp_cap[slot] < bytes) {
+                    (void)hipFree(ctx->tmp[slot]);
+                    ctx->tmp[slot] = nullptr;
+                    ctx->tmp_cap[slot] = 0;
+                    const size_t want = bytes + bytes / 4 + 256;
+                    const hipError_t e = hipMalloc(&ctx->tmp[slot], want);
+                    if (e != hipSuccess) return e;
+                    ctx->tmp_cap[slot] = want;
+                }
+                *outp = ctx->tmp[slot];
+                return hipSuccess;
+            };
+            HIPCHK(ctx, pool(24, (size_t)pl.nunits * nb * 64 * 4, (void **)&a.sel_mask));
+            HIPCHK(ctx, pool(25, (size_t)pl.nunits * 64 * 4, (void **)&a.sel_cnt));
+            HIPCHK(ctx, pool(26, (size_t)pl.nunits * 4 + 64, (void **)&a.sel_utot));
+            HIPCHK(ctx, pool(27, ((size_t)pl.nunits + nblocks + 8) * 8, (void **)&a.sel_ubase));
+            a.sel_lookback = a.sel_ubase + pl.nunits;
+            a.sel_nb = nb;
+            HIPCHK(ctx, hipMemsetAsync(a.sel_lookback, 0, (size_t)nblocks * 8, ctx->stream));
+            sel_syncmer_launch(pl.fast_w, pl.grid, std::min(pl.grid, ctx->cus * 8), ctx->cus, b->maxlen / 16 + 6, ctx->stream, a);  // (words: the last k-mer's five words start at word (L - k) / 16; pad_words covers the overrun)
+            break;
+        }
+#endif
         case K_PROT_MIN_FAST:
             if (pl.fused_dna) {
                 a.frame = p->frame;
@@ -1820,6 +2117,10 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
             else if (a.canonical) hipLaunchKernelGGL(k_nthash_fast<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             else hipLaunchKernelGGL(k_nthash_fast<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             break;
+    }
+    if (cs) {  // the other classes' reads: their reference words point into the tail (before the ASCII side launch, which owns the reads with an N)
+        const int arc = adopt_parts(ctx, cs, res);
+        if (arc != BSK_OK) return arc;
     }
     if (pl.mixed) {  // the reads with a non-ACGT letter again, from their ASCII bytes, into [main_cap, cap)
         KArgs sd = a;
@@ -1902,7 +2203,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
     Plan pl;
     rc = make_plan(ctx, b, p, pl);
     if (rc != BSK_OK) return cleanup(rc);
-    u64 ovf_cap = pl.slab ? std::max<u64>(65536, pl.slab_total / 50) : 0;
+    u64 ovf_cap = pl.slab ? std::max<u64>(65536, pl.slab_total / (pl.which == K_SYN_SEL ? 8 : 50)) : 0;  // (two-pass syncmers: the listed reads' tuples, a few per cent of a DENSE region)
     if (pl.which == K_MIN_PK || pl.which == K_MIN_RING) {
         // the list pass gives every listed read a slab of one tuple per window out of this region (a wavefront claims 64 of them): room
         // for 1.5 % of the reads -- low-complexity tails are per cent of real reads -- before the call has to be sized again
@@ -1926,7 +2227,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         return cleanup(BSK_ERR_ARG);
     }
     for (int attempt = 0; sizing && attempt < 3; ++attempt) {
-        rc = result_prepare(ctx, result, b->n, p->kind, cap + side_cap);
+        rc = result_prepare(ctx, result, b->n, p->kind, cap + side_cap, (ctx->cls && b == ctx->cls->view) ? ctx->cls->tail : 0);
         if (rc == BSK_ERR_NOMEM && (pl.which == K_MIN_DENSE || pl.which == K_MIN_SEG || pl.which == K_MIN_WPR || pl.which == K_PROT_MIN_FAST) && attempt < 2) {
             // per-read slabs did not fit the device: the unit-slab / dense-CSR kernels need far less
             ctx->no_prot_fast = true;
@@ -1964,7 +2265,17 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
             ctx->err = "result capacity overflow after exact re-size";
             return cleanup(BSK_ERR_DEVICE);
         }
-        if (pl.which == K_PROT_MIN_FAST || pl.which == K_MIN_DENSE || ((pl.which == K_SYN_PK || pl.which == K_MIN_PK || pl.which == K_MIN_RING) && (ovf & 2u))) {  // a sequence outgrew its slab (unusual density), or too many reads with key ties: re-plan without that kernel
+        if (pl.which == K_SYN_SEL && !(ovf & 2u)) {  // the dense region (or the listed reads' region) was too small: total = what pass 2 needs
+            ctx->sel_need = total + total / 32 + 4096;
+            pl = Plan();
+            rc = make_plan(ctx, b, p, pl);
+            ctx->sel_need = 0;
+            if (rc != BSK_OK) return cleanup(rc);
+            ovf_cap = std::max<u64>(ovf_cap, ovf_used + ovf_used / 4 + 65536);
+            cap = pl.slab_total + ovf_cap;
+            continue;
+        }
+        if (pl.which == K_PROT_MIN_FAST || pl.which == K_MIN_DENSE || ((pl.which == K_SYN_PK || pl.which == K_MIN_PK || pl.which == K_MIN_RING || pl.which == K_SYN_SEL) && (ovf & 2u))) {  // a sequence outgrew its slab (unusual density), or too many reads with key ties: re-plan without that kernel
             ctx->no_prot_fast = true;
             ctx->no_dense = true;
             ctx->no_syn_pk = true;
@@ -1980,7 +2291,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         cap = pl.slab ? pl.slab_total + ovf_used + ovf_used / 4 + 65536 : total + 64;  // size known now: re-run once
     }
     if (sizing && *result) plan_record(*result, b, p, circ_ext, pl);
-    if (sizing && (pl.mixed || pl.slab || pl.which == K_NT_FAST || pl.which == K_PROT_HASH_FAST || pl.which == K_SIM_FAST) && b->n) {  // slab / line-padded kernels: sum the per-read counts once
+    if (sizing && (pl.mixed || pl.slab || pl.which == K_NT_FAST || pl.which == K_PROT_HASH_FAST || pl.which == K_SIM_FAST || (ctx->cls && b == ctx->cls->view)) && b->n) {  // slab / line-padded kernels: sum the per-read counts once
         HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, sizeof(u64), ctx->stream));
         hipLaunchKernelGGL(k_sum_counts, dim3(grid_for(ctx, b->n, 256)), dim3(256), 0, ctx->stream, (*result)->refs, b->n, ctx->d_total);
         hipError_t e = hipMemcpyAsync(ctx->h_pinned, ctx->d_total, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
@@ -2245,20 +2556,20 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     TCHK(hipMalloc(&fin->wfirst, (n ? n : 1) * 8));
     TCHK(hipMalloc(&fin->wcount, (n ? n : 1) * 8));
     if (two_strand) {  // twice the room; filled after k_tile_finish (k_two_strand)
-        fin->cap = 2 * tres->cap + 64;
+        fin->cap = fin->alloc_cap = 2 * tres->cap + 64;
         TCHK(hipMalloc(&fin->hash, fin->cap * 8));
     } else if (stream) {  // the tile runs are adjacent: the tile result's value array IS the sequence result
         fin->hash = tres->hash;
-        fin->cap = tres->cap;
+        fin->cap = fin->alloc_cap = tres->cap;
         tres->hash = nullptr;
-        tres->cap = 0;
+        tres->cap = tres->alloc_cap = 0;
         tres->main_cap = 0;
         tres->ovf_cap = 0;
     } else {
         const u64 cap = tres->n_tuples + 64;  // the stitch keeps a subset of the tile tuples
         TCHK(hipMalloc(&fin->hash, cap * 8));
         TCHK(hipMalloc(&fin->pos, cap * 4));
-        fin->cap = cap;
+        fin->cap = fin->alloc_cap = cap;
         TCHK(pool(9, (nt + 1) * 8, (void **)&oexcl));
         TCHK(hipMemsetAsync(oexcl, 0, (nt + 1) * 8, ctx->stream));
         if (nt) {
@@ -2317,6 +2628,326 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     const int rcd = done(BSK_OK);
     lap("free temporaries");
     return rcd;
+}
+
+// from which sequence length a batch of this kind is cut into tiles (0: the kind does not tile)
+static u32 tile_min_for(const bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p) {
+    const bool is_dna = b->alphabet == BSK_ALPHA_DNA;
+    // (syncmers: beyond the packed kernels' reach the per-read 64-bit kernel falls to 140-160 Gbases/s of wall time -- its 28-tuple slabs
+    // overflow -- and to 83 at 4 000 bases, where tiles run 170-210: scripts/dev/perf_midlen.py, round 4)
+    return ctx->opt.tile_min ? ctx->opt.tile_min
+           : (is_dna && p->kind == BSK_SYNCMER && syn_long_plan_ok(ctx, p) && p->k - p->s >= 16) ? kSynTileMin  // (measured at k-s = 20..24; small k-s: tiles of 32 positions + 61 bases of overlap were never measured)
+           : ((!is_dna || kind_has_pos(p->kind)) ? 4096u : 16u * (BSK_NT_FAST_WORDS - 2));
+}
+
+// ---- class plans: the decision (host, from the batch's length histogram) ------------------------------------------------------------
+struct ClassSig {
+    int which = -1, octave = 0;
+    bool syn_long = false;
+    bool operator==(const ClassSig &o) const { return which == o.which && octave == o.octave && syn_long == o.syn_long; }
+};
+// what the planner would run over `n` reads of `bases` bases, the longest `hi` (the pure 2-bit plan: reads with an N are the parent's side launch)
+static bool class_sig(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, u64 n, u64 bases, u32 hi, ClassSig &g) {
+    bsk_batch t = *b;  // shallow: only the shape is looked at
+    t.n = n;
+    t.n_bases = bases;
+    t.maxlen = hi;
+    t.uniform_len = 0;
+    t.n_nonacgt = 0;
+    t.subset = nullptr;
+    t.nsub = 0;
+    Plan pl;
+    if (make_plan(ctx, &t, p, pl) != BSK_OK) return false;
+    g.which = (int)pl.which;
+    g.syn_long = pl.syn_long;
+    g.octave = hi > 1024 ? 63 - __builtin_clzll((u64)hi) : 0;  // (long classes also split by octave: per-read slabs are sized by the class's longest read)
+    if (hi > tile_min_for(ctx, b, p)) g.which = -2, g.syn_long = false, g.octave = 99;  // tile work: one class, whatever its lengths
+    return true;
+}
+// rough kernel rates in Tbases/s (profiles/r04/robustness.jsonl): only their ratios matter -- is splitting worth its passes?
+static double class_rate(const ClassSig &g, double meanlen, bool tiled, int kind) {
+    if (tiled || g.which == -2) return kind == BSK_SYNCMER ? 0.25 : 0.19;
+    switch ((Which)g.which) {
+        case K_MIN_PK: return 1.2;
+        case K_MIN_RING: return meanlen <= 170 ? 1.06 : meanlen <= 260 ? 0.93 : 0.8;  // (150-base reads in a batch planned for its 250-base ones: 1 053 against 1 190 on k_minimizer_pk, profiles/r05)
+        case K_MIN_DENSE: return 0.7;
+        case K_MIN_FAST: return 0.75;
+        case K_SYN_PK: return g.syn_long ? 0.8 : 0.93;
+        case K_SYN_FAST: return meanlen <= 448 ? 0.6 : 0.15;
+        default: return 0.09;
+    }
+}
+struct ClassCut {
+    u32 lo, hi;   // the class takes the lengths [lo, hi]
+    u32 shortest; // the shortest read it holds
+    u64 n, bases;
+    ClassSig sig;
+};
+// -> the classes (ascending) and the index of the bulk; false: keep one plan
+static bool class_decide(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, int circ_ext, std::vector<ClassCut> &cuts, int &bulk) {
+    if (ctx->opt.no_class || ctx->opt.force_generic || !b->hist || !b->desc || b->alias || b->borrowed || b->alphabet != BSK_ALPHA_DNA || circ_ext || p->circular ||
+        (p->kind != BSK_MINIMIZER && p->kind != BSK_SYNCMER) || b->n < (u64)ctx->opt.class_min || b->n >= (1ULL << 32) || b->uniform_len || ctx->opt.no_tiles)
+        return false;
+    if (p->kind == BSK_SYNCMER && p->s == p->k) return false;  // (runs as the w = 1 minimizer over tiles)
+    const LenHist &h = *b->hist;
+    // quick exit: the shortest and the longest occupied bucket want the same kernel (two probes of the planner, the common case)
+    int b0 = -1, b1 = -1;
+    for (int i = 0; i < LenHist::NB; ++i)
+        if (h.cnt[i]) {
+            if (b0 < 0) b0 = i;
+            b1 = i;
+        }
+    if (b0 < 0 || b0 == b1) return false;
+    const u32 tmin = tile_min_for(ctx, b, p);
+    ClassSig s0, s1;
+    if (!class_sig(ctx, b, p, h.cnt[b0], h.bases[b0], h.hi[b0], s0) || !class_sig(ctx, b, p, h.cnt[b1], h.bases[b1], h.hi[b1], s1)) return false;
+    if (s0 == s1 && h.hi[b1] <= tmin) return false;
+    cuts.clear();
+    for (int i = b0; i <= b1; ++i) {
+        if (!h.cnt[i]) continue;
+        ClassSig g;
+        if (i == b0) g = s0;
+        else if (i == b1) g = s1;
+        else if (!class_sig(ctx, b, p, h.cnt[i], h.bases[i], h.hi[i], g)) return false;
+        if (!cuts.empty() && cuts.back().sig == g) {
+            cuts.back().hi = h.hi[i];
+            cuts.back().n += h.cnt[i];
+            cuts.back().bases += h.bases[i];
+        } else {
+            const u32 lo = cuts.empty() ? 0u : cuts.back().hi + 1;
+            cuts.push_back(ClassCut{lo, h.hi[i], h.lo[i], h.cnt[i], h.bases[i], g});
+        }
+    }
+    if (cuts.size() < 2 || cuts.size() > 8) return false;
+    bulk = 0;
+    for (size_t i = 1; i < cuts.size(); ++i)
+        if (cuts[i].bases > cuts[(size_t)bulk].bases) bulk = (int)i;
+    if (cuts[(size_t)bulk].hi > tmin) return false;  // the bulk itself is tile work: the tiled path takes the batch as before
+    if (ctx->opt.class_force) return true;
+    // is it worth the passes?  one plan: everything at the rate of the longest read's kernel
+    ClassSig sall;
+    if (!class_sig(ctx, b, p, b->n, b->n_bases, b->maxlen, sall)) return false;
+    const double single = (double)b->n_bases / (1e12 * class_rate(sall, (double)b->n_bases / (double)b->n, b->maxlen > tmin, p->kind));  // seconds
+    double split = (double)b->n * (8.0 * (double)cuts.size()) / 2e12;  // the list passes: 8 bytes per read and class (+ the view) at ~2 TB/s
+    for (const auto &c : cuts) split += (double)c.bases / (1e12 * class_rate(c.sig, c.n ? (double)c.bases / (double)c.n : 0.0, false, p->kind)) + 60e-6;  // + a launch
+    return ctx->opt.class_force || split < 0.95 * single;
+}
+
+static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, int circ_ext, bsk_result **result, int warmup, int iters, float *kernel_ms);
+
+// lists, views and sub-batches of the classes (device passes on the context's stream; the arrays live in the context's pool)
+static int class_build(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, const std::vector<ClassCut> &cuts, int bulk, ClassSet *cs) {
+    auto pool = [&](int slot, size_t bytes, void **outp) -> hipError_t {
+        if (ctx->tmp_cap[slot] < bytes) {
+            (void)hipFree(ctx->tmp[slot]);
+            ctx->tmp[slot] = nullptr;
+            ctx->tmp_cap[slot] = 0;
+            const size_t want = bytes + bytes / 4 + 256;
+            const hipError_t e = hipMalloc(&ctx->tmp[slot], want);
+            if (e != hipSuccess) return e;
+            ctx->tmp_cap[slot] = want;
+        }
+        *outp = ctx->tmp[slot];
+        return hipSuccess;
+    };
+    u64 n_out = 0;
+    for (size_t i = 0; i < cuts.size(); ++i)
+        if ((int)i != bulk) n_out += cuts[i].n;
+    u32 *lists = nullptr;
+    u64 *view = nullptr, *sdesc = nullptr;
+    HIPCHK(ctx, pool(21, (n_out + 64) * 4, (void **)&lists));
+    HIPCHK(ctx, pool(22, (b->n + 64) * 8, (void **)&view));
+    HIPCHK(ctx, pool(23, (n_out + 64) * 8, (void **)&sdesc));
+    const u32 nblocks = (u32)((b->n + 1023) / 1024);  // k_class_list: a ticket is 16 rows of 64 reads
+    int rc = ensure_scratch(ctx, nblocks, 0);
+    if (rc != BSK_OK) return rc;
+    const ClassCut &bk = cuts[(size_t)bulk];
+    const u32 pretend = bk.shortest == bk.hi ? bk.hi : 0u;  // a fixed-length bulk: the other reads pretend its length in the view
+    const u32 tmin = tile_min_for(ctx, b, p);
+    // the set keeps the part objects of an earlier call into the same result (their allocations), index by index
+    const size_t nparts = cuts.size() - 1;
+    for (size_t i = nparts; i < cs->parts.size(); ++i) {
+        if (cs->parts[i].res) bsk_result_release(cs->parts[i].res);
+        if (cs->parts[i].sub) bsk_batch_destroy(cs->parts[i].sub);
+    }
+    cs->parts.resize(nparts);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    if (e0) (void)hipEventRecord(e0, ctx->stream);
+    ClassCuts cc;
+    memset(&cc, 0, sizeof cc);
+    cc.ncls = (u32)cuts.size();
+    cc.bulk = (u32)bulk;
+    cc.pretend = pretend;
+    u64 at = 0;
+    size_t pi = 0;
+    for (size_t i = 0; i < cuts.size(); ++i) {
+        cc.hi[i] = cuts[i].hi;
+        cc.first[i] = (u32)at;
+        if ((int)i == bulk) continue;
+        ClassPart &pt = cs->parts[pi++];
+        const ClassCut &c = cuts[i];
+        pt.list = lists + at;
+        pt.n = c.n;
+        pt.bases = c.bases;
+        pt.lo = c.lo;
+        pt.hi = c.hi;
+        pt.tiled = c.hi > tmin;
+        pt.fresh = false;
+        if (!pt.sub) pt.sub = new (std::nothrow) bsk_batch();
+        if (!pt.sub) return BSK_ERR_NOMEM;
+        bsk_batch *sb = pt.sub;
+        sb->ctx = ctx;
+        sb->alphabet = b->alphabet;
+        sb->pairs = b->pairs;
+        sb->n = c.n;
+        sb->n_bases = c.bases;
+        sb->n_words = b->n_words;
+        sb->maxlen = c.hi;
+        sb->uniform_len = c.shortest == c.hi ? c.hi : 0;
+        sb->words = b->words;
+        sb->desc = sdesc + at;
+        sb->borrowed = true;
+        sb->bin_gran = 0;  // (a binned view of an earlier chunk is stale)
+        at += c.n;
+    }
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket, 0, 16 * sizeof(u32), ctx->stream));  // [0] the ticket, [8..15] the classes' cursors
+    // (the pass is latency-bound per ticket: every wave the CUs hold)
+    hipLaunchKernelGGL(k_class_cut, dim3(std::min<u32>(nblocks, (u32)ctx->cus * 32)), dim3(64), 0, ctx->stream, b->desc, b->n, nblocks, cc, ctx->d_ticket, ctx->d_ticket + 8,
+                       lists, sdesc, view);
+    HIPCHK(ctx, hipGetLastError());
+    if (e0 && e1) {
+        (void)hipEventRecord(e1, ctx->stream);
+        (void)hipEventSynchronize(e1);
+        (void)hipEventElapsedTime(&cs->build_ms, e0, e1);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    // the bulk's view of the batch
+    if (!cs->view) cs->view = new (std::nothrow) bsk_batch();
+    if (!cs->view) return BSK_ERR_NOMEM;
+    {
+        bsk_batch *v = cs->view;
+        u64 *bd = v->bdesc;  // its own binned copies survive (grow-only)
+        u8 *bf = v->bflags;
+        const size_t cbd = v->c_bdesc, cbf = v->c_bflags;
+        *v = *b;
+        v->hist = nullptr;
+        v->borrowed = true;
+        v->desc = view;
+        v->maxlen = bk.hi;
+        v->n_bases = pretend ? (u64)pretend * b->n : bk.bases;
+        v->uniform_len = pretend;
+        v->bdesc = bd;
+        v->bflags = bf;
+        v->c_bdesc = cbd;
+        v->c_bflags = cbf;
+        v->bin_gran = 0;
+        v->bin_lo = 0;
+        v->spare_ascii = nullptr;
+        v->spare_aoff = nullptr;
+    }
+    cs->n = b->n;
+    cs->n_bases = b->n_bases;
+    cs->maxlen = b->maxlen;
+    cs->desc = b->desc;
+    cs->words = b->words;
+    cs->blo = cuts[(size_t)bulk].lo;
+    cs->bhi = cuts[(size_t)bulk].hi;
+    return BSK_OK;
+}
+
+// what ran, for bsk_result_plan: the bulk's kernel + every part's
+static void class_plan_names(bsk_result *res, const ClassSet *cs) {
+    size_t at = strlen(res->plan);
+    for (const auto &pt : cs->parts) {
+        if (at + 8 >= sizeof res->plan) break;
+        at += (size_t)snprintf(res->plan + at, sizeof res->plan - at, " + %s [%llu reads of %u..%u bases]", pt.res->plan, (unsigned long long)pt.n, pt.lo, pt.hi);
+        at = std::min(at, sizeof res->plan - 1);
+    }
+}
+
+// *applied = false: the batch keeps one plan (the caller goes on as before)
+static int run_classed(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, int circ_ext, bsk_result **result, int warmup, int iters, float *kernel_ms, bool *applied) {
+    *applied = false;
+    const bool sizing = *result == nullptr || warmup + iters == 0;
+    if (!sizing) {  // bsk_sketch_timed on a sized result: the class plan it was sized with, or none
+        ClassSet *cs = (*result)->classes;
+        if (!cs) return BSK_OK;
+        if (ctx->cls_owner != *result || cs->n != b->n || cs->n_bases != b->n_bases || cs->maxlen != b->maxlen || cs->desc != b->desc || cs->words != b->words) {
+            ctx->err = "bsk_sketch_timed: the result's class plan belongs to another batch (or a later bsk_sketch on this context replaced it): call bsk_sketch first";
+            return BSK_ERR_ARG;
+        }
+        *applied = true;
+        ctx->cls = cs;
+        const int rc = run_planned(ctx, cs->view, p, 0, result, warmup, iters, kernel_ms);
+        ctx->cls = nullptr;
+        if (rc == BSK_OK) class_plan_names(*result, cs);
+        return rc;
+    }
+    std::vector<ClassCut> cuts;
+    int bulk = 0;
+    if (!class_decide(ctx, b, p, circ_ext, cuts, bulk)) {
+        if (*result && (*result)->classes) {
+            class_set_free((*result)->classes);
+            (*result)->classes = nullptr;
+        }
+        return BSK_OK;
+    }
+    ClassSet *cs = (*result && (*result)->classes) ? (*result)->classes : new (std::nothrow) ClassSet();
+    if (!cs) return BSK_ERR_NOMEM;
+    if (*result) (*result)->classes = nullptr;  // (held here until the run succeeded)
+    ctx->cls_owner = nullptr;
+    auto drop = [&](int code) {
+        class_set_free(cs);
+        return code;
+    };
+    int rc = class_build(ctx, b, p, cuts, bulk, cs);
+    if (rc != BSK_OK) return drop(rc);
+    // every part sized as a batch of its own; then the parent, with the parts' slabs as its tail
+    u64 tail = 0;
+    for (auto &pt : cs->parts) {
+        if (pt.res && pt.res->arrays_borrowed) {  // a part of an earlier call: its place in that call's tail may be gone
+            pt.res->hash = nullptr;
+            pt.res->pos = nullptr;
+            pt.res->arrays_borrowed = false;
+            pt.res->cap = pt.res->alloc_cap = 0;
+        }
+        if (pt.tiled) {
+            if (pt.res && !pt.res->wfirst) {  // (the part object of an earlier call that was not tile work)
+                bsk_result_release(pt.res);
+                pt.res = nullptr;
+            }
+            rc = sketch_tiled(ctx, pt.sub, p, 0, &pt.res, 0, 0, nullptr);
+            if (rc != BSK_OK) return drop(rc);
+            pt.fresh = true;
+            pt.extent = (pt.res->n_tuples + 31) & ~(u64)15;
+            pt.off = tail;
+            tail += pt.extent;
+            continue;
+        }
+        if (pt.res && pt.res->wfirst) {  // (a wide result of an earlier call)
+            bsk_result_release(pt.res);
+            pt.res = nullptr;
+        }
+        rc = run_planned(ctx, pt.sub, p, 0, &pt.res, 0, 0, nullptr);
+        if (rc != BSK_OK) return drop(rc);
+        pt.extent = (pt.res->cap + 15) & ~(u64)15;
+        pt.off = tail;
+        tail += pt.extent;
+    }
+    cs->tail = tail;
+    ctx->cls = cs;
+    rc = run_planned(ctx, cs->view, p, 0, result, warmup, iters, kernel_ms);
+    ctx->cls = nullptr;
+    if (rc != BSK_OK) return drop(rc);
+    bsk_result *res = *result;
+    res->classes = cs;
+    ctx->cls_owner = res;
+    class_plan_names(res, cs);
+    *applied = true;
+    return BSK_OK;
 }
 
 extern "C" int bsk_batch_prepare(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, float *ms) {
@@ -2415,11 +3046,12 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
     }
     // long sequences run as tiles; protein: only when really long (the protein kernels take any length per lane, slowly)
     const bool is_dna = b->alphabet == BSK_ALPHA_DNA;
-    // (syncmers: beyond the packed kernels' reach the per-read 64-bit kernel falls to 140-160 Gbases/s of wall time -- its 28-tuple slabs
-    // overflow -- and to 83 at 4 000 bases, where tiles run 170-210: scripts/dev/perf_midlen.py, round 4)
-    const u32 tile_min = ctx->opt.tile_min ? ctx->opt.tile_min
-                         : (is_dna && p->kind == BSK_SYNCMER && syn_long_plan_ok(ctx, p) && p->k - p->s >= 16) ? kSynTileMin  // (measured at k-s = 20..24; small k-s: tiles of 32 positions + 61 bases of overlap were never measured)
-                         : ((!is_dna || kind_has_pos(p->kind)) ? 4096u : 16u * (BSK_NT_FAST_WORDS - 2));
+    const u32 tile_min = tile_min_for(ctx, b, p);
+    if (!tmp) {  // a batch of several length classes: one plan per class (run_classed), outliers cost their own bases
+        bool applied = false;
+        rc = run_classed(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms, &applied);
+        if (rc != BSK_OK || applied) return rc;
+    }
     const bool outlier = !is_dna && p->kind == BSK_PROT_MINIMIZER && b->maxlen > 512 && !slab_budget_ok(b, (u64)b->maxlen);  // tiles are uniform: small slabs
     const bool tiled = kind_tiles(p) && (is_dna != prot_kind) && !ctx->opt.no_tiles && ((is_dna && !b->desc) || b->maxlen > tile_min || outlier);
     rc = tiled ? sketch_tiled(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms)

@@ -47,6 +47,12 @@ u32 pk_syncmer_pair_rows(bool lng);
 int pk_syncmer_blocks_per_cu(int w, bool lng);
 void pk_syncmer_launch(int w, bool lng, int grid, int fix_grid, hipStream_t stream, const KArgs &a);
 
+// the two-pass plan (kernels_syncmer_sel.hpp): selection by the packed s-mer machine, then the selected k-mers hashed from scratch
+bool sel_syncmer_supported(int w);
+u32 sel_syncmer_max_bases();
+int sel_syncmer_blocks_per_cu(int w);
+void sel_syncmer_launch(int w, int grid, int fix_grid, int cus, u32 nw, hipStream_t stream, const KArgs &a);  // nw: packed words of a read pass 2 stages (longest read + k)
+
 bool fast_prot_supported(int w, int k);
 int fast_prot_blocks_per_cu(int w, int k);
 void fast_prot_launch(int w, int k, int grid, hipStream_t stream, const KArgs &a);

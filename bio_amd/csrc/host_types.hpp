@@ -17,6 +17,10 @@ struct BskOpts {
          no_fused_translate = false, sets_no_small = false;
     int syn_margin = 2;
     bool no_syn_long = false;
+    bool syn_sel = false;    // BSK_SYN_SEL (make EXPERIMENTS=1): the two-pass syncmer plan, measured and not planned (kernels_syncmer_sel.hpp)
+    bool no_class = false;   // BSK_NO_CLASS: one plan per batch, keyed on the longest read (rounds 1-4)
+    u32 class_min = 16384;   // BSK_CLASS_MIN: batches below this many reads keep one plan
+    bool class_force = false;  // BSK_CLASS_FORCE: cut wherever the planner's choice changes, whatever the cost model says (tests: small batches)
     u32 wpr = 0, seg = 0, dense_min = 21, ring_max = 0, bin_min = 1024, waves_per_cu = 0, tile_min = 0, tile_pos = 0;  // tile_min 0: the kind's default
     void load();  // biosketch.hip
 };
@@ -39,8 +43,8 @@ struct bsk_ctx {
     u8 *d_lut = nullptr;      // codon tables of `lut_table` (kernels_translate.hpp layout)
     int lut_table = 0;
     // tiled calls: grow-only temporaries (hipMalloc / hipFree of ten buffers per call cost more than the kernels)
-    void *tmp[24] = {};      // 0-9: tiled calls / sets, 12-14: bsk_result_fetch, 16-19: bsk_result_compact, 20: bsk_sets_fetch_narrow, 21-23: class plans
-    size_t tmp_cap[24] = {};
+    void *tmp[28] = {};      // 0-9: tiled calls / sets, 12-14: bsk_result_fetch, 16-19: bsk_result_compact, 20: bsk_sets_fetch_narrow, 21-23: class plans, 24-27: two-pass syncmers
+    size_t tmp_cap[28] = {};
     u64 *h_refs = nullptr;   // pinned staging of bsk_result_fetch (refs down, offsets up), grow-only
     size_t h_refs_cap = 0;
     struct bsk_result *tile_res = nullptr;  // tile-level result of the previous tiled call, reused
@@ -48,9 +52,37 @@ struct bsk_ctx {
     void *comm = nullptr;  // ncclComm_t
     int comm_rank = 0, comm_world = 0;
     u64 *d_comm = nullptr;  // [(world + 1) * BSK_MAX_COUNTERS] device staging of bsk_gather_counts
+    struct ClassSet *cls = nullptr;       // the class plan a run_planned / launch in progress belongs to (biosketch.hip: run_classed)
+    struct bsk_result *cls_owner = nullptr;  // the result whose class plan the pooled lists / views (tmp 21-23) currently describe
+    u64 sel_need = 0;           // two-pass syncmers: the dense region a call that is being sized again needs (run_planned)
     bool no_syn_pk = false;     // set while a call falls back from k_syncmer_pk / k_minimizer_pk (the list of reads for the exact machine filled up)
     bool no_prot_fast = false;
     bool no_dense = false;      // same for the dense-minimizer kernel (per-read slabs)  // set while a call falls back from the per-sequence-slab protein kernel
+};
+
+// Exact histogram of a batch's sequence lengths, built on the host where the batch is created (the lengths pass through the host there
+// anyway): buckets of 16 bases below 1024, quarter octaves above.  What the per-length-class plans of biosketch.hip ("class plans") are
+// cut from: which lengths occur, how many reads and bases each class holds -- without a device pass or a read-back.
+struct LenHist {
+    static constexpr int NB = 160;
+    u64 cnt[NB] = {}, bases[NB] = {};
+    u32 hi[NB] = {};  // the longest sequence of the bucket
+    u32 lo[NB];       // ... and the shortest (valid where cnt != 0)
+    LenHist() {
+        for (int i = 0; i < NB; ++i) lo[i] = 0xffffffffu;
+    }
+    static int bucket(u64 L) {
+        if (L < 1024) return (int)(L >> 4);
+        const int lg = 63 - __builtin_clzll(L);  // >= 10
+        return 64 + 4 * (lg - 10) + (int)((L >> (lg - 2)) & 3);
+    }
+    void add(u64 L) {
+        const int i = bucket(L);
+        cnt[i]++;
+        bases[i] += L;
+        if ((u32)L > hi[i]) hi[i] = (u32)L;
+        if ((u32)L < lo[i]) lo[i] = (u32)L;
+    }
 };
 
 struct bsk_batch {
@@ -66,6 +98,8 @@ struct bsk_batch {
     u64 *llen = nullptr;   // [n] bases
     u64 *adesc = nullptr;  // tile batches over ASCII: (first_byte << 24) | n_bases per tile
     bool alias = false;    // words / ascii belong to another batch (tile batches)
+    bool borrowed = false; // a VIEW of another batch (class plans): nothing but desc / bdesc / bflags / adesc is its own
+    LenHist *hist = nullptr;  // DNA batches of varying length created from host data; NULL: unknown (synthetic, tiles, translated)
     u32 *wbits = nullptr;  // one bit per packed word: the word holds a non-ACGT letter (batches that may be tiled)
     u32 *subset = nullptr; // reads with a non-ACGT letter, ascending (side launch of the ASCII kernels); nsub = n_nonacgt
     u64 nsub = 0;
@@ -86,9 +120,14 @@ struct bsk_batch {
     u64 *spare_aoff = nullptr;
 };
 
+struct ClassSet;  // biosketch.hip: the parts of a class plan (sub-batches, their results, the lists of their reads)
 struct bsk_result {
     bsk_ctx *ctx = nullptr;
     u64 n = 0, cap = 0, n_tuples = 0;
+    u64 alloc_cap = 0;  // tuples hash[] / pos[] were allocated for: cap + tail_cap
+    u64 tail_cap = 0;   // class plans: tuples behind `cap` that hold the adopted parts' slabs
+    bool arrays_borrowed = false;  // hash / pos point into another result's tail (a part of a class plan)
+    ClassSet *classes = nullptr;   // class plan of the last sizing call (owned)
     u64 n_cap = 0;  // reads the refs / status arrays were allocated for
     u64 ovf_cap = 0;  // slab kernels: tuples reserved (inside cap) for units that outgrow their slab
     u64 main_cap = 0; // tuples [0, main_cap) belong to the main launch, [main_cap, cap) to the side launch (mixed batches)
@@ -98,7 +137,7 @@ struct bsk_result {
     u8 *status = nullptr;
     u64 *hash = nullptr;
     u32 *pos = nullptr;
-    char plan[96] = "";   // what ran: kernel name of the last launch into this result (bsk_result_plan)
+    char plan[320] = "";   // what ran: kernel name of the last launch into this result (bsk_result_plan)
     int plan_grid = 0, plan_per_cu = 0;
     // The plan the arrays were SIZED for (run_planned, biosketch.hip): bsk_sketch_timed on an existing result repeats exactly this plan --
     // a fresh plan could want more rows per unit than `cap` holds (k_minimizer_ring after a fall-back to 32-row slabs) and write past it.

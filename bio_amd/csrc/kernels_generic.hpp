@@ -64,6 +64,11 @@ struct KArgs {
     // by length class, so that the 64 reads of a unit end together; a binned descriptor carries the read's place in its chunk in bits
     // 12..23 (such batches hold reads of < 4096 bases), and the reference word / status byte of the read a lane holds belong at
     // out_index(), not at unit * 64 + lane
+    // two-pass syncmer plan (kernels_syncmer_sel.hpp): selection words [unit][sel_nb][64], per read (offset in its unit << 8 | count),
+    // per unit its total and -- after the scan -- where its tuples start
+    u32 *sel_mask, *sel_cnt, *sel_utot;
+    u64 *sel_ubase, *sel_lookback;
+    u32 sel_nb;
     u32 list_grid;   // workgroups of the main launch = segments of the list of reads (list_append); the list pass may run with fewer
     u32 len_mask;    // 0xffffff, or 0xfff for binned descriptors
     u32 binned;

@@ -164,12 +164,16 @@ struct SynVec {
     static_assert(N == 16 || N == 24 || N == 32, "SynVec");
     typedef typename std::conditional<N == 16, u32x16, u32x32>::type type;  // (no 24-register class: the tuple is 32 wide)
 };
-template <int W, class LY_ = SynPkLds>
+// SEL (k_syncmer_sel, kernels_syncmer_sel.hpp): the SELECTION alone -- no k-mer hash, no staging: bit O of a block's word says whether
+// idx = idx0 + O is selected, the word leaves to HBM at the end of the block and a second pass hashes the selected k-mers only.
+template <int W, class LY_ = SynPkLds, bool SEL = false>
 struct SynPk {
     typedef LY_ LY;
     static constexpr int NW = LY::NW;
     LDSQ char *lds;
     int k, s, lane;
+    u32 bsel, nsel;   // SEL: the current block's selection bits, the lane's count so far
+    u32 *gmask;       // SEL: this lane's column of the unit's mask rows (row m is 64 words further)
     u32 end_plus1;  // number of windows of this lane (end + 1), 0: the lane does not stage
     typename SynVec<NW>::type wr;  // the read's first NW packed words
     u32 kfl, kfh, krl, krh, sfl, sfh, srl, srh;
@@ -224,7 +228,8 @@ struct SynPk {
         Nib32 ns, nk;
         ns.set(sin, sout);
         const u32 idx0 = i0 - (u32)(2 * W - 1);  // idx of offset 0 (MODE >= 2)
-        if (FUSED) {
+        if (SEL) {
+        } else if (FUSED) {
             nk.set(codes(idx0 + (u32)k - 1), codes(idx0 - 1));
         } else if (MODE == 1) {  // only offset W-1 is a fused step: idx = 0, incoming base k-1, nothing leaves
             Codes32 kin = codes((u32)k - 1), z;
@@ -271,11 +276,13 @@ struct SynPk {
                     u32 so = ns.template off<O>();
                     if (MODE == 0 && O == 0) so = 0x100u | (so & 0x30u);
                     xs[O] = tabs(so);
-                    if (FUSED || (MODE == 1 && O == W - 1)) {
+#ifndef SYNPK_NOK
+                    if (!SEL && (FUSED || (MODE == 1 && O == W - 1))) {
                         u32 ko = nk.template off<O>();
                         if (MODE == 1) ko = 0x100u | (ko & 0x30u);
                         xk[O] = tabk(ko);
                     }
+#endif
                 }
             });
         };
@@ -289,8 +296,9 @@ struct SynPk {
             }
             // ---- s-mer i_s = i0 + O ----
             rolls(xs[O]);
-            const lmask srev = lt64(srl, srh, sfl, sfh);
-            const u32 sh_ = sel(srev, srh, sfh);
+            // the key is the HIGH word of the canonical hash min(fwd, rev): min(fwd.hi, rev.hi) exactly -- where the high words are equal the
+            // minimum's high word is that value whichever strand wins -- one full-rate v_min_u32 instead of a 64-bit compare and a select
+            const u32 sh_ = sfh < srh ? sfh : srh;
             u32 pk;
             asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(pk) : "v"(sh_), "s"(0xffffffe0u), "n"(O));
             if (MODE == 3) pk = nvs > O ? pk : (badkey | (u32)(O << 5) | (u32)O);
@@ -312,6 +320,19 @@ struct SynPk {
                     tie(M, D[O]);
                     const u32 win = M < D[O] ? M : D[O];  // (a tie: the exact machine decides)
                     selm |= 1u << (win & 31u);            // v_lshl_or_b32: the winner's residue
+                    if constexpr (SEL) {
+                        u32 b = (selm >> RS) & 1u;
+                        if (MODE == 3) b &= vb >> O;
+                        selm &= ~(1u << RS);
+                        bsel |= b << O;  // v_lshl_or_b32 (lanes without a read: masked when the word leaves)
+                    } else {
+#ifdef SYNPK_NOK  // dev knock-out (timing only): the s-mer machine alone -- no k-mer hash, no staging (what a selection-only first pass would cost)
+                    u32 b = (selm >> RS) & 1u;
+                    if (MODE == 3) b &= vb >> O;
+                    if (MODE == 1) b = end_plus1 ? b : 0u;
+                    selm &= ~(1u << RS);
+                    asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(slot) : "v"(b), "v"(sstep));
+#else
                     const u32 idx = FUSED ? idx0 + (u32)O : 0u;
                     rollk(xk[O]);
                     const lmask krev = lt64(krl, krh, kfl, kfh);
@@ -327,6 +348,8 @@ struct SynPk {
                     *reinterpret_cast<LDSQ u16 *>(lds + LY::SP + (addr >> 2)) = (u16)ps;
 #endif
                     asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(slot) : "v"(b), "v"(sstep));
+#endif
+                    }
                 }
                 D[O] = M;
             }
@@ -339,6 +362,18 @@ struct SynPk {
         // row until block 2) and block 1 compares them with T.
         constexpr int RB = LY::ROW * 8;
         const int park = sstep > 0 ? (int)slot + RB : sstep < 0 ? (int)slot - ((W + 1) / 2) * RB : (int)spare;  // rows 1.. upwards / below the top row
+        if constexpr (SEL) {  // (no staging rows: the lane's column of a [W][64] table)
+            if (MODE == 1) {
+#pragma unroll
+                for (int q = 0; q < W; ++q) tie(*reinterpret_cast<LDSQ const u32 *>(lds + LY::PARK + q * 256 + lane * 4), P);
+            }
+            if (MODE >= 1) {  // the block's selection word leaves: row i0 / W - 1 of the unit's mask rows
+                const u32 wsel = end_plus1 ? bsel : 0u;
+                gmask[(i0 / (u32)W - 1u) * 64u] = wsel;
+                nsel += (u32)__builtin_popcount(wsel);
+                bsel = 0;
+            }
+        } else
         if (MODE == 1) {
 #pragma unroll
             for (int q = 0; q < W; ++q) tie(*reinterpret_cast<LDSQ const u32 *>(lds + LY::SH + park0 + (q >> 1) * RB + (q & 1) * 4), P);
@@ -351,10 +386,15 @@ struct SynPk {
             }
         }
         if (MODE == 0) {
+            if constexpr (SEL) {
+#pragma unroll
+                for (int q = 0; q < W; ++q) *reinterpret_cast<LDSQ u32 *>(lds + LY::PARK + q * 256 + lane * 4) = S[q];
+            } else {
             park0 = (u32)park;
             if (sstep != 0) {
 #pragma unroll
                 for (int q = 0; q < W; ++q) *reinterpret_cast<LDSQ u32 *>(lds + LY::SH + park0 + (q >> 1) * RB + (q & 1) * 4) = S[q];
+            }
             }
         }
     }
@@ -363,6 +403,7 @@ struct SynPk {
     __device__ __forceinline__ void run(u32 ns_max, u32 nwin_min, u32 slot0, int step, u32 col8) {
         kfl = kfh = krl = krh = sfl = sfh = srl = srh = 0;
         selm = 0;
+        bsel = nsel = 0;
         tmin = 0xffffffffu;
         spare = (u32)(LY::PR * LY::ROW * 8) + col8;
         slot = slot0;
@@ -382,7 +423,7 @@ struct SynPk {
             }
             for (; j < nb; ++j) rolls(tabs(256 + (((word >> (2 * j)) & 3) << 4)));
         }
-        for (int t0 = 0; t0 < k - 1; t0 += 16) {  // k-mer warm-up
+        for (int t0 = 0; !SEL && t0 < k - 1; t0 += 16) {  // k-mer warm-up
             const u32 word = wr[(u32)__builtin_amdgcn_readfirstlane(t0 >> 4)];
             const int nb = (k - 1 - t0) < 16 ? (k - 1 - t0) : 16;
             int j = 0;

@@ -148,6 +148,12 @@ class BatchResult:
         self.eng._chk(self.eng.lib.bsk_result_plan(self.h, C.byref(name), C.byref(grid), C.byref(per_cu)))
         return dict(kernel=(name.value or b"").decode(), grid=grid.value, waves_per_cu=per_cu.value)
 
+    def class_plan(self):
+        """bsk_result_class_plan -> (classes besides the bulk, device ms of the passes that cut the batch)"""
+        n, ms = C.c_int(), C.c_float()
+        self.eng._chk(self.eng.lib.bsk_result_class_plan(self.h, C.byref(n), C.byref(ms)))
+        return n.value, float(ms.value)
+
     def fetch(self, first: int = 0, count: Optional[int] = None):
         """-> (offsets[count+1] rebased, status[count], hash[T], pos[T] or None)"""
         inf = self.info()

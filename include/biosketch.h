@@ -266,6 +266,13 @@ int bsk_result_info(const bsk_result *r, uint64_t *n_reads, uint64_t *n_tuples, 
  * ("k_minimizer_fast<11,32,true>", "k_syncmer<1>", "... (over tiles)"), its grid and the workgroups (= wavefronts) per CU
  * that grid amounts to.  The string lives as long as the result.  Any out-pointer may be NULL. */
 int bsk_result_plan(const bsk_result *r, const char **kernel, int *grid, int *waves_per_cu);
+/* Class plans.  The reference sketches one sequence at a time: a long contig costs its own bases, whatever else is in the file
+ * (sketch.go:46, :85-94).  A batch whose lengths fall into several classes of the planner (150-base reads + a few of 400 or 5 000
+ * bases) is therefore cut by length: the class with most bases runs over the whole batch with the other reads masked, every other class
+ * as a batch of its own into the tail of the same result -- callers see one result, bsk_result_plan names every kernel
+ * ("k_minimizer_pk<11,false> + k_minimizer_dense<11> [7 reads of 151..400 bases]").  *n_parts = classes besides the bulk (0: one plan),
+ * *build_ms = device time of the passes that cut the batch (lists of the other classes' reads + the masked view), paid per bsk_sketch. */
+int bsk_result_class_plan(const bsk_result *r, int *n_parts, float *build_ms);
 /* Copy reads [first, first+count) to the host.  offsets[count+1] are rebased to 0;
  * hash/pos may be NULL; tuple_cap = capacity (in tuples) of hash[]/pos[]. */
 int bsk_result_fetch(bsk_ctx *ctx, const bsk_result *r, uint64_t first, uint64_t count,

@@ -25,4 +25,5 @@ print(f"kind={kind} k={k} x={x} n={n} tuples={inf['n_tuples']} per_read={inf['n_
 print("kernel ms:", [round(m, 3) for m in ms], "wall", round(wall, 3))
 LL = rlen or (300 if prot else 150)
 print(f"Gbases/s best={n*LL/best/1e6:.1f} avg={n*LL/(sum(ms)/len(ms))/1e6:.1f}")
+print("plan:", res.plan()["kernel"])
 print(res.digest())

@@ -11,6 +11,8 @@ import numpy as np
 from bio_amd import sketches as S, _lib as L
 
 BASES = float(sys.argv[1]) if len(sys.argv) > 1 else 3e9
+ONLY_OUTLIERS = "--only-outliers" in sys.argv           # the class-plan rows alone
+N_OUTLIER = int(float(os.environ.get("BSK_SWEEP_OUTLIER_READS", "0")))  # reads of the outlier cases (0: BASES / 150 / 1.5; the review asks for a 10^8-scale batch)
 K, W = 21, 11
 eng = S.Engine(0)
 rng = np.random.default_rng(12)
@@ -24,10 +26,14 @@ def run(case, b, nbases, extra=None, p=None):
     ms = sorted(ms)
     inf, plan = res.info(), res.plan()
     dg = res.digest()
+    nparts, cut_ms = res.class_plan()
+    prep += cut_ms  # (class plans: the passes that cut the batch by length are paid by every bsk_sketch)
     out = dict(case=case, kernel=plan["kernel"], waves_per_cu=plan["waves_per_cu"], reads=inf["n_reads"], bases=int(nbases), tuples=inf["n_tuples"],
                kernel_ms_min=round(ms[0], 4), kernel_ms_median=round(ms[len(ms) // 2], 4), gbases_per_s=round(nbases / ms[0] / 1e6, 1),
                gbases_per_s_median=round(nbases / ms[len(ms) // 2] / 1e6, 1), prepare_ms=round(prep, 4), prepare_first_ms=round(prep_first, 4),
                gbases_per_s_with_prepare=round(nbases / (ms[0] + prep) / 1e6, 1), checksum=dg["checksum"], first_window_tie_reads=dg.get("first_window_tie", None))
+    if nparts:
+        out.update(class_parts=nparts, class_cut_ms=round(cut_ms, 4))
     if extra:
         out.update(extra)
     print(json.dumps(out), flush=True)
@@ -44,7 +50,7 @@ def ragged(lo, hi, n):
 
 
 base = None
-for rl in (100, 150, 151, 200, 250, 300, 350):
+for rl in (() if ONLY_OUTLIERS else (100, 150, 151, 200, 250, 300, 350)):
     n = int(BASES / rl)
     b = eng.synth(L.ALPHA_DNA, n, rl, 0x5EED0003)
     o = run("uniform %d bp" % rl, b, n * rl)
@@ -53,13 +59,16 @@ for rl in (100, 150, 151, 200, 250, 300, 350):
     b.close()
 
 ps = eng.params(L.SYNCMER, 31, s=11)
-for rl in (150, 200, 250, 300, 350):  # syncmers k = 31 s = 11 over the read length: k_syncmer_pk, then k_syncmer_pkl (round 4; k_syncmer_fast before)
+for rl in (() if ONLY_OUTLIERS else (150, 200, 250, 300, 350)):  # syncmers k = 31 s = 11 over the read length: k_syncmer_pk, then k_syncmer_pkl (round 4; k_syncmer_fast before)
     n = int(BASES / rl)
     b = eng.synth(L.ALPHA_DNA, n, rl, 0x5EED0003)
     run("syncmers k=31 s=11, uniform %d bp" % rl, b, n * rl, p=ps)
     b.close()
 
-n = int(BASES / 105 / 1.5)  # (host-generated: two thirds of the bases)
+if ONLY_OUTLIERS:
+    n = 2048
+else:
+    n = int(BASES / 105 / 1.5)  # (host-generated: two thirds of the bases)
 data, offs = ragged(60, 150, n)
 b = eng.batch_from_arrays(data, offs)
 r1 = run("ragged 60..150 bp, length-binned units", b, int(offs[-1]), dict(vs_uniform_150=None))
@@ -76,13 +85,39 @@ assert s1["checksum"] == s2["checksum"], "binned and unbinned syncmer digests di
 b.close()
 del data, offs
 
+# outliers (round 5, class plans): 150-base reads + a few longer ones -- an outlier costs its own bases (sketch.go:46), not the batch's plan
+n = N_OUTLIER or int(BASES / 150 / 1.5)
+uni = None
+for case, outl in (("150 bp (host arrays)", []), ("150 bp + 0.01 % of 400 bases", [(1e-4, 400)]), ("150 bp + 0.01 % of 5000 bases", [(1e-4, 5000)]),
+                   ("150 bp + 1 % of 250 bases", [(1e-2, 250)]), ("150 bp + 0.01 % of 400 + 0.01 % of 5000 + 1 % of 250 bases", [(1e-4, 400), (1e-4, 5000), (1e-2, 250)])):
+    lens = np.full(n, 150, np.uint64)
+    for frac, ln in outl:
+        lens[rng.integers(0, n, int(n * frac))] = ln
+    offs = np.zeros(n + 1, np.uint64)
+    np.cumsum(lens, out=offs[1:])
+    data = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(offs[-1]), dtype=np.uint8)]
+    b = eng.batch_from_arrays(data, offs)
+    o = run(case + ", class plans", b, int(offs[-1]))
+    if not outl:
+        uni = o["gbases_per_s"]
+    else:
+        os.environ["BSK_NO_CLASS"] = "1"
+        o1 = run(case + ", one plan (BSK_NO_CLASS)", b, int(offs[-1]))
+        del os.environ["BSK_NO_CLASS"]
+        assert o["checksum"] == o1["checksum"] and o["tuples"] == o1["tuples"], "class plans and the one-plan run differ"
+        print(json.dumps(dict(case="summary: " + case, class_plans_over_uniform_150=round(o["gbases_per_s"] / uni, 3),
+                              with_cut_passes_over_uniform_150=round(o["gbases_per_s_with_prepare"] / uni, 3), one_plan_over_uniform_150=round(o1["gbases_per_s"] / uni, 3))), flush=True)
+    b.close()
+    del data, offs, lens
+
 n, rl = int(BASES / 150 / 1.5), 150
-for frac in (0.02, 0.10):
+for frac in (() if ONLY_OUTLIERS else (0.02, 0.10)):
     d = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n * rl, dtype=np.uint8)].copy().reshape(n, rl)
     d[rng.random(n) < frac, 100:] = ord("A")
     b = eng.batch_from_arrays(d.reshape(-1), np.arange(n + 1, dtype=np.uint64) * rl)
     run("%d %% of the reads end in a 50-base poly-A tail" % round(frac * 100), b, n * rl)
     b.close()
-print(json.dumps(dict(case="summary", uniform_150=base, ragged_binned_over_uniform_150=round(r1["gbases_per_s"] / base, 3),
+if not ONLY_OUTLIERS:
+  print(json.dumps(dict(case="summary", uniform_150=base, ragged_binned_over_uniform_150=round(r1["gbases_per_s"] / base, 3),
                       ragged_binned_with_prepare_over_uniform_150=round(r1["gbases_per_s_with_prepare"] / base, 3),
                       ragged_unbinned_over_uniform_150=round(r2["gbases_per_s"] / base, 3))))

@@ -98,3 +98,42 @@ def test_shim_maps_every_abi_error_code_and_only_calls_declared_symbols():
     for code in ("INVALID_K", "EMPTY_SEQ", "SHORT_SEQ", "ILLEGAL_BASE", "K_TOO_LARGE", "INVALID_M", "INVALID_SCALE", "INVALID_S", "INVALID_W",
                  "BUF_NIL", "BUF_NOT_EMPTY"):
         assert f"C.BSK_ERR_{code}:" in src and f"BSK_ERR_{code}" in hdr
+
+
+# header entries the Go shim deliberately leaves unbound -- each with its reason; anything else in include/biosketch.h must be called from Go
+GO_UNBOUND = {
+    "bsk_batch_synth": "synthetic batches: bench / tests only",
+    "bsk_sketch_timed": "HIP-event timing of repeated launches: bench only",
+    "bsk_build_has_experiments": "make EXPERIMENTS=1 probe: tests only",
+    "bsk_ctx_reload_options": "developer switches (BSK_*): tests only",
+    "bsk_codon_lut": "host copy of the device codon table: tests only (the reference has its own seq.CodonTables)",
+    "bsk_batch_fetch_ascii": "reads a batch back: tests only",
+    "bsk_pipeline_run": "C callback form of the consumer loop: a Go host loops Pipeline.Next (no callback across cgo)",
+    # the reader: a Go host HAS seqio/fastx; the C reader exists for hosts without one and feeds bsk_pipeline_open_fastx internally
+    "bsk_fastx_open": "Go hosts read with seqio/fastx", "bsk_fastx_read_chunk": "Go hosts read with seqio/fastx", "bsk_fastx_info": "Go hosts read with seqio/fastx",
+    "bsk_fastx_error": "Go hosts read with seqio/fastx", "bsk_fastx_close": "Go hosts read with seqio/fastx", "bsk_fastx_par_open": "Go hosts read with seqio/fastx",
+    "bsk_fastx_par_next": "Go hosts read with seqio/fastx", "bsk_fastx_piece_data": "Go hosts read with seqio/fastx",
+    "bsk_fastx_piece_release": "Go hosts read with seqio/fastx", "bsk_fastx_par_info": "Go hosts read with seqio/fastx",
+    "bsk_fastx_par_error": "Go hosts read with seqio/fastx", "bsk_fastx_par_close": "Go hosts read with seqio/fastx",
+    "bsk_batch_from_fastx": "Go hosts read with seqio/fastx",
+}
+
+
+def test_every_header_entry_has_a_go_binding():
+    """include/biosketch.h and the shim move together: an entry added to the header fails this test until engine.go / pipeline.go /
+    device.go call it (or it is listed above with its reason)."""
+    hdr = open(os.path.join(ROOT, "include", "biosketch.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)  # prototypes only, not the prose
+    declared = set(re.findall(r"\b(bsk_\w+)\s*\(", hdr))
+    src = "".join(open(f).read() for f in glob.glob(os.path.join(SHIM, "*.go")))
+    called = set(re.findall(r"C\.(bsk_\w+)\(", src))
+    assert len(declared) >= 70
+    unbound = sorted(declared - called - set(GO_UNBOUND))
+    assert not unbound, f"header entries without a Go binding (bind them or list them in GO_UNBOUND with a reason): {unbound}"
+    stale = sorted(set(GO_UNBOUND) & called) + sorted(set(GO_UNBOUND) - declared)
+    assert not stale, f"GO_UNBOUND lists entries that are bound or no longer declared: {stale}"
+    # struct fields the shim reads must exist in the header (a renamed field is a silent cgo build break we cannot see here)
+    for struct, fields in (("bsk_chunk", re.findall(r"\bc\.(\w+)", src)), ("bsk_pipeline_stats", re.findall(r"\bst\.(\w+)", src))):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, re.S).group(1)
+        for f in set(fields):
+            assert re.search(r"\b%s\b" % f, body), (struct, f)

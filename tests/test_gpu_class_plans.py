@@ -1,0 +1,195 @@
+"""GPU: class plans (run_classed, biosketch.hip) -- one plan per LENGTH CLASS of a batch instead of one plan keyed on the longest read.
+
+The reference sketches one sequence at a time: a 5-kb contig costs its own 5 kb and nothing else (sketches/sketch.go:46, :85-94).  A batch
+of 150-base reads with a few longer ones must therefore (a) give every read exactly the tuples of its own iterator -- per-read parity
+against the oracle, through >= 2 kernels -- and (b) keep the digest of the one-plan run (BSK_NO_CLASS)."""
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+from bio_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_dna(rng, n, alpha="ACGT"):
+    return "".join(rng.choice(alpha) for _ in range(n))
+
+
+def check_min(res, oracle, seqs, k, w, idx):
+    for i in idx:
+        s = seqs[i]
+        st, h, p = res.read(i)
+        if "N" in s:
+            assert st & L.ST_HAS_NON_ACGT, (i, st)
+        try:
+            eh, ep, es, fl = oracle.minimizer(s, k, w, False, closed=True)
+        except oracle.OracleError as e:
+            assert e.name == "ErrShortSeq"
+            assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0, (i, len(s), k, w)
+            continue
+        assert (st & L.ST_CODE_MASK) == L.ST_OK, (i, len(s), st)
+        assert np.array_equal(h, eh), (i, len(s), k, w)
+        assert np.array_equal(p & L.POS_MASK, ep), (i, len(s), k, w)
+        assert np.array_equal(p >> 31, es), (i, len(s), k, w)
+
+
+def check_syn(res, oracle, seqs, k, s_, idx):
+    for i in idx:
+        st, h, p = res.read(i)
+        try:
+            eh, ep, es, fl = oracle.syncmer(seqs[i], k, s_, False, closed=True)
+        except oracle.OracleError as e:
+            assert e.name == "ErrShortSeq"
+            assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0
+            continue
+        assert np.array_equal(h, eh), (i, len(seqs[i]))
+        assert np.array_equal(p & L.POS_MASK, ep) and np.array_equal(p >> 31, es), (i, len(seqs[i]))
+
+
+def outlier_batch(rng, n, base_len, outliers, with_n=False, ragged=False):
+    """n reads of base_len bases (ragged: 60..base_len), plus `outliers` = [(count, lo, hi)] reads of other lengths at random places"""
+    seqs = [rand_dna(rng, rng.randint(60, base_len) if ragged else base_len) for _ in range(n)]
+    for cnt, lo, hi in outliers:
+        for _ in range(cnt):
+            seqs[rng.randrange(n)] = rand_dna(rng, rng.randint(lo, hi))
+    if with_n:
+        for _ in range(n // 40):
+            i = rng.randrange(n)
+            s = seqs[i]
+            if len(s) > 3:
+                j = rng.randrange(len(s))
+                seqs[i] = s[:j] + "N" + s[j + 1:]
+    # low-complexity reads in every class (the exact machine's list)
+    seqs[5] = "A" * len(seqs[5])
+    return seqs
+
+
+CASES = [
+    ("150 + a few 400", 20000, 150, [(7, 400, 400)], False, False),
+    ("150 + a few 5000", 20000, 150, [(3, 5000, 5000)], False, False),
+    ("150 + 1 % of 250", 20000, 150, [(200, 250, 250)], False, False),
+    ("150 + 400 + 5000 + 12000, reads with N", 20000, 150, [(9, 380, 420), (3, 4000, 6000), (1, 12000, 12000)], True, False),
+    ("ragged 60..150 + 300 + 3000", 20000, 150, [(50, 280, 330), (4, 3000, 3000)], False, True),
+    ("250 + a few 150 and 2000", 18000, 250, [(100, 150, 150), (5, 2000, 2000)], False, False),
+]
+
+
+@pytest.mark.parametrize("name,n,base,outl,with_n,ragged", CASES, ids=[c[0] for c in CASES])
+def test_class_plan_per_read_parity_minimizer(engine, oracle, monkeypatch, name, n, base, outl, with_n, ragged):
+    monkeypatch.setenv("BSK_CLASS_FORCE", "1")  # (a batch this small is not worth two launches: the cost model would keep one plan)
+    rng = random.Random(zlib.crc32(name.encode()))
+    seqs = outlier_batch(rng, n, base, outl, with_n, ragged)
+    b = engine.batch(seqs)
+    p = engine.params(L.MINIMIZER, 21, w=11)
+    res = engine.run(b, p)
+    plan = res.plan()["kernel"]
+    assert plan.count("k_minimizer") >= 2 and " reads of " in plan, plan  # >= 2 kernels over one result
+    idx = list(range(0, n, 37)) + [i for i, s in enumerate(seqs) if len(s) != base or "N" in s] + [5]
+    check_min(res, oracle, seqs, 21, 11, sorted(set(idx)))
+    d = res.digest()
+    # the consumers of a result see one result: dense copy, narrow fetch and sets agree with the wide fetch
+    off, st, h, pos = res.fetch()
+    if max(len(s) for s in seqs) < 32768:
+        o32, st2, h2, p16 = res.fetch_narrow()
+        assert np.array_equal(o32.astype(np.uint64), off) and np.array_equal(st2[:n], st[:n]) and np.array_equal(h2[: int(off[-1])], h[: int(off[-1])])
+        assert np.array_equal(p16[: int(off[-1])] & 0x7FFF, pos[: int(off[-1])] & L.POS_MASK)
+    s_off, s_val = res.sets()
+    for r in (0, 5, n // 2, n - 1):
+        assert np.array_equal(np.unique(h[int(off[r]):int(off[r + 1])]), s_val[int(s_off[r]):int(s_off[r + 1])])
+    # the timed re-run (the bench's pattern) repeats the class plan
+    res2, ms = engine.run_timed(b, p, 0, 2, reuse=res)
+    assert res2.digest() == d and res2.plan()["kernel"] == plan
+    res.close()
+    # one plan per batch gives the same digest
+    monkeypatch.delenv("BSK_CLASS_FORCE")
+    monkeypatch.setenv("BSK_NO_CLASS", "1")
+    one = engine.run(b, p)
+    assert " reads of " not in one.plan()["kernel"]
+    assert one.digest() == d
+    one.close()
+    b.close()
+
+
+@pytest.mark.parametrize("outl", [[(6, 300, 300)], [(4, 2000, 2500)], [(150, 230, 260), (2, 700, 700)]])
+def test_class_plan_per_read_parity_syncmer(engine, oracle, monkeypatch, outl):
+    monkeypatch.setenv("BSK_CLASS_FORCE", "1")
+    rng = random.Random(len(outl) * 7 + outl[0][1])
+    n = 18000
+    seqs = outlier_batch(rng, n, 150, outl)
+    b = engine.batch(seqs)
+    p = engine.params(L.SYNCMER, 31, s=11)
+    res = engine.run(b, p)
+    plan = res.plan()["kernel"]
+    assert plan.count("k_syncmer") >= 2 and " reads of " in plan, plan
+    idx = sorted(set(list(range(0, n, 41)) + [i for i, s in enumerate(seqs) if len(s) != 150]))
+    check_syn(res, oracle, seqs, 31, 11, idx)
+    d = res.digest()
+    res.close()
+    monkeypatch.delenv("BSK_CLASS_FORCE")
+    monkeypatch.setenv("BSK_NO_CLASS", "1")
+    one = engine.run(b, p)
+    assert one.digest() == d
+    one.close()
+    b.close()
+
+
+def test_class_plan_is_not_taken_when_it_cannot_pay(engine):
+    """uniform batches, small batches, a bulk that is itself tile work: one plan as before"""
+    rng = random.Random(3)
+    p = engine.params(L.MINIMIZER, 21, w=11)
+    for seqs in ([rand_dna(rng, 150) for _ in range(20000)],                                   # one length
+                 [rand_dna(rng, 150) for _ in range(2000)] + [rand_dna(rng, 900)],            # small batch
+                 [rand_dna(rng, rng.randint(60, 150)) for _ in range(20000)],                  # ragged, one kernel
+                 [rand_dna(rng, 6000) for _ in range(1000)] + [rand_dna(rng, 150) for _ in range(17000)]):  # most bases are tile work
+        b = engine.batch(seqs)
+        res = engine.run(b, p)
+        assert " reads of " not in res.plan()["kernel"], res.plan()
+        res.close()
+        b.close()
+
+
+def test_class_plan_by_the_cost_model(engine, monkeypatch):
+    """a batch large enough for the cost model itself to cut it: 3 10^6 reads of 150 bases + 0.01 % of 400 and of 5 000 bases"""
+    rng = np.random.default_rng(11)
+    n = 3_000_000
+    lens = np.full(n, 150, np.uint64)
+    lens[rng.integers(0, n, 300)] = 400
+    lens[rng.integers(0, n, 300)] = 5000
+    offs = np.zeros(n + 1, np.uint64)
+    np.cumsum(lens, out=offs[1:])
+    data = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(offs[-1]), dtype=np.uint8)].copy()
+    p = engine.params(L.MINIMIZER, 21, w=11)
+    b = engine.batch_from_arrays(data, offs)
+    res = engine.run(b, p)
+    plan = res.plan()["kernel"]
+    assert plan.startswith("k_minimizer_pk<11") and plan.count(" reads of ") == 2, plan
+    d = res.digest()
+    res.close()
+    monkeypatch.setenv("BSK_NO_CLASS", "1")
+    one = engine.run(b, p)
+    assert "over tiles" in one.plan()["kernel"] and one.digest() == d
+    one.close()
+    b.close()
+
+
+def test_class_plan_through_refill_and_pipeline(engine, monkeypatch):
+    """chunks of a stream: every chunk cut on its own, parts re-used from chunk to chunk; the sink delivers what one batch gives"""
+    from bio_amd import sketches as S
+    monkeypatch.setenv("BSK_CLASS_FORCE", "1")
+    rng = np.random.default_rng(5)
+    n = 60_000
+    lens = np.full(n, 150, np.uint64)
+    lens[rng.integers(0, n, 12)] = 420
+    lens[rng.integers(0, n, 3)] = 5200
+    offs = np.zeros(n + 1, np.uint64)
+    np.cumsum(lens, out=offs[1:])
+    data = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(offs[-1]), dtype=np.uint8)].copy()
+    p = engine.params(L.MINIMIZER, 21, w=11)
+    whole = engine.run(engine.batch_from_arrays(data, offs), p)
+    assert " reads of " in whole.plan()["kernel"]
+    want = whole.digest()
+    st = S.Engine.pipeline_memory(data, offs, p, n_streams=2, chunk_records=20000, fetch=True)
+    assert st["tuples"] == want["n_tuples"] and st["checksum"] == want["checksum"]

@@ -69,3 +69,39 @@ def test_experimental_kernels_equal_the_planned_one(engine, oracle, switch, k, w
             assert np.array_equal(h2[lo_:hi_], eh) and np.array_equal(p2[lo_:hi_] & L.POS_MASK, ep) and np.array_equal(p2[lo_:hi_] >> 31, es)
             assert (int(s2[i]) & 0xF0) == fl
         b.close()
+
+
+@pytest.mark.parametrize("k,s,lo,hi", [(31, 11, 150, 150), (31, 11, 60, 224), (21, 11, 40, 200), (25, 12, 100, 180), (64, 44, 130, 224)])
+def test_two_pass_syncmer_plan_equals_the_planned_kernels(engine, oracle, monkeypatch, k, s, lo, hi):
+    """BSK_SYN_SEL=1 -> k_syncmer_sel<k - s> + k_syncmer_emit (kernels_syncmer_sel.hpp: select, then hash only what was selected --
+    measured and not planned): the same tuples and flags as the one-pass kernels, read by read against the oracle."""
+    if not _built():
+        pytest.skip("libbiosketch.so was built without the experiments (make -C bio_amd/csrc EXPERIMENTS=1)")
+    import random
+    rng = random.Random(k * 100 + s + hi)
+    n = 9000
+    seqs = ["".join(rng.choice("ACGT") for _ in range(rng.randint(lo, hi))) for _ in range(n)]
+    seqs[3] = "A" * len(seqs[3])          # a read of key ties: the exact machine's
+    seqs[4] = "AC" * (len(seqs[4]) // 2)
+    seqs[7] = seqs[7][: 2 * k - s - 2]    # too short: ErrShortSeq
+    b = engine.batch(seqs)
+    p = engine.params(L.SYNCMER, k, s=s)
+    want = engine.run(b, p)
+    wd = want.digest()
+    monkeypatch.setenv("BSK_SYN_SEL", "1")
+    got = engine.run(b, p)
+    assert "k_syncmer_sel" in got.plan()["kernel"], got.plan()
+    assert got.digest() == wd
+    for i in list(range(0, n, 97)) + [3, 4, 7]:
+        st, h, ps = got.read(i)
+        st0, h0, p0 = want.read(i)
+        assert st == st0 and np.array_equal(h, h0) and np.array_equal(ps, p0), i
+        try:
+            eh, ep, es, fl = oracle.syncmer(seqs[i], k, s, False, closed=True)
+        except oracle.OracleError:
+            assert (st & L.ST_CODE_MASK) == L.ST_SHORT
+            continue
+        assert np.array_equal(h, eh) and np.array_equal(ps & L.POS_MASK, ep) and np.array_equal(ps >> 31, es), i
+    got.close()
+    want.close()
+    b.close()

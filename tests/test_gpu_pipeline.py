@@ -290,7 +290,7 @@ def _collect(pl):
     """every chunk of the run, copied, in delivery order"""
     out = []
     for c in pl.chunks():
-        out.append(dict(seq=c.sequence, first=c.first_record, n=c.n_records, src=c.source_index, offsets=c.offsets.astype(np.uint64).copy(), status=c.status.copy(),
+        out.append(dict(seq=c.sequence, first=c.first_record, n=c.n_records, src=c.source_index, offsets=None if c.offsets is None else c.offsets.astype(np.uint64).copy(), status=None if c.status is None else c.status.copy(),
                         hash=None if c.hash is None else c.hash.copy(), pos=None if c.pos is None else c.pos.copy(),
                         strand=None if c.strand is None else c.strand.copy(), link=c.link_bytes, n_tuples=c.n_tuples, n_values=c.n_values))
     return out
