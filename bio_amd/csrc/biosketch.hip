@@ -138,12 +138,25 @@ __global__ __launch_bounds__(64) void k_class_cut(const u64 *desc, u64 n, u32 nb
         const u64 r0 = (u64)blk * ROWS * 64 + lane;
         u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;  // reads per class in this ticket (wave-uniform)
         bool any = false;
+        u64 dd[ROWS];  // all sixteen rows are requested before the first is used (gfx9 counts loads and stores in ONE in-order vmcnt: a load
+                       // issued behind the previous row's store to view[] waited for that store -- 16 round trips per ticket, 1.4 ms for 6.7 10^7 reads)
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
             const u64 r = r0 + (u64)j * 64;
-            const u64 d = r < n ? desc[r] : 0;
+            dd[j] = r < n ? desc[r] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {  // (the view's rows leave back to back: a store between two uses of loaded rows made the compiler wait for it)
+            const u64 r = r0 + (u64)j * 64;
+            const u64 d = dd[j];
             const u32 c = r < n ? class_of(cc, (u32)(d & 0xffffffULL)) : cc.bulk;
-            if (r < n) view[r] = c == cc.bulk ? d : ((d & ~0xffffffULL) | cc.pretend);
+            view[r] = c == cc.bulk ? d : ((d & ~0xffffffULL) | cc.pretend);  // (unconditional: view[] has a ticket's worth of slack behind the batch -- a branch here costs a wait per row)
+        }
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            const u64 r = r0 + (u64)j * 64;
+            const u64 d = dd[j];
+            const u32 c = r < n ? class_of(cc, (u32)(d & 0xffffffULL)) : cc.bulk;
             if (__ballot(c != cc.bulk)) {  // (rare for outlier classes: most rows are all bulk)
                 any = true;
                 c0 += (u32)__builtin_popcountll(__ballot(c == 0u));
@@ -1413,7 +1426,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         const u64 dense_slab = (std::min<u64>((u64)std::max(nwin, 0.0), (u64)(std::max(nwin, 0.0) * 2.6 / (p->w + 1.0)) + 16) + 15) & ~(u64)15;
         // k_minimizer_seg: per-read slabs of the expected count + 30 % + 4 (150 bp, w = 11: 32 tuples), rounded to 64-byte pieces
         const double exp_sel = std::max(nwin, 0.0) * 2.0 / (p->w + 1.0) + 1.0;
-        const u64 seg_slab = (std::min<u64>((u64)std::max(nwin, 1.0), (u64)(exp_sel * 1.3) + 4) + 7) & ~(u64)7;
+        [[maybe_unused]] const u64 seg_slab = (std::min<u64>((u64)std::max(nwin, 1.0), (u64)(exp_sel * 1.3) + 4) + 7) & ~(u64)7;  // (make EXPERIMENTS=1)
         // unit rows through a ring (kernels_ring.hpp): reads that select more tuples than k_minimizer_pk stages (longer than ~156 bases at
         // w = 11) up to the length where the lanes of a unit drift too far apart for a ring of 16 rows (measured: DESIGN.md 3.2)
         const double exp_tuples = nwin * 2.0 / (p->w + 1.0);
@@ -2756,7 +2769,7 @@ static int class_build(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, co
     u32 *lists = nullptr;
     u64 *view = nullptr, *sdesc = nullptr;
     HIPCHK(ctx, pool(21, (n_out + 64) * 4, (void **)&lists));
-    HIPCHK(ctx, pool(22, (b->n + 64) * 8, (void **)&view));
+    HIPCHK(ctx, pool(22, (b->n + 1024 + 64) * 8, (void **)&view));  // (+ a ticket: k_class_cut writes whole tickets)
     HIPCHK(ctx, pool(23, (n_out + 64) * 8, (void **)&sdesc));
     const u32 nblocks = (u32)((b->n + 1023) / 1024);  // k_class_list: a ticket is 16 rows of 64 reads
     int rc = ensure_scratch(ctx, nblocks, 0);
@@ -2956,6 +2969,20 @@ extern "C" int bsk_batch_prepare(bsk_ctx *ctx, const bsk_batch *batch, const bsk
     if (batch->ctx != ctx) return fail_arg(ctx, "bsk_batch_prepare: the batch belongs to another context");
     if (batch->n == 0 || p->circular || !batch->desc) return BSK_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    {  // a batch that takes a class plan: the pass that cuts it by length (its lists and the bulk's view live in the context's pool, so a
+       // class-plan RESULT sized earlier on this context can no longer be re-run by bsk_sketch_timed -- bsk_sketch sizes it again)
+        std::vector<ClassCut> cuts;
+        int bulk = 0;
+        if (class_decide(ctx, batch, p, 0, cuts, bulk)) {
+            ClassSet *tmp = new (std::nothrow) ClassSet();
+            if (!tmp) return BSK_ERR_NOMEM;
+            ctx->cls_owner = nullptr;
+            const int crc = class_build(ctx, batch, p, cuts, bulk, tmp);
+            if (ms) *ms = tmp->build_ms;
+            class_set_free(tmp);
+            return crc;
+        }
+    }
     Plan pl;
     int rc = make_plan(ctx, batch, p, pl);
     if (rc != BSK_OK || !pl.bin_gran) return rc == BSK_OK ? BSK_OK : BSK_OK;  // (parameters bsk_sketch would refuse are its to report)

@@ -277,7 +277,10 @@ struct FastMin {
             }
             if (!FIRST || o == W - 1) {
                 HV m = P;
-                if (o != W - 1) m = selv(lt64(P.lo, P.hi, S[o + 1].lo, S[o + 1].hi), P, S[o + 1]);
+                if (o != W - 1) {
+                    const int o1 = o + 1 < W ? o + 1 : o;  // (folds when the loop is unrolled; keeps the dead last iteration inside the array)
+                    m = selv(lt64(P.lo, P.hi, S[o1].lo, S[o1].hi), P, S[o1]);
+                }
                 lmask e = __builtin_amdgcn_ballot_w64(m.p != prev);
                 e &= __builtin_amdgcn_ballot_w64(vi < nk);  // per-lane bound check (a wave-uniform variant without it did not pay for its code)
                 prev = m.p;

@@ -300,7 +300,7 @@ struct PkMin {
             }
             if (!FIRST || o == W - 1) {
                 u32 m = P;
-                if (o != W - 1) {
+                if constexpr (o != W - 1) {
 #ifndef PK_NOTIE
                     const u32 d = P ^ S[o + 1];
                     tmin = tmin < d ? tmin : d;

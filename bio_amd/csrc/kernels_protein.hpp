@@ -113,7 +113,10 @@ struct FastProt {
             else P = selv(lt64(v.lo, v.hi, P.lo, P.hi), v, P);
             if (!first || o == W - 1) {
                 HV m = P;
-                if (o != W - 1) m = selv(lt64(P.lo, P.hi, S[o + 1].lo, S[o + 1].hi), P, S[o + 1]);
+                if (o != W - 1) {
+                    const int o1 = o + 1 < W ? o + 1 : o;  // (folds when the loop is unrolled; keeps the dead last iteration inside the array)
+                    m = selv(lt64(P.lo, P.hi, S[o1].lo, S[o1].hi), P, S[o1]);
+                }
                 const lmask e = __builtin_amdgcn_ballot_w64(m.p != prev) & __builtin_amdgcn_ballot_w64(vi < nk);
                 prev = m.p;
                 *reinterpret_cast<LDSQ u64 *>(lds + LY::SH + slot) = ((u64)m.hi << 32) | m.lo;

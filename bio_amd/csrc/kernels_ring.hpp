@@ -434,7 +434,7 @@ struct RgMin {
             }
             if (!FIRST || o == W - 1) {
                 u32 m = P;
-                if (o != W - 1) {
+                if constexpr (o != W - 1) {
 #ifndef RG_NOTIE
                     const u32 d = P ^ S[o + 1];
                     tmin = tmin < d ? tmin : d;

@@ -131,7 +131,7 @@ struct FastSyn {
         else P = selv(lt64(v.lo, v.hi, P.lo, P.hi), v, P);
         if (MODE >= 1 || O == W - 1) {
             HV M = P;  // leftmost min of s-mers [i_s-W+1, i_s]
-            if (MODE >= 1 && O != W - 1) M = selv(lt64(P.lo, P.hi, S[O + 1].lo, S[O + 1].hi), P, S[O + 1]);
+            if constexpr (MODE >= 1 && O != W - 1) M = selv(lt64(P.lo, P.hi, S[O + 1].lo, S[O + 1].hi), P, S[O + 1]);
             if (MODE == 2 || (MODE == 1 && O == W - 1)) {
                 // ---- fused step: idx = i_s - 2W + 1 ----
                 const u32 idx = i0 + O - (2 * W - 1);

@@ -310,7 +310,7 @@ struct SynPk {
             }
             if (MODE >= 1 || O == W - 1) {
                 u32 M = P;  // leftmost min of s-mers [i_s-W+1, i_s]
-                if (MODE >= 1 && O != W - 1) {
+                if constexpr (MODE >= 1 && O != W - 1) {
                     tie(P, S[O + 1]);
                     M = P < S[O + 1] ? P : S[O + 1];
                 }

@@ -554,7 +554,8 @@ class ProteinMinimizerSketch(_Cursor):
 
 
 class ChunkView:
-    """One chunk of a Pipeline: numpy views over the pipeline's pinned arrays, valid until the next chunk is taken (copy what you keep)."""
+    """One chunk of a Pipeline: numpy VIEWS over the pipeline's pinned arrays (no copy is made on delivery), valid until the next chunk is
+    taken -- copy what you keep.  offsets / status / hash are views; pos / strand are decoded from the narrow arrays on first use."""
 
     def __init__(self, c: L.Chunk):
         self.sequence, self.source_index, self.device = c.sequence, c.source_index, c.device
@@ -563,26 +564,37 @@ class ChunkView:
         n, nv = int(c.n_records), int(c.n_values)
 
         def view(ptr, count, dtype):
-            if not ptr or count == 0:
-                return None if not ptr else np.empty(0, dtype)
+            if not ptr:
+                return None
+            if count == 0:
+                return np.empty(0, dtype)
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(count,))
 
         self.status = view(c.status, n, np.uint8)
-        if c.offsets32:
-            self.offsets = view(c.offsets32, n + 1, np.uint32)
-        else:
-            self.offsets = view(c.offsets64, n + 1, np.uint64)
-        self.hash = view(c.hash, nv, np.uint64) if c.hash else None
-        self.pos = None
-        self.strand = None
-        if c.pos16 and nv:
-            p16 = view(c.pos16, nv, np.uint16)
-            self.pos = (p16 & 0x7FFF).astype(np.uint32)
-            self.strand = (p16 >> 15).astype(np.uint8)
-        elif c.pos32 and nv:
-            p32 = view(c.pos32, nv, np.uint32)
-            self.pos = p32 & L.POS_MASK
-            self.strand = (p32 >> 31).astype(np.uint8)
+        self.offsets = view(c.offsets32, n + 1, np.uint32) if c.offsets32 else view(c.offsets64, n + 1, np.uint64)
+        self.hash = view(c.hash, nv, np.uint64)
+        self.pos16 = view(c.pos16, nv, np.uint16) if nv else None   # BSK_POS16 encoding (bit 15 = strand), as delivered
+        self.pos32 = view(c.pos32, nv, np.uint32) if nv else None   # BSK_POS encoding (bit 31 = strand): chunks with a read of 32 768 bases or more
+        self._pos = self._strand = None
+
+    @property
+    def pos(self):
+        """positions (u32, strand bit removed), decoded on first use; None for kinds with implicit positions / sets"""
+        if self._pos is None:
+            if self.pos16 is not None:
+                self._pos = (self.pos16 & 0x7FFF).astype(np.uint32)
+            elif self.pos32 is not None:
+                self._pos = self.pos32 & L.POS_MASK
+        return self._pos
+
+    @property
+    def strand(self):
+        if self._strand is None:
+            if self.pos16 is not None:
+                self._strand = (self.pos16 >> 15).astype(np.uint8)
+            elif self.pos32 is not None:
+                self._strand = (self.pos32 >> 31).astype(np.uint8)
+        return self._strand
 
 
 class Pipeline:

@@ -74,6 +74,11 @@ def diff(golden_cases, pinned):
 
 
 def main(argv):
+    out_json = None
+    if "--json" in argv:  # machine-readable verdict for scripts/pin_apply.py
+        i = argv.index("--json")
+        out_json = argv[i + 1]
+        argv = argv[:i] + argv[i + 2:]
     if len(argv) != 2:
         print(__doc__)
         return 2
@@ -84,6 +89,7 @@ def main(argv):
     for c, what in bad:
         print("MISMATCH %s: %s" % ("%s/%s k=%s" % (c["name"], c["fn"], c.get("k")) if c else "-", what))
     print("%d of %d cases agree with upstream" % (len(golden_cases) - len(bad), len(golden_cases)))
+    verdicts = {}
     for name, (where, pred) in BANNERS.items():
         cases = [c for c in golden_cases if pred(c)]
         wrong = [c for c in cases if id(c) in bad_ids]
@@ -93,7 +99,11 @@ def main(argv):
             verdict = "KEEP (%d of %d cases differ from upstream: fix the oracle first)" % (len(wrong), len(cases))
         else:
             verdict = "can be REMOVED (%d cases pinned by upstream)" % len(cases)
+        verdicts[name] = dict(cases=len(cases), differing=len(wrong), pinned=bool(cases) and not wrong, where=where)
         print("banner %-17s %s -- %s" % (name + ":", verdict, where))
+    if out_json:
+        json.dump(dict(cases=len(golden_cases), agreeing=len(golden_cases) - len(bad), banners=verdicts,
+                       mismatches=[dict(name=c["name"], fn=c["fn"], k=c.get("k"), what=what) for c, what in bad if c]), open(out_json, "w"), indent=1)
     return 1 if bad else 0
 
 

@@ -26,8 +26,8 @@ def run(case, b, nbases, extra=None, p=None):
     ms = sorted(ms)
     inf, plan = res.info(), res.plan()
     dg = res.digest()
-    nparts, cut_ms = res.class_plan()
-    prep += cut_ms  # (class plans: the passes that cut the batch by length are paid by every bsk_sketch)
+    nparts, cut_ms = res.class_plan()  # (class plans: the pass that cuts the batch by length is paid by every bsk_sketch; eng.prepare above timed it
+    # again right behind the launches -- cut_ms is the first, cold run's: an idle board clocks down and the pass takes several times as long)
     out = dict(case=case, kernel=plan["kernel"], waves_per_cu=plan["waves_per_cu"], reads=inf["n_reads"], bases=int(nbases), tuples=inf["n_tuples"],
                kernel_ms_min=round(ms[0], 4), kernel_ms_median=round(ms[len(ms) // 2], 4), gbases_per_s=round(nbases / ms[0] / 1e6, 1),
                gbases_per_s_median=round(nbases / ms[len(ms) // 2] / 1e6, 1), prepare_ms=round(prep, 4), prepare_first_ms=round(prep_first, 4),

@@ -62,3 +62,30 @@ def test_pin_diff_accepts_agreement_and_catches_a_difference(tmp_path):
     out.write_text("".join(json.dumps(r) + "\n" for r in recs))
     p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pin_diff.py"), str(out)], capture_output=True, text=True)
     assert p.returncode == 1 and "banner wyhash:" in p.stdout and "KEEP" in p.stdout, p.stdout
+
+
+def test_pin_apply_rewrites_exactly_the_confirmed_banners(tmp_path):
+    """scripts/pin_apply.py (the last step of bindings/go/pin/run.sh --apply): with an agreeing upstream every note it knows is found in
+    the tree (dry run: nothing is written), with a differing wyhash the wyhash note is kept."""
+    cases = GOLD["cases"]
+    recs = [_as_upstream(c) for c in cases]
+    out = tmp_path / "pin_out.jsonl"
+    out.write_text("".join(json.dumps(r) + "\n" for r in recs))
+    verdict = tmp_path / "pin_verdict.json"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pin_diff.py"), str(out), "--json", str(verdict)], capture_output=True, text=True)
+    assert p.returncode == 0 and json.load(open(verdict))["banners"]["wyhash"]["pinned"]
+    before = {f: open(os.path.join(ROOT, f)).read() for f in ("oracle/bio_oracle.h", "DESIGN.md")}
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pin_apply.py"), str(verdict), "--dry-run"], capture_output=True, text=True)
+    assert q.returncode == 0, q.stdout + q.stderr
+    assert "0 note(s) rewritten" not in q.stdout, q.stdout  # every note pin_apply knows still exists in the tree
+    assert "pinned banners: wyhash" in q.stdout.replace("\n", " ") or "wyhash" in q.stdout.splitlines()[-1]
+    assert before == {f: open(os.path.join(ROOT, f)).read() for f in before}  # a dry run writes nothing
+    i = next(i for i, c in enumerate(cases) if c["fn"] == "protein_hashes")
+    recs[i] = dict(recs[i], values=[recs[i]["values"][0] ^ 1] + recs[i]["values"][1:])
+    out.write_text("".join(json.dumps(r) + "\n" for r in recs))
+    subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pin_diff.py"), str(out), "--json", str(verdict)], capture_output=True, text=True)
+    q = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pin_apply.py"), str(verdict), "--dry-run"], capture_output=True, text=True)
+    assert "banner wyhash:" in q.stdout and "kept" in [ln for ln in q.stdout.splitlines() if ln.startswith("banner wyhash:")][0]
+    # the one-command wrapper names both tools
+    sh = open(os.path.join(ROOT, "bindings", "go", "pin", "run.sh")).read()
+    assert "pin_diff.py" in sh and "pin_apply.py" in sh and "go test -tags pin -run TestPin" in sh
