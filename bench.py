@@ -162,12 +162,10 @@ def end_to_end(kind: str, p, batch, read_len: int, n_streams: int = 5):
     # the pipeline WITH a consumer (bsk_pipeline_open_memory / _next / _release: every chunk delivered in record order, the role of fastx's
     # ChunkChan, seqio/fastx/reader.go:562-608).  The consumer here touches every chunk's counts and one value per chunk -- a real one
     # does its own work on its own thread while the workers run ahead (2 x workers + 2 output buffers).
-    def sink_run(sink, scale_):
-        import time as _t
-        t0 = _t.perf_counter()
+    def sink_run(sink, scale_, streams):
         seen = vals = link = recs = 0
         order_ok = True
-        with S.Engine.pipeline_open(p, data=data, offsets=offs, devices=[0], n_streams=n_mem_streams, chunk_records=1 << 18, sink=sink, sets_scale=scale_,
+        with S.Engine.pipeline_open(p, data=data, offsets=offs, devices=[0], n_streams=streams, chunk_records=1 << 18, sink=sink, sets_scale=scale_,
                                     alphabet=alpha, repeat=2) as pl:
             for c in pl.chunks():
                 order_ok &= c.sequence == seen
@@ -178,17 +176,20 @@ def end_to_end(kind: str, p, batch, read_len: int, n_streams: int = 5):
                 if c.n_values:
                     _ = int(c.hash[0]) + int(c.offsets[-1])
         stx = pl.stats
-        return {"value": round(stx["bases"] / stx["seconds"] / 1e9, 3), "unit": "Gresidues/s" if alpha else "Gbases/s", "reads": recs, "chunks": seen,
+        return {"value": round(stx["bases"] / stx["seconds"] / 1e9, 3), "unit": "Gresidues/s" if alpha else "Gbases/s", "n_streams": streams, "reads": recs, "chunks": seen,
                 "delivered_in_order": bool(order_ok), "values_delivered": vals, "d2h_bytes_per_read": round(link / max(recs, 1), 2),
                 "h2d_bytes_per_read": (read_len + 3) // 4 + 8 if not alpha else read_len + 8, "seconds": round(stx["seconds"], 4),
                 "stage_seconds_summed_over_streams": {k_: round(stx[k_], 4) for k_ in ("h2d_pack_seconds", "kernel_seconds", "fetch_seconds")}}
     try:
         from bio_amd import _lib as _L
         out["from_memory_to_sink"] = {"what": "bsk_pipeline_open_memory + bsk_pipeline_next / _release: chunks delivered to the caller in record order",
-                                      "tuples": sink_run(_L.SINK_TUPLES, 1)}
+                                      "tuples": sink_run(_L.SINK_TUPLES, 1, n_mem_streams)}
         if kind not in STREAM:
-            out["from_memory_to_sink"]["sets_scale_1"] = sink_run(_L.SINK_SETS, 1)
-            out["from_memory_to_sink"]["sets_scale_100"] = sink_run(_L.SINK_SETS, 100)
+            # (with ~25 B per read going down the workers' host-side 2-bit packing binds: twelve workers on the box's 16 CPUs -- 57 / 67 / 70
+            # Gbases/s with 8 / 12 / 14 at scale 100, profiles/NOTEBOOK.md 5.3)
+            n_sets_streams = int(os.environ.get("BSK_BENCH_SETS_STREAMS", str(max(n_mem_streams, 12))))
+            out["from_memory_to_sink"]["sets_scale_1"] = sink_run(_L.SINK_SETS, 1, n_sets_streams)
+            out["from_memory_to_sink"]["sets_scale_100"] = sink_run(_L.SINK_SETS, 100, n_sets_streams)
             out["from_memory_to_sink"]["sets_note"] = ("BSK_SINK_SETS: per read the ascending distinct hashes with hash <= MaxUint64 / scale (iterator.go:181-185), reduced on "
                                                        "the device; scale 1 still moves ~8 B per distinct value, scale 100 moves what a FracMinHash consumer keeps")
     except Exception as e:  # the line must not be lost to this section

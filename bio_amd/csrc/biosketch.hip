@@ -132,9 +132,8 @@ __device__ __forceinline__ u32 class_of(const ClassCuts &cc, u32 len) {
 __global__ __launch_bounds__(64) void k_class_cut(const u64 *desc, u64 n, u32 nblocks, ClassCuts cc, u32 *ticket, u32 *cursor, u32 *list, u64 *sdesc, u64 *view) {
     constexpr int ROWS = 16;
     const int lane = lane_id();
-    for (;;) {
-        const u32 blk = next_ticket(ticket, lane);
-        if (blk >= nblocks) break;
+    (void)ticket;
+    for (u32 blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {  // (lists are in arrival order anyway: no ticket counter to queue at)
         const u64 r0 = (u64)blk * ROWS * 64 + lane;
         u32 c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;  // reads per class in this ticket (wave-uniform)
         bool any = false;

@@ -12,10 +12,10 @@ one() {  # kernel tag lib ring?
   if [ "$KERN" = ring ]; then export BSK_RING=1; unset BSK_NO_RING; else unset BSK_RING; export BSK_NO_RING=1; fi
   export BSK_LIB=$LIB
   # pass 1: timing (10 launches) with rocm-smi sampled while it loops
-  python $REPO/scripts/perf_quick.py $N min 21 11 ${ITERS:-400} > /tmp/l_$TAG.log 2>&1 &
+  python $REPO/scripts/perf_quick.py $N min 21 11 ${ITERS:-900} > /tmp/l_$TAG.log 2>&1 &
   PID=$!
   : > /tmp/l_$TAG.smi
-  sleep ${SMI_DELAY:-7}
+  sleep ${SMI_DELAY:-3}
   while kill -0 $PID 2>/dev/null; do
     rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk" | tr -s ' ' | tr '\n' ';' >> /tmp/l_$TAG.smi; echo >> /tmp/l_$TAG.smi
     sleep 0.05

@@ -24,7 +24,7 @@ for w in $WORKLOADS; do
   tail -3 /tmp/prof_$w.log > "$OUT/bench_${w}_rocprof_tail.log"
 done
 cd "$REPO"
-cp profiles/valu_model.json "$OUT/valu_model.json" 2>/dev/null
+cp "$(ls profiles/r*/valu_model.json | tail -1)" "$OUT/valu_model.json" 2>/dev/null  # (the VALU issue-cost model travels with the round it was last measured in)
 python scripts/profile_post.py "$OUT" "$WORKLOADS" && mkdir -p profiles/$ROUND && cp "$OUT/traffic.json" profiles/$ROUND/traffic.json
 for w in $WORKLOADS; do
   python bench.py --workload $w --steps 20 --warmup 3 > "$OUT/BENCH_${w}_n1.json" 2> "$OUT/BENCH_${w}_n1.err" || true
