@@ -2374,7 +2374,18 @@ static bool syn_long_plan_ok(const bsk_ctx *ctx, const bsk_params *p) {
 // positions one tile owns: about 22 tuples per tile (the kernels stage 32 per lane; 16 for syncmers), a multiple of 16
 static u32 tile_positions(const bsk_ctx *ctx, const bsk_params *p) {
     u32 tp;
-    if (p->kind == BSK_MINIMIZER || p->kind == BSK_PROT_MINIMIZER) tp = 16u * std::max<u32>(2, (u32)(22.0 * (p->w + 1.0) / 2.0 / 16.0));
+    if (p->kind == BSK_MINIMIZER || p->kind == BSK_PROT_MINIMIZER) {
+        tp = 16u * std::max<u32>(2, (u32)(22.0 * (p->w + 1.0) / 2.0 / 16.0));
+        // round 5: a tile carries 2w + k + 16 bases of overlap, so 128 owned positions at k=21 w=11 are a 187-base tile that selects 26
+        // tuples -- k_minimizer_dense's (526 Gbases/s of tile bases); tiles whose windows (tp + w + 18) stay at the packed machine's
+        // tuple count run on k_minimizer_pk at twice that, which more than pays for the shorter tile (2 10^9 bases of long sequences:
+        // 10.0 -> 8.8 ms, scripts/dev/perf_long2.py)
+        if (p->kind == BSK_MINIMIZER && pk_minimizer_supported(p->w) && !ctx->opt.no_pk && !ctx->opt.force_generic) {
+            const double room = (double)ctx->opt.dense_min * (p->w + 1.0) / 2.0 - p->w - 18.0;
+            const u32 tpk = room > 0 ? 16u * (u32)(room / 16.0) : 0u;
+            if (tpk >= 64u) tp = tpk;
+        }
+    }
     else if (p->kind == BSK_SYNCMER) {
         tp = 16u * std::max<u32>(2, (u32)(11.0 * (p->k - p->s + 1.0) / 2.0 / 16.0));
         // round 4: k_syncmer_pkl takes tiles three times as long at 0.9 of the rate, and a tile carries 3k + 16 bases of overlap: at k=31
@@ -2604,7 +2615,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
             sa.cap = cap;
             sa.ticket = ctx->d_ticket;
             sa.lookback = ctx->d_lookback;
-            hipLaunchKernelGGL(k_tile_stitch, dim3(std::min<u32>(tunits, (u32)ctx->cus * 24)), dim3(64), 0, ctx->stream, sa);  // latency-bound: many waves
+            hipLaunchKernelGGL(k_tile_stitch, dim3(std::min<u32>(tunits, (u32)ctx->cus * 32)), dim3(64), 0, ctx->stream, sa);  // latency-bound: every wave the CUs hold
             TCHK(hipGetLastError());
         }
     }

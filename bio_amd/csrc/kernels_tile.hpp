@@ -168,60 +168,116 @@ struct StitchArgs {
     u64 *lookback;
 };
 
-// minimizer / syncmer: keep the tuples a tile owns, shift their positions, pack them in tile order
+// minimizer / syncmer: keep the tuples a tile owns, shift their positions, pack them in tile order.
+// A unit is 64 tiles; its tile tuples are ENTRIES 0 .. K_in - 1 in tile order (entry j belongs to the first tile whose inclusive count
+// prefix exceeds j; positions ascend inside a tile, so the owned tuples of a tile are one run).  Two streaming passes over the entries, 64
+// per step, every lane one entry: the count pass (positions only) gives the unit's total for the look-back and, per tile, how many kept
+// entries precede it (oexcl); the write pass tests again (the positions come from the L2 now) and writes the kept entries behind a running
+// offset, coalesced.  (Round 4's version gave every LANE a tile: a serial scan of its ~21 positions -- 21 dependent loads -- and then a
+// search per output; it was latency-bound at 6.1 ms for 4 10^8 tile tuples, the larger half of the tiled minimizer path.)
 __global__ __launch_bounds__(64) void k_tile_stitch(StitchArgs a) {
-    __shared__ u64 s_src[64], s_dst[64], s_shift[64];
-    __shared__ u32 s_cnt[64];
+    constexpr u32 OWN_CAP = 4096;  // entries whose tile is looked up in a table (a unit of pk tiles has ~1 700; larger units search)
+    __shared__ u64 s_first[64], s_shift[64];
+    __shared__ u32 s_pre[64], s_lo[64], s_hi[64], s_stride[64];
+    __shared__ u8 s_own[OWN_CAP];
     const int lane = lane_id();
     for (;;) {
         const u32 unit = next_ticket(a.ticket, lane);
         if (unit >= a.nunits) break;
         const u64 t = (u64)unit * 64 + lane;
-        u64 src = 0, sh = 0;
-        u32 kept = 0;
-        if (t < a.nt) {
-            const u64 ref = a.trefs[t], b = ref >> 24, cnt = ref & 0xffffffULL, kp = a.keep[t];
-            const u32 lo = (u32)kp, hi = (u32)(kp >> 32);
-            u64 s = 0, e = 0;  // positions ascend inside a tile: the owned tuples are one run [s, e)
-            for (u64 i = 0; i < cnt; ++i) {
-                const u32 p = a.tpos[b + i] & BSK_POS_MASK;
-                s += p < lo;
-                e += p < hi;
+        u32 cnt = 0;
+        {
+            u64 first = 0, sh = 0;
+            u32 lo = 0, hi = 0, stride = 1;
+            if (t < a.nt) {
+                const u64 ref = a.trefs[t], kp = a.keep[t];
+                first = BSK_REF_FIRST(ref);
+                cnt = (u32)(ref & 0xffffffULL);
+                stride = (u32)BSK_REF_STRIDE(ref);
+                lo = (u32)kp;
+                hi = (u32)(kp >> 32);
+                sh = a.shift[t];
             }
-            src = b + s;
-            kept = (u32)(e - s);
-            sh = a.shift[t];
+            s_first[lane] = first;
+            s_shift[lane] = sh;
+            s_lo[lane] = lo;
+            s_hi[lane] = hi;
+            s_stride[lane] = stride;
         }
-        const u64 incl = wave_incl_scan_u64((u64)kept, lane);
-        const u64 base = lookback_exclusive(a.lookback, unit, wave_bcast_u64(incl, 63), lane);
-        const u64 dst = base + incl - kept;
-        if (t < a.nt) a.oexcl[t] = dst;
-        if (unit == a.nunits - 1 && lane == 63) a.oexcl[a.nt] = base + incl;
-        const bool ovf = base + wave_bcast_u64(incl, 63) > a.cap;
-        if (ovf) {
+        const u32 pre = wave_incl_scan_u32(cnt, lane);
+        s_pre[lane] = pre;
+        const u32 K_in = wave_bcast_u32(pre, 63);
+        const u32 start = pre - cnt;  // this lane's TILE starts at entry `start`
+        // the table entry -> tile: every tile writes its number over its own run (no waits between the writes; a search per entry is six
+        // DEPENDENT LDS round trips, and the kernel is bound by exactly that latency)
+        const bool tabled = K_in <= OWN_CAP;
+        if (tabled)
+            for (u32 i = 0; i < cnt; ++i) s_own[start + i] = (u8)lane;
+        wave_sync_lds();
+        // entry j -> (its tile o, the index of its tuple)
+        auto locate = [&](u32 j, u32 &o, u64 &src) {
+            if (tabled) {
+                o = s_own[j];
+            } else {
+                u32 lo_ = 0, hi_ = 63;  // first tile whose inclusive prefix exceeds j
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const u32 mid = (lo_ + hi_) >> 1;
+                    const bool up = s_pre[mid] > j;
+                    hi_ = up ? mid : hi_;
+                    lo_ = up ? lo_ : mid + 1;
+                }
+                o = lo_ < 63u ? lo_ : 63u;
+            }
+            const u32 before = o ? s_pre[o - 1] : 0u;  // (s_pre is inclusive)
+            src = s_first[o] + (u64)(j - before) * s_stride[o];
+        };
+        // count pass
+        u32 acc = 0, kept_total = 0;
+        for (u32 j0 = 0; j0 < K_in; j0 += 64) {
+            const u32 j = j0 + (u32)lane;
+            bool keepf = false;
+            if (j < K_in) {
+                u32 o;
+                u64 src;
+                locate(j, o, src);
+                const u32 p = a.tpos[src] & BSK_POS_MASK;
+                keepf = p >= s_lo[o] && p < s_hi[o];
+            }
+            const u64 m = __builtin_amdgcn_ballot_w64(keepf);
+            kept_total += (u32)__builtin_popcountll(m);
+            const int d = (int)start - (int)j0;  // kept entries of this step that precede this lane's tile
+            const u64 below = d <= 0 ? 0ULL : d >= 64 ? ~0ULL : ((1ULL << d) - 1ULL);
+            acc += (u32)__builtin_popcountll(m & below);
+        }
+        const u64 base = lookback_exclusive(a.lookback, unit, (u64)kept_total, lane);
+        if (t < a.nt) a.oexcl[t] = base + acc;
+        if (unit == a.nunits - 1 && lane == 63) a.oexcl[a.nt] = base + kept_total;
+        if (base + kept_total > a.cap) {
             if (lane == 0) atomicOr(&a.ticket[1], 1u);
+            wave_sync_lds();
             continue;
         }
-        s_src[lane] = src;
-        s_dst[lane] = incl;  // inclusive prefix of the kept counts inside the unit
-        s_shift[lane] = sh;
-        s_cnt[lane] = kept;
-        wave_sync_lds();
-        // the unit's kept tuples are one contiguous output run [base, base + K): output k belongs to the first tile whose
-        // inclusive prefix exceeds k (6-step search over the 64 prefixes); iterations are independent, so their loads overlap
-        const u32 K = (u32)wave_bcast_u64(incl, 63);
-        for (u32 k = (u32)lane; k < K; k += 64) {
-            u32 lo_ = 0, hi_ = 63;
-            while (lo_ < hi_) {
-                const u32 mid = (lo_ + hi_) >> 1;
-                if ((u32)s_dst[mid] > k) hi_ = mid;
-                else lo_ = mid + 1;
+        // write pass
+        u64 run = base;
+        for (u32 j0 = 0; j0 < K_in; j0 += 64) {
+            const u32 j = j0 + (u32)lane;
+            bool keepf = false;
+            u32 o = 0, praw = 0;
+            u64 src = 0;
+            if (j < K_in) {
+                locate(j, o, src);
+                praw = a.tpos[src];
+                const u32 p = praw & BSK_POS_MASK;
+                keepf = p >= s_lo[o] && p < s_hi[o];
             }
-            const u32 j = k - ((u32)s_dst[lo_] - s_cnt[lo_]);
-            const u64 sidx = s_src[lo_] + j;
-            a.ohash[base + k] = a.thash[sidx];
-            const u32 p = a.tpos[sidx];
-            a.opos[base + k] = (p & BSK_POS_STRAND_BIT) | (u32)((p & BSK_POS_MASK) + s_shift[lo_]);
+            const u64 m = __builtin_amdgcn_ballot_w64(keepf);
+            if (keepf) {
+                const u64 dst = run + (u64)__builtin_popcountll(m & ((1ULL << lane) - 1ULL));
+                a.ohash[dst] = a.thash[src];
+                a.opos[dst] = (praw & BSK_POS_STRAND_BIT) | (u32)((praw & BSK_POS_MASK) + s_shift[o]);
+            }
+            run += (u64)__builtin_popcountll(m);
         }
         wave_sync_lds();
     }
