@@ -195,6 +195,10 @@ __global__ __launch_bounds__(64) void k_class_cut(const u64 *desc, u64 n, u32 nb
         }
     }
 }
+// descriptors of a host-built class list
+__global__ void k_gather_desc(const u64 *desc, const u32 *list, u64 n, u64 *sdesc) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) sdesc[i] = desc[list[i]];
+}
 // the reads of a part take their reference words (re-based into the parent's tail) and status bytes from the part's result
 __global__ void k_adopt_refs(const u32 *list, u64 n, const u64 *crefs, const u8 *cstatus, u64 base, u64 *refs, u8 *status) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
@@ -511,6 +515,7 @@ extern "C" void bsk_batch_destroy(bsk_batch *b) {
     if (!b) return;
     if (b->ctx) (void)hipSetDevice(b->ctx->device);
     delete b->hist;
+    delete b->odd;
     if (b->borrowed) {  // a view of another batch (class plans): its descriptors live in the context's pool, only the binned copies are its own
         (void)hipFree(b->bdesc);
         (void)hipFree(b->bflags);
@@ -534,6 +539,29 @@ extern "C" void bsk_batch_destroy(bsk_batch *b) {
     (void)hipFree(b->spare_ascii);
     (void)hipFree(b->spare_aoff);
     delete b;
+}
+
+// the sequences outside the histogram's fullest bucket, if they are few (bsk_batch::odd); len(r) = bases of sequence r
+template <class LenOf>
+static void collect_odd(bsk_batch *b, u64 n, LenOf len) {
+    delete b->odd;
+    b->odd = nullptr;
+    b->modal_bucket = -1;
+    if (!b->hist || n >= (1ULL << 32)) return;
+    int mb = 0;
+    for (int i = 1; i < LenHist::NB; ++i)
+        if (b->hist->cnt[i] > b->hist->cnt[mb]) mb = i;
+    const u64 others = n - b->hist->cnt[mb];
+    if (others == 0 || others > n / 20) return;
+    auto *v = new (std::nothrow) std::vector<u64>();
+    if (!v) return;
+    v->reserve((size_t)others);
+    for (u64 r = 0; r < n; ++r) {
+        const u64 L = len(r);
+        if (LenHist::bucket(L) != mb) v->push_back((r << 32) | L);
+    }
+    b->odd = v;
+    b->modal_bucket = mb;
 }
 
 // Slack behind the packed words.  Every prefetching kernel loads a fixed number of words from every read's FIRST word -- also the last
@@ -567,6 +595,7 @@ void BskOpts::load() {
     syn_sel = on("BSK_SYN_SEL");
     class_min = env_u32("BSK_CLASS_MIN", 16384);
     class_force = on("BSK_CLASS_FORCE");
+    class_view = on("BSK_CLASS_VIEW");
     no_syn_long = on("BSK_NO_SYN_LONG");  // dev: reads beyond k_syncmer_pk's limits go to k_syncmer_fast as before round 4
     syn_margin = (int)env_u32("BSK_SYN_MARGIN", 2 + 64) - 64;  // dev: rows of slack the planner wants in k_syncmer_pk's columns (BSK_SYN_MARGIN = 64 + margin)
     no_tiles = on("BSK_NO_TILES");
@@ -706,6 +735,7 @@ static int batch_from_ascii_impl(bsk_ctx *ctx, const uint8_t *bytes, const uint6
         }
         delete b->hist;
         b->hist = hist;
+        collect_odd(b, n, [&](u64 r) { return offsets[r + 1] - offsets[r]; });
         b->n_words = w;
         const u64 alloc_words = w + pad_words(maxlen);
         BCHK(take((void **)&b->words, &b->c_words, alloc_words * sizeof(u32), donor ? (void **)&donor->words : nullptr, donor ? &donor->c_words : nullptr));
@@ -805,6 +835,7 @@ static int batch_from_packed_impl(bsk_ctx *ctx, const uint32_t *words, uint64_t 
     bsk_batch *b = new (std::nothrow) bsk_batch();
     if (!b) return BSK_ERR_NOMEM;
     b->hist = hist.release();
+    collect_odd(b, n, [&](u64 r) { return desc[r] & 0xffffffULL; });
     b->ctx = ctx;
     b->alphabet = BSK_ALPHA_DNA;
     b->n = n;
@@ -1881,6 +1912,8 @@ struct ClassSet {
     const u64 *desc = nullptr;
     const u32 *words = nullptr;
     float build_ms = 0.0f;
+    bool masked = false;   // no view array: the bulk's kernel masks by length itself (KArgs::cls_lo / cls_hi / cls_pretend)
+    u32 pretend = 0;
 };
 static void class_set_free(ClassSet *cs) {
     if (!cs) return;
@@ -2003,6 +2036,11 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     a.total = ctx->d_total;
     a.ring_w = pl.ring_w;
     a.len_mask = 0xffffffu;
+    if (cs && cs->masked) {  // class plan without a view: the kernel masks the other classes' reads itself (desc_len)
+        a.cls_lo = cs->blo;
+        a.cls_hi = cs->bhi;
+        a.cls_pretend = cs->pretend;
+    }
     if (pl.bin_gran) {  // ragged short reads on a lock-step kernel: units of reads that end together (k_bin_desc)
         const int brc = ensure_binned(ctx, b, (u32)((p->kind == BSK_SYNCMER ? p->s : p->k) - 1), pl.bin_gran);  // (the kernels step over k-mers / s-mers)
         if (brc != BSK_OK) return brc;
@@ -2751,7 +2789,8 @@ static bool class_decide(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
     ClassSig sall;
     if (!class_sig(ctx, b, p, b->n, b->n_bases, b->maxlen, sall)) return false;
     const double single = (double)b->n_bases / (1e12 * class_rate(sall, (double)b->n_bases / (double)b->n, b->maxlen > tmin, p->kind));  // seconds
-    double split = (double)b->n * (8.0 * (double)cuts.size()) / 2e12;  // the list passes: 8 bytes per read and class (+ the view) at ~2 TB/s
+    double split = (b->odd && !ctx->opt.class_view) ? 20e-6  // (the host's list of odd sequences: no device pass over the batch)
+                                                     : (double)b->n * 16.0 / 1.2e12;  // k_class_cut: 16 bytes per read at the ~1.2 TB/s it reaches
     for (const auto &c : cuts) split += (double)c.bases / (1e12 * class_rate(c.sig, c.n ? (double)c.bases / (double)c.n : 0.0, false, p->kind)) + 60e-6;  // + a launch
     return ctx->opt.class_force || split < 0.95 * single;
 }
@@ -2776,10 +2815,19 @@ static int class_build(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, co
     u64 n_out = 0;
     for (size_t i = 0; i < cuts.size(); ++i)
         if ((int)i != bulk) n_out += cuts[i].n;
+    // no device pass at all when the batch kept the list of its sequences outside the fullest bucket (bsk_batch::odd), the bulk holds that
+    // bucket and the bulk's kernel reads its lengths through desc_len(): the lists are picked on the host, the kernel masks by length
+    bool masked = false;
+    if (b->odd && b->modal_bucket >= 0 && !ctx->opt.class_view) {
+        const u32 mlo = b->hist->lo[b->modal_bucket], mhi = b->hist->hi[b->modal_bucket];
+        const Which bw = (Which)cuts[(size_t)bulk].sig.which;
+        masked = mlo >= cuts[(size_t)bulk].lo && mhi <= cuts[(size_t)bulk].hi && n_out <= b->odd->size() &&
+                 (bw == K_MIN_PK || bw == K_MIN_RING || bw == K_MIN_DENSE || bw == K_MIN_FAST || bw == K_SYN_PK || bw == K_SYN_FAST);
+    }
     u32 *lists = nullptr;
     u64 *view = nullptr, *sdesc = nullptr;
     HIPCHK(ctx, pool(21, (n_out + 64) * 4, (void **)&lists));
-    HIPCHK(ctx, pool(22, (b->n + 1024 + 64) * 8, (void **)&view));  // (+ a ticket: k_class_cut writes whole tickets)
+    if (!masked) HIPCHK(ctx, pool(22, (b->n + 1024 + 64) * 8, (void **)&view));  // (+ a ticket: k_class_cut writes whole tickets)
     HIPCHK(ctx, pool(23, (n_out + 64) * 8, (void **)&sdesc));
     const u32 nblocks = (u32)((b->n + 1023) / 1024);  // k_class_list: a ticket is 16 rows of 64 reads
     int rc = ensure_scratch(ctx, nblocks, 0);
@@ -2835,11 +2883,34 @@ static int class_build(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, co
         sb->bin_gran = 0;  // (a binned view of an earlier chunk is stale)
         at += c.n;
     }
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket, 0, 16 * sizeof(u32), ctx->stream));  // [0] the ticket, [8..15] the classes' cursors
-    // (the pass is latency-bound per ticket: every wave the CUs hold)
-    hipLaunchKernelGGL(k_class_cut, dim3(std::min<u32>(nblocks, (u32)ctx->cus * 32)), dim3(64), 0, ctx->stream, b->desc, b->n, nblocks, cc, ctx->d_ticket, ctx->d_ticket + 8,
-                       lists, sdesc, view);
+    if (masked) {  // the lists from the host's list of odd sequences (ascending), one small copy, the descriptors gathered on the device
+        std::vector<u32> host((size_t)n_out);
+        std::vector<u64> fill(cuts.size(), 0);
+        for (const u64 e : *b->odd) {
+            const u32 L = (u32)e;
+            size_t c = 0;
+            while (c + 1 < cuts.size() && L > cuts[c].hi) ++c;
+            if ((int)c == bulk) continue;  // (a sequence of the bulk outside the fullest bucket)
+            const u64 at_c = (u64)cc.first[c] + fill[c]++;
+            if (at_c >= n_out) return fail_arg(ctx, "class plan: the batch's length histogram and its list of odd sequences disagree");
+            host[(size_t)at_c] = (u32)(e >> 32);
+        }
+        for (size_t c = 0; c < cuts.size(); ++c)
+            if ((int)c != bulk && fill[c] != cuts[c].n) return fail_arg(ctx, "class plan: the batch's length histogram and its list of odd sequences disagree");
+        if (n_out) {
+            HIPCHK(ctx, hipMemcpyAsync(lists, host.data(), (size_t)n_out * 4, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (`host` is pageable and goes out of scope)
+            hipLaunchKernelGGL(k_gather_desc, dim3(grid_for(ctx, n_out, 256)), dim3(256), 0, ctx->stream, b->desc, lists, n_out, sdesc);
+        }
+    } else {
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket, 0, 16 * sizeof(u32), ctx->stream));  // [8..15] the classes' cursors
+        // (the pass is latency-bound per ticket: every wave the CUs hold)
+        hipLaunchKernelGGL(k_class_cut, dim3(std::min<u32>(nblocks, (u32)ctx->cus * 32)), dim3(64), 0, ctx->stream, b->desc, b->n, nblocks, cc, ctx->d_ticket, ctx->d_ticket + 8,
+                           lists, sdesc, view);
+    }
     HIPCHK(ctx, hipGetLastError());
+    cs->masked = masked;
+    cs->pretend = pretend;
     if (e0 && e1) {
         (void)hipEventRecord(e1, ctx->stream);
         (void)hipEventSynchronize(e1);
@@ -2858,7 +2929,8 @@ static int class_build(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, co
         *v = *b;
         v->hist = nullptr;
         v->borrowed = true;
-        v->desc = view;
+        v->odd = nullptr;
+        if (!masked) v->desc = view;  // (masked: the batch's own descriptors, the kernel masks by length)
         v->maxlen = bk.hi;
         v->n_bases = pretend ? (u64)pretend * b->n : bk.bases;
         v->uniform_len = pretend;

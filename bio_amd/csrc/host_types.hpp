@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "biosketch.h"
 #include "device_common.hpp"
@@ -20,6 +21,7 @@ struct BskOpts {
     bool syn_sel = false;    // BSK_SYN_SEL (make EXPERIMENTS=1): the two-pass syncmer plan, measured and not planned (kernels_syncmer_sel.hpp)
     bool no_class = false;   // BSK_NO_CLASS: one plan per batch, keyed on the longest read (rounds 1-4)
     u32 class_min = 16384;   // BSK_CLASS_MIN: batches below this many reads keep one plan
+    bool class_view = false;   // BSK_CLASS_VIEW: class plans always cut on the device (k_class_cut + a view of the batch), also where the host's list would do
     bool class_force = false;  // BSK_CLASS_FORCE: cut wherever the planner's choice changes, whatever the cost model says (tests: small batches)
     u32 wpr = 0, seg = 0, dense_min = 21, ring_max = 0, bin_min = 1024, waves_per_cu = 0, tile_min = 0, tile_pos = 0;  // tile_min 0: the kind's default
     void load();  // biosketch.hip
@@ -100,6 +102,11 @@ struct bsk_batch {
     bool alias = false;    // words / ascii belong to another batch (tile batches)
     bool borrowed = false; // a VIEW of another batch (class plans): nothing but desc / bdesc / bflags / adesc is its own
     LenHist *hist = nullptr;  // DNA batches of varying length created from host data; NULL: unknown (synthetic, tiles, translated)
+    // ... and, when at most a twentieth of the sequences lie outside the histogram's fullest bucket, those sequences: (index << 32) | bases,
+    // ascending.  A class plan whose bulk holds that bucket then needs NO device pass to cut the batch: the other classes' lists are picked
+    // from here on the host and the bulk's kernel masks by length itself (KArgs::cls_*).
+    std::vector<u64> *odd = nullptr;
+    int modal_bucket = -1;
     u32 *wbits = nullptr;  // one bit per packed word: the word holds a non-ACGT letter (batches that may be tiled)
     u32 *subset = nullptr; // reads with a non-ACGT letter, ascending (side launch of the ASCII kernels); nsub = n_nonacgt
     u64 nsub = 0;

@@ -520,7 +520,7 @@ __global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs 
             d = r < a.n ? a.desc[r] : 0;
             pw = *reinterpret_cast<const GLBQ u32x4_u *>((size_t)(a.words + (d >> 24)));
         }
-        const u64 off = d >> 24, L = d & 0xffffffULL;
+        const u64 off = d >> 24, L = desc_len(a, d);
         const bool nxt = unit + 1 != uend && unit + 1 < a.nunits;
         if (nxt) d_next = r + 64 < a.n ? a.desc[r + 64] : 0;
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;

@@ -69,6 +69,7 @@ struct KArgs {
     u32 *sel_mask, *sel_cnt, *sel_utot;
     u64 *sel_ubase, *sel_lookback;
     u32 sel_nb;
+    u32 cls_lo, cls_hi, cls_pretend;  // class plans: see desc_len()
     u32 list_grid;   // workgroups of the main launch = segments of the list of reads (list_append); the list pass may run with fewer
     u32 len_mask;    // 0xffffff, or 0xfff for binned descriptors
     u32 binned;
@@ -93,7 +94,14 @@ __device__ __forceinline__ void list_close(u32 *list, u32 seg, u32 cur, int lane
     if (lane == 0) list[blockIdx.x] = cur < seg ? cur : seg;
 }
 
-__device__ __forceinline__ u64 desc_len(const KArgs &a, u64 d) { return d & (u64)a.len_mask; }
+// the length a kernel works with.  Class plans (biosketch.hip, run_classed): the kernel of the BULK class runs over the whole batch and a
+// read of another class -- length outside [cls_lo, cls_hi] -- pretends cls_pretend bases (the bulk's fixed length, or 0 = an empty SHORT
+// entry); what the kernel makes of it is overwritten by the part that owns the read.  cls_hi == 0: no class plan (a scalar branch).
+__device__ __forceinline__ u64 desc_len(const KArgs &a, u64 d) {
+    u64 L = d & (u64)a.len_mask;
+    if (a.cls_hi) L = (L >= (u64)a.cls_lo && L <= (u64)a.cls_hi) ? L : (u64)a.cls_pretend;
+    return L;
+}
 // where the outputs of the read in slot r (descriptor d) go: r itself, or the read's own place in its chunk of 4096
 #ifdef BSK_BIN_NOSCATTER  // dev, timing only: what the scattered reference words / status bytes of a binned batch cost
 __device__ __forceinline__ u64 out_index(const KArgs &, u64 r, u64) { return r; }

@@ -77,9 +77,14 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("cut", ["host list", "device pass"])
 @pytest.mark.parametrize("name,n,base,outl,with_n,ragged", CASES, ids=[c[0] for c in CASES])
-def test_class_plan_per_read_parity_minimizer(engine, oracle, monkeypatch, name, n, base, outl, with_n, ragged):
+def test_class_plan_per_read_parity_minimizer(engine, oracle, monkeypatch, name, n, base, outl, with_n, ragged, cut):
+    """cut: the other classes' lists picked on the host from the batch's list of odd sequences + the bulk's kernel masking by length
+    (no device pass), or k_class_cut + a view of the batch (BSK_CLASS_VIEW; also what ragged bulks take by themselves)"""
     monkeypatch.setenv("BSK_CLASS_FORCE", "1")  # (a batch this small is not worth two launches: the cost model would keep one plan)
+    if cut == "device pass":
+        monkeypatch.setenv("BSK_CLASS_VIEW", "1")
     rng = random.Random(zlib.crc32(name.encode()))
     seqs = outlier_batch(rng, n, base, outl, with_n, ragged)
     b = engine.batch(seqs)
