@@ -54,6 +54,11 @@ struct bsk_ctx {
     void *comm = nullptr;  // ncclComm_t
     int comm_rank = 0, comm_world = 0;
     u64 *d_comm = nullptr;  // [(world + 1) * BSK_MAX_COUNTERS] device staging of bsk_gather_counts
+    // class plans: the parts (the classes besides the bulk) run on a SIDE context -- a stream and scratch of their own -- so that their
+    // small, latency-bound launches overlap with the bulk's kernel instead of queueing in front of it; two events order the two streams
+    bsk_ctx *side = nullptr;              // created on first use, destroyed with this context
+    hipEvent_t ev_side_done = nullptr, ev_adopted = nullptr;
+    bool adopted_recorded = false;
     struct ClassSet *cls = nullptr;       // the class plan a run_planned / launch in progress belongs to (biosketch.hip: run_classed)
     struct bsk_result *cls_owner = nullptr;  // the result whose class plan the pooled lists / views (tmp 21-23) currently describe
     u64 sel_need = 0;           // two-pass syncmers: the dense region a call that is being sized again needs (run_planned)
