@@ -336,7 +336,10 @@ __global__ void k_digest_status(const u8 *status, u64 n, u64 *out4) {
 // never leaves a chunk, i.e. 32 KB of reference words written by a few wavefronts at about the same time.
 // One workgroup of 512 per chunk: wave v takes rows 8 v .. 8 v + 7 (a row = 64 consecutive reads); stable ranks inside a row come from
 // ballots, class by class; cnt[row][class] is scanned over the rows by 65 threads and the class totals by one wavefront.
-__global__ __launch_bounds__(512) void k_bin_desc(const u64 *desc, const u8 *rflags, u64 n, u32 lo, u32 gran, u64 *bdesc, u8 *bflags) {
+// (mlo / mhi / mpretend: a class plan's bulk over the whole batch -- desc_len(), kernels_generic.hpp: the sequences of the other classes enter
+// with the pretended length, so that the bits of a length of 4096 or more never reach the place field)
+__global__ __launch_bounds__(512) void k_bin_desc(const u64 *desc, const u8 *rflags, u64 n, u32 lo, u32 gran, u64 *bdesc, u8 *bflags, u32 mlo, u32 mhi,
+                                                  u32 mpretend) {
     __shared__ u32 cnt[64][66];  // reads of the class in the row, then the first place of that run inside its class
     __shared__ u32 tot[66];      // reads of the class in the chunk, then the class's first place in the chunk
     const u32 tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -353,7 +356,11 @@ __global__ __launch_bounds__(512) void k_bin_desc(const u64 *desc, const u8 *rfl
             d[j] = i < n ? desc[i] : 0;
             u32 cl = 64;
             if (i < n) {
-                const u32 L = (u32)(d[j] & 0xffffffULL);
+                u32 L = (u32)(d[j] & 0xffffffULL);
+                if (mhi && (L < mlo || L > mhi)) {
+                    L = mpretend;
+                    d[j] = (d[j] & ~0xffffffULL) | L;
+                }
                 cl = L > lo ? (L - lo + gran - 1) / gran : 0u;
                 cl = cl < 63u ? cl : 63u;
             }
@@ -1382,7 +1389,7 @@ static u32 bin_gran_for(const bsk_ctx *ctx, const bsk_batch *b, int step) {
 }
 // the batch's length-binned descriptors for classes of `gran` bases above `lo`, built on the context's stream on first use and kept
 // with the batch
-static int ensure_binned(bsk_ctx *ctx, const bsk_batch *b, u32 lo, u32 gran) {
+static int ensure_binned(bsk_ctx *ctx, const bsk_batch *b, u32 lo, u32 gran, u32 mlo = 0, u32 mhi = 0, u32 mpretend = 0) {
     if (b->bin_gran == gran && b->bin_lo == lo && b->bdesc) return BSK_OK;
     const size_t need_d = (size_t)b->n * sizeof(u64), need_f = b->rflags ? (size_t)b->n : 0;
     if (b->c_bdesc < need_d) {
@@ -1401,7 +1408,7 @@ static int ensure_binned(bsk_ctx *ctx, const bsk_batch *b, u32 lo, u32 gran) {
     }
     const u64 nchunks = (b->n + 4095) / 4096;
     hipLaunchKernelGGL(k_bin_desc, dim3((unsigned)std::min<u64>(nchunks, (u64)ctx->cus * 4)), dim3(512), 0, ctx->stream, b->desc, b->rflags, b->n, lo, gran,
-                       b->bdesc, b->rflags ? b->bflags : nullptr);
+                       b->bdesc, b->rflags ? b->bflags : nullptr, mlo, mhi, mpretend);
     HIPCHK(ctx, hipGetLastError());
     b->bin_gran = gran;
     b->bin_lo = lo;
@@ -2081,7 +2088,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         a.cls_pretend = cs->pretend;
     }
     if (pl.bin_gran) {  // ragged short reads on a lock-step kernel: units of reads that end together (k_bin_desc)
-        const int brc = ensure_binned(ctx, b, (u32)((p->kind == BSK_SYNCMER ? p->s : p->k) - 1), pl.bin_gran);  // (the kernels step over k-mers / s-mers)
+        const int brc = ensure_binned(ctx, b, (u32)((p->kind == BSK_SYNCMER ? p->s : p->k) - 1), pl.bin_gran, a.cls_lo, a.cls_hi, a.cls_pretend);  // (the kernels step over k-mers / s-mers)
         if (brc != BSK_OK) return brc;
         a.desc = b->bdesc;
         a.rflags = b->rflags ? b->bflags : nullptr;

@@ -200,8 +200,12 @@ struct SynPk {
     __device__ __forceinline__ u32x4 tabk(u32 off) const { return *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TABK + off); }
     __device__ __forceinline__ u32x4 tabs(u32 off) const { return *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TABS + off); }
     __device__ __forceinline__ void tie(u32 a, u32 b) {
+#ifndef SYNPK_NOTIE  // (dev knock-out, timing only)
         const u32 d = a ^ b;
         tmin = tmin < d ? tmin : d;
+#else
+        (void)a, (void)b;
+#endif
     }
     // 32 codes from base position p0 (wave-uniform; positions beyond the 16 words read as the last words: never a valid step's)
     __device__ __forceinline__ Codes32 codes(u32 p0) const {

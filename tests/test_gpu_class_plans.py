@@ -141,6 +141,32 @@ def test_class_plan_per_read_parity_syncmer(engine, oracle, monkeypatch, outl):
     b.close()
 
 
+def test_class_plan_masked_bulk_through_length_binned_units(engine, oracle, monkeypatch):
+    """scripts/fuzz_class.py seed 27: a bulk that is itself ragged (200-base reads and the 300..419-base ones that join them) runs on
+    length-binned units while the kernel masks the other classes by length -- the binning pass has to mask too, or the high bits of a
+    4 998-base length land in the place field of the binned descriptor and a read of the bulk loses its reference word"""
+    monkeypatch.setenv("BSK_CLASS_FORCE", "1")
+    rng = random.Random(27)
+    n = 17000
+    seqs = outlier_batch(rng, n, 200, [(400, 401, 419), (40, 300, 300), (3, 700, 700), (1, 4998, 4998)])
+    b = engine.batch(seqs)
+    p = engine.params(L.MINIMIZER, 15, w=5)
+    res = engine.run(b, p)
+    plan = res.plan()["kernel"]
+    assert "length-binned" in plan and " reads of " in plan, plan
+    off, st, h, pos = res.fetch()
+    assert not np.any((st[:n] & L.ST_CODE_MASK) == L.ST_SHORT)
+    check_min(res, oracle, seqs, 15, 5, sorted(set(list(range(0, n, 53)) + [i for i, s in enumerate(seqs) if len(s) > 419] + [5])))
+    d = res.digest()
+    res.close()
+    monkeypatch.delenv("BSK_CLASS_FORCE")
+    monkeypatch.setenv("BSK_NO_CLASS", "1")
+    one = engine.run(b, p)
+    assert one.digest() == d
+    one.close()
+    b.close()
+
+
 def test_class_plan_is_not_taken_when_it_cannot_pay(engine):
     """uniform batches, small batches, a bulk that is itself tile work: one plan as before"""
     rng = random.Random(3)
