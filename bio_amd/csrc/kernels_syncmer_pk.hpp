@@ -623,13 +623,47 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_pkl(KArgs a) {
     synpk_body<W, SynPkLdsL>(a, lds);
 }
 
-#ifdef BSK_IMPL_SYNPK
 #ifndef BSK_SYNPK_WS
 #define BSK_SYNPK_WS(X) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20)
 #endif
 #ifndef BSK_SYNPKL_WS
 #define BSK_SYNPKL_WS(X) BSK_SYNPK_WS(X) X(21) X(22) X(23) X(24)
 #endif
+// three translation units that compile side by side (clean build: 30 s + 30 s + 70 s instead of 113 s in one): k_syncmer_pkl.hip has the long
+// plan's kernels, k_syncmer_fix.hip the fix pass k_syncmer_fast<W, true> of both plans, k_syncmer_pk.hip everything else
+int pkl_syncmer_blocks_per_cu(int w);
+void pkl_syncmer_launch(int w, int grid, hipStream_t stream, const KArgs &a);
+void pk_syncmer_fix_launch(int w, int fix_grid, hipStream_t stream, const KArgs &a);
+#ifdef BSK_IMPL_SYNPKL
+int pkl_syncmer_blocks_per_cu(int w) {
+    int nb = 0;
+    hipError_t e = hipErrorInvalidValue;
+#define X(WW) \
+    if (w == WW) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_syncmer_pkl<WW>, 64, 0);
+    BSK_SYNPKL_WS(X)
+#undef X
+    if (e != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        nb = 1;
+    }
+    return nb;
+}
+void pkl_syncmer_launch(int w, int grid, hipStream_t stream, const KArgs &a) {
+#define X(WW) \
+    if (w == WW) hipLaunchKernelGGL((k_syncmer_pkl<WW>), dim3(grid), dim3(64), 0, stream, a);
+    BSK_SYNPKL_WS(X)
+#undef X
+}
+#endif  // BSK_IMPL_SYNPKL
+#ifdef BSK_IMPL_SYNFIX
+void pk_syncmer_fix_launch(int w, int fix_grid, hipStream_t stream, const KArgs &a) {
+#define X(WW) \
+    if (w == WW) hipLaunchKernelGGL((k_syncmer_fast<WW, true>), dim3(fix_grid), dim3(64), 0, stream, a);
+    BSK_SYNPKL_WS(X)
+#undef X
+}
+#endif  // BSK_IMPL_SYNFIX
+#ifdef BSK_IMPL_SYNPK
 // short plan: w <= 20 (the first-window tie test parks W suffix minima in the lane's half of a 23-row staging column); long plan: w <= 24
 bool pk_syncmer_supported(int w, bool lng) {
 #define X(WW) \
@@ -646,15 +680,12 @@ static_assert(SynPkLdsL::NW <= 32 && SynPkLds::NW <= 32, "biosketch.hip: kMaxPre
 u32 pk_syncmer_max_bases(bool lng) { return 16u * (u32)((lng ? SynPkLdsL::NW : SynPkLds::NW) - 2); }  // the words a lane keeps in registers
 u32 pk_syncmer_pair_rows(bool lng) { return (u32)(lng ? SynPkLdsL::PR : SynPkLds::PR); }
 int pk_syncmer_blocks_per_cu(int w, bool lng) {
+    if (lng) return pkl_syncmer_blocks_per_cu(w);
     int nb = 0;
     hipError_t e = hipErrorInvalidValue;
 #define X(WW) \
-    if (w == WW && !lng) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_syncmer_pk<WW>, 64, 0);
+    if (w == WW) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_syncmer_pk<WW>, 64, 0);
     BSK_SYNPK_WS(X)
-#undef X
-#define X(WW) \
-    if (w == WW && lng) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_syncmer_pkl<WW>, 64, 0);
-    BSK_SYNPKL_WS(X)
 #undef X
     if (e != hipSuccess || nb < 1) {
         (void)hipGetLastError();
@@ -663,20 +694,12 @@ int pk_syncmer_blocks_per_cu(int w, bool lng) {
     return nb;
 }
 void pk_syncmer_launch(int w, bool lng, int grid, int fix_grid, hipStream_t stream, const KArgs &a) {
-#define X(WW)                                                                                   \
-    if (w == WW && !lng) {                                                                      \
-        hipLaunchKernelGGL((k_syncmer_pk<WW>), dim3(grid), dim3(64), 0, stream, a);             \
-        hipLaunchKernelGGL((k_syncmer_fast<WW, true>), dim3(fix_grid), dim3(64), 0, stream, a); \
-    }
+    if (lng) pkl_syncmer_launch(w, grid, stream, a);
+#define X(WW) \
+    if (w == WW && !lng) hipLaunchKernelGGL((k_syncmer_pk<WW>), dim3(grid), dim3(64), 0, stream, a);
     BSK_SYNPK_WS(X)
 #undef X
-#define X(WW)                                                                                   \
-    if (w == WW && lng) {                                                                       \
-        hipLaunchKernelGGL((k_syncmer_pkl<WW>), dim3(grid), dim3(64), 0, stream, a);            \
-        hipLaunchKernelGGL((k_syncmer_fast<WW, true>), dim3(fix_grid), dim3(64), 0, stream, a); \
-    }
-    BSK_SYNPKL_WS(X)
-#undef X
+    pk_syncmer_fix_launch(w, fix_grid, stream, a);
 }
 #endif  // BSK_IMPL_SYNPK
 

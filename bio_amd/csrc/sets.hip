@@ -243,6 +243,10 @@ struct ArrayOf {
     const u64 *a;
     __device__ __forceinline__ u64 operator()(u64 r) const { return a[r]; }
 };
+struct KeepOf {
+    const u32 *a;
+    __device__ __forceinline__ u64 operator()(u64 r) const { return (u64)a[r]; }
+};
 #define SCAN_PER_THREAD 8
 #define SCAN_BLOCK 256
 #define SCAN_CHUNK (SCAN_PER_THREAD * SCAN_BLOCK)
@@ -856,16 +860,13 @@ static int sets_impl(bsk_ctx *ctx, const bsk_result *r, int scope, int scale, bs
     hipLaunchKernelGGL(k_mark_heads, dim3(grid_of(ctx, n_sets, 256)), dim3(256), 0, st, set_offs, n_sets, head);
     hipLaunchKernelGGL(k_flag_unique, dim3(grid_of(ctx, N, 256)), dim3(256), 0, st, vsorted, head, N, maxhash, keep);
     SCHK(hipGetLastError());
-    auto keep64 = rocprim::make_transform_iterator(keep, [] __device__(u32 k) -> u64 { return (u64)k; });
-    SCHK(rocprim::exclusive_scan(nullptr, tb, keep64, pos, (u64)0, (size_t)N, rocprim::plus<u64>(), st));
-    SCHK(pool(9, tb ? tb : 8, &tmp));
-    SCHK(rocprim::exclusive_scan(tmp, tb, keep64, pos, (u64)0, (size_t)N, rocprim::plus<u64>(), st));
-    u64 last_pos = 0;
-    u32 last_keep = 0;
-    SCHK(hipMemcpyAsync(&last_pos, pos + (N - 1), 8, hipMemcpyDeviceToHost, st));
-    SCHK(hipMemcpyAsync(&last_keep, keep + (N - 1), 4, hipMemcpyDeviceToHost, st));
+    // (the library's own three-kernel scan: rocprim::exclusive_scan over a transform iterator was 1.1 MB of the shared object)
+    u64 *part2 = nullptr;
+    SCHK(pool(9, ((N + SCAN_CHUNK - 1) / SCAN_CHUNK + 2) * 8, (void **)&part2));
+    SCHK(scan_counts(st, KeepOf{keep}, N, part2, pos, ctx->d_total + 1, (u64 *)nullptr));
+    u64 M = 0;
+    SCHK(hipMemcpyAsync(&M, ctx->d_total + 1, 8, hipMemcpyDeviceToHost, st));
     SCHK(hipStreamSynchronize(st));
-    const u64 M = last_pos + last_keep;
     hipLaunchKernelGGL(k_scatter_unique, dim3(grid_of(ctx, N, 256)), dim3(256), 0, st, vsorted, keep, pos, N, res->values);
     hipLaunchKernelGGL(k_new_offsets, dim3(grid_of(ctx, n_sets + 1, 256)), dim3(256), 0, st, set_offs, pos, n_sets, N, M, res->offsets);
     SCHK(hipGetLastError());
