@@ -329,8 +329,9 @@ __global__ void k_digest_status(const u8 *status, u64 n, u64 *out4) {
 // Length binning (KArgs::binned).  The packed minimizer / syncmer kernels walk the 64 reads of a unit in lock-step, so a unit costs its
 // LONGEST read: trimmed reads (lengths 60..150) ran at 0.64-0.73 of the fixed-length rate.  Here the reads of every chunk of 4096 -- 64
 // units -- are stably ordered by length class, so that the reads of a unit end together.  The class is the number of `gran`-wide steps
-// the kernel takes over the read: ceil((bases - lo) / gran) (lo = k - 1, gran = a multiple of the kernel's block of w k-mers; at most
-// 64 classes; slots beyond the batch sort last).  bdesc[4096 c + j] = the descriptor of chunk c's j-th read in that order | the read's
+// the kernel takes over the read: ceil((bases - lo) / gran) (a plan's own view: lo = k - 1, gran = a multiple of the kernel's block of w k-mers,
+// at most 64 classes; the view built with the batch, bin_with_batch: lo = the shortest read - 1, gran = 1 base where the lengths span 126 or
+// fewer, 128 classes; slots beyond the batch sort last).  bdesc[4096 c + j] = the descriptor of chunk c's j-th read in that order | the read's
 // own place in the chunk << 12 (batches of reads shorter than 4096 bases: bits 12..23 of a descriptor are free); bflags follows rflags.
 // The kernels write the reference word and status byte of a read at its own place (out_index, kernels_generic.hpp): the permutation
 // never leaves a chunk, i.e. 32 KB of reference words written by a few wavefronts at about the same time.
@@ -338,14 +339,16 @@ __global__ void k_digest_status(const u8 *status, u64 n, u64 *out4) {
 // ballots, class by class; cnt[row][class] is scanned over the rows by 65 threads and the class totals by one wavefront.
 // (mlo / mhi / mpretend: a class plan's bulk over the whole batch -- desc_len(), kernels_generic.hpp: the sequences of the other classes enter
 // with the pretended length, so that the bits of a length of 4096 or more never reach the place field)
+template <int NC>  // classes: 64 (a plan's own view), 128 (the view built with the batch)
 __global__ __launch_bounds__(512) void k_bin_desc(const u64 *desc, const u8 *rflags, u64 n, u32 lo, u32 gran, u64 *bdesc, u8 *bflags, u32 mlo, u32 mhi,
                                                   u32 mpretend) {
-    __shared__ u32 cnt[64][66];  // reads of the class in the row, then the first place of that run inside its class
-    __shared__ u32 tot[66];      // reads of the class in the chunk, then the class's first place in the chunk
+    __shared__ u32 cnt[64][NC + 2];  // reads of the class in the row, then the first place of that run inside its class
+    __shared__ u32 tot[NC + 2];      // reads of the class in the chunk, then the class's first place in the chunk
+    __shared__ u32 wsum[NC / 64];
     const u32 tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const u64 nchunks = (n + 4095) / 4096;
     for (u64 c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        for (u32 i = tid; i < 64 * 66; i += 512) (&cnt[0][0])[i] = 0;
+        for (u32 i = tid; i < 64 * (NC + 2); i += 512) (&cnt[0][0])[i] = 0;
         __syncthreads();
         u64 d[8];
         u32 cls[8], rank[8];
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(512) void k_bin_desc(const u64 *desc, const u8 *rfl
             const u32 row = wave * 8 + j;
             const u64 i = c * 4096 + row * 64 + lane;
             d[j] = i < n ? desc[i] : 0;
-            u32 cl = 64;
+            u32 cl = NC;
             if (i < n) {
                 u32 L = (u32)(d[j] & 0xffffffULL);
                 if (mhi && (L < mlo || L > mhi)) {
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(512) void k_bin_desc(const u64 *desc, const u8 *rfl
                     d[j] = (d[j] & ~0xffffffULL) | L;
                 }
                 cl = L > lo ? (L - lo + gran - 1) / gran : 0u;
-                cl = cl < 63u ? cl : 63u;
+                cl = cl < (u32)(NC - 1) ? cl : (u32)(NC - 1);
             }
             u32 rk = 0;
             for (u64 todo = ~0ULL; todo;) {
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(512) void k_bin_desc(const u64 *desc, const u8 *rfl
             rank[j] = rk;
         }
         __syncthreads();
-        if (tid < 65) {
+        if (tid < NC + 1) {
             u32 run = 0;
 #pragma unroll 8
             for (int r = 0; r < 64; ++r) {
@@ -388,11 +391,20 @@ __global__ __launch_bounds__(512) void k_bin_desc(const u64 *desc, const u8 *rfl
             tot[tid] = run;
         }
         __syncthreads();
-        if (tid < 64) {  // (class 64 = the slots beyond the batch: behind everything else)
-            const u32 t = tot[tid];
-            const u32 inc = wave_incl_scan_u32(t, (int)lane);
-            tot[tid] = inc - t;
-            if (tid == 63) tot[64] = inc;
+        {  // (class NC = the slots beyond the batch: behind everything else)
+            u32 t = 0, inc = 0;
+            if (tid < NC) {
+                t = tot[tid];
+                inc = wave_incl_scan_u32(t, (int)lane);
+                if (lane == 63) wsum[wave] = inc;
+            }
+            __syncthreads();
+            if (tid < NC) {
+                u32 before = 0;
+                for (u32 q = 0; q < wave; ++q) before += wsum[q];
+                tot[tid] = before + inc - t;
+                if (tid == NC - 1) tot[NC] = before + inc;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -555,6 +567,28 @@ extern "C" void bsk_batch_destroy(bsk_batch *b) {
 }
 
 // the sequences outside the histogram's fullest bucket, if they are few (bsk_batch::odd); len(r) = bases of sequence r
+static int ensure_binned(bsk_ctx *ctx, const bsk_batch *b, u32 lo, u32 gran, u32 mlo, u32 mhi, u32 mpretend, bool fine = false);
+// The length-binned view of a ragged batch of short reads, built WITH the batch (its lengths are known there, the pass runs behind the
+// pack kernel on the same stream): classes so fine -- (longest - shortest) / 63 bases, one or two bases for trimmed reads -- that the
+// reads of a unit end within a base or two of each other whatever the plan's block of w k-mers or k - s s-mers is, so that no plan
+// needs a pass of its own (round 4: k_bin_desc per plan was 10 % of the minimizer kernel on a fresh batch; bsk_batch_prepare now
+// reports 0 for such a batch).  Only batches the planner can bin at all (bin_gran_for); BSK_NO_BIN_EARLY=1: per plan, as before.
+static int bin_with_batch(bsk_ctx *ctx, bsk_batch *b) {
+    b->bin_gran = 0;
+    b->bin_early = false;
+    if (ctx->opt.no_bin || ctx->opt.no_bin_early || b->alphabet != BSK_ALPHA_DNA || b->uniform_len || !b->desc || b->alias || b->maxlen >= 4096u || b->n < (u64)ctx->opt.bin_min || !b->hist) return BSK_OK;
+    u32 shortest = b->maxlen;
+    for (int i = 0; i < LenHist::NB; ++i)
+        if (b->hist->cnt[i] && b->hist->lo[i] < shortest) shortest = b->hist->lo[i];
+    u32 lo = shortest ? shortest - 1 : 0;
+    u32 gran = std::max<u32>(1u, (b->maxlen - lo + 125u) / 126u);  // classes 1 .. 126: the reads of a chunk in order of length when they span 126 bases or fewer
+    if (const char *e = getenv("BSK_BIN_EARLY_GRAN")) gran = (u32)atoi(e);  // dev
+    if (const char *e = getenv("BSK_BIN_EARLY_LO")) lo = (u32)atoi(e);
+    const int rc = ensure_binned(ctx, b, lo, gran, 0, 0, 0, true);
+    if (rc == BSK_OK) b->bin_early = true;
+    return rc;
+}
+
 template <class LenOf>
 static void collect_odd(bsk_batch *b, u64 n, LenOf len) {
     delete b->odd;
@@ -600,6 +634,7 @@ void BskOpts::load() {
     no_pk = on("BSK_NO_PK");
     no_ring = on("BSK_NO_RING");
     no_bin = on("BSK_NO_BIN");
+    no_bin_early = on("BSK_NO_BIN_EARLY");
     compact = on("BSK_COMPACT");
     ring = on("BSK_RING");
     ring_max = env_u32("BSK_RING_MAX", 0);
@@ -788,6 +823,7 @@ static int batch_from_ascii_impl(bsk_ctx *ctx, const uint8_t *bytes, const uint6
             hipLaunchKernelGGL(k_count_flags, dim3(grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, b->rflags, n,
                                ctx->d_ticket + 1);
         }
+        if (!wide && (rc = bin_with_batch(ctx, b)) != BSK_OK) return bail(rc);  // (ragged short reads: the length-binned view, behind the pack kernel)
         BCHK(hipMemcpyAsync(ctx->h_pinned, ctx->d_ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
         BCHK(hipStreamSynchronize(ctx->stream));  // also: desc (host vector) no longer needed after this
         BCHK(hipGetLastError());
@@ -917,6 +953,13 @@ static int batch_from_packed_impl(bsk_ctx *ctx, const uint32_t *words, uint64_t 
         return fail_hip(ctx, e, "bsk_batch_from_packed");
     }
     b->device_bytes = alloc_words * 4 + n * 9;
+    {
+        const int brc = bin_with_batch(ctx, b);  // (ragged short reads: the length-binned view comes with the batch)
+        if (brc != BSK_OK) {
+            bsk_batch_destroy(b);
+            return brc;
+        }
+    }
     *out = b;
     return BSK_OK;
 }
@@ -1389,8 +1432,10 @@ static u32 bin_gran_for(const bsk_ctx *ctx, const bsk_batch *b, int step) {
 }
 // the batch's length-binned descriptors for classes of `gran` bases above `lo`, built on the context's stream on first use and kept
 // with the batch
-static int ensure_binned(bsk_ctx *ctx, const bsk_batch *b, u32 lo, u32 gran, u32 mlo = 0, u32 mhi = 0, u32 mpretend = 0) {
-    if (b->bin_gran == gran && b->bin_lo == lo && b->bdesc) return BSK_OK;
+static int ensure_binned(bsk_ctx *ctx, const bsk_batch *b, u32 lo, u32 gran, u32 mlo, u32 mhi, u32 mpretend, bool fine) {
+    if (b->bin_early && !mhi && b->bdesc) return BSK_OK;  // built with the batch, finer than any plan's classes (bin_with_batch)
+    if (b->bin_gran == gran && b->bin_lo == lo && b->bdesc && !b->bin_early) return BSK_OK;
+    b->bin_early = false;
     const size_t need_d = (size_t)b->n * sizeof(u64), need_f = b->rflags ? (size_t)b->n : 0;
     if (b->c_bdesc < need_d) {
         (void)hipFree(b->bdesc);
@@ -1407,8 +1452,12 @@ static int ensure_binned(bsk_ctx *ctx, const bsk_batch *b, u32 lo, u32 gran, u32
         b->c_bflags = need_f + need_f / 8;
     }
     const u64 nchunks = (b->n + 4095) / 4096;
-    hipLaunchKernelGGL(k_bin_desc, dim3((unsigned)std::min<u64>(nchunks, (u64)ctx->cus * 4)), dim3(512), 0, ctx->stream, b->desc, b->rflags, b->n, lo, gran,
-                       b->bdesc, b->rflags ? b->bflags : nullptr, mlo, mhi, mpretend);
+    if (fine)
+        hipLaunchKernelGGL(k_bin_desc<128>, dim3((unsigned)std::min<u64>(nchunks, (u64)ctx->cus * 4)), dim3(512), 0, ctx->stream, b->desc, b->rflags, b->n, lo,
+                           gran, b->bdesc, b->rflags ? b->bflags : nullptr, mlo, mhi, mpretend);
+    else
+        hipLaunchKernelGGL(k_bin_desc<64>, dim3((unsigned)std::min<u64>(nchunks, (u64)ctx->cus * 4)), dim3(512), 0, ctx->stream, b->desc, b->rflags, b->n, lo,
+                           gran, b->bdesc, b->rflags ? b->bflags : nullptr, mlo, mhi, mpretend);
     HIPCHK(ctx, hipGetLastError());
     b->bin_gran = gran;
     b->bin_lo = lo;
@@ -2988,6 +3037,7 @@ static int class_build(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, co
         v->c_bflags = cbf;
         v->bin_gran = 0;
         v->bin_lo = 0;
+        v->bin_early = false;
         v->spare_ascii = nullptr;
         v->spare_aoff = nullptr;
     }
@@ -3147,9 +3197,14 @@ extern "C" int bsk_batch_prepare(bsk_ctx *ctx, const bsk_batch *batch, const bsk
             return fail_hip(ctx, ec, "bsk_batch_prepare: hipEventCreate");
         }
     }
+    if (batch->bin_early) {  // the view came with the batch: no pass per plan
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        return BSK_OK;
+    }
     batch->bin_gran = 0;  // build (again): the call is also the way to time the pass
     hipError_t e = hipEventRecord(e0, ctx->stream);
-    rc = ensure_binned(ctx, batch, (u32)((p->kind == BSK_SYNCMER ? p->s : p->k) - 1), pl.bin_gran);
+    rc = ensure_binned(ctx, batch, (u32)((p->kind == BSK_SYNCMER ? p->s : p->k) - 1), pl.bin_gran, 0, 0, 0);
     if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     float t = 0.0f;

@@ -14,7 +14,7 @@
 // Developer switches (DESIGN.md "Switches"): read from the environment ONCE, when the context is created, or again on
 // bsk_ctx_reload_options (the test suite flips them inside one process) -- never on the bsk_sketch path.
 struct BskOpts {
-    bool force_generic = false, no_mixed = false, no_dense = false, no_pk = false, no_ring = false, ring = false, no_bin = false, compact = false, no_tiles = false, no_tile_cache = false, no_group_gather = false, timing = false,
+    bool force_generic = false, no_mixed = false, no_dense = false, no_pk = false, no_ring = false, ring = false, no_bin = false, no_bin_early = false, compact = false, no_tiles = false, no_tile_cache = false, no_group_gather = false, timing = false,
          no_fused_translate = false, sets_no_small = false;
     int syn_margin = 2;
     bool no_syn_long = false;
@@ -120,6 +120,7 @@ struct bsk_batch {
     mutable u64 *bdesc = nullptr;
     mutable u8 *bflags = nullptr;
     mutable u32 bin_gran = 0, bin_lo = 0;  // bases per length class (above bin_lo) the view was built with (0: not built)
+    mutable bool bin_early = false;        // the view was built with the batch (bin_with_batch, biosketch.hip): classes finer than any plan's, no pass per plan
     mutable size_t c_bdesc = 0, c_bflags = 0;
     u8 *ascii = nullptr;  // DNA: kept only when some read has a non-ACGT byte; protein: always
     u64 *aoff = nullptr;

@@ -50,7 +50,13 @@ def test_binned_units_per_read_parity(engine, oracle, k, w, lo, hi):
     b.close()
 
 
-def test_binned_digest_equals_unbinned(engine, monkeypatch):
+@pytest.mark.parametrize("view", ["built with the batch", "built per plan"])
+def test_binned_digest_equals_unbinned(engine, monkeypatch, view):
+    """the length-binned view comes with the batch (bin_with_batch: classes of a base or two, no pass per plan -- bsk_batch_prepare has
+    nothing to do) or, BSK_NO_BIN_EARLY=1, is built by the first plan that wants it (classes of the plan's block; the pass is what
+    bsk_batch_prepare times); either way the result is the one of units in batch order"""
+    if view == "built per plan":
+        monkeypatch.setenv("BSK_NO_BIN_EARLY", "1")
     rng = np.random.default_rng(9)
     n = 200_000
     lens = rng.integers(60, 151, n, dtype=np.uint64)
@@ -59,12 +65,20 @@ def test_binned_digest_equals_unbinned(engine, monkeypatch):
     data = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(offs[-1]), dtype=np.uint8)]
     b = engine.batch_from_arrays(data, offs)
     p = engine.params(L.MINIMIZER, 21, w=11)
-    assert engine.prepare(b, p) > 0.0
+    if view == "built per plan":
+        assert engine.prepare(b, p) > 0.0
+    else:
+        assert engine.prepare(b, p) == 0.0
     res = engine.run(b, p)
     assert "length-binned" in res.plan()["kernel"]
     d1 = res.digest()
     o1, s1, h1, p1 = res.fetch()
     res.close()
+    ps = engine.params(L.SYNCMER, 31, s=11)  # (another plan over the same batch: the same view, or a second pass)
+    rs = engine.run(b, ps)
+    assert "length-binned" in rs.plan()["kernel"]
+    ds = rs.digest()
+    rs.close()
     monkeypatch.setenv("BSK_NO_BIN", "1")
     assert engine.prepare(b, p) == 0.0
     res = engine.run(b, p)
@@ -72,6 +86,9 @@ def test_binned_digest_equals_unbinned(engine, monkeypatch):
     d2 = res.digest()
     o2, s2, h2, p2 = res.fetch()
     res.close()
+    rs = engine.run(b, ps)
+    assert "length-binned" not in rs.plan()["kernel"] and rs.digest() == ds
+    rs.close()
     b.close()
     assert d1 == d2
     assert np.array_equal(o1, o2) and np.array_equal(s1, s2) and np.array_equal(h1, h2) and np.array_equal(p1, p2)
