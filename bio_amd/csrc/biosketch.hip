@@ -580,10 +580,8 @@ static int bin_with_batch(bsk_ctx *ctx, bsk_batch *b) {
     u32 shortest = b->maxlen;
     for (int i = 0; i < LenHist::NB; ++i)
         if (b->hist->cnt[i] && b->hist->lo[i] < shortest) shortest = b->hist->lo[i];
-    u32 lo = shortest ? shortest - 1 : 0;
-    u32 gran = std::max<u32>(1u, (b->maxlen - lo + 125u) / 126u);  // classes 1 .. 126: the reads of a chunk in order of length when they span 126 bases or fewer
-    if (const char *e = getenv("BSK_BIN_EARLY_GRAN")) gran = (u32)atoi(e);  // dev
-    if (const char *e = getenv("BSK_BIN_EARLY_LO")) lo = (u32)atoi(e);
+    const u32 lo = shortest ? shortest - 1 : 0;
+    const u32 gran = std::max<u32>(1u, (b->maxlen - lo + 125u) / 126u);  // classes 1 .. 126: the reads of a chunk in order of length when they span 126 bases or fewer
     const int rc = ensure_binned(ctx, b, lo, gran, 0, 0, 0, true);
     if (rc == BSK_OK) b->bin_early = true;
     return rc;

@@ -22,9 +22,6 @@ for name, p in (("minimizer k=21 w=11", eng.params(L.MINIMIZER, 21, w=11)), ("sy
     print("== %s  uniform 150: %.1f Gbases/s" % (name, uni))
     dgs = []
     modes = [("view built with the batch", {}), ("view built per plan", {"BSK_NO_BIN_EARLY": "1"}), ("batch order", {"BSK_NO_BIN": "1"})]
-    for g, lo in ((2, 59), (4, 59), (6, 59), (11, 59), (11, 20), (11, 10), (11, 15), (20, 10)):
-        if os.environ.get("BSK_BIN_SWEEP"):
-            modes.append(("early gran %d lo %d" % (g, lo), {"BSK_BIN_EARLY_GRAN": str(g), "BSK_BIN_EARLY_LO": str(lo)}))
     for mode, env in modes:
         for k_, v in env.items():
             os.environ[k_] = v
