@@ -631,6 +631,7 @@ void BskOpts::load() {
     no_dense = on("BSK_NO_DENSE");
     no_pk = on("BSK_NO_PK");
     no_ring = on("BSK_NO_RING");
+    no_pkd = on("BSK_NO_PKD");
     no_bin = on("BSK_NO_BIN");
     no_bin_early = on("BSK_NO_BIN_EARLY");
     compact = on("BSK_COMPACT");
@@ -1369,7 +1370,7 @@ static int blocks_per_cu(K kernel) {
 
 // Which kernel runs a (batch, params) pair, on how many workgroups, and how the tuple arrays are organised.
 enum Which { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST, K_NT_FAST, K_SYN_P, K_SYN_A, K_KMER_P, K_KMER_A, K_SIM_P, K_SIM_A,
-             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST, K_MIN_DENSE, K_MIN_SEG, K_MIN_WPR, K_MIN_PK, K_SYN_PK, K_MIN_RING, K_SYN_SEL };
+             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST, K_MIN_DENSE, K_MIN_SEG, K_MIN_WPR, K_MIN_PK, K_SYN_PK, K_MIN_RING, K_SYN_SEL, K_MIN_PKD };
 struct Plan {
     Which which = K_MIN_GEN_P;
     int grid = 1;
@@ -1472,7 +1473,7 @@ static u64 ring_rows(double nwin, int w) {
 #define BSK_REPLAN_UNFUSED (-1000)  // internal: the fused DNA -> protein plan gave up, run the two-step path
 
 static bool which_is_fast(Which w) {
-    return w == K_MIN_FAST || w == K_NT_FAST || w == K_SYN_FAST || w == K_SIM_FAST || w == K_MIN_DENSE || w == K_MIN_SEG || w == K_MIN_WPR || w == K_MIN_PK || w == K_SYN_PK || w == K_MIN_RING || w == K_SYN_SEL;
+    return w == K_MIN_FAST || w == K_NT_FAST || w == K_SYN_FAST || w == K_SIM_FAST || w == K_MIN_DENSE || w == K_MIN_SEG || w == K_MIN_WPR || w == K_MIN_PK || w == K_SYN_PK || w == K_MIN_RING || w == K_SYN_SEL || w == K_MIN_PKD;
 }
 
 static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan &pl, bool use_ascii);
@@ -1535,9 +1536,12 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         // unit rows through a ring (kernels_ring.hpp): reads that select more tuples than k_minimizer_pk stages (longer than ~156 bases at
         // w = 11) up to the length where the lanes of a unit drift too far apart for a ring of 16 rows (measured: DESIGN.md 3.2)
         const double exp_tuples = nwin * 2.0 / (p->w + 1.0);
-        // (measured, profiles/r04/ring_window_sweep.txt: w = 4..13 x 150..350 bases against k_minimizer_dense / k_minimizer_pk -- the wider the
-        // window, the longer the unit-row kernel stays ahead: 34 + 2 w expected tuples; BSK_RING_MAX overrides)
-        const double ring_cap = ctx->opt.ring_max ? (double)ctx->opt.ring_max : 34.0 + 2.0 * p->w;
+        // (measured, profiles/r05/pkd_ring_sweep.txt: w = 3..13 x 100..450 bases against k_minimizer_pkd, which holds 720-820 Gbases/s at any length
+        // (w >= 9) where the unit-row kernel falls with it as its lanes drift apart.  The crossover in expected tuples per read: 72 / 80 / 80 / 65
+        // at w = 3 / 4 / 5 / 6 -- two or more blocks per flush round there, and the packed machine's per-block overhead weighs more on short
+        // blocks --, 40 / 41 / 42 / 45 / 46 / 50 / 53 at w = 7 .. 13 = 18 + 2.7 w.  Round 4's rule, 34 + 2 w, was fitted against
+        // k_minimizer_dense.  BSK_RING_MAX overrides.)
+        const double ring_cap = ctx->opt.ring_max ? (double)ctx->opt.ring_max : p->w <= 5 ? 76.0 : p->w == 6 ? 65.0 : 18.0 + 2.7 * p->w;
         const bool ring_wins = ctx->opt.ring ? true : exp_tuples > (double)ctx->opt.dense_min && exp_tuples <= ring_cap;
 #ifdef BSK_EXPERIMENTS  // the two measured-and-rejected minimizer kernels (make EXPERIMENTS=1; NOTEBOOK round 2): never planned without their switch
         if (!use_ascii && p->w == 11 && p->k + p->w <= 65 && b->maxlen < 32768u && nwin >= 1.0 && ctx->opt.wpr && !ctx->no_dense && slab_budget_ok(b, seg_slab) &&
@@ -1571,6 +1575,17 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
             pl.bin_gran = bin_gran_for(ctx, b, p->w);
             per_cu = ring_minimizer_blocks_per_cu(p->w);
+        } else
+        if (!use_ascii && pkd_minimizer_supported(p->w) && !b->alias && b->maxlen < 32768u && nwin * 2.0 / (p->w + 1.0) > (double)ctx->opt.dense_min && !ctx->no_dense &&
+            !ctx->no_syn_pk && slab_budget_ok(b, dense_slab) && !ctx->opt.force_generic && !ctx->opt.no_dense && !ctx->opt.no_pk && !ctx->opt.no_pkd) {
+            pl.which = K_MIN_PKD;  // w <= 13: the packed window machine over per-read slabs and mid-read flushes (kernels_pkd.hpp)
+            pl.fast_w = p->w;
+            pl.slab = true;
+            pl.slab_read = dense_slab;  // whole 128-byte lines of hashes per read
+            pl.slab_unit = 64 * pl.slab_read;
+            pl.slab_total = (u64)pl.nunits * pl.slab_unit;
+            pl.bin_gran = bin_gran_for(ctx, b, p->w);
+            per_cu = pkd_minimizer_blocks_per_cu(p->w);
         } else
         if (!use_ascii && dense_minimizer_supported(p->w) && b->maxlen < 32768u && nwin * 2.0 / (p->w + 1.0) > (double)ctx->opt.dense_min && !ctx->no_dense && slab_budget_ok(b, dense_slab) &&
             !ctx->opt.force_generic && !ctx->opt.no_dense) {
@@ -1928,6 +1943,7 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
         case K_MIN_PK: snprintf(b, sizeof b, "k_minimizer_pk<%d,%s>", pl.fast_w, pl.fast_k ? "true" : "false"); break;
         case K_MIN_RING: snprintf(b, sizeof b, "k_minimizer_ring<%d,%s>", pl.fast_w, pl.fast_k ? "true" : "false"); break;
         case K_MIN_DENSE: snprintf(b, sizeof b, "k_minimizer_dense<%d>", pl.fast_w); break;
+        case K_MIN_PKD: snprintf(b, sizeof b, "k_minimizer_pkd<%d>", pl.fast_w); break;
         case K_MIN_SEG: snprintf(b, sizeof b, "k_minimizer_seg<%d>", pl.fast_w); break;
         case K_MIN_WPR: snprintf(b, sizeof b, "k_minimizer_wpr<%d>", pl.fast_w); break;
         case K_NT_FAST: snprintf(b, sizeof b, pl.compact ? "k_nthash_fast<%d,true>" : "k_nthash_fast<%d>", p->kind == BSK_KMER ? 2 : p->canonical ? 1 : 0); break;
@@ -2142,7 +2158,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         a.len_mask = 0xfffu;
         a.binned = 1;
     }
-    const bool lists = pl.which == K_SYN_PK || pl.which == K_MIN_PK || pl.which == K_MIN_RING || pl.which == K_SYN_SEL;
+    const bool lists = pl.which == K_SYN_PK || pl.which == K_MIN_PK || pl.which == K_MIN_RING || pl.which == K_SYN_SEL || pl.which == K_MIN_PKD;
     const u64 fixcap = lists ? syn_pk_fixcap(b->n, pl.grid) : 0;  // u32 entries, behind one u32 count per workgroup
     int rc = ensure_scratch(ctx, std::max<u32>(lists ? (u32)((fixcap + (u64)pl.grid) / 2 + 2) : pl.slab ? 1 : pl.nunits, pl.mixed ? pl.side_nunits : 0), pl.ring_entries);
     if (rc != BSK_OK) return rc;
@@ -2155,6 +2171,10 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     if (pl.which == K_MIN_PK || pl.which == K_MIN_RING) {  // slab of a listed read (k_minimizer_dense<W, true>): one tuple per window, whole 128-byte lines
         const u64 nwin_max = b->maxlen + 2 > (u32)(p->k + p->w) ? (u64)b->maxlen - p->k - p->w + 2 : 1;
         a.slab_read = (nwin_max + 15) & ~(u64)15;
+    }
+    if (pl.which == K_MIN_PKD) {  // (the main kernel has per-read slabs of its own: KArgs::slab_read; the list pass runs with list_slab)
+        const u64 nwin_max = b->maxlen + 2 > (u32)(p->k + p->w) ? (u64)b->maxlen - p->k - p->w + 2 : 1;
+        a.list_slab = (nwin_max + 15) & ~(u64)15;
     }
     a.ring_h = ctx->d_ring_h;
     a.ring_p = ctx->d_ring_p;
@@ -2171,6 +2191,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_MIN_PK: pk_minimizer_launch(pl.fast_w, b->maxlen > pk_minimizer_short_bases(), pl.grid, ctx->stream, a); break;
         case K_MIN_RING: ring_minimizer_launch(pl.fast_w, b->maxlen > ring_minimizer_short_bases(), pl.grid, ctx->stream, a); break;
         case K_MIN_DENSE: dense_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
+        case K_MIN_PKD: pkd_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
 #ifdef BSK_EXPERIMENTS
         case K_MIN_SEG: seg_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_MIN_WPR: wpr_minimizer_launch(pl.grid, ctx->stream, a); break;
@@ -2349,7 +2370,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
     rc = make_plan(ctx, b, p, pl);
     if (rc != BSK_OK) return cleanup(rc);
     u64 ovf_cap = pl.slab ? std::max<u64>(65536, pl.slab_total / (pl.which == K_SYN_SEL ? 8 : 50)) : 0;  // (two-pass syncmers: the listed reads' tuples, a few per cent of a DENSE region)
-    if (pl.which == K_MIN_PK || pl.which == K_MIN_RING) {
+    if (pl.which == K_MIN_PK || pl.which == K_MIN_RING || pl.which == K_MIN_PKD) {
         // the list pass gives every listed read a slab of one tuple per window out of this region (a wavefront claims 64 of them): room
         // for 1.5 % of the reads -- low-complexity tails are per cent of real reads -- before the call has to be sized again
         const u64 nwin_max = b->maxlen + 2 > (u32)(p->k + p->w) ? (u64)b->maxlen - p->k - p->w + 2 : 1;
@@ -2373,7 +2394,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
     }
     for (int attempt = 0; sizing && attempt < 3; ++attempt) {
         rc = result_prepare(ctx, result, b->n, p->kind, cap + side_cap, (ctx->cls && b == ctx->cls->view) ? ctx->cls->tail : 0);
-        if (rc == BSK_ERR_NOMEM && (pl.which == K_MIN_DENSE || pl.which == K_MIN_SEG || pl.which == K_MIN_WPR || pl.which == K_PROT_MIN_FAST) && attempt < 2) {
+        if (rc == BSK_ERR_NOMEM && (pl.which == K_MIN_DENSE || pl.which == K_MIN_PKD || pl.which == K_MIN_SEG || pl.which == K_MIN_WPR || pl.which == K_PROT_MIN_FAST) && attempt < 2) {
             // per-read slabs did not fit the device: the unit-slab / dense-CSR kernels need far less
             ctx->no_prot_fast = true;
             ctx->no_dense = true;
@@ -2420,7 +2441,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
             cap = pl.slab_total + ovf_cap;
             continue;
         }
-        if (pl.which == K_PROT_MIN_FAST || pl.which == K_MIN_DENSE || ((pl.which == K_SYN_PK || pl.which == K_MIN_PK || pl.which == K_MIN_RING || pl.which == K_SYN_SEL) && (ovf & 2u))) {  // a sequence outgrew its slab (unusual density), or too many reads with key ties: re-plan without that kernel
+        if (pl.which == K_PROT_MIN_FAST || pl.which == K_MIN_DENSE || ((pl.which == K_SYN_PK || pl.which == K_MIN_PK || pl.which == K_MIN_RING || pl.which == K_SYN_SEL || pl.which == K_MIN_PKD) && (ovf & 2u))) {  // a sequence outgrew its slab (unusual density), or too many reads with key ties: re-plan without that kernel
             ctx->no_prot_fast = true;
             ctx->no_dense = true;
             ctx->no_syn_pk = true;
@@ -2827,6 +2848,7 @@ static double class_rate(const ClassSig &g, double meanlen, bool tiled, int kind
         case K_MIN_PK: return 1.2;
         case K_MIN_RING: return meanlen <= 170 ? 1.06 : meanlen <= 260 ? 0.93 : 0.8;  // (150-base reads in a batch planned for its 250-base ones: 1 053 against 1 190 on k_minimizer_pk, profiles/r05)
         case K_MIN_DENSE: return 0.7;
+        case K_MIN_PKD: return 0.78;
         case K_MIN_FAST: return 0.75;
         case K_SYN_PK: return g.syn_long ? 0.8 : 0.93;
         case K_SYN_FAST: return meanlen <= 448 ? 0.6 : 0.15;
@@ -2917,7 +2939,7 @@ static int class_build(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, co
         const u32 mlo = b->hist->lo[b->modal_bucket], mhi = b->hist->hi[b->modal_bucket];
         const Which bw = (Which)cuts[(size_t)bulk].sig.which;
         masked = mlo >= cuts[(size_t)bulk].lo && mhi <= cuts[(size_t)bulk].hi && n_out <= b->odd->size() &&
-                 (bw == K_MIN_PK || bw == K_MIN_RING || bw == K_MIN_DENSE || bw == K_MIN_FAST || bw == K_SYN_PK || bw == K_SYN_FAST);
+                 (bw == K_MIN_PK || bw == K_MIN_RING || bw == K_MIN_DENSE || bw == K_MIN_PKD || bw == K_MIN_FAST || bw == K_SYN_PK || bw == K_SYN_FAST);
     }
     u32 *lists = nullptr;
     u64 *view = nullptr, *sdesc = nullptr;

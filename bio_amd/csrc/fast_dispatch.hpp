@@ -22,6 +22,11 @@ bool pk_minimizer_supported(int w);  // packed 32-bit window machine, w <= 16 (k
 int pk_minimizer_blocks_per_cu(int w);
 u32 pk_minimizer_short_bases();
 void pk_minimizer_launch(int w, bool long_reads, int grid, hipStream_t stream, const KArgs &a);
+void pk_minimizer_list_launch(int w, int grid, hipStream_t stream, const KArgs &a);  // the list pass alone: k_minimizer_dense<W, true>
+
+bool pkd_minimizer_supported(int w);  // the packed machine over per-read slabs and mid-read flushes: reads of any length below 32 768 bases (kernels_pkd.hpp)
+int pkd_minimizer_blocks_per_cu(int w);
+void pkd_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a);  // (+ the list pass with KArgs::list_slab per listed read)
 
 bool ring_minimizer_supported(int w);  // packed window machine, unit rows through a ring of 16 staged rows: three waves per SIMD (kernels_ring.hpp)
 int ring_minimizer_blocks_per_cu(int w);

@@ -607,8 +607,9 @@ __global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs 
 // one batch.  The first version (flush_rows) -- head bitmap built with LDS atomics, rank by population count, owner, its offset / destination / ring
 // head from three more arrays, a 32-bit multiply, one row at a time behind two hand-offs -- ran this round every ten steps of the
 // protein minimizer and was 47 % of that kernel (33.2 ms with it, 17.4 ms with the flushes compiled out).
+// lost: where a lane whose slab is too small says so (k_minimizer_pkd sends that read to the exact machine's list); null: the call is sized again
 template <class LY, bool STRAND16, int GL, int RING>
-__device__ __forceinline__ void flush_groups(char *lds, int lane, u32 cnt, u32 done, u64 slab_read, u64 ubase, const KArgs &a, u32 head) {
+__device__ __forceinline__ void flush_groups(char *lds, int lane, u32 cnt, u32 done, u64 slab_read, u64 ubase, const KArgs &a, u32 head, u32 *lost = nullptr) {
     constexpr u32 GM = (1u << GL) - 1u;
     u32 *s_tab = reinterpret_cast<u32 *>(lds + LY::DST);  // 128 entries: a lane holds fewer than 2 << GL + ... staged tuples (RING <= 2 << GL + GM)
     static_assert(RING <= 64 && ((RING - 1) >> GL) <= 2, "a lane flushes at most two groups per round");
@@ -618,7 +619,8 @@ __device__ __forceinline__ void flush_groups(char *lds, int lane, u32 cnt, u32 d
     const u32 U = wave_bcast_u32(incl, 63);
     if (U == 0) return;
     const bool fits = (u64)done + ((u64)units << GL) <= slab_read && (u64)done + ((u64)units << GL) < (1u << 20);
-    if (__builtin_amdgcn_ballot_w64(!fits) && lane == 0) atomicOr(&a.ticket[1], 1u);  // slab too small: host falls back
+    if (lost) *lost |= fits ? 0u : 1u;
+    else if (__builtin_amdgcn_ballot_w64(!fits) && lane == 0) atomicOr(&a.ticket[1], 1u);  // slab too small: host falls back
     if (units > 0) {
         u32 row0 = head, doff = fits ? done : 0xfffffu;
         s_tab[excl] = ((u32)lane << 26) | (row0 << 20) | doff;
@@ -681,9 +683,9 @@ __device__ __forceinline__ void flush_groups(char *lds, int lane, u32 cnt, u32 d
 // same table with the lane's count beside the entry, outputs beyond the count masked.  (Sixteen rows of 64 outputs instead of the
 // seven or eight dense ones of the first version, but four at a time and without its chain of five dependent LDS reads per row.)
 template <class LY, bool STRAND16, int GL, int RING>
-__device__ __forceinline__ void flush_last(char *lds, int lane, u32 cnt, u32 done, u64 slab_read, u64 ubase, const KArgs &a, u32 head) {
+__device__ __forceinline__ void flush_last(char *lds, int lane, u32 cnt, u32 done, u64 slab_read, u64 ubase, const KArgs &a, u32 head, u32 *lost = nullptr) {
     constexpr u32 GM = (1u << GL) - 1u;
-    flush_groups<LY, STRAND16, GL, RING>(lds, lane, cnt, done, slab_read, ubase, a, head);
+    flush_groups<LY, STRAND16, GL, RING>(lds, lane, cnt, done, slab_read, ubase, a, head, lost);
     const u32 g = cnt & ~GM;
     head += g;
     head = head >= (u32)RING ? head - (u32)RING : head;
@@ -696,7 +698,8 @@ __device__ __forceinline__ void flush_last(char *lds, int lane, u32 cnt, u32 don
     const u32 U = wave_bcast_u32(incl, 63);
     if (U == 0) return;
     const bool fits = (u64)done + c <= slab_read && (u64)done + c < (1u << 20);
-    if (__builtin_amdgcn_ballot_w64(!fits) && lane == 0) atomicOr(&a.ticket[1], 1u);
+    if (lost) *lost |= fits ? 0u : 1u;
+    else if (__builtin_amdgcn_ballot_w64(!fits) && lane == 0) atomicOr(&a.ticket[1], 1u);
     if (c) {
         s_tab[incl - 1] = ((u32)lane << 26) | (head << 20) | (fits ? done : 0xfffffu);
         s_tab[64 + incl - 1] = c;

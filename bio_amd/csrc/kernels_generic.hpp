@@ -46,6 +46,7 @@ struct KArgs {
     u32 ring_w;
     u32 uniform_len;  // != 0: every read has exactly this many bases (synthetic / fixed-length batches)
     u64 slab_read;  // per-sequence slab kernels (protein): tuples reserved per sequence
+    u64 list_slab;  // k_minimizer_pkd: the slab of a LISTED read (its list pass runs with slab_read = this)
     u32 unit_rows;  // unit-row kernels (kernels_ring.hpp): rows of 64 tuples in a unit's slab
     u64 ovf_base;   // slab kernels: first tuple index of the overflow region, and its size
     u64 ovf_cap;

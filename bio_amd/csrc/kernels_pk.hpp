@@ -67,7 +67,7 @@ struct PkLds {
 struct PkTabs {
     u32x4 row;
     u32 at;  // LDS offset of the lane's row, or ~0
-    __device__ __forceinline__ void init(int k, int lane) {
+    __device__ __forceinline__ void init(int k, int lane, u32 tab = (u32)PkLds::TAB, u32 tab2 = (u32)PkLds::TAB2) {
         row = (u32x4){0, 0, 0, 0};
         at = 0xffffffffu;
         if (lane < 20) {  // build_xtab's rows
@@ -79,13 +79,13 @@ struct PkTabs {
                 r ^= ror64(seed_rev_code(out), 1);
             }
             row = (u32x4){(u32)f, (u32)(f >> 32), (u32)r, (u32)(r >> 32)};
-            at = (u32)(PkLds::TAB + lane * 16);
+            at = tab + (u32)lane * 16u;
         } else if (lane >= 32 && lane < 48) {  // entry (c0 | c1 << 2), c0 entering first, nothing leaving
             const unsigned c0 = (unsigned)lane & 3u, c1 = ((unsigned)lane >> 2) & 3u;
             const u64 f = rol64(seed_fwd_code(c0), 1) ^ seed_fwd_code(c1);
             const u64 r = ror64(rol64(seed_rev_code(c0), (unsigned)(k - 1)), 1) ^ rol64(seed_rev_code(c1), (unsigned)(k - 1));
             row = (u32x4){(u32)f, (u32)(f >> 32), (u32)r, (u32)(r >> 32)};
-            at = (u32)(PkLds::TAB2 + (lane - 32) * 16);
+            at = tab2 + (u32)(lane - 32) * 16u;
         }
     }
     __device__ __forceinline__ void write(LDSQ char *ldsq) const {
@@ -132,9 +132,12 @@ __device__ __forceinline__ u32 pk_load_u8(const u8 *p) {
 }
 // the packed window machine + staging of one read per lane
 // LONG: reads of more than 16 (PKNW - 1) bases (their further words are loaded inside the k-mer loop)
-template <int W, bool LONG>
+// RINGM (k_minimizer_pkd, kernels_pkd.hpp): the same machine over FLds staging -- the lane's CAP + 1 rows are a ring that the kernel
+// flushes to the read's own slab every few blocks (flush_groups), so a read may select any number of tuples; the words of a block are
+// requested one block ahead (in_lo .. out_hi) and there is no register copy of the read, no paired column and no guard.
+template <int W, bool LONG, class LY_ = PkLds, bool RINGM = false>
 struct PkMin {
-    typedef PkLds LY;
+    typedef LY_ LY;
     const u32 *__restrict__ w;
     LDSQ char *lds;
     int k, lane;
@@ -148,6 +151,9 @@ struct PkMin {
     u32 glo, gspan;  // guard(): the lane's staging pointer may start a block in [glo, glo + gspan]
     u32 c8000;
     int sstep;
+    u32 send;                          // RINGM: the slot one row past the lane's last row
+    u32 in_lo, in_hi, out_lo, out_hi;  // RINGM: the packed words of the next block to run
+    u32x4 pw;                          // RINGM: the read's first four words
     // The read's first PKNW packed words (240 bases) live in registers, loaded one unit ahead, BEFORE the previous unit's copy-out
     // stores: gfx9 counts loads and stores in one in-order vmcnt, so a load issued inside the k-mer loop waits for every copy-out
     // store queued before it.  A word is picked by its wave-uniform index (s_set_gpr_idx + v_mov); longer reads load the rest.
@@ -170,8 +176,28 @@ struct PkMin {
     }
     __device__ __forceinline__ u32 word(u32 i) const {
         const u32 iu = (u32)__builtin_amdgcn_readfirstlane((int)i);
+        if constexpr (RINGM) {  // the first four words came with the unit (requested a unit ahead), the rest is loaded here
+            if (iu < 4u) return iu == 0 ? pw.x : iu == 1 ? pw.y : iu == 2 ? pw.z : pw.w;
+            return w[iu];
+        }
         if (!LONG || iu < (u32)PKNW) return wr[iu];
         return w[iu];
+    }
+    // RINGM: what block i0 reads (FastMin::load_block_words).  Block 0's come through word() -- the unit's first four words or a load --,
+    // every other block's straight from memory: a branch per word cut the head of the block into pieces (7 % of k_minimizer_pk, 9 % here)
+    __device__ __forceinline__ void load_block_words(u32 i0) {
+        const u32 t0 = i0 + (u32)k - 1, p0 = i0 - 1;
+        in_lo = w[t0 >> 4];
+        in_hi = w[(t0 >> 4) + 1];
+        out_lo = w[p0 >> 4];
+        out_hi = w[(p0 >> 4) + 1];
+    }
+    __device__ __forceinline__ void load_block0_words() {
+        const u32 t0 = (u32)k - 1;
+        in_lo = word(t0 >> 4);
+        in_hi = word((t0 >> 4) + 1);
+        out_lo = word(0);
+        out_hi = word(1);
     }
     __device__ __forceinline__ void roll(u32x4 x) {
         const u32 a = __builtin_amdgcn_alignbit(fl, fh_, 31), b = __builtin_amdgcn_alignbit(fh_, fl, 31);
@@ -195,6 +221,7 @@ struct PkMin {
     // spare row for the rest of the unit -- its count then reads as a full column and both reads of the column go to the list.  Four
     // instructions per block instead of a clamp (v_min_u32) in every staging step.
     __device__ __forceinline__ void guard() {
+        if constexpr (RINGM) return;
         const bool in = slot - glo <= gspan;
         slot = in ? slot : spare;
         sstep = in ? sstep : 0;
@@ -219,6 +246,7 @@ struct PkMin {
         asm volatile("" ::"v"(H[O]), "v"(pv), "v"(slot));
 #endif
         asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(slot) : "v"(b), "v"(sstep));  // (the compiler's bfe_i32 + and + add is one instruction more)
+        if constexpr (RINGM) slot = slot == send ? (u32)lane * 8u : slot;  // the ring's wrap
     }
 
     // FIRST: block 0 (nothing leaves at slot 0, no window is complete before its last step, nothing to emit; okbit = 0 for lanes
@@ -232,8 +260,13 @@ struct PkMin {
         constexpr int XC = PkCfg<W>::XC;
         const u32 t0 = i0 + (u32)k - 1, p0 = FIRST ? 0u : i0 - 1u;
         u32 in_lo, in_hi, out_lo, out_hi;
-        word2(t0 >> 4, in_lo, in_hi);
-        word2(p0 >> 4, out_lo, out_hi);
+        if constexpr (RINGM) {  // requested a block ago; the next block's go out now
+            in_lo = this->in_lo, in_hi = this->in_hi, out_lo = this->out_lo, out_hi = this->out_hi;
+            load_block_words(i0 + (u32)W);
+        } else {
+            word2(t0 >> 4, in_lo, in_hi);
+            word2(p0 >> 4, out_lo, out_hi);
+        }
         const u32 cinb = __builtin_amdgcn_alignbit(in_hi, in_lo, (t0 & 15) * 2);  // code of slot o at bits [2o, 2o+2)
         u32 coutb;
         if (FIRST) coutb = out_lo << 2;  // slot 0: nothing leaves; slot o >= 1 sees base o-1
@@ -346,14 +379,21 @@ struct PkMin {
         c8000 = 0x8000u;
         asm volatile("" : "+v"(c8000));  // (stays a register: as a known constant the compiler re-materialises it, or goes back to select + shift)
         tmin = 0xffffffffu;
-        spare = (u32)(LY::PR * LY::ROW * 8) + col8;  // the column's slot in the spare row
         slot = slot0;
         sstep = step;
-        {  // W staging writes from `slot` on stay in rows 0 .. PR (the spare row may be scribbled on)
+        if constexpr (RINGM) {
+            (void)col8;
+            spare = glo = gspan = 0;
+            send = (u32)(LY::ROWS * LY::ROW * 8) + (u32)lane * 8u;
+        } else {
+            spare = (u32)(LY::PR * LY::ROW * 8) + col8;  // the column's slot in the spare row
+            send = 0;
+            // W staging writes from `slot` on stay in rows 0 .. PR (the spare row may be scribbled on)
             constexpr u32 RB = (u32)(LY::ROW * 8);
             glo = step < 0 ? col8 + (u32)(W - 1) * RB : col8;
             gspan = (u32)(LY::PR - W) * RB + (step < 0 ? 0u : RB);  // low lane: up to row PR - W + 1; high lane: rows W - 1 .. PR - 1
         }
+        if constexpr (RINGM) load_block0_words();  // (ahead of the warm-up: whatever it loads is in flight meanwhile)
         for (int t0 = 0; t0 < k - 1; t0 += 16) {
             const u32 word = this->word((u32)t0 >> 4);
             const int nb = (k - 1 - t0) < 16 ? (k - 1 - t0) : 16;
@@ -648,6 +688,15 @@ int pk_minimizer_blocks_per_cu(int w) {
         nb = 1;
     }
     return nb;
+}
+void pk_minimizer_list_launch(int w, int grid, hipStream_t stream, const KArgs &a) {
+    switch (w) {
+#define X(WW) \
+    case WW: hipLaunchKernelGGL((k_minimizer_dense<WW, true>), dim3(grid), dim3(64), 0, stream, a); break;
+        BSK_PK_WS(X)
+#undef X
+        default: break;
+    }
 }
 void pk_minimizer_launch(int w, bool long_reads, int grid, hipStream_t stream, const KArgs &a) {
     switch (w) {

@@ -142,21 +142,26 @@ def test_class_plan_per_read_parity_syncmer(engine, oracle, monkeypatch, outl):
 
 
 def test_class_plan_masked_bulk_through_length_binned_units(engine, oracle, monkeypatch):
-    """scripts/fuzz_class.py seed 27: a bulk that is itself ragged (200-base reads and the 300..419-base ones that join them) runs on
-    length-binned units while the kernel masks the other classes by length -- the binning pass has to mask too, or the high bits of a
-    4 998-base length land in the place field of the binned descriptor and a read of the bulk loses its reference word"""
+    """scripts/fuzz_class.py seed 27: a bulk that is itself ragged (here reads of 144..159 bases: one bucket of the batch's length histogram,
+    so the other classes come from the host's list and the bulk's kernel masks them by length) runs on length-binned units -- the binning pass
+    has to mask too, or the high bits of a 4 998-base length land in the place field of the binned descriptor and a read of the bulk
+    loses its reference word"""
     monkeypatch.setenv("BSK_CLASS_FORCE", "1")
     rng = random.Random(27)
     n = 17000
-    seqs = outlier_batch(rng, n, 200, [(400, 401, 419), (40, 300, 300), (3, 700, 700), (1, 4998, 4998)])
+    seqs = [rand_dna(rng, rng.randint(144, 159)) for _ in range(n)]
+    for cnt, ln in ((40, 300), (3, 700), (1, 4998), (2, 9000)):
+        for _ in range(cnt):
+            seqs[rng.randrange(n)] = rand_dna(rng, ln)
+    seqs[5] = "A" * len(seqs[5])
     b = engine.batch(seqs)
     p = engine.params(L.MINIMIZER, 15, w=5)
     res = engine.run(b, p)
     plan = res.plan()["kernel"]
-    assert "length-binned" in plan and " reads of " in plan, plan
+    assert "length-binned" in plan.split(" + ")[0] and " reads of " in plan, plan
     off, st, h, pos = res.fetch()
     assert not np.any((st[:n] & L.ST_CODE_MASK) == L.ST_SHORT)
-    check_min(res, oracle, seqs, 15, 5, sorted(set(list(range(0, n, 53)) + [i for i, s in enumerate(seqs) if len(s) > 419] + [5])))
+    check_min(res, oracle, seqs, 15, 5, sorted(set(list(range(0, n, 53)) + [i for i, s in enumerate(seqs) if len(s) > 159] + [5])))
     d = res.digest()
     res.close()
     monkeypatch.delenv("BSK_CLASS_FORCE")

@@ -147,7 +147,7 @@ def test_compact_device_copy_equals_fetch(engine, kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lens,plan", [((200, 250, 330), "k_minimizer_ring"), ((150,), "k_minimizer_pk"), ((60, 100, 150), "k_minimizer_pk"), ((40, 900, 2500), "minimizer")])
+@pytest.mark.parametrize("lens,plan", [((200, 250, 290), "k_minimizer_ring"), ((300, 420), "k_minimizer_pkd"), ((150,), "k_minimizer_pk"), ((60, 100, 150), "k_minimizer_pk"), ((40, 900, 2500), "minimizer")])
 def test_group_gather_layouts_and_mixed_groups(engine, lens, plan):
     """bsk_result_compact / bsk_result_fetch_narrow gather by GROUPS of 64 sequences (k_gather_groups: offsets searched with ds_bpermute,
     unit rows through an LDS image): against bsk_result_fetch's own wavefront-per-sequence gather on slab, unit-row and per-read-slab

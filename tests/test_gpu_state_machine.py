@@ -35,10 +35,15 @@ CASES = [
     (21, 11, (150,), "k_minimizer_pk"),             # headline plan: packed 32-bit window machine
     (21, 11, (60, 100, 150), "k_minimizer_pk"),     # ragged (length-binned units when the batch is large enough)
     (21, 11, (250,), "k_minimizer_ring"),           # unit rows
-    (21, 11, (200, 300, 330), "k_minimizer_ring"),
+    (21, 11, (200, 260, 290), "k_minimizer_ring"),
+    (21, 11, (200, 300, 350), "k_minimizer_pkd"),   # the packed machine over per-read slabs and mid-read flushes (round 5)
+    (21, 11, (900, 1700), "k_minimizer_pkd"),
+    (15, 5, (300, 420), "k_minimizer_pkd"),         # two blocks per flush round
+    (15, 3, (260,), "k_minimizer_pkd"),             # four blocks per flush round
+    (21, 13, (700,), "k_minimizer_pkd"),
     (31, 15, (150,), "k_minimizer_fast"),           # the reference's own benchmark parameters (sketch_test.go:128), w >= 14
     (21, 5, (150,), "k_minimizer_"),               # dense selection (small w): unit rows or k_minimizer_dense
-    (21, 11, (500, 700), "minimizer"),
+    (21, 11, (500, 700), "k_minimizer_pkd"),
     (15, 8, (5000, 9000), "over tiles"),                 # long sequences as tiles
     (64, 20, (150, 220), "minimizer"),            # k = 64: the rotation's last step
 ]
