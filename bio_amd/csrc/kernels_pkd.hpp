@@ -96,8 +96,12 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pkd(KArgs a) {
                 ++nflush;
                 const u32 wrow = (pm.slot - (u32)lane * 8u) / RB;
                 const u32 cnt = wrow >= head ? wrow - head : wrow + (u32)(CAP + 1) - head;
+#ifdef PKD_NOFLUSH  // dev knock-out (timing only): the regular rounds do not move anything
+                if (last) flush_last<LY, true, GL, CAP + 1>(lds, lane, cnt < (u32)G ? cnt : (u32)(G - 1), done, slab_read, ubase, a, head, &lost);
+#else
                 if (last) flush_last<LY, true, GL, CAP + 1>(lds, lane, cnt, done, slab_read, ubase, a, head, &lost);
                 else flush_groups<LY, true, GL, CAP + 1>(lds, lane, cnt, done, slab_read, ubase, a, head, &lost);
+#endif
                 const u32 nfl = last ? cnt : (cnt & ~(u32)(G - 1));
                 head += nfl;
                 head = head >= (u32)(CAP + 1) ? head - (u32)(CAP + 1) : head;
