@@ -17,6 +17,18 @@ namespace bsk {
 template <int W>
 struct PkdCfg {
     static constexpr int NB = DenseCfg<W>::NB, GL = DenseCfg<W>::GL, G = DenseCfg<W>::G, CAP = DenseCfg<W>::CAP;
+    // Blocks per flush round: TWICE what the ring is sized for (CAP = a left-over of up to G - 1 rows + NB W new ones).  A flush is a fifth
+    // of the kernel at one per NB blocks (knock-out at 400 bases, w = 11: 783 -> 999 Gbases/s without the regular rounds) and most of it is
+    // fixed cost; a lane selects a sixth of its windows on average, so 2 NB W windows overflow the ring only where a read selects more
+    // than half of them -- the flush sees that (the write pointer moved 2 NB W < CAP + 1 rows at most, so the distance is unambiguous),
+    // drops the lane's staged rows and the read goes to the exact machine's list with the tied ones (`lost`).
+#ifndef PKD_ROUND
+#define PKD_ROUND 2
+#endif
+    // (w >= 8 only: narrower windows select a third or more of their positions, and a round of twice the windows would run a few reads
+    // per thousand over their rings)
+    static constexpr int NBF = (W >= 8 ? PKD_ROUND : 1) * NB;
+    static_assert(NBF * W < CAP + 1, "the write pointer's distance per round must be unambiguous");
     typedef FLds<CAP, true> LY;
 };
 
@@ -24,7 +36,7 @@ template <int W>
 __global__ __launch_bounds__(64, 2) void k_minimizer_pkd(KArgs a) {
     typedef PkdCfg<W> C;
     typedef typename C::LY LY;
-    constexpr int CAP = C::CAP, NB = C::NB, GL = C::GL, G = C::G;
+    constexpr int CAP = C::CAP, NBF = C::NBF, GL = C::GL, G = C::G;
     __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
     LDSQ char *const ldsq = (LDSQ char *)lds;
     const int lane = lane_id();
@@ -85,7 +97,7 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pkd(KArgs a) {
             pm.nk = nk;
             pm.pw = pw_cur;
             pm.begin((u32)lane * 8u, ok ? (int)RB : 0, 0u);  // (a lane without a read stays on row 0 of its own column)
-            u32 head = 0;
+            u32 head = 0, left = 0, wprev = 0;
             // what the lane staged since the last flush, whole groups of G to the read's slab; `last`: everything
             auto flush = [&](bool last) {
                 // the next block's words (requested a block of hashing ago) are waited for HERE, before the flush's stores are issued: vmcnt
@@ -95,7 +107,11 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pkd(KArgs a) {
                 else asm volatile("" : "+v"(pw_n1));
                 ++nflush;
                 const u32 wrow = (pm.slot - (u32)lane * 8u) / RB;
-                const u32 cnt = wrow >= head ? wrow - head : wrow + (u32)(CAP + 1) - head;
+                const u32 moved = wrow >= wprev ? wrow - wprev : wrow + (u32)(CAP + 1) - wprev;  // rows staged since the last flush
+                const bool over = left + moved > (u32)CAP;  // the ring ran over the lane's own rows: what it holds is gone (see PkdCfg)
+                lost |= over ? 1u : 0u;
+                head = over ? wrow : head;
+                const u32 cnt = over ? 0u : left + moved;
 #ifdef PKD_NOFLUSH  // dev knock-out (timing only): the regular rounds do not move anything
                 if (last) flush_last<LY, true, GL, CAP + 1>(lds, lane, cnt < (u32)G ? cnt : (u32)(G - 1), done, slab_read, ubase, a, head, &lost);
 #else
@@ -107,6 +123,8 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pkd(KArgs a) {
                 head = head >= (u32)(CAP + 1) ? head - (u32)(CAP + 1) : head;
                 head = head >= (u32)(CAP + 1) ? head - (u32)(CAP + 1) : head;
                 done += nfl;
+                left = cnt - nfl;
+                wprev = wrow;
             };
             pm.template block<true, false, 0>(0, ok ? 1u : 0u, nk_max > (u32)W);
             u32 i0 = W;
@@ -120,7 +138,7 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pkd(KArgs a) {
                     if (full) pm.template block<false, false, 0>(i0, 1u, more);
                     else pm.template block<false, true, 0>(i0, 1u, more);
                 }
-                if (++inround == NB || !more) {  // (the last block's round leaves room for the W slots the drain emits)
+                if (++inround == NBF || !more) {  // (the last block's round leaves room for the W slots the drain emits)
                     inround = 0;
                     flush(false);
                 }
