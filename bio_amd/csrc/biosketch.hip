@@ -1539,9 +1539,9 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         // (measured, profiles/r05/pkd_ring_sweep.txt: w = 3..13 x 100..450 bases against k_minimizer_pkd, which holds 720-820 Gbases/s at any length
         // (w >= 9) where the unit-row kernel falls with it as its lanes drift apart.  The crossover in expected tuples per read: 72 / 80 / 80 / 65
         // at w = 3 / 4 / 5 / 6 -- two or more blocks per flush round there, and the packed machine's per-block overhead weighs more on short
-        // blocks --, 40 / 41 / 42 / 45 / 46 / 50 / 53 at w = 7 .. 13 = 18 + 2.7 w.  Round 4's rule, 34 + 2 w, was fitted against
-        // k_minimizer_dense.  BSK_RING_MAX overrides.)
-        const double ring_cap = ctx->opt.ring_max ? (double)ctx->opt.ring_max : p->w <= 5 ? 76.0 : p->w == 6 ? 65.0 : 18.0 + 2.7 * p->w;
+        // blocks --, 40 at w = 7, and 41 / 42 / 45 / 46 / 50 / 53 at w = 8 .. 13 in that sweep, 5 % of k_minimizer_pkd's rate lower since its
+        // flush rounds are two blocks there: 17 + 2.5 w.  Round 4's rule, 34 + 2 w, was fitted against k_minimizer_dense.  BSK_RING_MAX overrides.)
+        const double ring_cap = ctx->opt.ring_max ? (double)ctx->opt.ring_max : p->w <= 5 ? 76.0 : p->w == 6 ? 65.0 : p->w == 7 ? 40.0 : 17.0 + 2.5 * p->w;
         const bool ring_wins = ctx->opt.ring ? true : exp_tuples > (double)ctx->opt.dense_min && exp_tuples <= ring_cap;
 #ifdef BSK_EXPERIMENTS  // the two measured-and-rejected minimizer kernels (make EXPERIMENTS=1; NOTEBOOK round 2): never planned without their switch
         if (!use_ascii && p->w == 11 && p->k + p->w <= 65 && b->maxlen < 32768u && nwin >= 1.0 && ctx->opt.wpr && !ctx->no_dense && slab_budget_ok(b, seg_slab) &&
