@@ -1576,7 +1576,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.bin_gran = bin_gran_for(ctx, b, p->w);
             per_cu = ring_minimizer_blocks_per_cu(p->w);
         } else
-        if (!use_ascii && pkd_minimizer_supported(p->w) && !b->alias && b->maxlen < 32768u && nwin * 2.0 / (p->w + 1.0) > (double)ctx->opt.dense_min && !ctx->no_dense &&
+        if (!use_ascii && pkd_minimizer_supported(p->w) && b->maxlen < 32768u && nwin * 2.0 / (p->w + 1.0) > (double)ctx->opt.dense_min && !ctx->no_dense &&
             !ctx->no_syn_pk && slab_budget_ok(b, dense_slab) && !ctx->opt.force_generic && !ctx->opt.no_dense && !ctx->opt.no_pk && !ctx->opt.no_pkd) {
             pl.which = K_MIN_PKD;  // w <= 13: the packed window machine over per-read slabs and mid-read flushes (kernels_pkd.hpp)
             pl.fast_w = p->w;
@@ -2526,7 +2526,7 @@ static bool syn_long_plan_ok(const bsk_ctx *ctx, const bsk_params *p) {
 }
 
 // positions one tile owns: about 22 tuples per tile (the kernels stage 32 per lane; 16 for syncmers), a multiple of 16
-static u32 tile_positions(const bsk_ctx *ctx, const bsk_params *p) {
+static u32 tile_positions(const bsk_ctx *ctx, const bsk_params *p, u64 n_bases) {
     u32 tp;
     if (p->kind == BSK_MINIMIZER || p->kind == BSK_PROT_MINIMIZER) {
         tp = 16u * std::max<u32>(2, (u32)(22.0 * (p->w + 1.0) / 2.0 / 16.0));
@@ -2538,6 +2538,16 @@ static u32 tile_positions(const bsk_ctx *ctx, const bsk_params *p) {
             const double room = (double)ctx->opt.dense_min * (p->w + 1.0) / 2.0 - p->w - 18.0;
             const u32 tpk = room > 0 ? 16u * (u32)(room / 16.0) : 0u;
             if (tpk >= 64u) tp = tpk;
+            // k_minimizer_pkd (round 5) runs tiles of any length at 0.65 of k_minimizer_pk's rate, and a tile of 1 024 positions carries
+            // 5 % of overlap instead of 38 %, a tenth of the tiles to cut, stitch and gather: 2 10^9 bases of long sequences 9.1 -> 7.4 ms,
+            // 2 10^8 1.5 -> 1.2 ms with tiles of 512 -- as long as there are tiles enough for every lane of the device (scripts/dev/
+            // run_tilepos.sh: with fewer than ~300 000 the larger tile loses: 2 10^7 bases 0.45 ms on 96-position tiles, 0.7 on 512)
+            if (pkd_minimizer_supported(p->w) && !ctx->opt.no_pkd && !ctx->opt.no_dense && !ctx->no_dense && !ctx->no_syn_pk)
+                for (u32 big = 1024; big >= 256; big >>= 1)
+                    if (n_bases / big >= 300000ULL) {
+                        tp = big;
+                        break;
+                    }
         }
     }
     else if (p->kind == BSK_SYNCMER) {
@@ -2576,7 +2586,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     geo.k = p->k;
     geo.w = p->kind == BSK_SYNCMER ? p->k - p->s : p->w;
     geo.s = p->s;
-    geo.tp = tile_positions(ctx, p);
+    geo.tp = tile_positions(ctx, p, b->n_bases);
     geo.circ_ext = circ_ext;
     geo.syn_all = syn_all ? 1 : 0;
     const bool stream = !kind_has_pos(p->kind);

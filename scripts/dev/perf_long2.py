@@ -2,7 +2,7 @@ import sys, time, os
 import numpy as np
 sys.path.insert(0, "/root/repo")
 from bio_amd import sketches as S, _lib as L
-total = int(2e9); nseq = 400
+total = int(float(os.environ.get('TOTAL', '2e9'))); nseq = int(os.environ.get('NSEQ', '400'))
 eng = S.Engine(0)
 rng = np.random.default_rng(1)
 data = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, total, dtype=np.uint8)]
