@@ -50,7 +50,7 @@ def ragged(lo, hi, n):
 
 
 base = None
-for rl in (() if ONLY_OUTLIERS else (100, 150, 151, 200, 250, 300, 350)):
+for rl in (() if ONLY_OUTLIERS else (100, 150, 151, 200, 250, 300, 350, 400, 500, 1000)):
     n = int(BASES / rl)
     b = eng.synth(L.ALPHA_DNA, n, rl, 0x5EED0003)
     o = run("uniform %d bp" % rl, b, n * rl)
@@ -68,13 +68,18 @@ for rl in (() if ONLY_OUTLIERS else (150, 200, 250, 300, 350)):  # syncmers k = 
 if ONLY_OUTLIERS:
     n = 2048
 else:
-    n = int(BASES / 105 / 1.5)  # (host-generated: two thirds of the bases)
+    n = int(BASES / 105)  # (the same bases as the uniform cases: the rate of a batch grows with its size, and the ratio below is against them)
 data, offs = ragged(60, 150, n)
 b = eng.batch_from_arrays(data, offs)
 r1 = run("ragged 60..150 bp, length-binned units", b, int(offs[-1]), dict(vs_uniform_150=None))
 os.environ["BSK_NO_BIN"] = "1"
 r2 = run("ragged 60..150 bp, units in batch order (BSK_NO_BIN)", b, int(offs[-1]))
-del os.environ["BSK_NO_BIN"]
+os.environ.pop("BSK_NO_BIN", None)
+os.environ["BSK_NO_BIN_EARLY"] = "1"  # (round 4's way: the view is built by the first plan that wants it, in classes of the plan's block -- bsk_batch_prepare times that pass)
+b2 = eng.batch_from_arrays(data, offs)
+r3 = run("ragged 60..150 bp, length-binned units, view built per plan (BSK_NO_BIN_EARLY)", b2, int(offs[-1]))
+b2.close()
+del os.environ["BSK_NO_BIN_EARLY"]
 assert r1["checksum"] == r2["checksum"], "binned and unbinned digests differ"
 # the same trimmed reads through the syncmer kernels (k = 31, s = 11)
 s1 = run("syncmers k=31 s=11, ragged 60..150 bp, length-binned units", b, int(offs[-1]), p=ps)
@@ -120,4 +125,6 @@ for frac in (() if ONLY_OUTLIERS else (0.02, 0.10)):
 if not ONLY_OUTLIERS:
   print(json.dumps(dict(case="summary", uniform_150=base, ragged_binned_over_uniform_150=round(r1["gbases_per_s"] / base, 3),
                       ragged_binned_with_prepare_over_uniform_150=round(r1["gbases_per_s_with_prepare"] / base, 3),
-                      ragged_unbinned_over_uniform_150=round(r2["gbases_per_s"] / base, 3))))
+                      ragged_unbinned_over_uniform_150=round(r2["gbases_per_s"] / base, 3),
+                      ragged_view_per_plan_over_uniform_150=round(r3["gbases_per_s"] / base, 3),
+                      ragged_view_per_plan_with_prepare_over_uniform_150=round(r3["gbases_per_s_with_prepare"] / base, 3))))
