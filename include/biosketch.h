@@ -255,9 +255,11 @@ int bsk_sketch_timed(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, 
                      int warmup, int iters, float *kernel_ms);
 
 /* Per-batch preparation a sketch with these parameters would do on its first call, done now (optional; bsk_sketch does it itself and
- * keeps it with the batch): today the LENGTH-BINNED view of a ragged batch of short reads -- the kernels walk the 64 reads of a unit
- * in lock-step, so the reads of every chunk of 4096 are grouped by length before units are formed (reference words and status bytes
- * stay at the reads' own positions).  *ms (may be NULL) receives the device time of the pass, 0 when the plan needs none.  The
+ * keeps it with the batch): the cut of a class plan (see bsk_result_class_plan), and -- for batches made with BSK_NO_BIN_EARLY=1 -- the
+ * LENGTH-BINNED view of a ragged batch of short reads: the kernels walk the 64 reads of a unit in lock-step, so the reads of every chunk
+ * of 4096 are grouped by length before units are formed (reference words and status bytes stay at the reads' own positions).  Since
+ * round 5 that view is built with the batch (bsk_batch_from_ascii / _from_packed and the refills), in order of length, for whatever
+ * parameters come.  *ms (may be NULL) receives the device time of the pass, 0 when the plan needs none.  The
  * reference has no counterpart: its cost is per base of one sequence at a time (sketches/sketch.go:46). */
 int bsk_batch_prepare(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, float *ms);
 
