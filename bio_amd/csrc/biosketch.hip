@@ -199,6 +199,34 @@ __global__ __launch_bounds__(64) void k_class_cut(const u64 *desc, u64 n, u32 nb
 __global__ void k_gather_desc(const u64 *desc, const u32 *list, u64 n, u64 *sdesc) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) sdesc[i] = desc[list[i]];
 }
+// The lists of a class plan from the batch's list of odd sequences on the device (bsk_batch::d_odd: index << 32 | length, ascending): a
+// wavefront takes 64 entries and claims room in every class's list with one atomic per class present (cursor[c]); the descriptors are
+// gathered on the way.  (The same on the host -- a loop over the list and one copy -- is 0.9 ms for the 10^6 odd reads of a batch of
+// 10^8 with 1 % of 250-base reads, 7 % of its kernel, on every bsk_sketch.)  Order inside a class: ascending inside a wavefront's 64.
+__global__ __launch_bounds__(256) void k_odd_split(const u64 *odd, u64 n_odd, ClassCuts cc, u32 n_out, u32 *cursor, const u64 *desc, u32 *lists, u64 *sdesc) {
+    const u32 lane = threadIdx.x & 63u;
+    for (u64 i0 = ((u64)blockIdx.x * 256 + (threadIdx.x & ~63u)); i0 < n_odd; i0 += (u64)gridDim.x * 256) {
+        const u64 i = i0 + lane;
+        const u64 e = i < n_odd ? odd[i] : 0;
+        const u32 c = i < n_odd ? class_of(cc, (u32)e) : cc.bulk;
+        for (u32 q = 0; q < cc.ncls; ++q) {
+            if (q == cc.bulk) continue;
+            const u64 m = __builtin_amdgcn_ballot_w64(c == q);
+            if (!m) continue;
+            u32 base = 0;
+            if (lane == (u32)__builtin_ctzll(m)) base = atomicAdd(&cursor[q], (u32)__builtin_popcountll(m));
+            base = (u32)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+            if (c == q) {
+                const u32 at = cc.first[q] + base + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0));
+                const u32 end = q + 1 < cc.ncls ? cc.first[q + 1] : n_out;  // (first[] of the bulk's successor skips nothing: the bulk has no list)
+                if (at < end) {
+                    lists[at] = (u32)(e >> 32);
+                    sdesc[at] = desc[e >> 32];
+                }
+            }
+        }
+    }
+}
 // the reads of a part take their reference words (re-based into the parent's tail) and status bytes from the part's result
 __global__ void k_adopt_refs(const u32 *list, u64 n, const u64 *crefs, const u8 *cstatus, u64 base, u64 *refs, u8 *status) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
@@ -547,6 +575,7 @@ extern "C" void bsk_batch_destroy(bsk_batch *b) {
         delete b;
         return;
     }
+    (void)hipFree(b->d_odd);
     if (!b->alias) {
         (void)hipFree(b->words);
         (void)hipFree(b->ascii);
@@ -607,6 +636,22 @@ static void collect_odd(bsk_batch *b, u64 n, LenOf len) {
     }
     b->odd = v;
     b->modal_bucket = mb;
+}
+// the list on the device too (class plans split long lists there: k_odd_split); with the batch's other uploads, on its stream
+static void upload_odd(bsk_ctx *ctx, bsk_batch *b) {
+    (void)hipFree(b->d_odd);
+    b->d_odd = nullptr;
+    if (!b->odd || b->odd->size() < 65536) return;
+    if (hipMalloc(&b->d_odd, b->odd->size() * sizeof(u64)) != hipSuccess) {
+        (void)hipGetLastError();
+        b->d_odd = nullptr;
+        return;
+    }
+    if (hipMemcpyAsync(b->d_odd, b->odd->data(), b->odd->size() * sizeof(u64), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(b->d_odd);
+        b->d_odd = nullptr;
+    }
 }
 
 // Slack behind the packed words.  Every prefetching kernel loads a fixed number of words from every read's FIRST word -- also the last
@@ -798,6 +843,7 @@ static int batch_from_ascii_impl(bsk_ctx *ctx, const uint8_t *bytes, const uint6
         delete b->hist;
         b->hist = hist;
         collect_odd(b, n, [&](u64 r) { return offsets[r + 1] - offsets[r]; });
+        upload_odd(ctx, b);
         b->n_words = w;
         const u64 alloc_words = w + pad_words(maxlen);
         BCHK(take((void **)&b->words, &b->c_words, alloc_words * sizeof(u32), donor ? (void **)&donor->words : nullptr, donor ? &donor->c_words : nullptr));
@@ -899,6 +945,7 @@ static int batch_from_packed_impl(bsk_ctx *ctx, const uint32_t *words, uint64_t 
     if (!b) return BSK_ERR_NOMEM;
     b->hist = hist.release();
     collect_odd(b, n, [&](u64 r) { return desc[r] & 0xffffffULL; });
+    upload_odd(ctx, b);
     b->ctx = ctx;
     b->alphabet = BSK_ALPHA_DNA;
     b->n = n;
@@ -3013,6 +3060,11 @@ static int class_build(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, co
     if (masked) {  // the lists from the host's list of odd sequences (ascending), one small copy, the descriptors gathered on the device
         // (staged in the context's pinned buffer when it is large enough -- a batch made from host data on this context left it so:
         // 10^6 entries from pageable memory were 0.9 of the cut's 0.97 ms)
+        if (b->d_odd && b->odd->size() >= 65536 && n_out) {  // long lists: split on the device (k_odd_split)
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket + 8, 0, 8 * sizeof(u32), ctx->stream));  // [8..15] the classes' cursors
+            hipLaunchKernelGGL(k_odd_split, dim3(grid_for(ctx, b->odd->size(), 256)), dim3(256), 0, ctx->stream, b->d_odd, (u64)b->odd->size(), cc, (u32)n_out,
+                               ctx->d_ticket + 8, b->desc, lists, sdesc);
+        } else {
         std::vector<u32> pageable;
         u32 *host = nullptr;
         if (ctx->h_refs && (u64)ctx->h_refs_cap * 8 >= n_out * 4) host = reinterpret_cast<u32 *>(ctx->h_refs);
@@ -3036,6 +3088,7 @@ static int class_build(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, co
             HIPCHK(ctx, hipMemcpyAsync(lists, host, (size_t)n_out * 4, hipMemcpyHostToDevice, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (the staging buffer is the context's, or goes out of scope)
             hipLaunchKernelGGL(k_gather_desc, dim3(grid_for(ctx, n_out, 256)), dim3(256), 0, ctx->stream, b->desc, lists, n_out, sdesc);
+        }
         }
     } else {
         HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket, 0, 16 * sizeof(u32), ctx->stream));  // [8..15] the classes' cursors
@@ -3065,6 +3118,7 @@ static int class_build(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, co
         v->hist = nullptr;
         v->borrowed = true;
         v->odd = nullptr;
+        v->d_odd = nullptr;
         if (!masked) v->desc = view;  // (masked: the batch's own descriptors, the kernel masks by length)
         v->maxlen = bk.hi;
         v->n_bases = pretend ? (u64)pretend * b->n : bk.bases;

@@ -111,6 +111,7 @@ struct bsk_batch {
     // ascending.  A class plan whose bulk holds that bucket then needs NO device pass to cut the batch: the other classes' lists are picked
     // from here on the host and the bulk's kernel masks by length itself (KArgs::cls_*).
     std::vector<u64> *odd = nullptr;
+    u64 *d_odd = nullptr;  // the same list on the device (lists of 65 536 and more: class plans split them there)
     int modal_bucket = -1;
     u32 *wbits = nullptr;  // one bit per packed word: the word holds a non-ACGT letter (batches that may be tiled)
     u32 *subset = nullptr; // reads with a non-ACGT letter, ascending (side launch of the ASCII kernels); nsub = n_nonacgt

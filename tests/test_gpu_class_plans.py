@@ -172,6 +172,44 @@ def test_class_plan_masked_bulk_through_length_binned_units(engine, oracle, monk
     b.close()
 
 
+def test_class_plan_long_odd_list_is_split_on_the_device(engine, oracle, monkeypatch):
+    """65 536 odd sequences or more: the classes' lists come from the batch's list ON THE DEVICE (k_odd_split: one atomic per class and
+    wavefront, descriptors gathered on the way) instead of a host loop + copy (0.9 ms per 10^6 odd reads on every bsk_sketch)"""
+    monkeypatch.setenv("BSK_CLASS_FORCE", "1")
+    rng = np.random.default_rng(65536)
+    n = 1_500_000
+    lens = np.full(n, 150, np.uint64)
+    lens[rng.integers(0, n, 72_000)] = 250
+    lens[rng.integers(0, n, 300)] = 400
+    lens[rng.integers(0, n, 3)] = 5000
+    assert 65536 <= int((lens != 150).sum()) <= n // 20
+    offs = np.zeros(n + 1, np.uint64)
+    np.cumsum(lens, out=offs[1:])
+    data = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(offs[-1]), dtype=np.uint8)]
+    b = engine.batch_from_arrays(data, offs)
+    p = engine.params(L.MINIMIZER, 21, w=11)
+    res = engine.run(b, p)
+    plan = res.plan()["kernel"]
+    assert plan.count(" reads of ") >= 3, plan
+    odd = np.nonzero(lens != 150)[0]
+    idx = sorted(set(int(i) for i in np.concatenate([odd[:: max(1, len(odd) // 300)], np.nonzero(lens > 250)[0][:40], np.arange(0, n, n // 200)])))
+    seqs = {i: data[int(offs[i]):int(offs[i + 1])].tobytes().decode() for i in idx}
+    for i in idx:
+        st, h, pos = res.read(i)
+        eh, ep, es, fl = oracle.minimizer(seqs[i], 21, 11, False, closed=True)
+        assert np.array_equal(h, eh) and np.array_equal(pos & L.POS_MASK, ep) and np.array_equal(pos >> 31, es), (i, int(lens[i]))
+    d = res.digest()
+    res2, ms = engine.run_timed(b, p, 0, 2, reuse=res)  # (the lists are split again on every call: any order inside a class gives the same result)
+    assert res2.digest() == d
+    res.close()
+    monkeypatch.delenv("BSK_CLASS_FORCE")
+    monkeypatch.setenv("BSK_NO_CLASS", "1")
+    one = engine.run(b, p)
+    assert one.digest() == d
+    one.close()
+    b.close()
+
+
 def test_class_plan_is_not_taken_when_it_cannot_pay(engine):
     """uniform batches, small batches, a bulk that is itself tile work: one plan as before"""
     rng = random.Random(3)
