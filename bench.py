@@ -46,6 +46,7 @@ WORKLOADS = {
     "simhash": ("sim", 20_000_000, 150, 21, 5, "20M x 150 bp reads, SimHash k=21 m=5 scale=5"),
     # off the headline point (the same 1.5e10 bases): the unit-row kernel's length range (scripts/robustness_sweep.py has the rest)
     "minimizer250": ("min", 60_000_000, 250, 21, 11, "60M x 250 bp reads, minimizer sketch k=21 w=11 (the configs[2] parameters on longer reads)"),
+    "minimizer400": ("min", 37_500_000, 400, 21, 11, "37.5M x 400 bp reads, minimizer sketch k=21 w=11 (the configs[2] parameters beyond the unit-row kernel's reach: k_minimizer_pkd, DESIGN.md 3.1c)"),
     "syncmer250": ("syn", 60_000_000, 250, 31, 11, "60M x 250 bp reads, syncmer sketch k=31 s=11 (the configs[3] parameters on longer reads: k_syncmer_pkl, DESIGN.md 3.3a)"),
 }
 NOTES = {

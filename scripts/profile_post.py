@@ -25,7 +25,7 @@ for cand in (os.path.join(out_dir, "valu_model.json"), os.path.join(os.path.dirn
 entries = []
 for w in workloads:
     kind, n_reads = bench.WORKLOADS[w][0], bench.WORKLOADS[w][1]
-    kname = "k_minimizer_ring<" if w == "minimizer250" else "k_syncmer_pkl<" if w == "syncmer250" else FAMILY[kind]  # (reads of ~160-280 bases are planned on the unit-row kernel; syncmers of 190+ bases on the long packed plan)
+    kname = "k_minimizer_ring<" if w == "minimizer250" else "k_minimizer_pkd<" if w == "minimizer400" else "k_syncmer_pkl<" if w == "syncmer250" else FAMILY[kind]  # (reads of ~160-280 bases are planned on the unit-row kernel; syncmers of 190+ bases on the long packed plan)
     full = {"name": None}
 
     def mean_counter(path, counter):

@@ -28,6 +28,7 @@ WIDE = re.compile(r"^v_(mad_u64_u32|mad_i64_i32|lshl_add_u64|mul_lo_u32|mul_hi_u
 # workload -> (translation unit, -D flags, substring of the kernel's mangled name)
 KERNELS = {
     "minimizer": ("k_minimizer_pk.hip", ["-DBSK_PK_WS(X)=X(11)"], "k_minimizer_pkILi11ELb0"),
+    "minimizer400": ("k_minimizer_pkd.hip", ["-DBSK_PKD_WS(X)=X(11)"], "k_minimizer_pkdILi11"),
     "syncmer": ("k_syncmer_pk.hip", ["-DBSK_SYNPK_WS(X)=X(20)"], "k_syncmer_pkILi20"),
     "nthash": ("biosketch.hip", [], "k_nthash_fastILi1"),
     "kmer": ("biosketch.hip", [], "k_nthash_fastILi2"),
