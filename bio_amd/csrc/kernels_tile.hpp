@@ -232,23 +232,34 @@ __global__ __launch_bounds__(64) void k_tile_stitch(StitchArgs a) {
             const u32 before = o ? s_pre[o - 1] : 0u;  // (s_pre is inclusive)
             src = s_first[o] + (u64)(j - before) * s_stride[o];
         };
-        // count pass
+        // count pass (four steps' positions requested together: a step is one dependent load, and a unit of a small batch -- a class
+        // plan's few thousand long reads -- is alone on its SIMD with nothing to hide it behind)
+        constexpr int SU = 4;
         u32 acc = 0, kept_total = 0;
-        for (u32 j0 = 0; j0 < K_in; j0 += 64) {
-            const u32 j = j0 + (u32)lane;
-            bool keepf = false;
-            if (j < K_in) {
-                u32 o;
-                u64 src;
-                locate(j, o, src);
-                const u32 p = a.tpos[src] & BSK_POS_MASK;
-                keepf = p >= s_lo[o] && p < s_hi[o];
+        for (u32 j0 = 0; j0 < K_in; j0 += 64 * SU) {
+            u32 pv[SU], ov[SU];
+#pragma unroll
+            for (int q = 0; q < SU; ++q) {
+                const u32 j = j0 + 64u * (u32)q + (u32)lane;
+                pv[q] = 0;
+                ov[q] = 0;
+                if (j < K_in) {
+                    u64 src;
+                    locate(j, ov[q], src);
+                    pv[q] = a.tpos[src];
+                }
             }
-            const u64 m = __builtin_amdgcn_ballot_w64(keepf);
-            kept_total += (u32)__builtin_popcountll(m);
-            const int d = (int)start - (int)j0;  // kept entries of this step that precede this lane's tile
-            const u64 below = d <= 0 ? 0ULL : d >= 64 ? ~0ULL : ((1ULL << d) - 1ULL);
-            acc += (u32)__builtin_popcountll(m & below);
+#pragma unroll
+            for (int q = 0; q < SU; ++q) {
+                const u32 jq = j0 + 64u * (u32)q, j = jq + (u32)lane;
+                const u32 p = pv[q] & BSK_POS_MASK;
+                const bool keepf = j < K_in && p >= s_lo[ov[q]] && p < s_hi[ov[q]];
+                const u64 m = __builtin_amdgcn_ballot_w64(keepf);
+                kept_total += (u32)__builtin_popcountll(m);
+                const int d = (int)start - (int)jq;  // kept entries of this step that precede this lane's tile
+                const u64 below = d <= 0 ? 0ULL : d >= 64 ? ~0ULL : ((1ULL << d) - 1ULL);
+                acc += (u32)__builtin_popcountll(m & below);
+            }
         }
         const u64 base = lookback_exclusive(a.lookback, unit, (u64)kept_total, lane);
         if (t < a.nt) a.oexcl[t] = base + acc;
@@ -260,24 +271,35 @@ __global__ __launch_bounds__(64) void k_tile_stitch(StitchArgs a) {
         }
         // write pass
         u64 run = base;
-        for (u32 j0 = 0; j0 < K_in; j0 += 64) {
-            const u32 j = j0 + (u32)lane;
-            bool keepf = false;
-            u32 o = 0, praw = 0;
-            u64 src = 0;
-            if (j < K_in) {
-                locate(j, o, src);
-                praw = a.tpos[src];
-                const u32 p = praw & BSK_POS_MASK;
-                keepf = p >= s_lo[o] && p < s_hi[o];
+        for (u32 j0 = 0; j0 < K_in; j0 += 64 * SU) {
+            u32 pv[SU], ov[SU];
+            u64 sv[SU], hv[SU];
+#pragma unroll
+            for (int q = 0; q < SU; ++q) {
+                const u32 j = j0 + 64u * (u32)q + (u32)lane;
+                pv[q] = 0;
+                ov[q] = 0;
+                sv[q] = 0;
+                hv[q] = 0;
+                if (j < K_in) {
+                    locate(j, ov[q], sv[q]);
+                    pv[q] = a.tpos[sv[q]];
+                    hv[q] = a.thash[sv[q]];  // (requested with the position: most entries of a pk-sized tile are kept)
+                }
             }
-            const u64 m = __builtin_amdgcn_ballot_w64(keepf);
-            if (keepf) {
-                const u64 dst = run + (u64)__builtin_popcountll(m & ((1ULL << lane) - 1ULL));
-                a.ohash[dst] = a.thash[src];
-                a.opos[dst] = (praw & BSK_POS_STRAND_BIT) | (u32)((praw & BSK_POS_MASK) + s_shift[o]);
+#pragma unroll
+            for (int q = 0; q < SU; ++q) {
+                const u32 j = j0 + 64u * (u32)q + (u32)lane;
+                const u32 p = pv[q] & BSK_POS_MASK;
+                const bool keepf = j < K_in && p >= s_lo[ov[q]] && p < s_hi[ov[q]];
+                const u64 m = __builtin_amdgcn_ballot_w64(keepf);
+                if (keepf) {
+                    const u64 dst = run + (u64)__builtin_popcountll(m & ((1ULL << lane) - 1ULL));
+                    a.ohash[dst] = hv[q];
+                    a.opos[dst] = (pv[q] & BSK_POS_STRAND_BIT) | (u32)(p + s_shift[ov[q]]);
+                }
+                run += (u64)__builtin_popcountll(m);
             }
-            run += (u64)__builtin_popcountll(m);
         }
         wave_sync_lds();
     }
