@@ -414,8 +414,9 @@ struct PkMin {
         }
     }
 
-    // uniform: every lane with a read has nk == nk_max (fixed-length batch): full blocks need no per-lane window test
-    __device__ __forceinline__ void run(u32 nk_max, bool ok, bool uniform, u32 slot0, int step, u32 col8) {
+    // nk_min: the fewest windows of a lane WITH a read (fixed-length batches: nk_max): the blocks every such lane fills need no per-lane
+    // window test -- in a length-binned unit that is all but the last block or two (round 5; until then ragged batches took the test in every block)
+    __device__ __forceinline__ void run(u32 nk_max, bool ok, u32 nk_min, u32 slot0, int step, u32 col8) {
         begin(slot0, step, col8);
         block<true, false, 0>(0, ok ? 1u : 0u, nk_max > (u32)W);
         u32 i0 = W;
@@ -425,7 +426,7 @@ struct PkMin {
             // odd block
             {
                 const bool more = i0 + W < nk_max;
-                if (uniform && i0 + W <= nk_max) block<false, false, 1>(i0, 1u, more);
+                if (i0 + W <= nk_min) block<false, false, 1>(i0, 1u, more);
                 else block<false, true, 1>(i0, 1u, more);
             }
             i0 += W;
@@ -434,7 +435,7 @@ struct PkMin {
             // even block
             {
                 const bool more = i0 + W < nk_max;
-                if (uniform && i0 + W <= nk_max) block<false, false, 0>(i0, 1u, more);
+                if (i0 + W <= nk_min) block<false, false, 0>(i0, 1u, more);
                 else block<false, true, 0>(i0, 1u, more);
             }
             i0 += W;
@@ -562,7 +563,6 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
     for (u32 i = (((blockIdx.x * 2654435761u) >> 24) * (u32)PK_STAGGER) >> 8; i; --i) __builtin_amdgcn_s_sleep(32);
 #endif
     const u64 slab = (u64)64 * BSK_FAST_CAP;
-    const bool uniform = a.uniform_len != 0;
     const u32 col8 = (u32)(lane & 31) * 8u;
     constexpr u32 RB = (u32)(LY::ROW * 8);
     const u32 top = (u32)(LY::PR - 1) * RB + col8;  // the high lane's first slot
@@ -606,6 +606,7 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
         const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
         const u32 nk_max = wave_max_u32(nk);
+        const u32 nk_min = ~wave_max_u32(~(ok ? nk : 0xffffffffu));  // (over the lanes with a read)
         u32 cnt = 0, tmin_lane = 0xffffffffu;
         if (nk_max) {
             tabs.write(ldsq);  // the previous copy-out's tables took their place
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
             // lanes l and l+32 share column l & 31, the low lane filling it from row 0 upwards, the high lane from the last row downwards;
             // a lane without a read is parked on the spare row
             const u32 spare = (u32)LY::PR * RB + col8;
-            pm.run(nk_max, ok, uniform, !ok ? spare : lane < 32 ? col8 : top, !ok ? 0 : lane < 32 ? (int)RB : -(int)RB, col8);
+            pm.run(nk_max, ok, nk_min, !ok ? spare : lane < 32 ? col8 : top, !ok ? 0 : lane < 32 ? (int)RB : -(int)RB, col8);
             if (ok) cnt = (lane < 32 ? pm.slot - col8 : top - pm.slot) / RB;
             tmin_lane = pm.tmin;
         }

@@ -47,7 +47,6 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pkd(KArgs a) {
     }
     __syncthreads();
     const u64 slab_read = a.slab_read;
-    const bool uniform = a.uniform_len != 0;
     constexpr u32 RB = (u32)(LY::ROW * 8);
     const u32 lseg = a.fixcap / a.list_grid;  // this workgroup's segment of the list of reads for the exact machine (list_append)
     u32 lcur = 0;
@@ -86,6 +85,7 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pkd(KArgs a) {
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
         const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
         const u32 nk_max = wave_max_u32(nk);
+        const u32 nk_min = ~wave_max_u32(~(ok ? nk : 0xffffffffu));  // (over the lanes with a read: the blocks all of them fill take no per-lane window test)
         const u64 ubase = (u64)unit * 64 * slab_read;
         u32 done = 0, tmin_lane = 0xffffffffu, lost = 0;
         if (nk_max) {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pkd(KArgs a) {
             u32 i0 = W;
             int par = 1, inround = 0;
             while (i0 < nk_max) {
-                const bool more = i0 + (u32)W < nk_max, full = uniform && i0 + (u32)W <= nk_max;
+                const bool more = i0 + (u32)W < nk_max, full = i0 + (u32)W <= nk_min;
                 if (par) {
                     if (full) pm.template block<false, false, 1>(i0, 1u, more);
                     else pm.template block<false, true, 1>(i0, 1u, more);
