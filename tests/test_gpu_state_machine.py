@@ -117,3 +117,25 @@ def test_dna_fed_protein_minimizer_matches_state_machine(engine, oracle, frame):
         assert (st & L.ST_CODE_MASK) == L.ST_OK and np.array_equal(h, mh) and np.array_equal(p & L.POS_MASK, mp), (i, frame, len(q))
     res.close()
     b.close()
+
+
+@pytest.mark.parametrize("k,w", [(21, 11), (15, 5)])
+def test_pkd_batches_of_low_complexity_reads(engine, oracle, k, w):
+    """k_minimizer_pkd when MOST reads are the exact machine's: homopolymers (every position selected: the read outgrows its slab and its
+    ring, `lost`), dinucleotide repeats (key ties in every window), half a batch of poly-A -- the list of reads, its slabs in the overflow
+    region and the first-window flag, read by read against the closed form"""
+    rng = random.Random(5 * k + w)
+    makers = (lambda i: "ACGT"[i % 4] * 400, lambda i: ("ACGTAG"[i % 5:i % 5 + 2] * 300)[:500],
+              lambda i: ("A" * 450) if i % 2 else rand_seq(rng, 450))
+    for mk in makers:
+        seqs = [mk(i) for i in range(4000)]
+        b = engine.batch(seqs)
+        res = engine.run(b, engine.params(L.MINIMIZER, k, w=w))
+        assert "k_minimizer_pkd" in res.plan()["kernel"], res.plan()
+        for i in list(range(0, 4000, 211)) + [1, 2, 3]:
+            st, h, p = res.read(i)
+            eh, ep, es, fl = oracle.minimizer(seqs[i], k, w, False, closed=True)
+            assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep) and np.array_equal(p >> 31, es), (i, len(seqs[i]))
+            assert bool(st & L.ST_FIRST_WINDOW_TIE) == bool(fl & oracle.FLAG_FIRST_WINDOW_TIE), i
+        res.close()
+        b.close()
