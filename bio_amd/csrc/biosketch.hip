@@ -668,7 +668,7 @@ static u32 env_u32(const char *name, u32 dflt) {
     const char *v = getenv(name);
     return v && *v ? (u32)strtoul(v, nullptr, 10) : dflt;
 }
-static u32 min_tile_min(const bsk_ctx *ctx) { return ctx->opt.tile_min ? ctx->opt.tile_min : std::min<u32>(kSynTileMin, 16u * (BSK_NT_FAST_WORDS - 2)); }
+static u32 min_tile_min(const bsk_ctx *ctx) { return ctx->opt.tile_min ? ctx->opt.tile_min : std::min<u32>(256u, 16u * (BSK_NT_FAST_WORDS - 2)); }  // (syncmers tile from where the long packed plan's columns fill up: >= ~290 bases)
 void BskOpts::load() {
     auto on = [](const char *n) { return getenv(n) != nullptr; };
     force_generic = on("BSK_FORCE_GENERIC");
@@ -2864,13 +2864,23 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     return rcd;
 }
 
+// the longest read the long packed syncmer plan takes (make_plan_enc's rule for k_syncmer_pkl, solved for the length): a pair of reads
+// wants 1.12 x + margin rows of its column, x = 2 (1.5 windows / (k - s + 1) + 0.5)
+static u32 syn_long_fit_bases(const bsk_ctx *ctx, const bsk_params *p) {
+    const double x_max = ((double)pk_syncmer_pair_rows(true) - (double)ctx->opt.syn_margin) / 1.12;
+    const double nwin_max = (x_max / 2.0 - 0.5) * (p->k - p->s + 1.0) / 1.5;
+    const long long fit = (long long)(nwin_max + 1e-6) + 2LL * p->k - p->s - 2;
+    return (u32)std::max<long long>(64, std::min<long long>(fit, (long long)pk_syncmer_max_bases(true)));
+}
 // from which sequence length a batch of this kind is cut into tiles (0: the kind does not tile)
 static u32 tile_min_for(const bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p) {
     const bool is_dna = b->alphabet == BSK_ALPHA_DNA;
     // (syncmers: beyond the packed kernels' reach the per-read 64-bit kernel falls to 140-160 Gbases/s of wall time -- its 28-tuple slabs
     // overflow -- and to 83 at 4 000 bases, where tiles run 170-210: scripts/dev/perf_midlen.py, round 4)
+    // (round 5: from where the long packed plan's columns fill up -- 392 bases at k = 31, s = 11 -- not from a fixed 448: the reads in
+    // between ran on k_syncmer_fast at 283 Gbases/s, tiles run them at ~420: scripts/dev/run_synlen.sh)
     return ctx->opt.tile_min ? ctx->opt.tile_min
-           : (is_dna && p->kind == BSK_SYNCMER && syn_long_plan_ok(ctx, p) && p->k - p->s >= 16) ? kSynTileMin  // (measured at k-s = 20..24; small k-s: tiles of 32 positions + 61 bases of overlap were never measured)
+           : (is_dna && p->kind == BSK_SYNCMER && syn_long_plan_ok(ctx, p) && p->k - p->s >= 16) ? std::min<u32>(kSynTileMin, syn_long_fit_bases(ctx, p))  // (measured at k-s = 20..24; small k-s: tiles of 32 positions + 61 bases of overlap were never measured)
            : ((!is_dna || kind_has_pos(p->kind)) ? 4096u : 16u * (BSK_NT_FAST_WORDS - 2));
 }
 
