@@ -668,7 +668,7 @@ static u32 env_u32(const char *name, u32 dflt) {
     const char *v = getenv(name);
     return v && *v ? (u32)strtoul(v, nullptr, 10) : dflt;
 }
-static u32 min_tile_min(const bsk_ctx *ctx) { return ctx->opt.tile_min ? ctx->opt.tile_min : std::min<u32>(256u, 16u * (BSK_NT_FAST_WORDS - 2)); }  // (syncmers tile from where the long packed plan's columns fill up: >= ~290 bases)
+static u32 min_tile_min(const bsk_ctx *ctx) { return ctx->opt.tile_min ? ctx->opt.tile_min : std::min<u32>(64u, 16u * (BSK_NT_FAST_WORDS - 2)); }  // (syncmers and wide-window minimizers tile from where their staged kernel stops fitting: tile_min_for)
 void BskOpts::load() {
     auto on = [](const char *n) { return getenv(n) != nullptr; };
     force_generic = on("BSK_FORCE_GENERIC");
@@ -2577,6 +2577,13 @@ static u32 tile_positions(const bsk_ctx *ctx, const bsk_params *p, u64 n_bases) 
     u32 tp;
     if (p->kind == BSK_MINIMIZER || p->kind == BSK_PROT_MINIMIZER) {
         tp = 16u * std::max<u32>(2, (u32)(22.0 * (p->w + 1.0) / 2.0 / 16.0));
+        // windows only k_minimizer_fast takes (w >= 17): its lanes stage in PAIRS of reads sharing a 56-row column, and a tile of 22 owned
+        // tuples carries 25 with its overlap -- 50 +- 5 per pair, a tenth of the pairs over, i.e. every unit run again with direct stores
+        // (w = 20, 700-base reads over such tiles: 288 Gbases/s).  20 expected tuples per tile instead.
+        if (p->kind == BSK_MINIMIZER && !pk_minimizer_supported(p->w) && !dense_minimizer_supported(p->w)) {
+            const double room = 10.0 * (p->w + 1.0) - p->w - 18.0;
+            tp = 16u * std::max<u32>(2, (u32)(room / 16.0));
+        }
         // round 5: a tile carries 2w + k + 16 bases of overlap, so 128 owned positions at k=21 w=11 are a 187-base tile that selects 26
         // tuples -- k_minimizer_dense's (526 Gbases/s of tile bases); tiles whose windows (tp + w + 18) stay at the packed machine's
         // tuple count run on k_minimizer_pk at twice that, which more than pays for the shorter tile (2 10^9 bases of long sequences:
@@ -2879,9 +2886,15 @@ static u32 tile_min_for(const bsk_ctx *ctx, const bsk_batch *b, const bsk_params
     // overflow -- and to 83 at 4 000 bases, where tiles run 170-210: scripts/dev/perf_midlen.py, round 4)
     // (round 5: from where the long packed plan's columns fill up -- 392 bases at k = 31, s = 11 -- not from a fixed 448: the reads in
     // between ran on k_syncmer_fast at 283 Gbases/s, tiles run them at ~420: scripts/dev/run_synlen.sh)
-    return ctx->opt.tile_min ? ctx->opt.tile_min
-           : (is_dna && p->kind == BSK_SYNCMER && syn_long_plan_ok(ctx, p) && p->k - p->s >= 16) ? std::min<u32>(kSynTileMin, syn_long_fit_bases(ctx, p))  // (measured at k-s = 20..24; small k-s: tiles of 32 positions + 61 bases of overlap were never measured)
-           : ((!is_dna || kind_has_pos(p->kind)) ? 4096u : 16u * (BSK_NT_FAST_WORDS - 2));
+    // (off the tuned parameter points, scripts/dev/run_holes.sh: syncmers with k - s < 16 -- k=21 s=11, k=25 s=15 -- stayed on k_syncmer_fast
+    // from 210 bases to the general threshold of 4 096: 250 -> 118 Gbases/s from 250 to 4 000 bases; minimizers with windows neither
+    // packed kernel nor k_minimizer_dense takes (w >= 17) on k_minimizer_fast, whose 32-tuple columns overflow from ~300 bases:
+    // w = 20: 812 at 250 bases, 392 / 294 / 192 at 400 / 700 / 4 000.  Both tile now from where their staged kernel stops fitting.)
+    if (ctx->opt.tile_min) return ctx->opt.tile_min;
+    if (is_dna && p->kind == BSK_SYNCMER && syn_long_plan_ok(ctx, p)) return std::min<u32>(kSynTileMin, syn_long_fit_bases(ctx, p));
+    if (is_dna && p->kind == BSK_MINIMIZER && !pkd_minimizer_supported(p->w) && !dense_minimizer_supported(p->w) && fast_minimizer_supported(p->w) && !ctx->opt.force_generic)
+        return std::min<u32>(4096u, (u32)(11 * (p->w + 1) + p->k + p->w));  // 22 expected tuples of the 32 a lane stages
+    return (!is_dna || kind_has_pos(p->kind)) ? 4096u : 16u * (BSK_NT_FAST_WORDS - 2);
 }
 
 // ---- class plans: the decision (host, from the batch's length histogram) ------------------------------------------------------------

@@ -130,15 +130,16 @@ def test_binned_view_is_rebuilt_per_window_and_after_refill(engine, oracle):
     b.close()
 
 
-@pytest.mark.parametrize("k,s,lo,hi", [(31, 11, 40, 150), (21, 11, 30, 224), (15, 9, 20, 400)])
+@pytest.mark.parametrize("k,s,lo,hi", [(31, 11, 40, 150), (21, 11, 30, 200), (21, 11, 30, 224), (15, 9, 20, 400)])
 def test_binned_units_syncmers(engine, oracle, k, s, lo, hi):
-    """The syncmer kernels (k_syncmer_pk + its list pass, k_syncmer_fast for the longer reads) over length-binned units."""
+    """The syncmer kernels (k_syncmer_pk / k_syncmer_pkl + their list pass) over length-binned units -- and, since round 5, ragged batches
+    whose longest read is beyond the long packed plan's columns (209 bases at k = 21 s = 11; dense selections at k = 15 s = 9) over tiles"""
     rng = random.Random(k * 100 + s)
     n = 9000 + rng.randint(0, 500)
     seqs = [rand_dna(rng, rng.randint(lo, hi)) for _ in range(n)]
     b = engine.batch(seqs)
     res = engine.run(b, engine.params(L.SYNCMER, k, s=s))
-    assert "length-binned" in res.plan()["kernel"], res.plan()
+    assert ("length-binned" if hi <= 200 else "over tiles") in res.plan()["kernel"], res.plan()
     for i in range(0, n, 3):
         st, h, p = res.read(i)
         try:
