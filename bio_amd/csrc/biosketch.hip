@@ -1796,7 +1796,9 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.fast_k = p->k;
             pl.slab = true;
             const u64 nwin = plen >= (u32)(p->k + p->w) ? (u64)plen - p->k - p->w + 2 : 1;
-            pl.slab_read = std::min<u64>(nwin, (u64)(nwin * 2.6 / (p->w + 1.0)) + 8);  // mean 2/(w+1) of the windows, +30 %
+            // mean 2/(w+1) of the windows, +30 % + 16 (+ 8 until round 5: 2 10^7 sequences of 100 residues at k = 8 w = 8 -- 19 +- 3 tuples in a
+            // slab of 32 -- had one sequence over, and the whole batch fell back to the general kernel: 72 instead of 530 G residues/s)
+            pl.slab_read = std::min<u64>(nwin, (u64)(nwin * 2.6 / (p->w + 1.0)) + 16);
             pl.slab_read = (pl.slab_read + 15) & ~(u64)15;  // whole 128-byte lines of hashes per sequence
             pl.slab_unit = 64 * pl.slab_read;
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;

@@ -47,7 +47,7 @@ __device__ __forceinline__ u64 mum64(u32 a0, u32 a1, u32 b0, u32 b1) {  // hi64(
 
 template <int W, int K>
 struct FastProt {
-    static_assert(K >= 9 && K <= 16, "register wyhash covers 9..16 residues");
+    static_assert(K >= 4 && K <= 16, "register wyhash covers 4..16 residues");
     static constexpr int MB = ilcm4(W);  // steps per macro block: a whole number of windows-blocks and of dwords
     // Tuples leave in whole groups of 16 (full 128-byte lines of hashes; groups of 8 were 18 % faster through two more waves per
     // CU but doubled the HBM traffic: half-line writes are read-modify-write).  The staging holds the left-over of a group
@@ -69,6 +69,19 @@ struct FastProt {
     __device__ __forceinline__ u64 hashK(u32 A, u32 B, u32 C, u32 D, u32 E) const {
         const u32 h0 = J ? __builtin_amdgcn_alignbit(B, A, 8 * J) : A;  // r32(p)
         const u32 h1 = J ? __builtin_amdgcn_alignbit(C, B, 8 * J) : B;  // r32(p+4)
+        if constexpr (K <= 8) {  // (round 5) 4..8 residues: one product with the whole k-mer as its tail, wymum(seed, tail ^ p1)
+            u64 x;
+            if (K == 4) x = h0;
+            else if (K == 5) x = ((u64)h0 << 8) | (h1 & 0xffu);
+            else if (K == 6) x = ((u64)h0 << 16) | (h1 & 0xffffu);
+            else if (K == 7) x = ((u64)h0 << 24) | ((u64)(h1 & 0xffffu) << 8) | ((h1 >> 16) & 0xffu);
+            else x = ((u64)h0 << 32) | h1;
+            constexpr u64 sd = 1ULL ^ WYP0;
+            const u64 bb = x ^ WYP1;
+            const u64 s1 = mum64((u32)sd, (u32)(sd >> 32), (u32)bb, (u32)(bb >> 32));
+            constexpr u64 fin = (u64)K ^ WYP5;
+            return mum64((u32)s1, (u32)(s1 >> 32), (u32)fin, (u32)(fin >> 32));
+        }
         const u32 t0 = J ? __builtin_amdgcn_alignbit(D, C, 8 * J) : C;  // bytes 8..11
         const u32 t1 = (K > 12) ? (J ? __builtin_amdgcn_alignbit(E, D, 8 * J) : D) : 0u;  // bytes 12..15
         constexpr int r = K - 8;
@@ -358,20 +371,32 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
     }
 }
 
-#ifdef BSK_IMPL_PROTEIN
-// every window 2..8 with every k 9..16 (the register wyhash covers 9..16 residues), protein-fed and DNA-fed
+// every window 2..8 with every k 4..16 (the register wyhash covers 4..16 residues), protein-fed and DNA-fed, in two translation units:
+// k_protein.hip k = 9..16, k_protein_short.hip k = 4..8 (round 5: k = 7 w = 3 ran on the general kernel, 30 G residues/s against 550)
+bool fast_prot_short_supported(int w, int k);
+int fast_prot_short_blocks_per_cu(int w, int k);
+void fast_prot_short_launch(int w, int k, int grid, hipStream_t stream, const KArgs &a, bool dna);
+#if defined(BSK_IMPL_PROTEIN) || defined(BSK_IMPL_PROTEIN_SHORT)
+#ifdef BSK_IMPL_PROTEIN_SHORT
+#define BSK_PROT_K(X, WW) X(WW, 4) X(WW, 5) X(WW, 6) X(WW, 7) X(WW, 8)
+#define BSK_PROT_FN(name) fast_prot_short_##name
+#else
 #ifndef BSK_PROT_KW  // (dev builds narrow the list: -D'BSK_PROT_KW(X)=X(5,9)')
 #define BSK_PROT_K(X, WW) X(WW, 9) X(WW, 10) X(WW, 11) X(WW, 12) X(WW, 13) X(WW, 14) X(WW, 15) X(WW, 16)
+#endif
+#define BSK_PROT_FN(name) fast_prot_long_##name
+#endif
+#ifndef BSK_PROT_KW
 #define BSK_PROT_KW(X) BSK_PROT_K(X, 2) BSK_PROT_K(X, 3) BSK_PROT_K(X, 4) BSK_PROT_K(X, 5) BSK_PROT_K(X, 6) BSK_PROT_K(X, 7) BSK_PROT_K(X, 8)
 #endif
-bool fast_prot_supported(int w, int k) {
+bool BSK_PROT_FN(supported)(int w, int k) {
 #define X(WW, KK) \
     if (w == WW && k == KK) return true;
     BSK_PROT_KW(X)
 #undef X
     return false;
 }
-int fast_prot_blocks_per_cu(int w, int k) {
+int BSK_PROT_FN(blocks_per_cu)(int w, int k) {
     int nb = 0;
     hipError_t e = hipErrorInvalidValue;
 #define X(WW, KK) \
@@ -384,19 +409,27 @@ int fast_prot_blocks_per_cu(int w, int k) {
     }
     return nb;
 }
+void BSK_PROT_FN(launch)(int w, int k, int grid, hipStream_t stream, const KArgs &a, bool dna) {  // dna: 2-bit DNA in, translated on the fly
+#define X(WW, KK)                                                                                                              \
+    if (w == WW && k == KK) {                                                                                                  \
+        if (dna) hipLaunchKernelGGL((k_prot_minimizer_fast<WW, KK, true>), dim3(grid), dim3(64), 0, stream, a);               \
+        else hipLaunchKernelGGL((k_prot_minimizer_fast<WW, KK, false>), dim3(grid), dim3(64), 0, stream, a);                  \
+    }
+    BSK_PROT_KW(X)
+#undef X
+}
+#endif
+#ifdef BSK_IMPL_PROTEIN
+bool fast_prot_supported(int w, int k) { return k <= 8 ? fast_prot_short_supported(w, k) : fast_prot_long_supported(w, k); }
+int fast_prot_blocks_per_cu(int w, int k) { return k <= 8 ? fast_prot_short_blocks_per_cu(w, k) : fast_prot_long_blocks_per_cu(w, k); }
 void fast_prot_launch(int w, int k, int grid, hipStream_t stream, const KArgs &a) {
-#define X(WW, KK) \
-    if (w == WW && k == KK) hipLaunchKernelGGL((k_prot_minimizer_fast<WW, KK, false>), dim3(grid), dim3(64), 0, stream, a);
-    BSK_PROT_KW(X)
-#undef X
+    if (k <= 8) fast_prot_short_launch(w, k, grid, stream, a, false);
+    else fast_prot_long_launch(w, k, grid, stream, a, false);
 }
-void fast_prot_dna_launch(int w, int k, int grid, hipStream_t stream, const KArgs &a) {  // 2-bit DNA in, translated on the fly
-#define X(WW, KK) \
-    if (w == WW && k == KK) hipLaunchKernelGGL((k_prot_minimizer_fast<WW, KK, true>), dim3(grid), dim3(64), 0, stream, a);
-    BSK_PROT_KW(X)
-#undef X
+void fast_prot_dna_launch(int w, int k, int grid, hipStream_t stream, const KArgs &a) {
+    if (k <= 8) fast_prot_short_launch(w, k, grid, stream, a, true);
+    else fast_prot_long_launch(w, k, grid, stream, a, true);
 }
-
 #endif  // BSK_IMPL_PROTEIN
 
 // ---------------------------------------------------------------------------------------
@@ -635,14 +668,24 @@ __global__ __launch_bounds__(64) void k_prot_hash_fast(KArgs a) {
     }
 }
 
-#ifdef BSK_IMPL_PROTEIN
+int fast_prot_hash_short_blocks_per_cu(int k, bool dna);
+void fast_prot_hash_short_launch(int k, int grid, hipStream_t stream, const KArgs &a, bool dna);
+#if defined(BSK_IMPL_PROTEIN) || defined(BSK_IMPL_PROTEIN_SHORT)
+#ifdef BSK_IMPL_PROTEIN_SHORT
+#define BSK_PH_KS(X) X(4) X(5) X(6) X(7) X(8)
+#define BSK_PH_FN(name) fast_prot_hash_short_##name
+#else
 #define BSK_PH_KS(X) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
-bool fast_prot_hash_supported(int k) { return k >= 9 && k <= 16; }
-int fast_prot_hash_blocks_per_cu(int k) {
+#define BSK_PH_FN(name) fast_prot_hash_long_##name
+#endif
+int BSK_PH_FN(blocks_per_cu)(int k, bool dna) {
     int nb = 0;
     hipError_t e = hipErrorInvalidValue;
-#define X(KK) \
-    if (k == KK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_prot_hash_fast<KK, false>, 64, 0);
+#define X(KK)                                                                                                        \
+    if (k == KK) {                                                                                                   \
+        if (dna) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_prot_hash_fast<KK, true>, 64, 0);           \
+        else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_prot_hash_fast<KK, false>, 64, 0);              \
+    }
     BSK_PH_KS(X)
 #undef X
     if (e != hipSuccess || nb < 1) {
@@ -651,32 +694,28 @@ int fast_prot_hash_blocks_per_cu(int k) {
     }
     return nb;
 }
+void BSK_PH_FN(launch)(int k, int grid, hipStream_t stream, const KArgs &a, bool dna) {
+#define X(KK)                                                                                                \
+    if (k == KK) {                                                                                           \
+        if (dna) hipLaunchKernelGGL((k_prot_hash_fast<KK, true>), dim3(grid), dim3(64), 0, stream, a);       \
+        else hipLaunchKernelGGL((k_prot_hash_fast<KK, false>), dim3(grid), dim3(64), 0, stream, a);          \
+    }
+    BSK_PH_KS(X)
+#undef X
+}
+#endif
+#ifdef BSK_IMPL_PROTEIN
+bool fast_prot_hash_supported(int k) { return k >= 4 && k <= 16; }
+int fast_prot_hash_blocks_per_cu(int k) { return k <= 8 ? fast_prot_hash_short_blocks_per_cu(k, false) : fast_prot_hash_long_blocks_per_cu(k, false); }
 void fast_prot_hash_launch(int k, int grid, hipStream_t stream, const KArgs &a) {
-#define X(KK) \
-    if (k == KK) hipLaunchKernelGGL((k_prot_hash_fast<KK, false>), dim3(grid), dim3(64), 0, stream, a);
-    BSK_PH_KS(X)
-#undef X
+    if (k <= 8) fast_prot_hash_short_launch(k, grid, stream, a, false);
+    else fast_prot_hash_long_launch(k, grid, stream, a, false);
 }
-int fast_prot_hash_dna_blocks_per_cu(int k) {
-    int nb = 0;
-    hipError_t e = hipErrorInvalidValue;
-#define X(KK) \
-    if (k == KK) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_prot_hash_fast<KK, true>, 64, 0);
-    BSK_PH_KS(X)
-#undef X
-    if (e != hipSuccess || nb < 1) {
-        (void)hipGetLastError();
-        nb = 1;
-    }
-    return nb;
-}
+int fast_prot_hash_dna_blocks_per_cu(int k) { return k <= 8 ? fast_prot_hash_short_blocks_per_cu(k, true) : fast_prot_hash_long_blocks_per_cu(k, true); }
 void fast_prot_hash_dna_launch(int k, int grid, hipStream_t stream, const KArgs &a) {  // 2-bit DNA in, translated on the fly
-#define X(KK) \
-    if (k == KK) hipLaunchKernelGGL((k_prot_hash_fast<KK, true>), dim3(grid), dim3(64), 0, stream, a);
-    BSK_PH_KS(X)
-#undef X
+    if (k <= 8) fast_prot_hash_short_launch(k, grid, stream, a, true);
+    else fast_prot_hash_long_launch(k, grid, stream, a, true);
 }
-
 #endif  // BSK_IMPL_PROTEIN
 
 }  // namespace bsk

@@ -310,14 +310,15 @@ def test_protein_minimizer_and_hash(engine, oracle, k, w):
             assert np.array_equal(h2, e2), (i, q)
 
 
-@pytest.mark.parametrize("k", [9, 10, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("k", [3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17])
 def test_protein_hash_register_kernel_all_k_and_long_sequences(engine, oracle, k):
-    """k = 9..16 run on k_prot_hash_fast<K> (256-position chunks staged in LDS); 17 on the general kernel."""
+    """k = 4..16 (4..8: round 5) run on k_prot_hash_fast<K> (256-position chunks staged in LDS); 3 and 17 on the general kernel."""
     rng = random.Random(900 + k)
     lens = [3 * k - 1, 3 * k, 3 * k + 1, 47, 48, 49, 511, 512, 513, 512 + k - 1, 512 + k, 1023, 1024, 1025, 1500, 2600]
     seqs = [rand_seq(rng, n, AA) for n in lens] + [rand_seq(rng, rng.randint(1, 700), AA) for _ in range(150)]
     b = engine.batch(seqs, L.ALPHA_PROTEIN)
     res = engine.run(b, engine.params(L.PROT_HASH, k))
+    assert ("k_prot_hash_fast" in res.plan()["kernel"]) == (4 <= k <= 16), res.plan()
     for i, q in enumerate(seqs):
         st, h, _ = res.read(i)
         try:
@@ -531,9 +532,9 @@ def test_long_outliers_do_not_inflate_per_read_slabs(engine, oracle):
 
 @pytest.mark.parametrize("w", [2, 3, 4, 5, 6, 7, 8])
 def test_protein_minimizer_register_kernel_whole_grid(engine, oracle, w):
-    """Every window 2..8 with every k 9..16 runs on k_prot_minimizer_fast<W,K> -- protein-fed and, for 2-bit DNA batches, with the
-    translation fused into its residue fetch (all six frames): both against the oracle, and the plan is the register kernel."""
-    for k in range(9, 17):
+    """Every window 2..8 with every k 4..16 (4..8: round 5) runs on k_prot_minimizer_fast<W,K> -- protein-fed and, for 2-bit DNA batches,
+    with the translation fused into its residue fetch (all six frames): both against the oracle, and the plan is the register kernel."""
+    for k in range(4, 17):
         rng = random.Random(w * 100 + k)
         prot = [rand_seq(rng, rng.choice([300, rng.randint(1, 500)]), AA) for _ in range(70)] + ["A" * 90, rand_seq(rng, 3 * k + w - 1, AA)]
         b = engine.batch(prot, L.ALPHA_PROTEIN)
