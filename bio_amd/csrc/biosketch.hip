@@ -2582,6 +2582,7 @@ static u32 tile_positions(const bsk_ctx *ctx, const bsk_params *p, u64 n_bases) 
         // windows only k_minimizer_fast takes (w >= 17): its lanes stage in PAIRS of reads sharing a 56-row column, and a tile of 22 owned
         // tuples carries 25 with its overlap -- 50 +- 5 per pair, a tenth of the pairs over, i.e. every unit run again with direct stores
         // (w = 20, 700-base reads over such tiles: 288 Gbases/s).  20 expected tuples per tile instead.
+        if (p->kind == BSK_MINIMIZER && p->w == 1) tp = 512;  // every position selected: k_minimizer_dense<1>'s per-read slabs take any tile, and 32 positions + k + 18 of overlap were two thirds overlap
         if (p->kind == BSK_MINIMIZER && !pk_minimizer_supported(p->w) && !dense_minimizer_supported(p->w)) {
             const double room = 10.0 * (p->w + 1.0) - p->w - 18.0;
             tp = 16u * std::max<u32>(2, (u32)(room / 16.0));
@@ -3343,6 +3344,16 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
     if (rc != BSK_OK) {
         ctx->err = bsk_err_name(rc);
         return rc;
+    }
+    // a syncmer sketch with s == k yields every k-mer with its index (sketch.go:328-331) -- the minimizer sketch with w = 1 (sketch.go:
+    // 218-222), same length rule (sketch.go:179-182): it runs as that (k_minimizer_dense<1>; the tiled path always did, and until round 5
+    // shorter sequences took the general syncmer kernel at 50-70 Gbases/s).  Not circular sequences: their length rules differ.
+    bsk_params as_min;
+    if (p->kind == BSK_SYNCMER && p->s == p->k && !p->circular && batch->alphabet == BSK_ALPHA_DNA && !ctx->opt.force_generic) {
+        as_min = *p;
+        as_min.kind = BSK_MINIMIZER;
+        as_min.w = 1;
+        p = &as_min;
     }
     const bsk_batch *b = batch;
     bsk_batch *tmp = nullptr;

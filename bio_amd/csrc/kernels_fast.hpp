@@ -1212,8 +1212,8 @@ void fast_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a) 
 #endif  // BSK_IMPL_MINIMIZER
 
 #ifdef BSK_IMPL_DENSE  // k_minimizer_dense<W>: its own translation unit (k_minimizer_dense.hip)
-#define BSK_DENSE_WS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
-bool dense_minimizer_supported(int w) { return w >= 2 && w <= 16; }
+#define BSK_DENSE_WS(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+bool dense_minimizer_supported(int w) { return w >= 1 && w <= 16; }  // (w = 1: every k-mer with its position -- sketch.go:218-222 -- ran on the general kernel until round 5)
 int dense_minimizer_blocks_per_cu(int w) {
     int nb = 0;
     hipError_t e = hipErrorInvalidValue;

@@ -564,3 +564,27 @@ def test_protein_minimizer_register_kernel_whole_grid(engine, oracle, w):
             else:
                 assert (st & L.ST_CODE_MASK) == 0 and np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep), (w, k, frame, i, len(q))
         bd.close()
+
+
+@pytest.mark.parametrize("k", [11, 21, 32])
+def test_every_kmer_with_its_position_w1_and_s_equal_k(engine, oracle, k):
+    """minimizer w = 1 (sketch.go:218-222) and syncmer s == k (sketch.go:328-331) yield every k-mer with its index: both run on
+    k_minimizer_dense<1> since round 5 (general kernels before), read by read against the oracle, short and low-complexity reads included"""
+    rng = random.Random(1000 + k)
+    seqs = [rand_seq(rng, rng.choice([150, 250, rng.randint(1, 600)])) for _ in range(700)] + ["A" * 200, rand_seq(rng, k - 1), rand_seq(rng, k), ""]
+    b = engine.batch(seqs)
+    for kind, par, ref in ((L.MINIMIZER, dict(w=1), lambda q: oracle.minimizer(q, k, 1, False, closed=True)),
+                           (L.SYNCMER, dict(s=k), lambda q: oracle.syncmer(q, k, k, False, closed=True))):
+        res = engine.run(b, engine.params(kind, k, **par))
+        assert "k_minimizer_dense<1>" in res.plan()["kernel"], res.plan()
+        for i, q in enumerate(seqs):
+            st, h, p = res.read(i)
+            try:
+                eh, ep, es, fl = ref(q)
+            except oracle.OracleError as err:
+                assert (st & L.ST_CODE_MASK) != 0 and len(h) == 0, (i, len(q), err.name)
+                continue
+            assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep) and np.array_equal(p >> 31, es), (kind, i, len(q))
+            assert (st & 0xF0) == fl, (kind, i, st, fl)
+        res.close()
+    b.close()
