@@ -236,6 +236,15 @@ __global__ void k_adopt_refs(const u32 *list, u64 n, const u64 *crefs, const u8 
         status[r] = cstatus[i];
     }
 }
+// the ASCII side launch ran beside the main kernel with reference words and status bytes of its own (indexed like the batch): they
+// replace the main kernel's for the reads of the subset
+__global__ void k_adopt_side(const u32 *subset, u64 nsub, const u64 *srefs, const u8 *sstatus, u64 *refs, u8 *status) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nsub; i += (u64)gridDim.x * blockDim.x) {
+        const u64 r = subset[i];
+        refs[r] = srefs[r];
+        status[r] = sstatus[r];
+    }
+}
 // ... the same from a part that ran over tiles (a wide result: first / count per sequence)
 __global__ void k_adopt_wide(const u32 *list, u64 n, const u64 *wfirst, const u64 *wcount, const u8 *cstatus, u64 base, u64 *refs, u8 *status) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
@@ -531,6 +540,8 @@ extern "C" void bsk_ctx_destroy(bsk_ctx *ctx) {
     }
     if (ctx->ev_side_done) (void)hipEventDestroy(ctx->ev_side_done);
     if (ctx->ev_adopted) (void)hipEventDestroy(ctx->ev_adopted);
+    if (ctx->ev_mix0) (void)hipEventDestroy(ctx->ev_mix0);
+    if (ctx->ev_mix1) (void)hipEventDestroy(ctx->ev_mix1);
     bsk_comm_destroy(ctx);
     (void)hipFree(ctx->d_ticket);
     (void)hipFree(ctx->d_total);
@@ -677,6 +688,8 @@ void BskOpts::load() {
     no_pk = on("BSK_NO_PK");
     no_ring = on("BSK_NO_RING");
     no_pkd = on("BSK_NO_PKD");
+    no_side_early = on("BSK_NO_SIDE_EARLY");
+    no_side_dense = on("BSK_NO_SIDE_DENSE");
     no_bin = on("BSK_NO_BIN");
     no_bin_early = on("BSK_NO_BIN_EARLY");
     compact = on("BSK_COMPACT");
@@ -721,7 +734,8 @@ static bsk_ctx *side_ctx(bsk_ctx *ctx) {
     if (!ctx->side) {
         bsk_ctx *s = nullptr;
         if (bsk_ctx_create(ctx->device, &s) != BSK_OK) return nullptr;
-        if (hipEventCreateWithFlags(&ctx->ev_side_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_adopted, hipEventDisableTiming) != hipSuccess) {
+        if (hipEventCreateWithFlags(&ctx->ev_side_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_adopted, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_mix0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_mix1, hipEventDisableTiming) != hipSuccess) {
             bsk_ctx_destroy(s);
             return nullptr;
         }
@@ -1417,7 +1431,7 @@ static int blocks_per_cu(K kernel) {
 
 // Which kernel runs a (batch, params) pair, on how many workgroups, and how the tuple arrays are organised.
 enum Which { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST, K_NT_FAST, K_SYN_P, K_SYN_A, K_KMER_P, K_KMER_A, K_SIM_P, K_SIM_A,
-             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST, K_MIN_DENSE, K_MIN_SEG, K_MIN_WPR, K_MIN_PK, K_SYN_PK, K_MIN_RING, K_SYN_SEL, K_MIN_PKD };
+             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST, K_MIN_DENSE, K_MIN_SEG, K_MIN_WPR, K_MIN_PK, K_SYN_PK, K_MIN_RING, K_SYN_SEL, K_MIN_PKD, K_MIN_DENSE_A };
 struct Plan {
     Which which = K_MIN_GEN_P;
     int grid = 1;
@@ -1438,6 +1452,7 @@ struct Plan {
     bool mixed = false;
     Which side_which = K_MIN_GEN_A;
     u32 side_nunits = 0, side_ring_w = 0;
+    u64 side_slab = 0;     // K_MIN_DENSE_A: tuples of a read's slab in the side launch's region
     int side_grid = 1;
 };
 
@@ -1547,6 +1562,24 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
             pl.side_ring_w = sd.ring_w;
             pl.side_grid = sd.grid;
             pl.ring_entries = std::max(pl.ring_entries, sd.ring_entries);
+            // minimizers: the flagged reads on k_minimizer_dense<W, false, true> -- the staged 64-bit machine fed from ASCII, one slab of a
+            // tuple per window for every read (nothing to outgrow) -- while those slabs stay below 4 GB (round 5: the general kernel, whose
+            // window lives in global memory, ran 1 % of the reads in a third of the call: 1.5 10^9 bases of 150-base reads 755 against
+            // 1 150 Gbases/s, 1 000-base reads 355 against 600)
+            if (p->kind == BSK_MINIMIZER && sd.which == K_MIN_GEN_A && dense_minimizer_supported(p->w) && !p->circular && !b->adesc && b->aoff && std::max(b->maxlen, b->side_maxlen) < 32768u &&
+                !ctx->opt.force_generic && !ctx->opt.no_side_dense) {
+                const u32 longest = b->side_maxlen ? b->side_maxlen : b->maxlen;  // (a class view's side launch takes the other classes' flagged reads too)
+                const u64 nwin_max = longest + 2 > (u32)(p->k + p->w) ? (u64)longest - p->k - p->w + 2 : 1;
+                const u64 slab = (nwin_max + 15) & ~(u64)15;
+                const u64 units = (b->nsub + 63) / 64;
+                if (units * 64 * slab * 12 <= (4ULL << 30)) {
+                    pl.side_which = K_MIN_DENSE_A;
+                    pl.side_slab = slab;
+                    pl.side_nunits = (u32)units;
+                    pl.side_grid = (int)std::max<u64>(1, std::min<u64>((units + 3) / 4, (u64)ctx->cus * (u64)dense_minimizer_ascii_blocks_per_cu(p->w)));
+                    pl.side_ring_w = 0;
+                }
+            }
             return BSK_OK;
         }
     }
@@ -2231,6 +2264,69 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     HIPCHK(ctx, hipMemsetAsync(ctx->d_total, 0, 4 * sizeof(u64), ctx->stream));
     if (!pl.slab) HIPCHK(ctx, hipMemsetAsync(ctx->d_lookback, 0, (size_t)pl.nunits * sizeof(u64), ctx->stream));
     if (ev0 && !cs) HIPCHK(ctx, hipEventRecord(ev0, ctx->stream));
+    // The ASCII side launch of a mixed batch (a general per-lane kernel over the reads with a non-ACGT letter: 60-100 Gbases/s on a grid
+    // of its own).  Position kinds: it runs BESIDE the main kernel, on the side context's stream and look-back scratch, queued ahead of it,
+    // into reference words and status bytes of its own that k_adopt_side copies over the main kernel's afterwards -- behind the main
+    // kernel it cost 35 % of the call with 1 % of the reads flagged (1.5 10^9 bases of 150-base reads: 755 against 1 150 Gbases/s).
+    // Stream kinds overwrite the runs the main kernel laid out (inplace) and stay behind it.
+    auto side_launch = [&](hipStream_t st, u64 *lookback, u64 *refs_to, u8 *status_to) -> int {
+        KArgs sd = a;
+        sd.desc = b->desc;  // (the side launch names its reads by their batch positions)
+        sd.rflags = b->rflags;
+        sd.len_mask = 0xffffffu;
+        sd.binned = 0;
+        sd.cls_lo = sd.cls_hi = sd.cls_pretend = 0;
+        sd.subset = b->subset;
+        sd.nsub = b->nsub;
+        sd.nunits = pl.side_nunits;
+        sd.out_base = res->main_cap;
+        sd.cap = res->cap;
+        sd.uniform_len = 0;
+        sd.inplace = !kind_has_pos(p->kind);  // stream kinds: overwrite the read's own run, keep the layout contiguous
+        sd.ticket = ctx->d_ticket + 2;
+        sd.total = ctx->d_total + 2;
+        sd.ring_w = pl.side_ring_w;
+        sd.lookback = lookback;
+        sd.refs = refs_to;
+        sd.status = status_to;
+        HIPCHK(ctx, hipMemsetAsync(lookback, 0, (size_t)pl.side_nunits * sizeof(u64), st));
+        switch (pl.side_which) {
+            case K_MIN_GEN_A: hipLaunchKernelGGL(k_minimizer_generic<1>, dim3(pl.side_grid), dim3(64), 0, st, sd); break;
+            case K_MIN_DENSE_A:
+                sd.slab_read = pl.side_slab;
+                dense_minimizer_ascii_launch(p->w, pl.side_grid, st, sd);
+                break;
+            case K_NT_A: hipLaunchKernelGGL(k_nthash_stream<1>, dim3(pl.side_grid), dim3(64), 0, st, sd); break;
+            case K_SYN_A: hipLaunchKernelGGL(k_syncmer<1>, dim3(pl.side_grid), dim3(64), 0, st, sd); break;
+            case K_KMER_A: hipLaunchKernelGGL(k_kmer<1>, dim3(pl.side_grid), dim3(64), 0, st, sd); break;
+            case K_SIM_A: hipLaunchKernelGGL(k_simhash<1>, dim3(pl.side_grid), dim3(64), 0, st, sd); break;
+            default: ctx->err = "mixed plan without an ASCII kernel"; return BSK_ERR_DEVICE;
+        }
+        return BSK_OK;
+    };
+    bool side_early = false;
+    if (pl.mixed && kind_has_pos(p->kind) && !ctx->opt.no_side_early && side_ctx(ctx)) {
+        bsk_ctx *sc = ctx->side;
+        auto grow = [&](int slot, size_t bytes) -> hipError_t {
+            if (ctx->tmp_cap[slot] >= bytes) return hipSuccess;
+            (void)hipFree(ctx->tmp[slot]);
+            ctx->tmp[slot] = nullptr;
+            ctx->tmp_cap[slot] = 0;
+            const hipError_t e = hipMalloc(&ctx->tmp[slot], bytes + bytes / 4 + 256);
+            if (e == hipSuccess) ctx->tmp_cap[slot] = bytes + bytes / 4 + 256;
+            return e;
+        };
+        if (ensure_scratch(sc, pl.side_nunits, 0) == BSK_OK && grow(28, (size_t)b->n * 8) == hipSuccess && grow(29, (size_t)b->n) == hipSuccess) {
+            // (behind the counters' memsets above: the side kernel's ticket and total live beside the main kernel's)
+            HIPCHK(ctx, hipEventRecord(ctx->ev_mix0, ctx->stream));
+            HIPCHK(ctx, hipStreamWaitEvent(sc->stream, ctx->ev_mix0, 0));
+            const int src = side_launch(sc->stream, sc->d_lookback, (u64 *)ctx->tmp[28], (u8 *)ctx->tmp[29]);
+            if (src != BSK_OK) return src;
+            side_early = true;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     switch (pl.which) {
         case K_MIN_GEN_P: hipLaunchKernelGGL(k_minimizer_generic<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_MIN_GEN_A: hipLaunchKernelGGL(k_minimizer_generic<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
@@ -2241,6 +2337,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_MIN_RING: ring_minimizer_launch(pl.fast_w, b->maxlen > ring_minimizer_short_bases(), pl.grid, ctx->stream, a); break;
         case K_MIN_DENSE: dense_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_MIN_PKD: pkd_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
+        case K_MIN_DENSE_A: break;  // (a side launch's kernel only)
 #ifdef BSK_EXPERIMENTS
         case K_MIN_SEG: seg_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_MIN_WPR: wpr_minimizer_launch(pl.grid, ctx->stream, a); break;
@@ -2337,31 +2434,15 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         const int arc = adopt_parts(ctx, cs, res);
         if (arc != BSK_OK) return arc;
     }
-    if (pl.mixed) {  // the reads with a non-ACGT letter again, from their ASCII bytes, into [main_cap, cap)
-        KArgs sd = a;
-        sd.desc = b->desc;  // (the side launch names its reads by their batch positions)
-        sd.rflags = b->rflags;
-        sd.len_mask = 0xffffffu;
-        sd.binned = 0;
-        sd.subset = b->subset;
-        sd.nsub = b->nsub;
-        sd.nunits = pl.side_nunits;
-        sd.out_base = res->main_cap;
-        sd.cap = res->cap;
-        sd.uniform_len = 0;
-        sd.inplace = !kind_has_pos(p->kind);  // stream kinds: overwrite the read's own run, keep the layout contiguous
-        sd.ticket = ctx->d_ticket + 2;
-        sd.total = ctx->d_total + 2;
-        sd.ring_w = pl.side_ring_w;
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_lookback, 0, (size_t)pl.side_nunits * sizeof(u64), ctx->stream));
-        switch (pl.side_which) {
-            case K_MIN_GEN_A: hipLaunchKernelGGL(k_minimizer_generic<1>, dim3(pl.side_grid), dim3(64), 0, ctx->stream, sd); break;
-            case K_NT_A: hipLaunchKernelGGL(k_nthash_stream<1>, dim3(pl.side_grid), dim3(64), 0, ctx->stream, sd); break;
-            case K_SYN_A: hipLaunchKernelGGL(k_syncmer<1>, dim3(pl.side_grid), dim3(64), 0, ctx->stream, sd); break;
-            case K_KMER_A: hipLaunchKernelGGL(k_kmer<1>, dim3(pl.side_grid), dim3(64), 0, ctx->stream, sd); break;
-            case K_SIM_A: hipLaunchKernelGGL(k_simhash<1>, dim3(pl.side_grid), dim3(64), 0, ctx->stream, sd); break;
-            default: ctx->err = "mixed plan without an ASCII kernel"; return BSK_ERR_DEVICE;
-        }
+    if (pl.mixed && !side_early) {  // the reads with a non-ACGT letter again, from their ASCII bytes, into [main_cap, cap)
+        const int src = side_launch(ctx->stream, ctx->d_lookback, res->refs, res->status);
+        if (src != BSK_OK) return src;
+    }
+    if (side_early) {  // ... or it ran beside the main kernel (below): its reference words and status bytes replace the main kernel's
+        HIPCHK(ctx, hipEventRecord(ctx->ev_mix1, ctx->side->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_mix1, 0));
+        hipLaunchKernelGGL(k_adopt_side, dim3(grid_for(ctx, b->nsub, 256)), dim3(256), 0, ctx->stream, b->subset, (u64)b->nsub, (const u64 *)ctx->tmp[28], (const u8 *)ctx->tmp[29],
+                           res->refs, res->status);
     }
     if (ev1) HIPCHK(ctx, hipEventRecord(ev1, ctx->stream));
     HIPCHK(ctx, hipGetLastError());
@@ -2428,6 +2509,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
     if (pl.slab && *result && (*result)->ovf_cap > ovf_cap) ovf_cap = (*result)->ovf_cap;
     u64 cap = pl.slab ? pl.slab_total + ovf_cap : estimate_cap(b, p, circ_ext);
     u64 side_cap = (pl.mixed && kind_has_pos(p->kind)) ? estimate_cap_n(p, b->nsub * (u64)b->maxlen, b->nsub) : 0;  // maxlen already includes a circular extension
+    if (pl.mixed && pl.side_which == K_MIN_DENSE_A) side_cap = (u64)pl.side_nunits * 64 * pl.side_slab + 64;
     if (*result && pl.mixed && (*result)->main_cap && (*result)->cap > (*result)->main_cap) {
         cap = std::max(cap, (*result)->main_cap);
         side_cap = std::max(side_cap, (*result)->cap - (*result)->main_cap);
@@ -3146,6 +3228,7 @@ static int class_build(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, co
         v->odd = nullptr;
         v->d_odd = nullptr;
         if (!masked) v->desc = view;  // (masked: the batch's own descriptors, the kernel masks by length)
+        v->side_maxlen = b->maxlen;
         v->maxlen = bk.hi;
         v->n_bases = pretend ? (u64)pretend * b->n : bk.bases;
         v->uniform_len = pretend;

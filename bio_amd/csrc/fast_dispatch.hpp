@@ -17,6 +17,8 @@ void fast_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a);
 bool dense_minimizer_supported(int w);  // per-read slabs + mid-read flushes: windows that select more than 32 positions per read
 int dense_minimizer_blocks_per_cu(int w);
 void dense_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a);
+void dense_minimizer_ascii_launch(int w, int grid, hipStream_t stream, const KArgs &a);  // the ASCII side launch of a mixed batch (KArgs::subset, ascii, aoff, out_base)
+int dense_minimizer_ascii_blocks_per_cu(int w);
 
 bool pk_minimizer_supported(int w);  // packed 32-bit window machine, w <= 16 (kernels_pk.hpp)
 int pk_minimizer_blocks_per_cu(int w);

@@ -14,7 +14,7 @@
 // Developer switches (DESIGN.md "Switches"): read from the environment ONCE, when the context is created, or again on
 // bsk_ctx_reload_options (the test suite flips them inside one process) -- never on the bsk_sketch path.
 struct BskOpts {
-    bool force_generic = false, no_mixed = false, no_dense = false, no_pk = false, no_ring = false, no_pkd = false, ring = false, no_bin = false, no_bin_early = false, compact = false, no_tiles = false, no_tile_cache = false, no_group_gather = false, timing = false,
+    bool force_generic = false, no_mixed = false, no_dense = false, no_pk = false, no_ring = false, no_pkd = false, no_side_early = false, no_side_dense = false, ring = false, no_bin = false, no_bin_early = false, compact = false, no_tiles = false, no_tile_cache = false, no_group_gather = false, timing = false,
          no_fused_translate = false, sets_no_small = false;
     int syn_margin = 2;
     bool no_syn_long = false;
@@ -45,8 +45,8 @@ struct bsk_ctx {
     u8 *d_lut = nullptr;      // codon tables of `lut_table` (kernels_translate.hpp layout)
     int lut_table = 0;
     // tiled calls: grow-only temporaries (hipMalloc / hipFree of ten buffers per call cost more than the kernels)
-    void *tmp[28] = {};      // 0-9: tiled calls / sets, 12-14: bsk_result_fetch, 16-19: bsk_result_compact, 20: bsk_sets_fetch_narrow, 21-23: class plans, 24-27: two-pass syncmers
-    size_t tmp_cap[28] = {};
+    void *tmp[32] = {};      // 0-9: tiled calls / sets, 12-14: bsk_result_fetch, 16-19: bsk_result_compact, 20: bsk_sets_fetch_narrow, 21-23: class plans, 24-27: two-pass syncmers, 28-29: the ASCII side launch's own reference words / status bytes
+    size_t tmp_cap[32] = {};
     u64 *h_refs = nullptr;   // pinned staging of bsk_result_fetch (refs down, offsets up), grow-only
     size_t h_refs_cap = 0;
     struct bsk_result *tile_res = nullptr;  // tile-level result of the previous tiled call, reused
@@ -57,7 +57,7 @@ struct bsk_ctx {
     // class plans: the parts (the classes besides the bulk) run on a SIDE context -- a stream and scratch of their own -- so that their
     // small, latency-bound launches overlap with the bulk's kernel instead of queueing in front of it; two events order the two streams
     bsk_ctx *side = nullptr;              // created on first use, destroyed with this context
-    hipEvent_t ev_side_done = nullptr, ev_adopted = nullptr;
+    hipEvent_t ev_side_done = nullptr, ev_adopted = nullptr, ev_mix0 = nullptr, ev_mix1 = nullptr;
     bool adopted_recorded = false;
     struct ClassSet *cls = nullptr;       // the class plan a run_planned / launch in progress belongs to (biosketch.hip: run_classed)
     struct bsk_result *cls_owner = nullptr;  // the result whose class plan the pooled lists / views (tmp 21-23) currently describe
@@ -98,6 +98,7 @@ struct bsk_batch {
     int pairs = BSK_ALPHA_DNA;  // nucleotide batches: the alphabet whose PairLetter the two-strand k-mer mode applies (BSK_ALPHA_DNA = DNAredundant, 2..5)
     u64 n = 0, n_bases = 0, n_words = 0, n_nonacgt = 0;
     u32 maxlen = 0;
+    u32 side_maxlen = 0;   // class views: the longest read of the WHOLE batch (the ASCII side launch covers every flagged read, whatever its class); 0: maxlen
     u32 uniform_len = 0;  // != 0: every read has this length (synthetic batches)
     u32 *words = nullptr;
     u64 *desc = nullptr;   // NULL when a sequence has 2^24 bases or more: fw + llen then locate the sequences (tiled runs only)

@@ -149,6 +149,14 @@ struct PLds {
     static constexpr int CTAB = TAB2 + 256;                                // u64 [64]: fast_copyout's owner table
     static constexpr int TOTAL = CTAB + 512;                               // 20 400 B: eight waves per CU use 163 200 of the 163 840 B
 };
+// FLds + the two byte tables of the ASCII path (build_bytetabs: tin[b], tout[b], 256 x 16 bytes each): k_minimizer_dense<W, false, true>,
+// the side launch over the reads of a mixed batch that hold a non-ACGT letter
+template <int CAP>
+struct FLdsA : FLds<CAP, true> {
+    static constexpr int TIN = (FLds<CAP, true>::TOTAL + 15) & ~15;
+    static constexpr int TOUT = TIN + 4096;
+    static constexpr int TOTAL = TOUT + 4096;
+};
 template <bool PAIR, int CAP, bool POS16, int PR>
 struct MinLds {
     typedef FLds<CAP, POS16> type;
@@ -160,9 +168,11 @@ struct MinLds<true, CAP, POS16, PR> {
 
 // RING: the lane's CAP+1 rows are a ring (k_minimizer_dense: no left-over moves after a flush); `send` = one row past the last.
 // PR: rows of a paired column.  XCH: table rows fetched per chunk (0: all W up front for W <= 16, 4 beyond).
-template <int W, int CAP, bool POS16, bool DIRECT, bool PAIR = false, bool RING = false, int PR = BSK_PAIR_ROWS, int XCH = 0>
+// ASC: the sequence is ASCII (`ab`: its first byte); a step's table row is tin[incoming byte] ^ tout[outgoing byte] (FLdsA)
+template <int W, int CAP, bool POS16, bool DIRECT, bool PAIR = false, bool RING = false, int PR = BSK_PAIR_ROWS, int XCH = 0, bool ASC = false>
 struct FastMin {
-    typedef typename MinLds<PAIR, CAP, POS16, PR>::type LY;
+    typedef typename std::conditional<ASC, FLdsA<CAP>, typename MinLds<PAIR, CAP, POS16, PR>::type>::type LY;
+    const u8 *__restrict__ ab;
     static constexpr u32 SBIT = POS16 ? 0x8000u : 0x80000000u;  // strand bit inside the staged pos word
     const u32 *__restrict__ w;
     LDSQ char *lds;
@@ -248,9 +258,28 @@ struct FastMin {
                 xs[o] = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TAB + (a | b));
             }
         };
+        if constexpr (ASC) {  // (bytes straight from memory, all of the block's at once; two table reads per step)
+            u32 ib[W], ob[W];
+#pragma unroll
+            for (int o = 0; o < W; ++o) {
+                ib[o] = ab[t0 + (u32)o];
+                ob[o] = (FIRST && o == 0) ? 0u : ab[i0 + (u32)o - 1u];
+            }
+#pragma unroll
+            for (int o = 0; o < W; ++o) {
+                const u32x4 xi = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TIN + (ib[o] << 4));
+                if (FIRST && o == 0) {
+                    xs[o] = xi;
+                } else {
+                    const u32x4 xo = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TOUT + (ob[o] << 4));
+                    xs[o] = (u32x4){xi.x ^ xo.x, xi.y ^ xo.y, xi.z ^ xo.z, xi.w ^ xo.w};
+                }
+            }
+        } else {
         fetch(0);
         if (XC < W) fetch(XC);
         load_block_words(i0 + W);  // next block's words: in flight while this block is hashed
+        }
         u32 vi = i0;               // k-mer index as a VGPR (selects need VGPR operands)
         const u32 spare = PAIR ? sspare : (u32)(CAP * LY::ROW + lane) * 8u;
 #pragma unroll
@@ -260,7 +289,7 @@ struct FastMin {
                 // windows: five blocks of 32 would run 160 steps).  No block follows, so the suffix pass goes too.
                 if (i0 + (u32)o >= nku) return;
             }
-            if (XC < W && o && o % XC == 0 && o + XC < W) {
+            if (!ASC && XC < W && o && o % XC == 0 && o + XC < W) {
                 __builtin_amdgcn_sched_barrier(0);  // keep the next chunk's reads here (hoisted, they are all live at once again)
                 fetch(o + XC);
             }
@@ -768,10 +797,13 @@ struct DenseCfg {
 // tails, repeats), and a homopolymer selects EVERY position -- which is this kernel's case (per-read slabs, mid-read flushes), not
 // k_minimizer_fast's, whose staging columns such reads overflow.  64 listed reads per wavefront; every read gets a slab of
 // a.slab_read tuples (the caller passes the largest possible count) in the overflow region.
-template <int W, bool LIST = false>
+// ASC (round 5): the side launch of a mixed batch -- the reads a.subset names, from their ASCII bytes (a.ascii, a.aoff), every read a slab of
+// a.slab_read tuples (the caller passes one per window: nothing to outgrow) in [a.out_base, a.cap).  The general per-lane ASCII kernel it
+// replaces keeps its window in global memory and ran 1 % of a batch's reads in a third of the batch's time.
+template <int W, bool LIST = false, bool ASC = false>
 __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
     constexpr int CAP = DenseCfg<W>::CAP, NB = DenseCfg<W>::NB, GL = DenseCfg<W>::GL, G = DenseCfg<W>::G;
-    typedef FLds<CAP, true> LY;
+    typedef typename std::conditional<ASC, FLdsA<CAP>, FLds<CAP, true>>::type LY;
     __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
     LDSQ char *const ldsq = (LDSQ char *)lds;
     const int lane = lane_id();
@@ -782,7 +814,8 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
         for (u32 sg = blockIdx.x; sg < a.list_grid; sg += gridDim.x) any |= a.rlist[sg];
         if (!any) return;
     }
-    build_xtab(reinterpret_cast<uint4 *>(lds + LY::TAB), a.k, lane);
+    if constexpr (ASC) build_bytetabs(reinterpret_cast<uint4 *>(lds + FLdsA<CAP>::TIN), reinterpret_cast<uint4 *>(lds + FLdsA<CAP>::TOUT), a.k, lane);
+    else build_xtab(reinterpret_cast<uint4 *>(lds + LY::TAB), a.k, lane);
     __syncthreads();
     const u64 slab_read = a.slab_read;
     for (u32 sg = LIST ? blockIdx.x : 0u; sg < (LIST ? a.list_grid : 1u); sg += LIST ? gridDim.x : 1u) {
@@ -796,18 +829,29 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
          })) {
         u64 r = (u64)unit * 64 + lane;
         if (LIST) r = r < nlist ? (u64)mylist[r] : ~0ULL;
+        if (ASC) r = r < a.nsub ? (u64)a.subset[r] : ~0ULL;
         u64 off = 0, L = 0, ro = r;
         if (r < a.n) {
-            const u64 d = a.desc[r];
-            off = d >> 24;
-            L = desc_len(a, d);
-            ro = out_index(a, r, d);  // (length-binned batches: the read's own place in its chunk)
+            if constexpr (ASC) {
+                ascii_span(a, r, off, L);  // (byte offset and length of the read's ASCII)
+            } else {
+                const u64 d = a.desc[r];
+                off = d >> 24;
+                L = desc_len(a, d);
+                ro = out_index(a, r, d);  // (length-binned batches: the read's own place in its chunk)
+            }
         }
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) + 1 >= (u64)a.k + (u64)W;
         const u32 nk = ok ? (u32)(L - a.k + 1) : 0u;
         const u32 nk_max = wave_max_u32(nk);
         u64 ubase = (u64)unit * 64 * slab_read;
         bool room = true;
+        if (ASC) {  // slabs of the side launch's own region
+            ubase += a.out_base;
+            room = ubase + 64 * slab_read <= a.cap;
+            if (!room && lane == 0) atomicOr(&a.ticket[1], 1u);
+            if (unit == a.nunits - 1 && lane == 0) *a.total = ubase + 64 * slab_read;
+        }
         if (LIST) {  // 64 slabs from the overflow region
             u64 ob = 0;
             if (lane == 0) ob = atomicAdd(a.total + 1, 64 * slab_read);
@@ -818,8 +862,10 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
         }
         u32 done = 0, tie = 0;
         if (nk_max && room) {
-            FastMin<W, CAP, true, false, false, true> fm;
+            FastMin<W, CAP, true, false, false, true, BSK_PAIR_ROWS, 0, ASC> fm;
             fm.w = a.words + off;
+            fm.ab = ASC ? a.ascii + off : nullptr;
+            fm.in_lo = fm.in_hi = fm.out_lo = fm.out_hi = 0;
             fm.send = (u32)((CAP + 1) * LY::ROW + lane) * 8u;
             fm.lds = ldsq;
             fm.k = a.k;
@@ -830,6 +876,19 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
             fm.tie = 0;
             fm.nku = 0xffffffffu;
             fm.slot = (u32)lane * 8u;
+            if constexpr (ASC) {  // warm-up from the bytes: tin rows alone (nothing leaves)
+                int t = 0;
+                for (; t + 4 <= a.k - 1; t += 4) {
+                    const u32 b0 = fm.ab[t], b1 = fm.ab[t + 1], b2 = fm.ab[t + 2], b3 = fm.ab[t + 3];
+                    const u32x4 x0 = *reinterpret_cast<LDSQ const u32x4 *>(ldsq + LY::TIN + (b0 << 4)), x1 = *reinterpret_cast<LDSQ const u32x4 *>(ldsq + LY::TIN + (b1 << 4));
+                    const u32x4 x2 = *reinterpret_cast<LDSQ const u32x4 *>(ldsq + LY::TIN + (b2 << 4)), x3 = *reinterpret_cast<LDSQ const u32x4 *>(ldsq + LY::TIN + (b3 << 4));
+                    fm.roll(x0);
+                    fm.roll(x1);
+                    fm.roll(x2);
+                    fm.roll(x3);
+                }
+                for (; t < a.k - 1; ++t) fm.roll(*reinterpret_cast<LDSQ const u32x4 *>(ldsq + LY::TIN + ((u32)fm.ab[t] << 4)));
+            } else {
             for (int t0 = 0; t0 < a.k - 1; t0 += 16) {  // warm-up: bases 0..k-2 enter, nothing leaves
                 const u32 word = fm.w[t0 >> 4];
                 const int nb = (a.k - 1 - t0) < 16 ? (a.k - 1 - t0) : 16;
@@ -849,6 +908,7 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
                     fm.roll(*reinterpret_cast<LDSQ const u32x4 *>(ldsq + LY::TAB + 256 + (((word >> (2 * j)) & 3) << 4)));
             }
             fm.load_block_words(0);
+            }
             int inround = 0;
             u32 head = 0;
             for (u32 i0 = 0; i0 < nk_max; i0 += W) {
@@ -1220,6 +1280,31 @@ int dense_minimizer_blocks_per_cu(int w) {
     switch (w) {
 #define X(WW) \
     case WW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_minimizer_dense<WW>, 64, 0); break;
+        BSK_DENSE_WS(X)
+#undef X
+        default: break;
+    }
+    if (e != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        nb = 1;
+    }
+    return nb;
+}
+void dense_minimizer_ascii_launch(int w, int grid, hipStream_t stream, const KArgs &a) {  // the side launch over a.subset, from ASCII
+    switch (w) {
+#define X(WW) \
+    case WW: hipLaunchKernelGGL((k_minimizer_dense<WW, false, true>), dim3(grid), dim3(64), 0, stream, a); break;
+        BSK_DENSE_WS(X)
+#undef X
+        default: break;
+    }
+}
+int dense_minimizer_ascii_blocks_per_cu(int w) {
+    int nb = 0;
+    hipError_t e = hipErrorInvalidValue;
+    switch (w) {
+#define X(WW) \
+    case WW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_minimizer_dense<WW, false, true>, 64, 0); break;
         BSK_DENSE_WS(X)
 #undef X
         default: break;

@@ -62,6 +62,11 @@ def outlier_batch(rng, n, base_len, outliers, with_n=False, ragged=False):
             if len(s) > 3:
                 j = rng.randrange(len(s))
                 seqs[i] = s[:j] + "N" + s[j + 1:]
+    if with_n:  # ... and in every second outlier (the bulk's ASCII side launch owns the flagged reads of EVERY class: its slabs follow the batch's longest read)
+        for i, s in enumerate(seqs):
+            if len(s) > base_len and i % 2 == 0:
+                j = rng.randrange(len(s))
+                seqs[i] = s[:j] + "N" + s[j + 1:]
     # low-complexity reads in every class (the exact machine's list)
     seqs[5] = "A" * len(seqs[5])
     return seqs
