@@ -1431,7 +1431,7 @@ static int blocks_per_cu(K kernel) {
 
 // Which kernel runs a (batch, params) pair, on how many workgroups, and how the tuple arrays are organised.
 enum Which { K_MIN_GEN_P, K_MIN_GEN_A, K_NT_P, K_NT_A, K_MIN_FAST, K_NT_FAST, K_SYN_P, K_SYN_A, K_KMER_P, K_KMER_A, K_SIM_P, K_SIM_A,
-             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST, K_MIN_DENSE, K_MIN_SEG, K_MIN_WPR, K_MIN_PK, K_SYN_PK, K_MIN_RING, K_SYN_SEL, K_MIN_PKD, K_MIN_DENSE_A };
+             K_PROT_HASH, K_PROT_MIN, K_SYN_FAST, K_PROT_MIN_FAST, K_PROT_HASH_FAST, K_SIM_FAST, K_MIN_DENSE, K_MIN_SEG, K_MIN_WPR, K_MIN_PK, K_SYN_PK, K_MIN_RING, K_SYN_SEL, K_MIN_PKD, K_MIN_DENSE_A, K_SYN_FAST_A };
 struct Plan {
     Which which = K_MIN_GEN_P;
     int grid = 1;
@@ -1567,7 +1567,7 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
             // window lives in global memory, ran 1 % of the reads in a third of the call: 1.5 10^9 bases of 150-base reads 755 against
             // 1 150 Gbases/s, 1 000-base reads 355 against 600)
             if (p->kind == BSK_MINIMIZER && sd.which == K_MIN_GEN_A && dense_minimizer_supported(p->w) && !p->circular && !b->adesc && b->aoff && std::max(b->maxlen, b->side_maxlen) < 32768u &&
-                !ctx->opt.force_generic && !ctx->opt.no_side_dense) {
+                !ctx->opt.force_generic && !ctx->opt.no_side_dense && !ctx->no_side_fast) {
                 const u32 longest = b->side_maxlen ? b->side_maxlen : b->maxlen;  // (a class view's side launch takes the other classes' flagged reads too)
                 const u64 nwin_max = longest + 2 > (u32)(p->k + p->w) ? (u64)longest - p->k - p->w + 2 : 1;
                 const u64 slab = (nwin_max + 15) & ~(u64)15;
@@ -1579,6 +1579,17 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
                     pl.side_grid = (int)std::max<u64>(1, std::min<u64>((units + 3) / 4, (u64)ctx->cus * (u64)dense_minimizer_ascii_blocks_per_cu(p->w)));
                     pl.side_ring_w = 0;
                 }
+            }
+            // syncmers likewise: k_syncmer_fast<W, false, true> (unit slabs of 28 tuples per read + an overflow region for the units with a
+            // read beyond them, all inside the side region; 1 % of 150-base reads flagged: 603-621 against 827 Gbases/s clean)
+            if (p->kind == BSK_SYNCMER && sd.which == K_SYN_A && fast_syncmer_supported(p->k, p->s) && p->s != p->k && !p->circular && !b->adesc && b->aoff &&
+                std::max(b->maxlen, b->side_maxlen) < 32768u && !ctx->opt.force_generic && !ctx->opt.no_side_dense && !ctx->no_side_fast) {
+                const u64 units = (b->nsub + 63) / 64;
+                pl.side_which = K_SYN_FAST_A;
+                pl.side_slab = BSK_SYN_CAP;
+                pl.side_nunits = (u32)units;
+                pl.side_grid = (int)std::max<u64>(1, std::min<u64>(units, (u64)ctx->cus * 4));  // (a ticket is one unit)
+                pl.side_ring_w = 0;
             }
             return BSK_OK;
         }
@@ -2296,6 +2307,11 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
                 sd.slab_read = pl.side_slab;
                 dense_minimizer_ascii_launch(p->w, pl.side_grid, st, sd);
                 break;
+            case K_SYN_FAST_A:
+                sd.ovf_base = res->main_cap + (u64)pl.side_nunits * 64 * pl.side_slab;
+                sd.ovf_cap = res->cap > sd.ovf_base ? res->cap - sd.ovf_base : 0;
+                fast_syncmer_ascii_launch(p->k - p->s, pl.side_grid, st, sd);
+                break;
             case K_NT_A: hipLaunchKernelGGL(k_nthash_stream<1>, dim3(pl.side_grid), dim3(64), 0, st, sd); break;
             case K_SYN_A: hipLaunchKernelGGL(k_syncmer<1>, dim3(pl.side_grid), dim3(64), 0, st, sd); break;
             case K_KMER_A: hipLaunchKernelGGL(k_kmer<1>, dim3(pl.side_grid), dim3(64), 0, st, sd); break;
@@ -2337,7 +2353,8 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_MIN_RING: ring_minimizer_launch(pl.fast_w, b->maxlen > ring_minimizer_short_bases(), pl.grid, ctx->stream, a); break;
         case K_MIN_DENSE: dense_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_MIN_PKD: pkd_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
-        case K_MIN_DENSE_A: break;  // (a side launch's kernel only)
+        case K_MIN_DENSE_A:
+        case K_SYN_FAST_A: break;  // (side launches' kernels only)
 #ifdef BSK_EXPERIMENTS
         case K_MIN_SEG: seg_minimizer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_MIN_WPR: wpr_minimizer_launch(pl.grid, ctx->stream, a); break;
@@ -2510,6 +2527,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
     u64 cap = pl.slab ? pl.slab_total + ovf_cap : estimate_cap(b, p, circ_ext);
     u64 side_cap = (pl.mixed && kind_has_pos(p->kind)) ? estimate_cap_n(p, b->nsub * (u64)b->maxlen, b->nsub) : 0;  // maxlen already includes a circular extension
     if (pl.mixed && pl.side_which == K_MIN_DENSE_A) side_cap = (u64)pl.side_nunits * 64 * pl.side_slab + 64;
+    if (pl.mixed && pl.side_which == K_SYN_FAST_A) side_cap += (u64)pl.side_nunits * 64 * pl.side_slab + 64;  // (unit slabs, then the dense estimate above as their overflow region)
     if (*result && pl.mixed && (*result)->main_cap && (*result)->cap > (*result)->main_cap) {
         cap = std::max(cap, (*result)->main_cap);
         side_cap = std::max(side_cap, (*result)->cap - (*result)->main_cap);
@@ -2523,6 +2541,11 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         ctx->err = "bsk_sketch_timed: the result was not sized for this batch and these parameters: call bsk_sketch first";
         return cleanup(BSK_ERR_ARG);
     }
+    bool side_fell_back = false;
+    struct SideGuard {
+        bsk_ctx *c;
+        ~SideGuard() { c->no_side_fast = false; }
+    } side_guard{ctx};
     for (int attempt = 0; sizing && attempt < 3; ++attempt) {
         rc = result_prepare(ctx, result, b->n, p->kind, cap + side_cap, (ctx->cls && b == ctx->cls->view) ? ctx->cls->tail : 0);
         if (rc == BSK_ERR_NOMEM && (pl.which == K_MIN_DENSE || pl.which == K_MIN_PKD || pl.which == K_MIN_SEG || pl.which == K_MIN_WPR || pl.which == K_PROT_MIN_FAST) && attempt < 2) {
@@ -2556,6 +2579,17 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         const u32 ovf = ((u32 *)(ctx->h_pinned + 4))[1], side_ovf = ((u32 *)(ctx->h_pinned + 4))[3];
         res->n_tuples = total;
         if (!ovf && !side_ovf) break;
+        if (side_ovf && (pl.side_which == K_SYN_FAST_A || pl.side_which == K_MIN_DENSE_A) && !side_fell_back) {  // the staged side kernels' regions are sized up front: plan again with the general one
+            ctx->no_side_fast = true;  // (for the rest of this call: side_guard)
+            pl = Plan();
+            rc = make_plan(ctx, b, p, pl);
+            if (rc != BSK_OK) return cleanup(rc);
+            cap = pl.slab ? pl.slab_total + ovf_cap : estimate_cap(b, p, circ_ext);
+            side_cap = (pl.mixed && kind_has_pos(p->kind)) ? estimate_cap_n(p, b->nsub * (u64)b->maxlen, b->nsub) : 0;
+            --attempt;  // (the general kernel keeps its own two tries: an estimate, then the exact size -- fuzz seed 11003764: k = 21, s = 1)
+            side_fell_back = true;
+            continue;
+        }
         if (side_ovf && attempt < 2) side_cap = side_end - res->main_cap + 64;  // dense side kernel: its end is exact even when it overflowed
         if (!ovf && attempt < 2) continue;
         if (attempt == 2) {

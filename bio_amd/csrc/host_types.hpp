@@ -60,6 +60,7 @@ struct bsk_ctx {
     hipEvent_t ev_side_done = nullptr, ev_adopted = nullptr, ev_mix0 = nullptr, ev_mix1 = nullptr;
     bool adopted_recorded = false;
     struct ClassSet *cls = nullptr;       // the class plan a run_planned / launch in progress belongs to (biosketch.hip: run_classed)
+    bool no_side_fast = false;            // run_planned: a staged side kernel's region overflowed, plan the general one
     struct bsk_result *cls_owner = nullptr;  // the result whose class plan the pooled lists / views (tmp 21-23) currently describe
     u64 sel_need = 0;           // two-pass syncmers: the dense region a call that is being sized again needs (run_planned)
     bool no_syn_pk = false;     // set while a call falls back from k_syncmer_pk / k_minimizer_pk (the list of reads for the exact machine filled up)

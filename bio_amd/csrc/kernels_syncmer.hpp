@@ -37,6 +37,17 @@ struct SynLds {
     static constexpr int TOTAL = NZ + 64;
 };
 
+// SynLds + the four byte tables of the ASCII path (build_bytetabs for k and for s): k_syncmer_fast<W, false, true>, the side launch over
+// the reads of a mixed batch that hold a non-ACGT letter (round 5; the general per-lane kernel before)
+template <int W, int CAP>
+struct SynLdsA : SynLds<W, CAP> {
+    static constexpr int TINK = (SynLds<W, CAP>::TOTAL + 15) & ~15;
+    static constexpr int TOUTK = TINK + 4096;
+    static constexpr int TINS = TOUTK + 4096;
+    static constexpr int TOUTS = TINS + 4096;
+    static constexpr int TOTAL = TOUTS + 4096;
+};
+
 // 32 consecutive 2-bit codes starting at base position p0 (p0 >= 0): lo = codes 0..15, hi = codes 16..31
 struct Codes32 {
     u32 lo, hi;
@@ -78,10 +89,12 @@ struct Codes32 {
     }
 };
 
-template <int W, int CAP, bool DIRECT>
+// ASC: the sequence is ASCII (`ab`: its first byte); a step's table rows are tin[incoming byte] ^ tout[outgoing byte] (SynLdsA)
+template <int W, int CAP, bool DIRECT, bool ASC = false>
 struct FastSyn {
-    typedef SynLds<W, CAP> LY;
+    typedef typename std::conditional<ASC, SynLdsA<W, CAP>, SynLds<W, CAP>>::type LY;
     const u32 *__restrict__ w;
+    const u8 *__restrict__ ab;
     LDSQ char *lds;
     int k, s, lane;
     u32 end_plus1;  // number of windows of this lane (end + 1), 0 if the read is short
@@ -120,8 +133,17 @@ struct FastSyn {
     template <int MODE, int O>
     __device__ __forceinline__ void step(u32 i0, const Codes32 &sin, const Codes32 &sout, const Codes32 &kin, const Codes32 &kout) {
         // ---- s-mer i_s = i0 + O ----
+        if constexpr (ASC) {
+            u32x4 x = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TINS + ((u32)ab[i0 + (u32)O + (u32)s - 1u] << 4));
+            if (!(MODE == 0 && O == 0)) {
+                const u32x4 y = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TOUTS + ((u32)ab[i0 + (u32)O - 1u] << 4));
+                x = (u32x4){x.x ^ y.x, x.y ^ y.y, x.z ^ y.z, x.w ^ y.w};
+            }
+            rolls(x);
+        } else {
         const u32 so = (MODE == 0 && O == 0) ? 0x100u : sout.template out_off<O>();
         rolls(tabs(sin.template in_off<O>() | so));
+        }
         const lmask srev = lt64(srl, srh, sfl, sfh);
         HV v;
         v.lo = sel(srev, srl, sfl);
@@ -139,8 +161,17 @@ struct FastSyn {
                 const u32 b = sel(right, M.p - (u32)W, D[O].p);          // sketch.go:413-420
                 pend |= 0x80000000u >> (b - idx);  // bit 31 = position idx: "selected" is the sign bit
                 // k-mer at idx
+                if constexpr (ASC) {
+                    u32x4 x = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TINK + ((u32)ab[idx + (u32)k - 1u] << 4));
+                    if (MODE != 1) {
+                        const u32x4 y = *reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TOUTK + ((u32)ab[idx - 1u] << 4));
+                        x = (u32x4){x.x ^ y.x, x.y ^ y.y, x.z ^ y.z, x.w ^ y.w};
+                    }
+                    rollk(x);
+                } else {
                 const u32 ko = (MODE == 1) ? 0x100u : kout.template out_off<O>();
                 rollk(tabk(kin.template in_off<O>() | ko));
+                }
                 const lmask krev = lt64(krl, krh, kfl, kfh);
                 const u32 hl = sel(krev, krl, kfl), hh = sel(krev, krh, kfh);
                 const u32 ps = (sel01(krev) << 15) | idx;
@@ -183,6 +214,9 @@ struct FastSyn {
     template <int MODE>
     __device__ __forceinline__ void block(u32 i0) {
         Codes32 sin, sout, kin, kout;
+        if constexpr (ASC) {
+            sin.lo = sin.hi = sout.lo = sout.hi = kin.lo = kin.hi = kout.lo = kout.hi = 0;  // (unused: the steps read bytes)
+        } else
         if (MODE == 2) {
             const u32 idx0 = i0 - (2 * W - 1);
             sin.finish(nsin, i0 + (u32)s - 1);
@@ -199,7 +233,7 @@ struct FastSyn {
             sout.lo = (u32)v;
             sout.hi = (u32)(v >> 32);
         }
-        if (MODE == 2) {
+        if (MODE == 2 || ASC) {
         } else if (MODE == 1) {
             prefetch(2 * W);
             // only offset W-1 is a fused step: idx = 0, incoming base k-1; place it at code index W-1
@@ -256,6 +290,10 @@ struct FastSyn {
         tm = 0;
         Al = Ah = 0xffffffffu;
         slot = (u32)lane * 8u;
+        if constexpr (ASC) {  // warm-ups from the bytes: tin rows alone (nothing leaves)
+            for (int t = 0; t < s - 1; ++t) rolls(*reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TINS + ((u32)ab[t] << 4)));
+            for (int t = 0; t < k - 1; ++t) rollk(*reinterpret_cast<LDSQ const u32x4 *>(lds + LY::TINK + ((u32)ab[t] << 4)));
+        } else {
         // warm-ups: four table rows in flight per trip (one row per trip exposes the LDS latency k + s - 2 times per read)
         for (int t0 = 0; t0 < s - 1; t0 += 16) {  // s-mer warm-up
             const u32 word = w[t0 >> 4];
@@ -287,6 +325,7 @@ struct FastSyn {
             }
             for (; j < nb; ++j) rollk(tabk(256 + (((word >> (2 * j)) & 3) << 4)));
         }
+        }
         block<0>(0);
         block<1>(W);  // unconditional: a lane that is not short has at least 2W s-mers (sketch.go:149), and a conditional block leaves
                       // D[] undefined on one path -- the compiler then keeps last unit's registers alive across the unit loop
@@ -300,16 +339,23 @@ struct FastSyn {
 // LIST: the READS k_syncmer_pk listed in a.fixlist (u32 read numbers, one segment per workgroup of the main launch: list_append) -- reads in
 // which two equal 27-bit s-mer keys met in a min operation, or whose staging column filled up -- 64 per wavefront, on this kernel's
 // 64-bit machine; their tuples go to the overflow region.
-template <int W, bool LIST = false>
-__global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves per SIMD: at most 256 VGPRs.  One wave with 512 registers
+// ASC (round 5): the side launch of a mixed batch -- the reads a.subset names, from their ASCII bytes, unit slabs in [a.out_base, a.ovf_base),
+// units with a read over its 28 tuples in [a.ovf_base, + a.ovf_cap) as in the main launch
+template <int W, bool LIST = false, bool ASC = false>
+__global__ __launch_bounds__(64, (ASC ? 1 : 2)) void k_syncmer_fast(KArgs a) {  // (ASC: 36 KB of LDS, four waves per CU)  // 2 waves per SIMD: at most 256 VGPRs.  One wave with 512 registers
                                                                     // removes the W >= 13 spills but runs 1.5x slower (432 -> 284 Gbases/s at W = 20)
     constexpr int CAP = BSK_SYN_CAP;
-    typedef SynLds<W, CAP> LY;
+    typedef typename std::conditional<ASC, SynLdsA<W, CAP>, SynLds<W, CAP>>::type LY;
     __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
     LDSQ char *const ldsq = (LDSQ char *)lds;
     const int lane = lane_id();
-    build_xtab(reinterpret_cast<uint4 *>(lds + LY::TABK), a.k, lane);
-    build_xtab(reinterpret_cast<uint4 *>(lds + LY::TABS), a.s, lane);
+    if constexpr (ASC) {
+        build_bytetabs(reinterpret_cast<uint4 *>(lds + SynLdsA<W, CAP>::TINK), reinterpret_cast<uint4 *>(lds + SynLdsA<W, CAP>::TOUTK), a.k, lane);
+        build_bytetabs(reinterpret_cast<uint4 *>(lds + SynLdsA<W, CAP>::TINS), reinterpret_cast<uint4 *>(lds + SynLdsA<W, CAP>::TOUTS), a.s, lane);
+    } else {
+        build_xtab(reinterpret_cast<uint4 *>(lds + LY::TABK), a.k, lane);
+        build_xtab(reinterpret_cast<uint4 *>(lds + LY::TABS), a.s, lane);
+    }
     __syncthreads();
     const u64 slab = (u64)64 * CAP;
     u64 d_next = 0;
@@ -320,21 +366,29 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves p
     for (u32 sg = LIST ? blockIdx.x : 0u; sg < (LIST ? a.list_grid : 1u); sg += LIST ? gridDim.x : 1u) {
     const u32 nlist = LIST ? (flist[sg] < lseg ? flist[sg] : lseg) : 0u;
     const u32 *const rlist = LIST ? flist + a.list_grid + sg * lseg : nullptr;
-    for (u32 unit = LIST ? 0u : next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; LIST ? unit < (nlist + 63u) / 64u : unit < a.nunits; ++unit, ({
+    constexpr u32 TK = ASC ? 1u : 8u;  // units per ticket (the side launch's few units are latency: one per wavefront)
+    for (u32 unit = LIST ? 0u : next_ticket(a.ticket, lane) * TK, uend = unit + TK; LIST ? unit < (nlist + 63u) / 64u : unit < a.nunits; ++unit, ({
              if (LIST) {
              } else if (unit == uend) {
-                 unit = next_ticket(a.ticket, lane) * 8u;
-                 uend = unit + 8u;
+                 unit = next_ticket(a.ticket, lane) * TK;
+                 uend = unit + TK;
              }
          })) {
         u64 r = (u64)unit * 64 + lane;
         if (LIST) r = r < nlist ? (u64)rlist[r] : ~0ULL;
+        if (ASC) r = r < a.nsub ? (u64)a.subset[r] : ~0ULL;
         // the next unit's descriptors are loaded one unit ahead (a load issued here waits for the copy-out stores to drain)
-        const u64 d = (pre && !LIST) ? d_next : (r < a.n ? a.desc[r] : 0);
-        const u64 off = d >> 24, L = desc_len(a, d);
-        const u64 ro = out_index(a, r, d);  // (length-binned batches: the read's own place in its chunk)
-        pre = !LIST && unit + 1 != uend && unit + 1 < a.nunits;
-        if (pre) d_next = r + 64 < a.n ? a.desc[r + 64] : 0;
+        u64 d = 0, off = 0, L = 0, ro = r;
+        if constexpr (ASC) {
+            if (r < a.n) ascii_span(a, r, off, L);  // (byte offset and length of the read's ASCII)
+        } else {
+            d = (pre && !LIST) ? d_next : (r < a.n ? a.desc[r] : 0);
+            off = d >> 24;
+            L = desc_len(a, d);
+            ro = out_index(a, r, d);  // (length-binned batches: the read's own place in its chunk)
+            pre = !LIST && unit + 1 != uend && unit + 1 < a.nunits;
+            if (pre) d_next = r + 64 < a.n ? a.desc[r + 64] : 0;
+        }
         const long long Lorig = (long long)L - a.circ_ext;
         const bool ok = r < a.n && Lorig >= 0 && Lorig >= 2LL * a.k - a.s - 1 && L >= (u64)a.k;  // sketch.go:149
         const u32 nwin = ok ? (u32)(L - 2 * (u64)a.k + a.s + 2) : 0u;                             // end + 1
@@ -342,8 +396,9 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves p
         const u32 ns_max = wave_max_u32(ns);
         u32 cnt = 0, tie = 0;
         if (ns_max) {
-            FastSyn<W, CAP, false> fs;
+            FastSyn<W, CAP, false, ASC> fs;
             fs.w = a.words + off;
+            fs.ab = ASC ? a.ascii + off : nullptr;
             fs.lds = ldsq;
             fs.k = a.k;
             fs.s = a.s;
@@ -357,7 +412,7 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves p
         const u32 excl = incl - cnt;
         const u32 T = wave_bcast_u32(incl, 63);
         const bool any_over = __builtin_amdgcn_ballot_w64(cnt > (u32)CAP) != 0;
-        u64 base = (u64)unit * slab;
+        u64 base = (ASC ? a.out_base : 0) + (u64)unit * slab;
         u64 ob = 0;
         if (LIST || any_over) {
             if (lane == 0) ob = atomicAdd(a.total + 1, (u64)T);
@@ -369,8 +424,9 @@ __global__ __launch_bounds__(64, 2) void k_syncmer_fast(KArgs a) {  // 2 waves p
         } else {
             if (ob + T <= a.ovf_cap) {
                 base = a.ovf_base + ob;
-                FastSyn<W, CAP, true> fs;
+                FastSyn<W, CAP, true, ASC> fs;
                 fs.w = a.words + off;
+                fs.ab = ASC ? a.ascii + off : nullptr;
                 fs.lds = ldsq;
                 fs.k = a.k;
                 fs.s = a.s;
@@ -436,5 +492,20 @@ void fast_syncmer_launch(int w, int grid, hipStream_t stream, const KArgs &a) {
 }
 
 #endif  // BSK_IMPL_SYNCMER
+#ifdef BSK_IMPL_SYNCMER_ASCII  // k_syncmer_ascii.hip: the ASCII side launch's instantiations, a translation unit of their own
+#ifndef BSK_SYN_WS
+#define BSK_SYN_WS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
+#endif
+void fast_syncmer_ascii_launch(int w, int grid, hipStream_t stream, const KArgs &a) {  // the side launch over a.subset, from ASCII
+    switch (w) {
+#define X(WW) \
+    case WW: hipLaunchKernelGGL((k_syncmer_fast<WW, false, true>), dim3(grid), dim3(64), 0, stream, a); break;
+        BSK_SYN_WS(X)
+#undef X
+        default: break;
+    }
+}
+#endif  // BSK_IMPL_SYNCMER_ASCII
+
 
 }  // namespace bsk
