@@ -1576,7 +1576,7 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
                     pl.side_which = K_MIN_DENSE_A;
                     pl.side_slab = slab;
                     pl.side_nunits = (u32)units;
-                    pl.side_grid = (int)std::max<u64>(1, std::min<u64>((units + 3) / 4, (u64)ctx->cus * (u64)dense_minimizer_ascii_blocks_per_cu(p->w)));
+                    pl.side_grid = (int)std::max<u64>(1, std::min<u64>(units, (u64)ctx->cus * (u64)dense_minimizer_ascii_blocks_per_cu(p->w)));  // (a ticket is one unit)
                     pl.side_ring_w = 0;
                 }
             }

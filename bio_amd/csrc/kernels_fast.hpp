@@ -821,10 +821,11 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
     for (u32 sg = LIST ? blockIdx.x : 0u; sg < (LIST ? a.list_grid : 1u); sg += LIST ? gridDim.x : 1u) {
     const u32 nlist = LIST ? (a.rlist[sg] < lseg ? a.rlist[sg] : lseg) : 0u;
     const u32 *const mylist = LIST ? a.rlist + a.list_grid + sg * lseg : nullptr;
-    for (u32 unit = LIST ? 0u : next_ticket(a.ticket, lane) * 4u, uend = unit + 4u; LIST ? unit < (nlist + 63u) / 64u : unit < a.nunits; ++unit, ({
+    constexpr u32 TK = ASC ? 1u : 4u;  // units per ticket (the side launch's few units are latency: one per wavefront)
+    for (u32 unit = LIST ? 0u : next_ticket(a.ticket, lane) * TK, uend = unit + TK; LIST ? unit < (nlist + 63u) / 64u : unit < a.nunits; ++unit, ({
              if (!LIST && unit == uend) {
-                 unit = next_ticket(a.ticket, lane) * 4u;
-                 uend = unit + 4u;
+                 unit = next_ticket(a.ticket, lane) * TK;
+                 uend = unit + TK;
              }
          })) {
         u64 r = (u64)unit * 64 + lane;
