@@ -71,6 +71,8 @@ struct KArgs {
     u64 *sel_ubase, *sel_lookback;
     u32 sel_nb;
     u32 cls_lo, cls_hi, cls_pretend;  // class plans: see desc_len()
+    u32 tk;          // units per ticket of the persistent-wave kernels (0: the kernel's own 4 or 8): a batch with fewer units than the grid has
+                     // wavefronts x that number takes smaller tickets -- a pipeline chunk or a class plan's part is latency, not throughput
     u32 list_grid;   // workgroups of the main launch = segments of the list of reads (list_append); the list pass may run with fewer
     u32 len_mask;    // 0xffffff, or 0xfff for binned descriptors
     u32 binned;

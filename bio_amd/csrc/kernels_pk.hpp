@@ -576,10 +576,11 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pk(KArgs a) {  // two waves
     bool have = false;
     const u32 lseg = a.fixcap / a.list_grid;  // this workgroup's segment of the list of reads for the exact machine (list_append)
     u32 lcur = 0;
-    for (u32 unit = next_ticket(a.ticket, lane) * PK_TICKET, uend = unit + PK_TICKET; unit < a.nunits; ++unit, ({
+    const u32 tku = a.tk ? a.tk : PK_TICKET;
+    for (u32 unit = next_ticket(a.ticket, lane) * tku, uend = unit + tku; unit < a.nunits; ++unit, ({
              if (unit == uend) {
-                 unit = next_ticket(a.ticket, lane) * PK_TICKET;
-                 uend = unit + PK_TICKET;
+                 unit = next_ticket(a.ticket, lane) * tku;
+                 uend = unit + tku;
              }
          })) {
         const u64 r = (u64)unit * 64 + lane;

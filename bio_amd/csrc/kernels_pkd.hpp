@@ -58,10 +58,11 @@ __global__ __launch_bounds__(64, 2) void k_minimizer_pkd(KArgs a) {
     u32 rfl_cur = 0, rfl_n1 = 0;
     bool have = false;
     const u64 rmax = a.n - 1;
-    for (u32 unit = next_ticket(a.ticket, lane) * 4u, uend = unit + 4u; unit < a.nunits; ++unit, ({
+    const u32 tku = a.tk ? a.tk : 4u;
+    for (u32 unit = next_ticket(a.ticket, lane) * tku, uend = unit + tku; unit < a.nunits; ++unit, ({
              if (unit == uend) {
-                 unit = next_ticket(a.ticket, lane) * 4u;
-                 uend = unit + 4u;
+                 unit = next_ticket(a.ticket, lane) * tku;
+                 uend = unit + tku;
              }
          })) {
         const u64 r = (u64)unit * 64 + lane;

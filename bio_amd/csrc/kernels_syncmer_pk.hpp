@@ -477,10 +477,11 @@ __device__ __forceinline__ void synpk_body(const KArgs &a, char *lds) {
     u32 lcur = 0;
     const u32 wbuf = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(size_t)(ldsq + LY::WBUF));  // LDS byte addresses of the two buffers
     const u32 dbuf = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(size_t)(ldsq + LY::DBUF));
-    for (u32 unit = next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; unit < a.nunits; ++unit, ({
+    const u32 tku = a.tk ? a.tk : 8u;
+    for (u32 unit = next_ticket(a.ticket, lane) * tku, uend = unit + tku; unit < a.nunits; ++unit, ({
              if (unit == uend) {
-                 unit = next_ticket(a.ticket, lane) * 8u;
-                 uend = unit + 8u;
+                 unit = next_ticket(a.ticket, lane) * tku;
+                 uend = unit + tku;
              }
          })) {
         const u64 r = (u64)unit * 64 + lane;
