@@ -2239,10 +2239,11 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
     a.ring_w = pl.ring_w;
     a.len_mask = 0xffffffu;
     {  // units per ticket (KArgs::tk): the kernel's own while every wavefront of the grid gets a whole ticket, fewer below that
-        const u32 own = (pl.which == K_MIN_PKD) ? 4u : 8u;
+        const u32 own = (pl.which == K_MIN_PKD || pl.which == K_MIN_DENSE || pl.which == K_PROT_MIN_FAST) ? 4u : 8u;
         const u64 waves = (u64)std::max(pl.grid, 1);
         a.tk = 0;
-        if ((pl.which == K_MIN_PK || pl.which == K_MIN_PKD || pl.which == K_MIN_RING || pl.which == K_SYN_PK) && (u64)pl.nunits < waves * own)
+        if ((pl.which == K_MIN_PK || pl.which == K_MIN_PKD || pl.which == K_MIN_RING || pl.which == K_SYN_PK || pl.which == K_MIN_FAST || pl.which == K_MIN_DENSE || pl.which == K_SYN_FAST ||
+             pl.which == K_PROT_MIN_FAST) && (u64)pl.nunits < waves * own)
             a.tk = (u32)std::max<u64>(1, ((u64)pl.nunits + waves - 1) / waves);  // (rounded up: one ticket per wavefront -- rounded down, 10^6 reads were 2 232 tickets of seven units on 2 048 wavefronts)
     }
     if (cs && cs->masked) {  // class plan without a view: the kernel masks the other classes' reads itself (desc_len)

@@ -530,10 +530,11 @@ __global__ __launch_bounds__(64, (W >= 16 ? 2 : 1)) void k_minimizer_fast(KArgs 
     u32x4 pw_next = {0, 0, 0, 0};
     bool pre = false;
     // work distribution: a wave takes 8 consecutive units per ticket (one atomic per 512 reads)
-    for (u32 unit = next_ticket(a.ticket, lane) * 8u, uend = unit + 8u; unit < a.nunits; ++unit, ({
+    const u32 tku = a.tk ? a.tk : 8u;  // (KArgs::tk: fewer for small batches)
+    for (u32 unit = next_ticket(a.ticket, lane) * tku, uend = unit + tku; unit < a.nunits; ++unit, ({
              if (unit == uend) {
-                 unit = next_ticket(a.ticket, lane) * 8u;
-                 uend = unit + 8u;
+                 unit = next_ticket(a.ticket, lane) * tku;
+                 uend = unit + tku;
              }
          })) {
         const u64 r = (u64)unit * 64 + lane;
@@ -821,7 +822,7 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
     for (u32 sg = LIST ? blockIdx.x : 0u; sg < (LIST ? a.list_grid : 1u); sg += LIST ? gridDim.x : 1u) {
     const u32 nlist = LIST ? (a.rlist[sg] < lseg ? a.rlist[sg] : lseg) : 0u;
     const u32 *const mylist = LIST ? a.rlist + a.list_grid + sg * lseg : nullptr;
-    constexpr u32 TK = ASC ? 1u : 4u;  // units per ticket (the side launch's few units are latency: one per wavefront)
+    const u32 TK = ASC ? 1u : (a.tk ? a.tk : 4u);  // units per ticket (the side launch's few units are latency: one per wavefront; KArgs::tk: fewer for small batches)
     for (u32 unit = LIST ? 0u : next_ticket(a.ticket, lane) * TK, uend = unit + TK; LIST ? unit < (nlist + 63u) / 64u : unit < a.nunits; ++unit, ({
              if (!LIST && unit == uend) {
                  unit = next_ticket(a.ticket, lane) * TK;

@@ -239,10 +239,11 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
         __syncthreads();
     }
     const u64 slab_read = a.slab_read;  // tuples reserved per sequence
-    for (u32 unit = next_ticket(a.ticket, lane) * 4u, uend = unit + 4u; unit < a.nunits; ++unit, ({
+    const u32 tku = a.tk ? a.tk : 4u;  // (KArgs::tk: fewer for small batches)
+    for (u32 unit = next_ticket(a.ticket, lane) * tku, uend = unit + tku; unit < a.nunits; ++unit, ({
              if (unit == uend) {
-                 unit = next_ticket(a.ticket, lane) * 4u;
-                 uend = unit + 4u;
+                 unit = next_ticket(a.ticket, lane) * tku;
+                 uend = unit + tku;
              }
          })) {
         const u64 r = (u64)unit * 64 + lane;

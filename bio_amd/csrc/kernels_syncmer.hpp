@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64, (ASC ? 1 : 2)) void k_syncmer_fast(KArgs a) {  
     for (u32 sg = LIST ? blockIdx.x : 0u; sg < (LIST ? a.list_grid : 1u); sg += LIST ? gridDim.x : 1u) {
     const u32 nlist = LIST ? (flist[sg] < lseg ? flist[sg] : lseg) : 0u;
     const u32 *const rlist = LIST ? flist + a.list_grid + sg * lseg : nullptr;
-    constexpr u32 TK = ASC ? 1u : 8u;  // units per ticket (the side launch's few units are latency: one per wavefront)
+    const u32 TK = ASC ? 1u : (a.tk ? a.tk : 8u);  // units per ticket (the side launch's few units are latency: one per wavefront; KArgs::tk: fewer for small batches)
     for (u32 unit = LIST ? 0u : next_ticket(a.ticket, lane) * TK, uend = unit + TK; LIST ? unit < (nlist + 63u) / 64u : unit < a.nunits; ++unit, ({
              if (LIST) {
              } else if (unit == uend) {
