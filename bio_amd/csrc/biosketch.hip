@@ -2549,7 +2549,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         ctx->err = "bsk_sketch_timed: the result was not sized for this batch and these parameters: call bsk_sketch first";
         return cleanup(BSK_ERR_ARG);
     }
-    bool side_fell_back = false;
+    bool side_fell_back = false, ovf_grown = false;
     struct SideGuard {
         bsk_ctx *c;
         ~SideGuard() { c->no_side_fast = false; }
@@ -2586,7 +2586,19 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         const u64 total = ctx->h_pinned[0], ovf_used = ctx->h_pinned[1], side_end = ctx->h_pinned[2];
         const u32 ovf = ((u32 *)(ctx->h_pinned + 4))[1], side_ovf = ((u32 *)(ctx->h_pinned + 4))[3];
         res->n_tuples = total;
-        if (!ovf && !side_ovf) break;
+        if (ctx->opt.timing) fprintf(stderr, "[bsk] sizing attempt %d: overflow region %llu of %llu tuples used, flags %u / %u\n", attempt, (unsigned long long)ovf_used, (unsigned long long)res->ovf_cap, ovf, side_ovf);
+        if (!ovf && !side_ovf) {
+            // The overflow region's use varies from launch to launch by a few slabs (the list pass takes 64 slabs per wavefront and segment, and
+            // which workgroup lists which reads follows the tickets): a launch that fitted by less than a fifth is sized again with room to
+            // spare, or a timed re-run of the same plan overflows now and then (6 10^7 x 250 bases on k_minimizer_ring: 277.07-277.33 M tuples
+            // used of 277.21 M -- two of six bench runs failed).
+            if (pl.slab && res->ovf_cap && ovf_used * 5 > res->ovf_cap * 4 && !ovf_grown && attempt < 2) {
+                ovf_grown = true;
+                cap = pl.slab_total + ovf_used + ovf_used / 4 + 65536;
+                continue;
+            }
+            break;
+        }
         if (side_ovf && (pl.side_which == K_SYN_FAST_A || pl.side_which == K_MIN_DENSE_A) && !side_fell_back) {  // the staged side kernels' regions are sized up front: plan again with the general one
             ctx->no_side_fast = true;  // (for the rest of this call: side_guard)
             pl = Plan();
@@ -2666,7 +2678,12 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e == hipSuccess && (((u32 *)(ctx->h_pinned + 2))[1] | ((u32 *)(ctx->h_pinned + 2))[3])) {
             drop_events();
-            ctx->err = "result too small for this batch: call bsk_sketch first";
+            {
+                char msg[160];
+                snprintf(msg, sizeof msg, "result too small for this batch (overflow flags %u / side %u: 1 = a region or slab, 2 = a list segment): call bsk_sketch first",
+                         ((u32 *)(ctx->h_pinned + 2))[1], ((u32 *)(ctx->h_pinned + 2))[3]);
+                ctx->err = msg;
+            }
             return cleanup(BSK_ERR_ARG);
         }
         for (int i = 0; e == hipSuccess && kernel_ms && i < iters; ++i) e = hipEventElapsedTime(&kernel_ms[i], evs[2 * i], evs[2 * i + 1]);
