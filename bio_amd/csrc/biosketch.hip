@@ -1582,7 +1582,7 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
             }
             // syncmers likewise: k_syncmer_fast<W, false, true> (unit slabs of 28 tuples per read + an overflow region for the units with a
             // read beyond them, all inside the side region; 1 % of 150-base reads flagged: 603-621 against 827 Gbases/s clean)
-            if (p->kind == BSK_SYNCMER && sd.which == K_SYN_A && fast_syncmer_supported(p->k, p->s) && p->s != p->k && !p->circular && !b->adesc && b->aoff &&
+            if (p->kind == BSK_SYNCMER && sd.which == K_SYN_A && fast_syncmer_supported(p->k, p->s) && p->k - p->s <= 24 /* (k_syncmer_ascii.hip's list) */ && p->s != p->k && !p->circular && !b->adesc && b->aoff &&
                 std::max(b->maxlen, b->side_maxlen) < 32768u && !ctx->opt.force_generic && !ctx->opt.no_side_dense && !ctx->no_side_fast) {
                 const u64 units = (b->nsub + 63) / 64;
                 pl.side_which = K_SYN_FAST_A;

@@ -46,6 +46,9 @@ bool fast_syncmer_supported(int k, int s);
 int fast_syncmer_blocks_per_cu(int w);
 void fast_syncmer_launch(int w, int grid, hipStream_t stream, const KArgs &a);
 void fast_syncmer_ascii_launch(int w, int grid, hipStream_t stream, const KArgs &a);  // the ASCII side launch of a mixed batch
+bool fast_syncmer_wide_supported(int w);  // k - s = 25..32 (k_syncmer_wide.hip), reached through the three functions above
+int fast_syncmer_wide_blocks_per_cu(int w);
+void fast_syncmer_wide_launch(int w, int grid, hipStream_t stream, const KArgs &a);
 
 // packed window machine (kernels_syncmer_pk.hpp).  lng = false: k_syncmer_pk, three waves per SIMD, reads up to 224 bases in 23-row
 // columns; lng = true: k_syncmer_pkl, two waves per SIMD, reads up to 480 bases in 58-row columns, k - s up to 24

@@ -462,7 +462,7 @@ bool fast_syncmer_supported(int k, int s) {
         BSK_SYN_WS(X)
 #undef X
         return true;
-        default: return false;
+        default: return fast_syncmer_wide_supported(k - s);
     }
 }
 int fast_syncmer_blocks_per_cu(int w) {
@@ -473,7 +473,7 @@ int fast_syncmer_blocks_per_cu(int w) {
     case WW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_syncmer_fast<WW>, 64, 0); break;
         BSK_SYN_WS(X)
 #undef X
-        default: break;
+        default: return fast_syncmer_wide_blocks_per_cu(w);
     }
     if (e != hipSuccess || nb < 1) {
         (void)hipGetLastError();
@@ -487,11 +487,41 @@ void fast_syncmer_launch(int w, int grid, hipStream_t stream, const KArgs &a) {
     case WW: hipLaunchKernelGGL((k_syncmer_fast<WW>), dim3(grid), dim3(64), 0, stream, a); break;
         BSK_SYN_WS(X)
 #undef X
-        default: break;
+        default: fast_syncmer_wide_launch(w, grid, stream, a); break;
     }
 }
 
 #endif  // BSK_IMPL_SYNCMER
+#ifdef BSK_IMPL_SYNCMER_WIDE  // k_syncmer_wide.hip: k - s = 25..32 (round 5: the general kernel before, 25-106 Gbases/s at k=63 s=31), a
+                              // translation unit of their own; the block of W steps reads 32 codes, the pending mask has 32 bits: W <= 32
+#define BSK_SYN_WIDE_WS(X) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32)
+bool fast_syncmer_wide_supported(int w) { return w >= 25 && w <= 32; }
+int fast_syncmer_wide_blocks_per_cu(int w) {
+    int nb = 0;
+    hipError_t e = hipErrorInvalidValue;
+    switch (w) {
+#define X(WW) \
+    case WW: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_syncmer_fast<WW>, 64, 0); break;
+        BSK_SYN_WIDE_WS(X)
+#undef X
+        default: break;
+    }
+    if (e != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        nb = 1;
+    }
+    return nb;
+}
+void fast_syncmer_wide_launch(int w, int grid, hipStream_t stream, const KArgs &a) {
+    switch (w) {
+#define X(WW) \
+    case WW: hipLaunchKernelGGL((k_syncmer_fast<WW>), dim3(grid), dim3(64), 0, stream, a); break;
+        BSK_SYN_WIDE_WS(X)
+#undef X
+        default: break;
+    }
+}
+#endif  // BSK_IMPL_SYNCMER_WIDE
 #ifdef BSK_IMPL_SYNCMER_ASCII  // k_syncmer_ascii.hip: the ASCII side launch's instantiations, a translation unit of their own
 #ifndef BSK_SYN_WS
 #define BSK_SYN_WS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)

@@ -144,6 +144,31 @@ def test_syncmer_small_s_is_not_planned_on_the_packed_kernels(engine, oracle):
     b.close()
 
 
+@pytest.mark.parametrize("k,s", [(33, 8), (31, 5), (45, 16), (63, 32), (63, 31), (40, 8)])
+def test_syncmer_wide_windows_run_on_the_staged_kernel(engine, oracle, k, s):
+    """k - s = 25..32 (k_syncmer_wide.hip, round 5; the general per-lane kernel before): k_syncmer_fast<k - s>, read by read against the
+    closed form and the state machine -- short reads, reads of one letter, reads that overflow their staging columns included"""
+    rng = random.Random(97 * k + s)
+    seqs = [rand_seq(rng, rng.choice([150, 250, rng.randint(1, 900)])) for _ in range(900)] + ["A" * 300, "ACGT" * 80, rand_seq(rng, 2 * k - s), rand_seq(rng, 2 * k - s - 1), ""]
+    b = engine.batch(seqs)
+    res = engine.run(b, engine.params(L.SYNCMER, k, s=s))
+    assert "k_syncmer_fast<%d>" % (k - s) in res.plan()["kernel"], res.plan()
+    for i, q in enumerate(seqs):
+        st, h, p = res.read(i)
+        try:
+            eh, ep, es, fl = oracle.syncmer(q, k, s, False, closed=True)
+        except oracle.OracleError as err:
+            assert (st & L.ST_CODE_MASK) != 0 and len(h) == 0, (i, len(q), err.name)
+            continue
+        assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep) and np.array_equal(p >> 31, es), (k, s, i, len(q))
+        assert (st & 0xF0) == fl, (k, s, i, st, fl)
+        if i % 7 == 0:
+            mh, mp, _, _ = oracle.syncmer(q, k, s)  # the state machine
+            assert np.array_equal(h, mh) and np.array_equal(p & L.POS_MASK, mp), (k, s, i, len(q))
+    res.close()
+    b.close()
+
+
 def test_syncmer_long_plan_digest_equals_the_64_bit_kernels(engine):
     """Same batch through k_syncmer_pkl and (BSK_NO_SYN_LONG) k_syncmer_fast: identical digests and flag counts."""
     import os
