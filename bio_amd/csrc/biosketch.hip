@@ -2716,7 +2716,7 @@ static bool syn_long_plan_ok(const bsk_ctx *ctx, const bsk_params *p) {
 }
 
 // positions one tile owns: about 22 tuples per tile (the kernels stage 32 per lane; 16 for syncmers), a multiple of 16
-static u32 tile_positions(const bsk_ctx *ctx, const bsk_params *p, u64 n_bases) {
+static u32 tile_positions(const bsk_ctx *ctx, const bsk_params *p, u64 n_bases, u64 maxlen) {
     u32 tp;
     if (p->kind == BSK_MINIMIZER || p->kind == BSK_PROT_MINIMIZER) {
         tp = 16u * std::max<u32>(2, (u32)(22.0 * (p->w + 1.0) / 2.0 / 16.0));
@@ -2754,8 +2754,15 @@ static u32 tile_positions(const bsk_ctx *ctx, const bsk_params *p, u64 n_bases) 
         // s=11 tiles of 112 + 109 bases spend half of the kernel on overlaps, tiles of 224 + 109 a third (~21 expected selections
         // per tile: where the long plan's rate is still flat, scripts/dev/perf_syn_long.py)
         const int w = p->k - p->s;
-        const long long lt = std::min<long long>(480, 14LL * (w + 1) + 2LL * p->k - p->s - 2), over = 3LL * p->k + 16;
-        if (syn_long_plan_ok(ctx, p) && lt - over > (long long)tp) tp = (u32)(lt - over) & ~15u;
+        const long long lt = std::min<long long>(480, 14LL * (w + 1) + 2LL * p->k - p->s - 2), over = 3LL * p->k - 2LL * p->s + 12;  // (a tile's bases beyond its own positions: w - 1 idx before them, 2k - s - 1 after the last, up to 15 of alignment -- k_tile_desc)
+        if (syn_long_plan_ok(ctx, p) && lt - over > (long long)tp) {
+            tp = (u32)(lt - over) & ~15u;
+            // (the tightest tiles are the longest the plan's columns take; a batch whose longest read is two tiles either way runs 9 %
+            // faster on tiles one step shorter -- 420 bases at k=31 s=11: 581 on 224 + 147 positions, 528 on 256 + 115; 500 bases are 224 + 224 + 3
+            // there and 256 + 195 here: 420 -> 651 Gbases/s; 1 000 / 3 000 bases 504 / 534 -> 560 / 560: scripts/dev/run_synlen.sh)
+            const long long np = (long long)maxlen + p->s + 2 - 2LL * p->k;
+            if (tp >= 48u && np > (long long)tp && np <= 2LL * (tp - 32u)) tp -= 32u;
+        }
     }
     else tp = 256;
     tp = std::min<u32>(tp, 8192);
@@ -2784,7 +2791,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     geo.k = p->k;
     geo.w = p->kind == BSK_SYNCMER ? p->k - p->s : p->w;
     geo.s = p->s;
-    geo.tp = tile_positions(ctx, p, b->n_bases);
+    geo.tp = tile_positions(ctx, p, b->n_bases, b->maxlen);
     geo.circ_ext = circ_ext;
     geo.syn_all = syn_all ? 1 : 0;
     const bool stream = !kind_has_pos(p->kind);
