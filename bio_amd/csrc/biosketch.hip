@@ -2912,7 +2912,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
         if (rc != BSK_OK) return done(rc);
     }
     const u64 over = (p->kind == BSK_MINIMIZER || p->kind == BSK_PROT_MINIMIZER) ? 2ULL * p->w + p->k + 16
-                     : p->kind == BSK_SYNCMER                                     ? 3ULL * p->k + 16
+                     : p->kind == BSK_SYNCMER                                     ? 3ULL * p->k - 2ULL * p->s + 12  // (k_tile_desc: w - 1 idx before the tile's positions, 2k - s - 1 bases after the last, <= 15 of alignment; 3k + 16 kept tiles of k - s < 20 off the long packed plan once tile_positions sized them by the exact extent)
                                                                                   : (u64)p->k;
     tb->maxlen = (u32)std::min<u64>((u64)geo.tp + over, (u64)b->maxlen);
     tb->n_bases = nt * tb->maxlen;  // upper bound: sizes the first capacity guess
