@@ -107,7 +107,7 @@ def test_syncmer_long_packed_kernel(engine, oracle, k, s, lo, hi):
 
 
 def test_syncmer_mid_length_reads_run_as_tiles(engine, oracle):
-    """Reads beyond the packed syncmer kernels' reach (449+ bases) run as tiles of 224 + 3k + 16 bases on k_syncmer_pkl instead of on the
+    """Reads beyond the packed syncmer kernels' reach (449+ bases) run as tiles of 256 + 3k - 2s + 12 bases on k_syncmer_pkl instead of on the
     per-read 64-bit kernel (whose 28-tuple slabs overflow there): same tuples, every read against the closed form, every fourth
     against the state machine."""
     rng = random.Random(4490)
@@ -124,6 +124,25 @@ def test_syncmer_mid_length_reads_run_as_tiles(engine, oracle):
         if i % 4 == 0:
             mh, mp, _, _ = oracle.syncmer(q, 31, 11)
             assert np.array_equal(h, mh) and np.array_equal(p & L.POS_MASK, mp), (i, len(q))
+    res.close()
+    b.close()
+
+
+@pytest.mark.parametrize("k,s", [(21, 11), (25, 15), (31, 15), (64, 48), (15, 9)])
+def test_syncmer_tiles_stay_on_the_long_packed_plan(engine, oracle, k, s):
+    """Tiles are sized by the long packed plan's limit and the tile batch's length bound is the tile's exact extent (tp + 3k - 2s + 12):
+    with the looser 3k + 16 the planner put k=25 s=15 and k=64 s=48 back on k_syncmer_fast (round 5, scripts/dev/run_holes.sh).  Every read
+    against the closed form; reads of two tiles either way, of many tiles, of one letter."""
+    rng = random.Random(31 * k + s)
+    seqs = [rand_seq(rng, rng.choice((460, 700, 1000, 2500))) for _ in range(300)] + ["A" * 900, "ACG" * 400]
+    b = engine.batch(seqs)
+    res = engine.run(b, engine.params(L.SYNCMER, k, s=s))
+    assert "over tiles" in res.plan()["kernel"] and "k_syncmer_pkl<%d>" % (k - s) in res.plan()["kernel"], res.plan()
+    for i, q in enumerate(seqs):
+        st, h, p = res.read(i)
+        eh, ep, es, fl = oracle.syncmer(q, k, s, False, closed=True)
+        assert (st & L.ST_CODE_MASK) == L.ST_OK and np.array_equal(h, eh), (k, s, i, len(q))
+        assert np.array_equal(p & L.POS_MASK, ep) and np.array_equal(p >> 31, es), (k, s, i, len(q))
     res.close()
     b.close()
 
