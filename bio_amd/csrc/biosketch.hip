@@ -1545,7 +1545,10 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
     // reads with a non-ACGT letter (up to 90 %: the side launch costs flagged/60 against 1/690 Gbases/s for the fast kernel, so this wins
     // almost always): plan the batch as 2-bit; if that lands on a fast kernel, the flagged reads are
     // re-done by the general ASCII kernel in a side launch.  Otherwise the whole batch runs on the ASCII kernels.
-    if (has_n && b->subset && b->nsub * 10 <= b->n * 9 && !ctx->opt.no_mixed) {
+    // (round 5: with the flagged reads on a STAGED ASCII kernel -- K_MIN_DENSE_A / K_SYN_FAST_A below -- the pair wins at any share: a batch with
+    // an IUPAC letter in every read ran on the general ASCII kernel at 63 Gbases/s, scripts/dev/scan_plans.py)
+    const bool few_flagged = has_n && b->nsub * 10 <= b->n * 9;
+    if (has_n && b->subset && !ctx->opt.no_mixed) {
         Plan t;
         int rc = make_plan_enc(ctx, b, p, t, false);
         if (rc != BSK_OK) return rc;
@@ -1572,7 +1575,13 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
                 const u64 nwin_max = longest + 2 > (u32)(p->k + p->w) ? (u64)longest - p->k - p->w + 2 : 1;
                 const u64 slab = (nwin_max + 15) & ~(u64)15;
                 const u64 units = (b->nsub + 63) / 64;
-                if (units * 64 * slab * 12 <= (4ULL << 30)) {
+                u64 budget = 4ULL << 30;
+                if (units * 64 * slab * 12 > budget) {  // (many flagged reads: up to 24 GB of side region where the device has four times that free)
+                    size_t fr = 0, tot = 0;
+                    if (hipMemGetInfo(&fr, &tot) == hipSuccess && (u64)fr >= (96ULL << 30)) budget = 24ULL << 30;
+                    else (void)hipGetLastError();
+                }
+                if (units * 64 * slab * 12 <= budget) {
                     pl.side_which = K_MIN_DENSE_A;
                     pl.side_slab = slab;
                     pl.side_nunits = (u32)units;
@@ -1591,7 +1600,8 @@ static int make_plan(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan
                 pl.side_grid = (int)std::max<u64>(1, std::min<u64>(units, (u64)ctx->cus * 4));  // (a ticket is one unit)
                 pl.side_ring_w = 0;
             }
-            return BSK_OK;
+            if (few_flagged || pl.side_which == K_MIN_DENSE_A || pl.side_which == K_SYN_FAST_A) return BSK_OK;
+            pl = Plan();  // nearly every read flagged and only the general ASCII kernel to take them: one ASCII plan for the batch
         }
     }
     return make_plan_enc(ctx, b, p, pl, has_n);

@@ -481,10 +481,11 @@ def test_protein_constructors_on_dna_seq(engine, oracle):
         S.NewProteinIterator(seq, 9, 1, 0, engine)
 
 
-@pytest.mark.parametrize("frac", [0.01, 0.2, 0.6, 0.97])
+@pytest.mark.parametrize("frac", [0.01, 0.2, 0.6, 0.97, 1.0])
 def test_mixed_batches_fast_kernels_plus_ascii_side_launch(engine, oracle, frac):
     """A batch where a few reads carry N / IUPAC letters: the 2-bit fast kernels run over everything and the general ASCII
-    kernels re-do the flagged reads in a side launch (frac <= 0.9), otherwise the whole batch runs on the ASCII kernels.
+    kernels re-do the flagged reads in a side launch (frac <= 0.9, or any share where the side launch is a staged kernel: minimizers with
+    w <= 16, syncmers with k - s <= 24), otherwise the whole batch runs on the ASCII kernels.
     Either way every read must equal the oracle; BSK_NO_MIXED forces the second form for comparison of the digests."""
     import os
     rng = random.Random(int(frac * 1000))
