@@ -2361,7 +2361,9 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
             (void)hipGetLastError();
         }
     }
-    switch (pl.which) {
+    // every read of the batch is the side launch's (a non-ACGT letter in each): nothing of the main kernel's would be kept
+    const bool main_moot = side_early && !cs && b->nsub == b->n && (pl.side_which == K_MIN_DENSE_A || pl.side_which == K_SYN_FAST_A);
+    if (!main_moot) switch (pl.which) {
         case K_MIN_GEN_P: hipLaunchKernelGGL(k_minimizer_generic<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_MIN_GEN_A: hipLaunchKernelGGL(k_minimizer_generic<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_NT_P: hipLaunchKernelGGL(k_nthash_stream<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;

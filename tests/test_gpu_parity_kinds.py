@@ -527,6 +527,46 @@ def test_mixed_batches_fast_kernels_plus_ascii_side_launch(engine, oracle, frac)
         assert d1 == d2, (kind, pk)
 
 
+@pytest.mark.parametrize("n", [700, 40000])
+def test_a_non_acgt_letter_in_every_read(engine, oracle, n):
+    """Every read flagged: the mixed plan at any share where the side launch is a staged kernel (round 5; the general ASCII kernel over the
+    whole batch before), and the 2-bit kernel is not launched at all -- every reference word and status byte is the side launch's."""
+    rng = random.Random(n)
+    seqs = []
+    for i in range(n):
+        q = list(rand_seq(rng, rng.choice([150, 150, rng.randint(1, 300)])))  # (below the syncmers' tile threshold: tiles carry descriptors of their own and keep the general side kernel)
+        q[rng.randrange(len(q))] = rng.choice("NRYn")
+        seqs.append("".join(q))
+    b = engine.batch(seqs)
+    step = max(1, n // 1500)
+    for kind, pk, fn in ((L.MINIMIZER, dict(k=21, w=11), lambda q: oracle.minimizer(q, 21, 11, False, closed=True)),
+                         (L.SYNCMER, dict(k=31, s=11), lambda q: oracle.syncmer(q, 31, 11, False, closed=True))):
+        res = engine.run(b, engine.params(kind, **pk))
+        assert "ASCII side launch" in res.plan()["kernel"], res.plan()
+        for i in range(0, n, step):
+            q = seqs[i]
+            st, h, p = res.read(i)
+            try:
+                eh, ep, es, fl = fn(q)
+            except oracle.OracleError as e:
+                assert e.name == "ErrShortSeq" and (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0, (kind, i, e.name)
+                continue
+            assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep) and np.array_equal(p >> 31, es), (kind, i, q)
+            assert st & L.ST_HAS_NON_ACGT, (kind, i, st)
+        d1 = res.digest()
+        res.close()
+        os.environ["BSK_NO_MIXED"] = "1"  # the whole batch on the general ASCII kernel
+        try:
+            r2 = engine.run(b, engine.params(kind, **pk))
+            assert "side launch" not in r2.plan()["kernel"], r2.plan()
+            d2 = r2.digest()
+            r2.close()
+        finally:
+            del os.environ["BSK_NO_MIXED"]
+        assert d1 == d2, (kind, pk)
+    b.close()
+
+
 def test_protein_slab_overflow_falls_back_with_many_units(engine, oracle):
     """A low-complexity protein selects a new minimizer at every position and outgrows its slab of the register kernel: the
     call re-plans on the general kernel.  With more than 64 sequences that re-plan once kept the slab flags of the abandoned
