@@ -2769,11 +2769,16 @@ static u32 tile_positions(const bsk_ctx *ctx, const bsk_params *p, u64 n_bases, 
         const long long lt = std::min<long long>(480, 14LL * (w + 1) + 2LL * p->k - p->s - 2), over = 3LL * p->k - 2LL * p->s + 12;  // (a tile's bases beyond its own positions: w - 1 idx before them, 2k - s - 1 after the last, up to 15 of alignment -- k_tile_desc)
         if (syn_long_plan_ok(ctx, p) && lt - over > (long long)tp) {
             tp = (u32)(lt - over) & ~15u;
-            // (the tightest tiles are the longest the plan's columns take; a batch whose longest read is two tiles either way runs 9 %
-            // faster on tiles one step shorter -- 420 bases at k=31 s=11: 581 on 224 + 147 positions, 528 on 256 + 115; 500 bases are 224 + 224 + 3
-            // there and 256 + 195 here: 420 -> 651 Gbases/s; 1 000 / 3 000 bases 504 / 534 -> 560 / 560: scripts/dev/run_synlen.sh)
+            // (the tightest tiles are the longest the plan's columns take.  A wavefront runs 64 tiles in lock step, so the tiles of the batch's
+            // longest read are made equal: 700 bases at k=31 s=11 are 224 + 224 + 203 positions, not 256 + 256 + 139; 420 bases 192 + 179 --
+            // 224 + 147 ran 9 % faster than 256 + 115 there.  500 bases were 224 + 224 + 3 with the overlap priced at 3k + 16: 420 -> 650
+            // Gbases/s; 1 000 / 3 000 bases 504 / 534 -> 566 / 560: scripts/dev/run_synlen.sh)
             const long long np = (long long)maxlen + p->s + 2 - 2LL * p->k;
-            if (tp >= 48u && np > (long long)tp && np <= 2LL * (tp - 32u)) tp -= 32u;
+            if (np > (long long)tp) {
+                const long long nt = (np + tp - 1) / tp;
+                const u32 bal = (u32)(((np + nt - 1) / nt + 15) & ~15LL);
+                if (bal >= 32u && bal < tp) tp = bal;
+            }
         }
     }
     else tp = 256;
