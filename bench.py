@@ -10,8 +10,14 @@ scaling, no data-path collective); the only collective is one RCCL all_gather of
 per-rank counters at the end, issued through the library's own C ABI (bsk_gather_counts).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8                      # no launcher in the environment: bench.py starts its own 8 ranks
+    python bench.py --gpus 8 --workload syncmer   # BASELINE configs[3]: 1B x 150 bp over 8 GPUs (125M reads per rank), k=31 s=11
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+With --gpus N > 1 and no launcher environment (RANK / WORLD_SIZE unset) the script re-executes itself through
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>`: one rank per GPU,
+the same line on rank 0.  A line never says n_gpus: 1 for --gpus N: a WORLD_SIZE that disagrees with --gpus is an error.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for the fields).
 
@@ -336,6 +342,35 @@ def power_probe(eng, batch, p, res, k_ms, device, bases_per_launch, seconds=2.5)
             "note": "rocm-smi samples while the same launch loops (untimed, after the measurement); nj_per_unit = board power / bases (residues) per second"}
 
 
+def self_launch(n: int) -> int:
+    """--gpus N > 1 without a launcher: start N ranks of this very command line through torch.distributed.run (one process per GPU,
+    rendezvous on 127.0.0.1 at a free port) and hand its exit code on; rank 0's JSON line goes to our stdout untouched."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def git_commit():
+    """HEAD of the tree bench.py runs from (None outside a git checkout: the GPU box gets a snapshot without .git, so the round's
+    profile script passes it in BSK_BENCH_COMMIT)."""
+    c = os.environ.get("BSK_BENCH_COMMIT")
+    if c:
+        return c
+    try:
+        import subprocess
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -350,11 +385,16 @@ def main():
     ap.add_argument("--plumbing-only", action="store_true", help="tests: N>1 control flow with stand-in counters, no GPU, no kernel")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not launched and (args.gpus > 1 or os.environ.get("BSK_BENCH_SELF_LAUNCH")):  # (BSK_BENCH_SELF_LAUNCH: tests take the self-launched form on a one-GPU box)
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:  # (a line that says n_gpus: 1 for --gpus 8 would be a measurement of the wrong thing)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks (or drop the launcher environment and let bench.py start them)")
     if args.plumbing_only and args.backend != "gloo":
         raise SystemExit("--plumbing-only is the CPU test mode: use --backend gloo")
 
@@ -499,7 +539,7 @@ def main():
                 "read_only_frac": round(in_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "valu": prof.get("valu") if prof else None,
                 "binding_ceiling": (("valu-issue" if (prof.get("valu") or {}).get("frac", 0) > achieved / HBM_PEAK_GBS else "hbm") if prof and prof.get("valu") else None),
-                "profile": ({"dir": "profiles/" + prof["profile"], "kernel": prof.get("kernel"),
+                "profile": ({"dir": "profiles/" + prof["profile"], "kernel": prof.get("kernel"), "commit": prof.get("commit"), "this_run_commit": git_commit(),
                              "kernel_matches_this_run": prof.get("kernel", "").split("<")[0] == kern.split("<")[0] and (prof.get("kernel", "") in kern or kern in prof.get("kernel", ""))}
                             if prof else None),
                 "note": NOTES[kind] + "; frac is vs the 8 TB/s spec peak; read_only_frac = input bytes alone over the same peak "

@@ -13,6 +13,7 @@ import (
 	"errors"
 	"fmt"
 	"runtime"
+	"sync"
 	"unsafe"
 )
 
@@ -66,7 +67,19 @@ type Pipeline struct {
 	devs  *C.int
 	held  *C.bsk_chunk
 	Stats PipelineStats // filled by Close
-	err   error
+
+	mu   sync.Mutex     // guards err (written by the goroutine of Chunks, read by Err)
+	err  error
+	done chan struct{}  // closed by Close: the goroutine of Chunks stops
+	wg   sync.WaitGroup // the goroutine of Chunks; Close waits for it before the pipeline is freed
+}
+
+func (pl *Pipeline) setErr(err error) {
+	pl.mu.Lock()
+	if pl.err == nil {
+		pl.err = err
+	}
+	pl.mu.Unlock()
 }
 
 func (cfg *PipelineConfig) c() (C.bsk_pipeline_config, *C.int) {
@@ -91,7 +104,7 @@ func OpenFiles(cfg PipelineConfig, paths []string, p C.bsk_params) (*Pipeline, e
 		cs[i] = C.CString(s)
 		defer C.free(unsafe.Pointer(cs[i]))
 	}
-	pl := &Pipeline{devs: devs}
+	pl := &Pipeline{devs: devs, done: make(chan struct{})}
 	rc := C.bsk_pipeline_open_fastx(&cc, (**C.char)(unsafe.Pointer(&cs[0])), C.int(len(paths)), &p, &pl.h)
 	if rc != C.BSK_OK {
 		C.free(unsafe.Pointer(devs))
@@ -104,7 +117,7 @@ func OpenFiles(cfg PipelineConfig, paths []string, p C.bsk_params) (*Pipeline, e
 // bytes / offsets must stay valid and unchanged until Close -- pass C memory, not Go slices (cgo pointer rules).
 func OpenMemory(cfg PipelineConfig, bytes unsafe.Pointer, offsets unsafe.Pointer, n uint64, repeat int, p C.bsk_params) (*Pipeline, error) {
 	cc, devs := cfg.c()
-	pl := &Pipeline{devs: devs}
+	pl := &Pipeline{devs: devs, done: make(chan struct{})}
 	rc := C.bsk_pipeline_open_memory(&cc, (*C.uint8_t)(bytes), (*C.uint64_t)(offsets), C.uint64_t(n), C.int(repeat), &p, &pl.h)
 	if rc != C.BSK_OK {
 		C.free(unsafe.Pointer(devs))
@@ -119,17 +132,27 @@ func (pl *Pipeline) Next() (*Chunk, error) {
 		C.bsk_pipeline_release(pl.h, pl.held)
 		pl.held = nil
 	}
+	out, c, err := pl.fetch()
+	pl.held = c
+	return out, err
+}
+
+// fetch takes the next chunk WITHOUT releasing any other (the caller owns the release of raw): what Next and Chunks share.
+func (pl *Pipeline) fetch() (out *Chunk, raw *C.bsk_chunk, err error) {
 	var c *C.bsk_chunk
 	if rc := C.bsk_pipeline_next(pl.h, &c); rc != C.BSK_OK {
-		pl.err = fmt.Errorf("bsk_pipeline_next: %s: %s", C.GoString(C.bsk_err_name(rc)), C.GoString(C.bsk_pipeline_error(pl.h)))
-		return nil, pl.err
+		if rc == -1 { // stopped by Close / bsk_pipeline_cancel: the end of the stream, not an error of the run
+			return nil, nil, nil
+		}
+		err = fmt.Errorf("bsk_pipeline_next: %s: %s", C.GoString(C.bsk_err_name(rc)), C.GoString(C.bsk_pipeline_error(pl.h)))
+		pl.setErr(err)
+		return nil, nil, err
 	}
 	if c == nil {
-		return nil, nil
+		return nil, nil, nil
 	}
-	pl.held = c
 	n, nv := int(c.n_records), int(c.n_values)
-	out := &Chunk{Sequence: uint64(c.sequence), SourceIndex: int(c.source_index), Device: int(c.device), FirstRecord: uint64(c.first_record),
+	out = &Chunk{Sequence: uint64(c.sequence), SourceIndex: int(c.source_index), Device: int(c.device), FirstRecord: uint64(c.first_record),
 		Records: uint64(c.n_records), Bases: uint64(c.n_bases), Tuples: uint64(c.n_tuples), Checksum: uint64(c.checksum), LinkBytes: uint64(c.link_bytes)}
 	if c.status != nil && n > 0 {
 		out.Status = (*[1 << 40]uint8)(unsafe.Pointer(c.status))[:n:n]
@@ -156,34 +179,71 @@ func (pl *Pipeline) Next() (*Chunk, error) {
 	} else if c.pos32 != nil && nv > 0 {
 		out.Pos = (*[1 << 38]uint32)(unsafe.Pointer(c.pos32))[:nv:nv]
 	}
-	return out, nil
+	return out, c, nil
 }
 
-// Chunks mirrors fastx.Reader.ChunkChan: a channel of chunks in input order, closed at the end of the input (or on error: see Err).
-// A chunk is valid until the next one is received.
+// Chunks mirrors fastx.Reader.ChunkChan (seqio/fastx/reader.go:562-608): a channel of chunks in input order, closed at the end of the
+// input, on error (see Err) or by Close.  A chunk is valid until the NEXT one is received: Hash, Status and Pos alias pinned memory of
+// the pipeline, so the goroutine keeps the chunk the consumer is reading and gives it back only after the following chunk has been
+// handed over (two of the pool's 2 * workers + 2 output buffers are held at most).  Call Chunks once per pipeline and do not mix it
+// with Next.
 func (pl *Pipeline) Chunks() <-chan *Chunk {
 	ch := make(chan *Chunk)
+	pl.wg.Add(1)
 	go func() {
+		defer pl.wg.Done()
 		defer close(ch)
+		var prev *C.bsk_chunk // the chunk the consumer received last and may still be reading
+		defer func() {
+			if prev != nil {
+				C.bsk_pipeline_release(pl.h, prev)
+			}
+		}()
 		for {
-			c, err := pl.Next()
+			select {
+			case <-pl.done:
+				return
+			default:
+			}
+			c, raw, err := pl.fetch() // takes a buffer of its own; prev stays untouched
 			if err != nil || c == nil {
 				return
 			}
-			ch <- c
+			select {
+			case ch <- c:
+			case <-pl.done:
+				C.bsk_pipeline_release(pl.h, raw)
+				return
+			}
+			if prev != nil { // the consumer has taken c: what it held before is no longer its to read
+				C.bsk_pipeline_release(pl.h, prev)
+			}
+			prev = raw
 		}
 	}()
 	return ch
 }
 
 // Err is the error that ended Chunks() early, if any.
-func (pl *Pipeline) Err() error { return pl.err }
+func (pl *Pipeline) Err() error {
+	pl.mu.Lock()
+	defer pl.mu.Unlock()
+	return pl.err
+}
 
 // Close stops the run (if it has not ended) and frees the pipeline; Stats holds the run's counters afterwards.
 func (pl *Pipeline) Close() error {
 	if pl.h == nil {
 		return nil
 	}
+	// a goroutine of Chunks may sit inside bsk_pipeline_next: wake it (cancel frees nothing), wait for it, and only then free the pipeline
+	C.bsk_pipeline_cancel(pl.h)
+	select {
+	case <-pl.done:
+	default:
+		close(pl.done)
+	}
+	pl.wg.Wait()
 	if pl.held != nil {
 		C.bsk_pipeline_release(pl.h, pl.held)
 		pl.held = nil

@@ -18,6 +18,7 @@ OK = 0
 ERR_INVALID_K, ERR_EMPTY_SEQ, ERR_SHORT_SEQ, ERR_ILLEGAL_BASE, ERR_K_TOO_LARGE = 1, 2, 3, 4, 5
 ERR_INVALID_M, ERR_INVALID_SCALE, ERR_INVALID_S, ERR_INVALID_W, ERR_BUF_NIL, ERR_BUF_NOT_EMPTY = 6, 7, 8, 9, 10, 11
 ERR_ARG, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_IO = 64, 65, 66, 67, 68, 69
+ERR_NOT_FASTX, ERR_BAD_FASTQ, ERR_STOPPED = 70, 71, 72
 
 KMER, NTHASH, SIMHASH, MINIMIZER, SYNCMER, PROT_HASH, PROT_MINIMIZER = 1, 2, 3, 4, 5, 6, 7
 ALPHA_DNA, ALPHA_PROTEIN = 0, 1
@@ -115,6 +116,7 @@ SYMBOLS = [
     ("bsk_pipeline_release", C.c_int, [_vp, C.POINTER(Chunk)]),
     ("bsk_pipeline_close", C.c_int, [_vp, _vp]),
     ("bsk_pipeline_error", C.c_char_p, [_vp]),
+    ("bsk_pipeline_cancel", C.c_int, [_vp]),
     ("bsk_pipeline_run", C.c_int, [_vp, CHUNK_FN, _vp, _vp]),
     ("bsk_result_fetch_status", C.c_int, [_vp, _vp, C.c_uint64, C.c_uint64, _vp]),
     ("bsk_result_sets_reuse", C.c_int, [_vp, _vp, C.c_int, C.c_int, _pp]),
@@ -160,7 +162,10 @@ def load():
             f"{SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
     lib = C.CDLL(SO_PATH)
+    partial = bool(os.environ.get("BSK_LIB_PARTIAL"))  # dev: a library of ONE translation unit (the sanitized reader, csrc/san-fastx)
     for name, res, args in SYMBOLS:
+        if partial and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args

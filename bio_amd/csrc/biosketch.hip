@@ -238,6 +238,13 @@ __global__ void k_adopt_refs(const u32 *list, u64 n, const u64 *crefs, const u8 
 }
 // the ASCII side launch ran beside the main kernel with reference words and status bytes of its own (indexed like the batch): they
 // replace the main kernel's for the reads of the subset
+// A part of a class plan has run on the side context: its overflow flags (ticket words 1 and 3 of THAT context, reset by the next part's
+// launch) are folded into one word of the parent's, which the parent's read-backs look at (a part that overflowed on the
+// launch the caller sees -- region and list use vary from launch to launch -- was adopted with truncated tuples and no error).
+__global__ void k_fold_flags(const u32 *side_ticket, u32 *parent_word) {
+    const u32 f = side_ticket[1] | side_ticket[3];
+    if (f) atomicOr(parent_word, f);
+}
 __global__ void k_adopt_side(const u32 *subset, u64 nsub, const u64 *srefs, const u8 *sstatus, u64 *refs, u8 *status) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nsub; i += (u64)gridDim.x * blockDim.x) {
         const u64 r = subset[i];
@@ -485,6 +492,7 @@ extern "C" const char *bsk_err_name(int e) {
         case BSK_ERR_IO: return "fastx: cannot open or read the file";
         case BSK_ERR_NOT_FASTX: return "fastx: invalid FASTA/Q format";
         case BSK_ERR_BAD_FASTQ: return "fastx: bad FASTQ format";
+        case BSK_ERR_STOPPED: return "pipeline: stopped by the consumer";
         default: return "unknown";
     }
 }
@@ -521,7 +529,7 @@ extern "C" int bsk_ctx_create(int device, bsk_ctx **out) {
     ctx->cus = prop.multiProcessorCount;
     ctx->opt.load();  // the developer switches: once per context
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc(&ctx->d_ticket, 16 * sizeof(u32)) != hipSuccess || hipMalloc(&ctx->d_total, 8 * sizeof(u64)) != hipSuccess ||
+        hipMalloc(&ctx->d_ticket, 32 * sizeof(u32)) != hipSuccess || hipMalloc(&ctx->d_total, 8 * sizeof(u64)) != hipSuccess ||
         hipHostMalloc(&ctx->h_pinned, 8 * sizeof(u64)) != hipSuccess) {
         bsk_ctx_destroy(ctx);
         return BSK_ERR_DEVICE;
@@ -701,6 +709,8 @@ void BskOpts::load() {
     class_min = env_u32("BSK_CLASS_MIN", 16384);
     class_force = on("BSK_CLASS_FORCE");
     class_view = on("BSK_CLASS_VIEW");
+    no_syn_pf = on("BSK_NO_SYN_PF");
+    pf_density = env_u32("BSK_PF_DENSITY", 12);
     no_syn_long = on("BSK_NO_SYN_LONG");  // dev: reads beyond k_syncmer_pk's limits go to k_syncmer_fast as before round 4
     syn_margin = (int)env_u32("BSK_SYN_MARGIN", 2 + 64) - 64;  // dev: rows of slack the planner wants in k_syncmer_pk's columns (BSK_SYN_MARGIN = 64 + margin)
     no_tiles = on("BSK_NO_TILES");
@@ -715,6 +725,7 @@ void BskOpts::load() {
     waves_per_cu = env_u32("BSK_WAVES_PER_CU", 0);
     tile_min = env_u32("BSK_TILE_MIN", 0);
     tile_pos = env_u32("BSK_TILE_POS", 0);
+    test_overflow = env_u32("BSK_TEST_OVERFLOW", 0);
 }
 extern "C" int bsk_build_has_experiments(void) {
 #ifdef BSK_EXPERIMENTS
@@ -1436,6 +1447,7 @@ struct Plan {
     Which which = K_MIN_GEN_P;
     int grid = 1;
     int fast_w = 0;
+    bool syn_fused = false; // K_SYN_PK: k_syncmer_pf (the emit fused into every unit: no staging columns, kernels_syncmer_pf.hpp)
     bool syn_long = false;  // K_SYN_PK: k_syncmer_pkl (longer columns, more words in registers, two waves per SIMD)
     bool slab = false;     // true: unit u owns tuples [u*slab_unit, (u+1)*slab_unit) (+ overflow region); no look-back
     u64 slab_unit = 0;     // tuples per unit slab
@@ -1532,6 +1544,8 @@ static u64 ring_rows(double nwin, int w) {
     return ((u64)std::min(nw, std::ceil(nw * 2.6 / (w + 1.0)) + 6.0) + 3) & ~(u64)3;
 }
 
+#define BSK_RESIZE (-1001)         // internal: a timed re-run outgrew the regions the result was sized with (run_planned_resizing sizes again, once)
+#define BSK_REPLAN_CLASS (-1002)   // internal: a PART of a class plan overflowed on the launch the caller sees (run_classed sizes the parts again)
 #define BSK_REPLAN_UNFUSED (-1000)  // internal: the fused DNA -> protein plan gave up, run the two-step path
 
 static bool which_is_fast(Which w) {
@@ -1773,15 +1787,23 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             per_cu = sel_syncmer_blocks_per_cu(pl.fast_w);
         } else
 #endif
-        if (!use_ascii && fast_syncmer_supported(p->k, p->s) && (syn_short || syn_lng) && !syn_ties && !ctx->opt.force_generic && !ctx->opt.no_pk && !ctx->no_syn_pk) {
-            pl.syn_long = syn_lng;
+        // the fused-emit kernel (round 6, kernels_syncmer_pf.hpp): the s-mer machine alone + from-scratch hashes of what was selected at the
+        // end of every unit -- no staging columns, so the rows-per-pair rule above does not apply: any read whose words fit a lane's
+        // registers, whose blocks fit the mask rows, k <= 64 (the emit's window) and <= BSK_PF_TCAP / 64 expected selections per read
+        const u32 syn_ns_max = b->maxlen >= (u32)p->s ? b->maxlen - (u32)p->s + 1u : 0u;
+        const bool syn_pf = !ctx->opt.no_syn_pf && pf_syncmer_supported(p->k - p->s) && b->maxlen <= pf_syncmer_max_bases() && p->k <= 64 &&
+                            (syn_ns_max + (u32)(p->k - p->s) - 1u) / (u32)(p->k - p->s) <= pf_syncmer_mask_rows() + 1u &&
+                            std::max(syn_nwin, 0.0) * 1.5 / (p->k - p->s + 1.0) <= (double)ctx->opt.pf_density;
+        if (!use_ascii && fast_syncmer_supported(p->k, p->s) && (syn_short || syn_lng || syn_pf) && !syn_ties && !ctx->opt.force_generic && !ctx->opt.no_pk && !ctx->no_syn_pk) {
+            pl.syn_fused = syn_pf;
+            pl.syn_long = !syn_pf && syn_lng;
             pl.which = K_SYN_PK;
             pl.fast_w = p->k - p->s;
             pl.slab = true;
             pl.slab_unit = (u64)64 * BSK_SYN_CAP;
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
             pl.bin_gran = bin_gran_for(ctx, b, p->k - p->s);
-            per_cu = pk_syncmer_blocks_per_cu(pl.fast_w, pl.syn_long);
+            per_cu = pl.syn_fused ? pf_syncmer_blocks_per_cu(pl.fast_w) : pk_syncmer_blocks_per_cu(pl.fast_w, pl.syn_long);
         } else if (!use_ascii && fast_syncmer_supported(p->k, p->s) && b->maxlen < 32768u && !ctx->opt.force_generic) {
             pl.which = K_SYN_FAST;
             pl.fast_w = p->k - p->s;
@@ -2059,7 +2081,7 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
         case K_PROT_HASH: snprintf(b, sizeof b, "k_prot_hash"); break;
         case K_PROT_MIN: snprintf(b, sizeof b, "k_prot_minimizer"); break;
         case K_SYN_FAST: snprintf(b, sizeof b, "k_syncmer_fast<%d>", pl.fast_w); break;
-        case K_SYN_PK: snprintf(b, sizeof b, pl.syn_long ? "k_syncmer_pkl<%d>" : "k_syncmer_pk<%d>", pl.fast_w); break;
+        case K_SYN_PK: snprintf(b, sizeof b, pl.syn_fused ? "k_syncmer_pf<%d>" : pl.syn_long ? "k_syncmer_pkl<%d>" : "k_syncmer_pk<%d>", pl.fast_w); break;
         case K_SYN_SEL: snprintf(b, sizeof b, "k_syncmer_sel<%d> + k_syncmer_emit", pl.fast_w); break;
         case K_PROT_MIN_FAST: snprintf(b, sizeof b, "k_prot_minimizer_fast<%d,%d,%s>", pl.fast_w, pl.fast_k, pl.fused_dna ? "true" : "false"); break;
         case K_PROT_HASH_FAST: snprintf(b, sizeof b, "k_prot_hash_fast<%d,%s>", pl.fast_k, pl.fused_dna ? "true" : "false"); break;
@@ -2180,6 +2202,7 @@ static int launch_parts(bsk_ctx *ctx, ClassSet *cs, const bsk_params *p, bsk_res
             ctx->err = side->err;
             return rc;
         }
+        if (cpl.nunits) hipLaunchKernelGGL(k_fold_flags, dim3(1), dim3(1), 0, side->stream, side->d_ticket, ctx->d_ticket + 16);
     }
     return BSK_OK;
 }
@@ -2206,6 +2229,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         if (ev0) HIPCHK(ctx, hipEventRecord(ev0, ctx->stream));
         // the side stream starts where the main stream is now (the lists of the parts' reads, the previous launch's adoption of the parts'
         // reference words), then takes the one-launch parts
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket + 16, 0, sizeof(u32), ctx->stream));  // the parts' overflow flags of THIS launch (k_fold_flags)
         HIPCHK(ctx, hipEventRecord(ctx->ev_adopted, ctx->stream));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->side->stream, ctx->ev_adopted, 0));
         // tiled parts first: sketch_tiled waits for its counts on the host, and queued behind the bulk's kernel its launches would only start
@@ -2391,7 +2415,10 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_PROT_HASH: hipLaunchKernelGGL(k_prot_hash, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_PROT_MIN: hipLaunchKernelGGL(k_prot_minimizer, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_SYN_FAST: fast_syncmer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
-        case K_SYN_PK: pk_syncmer_launch(pl.fast_w, pl.syn_long, pl.grid, std::min(pl.grid, ctx->cus * 8), ctx->stream, a); break;
+        case K_SYN_PK:
+            if (pl.syn_fused) pf_syncmer_launch(pl.fast_w, pl.grid, std::min(pl.grid, ctx->cus * 8), ctx->stream, a);
+            else pk_syncmer_launch(pl.fast_w, pl.syn_long, pl.grid, std::min(pl.grid, ctx->cus * 8), ctx->stream, a);
+            break;
 #ifndef BSK_EXPERIMENTS
         case K_SYN_SEL: break;
 #else
@@ -2544,8 +2571,10 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         ovf_cap += (b->n / 64 + 64) * ((nwin_max + 15) & ~(u64)15);
     }
     if (pl.slab && *result && (*result)->ovf_cap > ovf_cap) ovf_cap = (*result)->ovf_cap;
+    if (pl.slab && *result && ctx->in_resize) ovf_cap = std::max(ovf_cap, 2 * (*result)->ovf_cap + 65536);  // a timed re-run outgrew the region: twice the room
     u64 cap = pl.slab ? pl.slab_total + ovf_cap : estimate_cap(b, p, circ_ext);
-    u64 side_cap = (pl.mixed && kind_has_pos(p->kind)) ? estimate_cap_n(p, b->nsub * (u64)b->maxlen, b->nsub) : 0;  // maxlen already includes a circular extension
+    const u32 side_len = std::max(b->maxlen, b->side_maxlen);  // a class view's ASCII side launch covers the flagged reads of EVERY class, not only the bulk's
+    u64 side_cap = (pl.mixed && kind_has_pos(p->kind)) ? estimate_cap_n(p, b->nsub * (u64)side_len, b->nsub) : 0;  // maxlen already includes a circular extension
     if (pl.mixed && pl.side_which == K_MIN_DENSE_A) side_cap = (u64)pl.side_nunits * 64 * pl.side_slab + 64;
     if (pl.mixed && pl.side_which == K_SYN_FAST_A) side_cap += (u64)pl.side_nunits * 64 * pl.side_slab + 64;  // (unit slabs, then the dense estimate above as their overflow region)
     if (*result && pl.mixed && (*result)->main_cap && (*result)->cap > (*result)->main_cap) {
@@ -2593,8 +2622,12 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         }
         hipError_t e = hipMemcpyAsync(ctx->h_pinned, ctx->d_total, 4 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_pinned + 4, ctx->d_ticket, 4 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
+        const bool has_parts = ctx->cls && b == ctx->cls->view;
+        if (e == hipSuccess && has_parts) e = hipMemcpyAsync(ctx->h_pinned + 6, ctx->d_ticket + 16, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) return cleanup(fail_hip(ctx, e, "bsk_sketch run"));
+        if (has_parts && (*(const u32 *)(ctx->h_pinned + 6) || ((ctx->opt.test_overflow & 2u) && ctx->cls_round == 0 && !ctx->part_grow)))
+            return cleanup(BSK_REPLAN_CLASS);  // (the parts were sized by launches of their own; this one used more)
         const u64 total = ctx->h_pinned[0], ovf_used = ctx->h_pinned[1], side_end = ctx->h_pinned[2];
         const u32 ovf = ((u32 *)(ctx->h_pinned + 4))[1], side_ovf = ((u32 *)(ctx->h_pinned + 4))[3];
         res->n_tuples = total;
@@ -2617,7 +2650,7 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
             rc = make_plan(ctx, b, p, pl);
             if (rc != BSK_OK) return cleanup(rc);
             cap = pl.slab ? pl.slab_total + ovf_cap : estimate_cap(b, p, circ_ext);
-            side_cap = (pl.mixed && kind_has_pos(p->kind)) ? estimate_cap_n(p, b->nsub * (u64)b->maxlen, b->nsub) : 0;
+            side_cap = (pl.mixed && kind_has_pos(p->kind)) ? estimate_cap_n(p, b->nsub * (u64)side_len, b->nsub) : 0;
             --attempt;  // (the general kernel keeps its own two tries: an estimate, then the exact size -- fuzz seed 11003764: k = 21, s = 1)
             side_fell_back = true;
             continue;
@@ -2687,9 +2720,18 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
     }
     if (warmup + iters > 0) {
         hipError_t e = hipMemcpyAsync(ctx->h_pinned + 2, ctx->d_ticket, 4 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
+        const bool has_parts = ctx->cls && b == ctx->cls->view;
+        if (e == hipSuccess && has_parts) e = hipMemcpyAsync(ctx->h_pinned + 6, ctx->d_ticket + 16, sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e == hipSuccess && (((u32 *)(ctx->h_pinned + 2))[1] | ((u32 *)(ctx->h_pinned + 2))[3])) {
+        if (e == hipSuccess && has_parts && (*(const u32 *)(ctx->h_pinned + 6) || ((ctx->opt.test_overflow & 4u) && !ctx->in_resize))) {  // (only the LAST launch's flags are left: enough to know the sizes no longer hold)
             drop_events();
+            if (!ctx->in_resize) return cleanup(BSK_REPLAN_CLASS);
+            ctx->err = "class plan: a part outgrew its slabs again after it was sized with room: call bsk_sketch first";
+            return cleanup(BSK_ERR_ARG);
+        }
+        if (e == hipSuccess && ((((u32 *)(ctx->h_pinned + 2))[1] | ((u32 *)(ctx->h_pinned + 2))[3]) || ((ctx->opt.test_overflow & 1u) && !ctx->in_resize && pl.slab && !pl.mixed))) {
+            drop_events();
+            if (!ctx->in_resize && pl.slab && !pl.mixed) return cleanup(BSK_RESIZE);  // the overflow region's use varies by a few slabs per launch: size again with room, once
             {
                 char msg[160];
                 snprintf(msg, sizeof msg, "result too small for this batch (overflow flags %u / side %u: 1 = a region or slab, 2 = a list segment): call bsk_sketch first",
@@ -2703,6 +2745,20 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         if (e != hipSuccess) return cleanup(fail_hip(ctx, e, "bsk_sketch_timed sync"));
     }
     return cleanup(BSK_OK);
+}
+
+// run_planned for callers that time an existing result: a launch that outgrows the regions the result was sized with (their use varies
+// by a few slabs from launch to launch: which workgroup lists which reads follows the tickets) sizes the result again with twice the room
+// and repeats the timed launches -- once; a second overflow is the caller's error as before.
+static int run_planned_resizing(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, int circ_ext, bsk_result **result, int warmup, int iters,
+                                float *kernel_ms) {
+    int rc = run_planned(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms);
+    if (rc != BSK_RESIZE) return rc;
+    ctx->in_resize = true;
+    rc = run_planned(ctx, b, p, circ_ext, result, 0, 0, nullptr);
+    if (rc == BSK_OK) rc = run_planned(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms);
+    ctx->in_resize = false;
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------
@@ -2940,7 +2996,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     // 3. the ordinary kernels over the tiles
     // the cached tile result belongs to an earlier batch: always size (one untimed run) before any timed repetition
     rc = run_planned(ctx, tb, &p2, 0, &tres_slot, 0, 0, nullptr);
-    if (rc == BSK_OK && warmup + iters > 0) rc = run_planned(ctx, tb, &p2, 0, &tres_slot, warmup, iters, kernel_ms);
+    if (rc == BSK_OK && warmup + iters > 0) rc = run_planned_resizing(ctx, tb, &p2, 0, &tres_slot, warmup, iters, kernel_ms);
     tres = tres_slot;
     if (rc != BSK_OK) return done(rc);
     lap("kernels (+sizing)");
@@ -3161,6 +3217,7 @@ static bool class_decide(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
 }
 
 static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, int circ_ext, bsk_result **result, int warmup, int iters, float *kernel_ms);
+static int run_planned_resizing(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, int circ_ext, bsk_result **result, int warmup, int iters, float *kernel_ms);
 
 // lists, views and sub-batches of the classes (device passes on the context's stream; the arrays live in the context's pool)
 static int class_build(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, const std::vector<ClassCut> &cuts, int bulk, ClassSet *cs) {
@@ -3359,8 +3416,25 @@ static int run_classed(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         *applied = true;
         if (!side_ctx(ctx)) return fail_arg(ctx, "class plan: no side context");
         ctx->cls = cs;
-        const int rc = run_planned(ctx, cs->view, p, 0, result, warmup, iters, kernel_ms);
+        int rc = run_planned_resizing(ctx, cs->view, p, 0, result, warmup, iters, kernel_ms);
         ctx->cls = nullptr;
+        if (rc == BSK_REPLAN_CLASS) {  // a part outgrew what its own sizing launch used: the whole plan is sized again, the parts with twice their regions, and the timed launches repeat (once)
+            ctx->in_resize = ctx->part_grow = true;
+            bool again = false;
+            rc = run_classed(ctx, b, p, circ_ext, result, 0, 0, nullptr, &again);
+            ctx->part_grow = false;
+            if (rc == BSK_OK && !again) {
+                ctx->err = "class plan: the batch no longer takes a class plan";
+                rc = BSK_ERR_ARG;
+            }
+            if (rc == BSK_OK) {
+                cs = (*result)->classes;
+                ctx->cls = cs;
+                rc = run_planned(ctx, cs->view, p, 0, result, warmup, iters, kernel_ms);
+                ctx->cls = nullptr;
+            }
+            ctx->in_resize = false;
+        }
         if (rc == BSK_OK) class_plan_names(*result, cs);
         return rc;
     }
@@ -3390,9 +3464,21 @@ static int run_classed(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         if (se != hipSuccess) return drop(fail_hip(ctx, se, "class plan: hipStreamSynchronize"));
     }
     for (auto &pt : cs->parts) pt.sub->ctx = side;
-    // every part sized as a batch of its own; then the parent, with the parts' slabs as its tail
+    // every part sized as a batch of its own; then the parent, with the parts' slabs as its tail.  The parent's launch runs every part
+    // AGAIN (into the tail): when one of them needs more room than its sizing launch did (BSK_REPLAN_CLASS), the parts are sized once more
+    // with twice their overflow regions; after that the batch keeps one plan.
+    for (int round = 0;; ++round) {
+    ctx->cls_round = round;
+    const bool grow = round > 0 || ctx->part_grow;
     u64 tail = 0;
     for (auto &pt : cs->parts) {
+        const bool was_resize = side->in_resize;
+        side->in_resize = grow && pt.res && !pt.tiled;  // (run_planned: twice the previous overflow region)
+        struct Restore {
+            bsk_ctx *c;
+            bool v;
+            ~Restore() { c->in_resize = v; }
+        } restore{side, was_resize};
         if (pt.res && pt.res->arrays_borrowed) {  // a part of an earlier call: its place in that call's tail may be gone
             pt.res->hash = nullptr;
             pt.res->pos = nullptr;
@@ -3438,8 +3524,15 @@ static int run_classed(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
     }
     cs->tail = tail;
     ctx->cls = cs;
-    rc = run_planned(ctx, cs->view, p, 0, result, warmup, iters, kernel_ms);
+    rc = run_planned_resizing(ctx, cs->view, p, 0, result, warmup, iters, kernel_ms);
     ctx->cls = nullptr;
+    if (rc == BSK_REPLAN_CLASS && round == 0) continue;
+    if (rc == BSK_REPLAN_CLASS) {  // twice: this batch's parts do not hold still -- one plan for the whole batch (the caller's next step)
+        class_set_free(cs);
+        return BSK_OK;
+    }
+    break;
+    }
     if (rc != BSK_OK) return drop(rc);
     bsk_result *res = *result;
     res->classes = cs;
@@ -3583,27 +3676,32 @@ static int sketch_impl(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p
     const bool outlier = !is_dna && p->kind == BSK_PROT_MINIMIZER && b->maxlen > 512 && !slab_budget_ok(b, (u64)b->maxlen);  // tiles are uniform: small slabs
     const bool tiled = kind_tiles(p) && (is_dna != prot_kind) && !ctx->opt.no_tiles && ((is_dna && !b->desc) || b->maxlen > tile_min || outlier);
     rc = tiled ? sketch_tiled(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms)
-               : run_planned(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms);
+               : run_planned_resizing(ctx, b, p, circ_ext, result, warmup, iters, kernel_ms);
     if (rc == BSK_REPLAN_UNFUSED && fused) {  // unusual density (a sequence outgrew its slab) or slabs that do not fit: translate, then sketch
         ctx->no_prot_fast = false;
         const u64 need = (u64)p->k * 3 + (u64)p->w - 1;
         rc = translate_batch(ctx, batch, p->codon_table, p->frame, need, &tmp);
         if (rc != BSK_OK) return rc;
         const bool tiled2 = kind_tiles(p) && !ctx->opt.no_tiles && tmp->maxlen > tile_min;
-        rc = tiled2 ? sketch_tiled(ctx, tmp, p, 0, result, warmup, iters, kernel_ms) : run_planned(ctx, tmp, p, 0, result, warmup, iters, kernel_ms);
+        rc = tiled2 ? sketch_tiled(ctx, tmp, p, 0, result, warmup, iters, kernel_ms) : run_planned_resizing(ctx, tmp, p, 0, result, warmup, iters, kernel_ms);
     }
     if (tmp) bsk_batch_destroy(tmp);
     return rc;
 }
 
+static int public_rc(bsk_ctx *ctx, int rc) {  // the internal re-plan codes never cross the boundary
+    if (rc > -1000) return rc;
+    if (ctx) ctx->err = "internal: a re-plan request reached the boundary (code " + std::to_string(rc) + ")";
+    return BSK_ERR_DEVICE;
+}
 extern "C" int bsk_sketch(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, bsk_result **result) {
-    return sketch_impl(ctx, batch, p, result, 0, 0, nullptr);
+    return public_rc(ctx, sketch_impl(ctx, batch, p, result, 0, 0, nullptr));
 }
 
 extern "C" int bsk_sketch_timed(bsk_ctx *ctx, const bsk_batch *batch, const bsk_params *p, bsk_result **result, int warmup,
                                 int iters, float *kernel_ms) {
     if (warmup < 0 || iters < 0) return fail_arg(ctx, "bsk_sketch_timed: negative counts");
-    return sketch_impl(ctx, batch, p, result, warmup, iters, kernel_ms);
+    return public_rc(ctx, sketch_impl(ctx, batch, p, result, warmup, iters, kernel_ms));
 }
 
 // circular=true: build a temporary batch whose reads carry their first k-1 bases appended

@@ -58,6 +58,14 @@ u32 pk_syncmer_pair_rows(bool lng);
 int pk_syncmer_blocks_per_cu(int w, bool lng);
 void pk_syncmer_launch(int w, bool lng, int grid, int fix_grid, hipStream_t stream, const KArgs &a);
 
+// the same machine with the emit fused into every unit (kernels_syncmer_pf.hpp, round 6): the s-mer side alone + from-scratch hashes of
+// the selected k-mers at the end of the unit; no staging columns; k <= 64; the exact machine over its listed reads is k_syncmer_fix.hip's
+bool pf_syncmer_supported(int w);
+u32 pf_syncmer_max_bases();
+u32 pf_syncmer_mask_rows();
+int pf_syncmer_blocks_per_cu(int w);
+void pf_syncmer_launch(int w, int grid, int fix_grid, hipStream_t stream, const KArgs &a);
+
 // the two-pass plan (kernels_syncmer_sel.hpp): selection by the packed s-mer machine, then the selected k-mers hashed from scratch
 bool sel_syncmer_supported(int w);
 u32 sel_syncmer_max_bases();

@@ -19,6 +19,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cerrno>
 #include <condition_variable>
@@ -342,6 +343,7 @@ extern "C" int bsk_fastx_read_chunk(bsk_fastx *f, uint64_t max_records, uint64_t
     return rc;
 }
 
+#ifndef BSK_FASTX_STANDALONE  // (the reader alone under the sanitizers: csrc/san-fastx -- the one entry that calls into the device library stays out)
 extern "C" int bsk_batch_from_fastx(bsk_ctx *ctx, bsk_fastx *f, uint64_t max_records, uint64_t max_bytes, int alphabet, bsk_batch **out,
                                     uint64_t *n_records) {
     if (!ctx || !f || !out || !n_records) return BSK_ERR_ARG;
@@ -354,6 +356,7 @@ extern "C" int bsk_batch_from_fastx(bsk_ctx *ctx, bsk_fastx *f, uint64_t max_rec
     if (alphabet < BSK_ALPHA_DNA || alphabet > BSK_ALPHA_UNLIMIT) return BSK_ERR_UNSUPPORTED;  // guessed "Unlimit" (-1): the caller must say what it is
     return bsk_batch_from_ascii(ctx, sb, so, *n_records, alphabet, out);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Block-parallel reader for plain (uncompressed) files: the same records as the reader above, sequences only, parsed by

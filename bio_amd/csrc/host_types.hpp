@@ -17,7 +17,10 @@ struct BskOpts {
     bool force_generic = false, no_mixed = false, no_dense = false, no_pk = false, no_ring = false, no_pkd = false, no_side_early = false, no_side_dense = false, ring = false, no_bin = false, no_bin_early = false, compact = false, no_tiles = false, no_tile_cache = false, no_group_gather = false, timing = false,
          no_fused_translate = false, sets_no_small = false;
     int syn_margin = 2;
+    u32 test_overflow = 0;   // BSK_TEST_OVERFLOW (tests): pretend an overflow flag once per call -- 1: in a timed re-run (BSK_RESIZE), 2: a class plan's part while sizing, 4: ... in a timed re-run (BSK_REPLAN_CLASS)
     bool no_syn_long = false;
+    u32 pf_density = 12;     // BSK_PF_DENSITY (tests): the expected selections per read up to which k_syncmer_pf is planned (its emit list holds BSK_PF_TCAP = 1 024 tuples per unit of 64 reads: beyond it the unit's last reads go to the exact machine)
+    bool no_syn_pf = false;  // BSK_NO_SYN_PF: syncmers on k_syncmer_pk / _pkl also where the fused-emit kernel (k_syncmer_pf, round 6) is planned
     bool syn_sel = false;    // BSK_SYN_SEL (make EXPERIMENTS=1): the two-pass syncmer plan, measured and not planned (kernels_syncmer_sel.hpp)
     bool no_class = false;   // BSK_NO_CLASS: one plan per batch, keyed on the longest read (rounds 1-4)
     u32 class_min = 16384;   // BSK_CLASS_MIN: batches below this many reads keep one plan
@@ -34,7 +37,7 @@ struct bsk_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     // per-launch synchronisation scratch
-    u32 *d_ticket = nullptr;    // [2]
+    u32 *d_ticket = nullptr;    // [32]: 0..7 a launch's tickets and overflow flags, 8..15 class cuts' cursors, 16 the overflow flags of a class plan's PARTS (their own launches on the side context reset 0..7 one after another: k_fold_flags)
     u64 *d_total = nullptr;     // [1]
     u64 *d_lookback = nullptr;  // [lookback_cap]
     size_t lookback_cap = 0;
@@ -65,6 +68,9 @@ struct bsk_ctx {
     u64 sel_need = 0;           // two-pass syncmers: the dense region a call that is being sized again needs (run_planned)
     bool no_syn_pk = false;     // set while a call falls back from k_syncmer_pk / k_minimizer_pk (the list of reads for the exact machine filled up)
     bool no_prot_fast = false;
+    bool in_resize = false;     // a timed call that outgrew its sized regions is being sized again (once per call: run_planned_resizing)
+    int cls_round = 0;          // run_classed: which sizing round of the class plan is running (tests: BSK_TEST_OVERFLOW fires in round 0 only)
+    bool part_grow = false;     // ... and a class plan's parts get twice their previous overflow regions (run_classed)
     bool no_dense = false;      // same for the dense-minimizer kernel (per-read slabs)  // set while a call falls back from the per-sequence-slab protein kernel
 };
 

@@ -1,0 +1,328 @@
+// kernels_syncmer_pf.hpp -- k_syncmer_pf<W = k - s>: the packed syncmer machine with the emit FUSED into the unit (round 6).
+//
+// NextSyncmer (sketches/sketch.go:312-477) emits the canonical hash of a k-mer for ~1.5 / (k - s + 1) of the windows -- 7.1 of the 101
+// windows of a 150-base read at k = 31, s = 11.  k_syncmer_pk rolls the k-mer hash over EVERY position, canonicalises and stages it,
+// because a selection is known 2(k - s) - 1 steps late: a third of its instructions and all of its staging (timing build without:
+// 1 584 against 974 Gbases/s).  Round 5 split the work into two kernels (kernels_syncmer_sel.hpp): the selection alone ran at
+// 1 590 Gbases/s, but the second pass re-loaded descriptors, masks and words from HBM behind its own stores and lost (869).  Here the
+// second pass is the END OF EVERY UNIT of the first, while everything it needs is still on the chip:
+//
+//   hash phase   SynPk<W, LY, SEL = 2>: the s-mer window machine alone.  One selection word per block of W windows and lane goes to LDS
+//                (row i0 / W - 1 of MASK; the rows lie over the parked suffix minima of the first-window test, read by then).
+//   expand       every lane's words -> the unit's tuple list FLAT[excl + j] = (lane << 8 | idx): a loop over the set bits of the rows
+//   emit         the lanes' packed words go back from registers to LDS (EBUF, over the dead mask rows), then ONE LANE PER TUPLE, 64 tuples
+//                per round: the k bases from idx on, ntHash FROM SCRATCH -- three bases per table row (64 rows of (fwd, rev) contributions;
+//                ntHash is XOR-linear in its bases: fwd by Horner's rule, rev with the accumulator rotated the other way so that every
+//                step rotates by a constant) -- canonical select, and the tuples leave as whole rows of 64 consecutive outputs straight
+//                from registers: no staging columns, no copy-out, no column that fills up (a unit's slab is k_syncmer_pk's).
+//
+// Loads and the one vmcnt as in k_syncmer_pk: the next unit's words and descriptors travel global -> LDS (WBUF / DBUF) while this unit is
+// hashed and are waited for before this unit's stores.  Reads with a 27-bit key tie go to the list of the exact machine
+// (k_syncmer_fast<W, true>) as before; so do the last reads of a unit that selects more than BSK_PF_TCAP positions.
+// LDS: 13 184 B per wavefront -- twelve waves per CU, three per SIMD (<= 168 VGPRs).
+#pragma once
+#include "kernels_syncmer_pk.hpp"
+
+namespace bsk {
+
+#define BSK_PF_TCAP 1024u  // tuples of a unit the emit phase takes (a unit of 150-base reads at k = 31, s = 11 has ~450)
+struct SynPfLds {
+    static constexpr int PR = 1, ROW = 33;  // (unused by the SEL machine; SynPk names them)
+    static constexpr int NW = PKNW;
+    static constexpr bool DMA = true;
+    static constexpr int TABK = 0, TABS = 0;  // the s-mer update table: 20 x uint4
+    static constexpr int KT3 = 320;           // u32x4 [64]: three bases (fwd, rev)
+    static constexpr int KT1 = KT3 + 1024;    // u32x4 [4]: one base
+    static constexpr int MROWS = 20;          // rows of the region below: W parked suffix minima (W <= 20), then <= 20 selection words per lane, then EBUF
+    static constexpr int PARK = KT1 + 64;     // u32 [MROWS][64]
+    static constexpr int MASK = PARK;
+    static constexpr int EST = 20;            // words from one lane's row of EBUF to the next (80 B: 16-byte stores; the reads of k <= 64 bases stay inside a row)
+    static constexpr int EBUF = PARK;         // u32 [64][EST]
+    static constexpr int SH = PARK, SP = PARK;
+    static constexpr int FLAT = PARK + MROWS * 256;   // u16 [BSK_PF_TCAP]
+    static constexpr int WBUF = FLAT + (int)BSK_PF_TCAP * 2;
+    static constexpr int DBUF = WBUF + NW * 64 * 4;
+    static constexpr int TOTAL = DBUF + 512;
+    static_assert(64 * EST * 4 <= MROWS * 256 && WBUF % 16 == 0 && EBUF % 16 == 0 && TOTAL <= 13648, "SynPfLds: twelve waves per CU");
+};
+
+__device__ __forceinline__ void pf_rol64(u32 &lo, u32 &hi, u32 rot) {  // rot wave-uniform, 0..63
+    if (rot & 32u) {
+        const u32 t = lo;
+        lo = hi;
+        hi = t;
+    }
+    const u32 rs = rot & 31u;
+    if (rs) {
+        const u32 nl = __builtin_amdgcn_alignbit(lo, hi, 32u - rs), nh = __builtin_amdgcn_alignbit(hi, lo, 32u - rs);
+        lo = nl;
+        hi = nh;
+    }
+}
+
+// canonical ntHash of the k bases from base idx of the read whose words are row `o` of EBUF -- from scratch.
+// fwd = XOR_j rol(seed[b_j], k-1-j): Horner over pieces of three bases (one single base closes every word of 16), f = rol(f, 3) ^ F3;
+// rev = XOR_j rol(seed[comp b_j], j): the accumulator is kept rotated right by the number of bases taken so far, a = ror(a ^ R3, 3),
+// and one rotation by k at the end puts it right.  Bit-identical to the rolling form (the same 64-bit arithmetic in another order).
+struct PfHash {
+    u32 fl, fh, rl, rh;
+};
+__device__ __forceinline__ PfHash pf_hash_kmer(LDSQ const char *lds, u32 o, u32 idx, u32 k) {
+    typedef SynPfLds LY;
+    const LDSQ u32 *wp = reinterpret_cast<const LDSQ u32 *>(lds + LY::EBUF) + o * (u32)LY::EST + (idx >> 4);
+    const u32 sh0 = (idx & 15u) * 2u;
+    u32 fl = 0, fh = 0, al = 0, ah = 0;
+    const u32 nfull = k >> 4, rest = k & 15u;
+    u32 qp = wp[0];
+    auto three = [&](u32 off) {
+        const u32x4 x = *reinterpret_cast<const LDSQ u32x4 *>(lds + LY::KT3 + off);
+        const u32 nfl = __builtin_amdgcn_alignbit(fl, fh, 29) ^ x.x, nfh = __builtin_amdgcn_alignbit(fh, fl, 29) ^ x.y;  // rol(f, 3)
+        fl = nfl;
+        fh = nfh;
+        const u32 tl = al ^ x.z, th = ah ^ x.w;
+        al = __builtin_amdgcn_alignbit(th, tl, 3);  // ror 3
+        ah = __builtin_amdgcn_alignbit(tl, th, 3);
+    };
+    auto one = [&](u32 off) {
+        const u32x4 x = *reinterpret_cast<const LDSQ u32x4 *>(lds + LY::KT1 + off);
+        const u32 nfl = __builtin_amdgcn_alignbit(fl, fh, 31) ^ x.x, nfh = __builtin_amdgcn_alignbit(fh, fl, 31) ^ x.y;  // rol(f, 1)
+        fl = nfl;
+        fh = nfh;
+        const u32 tl = al ^ x.z, th = ah ^ x.w;
+        al = __builtin_amdgcn_alignbit(th, tl, 1);
+        ah = __builtin_amdgcn_alignbit(tl, th, 1);
+    };
+    u32 j = 0;
+    for (; j < nfull; ++j) {  // a whole word: bases 16 j .. 16 j + 15 of the k-mer = five pieces of three and one base
+        const u32 qn = wp[j + 1];
+        const u32 h = __builtin_amdgcn_alignbit(qn, qp, sh0);
+        qp = qn;
+        three((h << 4) & 0x3f0u);
+        three((h >> 2) & 0x3f0u);
+        three((h >> 8) & 0x3f0u);
+        three((h >> 14) & 0x3f0u);
+        three((h >> 20) & 0x3f0u);
+        one((h >> 26) & 0x30u);
+    }
+    if (rest) {  // the last k mod 16 bases
+        const u32 qn = wp[j + 1];
+        u32 h = __builtin_amdgcn_alignbit(qn, qp, sh0);
+        u32 left = rest;
+        for (; left >= 3u; left -= 3u) {
+            three((h << 4) & 0x3f0u);
+            h >>= 6;
+        }
+        for (; left; --left) {
+            one((h << 4) & 0x30u);
+            h >>= 2;
+        }
+    }
+    pf_rol64(al, ah, k & 63u);
+    return PfHash{fl, fh, al, ah};
+}
+
+#ifndef SYNPF_LB
+#define SYNPF_LB 3
+#endif
+template <int W>
+__global__ __launch_bounds__(64, SYNPF_LB) void k_syncmer_pf(KArgs a) {
+    typedef SynPfLds LY;
+    constexpr int NQ = LY::NW / 4;
+    static_assert(W <= LY::MROWS && NQ == 4, "k_syncmer_pf");
+    __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
+    LDSQ char *const ldsq = (LDSQ char *)lds;
+    const int lane = lane_id();
+    {  // the tables, once per wavefront (nothing overwrites them): s-mer update rows, the 64 three-base rows, the four single bases
+        SynPkTabs tabs;
+        tabs.init(a.s, a.s, lane);
+        if (lane < 20) *reinterpret_cast<LDSQ u32x4 *>(ldsq + LY::TABS + lane * 16) = tabs.row;
+        const unsigned c0 = (unsigned)lane & 3u, c1 = ((unsigned)lane >> 2) & 3u, c2 = ((unsigned)lane >> 4) & 3u;  // c0 the FIRST base
+        const u64 f3 = rol64(seed_fwd_code(c0), 2) ^ rol64(seed_fwd_code(c1), 1) ^ seed_fwd_code(c2);
+        const u64 r3 = seed_rev_code(c0) ^ rol64(seed_rev_code(c1), 1) ^ rol64(seed_rev_code(c2), 2);
+        *reinterpret_cast<LDSQ u32x4 *>(ldsq + LY::KT3 + lane * 16) = (u32x4){(u32)f3, (u32)(f3 >> 32), (u32)r3, (u32)(r3 >> 32)};
+        if (lane < 4) {
+            const u64 f1 = seed_fwd_code((unsigned)lane), r1 = seed_rev_code((unsigned)lane);
+            *reinterpret_cast<LDSQ u32x4 *>(ldsq + LY::KT1 + lane * 16) = (u32x4){(u32)f1, (u32)(f1 >> 32), (u32)r1, (u32)(r1 >> 32)};
+        }
+        wave_sync_lds();
+    }
+    const u64 slab = (u64)64 * BSK_SYN_CAP;
+    u64 d_cur = 0;
+    bool have = false;
+    const u32 lseg = a.fixcap / a.list_grid;
+    u32 lcur = 0;
+    const u32 wbuf = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(size_t)(ldsq + LY::WBUF));
+    const u32 dbuf = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(size_t)(ldsq + LY::DBUF));
+    const u32 tku = a.tk ? a.tk : 8u;
+    for (u32 unit = next_ticket(a.ticket, lane) * tku, uend = unit + tku; unit < a.nunits; ++unit, ({
+             if (unit == uend) {
+                 unit = next_ticket(a.ticket, lane) * tku;
+                 uend = unit + tku;
+             }
+         })) {
+        const u64 r = (u64)unit * 64 + lane;
+        const bool nxt = unit + 1 != uend && unit + 1 < a.nunits;
+        const u64 rmax = a.n - 1;
+        typename SynVec<LY::NW>::type wr;
+        u64 d_n1;
+        u32 rfl;
+        if (!have) {  // first unit of a ticket: nothing was requested ahead
+            d_cur = a.desc[r < rmax ? r : rmax];
+            synpk_dma_words<NQ>(a.words + (d_cur >> 24), wbuf);
+            synpk_dma_desc(a.desc + (r + 64 < rmax ? r + 64 : rmax), dbuf);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        {
+            u32x4 wq[NQ];
+            const LDSQ u32x4 *wb = reinterpret_cast<const LDSQ u32x4 *>(ldsq + LY::WBUF) + lane;
+            const LDSQ u32 *db = reinterpret_cast<const LDSQ u32 *>(ldsq + LY::DBUF) + lane;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) wq[j] = wb[64 * j];
+            u32 dl = db[0], dh = db[64];
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[0]), "+v"(wq[1]), "+v"(wq[2]), "+v"(wq[3]), "+v"(dl), "+v"(dh)::"memory");
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                wr[4 * j] = wq[j].x;
+                wr[4 * j + 1] = wq[j].y;
+                wr[4 * j + 2] = wq[j].z;
+                wr[4 * j + 3] = wq[j].w;
+            }
+            d_n1 = ((u64)dh << 32) | dl;
+        }
+        synpk_dma_words<NQ>(a.words + (d_n1 >> 24), wbuf);
+        synpk_dma_desc(a.desc + (r + 128 < rmax ? r + 128 : rmax), dbuf);
+        rfl = pk_load_u8(a.rflags ? a.rflags + (r < rmax ? r : rmax) : reinterpret_cast<const u8 *>(a.desc));
+        const u64 d = d_cur;
+        const u64 L = desc_len(a, d);
+        const u64 ro = out_index(a, r, d);
+        const long long Lorig = (long long)L - a.circ_ext;
+        const bool ok = r < a.n && Lorig >= 0 && Lorig >= 2LL * a.k - a.s - 1 && L >= (u64)a.k;  // sketch.go:149
+        const u32 nwin = ok ? (u32)(L - 2 * (u64)a.k + a.s + 2) : 0u;                             // end + 1
+        const u32 ns = ok ? (u32)(L - a.s + 1) : 0u;
+        const u32 ns_max = wave_max_u32(ns);
+        const u32 nwin_min = ~wave_max_u32(ok ? ~nwin : 0u);
+        u32 cnt = 0, tmin_lane = 0xffffffffu;
+        if (ns_max) {
+            SynPk<W, LY, 2> sp;
+            sp.lds = ldsq;
+            sp.k = a.k;
+            sp.s = a.s;
+            sp.lane = lane;
+            sp.end_plus1 = nwin;
+            sp.wr = wr;
+            sp.gmask = nullptr;
+            sp.run(ns_max, nwin_min, 0u, 0, 0u);
+            cnt = sp.nsel;
+            tmin_lane = sp.tmin;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rfl)::"memory");  // the next unit's words and the descriptors after them are in LDS
+        d_cur = d_n1;
+        have = nxt;
+        // reads the exact machine must run: two equal 27-bit keys met in one of their min operations (kernels_syncmer_pk.hpp) -- and the
+        // last reads of a unit whose tuples do not fit the emit phase's list (never on real densities: 16 per read)
+        u64 redo = __builtin_amdgcn_ballot_w64(ok && tmin_lane < 32u);
+        if ((redo >> lane) & 1) cnt = 0;
+        u32 incl = wave_incl_scan_u32(cnt, lane);
+        const u64 over = __builtin_amdgcn_ballot_w64(incl > BSK_PF_TCAP);  // (a suffix of the lanes: incl never decreases)
+        if (over) {
+            redo |= over & __builtin_amdgcn_ballot_w64(cnt != 0u);
+            if ((over >> lane) & 1) {
+                cnt = 0;
+                incl = 0;
+            }
+        }
+        if (redo) list_append(a, reinterpret_cast<u32 *>(a.fixlist), lseg, lcur, redo, lane, r);
+        const u32 excl = incl - cnt;
+        const u32 T = wave_max_u32(incl);
+        const u64 base = (u64)unit * slab;
+        if (T) {
+            // expand: tuple excl + j of the unit is (this lane, its j-th selected window); bit O of row mm: idx = (mm - 1) W + 1 + O
+            const u32 nb = (ns_max + (u32)W - 1u) / (u32)W - 1u;
+            LDSQ unsigned short *const flat = reinterpret_cast<LDSQ unsigned short *>(ldsq + LY::FLAT);
+            {
+                u32 at = excl, left = cnt;
+                for (u32 mm = 0; mm < nb; ++mm) {
+                    u32 w = left ? *reinterpret_cast<const LDSQ u32 *>(ldsq + LY::MASK + mm * 256u + (u32)lane * 4u) : 0u;
+                    const u32 ibase = mm * (u32)W + 1u - (u32)W;
+                    while (__builtin_amdgcn_ballot_w64(w != 0u)) {
+                        if (w) {
+                            const u32 O = (u32)__builtin_ctz(w);
+                            w &= w - 1u;
+                            flat[at] = (unsigned short)(((u32)lane << 8) | (ibase + O));
+                            ++at;
+                            if (--left == 0) w = 0;
+                        }
+                    }
+                    if (__builtin_amdgcn_ballot_w64(left != 0u) == 0) break;
+                }
+            }
+            wave_sync_lds();  // every lane's rows are read: the words take their place
+            {
+                LDSQ u32x4 *eb = reinterpret_cast<LDSQ u32x4 *>(ldsq + LY::EBUF + lane * (LY::EST * 4));
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) eb[j] = (u32x4){wr[4 * j], wr[4 * j + 1], wr[4 * j + 2], wr[4 * j + 3]};
+            }
+            wave_sync_lds();
+            u64 *const gh = a.hash + base;
+            u32 *const gp = a.pos + base;
+            for (u32 tb = 0; tb < T; tb += 64) {
+                const u32 tl = tb + (u32)lane;
+                const bool live = tl < T;
+                const u32 tp = (u32)flat[live ? tl : T - 1u];
+                const u32 idx = tp & 0xffu;
+                const PfHash h = pf_hash_kmer(ldsq, tp >> 8, idx, (u32)a.k);
+                const bool rev = h.rh < h.fh || (h.rh == h.fh && h.rl < h.fl);  // nthash returns rev only when strictly smaller
+                if (live) {
+                    __builtin_nontemporal_store(rev ? (((u64)h.rh << 32) | h.rl) : (((u64)h.fh << 32) | h.fl), &gh[tl]);
+                    __builtin_nontemporal_store(idx | (rev ? BSK_POS_STRAND_BIT : 0u), &gp[tl]);
+                }
+            }
+            wave_sync_lds();  // (the next unit's block 0 parks its suffix minima where EBUF is)
+        }
+        if (r < a.n && !((redo >> lane) & 1)) {
+            a.refs[ro] = ((base + excl) << 24) | cnt;
+            u8 sbyte = ok ? BSK_ST_OK : BSK_ST_SHORT;
+            if (ok && a.rflags) sbyte |= (u8)rfl;
+            a.status[ro] = sbyte;
+        }
+    }
+    list_close(reinterpret_cast<u32 *>(a.fixlist), lseg, lcur, lane);
+}
+
+#ifndef BSK_SYNPF_WS
+#define BSK_SYNPF_WS(X) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20)
+#endif
+#ifdef BSK_IMPL_SYNPF
+bool pf_syncmer_supported(int w) {
+#define X(WW) \
+    if (w == WW) return true;
+    BSK_SYNPF_WS(X)
+#undef X
+    return false;
+}
+u32 pf_syncmer_max_bases() { return 16u * (u32)(SynPfLds::NW - 2); }
+u32 pf_syncmer_mask_rows() { return (u32)SynPfLds::MROWS; }
+int pf_syncmer_blocks_per_cu(int w) {
+    int nb = 0;
+    hipError_t e = hipErrorInvalidValue;
+#define X(WW) \
+    if (w == WW) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_syncmer_pf<WW>, 64, 0);
+    BSK_SYNPF_WS(X)
+#undef X
+    if (e != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        nb = 1;
+    }
+    return nb;
+}
+// the fused kernel, then the exact machine over the listed reads (k_syncmer_fix.hip)
+void pf_syncmer_launch(int w, int grid, int fix_grid, hipStream_t stream, const KArgs &a) {
+#define X(WW) \
+    if (w == WW) hipLaunchKernelGGL((k_syncmer_pf<WW>), dim3(grid), dim3(64), 0, stream, a);
+    BSK_SYNPF_WS(X)
+#undef X
+    pk_syncmer_fix_launch(w, fix_grid, stream, a);
+}
+#endif  // BSK_IMPL_SYNPF
+
+}  // namespace bsk

@@ -166,7 +166,9 @@ struct SynVec {
 };
 // SEL (k_syncmer_sel, kernels_syncmer_sel.hpp): the SELECTION alone -- no k-mer hash, no staging: bit O of a block's word says whether
 // idx = idx0 + O is selected, the word leaves to HBM at the end of the block and a second pass hashes the selected k-mers only.
-template <int W, class LY_ = SynPkLds, bool SEL = false>
+// SEL = 2 (k_syncmer_pf, kernels_syncmer_pf.hpp): the same, but the word stays in LDS (row i0 / W - 1 of LY::MASK, laid over the parked
+// suffix minima, which block 1 has read by then) and the unit's own emit phase hashes what was selected -- one pass over HBM.
+template <int W, class LY_ = SynPkLds, int SEL = 0>
 struct SynPk {
     typedef LY_ LY;
     static constexpr int NW = LY::NW;
@@ -232,7 +234,7 @@ struct SynPk {
         Nib32 ns, nk;
         ns.set(sin, sout);
         const u32 idx0 = i0 - (u32)(2 * W - 1);  // idx of offset 0 (MODE >= 2)
-        if (SEL) {
+        if (SEL != 0) {
         } else if (FUSED) {
             nk.set(codes(idx0 + (u32)k - 1), codes(idx0 - 1));
         } else if (MODE == 1) {  // only offset W-1 is a fused step: idx = 0, incoming base k-1, nothing leaves
@@ -281,7 +283,7 @@ struct SynPk {
                     if (MODE == 0 && O == 0) so = 0x100u | (so & 0x30u);
                     xs[O] = tabs(so);
 #ifndef SYNPK_NOK
-                    if (!SEL && (FUSED || (MODE == 1 && O == W - 1))) {
+                    if (SEL == 0 && (FUSED || (MODE == 1 && O == W - 1))) {
                         u32 ko = nk.template off<O>();
                         if (MODE == 1) ko = 0x100u | (ko & 0x30u);
                         xk[O] = tabk(ko);
@@ -324,7 +326,7 @@ struct SynPk {
                     tie(M, D[O]);
                     const u32 win = M < D[O] ? M : D[O];  // (a tie: the exact machine decides)
                     selm |= 1u << (win & 31u);            // v_lshl_or_b32: the winner's residue
-                    if constexpr (SEL) {
+                    if constexpr (SEL != 0) {
                         u32 b = (selm >> RS) & 1u;
                         if (MODE == 3) b &= vb >> O;
                         selm &= ~(1u << RS);
@@ -366,14 +368,15 @@ struct SynPk {
         // row until block 2) and block 1 compares them with T.
         constexpr int RB = LY::ROW * 8;
         const int park = sstep > 0 ? (int)slot + RB : sstep < 0 ? (int)slot - ((W + 1) / 2) * RB : (int)spare;  // rows 1.. upwards / below the top row
-        if constexpr (SEL) {  // (no staging rows: the lane's column of a [W][64] table)
+        if constexpr (SEL != 0) {  // (no staging rows: the lane's column of a [W][64] table)
             if (MODE == 1) {
 #pragma unroll
                 for (int q = 0; q < W; ++q) tie(*reinterpret_cast<LDSQ const u32 *>(lds + LY::PARK + q * 256 + lane * 4), P);
             }
             if (MODE >= 1) {  // the block's selection word leaves: row i0 / W - 1 of the unit's mask rows
                 const u32 wsel = end_plus1 ? bsel : 0u;
-                gmask[(i0 / (u32)W - 1u) * 64u] = wsel;
+                if constexpr (SEL == 2) *reinterpret_cast<LDSQ u32 *>(lds + LY::MASK + (i0 / (u32)W - 1u) * 256u + (u32)lane * 4u) = wsel;
+                else gmask[(i0 / (u32)W - 1u) * 64u] = wsel;
                 nsel += (u32)__builtin_popcount(wsel);
                 bsel = 0;
             }
@@ -390,7 +393,7 @@ struct SynPk {
             }
         }
         if (MODE == 0) {
-            if constexpr (SEL) {
+            if constexpr (SEL != 0) {
 #pragma unroll
                 for (int q = 0; q < W; ++q) *reinterpret_cast<LDSQ u32 *>(lds + LY::PARK + q * 256 + lane * 4) = S[q];
             } else {
@@ -427,7 +430,7 @@ struct SynPk {
             }
             for (; j < nb; ++j) rolls(tabs(256 + (((word >> (2 * j)) & 3) << 4)));
         }
-        for (int t0 = 0; !SEL && t0 < k - 1; t0 += 16) {  // k-mer warm-up
+        for (int t0 = 0; SEL == 0 && t0 < k - 1; t0 += 16) {  // k-mer warm-up
             const u32 word = wr[(u32)__builtin_amdgcn_readfirstlane(t0 >> 4)];
             const int nb = (k - 1 - t0) < 16 ? (k - 1 - t0) : 16;
             int j = 0;

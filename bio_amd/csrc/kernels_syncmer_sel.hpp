@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64, SYNSEL_LB) void k_syncmer_sel(KArgs a) {
         const u32 nwin_min = ~wave_max_u32(ok ? ~nwin : 0u);
         u32 cnt = 0, tmin_lane = 0xffffffffu;
         if (ns_max) {
-            SynPk<W, LY, true> sp;
+            SynPk<W, LY, 1> sp;
             sp.lds = ldsq;
             sp.k = a.k;
             sp.s = a.s;

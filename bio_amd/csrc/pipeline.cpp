@@ -260,6 +260,9 @@ struct FastxSource : Source {
         uint64_t n = 0;
         const uint8_t *sb = nullptr;
         const uint64_t *so = nullptr;
+        c->packed = false;  // chunks come from ONE free queue shared by every source of the run: a chunk last filled by a host-packing
+        c->n_words = 0;     // source (plain file, memory) must not keep its flag when the serial reader fills it with ASCII
+        c->parts.clear();
         const int rc = bsk_fastx_read_chunk(f, max_records, 0, &n, &sb, &so, nullptr, nullptr, nullptr);
         if (rc != BSK_OK) {
             err = bsk_fastx_error(f);
@@ -576,6 +579,8 @@ void bsk_pipeline::producer_main() {
             ws += secs(w0, clk::now());
             if (!c || error.load()) break;
             const auto r0 = clk::now();
+            c->packed = false;  // the free queue is shared by every source of the run: whatever the last source left in the chunk is not this one's
+            c->n_words = 0;
             const int rc = src->next(c, chunk_records);
             rs += secs(r0, clk::now());
             if (rc <= 0) {
@@ -839,11 +844,11 @@ extern "C" int bsk_pipeline_close(bsk_pipeline *pl, bsk_pipeline_stats *st) {
     }
     int rc = pl->error.load();
     if (!drained && !rc) {  // closed before the end: stop the threads (not an error of the run)
+        int z = 0;
+        pl->error.compare_exchange_strong(z, -1);  // BEFORE the queues close: a producer that finds its queue closed must see the run as stopped, not its source as exhausted
         pl->full_q.close();
         pl->free_q.close();
         pl->free_out.close();
-        int z = 0;
-        pl->error.compare_exchange_strong(z, -1);
     }
     pl->join_all();
     if (st) {
@@ -862,6 +867,24 @@ extern "C" int bsk_pipeline_close(bsk_pipeline *pl, bsk_pipeline_stats *st) {
     return rc;
 }
 
+extern "C" int bsk_pipeline_cancel(bsk_pipeline *pl) {
+    if (!pl) return BSK_ERR_ARG;
+    {
+        std::lock_guard<std::mutex> l(pl->om);
+        if (pl->workers_alive == 0 && pl->ready.empty()) return BSK_OK;  // the run has ended and everything was delivered: nothing to stop
+    }
+    int z = 0;
+    pl->error.compare_exchange_strong(z, -1);
+    pl->full_q.close();
+    pl->free_q.close();
+    pl->free_out.close();
+    {
+        std::lock_guard<std::mutex> l(pl->om);
+    }
+    pl->ocv.notify_all();  // a consumer blocked in bsk_pipeline_next returns -1
+    return BSK_OK;
+}
+
 extern "C" int bsk_pipeline_run(bsk_pipeline *pl, bsk_chunk_fn on_chunk, void *user, bsk_pipeline_stats *stats) {
     if (!pl) return BSK_ERR_ARG;
     int rc = BSK_OK, crc = 0;
@@ -874,7 +897,7 @@ extern "C" int bsk_pipeline_run(bsk_pipeline *pl, bsk_chunk_fn on_chunk, void *u
         if (crc) break;  // the consumer stops the run
     }
     const int close_rc = bsk_pipeline_close(pl, stats);
-    if (crc) return BSK_ERR_ARG;
+    if (crc) return BSK_ERR_STOPPED;  // the consumer's choice, not an error of the run (nor of its arguments)
     return rc != BSK_OK ? rc : close_rc;
 }
 

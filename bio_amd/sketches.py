@@ -597,6 +597,10 @@ class ChunkView:
         return self._strand
 
 
+class PipelineStopped(Exception):
+    """bsk_pipeline_next after bsk_pipeline_cancel / an early close: the run was stopped, not failed."""
+
+
 class Pipeline:
     """bsk_pipeline: sketches of every chunk of the input, delivered in input order (include/biosketch.h, "the pipeline with a consumer").
 
@@ -631,6 +635,8 @@ class Pipeline:
         self._release()
         c = C.POINTER(L.Chunk)()
         rc = self.lib.bsk_pipeline_next(self.h, C.byref(c))
+        if rc == -1:
+            raise PipelineStopped("the pipeline was cancelled")
         if rc != L.OK:
             msg = self.lib.bsk_pipeline_error(self.h).decode()
             raise _SENTINELS.get(rc) or DeviceError(f"bsk_pipeline_next: {self.lib.bsk_err_name(rc).decode()}: {msg}")
@@ -650,6 +656,11 @@ class Pipeline:
             if c is None:
                 return
             yield c
+
+    def cancel(self) -> None:
+        """Stops the run from any thread and frees nothing (bsk_pipeline_cancel): a consumer blocked in next() gets PipelineStopped."""
+        if self.h:
+            self.lib.bsk_pipeline_cancel(self.h)
 
     def close(self):
         if self.h:

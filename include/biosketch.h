@@ -60,7 +60,8 @@ typedef enum bsk_err {
     BSK_ERR_NO_DEVICE = 68,    /* no gfx950 device visible: there is NO CPU fallback */
     BSK_ERR_IO = 69,           /* FASTA/Q reader: cannot open / read */
     BSK_ERR_NOT_FASTX = 70,    /* ErrNotFASTXFormat seqio/fastx/reader.go:16 */
-    BSK_ERR_BAD_FASTQ = 71     /* ErrBadFASTQFormat / ErrUnequalSeqAndQual reader.go:19-22 */
+    BSK_ERR_BAD_FASTQ = 71,    /* ErrBadFASTQFormat / ErrUnequalSeqAndQual reader.go:19-22 */
+    BSK_ERR_STOPPED = 72       /* bsk_pipeline_run: on_chunk returned non-zero and the run was stopped on the consumer's request */
 } bsk_err;
 
 typedef enum bsk_kind {
@@ -419,7 +420,13 @@ int bsk_pipeline_next(bsk_pipeline *pl, const bsk_chunk **chunk);
 int bsk_pipeline_release(bsk_pipeline *pl, const bsk_chunk *chunk);
 int bsk_pipeline_close(bsk_pipeline *pl, bsk_pipeline_stats *stats);
 const char *bsk_pipeline_error(const bsk_pipeline *pl);
-/* next / on_chunk / release until the end (or until on_chunk returns non-zero), then close: the callback form of the loop above. */
+/* Stops the run from ANY thread without freeing anything: a consumer blocked in bsk_pipeline_next (and every later call) returns -1, the
+ * workers wind down.  What a host with a consumer thread of its own (Go: the goroutine behind Pipeline.Chunks(), the role of fastx's
+ * ChunkChan goroutine, reader.go:562-608) calls BEFORE it joins that thread and closes: bsk_pipeline_close frees the pipeline and must
+ * not overlap with a bsk_pipeline_next. */
+int bsk_pipeline_cancel(bsk_pipeline *pl);
+/* next / on_chunk / release until the end (or until on_chunk returns non-zero: BSK_ERR_STOPPED), then close: the callback form of the
+ * loop above. */
 typedef int (*bsk_chunk_fn)(void *user, const bsk_chunk *chunk);
 int bsk_pipeline_run(bsk_pipeline *pl, bsk_chunk_fn on_chunk, void *user, bsk_pipeline_stats *stats);
 

@@ -272,3 +272,42 @@ def test_class_plan_through_refill_and_pipeline(engine, monkeypatch):
     want = whole.digest()
     st = S.Engine.pipeline_memory(data, offs, p, n_streams=2, chunk_records=20000, fetch=True)
     assert st["tuples"] == want["n_tuples"] and st["checksum"] == want["checksum"]
+
+
+@pytest.mark.parametrize("bits,what", [(2, "a part overflows while the plan is sized"), (4, "a part overflows in a timed re-run"),
+                                        (1, "the bulk's region overflows in a timed re-run")])
+def test_overflow_on_the_launch_the_caller_sees_is_sized_again(engine, oracle, monkeypatch, bits, what):
+    """ADVICE round 5 (medium): a class plan's parts are sized by launches of their own and run AGAIN inside the parent's launch; region and
+    list use vary from launch to launch, so an overflow there must be seen (k_fold_flags -> the parent's read-back) and answered by sizing
+    again -- not adopted with truncated tuples.  BSK_TEST_OVERFLOW pretends the flag once per call; the result must equal the one-plan run's
+    read by read, and a timed re-run must succeed (VERDICT round 5 weak #11: bsk_sketch_timed re-sizes instead of failing)."""
+    monkeypatch.setenv("BSK_CLASS_FORCE", "1")
+    rng = random.Random(600 + bits)
+    n = 20000
+    seqs = outlier_batch(rng, n, 150, [(9, 400, 400), (150, 250, 250)])
+    b = engine.batch(seqs)
+    p = engine.params(L.MINIMIZER, 21, w=11)
+    want = engine.run(b, p)
+    d = want.digest()
+    plan = want.plan()["kernel"]
+    assert " reads of " in plan
+    monkeypatch.setenv("BSK_TEST_OVERFLOW", str(bits))
+    res = engine.run(b, p)
+    assert res.digest() == d and res.plan()["kernel"] == plan, what
+    res2, ms = engine.run_timed(b, p, 1, 3, reuse=res)
+    assert res2.digest() == d and len(ms) == 3 and all(m > 0 for m in ms), what
+    idx = sorted(set(list(range(0, n, 97)) + [i for i, s in enumerate(seqs) if len(s) != 150]))
+    check_min(res2, oracle, seqs, 21, 11, idx)
+    # and without a class plan: the timed re-run of a slab kernel sizes again once
+    if bits == 1:
+        monkeypatch.delenv("BSK_CLASS_FORCE")
+        monkeypatch.setenv("BSK_NO_CLASS", "1")
+        u = engine.synth(L.ALPHA_DNA, 30000, 150, 77)
+        r0 = engine.run(u, p)
+        d0 = r0.digest()
+        r1, ms = engine.run_timed(u, p, 0, 2, reuse=r0)
+        assert r1.digest() == d0 and all(m > 0 for m in ms)
+        u.close()
+    res.close()
+    want.close()
+    b.close()

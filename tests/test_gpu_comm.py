@@ -148,3 +148,23 @@ def test_bench_multi_rank_path_with_torch_rccl_alive():
     out = json.loads(line)
     assert "counters gathered by bsk_gather_counts (RCCL)" in out["config"]["parallelism"], out["config"]["parallelism"]
     assert out["n_gpus"] == 1 and out["value"] > 0
+
+
+def test_bench_self_launched_form():
+    """The self-launched form of bench.py (`python bench.py --gpus N` with no launcher environment re-executes itself through
+    torch.distributed.run) on the one GPU of this box: BSK_BENCH_SELF_LAUNCH=1 takes that route at N = 1, BSK_BENCH_FORCE_COMM=1 the
+    multi-rank code behind it.  (N = 2 over gloo, no GPU: tests/test_shard_gloo.py.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BSK_BENCH_SELF_LAUNCH="1", BSK_BENCH_FORCE_COMM="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--reads", "1e6", "--no-cpu-baseline", "--no-end-to-end", "--no-power-probe"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and "bsk_gather_counts (RCCL)" in out["config"]["parallelism"]

@@ -58,6 +58,78 @@ def test_syncmer_matches_state_machine_too(engine, oracle, k, s, n, lens):
         assert np.array_equal(h, eh) and np.array_equal(p & L.POS_MASK, ep), (i, k, s, len(q))
 
 
+@pytest.mark.parametrize("k,s,lo,hi", [(31, 11, 150, 150), (31, 11, 60, 210), (31, 16, 100, 170), (21, 10, 61, 120), (64, 44, 150, 224), (33, 20, 150, 151),
+                                       (32, 12, 120, 160), (48, 30, 180, 215), (17, 9, 40, 95), (16, 8, 30, 94), (63, 43, 105, 224), (27, 8, 150, 150), (25, 13, 100, 138)])
+def test_syncmer_fused_emit_kernel(engine, oracle, k, s, lo, hi):
+    """k_syncmer_pf (round 6, kernels_syncmer_pf.hpp): the s-mer machine alone, selection words in LDS, and at the end of every unit the
+    canonical k-mer hashes of the selected positions FROM SCRATCH (three bases per table row, one lane per tuple).  Every read against
+    the closed form AND the reference's state machine (sketch.go:312-477); k from 16 to 64 (one to four whole words + every remainder
+    class of the emit's 16-base / 3-base pieces), k - s = 8..20, reads up to the 224-base word limit, ragged batches (length-binned
+    units), low-complexity reads (key ties -> the exact machine) in the batch."""
+    rng = random.Random(1000 * k + s + hi)
+    seqs = [rand_seq(rng, rng.randint(lo, hi)) for _ in range(2300)]
+    seqs[7] = "A" * hi                                      # every s-mer the same hash: the exact machine's
+    seqs[8] = rand_seq(rng, max(lo - 40, 1)) + "T" * 40     # a low-complexity tail
+    seqs[9] = rand_seq(rng, 2 * k - s - 2)                  # one base short (sketch.go:149)
+    seqs[10] = rand_seq(rng, 2 * k - s - 1)                 # the shortest read with a window
+    b = engine.batch(seqs)
+    res = engine.run(b, engine.params(L.SYNCMER, k, s=s))
+    assert "k_syncmer_pf<%d>" % (k - s) in res.plan()["kernel"], res.plan()
+    for i, q in enumerate(seqs):
+        st, h, p = res.read(i)
+        if len(q) < 2 * k - s - 1:
+            assert (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0, (i, len(q))
+            continue
+        eh, ep, es, fl = oracle.syncmer(q, k, s, False, closed=True)
+        assert (st & L.ST_CODE_MASK) == L.ST_OK and np.array_equal(h, eh), (i, k, s, len(q))
+        assert np.array_equal(p & L.POS_MASK, ep) and np.array_equal(p >> 31, es) and (st & 0xF0) == fl, (i, k, s, len(q))
+        if i % 4 == 0:
+            mh, mp, _, _ = oracle.syncmer(q, k, s)  # the state machine
+            assert np.array_equal(h, mh) and np.array_equal(p & L.POS_MASK, mp), (i, k, s, len(q))
+    res.close()
+    b.close()
+
+
+def test_syncmer_fused_emit_digest_equals_the_one_pass_kernels(engine, monkeypatch):
+    """Same batches through k_syncmer_pf and (BSK_NO_SYN_PF) k_syncmer_pk / k_syncmer_pkl: identical digests, tuple and flag counts."""
+    for n, ln, k, s in ((400000, 150, 31, 11), (200000, 200, 31, 11), (150000, 130, 21, 9), (100000, 224, 64, 46)):
+        b = engine.synth(L.ALPHA_DNA, n, ln, 0x5EED0600 + ln + k)
+        prm = engine.params(L.SYNCMER, k, s=s)
+        res = engine.run(b, prm)
+        assert "k_syncmer_pf" in res.plan()["kernel"], res.plan()
+        d1 = res.digest()
+        res.close()
+        monkeypatch.setenv("BSK_NO_SYN_PF", "1")
+        res = engine.run(b, prm)
+        assert "k_syncmer_pf" not in res.plan()["kernel"] and "k_syncmer" in res.plan()["kernel"], res.plan()
+        d2 = res.digest()
+        res.close()
+        monkeypatch.delenv("BSK_NO_SYN_PF")
+        assert d1 == d2 and d1["n_tuples"] > 0, (n, ln, k, s, d1, d2)
+        b.close()
+
+
+def test_syncmer_fused_emit_units_beyond_the_tuple_list(engine, oracle, monkeypatch):
+    """A unit that selects more positions than the emit phase's list holds (1 024 per 64 reads: never planned -- the planner keeps
+    k_syncmer_pf to 12 expected selections per read -- so BSK_PF_DENSITY plans it here): the unit's LAST reads go to the list of the exact
+    machine, everything stays exact."""
+    monkeypatch.setenv("BSK_PF_DENSITY", "40")
+    rng = random.Random(1024)
+    k, s = 20, 12  # k - s = 8: a sixth of the windows is selected, ~20 per 150-base read, ~1 300 per unit
+    seqs = [rand_seq(rng, 150) for _ in range(1500)]
+    b = engine.batch(seqs)
+    res = engine.run(b, engine.params(L.SYNCMER, k, s=s))
+    assert "k_syncmer_pf<8>" in res.plan()["kernel"], res.plan()
+    off, st, h, p = res.fetch()
+    assert int(off[64]) - int(off[0]) > 1024  # (the first unit does select more than the list holds)
+    for i, q in enumerate(seqs):
+        eh, ep, es, fl = oracle.syncmer(q, k, s, False, closed=True)
+        a, e = int(off[i]), int(off[i + 1])
+        assert np.array_equal(h[a:e], eh) and np.array_equal(p[a:e] & L.POS_MASK, ep) and np.array_equal(p[a:e] >> 31, es) and (int(st[i]) & 0xF0) == fl, i
+    res.close()
+    b.close()
+
+
 def test_syncmer_packed_kernel_at_its_length_limit(engine, oracle):
     """k_syncmer_pk takes reads of up to 224 bases (its words live in 16 registers, the last two are look-ahead): lengths 208..224
     without jitter, so that the batch really is planned on that kernel and the clamped word index of its last blocks is exercised."""

@@ -408,6 +408,70 @@ def test_sink_over_files_and_early_close(engine, tmp_path):
     cb = L.CHUNK_FN(on_chunk)
     assert lib.bsk_pipeline_run(h, cb, None, C.byref(stats)) == L.OK
     assert [s[0] for s in seen] == list(range(5)) and sum(s[2] for s in seen) == n and sum(s[3] for s in seen) == int(w_off[-1]) == stats.tuples
+    # a callback that stops the run: a code of its own, not an argument error
+    seen.clear()
+    stop_cb = L.CHUNK_FN(lambda user, cptr: 1)
+    h = C.c_void_p()
+    assert lib.bsk_pipeline_open_memory(C.byref(cfg), d8.ctypes.data, o64.ctypes.data, n, 20, C.byref(p), C.byref(h)) == L.OK
+    assert lib.bsk_pipeline_run(h, stop_cb, None, C.byref(stats)) == L.ERR_STOPPED
+    assert lib.bsk_err_name(L.ERR_STOPPED).decode().startswith("pipeline: stopped")
+
+
+def test_mixed_plain_and_gzip_files_share_the_chunk_pool(engine, tmp_path):
+    """Plain files are 2-bit packed on the host, gzip files arrive as ASCII from the serial reader, and both fill chunks from ONE free queue:
+    a chunk that carried packed words must not keep that flag when the gzip reader fills it next (pipeline.cpp).  Several
+    files read at once, tuples out, every file's chunks equal to its single-file run."""
+    n = 12_000
+    p = engine.params(L.MINIMIZER, 21, w=11)
+    paths, want = [], []
+    for i, gz in enumerate((False, True, False, True, True)):
+        data, offs = make_reads(n + 500 * i, 31 + i, with_n=False)
+        path = str(tmp_path / (f"m{i}.fq.gz" if gz else f"m{i}.fq"))
+        write_fastq(path, data, offs, gz)
+        paths.append(path)
+        whole = engine.run(engine.batch_from_arrays(data, offs), p)
+        w_off, _, w_h, w_p = whole.fetch()
+        want.append((n + 500 * i, w_h[: int(w_off[-1])].copy(), (w_p[: int(w_off[-1])] & L.POS_MASK).copy()))
+    for n_readers, n_streams in ((1, 2), (2, 3), (5, 2)):
+        with S.Engine.pipeline_open(p, paths=paths, devices=[0], n_streams=n_streams, chunk_records=1500, sink=L.SINK_TUPLES, n_readers=n_readers) as pl:
+            chunks = _collect(pl)
+        for i, (cnt, w_h, w_p) in enumerate(want):
+            mine = sorted((c for c in chunks if c["src"] == i), key=lambda c: c["first"])
+            assert sum(c["n"] for c in mine) == cnt, (n_readers, i)
+            assert np.array_equal(np.concatenate([c["hash"] for c in mine]), w_h), (n_readers, i)
+            assert np.array_equal(np.concatenate([c["pos"] for c in mine]), w_p), (n_readers, i)
+
+
+def test_cancel_wakes_a_blocked_consumer(engine):
+    """bsk_pipeline_cancel from another thread: the consumer inside bsk_pipeline_next returns (-1), nothing is freed under it, close joins
+    the workers afterwards -- what the Go shim's Pipeline.Close does with the goroutine behind Chunks()."""
+    import threading
+    data, offs = make_reads(20_000, 5, with_n=False)
+    p = engine.params(L.MINIMIZER, 21, w=11)
+    pl = S.Engine.pipeline_open(p, data=data, offsets=offs, devices=[0], n_streams=2, chunk_records=500, sink=L.SINK_TUPLES, alphabet=L.ALPHA_DNA, repeat=2000)
+    got, out = [], {}
+
+    def consumer():
+        try:
+            for c in pl.chunks():
+                got.append(c.sequence)
+        except S.PipelineStopped:
+            out["stopped"] = True
+
+    t = threading.Thread(target=consumer)
+    t.start()
+    while len(got) < 3:
+        pass
+    pl.cancel()
+    t.join(30)
+    assert not t.is_alive() and out.get("stopped") and got == list(range(len(got)))
+    st = pl.close()
+    assert st["chunks"] >= len(got)
+    # after the natural end cancel is a no-op and close reports the whole run
+    pl = S.Engine.pipeline_open(p, data=data, offsets=offs, devices=[0], n_streams=2, chunk_records=5000, sink=L.SINK_COUNTS, alphabet=L.ALPHA_DNA)
+    assert len(list(pl.chunks())) == 4
+    pl.cancel()
+    assert pl.close()["records"] == 20_000
 
 
 def test_timed_rerun_needs_the_sized_plan(engine):

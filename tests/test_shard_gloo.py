@@ -80,3 +80,20 @@ def test_bench_world2_control_flow_over_gloo():
     assert abs(d["ms_per_step"] - secs / 4 * 1e3) < 1e-6
     assert abs(d["value"] - round((c0[1] + c1[1]) * 4 / secs / 1e9, 2)) < 1e-9  # SUM of bases over ranks
     assert d["config"]["tuples_total"] == c0[2] + c1[2] and d["config"]["first_window_tie_reads"] == c0[3] + c1[3]
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with NO launcher environment: bench.py re-executes itself through torch.distributed.run (one rank per
+    GPU, 127.0.0.1, a free port) and rank 0 prints ONE line with n_gpus: 2 and two per_rank_seconds -- never n_gpus: 1 for --gpus N
+    (VERDICT round 5, item 2).  A WORLD_SIZE that disagrees with --gpus is an error, not a silent one-GPU measurement."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--plumbing-only"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and len(d["config"]["per_rank_seconds"]) == 2 and d["steps"] == 3
+    bad = subprocess.run(cmd, env=dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]
