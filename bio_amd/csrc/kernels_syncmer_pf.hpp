@@ -25,25 +25,28 @@
 
 namespace bsk {
 
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+
 #define BSK_PF_TCAP 1024u  // tuples of a unit the emit phase takes (a unit of 150-base reads at k = 31, s = 11 has ~450)
 struct SynPfLds {
     static constexpr int PR = 1, ROW = 33;  // (unused by the SEL machine; SynPk names them)
     static constexpr int NW = PKNW;
     static constexpr bool DMA = true;
     static constexpr int TABK = 0, TABS = 0;  // the s-mer update table: 20 x uint4
-    static constexpr int KT3 = 320;           // u32x4 [64]: three bases (fwd, rev)
-    static constexpr int KT1 = KT3 + 1024;    // u32x4 [4]: one base
-    static constexpr int MROWS = 20;          // rows of the region below: W parked suffix minima (W <= 20), then <= 20 selection words per lane, then EBUF
+    static constexpr int KTA = 320;           // u32x4 [64]: three bases, first half of a piece of six: (rol(F3, 3), R3)
+    static constexpr int KT1 = KTA + 1024;    // u32x4 [4]: one base
+    static constexpr int MROWS = 20;          // rows of the region below: W parked suffix minima (W <= 20), then <= 20 selection words per lane, then EBUF + KTB
     static constexpr int PARK = KT1 + 64;     // u32 [MROWS][64]
     static constexpr int MASK = PARK;
-    static constexpr int EST = 20;            // words from one lane's row of EBUF to the next (80 B: 16-byte stores; the reads of k <= 64 bases stay inside a row)
-    static constexpr int EBUF = PARK;         // u32 [64][EST]
+    static constexpr int EST = 16;            // words from one lane's row of EBUF to the next (a window that runs over the row's end reads bits nobody uses)
+    static constexpr int EBUF = PARK;         // u32 [64][EST]: the unit's packed words, in the emit phase
+    static constexpr int KTB = EBUF + 64 * EST * 4;  // u32x4 [64]: second half of a piece of six: (F3, rol(R3, 3)) -- written at the start of every emit phase (the hash phase parks over it)
     static constexpr int SH = PARK, SP = PARK;
     static constexpr int FLAT = PARK + MROWS * 256;   // u16 [BSK_PF_TCAP]
     static constexpr int WBUF = FLAT + (int)BSK_PF_TCAP * 2;
     static constexpr int DBUF = WBUF + NW * 64 * 4;
     static constexpr int TOTAL = DBUF + 512;
-    static_assert(64 * EST * 4 <= MROWS * 256 && WBUF % 16 == 0 && EBUF % 16 == 0 && TOTAL <= 13648, "SynPfLds: twelve waves per CU");
+    static_assert(KTB + 1024 <= PARK + MROWS * 256 && WBUF % 16 == 0 && EBUF % 16 == 0 && TOTAL <= 13648, "SynPfLds: twelve waves per CU");
 };
 
 __device__ __forceinline__ void pf_rol64(u32 &lo, u32 &hi, u32 rot) {  // rot wave-uniform, 0..63
@@ -61,60 +64,90 @@ __device__ __forceinline__ void pf_rol64(u32 &lo, u32 &hi, u32 rot) {  // rot wa
 }
 
 // canonical ntHash of the k bases from base idx of the read whose words are row `o` of EBUF -- from scratch.
-// fwd = XOR_j rol(seed[b_j], k-1-j): Horner over pieces of three bases (one single base closes every word of 16), f = rol(f, 3) ^ F3;
-// rev = XOR_j rol(seed[comp b_j], j): the accumulator is kept rotated right by the number of bases taken so far, a = ror(a ^ R3, 3),
-// and one rotation by k at the end puts it right.  Bit-identical to the rolling form (the same 64-bit arithmetic in another order).
+// fwd = XOR_j rol(seed[b_j], k-1-j), rev = XOR_j rol(seed[comp b_j], j): XOR-linear in the bases, so any split of the k bases into
+// consecutive pieces works.  A piece of SIX bases is two table rows -- KTA[c0] = (rol(F3, 3), R3) and KTB[c1] = (F3, rol(R3, 3)), c = three
+// bases, 64 rows each -- and ONE rotation per strand: f = rol(f, 6) ^ A.f ^ B.f (Horner), and for rev the accumulator is kept rotated
+// right by the number of bases taken so far, a = ror(a ^ A.r ^ B.r, 6), one rotation by k at the end puts it right.  Thirty bases (five
+// sixes) come out of one 64-bit window of the read and their ten table reads are issued together; what is left of k (< 30 bases) goes
+// six / three / one base at a time.  Bit-identical to the rolling form (the same 64-bit arithmetic in another order).
 struct PfHash {
     u32 fl, fh, rl, rh;
 };
 __device__ __forceinline__ PfHash pf_hash_kmer(LDSQ const char *lds, u32 o, u32 idx, u32 k) {
     typedef SynPfLds LY;
-    const LDSQ u32 *wp = reinterpret_cast<const LDSQ u32 *>(lds + LY::EBUF) + o * (u32)LY::EST + (idx >> 4);
-    const u32 sh0 = (idx & 15u) * 2u;
+    const LDSQ u32 *const row = reinterpret_cast<const LDSQ u32 *>(lds + LY::EBUF) + o * (u32)LY::EST;
     u32 fl = 0, fh = 0, al = 0, ah = 0;
-    const u32 nfull = k >> 4, rest = k & 15u;
-    u32 qp = wp[0];
-    auto three = [&](u32 off) {
-        const u32x4 x = *reinterpret_cast<const LDSQ u32x4 *>(lds + LY::KT3 + off);
-        const u32 nfl = __builtin_amdgcn_alignbit(fl, fh, 29) ^ x.x, nfh = __builtin_amdgcn_alignbit(fh, fl, 29) ^ x.y;  // rol(f, 3)
+    auto rows_of = [&](u32 offa, u32 offb, u32x4 &xa, u32x4 &xb) {
+        xa = *reinterpret_cast<const LDSQ u32x4 *>(lds + LY::KTA + offa);
+        xb = *reinterpret_cast<const LDSQ u32x4 *>(lds + LY::KTB + offb);
+    };
+    auto six = [&](const u32x4 &xa, const u32x4 &xb) {
+        const u32 nfl = __builtin_amdgcn_alignbit(fl, fh, 26) ^ xa.x ^ xb.x, nfh = __builtin_amdgcn_alignbit(fh, fl, 26) ^ xa.y ^ xb.y;  // rol(f, 6)
         fl = nfl;
         fh = nfh;
-        const u32 tl = al ^ x.z, th = ah ^ x.w;
-        al = __builtin_amdgcn_alignbit(th, tl, 3);  // ror 3
-        ah = __builtin_amdgcn_alignbit(tl, th, 3);
+        const u32 tl = al ^ xa.z ^ xb.z, th = ah ^ xa.w ^ xb.w;
+        al = __builtin_amdgcn_alignbit(th, tl, 6);  // ror 6
+        ah = __builtin_amdgcn_alignbit(tl, th, 6);
     };
-    auto one = [&](u32 off) {
-        const u32x4 x = *reinterpret_cast<const LDSQ u32x4 *>(lds + LY::KT1 + off);
-        const u32 nfl = __builtin_amdgcn_alignbit(fl, fh, 31) ^ x.x, nfh = __builtin_amdgcn_alignbit(fh, fl, 31) ^ x.y;  // rol(f, 1)
-        fl = nfl;
-        fh = nfh;
-        const u32 tl = al ^ x.z, th = ah ^ x.w;
-        al = __builtin_amdgcn_alignbit(th, tl, 1);
-        ah = __builtin_amdgcn_alignbit(tl, th, 1);
+    auto window = [&](u32 base, u32 &h0, u32 &h1) {  // 32 bases from base position `base` of the read on
+        const LDSQ u32 *const wp = row + (base >> 4);
+        const u32 q0 = wp[0], q1 = wp[1], q2 = wp[2], sh = (base & 15u) * 2u;
+        h0 = __builtin_amdgcn_alignbit(q1, q0, sh);
+        h1 = __builtin_amdgcn_alignbit(q2, q1, sh);
     };
-    u32 j = 0;
-    for (; j < nfull; ++j) {  // a whole word: bases 16 j .. 16 j + 15 of the k-mer = five pieces of three and one base
-        const u32 qn = wp[j + 1];
-        const u32 h = __builtin_amdgcn_alignbit(qn, qp, sh0);
-        qp = qn;
-        three((h << 4) & 0x3f0u);
-        three((h >> 2) & 0x3f0u);
-        three((h >> 8) & 0x3f0u);
-        three((h >> 14) & 0x3f0u);
-        three((h >> 20) & 0x3f0u);
-        one((h >> 26) & 0x30u);
+    const u32 nseg = k / 30u;
+    u32 rem = k - 30u * nseg;
+    u32 h0 = 0, h1 = 0;
+    for (u32 sg = 0; sg < nseg; ++sg) {
+        window(idx + 30u * sg, h0, h1);
+        const u32 mid = __builtin_amdgcn_alignbit(h1, h0, 24);  // bases 12..27
+        u32x4 xa[5], xb[5];
+        rows_of((h0 << 4) & 0x3f0u, (h0 >> 2) & 0x3f0u, xa[0], xb[0]);
+        rows_of((h0 >> 8) & 0x3f0u, (h0 >> 14) & 0x3f0u, xa[1], xb[1]);
+        rows_of((mid << 4) & 0x3f0u, (mid >> 2) & 0x3f0u, xa[2], xb[2]);
+        rows_of((h1 >> 0) & 0x3f0u, (h1 >> 6) & 0x3f0u, xa[3], xb[3]);   // bases 18.. = bits 36..: h1 bits 4..
+        rows_of((h1 >> 12) & 0x3f0u, (h1 >> 18) & 0x3f0u, xa[4], xb[4]);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) six(xa[q], xb[q]);
     }
-    if (rest) {  // the last k mod 16 bases
-        const u32 qn = wp[j + 1];
-        u32 h = __builtin_amdgcn_alignbit(qn, qp, sh0);
-        u32 left = rest;
-        for (; left >= 3u; left -= 3u) {
-            three((h << 4) & 0x3f0u);
-            h >>= 6;
+    if (rem) {
+        u32 t0, t1;
+        if (nseg && rem <= 2u) {  // (the last window still holds them: bases 30, 31)
+            t0 = h1 >> 28;
+            t1 = 0;
+        } else {
+            window(idx + 30u * nseg, t0, t1);
         }
-        for (; left; --left) {
-            one((h << 4) & 0x30u);
-            h >>= 2;
+        for (; rem >= 6u; rem -= 6u) {
+            u32x4 xa, xb;
+            rows_of((t0 << 4) & 0x3f0u, (t0 >> 2) & 0x3f0u, xa, xb);
+            six(xa, xb);
+            t0 = __builtin_amdgcn_alignbit(t1, t0, 12);
+            t1 >>= 12;
+        }
+        if (rem >= 3u) {  // three bases: F3 is KTB's fwd half, R3 KTA's rev half
+            const u32 off = (t0 << 4) & 0x3f0u;
+            const u32x2 f3 = *reinterpret_cast<const LDSQ u32x2 *>(lds + LY::KTB + off);
+            const u32x2 r3 = *reinterpret_cast<const LDSQ u32x2 *>(lds + LY::KTA + off + 8u);
+            const u32 nfl = __builtin_amdgcn_alignbit(fl, fh, 29) ^ f3.x, nfh = __builtin_amdgcn_alignbit(fh, fl, 29) ^ f3.y;
+            fl = nfl;
+            fh = nfh;
+            const u32 tl = al ^ r3.x, th = ah ^ r3.y;
+            al = __builtin_amdgcn_alignbit(th, tl, 3);
+            ah = __builtin_amdgcn_alignbit(tl, th, 3);
+            t0 = __builtin_amdgcn_alignbit(t1, t0, 6);
+            t1 >>= 6;
+            rem -= 3u;
+        }
+        for (; rem; --rem) {
+            const u32x4 x = *reinterpret_cast<const LDSQ u32x4 *>(lds + LY::KT1 + ((t0 << 4) & 0x30u));
+            const u32 nfl = __builtin_amdgcn_alignbit(fl, fh, 31) ^ x.x, nfh = __builtin_amdgcn_alignbit(fh, fl, 31) ^ x.y;  // rol(f, 1)
+            fl = nfl;
+            fh = nfh;
+            const u32 tl = al ^ x.z, th = ah ^ x.w;
+            al = __builtin_amdgcn_alignbit(th, tl, 1);
+            ah = __builtin_amdgcn_alignbit(tl, th, 1);
+            t0 >>= 2;
         }
     }
     pf_rol64(al, ah, k & 63u);
@@ -132,14 +165,17 @@ __global__ __launch_bounds__(64, SYNPF_LB) void k_syncmer_pf(KArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
     LDSQ char *const ldsq = (LDSQ char *)lds;
     const int lane = lane_id();
-    {  // the tables, once per wavefront (nothing overwrites them): s-mer update rows, the 64 three-base rows, the four single bases
+    u32x4 ktb_row;  // this lane's row of KTB (kept in registers: the table's place is the hash phase's)
+    {  // the tables, once per wavefront (nothing overwrites them): s-mer update rows, the 64 three-base rows of KTA, the four single bases
         SynPkTabs tabs;
         tabs.init(a.s, a.s, lane);
         if (lane < 20) *reinterpret_cast<LDSQ u32x4 *>(ldsq + LY::TABS + lane * 16) = tabs.row;
         const unsigned c0 = (unsigned)lane & 3u, c1 = ((unsigned)lane >> 2) & 3u, c2 = ((unsigned)lane >> 4) & 3u;  // c0 the FIRST base
         const u64 f3 = rol64(seed_fwd_code(c0), 2) ^ rol64(seed_fwd_code(c1), 1) ^ seed_fwd_code(c2);
         const u64 r3 = seed_rev_code(c0) ^ rol64(seed_rev_code(c1), 1) ^ rol64(seed_rev_code(c2), 2);
-        *reinterpret_cast<LDSQ u32x4 *>(ldsq + LY::KT3 + lane * 16) = (u32x4){(u32)f3, (u32)(f3 >> 32), (u32)r3, (u32)(r3 >> 32)};
+        const u64 fa = rol64(f3, 3), rb = rol64(r3, 3);
+        *reinterpret_cast<LDSQ u32x4 *>(ldsq + LY::KTA + lane * 16) = (u32x4){(u32)fa, (u32)(fa >> 32), (u32)r3, (u32)(r3 >> 32)};
+        ktb_row = (u32x4){(u32)f3, (u32)(f3 >> 32), (u32)rb, (u32)(rb >> 32)};
         if (lane < 4) {
             const u64 f1 = seed_fwd_code((unsigned)lane), r1 = seed_rev_code((unsigned)lane);
             *reinterpret_cast<LDSQ u32x4 *>(ldsq + LY::KT1 + lane * 16) = (u32x4){(u32)f1, (u32)(f1 >> 32), (u32)r1, (u32)(r1 >> 32)};
@@ -235,7 +271,11 @@ __global__ __launch_bounds__(64, SYNPF_LB) void k_syncmer_pf(KArgs a) {
         const u32 excl = incl - cnt;
         const u32 T = wave_max_u32(incl);
         const u64 base = (u64)unit * slab;
+#ifdef SYNPF_NOEXPAND  // dev knock-outs (timing only): the hash phase alone / + expansion / + hashes without their stores
+        if (false) {
+#else
         if (T) {
+#endif
             // expand: tuple excl + j of the unit is (this lane, its j-th selected window); bit O of row mm: idx = (mm - 1) W + 1 + O
             const u32 nb = (ns_max + (u32)W - 1u) / (u32)W - 1u;
             LDSQ unsigned short *const flat = reinterpret_cast<LDSQ unsigned short *>(ldsq + LY::FLAT);
@@ -261,21 +301,30 @@ __global__ __launch_bounds__(64, SYNPF_LB) void k_syncmer_pf(KArgs a) {
                 LDSQ u32x4 *eb = reinterpret_cast<LDSQ u32x4 *>(ldsq + LY::EBUF + lane * (LY::EST * 4));
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) eb[j] = (u32x4){wr[4 * j], wr[4 * j + 1], wr[4 * j + 2], wr[4 * j + 3]};
+                *reinterpret_cast<LDSQ u32x4 *>(ldsq + LY::KTB + lane * 16) = ktb_row;
             }
             wave_sync_lds();
             u64 *const gh = a.hash + base;
             u32 *const gp = a.pos + base;
+#ifdef SYNPF_NOEMIT
+            for (u32 tb = 0; tb < 0; tb += 64) {
+#else
             for (u32 tb = 0; tb < T; tb += 64) {
+#endif
                 const u32 tl = tb + (u32)lane;
                 const bool live = tl < T;
                 const u32 tp = (u32)flat[live ? tl : T - 1u];
                 const u32 idx = tp & 0xffu;
                 const PfHash h = pf_hash_kmer(ldsq, tp >> 8, idx, (u32)a.k);
                 const bool rev = h.rh < h.fh || (h.rh == h.fh && h.rl < h.fl);  // nthash returns rev only when strictly smaller
+#ifdef SYNPF_NOSTORE
+                asm volatile("" ::"v"(h.rh), "v"(h.rl), "v"(h.fh), "v"(h.fl), "v"(rev), "v"(gh), "v"(gp));
+#else
                 if (live) {
                     __builtin_nontemporal_store(rev ? (((u64)h.rh << 32) | h.rl) : (((u64)h.fh << 32) | h.fl), &gh[tl]);
                     __builtin_nontemporal_store(idx | (rev ? BSK_POS_STRAND_BIT : 0u), &gp[tl]);
                 }
+#endif
             }
             wave_sync_lds();  // (the next unit's block 0 parks its suffix minima where EBUF is)
         }
