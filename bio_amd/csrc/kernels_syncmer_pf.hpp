@@ -73,7 +73,13 @@ __device__ __forceinline__ void pf_rol64(u32 &lo, u32 &hi, u32 rot) {  // rot wa
 struct PfHash {
     u32 fl, fh, rl, rh;
 };
-__device__ __forceinline__ PfHash pf_hash_kmer(LDSQ const char *lds, u32 o, u32 idx, u32 k) {
+__device__ __forceinline__ u32 pf_xor3(u32 a, u32 b, u32 c) {  // one full-rate v_bitop3_b32 (truth table 0x96 = parity) instead of two v_xor_b32
+    u32 r;
+    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// (q0, q1, q2: the three words of the read from word idx / 16 on -- the caller requests them a round ahead)
+__device__ __forceinline__ PfHash pf_hash_kmer(LDSQ const char *lds, u32 o, u32 idx, u32 k, u32 q0, u32 q1, u32 q2) {
     typedef SynPfLds LY;
     const LDSQ u32 *const row = reinterpret_cast<const LDSQ u32 *>(lds + LY::EBUF) + o * (u32)LY::EST;
     u32 fl = 0, fh = 0, al = 0, ah = 0;
@@ -82,10 +88,10 @@ __device__ __forceinline__ PfHash pf_hash_kmer(LDSQ const char *lds, u32 o, u32 
         xb = *reinterpret_cast<const LDSQ u32x4 *>(lds + LY::KTB + offb);
     };
     auto six = [&](const u32x4 &xa, const u32x4 &xb) {
-        const u32 nfl = __builtin_amdgcn_alignbit(fl, fh, 26) ^ xa.x ^ xb.x, nfh = __builtin_amdgcn_alignbit(fh, fl, 26) ^ xa.y ^ xb.y;  // rol(f, 6)
+        const u32 nfl = pf_xor3(__builtin_amdgcn_alignbit(fl, fh, 26), xa.x, xb.x), nfh = pf_xor3(__builtin_amdgcn_alignbit(fh, fl, 26), xa.y, xb.y);  // rol(f, 6)
         fl = nfl;
         fh = nfh;
-        const u32 tl = al ^ xa.z ^ xb.z, th = ah ^ xa.w ^ xb.w;
+        const u32 tl = pf_xor3(al, xa.z, xb.z), th = pf_xor3(ah, xa.w, xb.w);
         al = __builtin_amdgcn_alignbit(th, tl, 6);  // ror 6
         ah = __builtin_amdgcn_alignbit(tl, th, 6);
     };
@@ -98,8 +104,13 @@ __device__ __forceinline__ PfHash pf_hash_kmer(LDSQ const char *lds, u32 o, u32 
     const u32 nseg = k / 30u;
     u32 rem = k - 30u * nseg;
     u32 h0 = 0, h1 = 0;
+    {  // the first window: from the caller's words
+        const u32 sh = (idx & 15u) * 2u;
+        h0 = __builtin_amdgcn_alignbit(q1, q0, sh);
+        h1 = __builtin_amdgcn_alignbit(q2, q1, sh);
+    }
     for (u32 sg = 0; sg < nseg; ++sg) {
-        window(idx + 30u * sg, h0, h1);
+        if (sg) window(idx + 30u * sg, h0, h1);
         const u32 mid = __builtin_amdgcn_alignbit(h1, h0, 24);  // bases 12..27
         u32x4 xa[5], xb[5];
         rows_of((h0 << 4) & 0x3f0u, (h0 >> 2) & 0x3f0u, xa[0], xb[0]);
@@ -115,8 +126,11 @@ __device__ __forceinline__ PfHash pf_hash_kmer(LDSQ const char *lds, u32 o, u32 
         if (nseg && rem <= 2u) {  // (the last window still holds them: bases 30, 31)
             t0 = h1 >> 28;
             t1 = 0;
-        } else {
+        } else if (nseg) {
             window(idx + 30u * nseg, t0, t1);
+        } else {
+            t0 = h0;
+            t1 = h1;
         }
         for (; rem >= 6u; rem -= 6u) {
             u32x4 xa, xb;
@@ -280,20 +294,19 @@ __global__ __launch_bounds__(64, SYNPF_LB) void k_syncmer_pf(KArgs a) {
             const u32 nb = (ns_max + (u32)W - 1u) / (u32)W - 1u;
             LDSQ unsigned short *const flat = reinterpret_cast<LDSQ unsigned short *>(ldsq + LY::FLAT);
             {
-                u32 at = excl, left = cnt;
+                u32 at = ((u32)(size_t)flat) + excl * 2u;  // (byte address of this lane's next entry; the rows' bits are exactly its cnt selections: windows beyond a lane's end are masked in the hash phase)
+                const u32 tag = (u32)lane << 8;
                 for (u32 mm = 0; mm < nb; ++mm) {
-                    u32 w = left ? *reinterpret_cast<const LDSQ u32 *>(ldsq + LY::MASK + mm * 256u + (u32)lane * 4u) : 0u;
-                    const u32 ibase = mm * (u32)W + 1u - (u32)W;
+                    u32 w = cnt ? *reinterpret_cast<const LDSQ u32 *>(ldsq + LY::MASK + mm * 256u + (u32)lane * 4u) : 0u;
+                    const u32 val0 = tag + (mm * (u32)W + 1u - (u32)W);  // (+, not |: row 0 starts at idx 1 - W and only its last bit is ever set)
                     while (__builtin_amdgcn_ballot_w64(w != 0u)) {
                         if (w) {
                             const u32 O = (u32)__builtin_ctz(w);
                             w &= w - 1u;
-                            flat[at] = (unsigned short)(((u32)lane << 8) | (ibase + O));
-                            ++at;
-                            if (--left == 0) w = 0;
+                            *reinterpret_cast<LDSQ unsigned short *>(at) = (unsigned short)(val0 + O);
+                            at += 2u;
                         }
                     }
-                    if (__builtin_amdgcn_ballot_w64(left != 0u) == 0) break;
                 }
             }
             wave_sync_lds();  // every lane's rows are read: the words take their place
@@ -306,6 +319,17 @@ __global__ __launch_bounds__(64, SYNPF_LB) void k_syncmer_pf(KArgs a) {
             wave_sync_lds();
             u64 *const gh = a.hash + base;
             u32 *const gp = a.pos + base;
+            // one lane per tuple, 64 per round; the round's list entry and the three words of its read are requested a round ahead
+            auto request = [&](u32 tb, u32 &tp, u32 &q0, u32 &q1, u32 &q2) {
+                const u32 tl = tb + (u32)lane;
+                tp = (u32)flat[tl < T ? tl : T - 1u];
+                const LDSQ u32 *const wp = reinterpret_cast<const LDSQ u32 *>(ldsq + LY::EBUF) + (tp >> 8) * (u32)LY::EST + ((tp & 0xffu) >> 4);
+                q0 = wp[0];
+                q1 = wp[1];
+                q2 = wp[2];
+            };
+            u32 tp, q0, q1, q2;
+            request(0u, tp, q0, q1, q2);
 #ifdef SYNPF_NOEMIT
             for (u32 tb = 0; tb < 0; tb += 64) {
 #else
@@ -313,9 +337,9 @@ __global__ __launch_bounds__(64, SYNPF_LB) void k_syncmer_pf(KArgs a) {
 #endif
                 const u32 tl = tb + (u32)lane;
                 const bool live = tl < T;
-                const u32 tp = (u32)flat[live ? tl : T - 1u];
-                const u32 idx = tp & 0xffu;
-                const PfHash h = pf_hash_kmer(ldsq, tp >> 8, idx, (u32)a.k);
+                const u32 idx = tp & 0xffu, o = tp >> 8, c0 = q0, c1 = q1, c2 = q2;
+                if (tb + 64u < T) request(tb + 64u, tp, q0, q1, q2);
+                const PfHash h = pf_hash_kmer(ldsq, o, idx, (u32)a.k, c0, c1, c2);
                 const bool rev = h.rh < h.fh || (h.rh == h.fh && h.rl < h.fl);  // nthash returns rev only when strictly smaller
 #ifdef SYNPF_NOSTORE
                 asm volatile("" ::"v"(h.rh), "v"(h.rl), "v"(h.fh), "v"(h.fl), "v"(rev), "v"(gh), "v"(gp));
