@@ -710,7 +710,7 @@ void BskOpts::load() {
     class_force = on("BSK_CLASS_FORCE");
     class_view = on("BSK_CLASS_VIEW");
     no_syn_pf = on("BSK_NO_SYN_PF");
-    pf_density = env_u32("BSK_PF_DENSITY", 12);
+    pf_density = env_u32("BSK_PF_DENSITY", 0);
     no_syn_long = on("BSK_NO_SYN_LONG");  // dev: reads beyond k_syncmer_pk's limits go to k_syncmer_fast as before round 4
     syn_margin = (int)env_u32("BSK_SYN_MARGIN", 2 + 64) - 64;  // dev: rows of slack the planner wants in k_syncmer_pk's columns (BSK_SYN_MARGIN = 64 + margin)
     no_tiles = on("BSK_NO_TILES");
@@ -1791,19 +1791,24 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         // end of every unit -- no staging columns, so the rows-per-pair rule above does not apply: any read whose words fit a lane's
         // registers, whose blocks fit the mask rows, k <= 64 (the emit's window) and <= BSK_PF_TCAP / 64 expected selections per read
         const u32 syn_ns_max = b->maxlen >= (u32)p->s ? b->maxlen - (u32)p->s + 1u : 0u;
-        const bool syn_pf = !ctx->opt.no_syn_pf && pf_syncmer_supported(p->k - p->s) && b->maxlen <= pf_syncmer_max_bases() && p->k <= 64 &&
-                            (syn_ns_max + (u32)(p->k - p->s) - 1u) / (u32)(p->k - p->s) <= pf_syncmer_mask_rows() + 1u &&
-                            std::max(syn_nwin, 0.0) * 1.5 / (p->k - p->s + 1.0) <= (double)ctx->opt.pf_density;
+        auto syn_pf_fits = [&](bool lng) {  // (expected selections per read with a seventh of room below what a unit's emit phase takes)
+            const double dens = std::max(syn_nwin, 0.0) * 1.5 / (p->k - p->s + 1.0);
+            const double dmax = ctx->opt.pf_density ? (double)ctx->opt.pf_density : (double)pf_syncmer_unit_tuples(lng) / 64.0 * 0.86;
+            return !ctx->opt.no_syn_pf && pf_syncmer_supported(p->k - p->s, lng) && b->maxlen <= pf_syncmer_max_bases(lng) && p->k <= 64 &&
+                   (syn_ns_max + (u32)(p->k - p->s) - 1u) / (u32)(p->k - p->s) <= pf_syncmer_mask_rows(lng) + 1u && dens <= dmax;
+        };
+        const bool syn_pf_short = syn_pf_fits(false), syn_pf_long = !syn_pf_short && !ctx->opt.no_syn_long && syn_pf_fits(true);
+        const bool syn_pf = syn_pf_short || syn_pf_long;
         if (!use_ascii && fast_syncmer_supported(p->k, p->s) && (syn_short || syn_lng || syn_pf) && !syn_ties && !ctx->opt.force_generic && !ctx->opt.no_pk && !ctx->no_syn_pk) {
             pl.syn_fused = syn_pf;
-            pl.syn_long = !syn_pf && syn_lng;
+            pl.syn_long = syn_pf ? syn_pf_long : syn_lng;
             pl.which = K_SYN_PK;
             pl.fast_w = p->k - p->s;
             pl.slab = true;
             pl.slab_unit = (u64)64 * BSK_SYN_CAP;
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
             pl.bin_gran = bin_gran_for(ctx, b, p->k - p->s);
-            per_cu = pl.syn_fused ? pf_syncmer_blocks_per_cu(pl.fast_w) : pk_syncmer_blocks_per_cu(pl.fast_w, pl.syn_long);
+            per_cu = pl.syn_fused ? pf_syncmer_blocks_per_cu(pl.fast_w, pl.syn_long) : pk_syncmer_blocks_per_cu(pl.fast_w, pl.syn_long);
         } else if (!use_ascii && fast_syncmer_supported(p->k, p->s) && b->maxlen < 32768u && !ctx->opt.force_generic) {
             pl.which = K_SYN_FAST;
             pl.fast_w = p->k - p->s;
@@ -2081,7 +2086,7 @@ static void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, 
         case K_PROT_HASH: snprintf(b, sizeof b, "k_prot_hash"); break;
         case K_PROT_MIN: snprintf(b, sizeof b, "k_prot_minimizer"); break;
         case K_SYN_FAST: snprintf(b, sizeof b, "k_syncmer_fast<%d>", pl.fast_w); break;
-        case K_SYN_PK: snprintf(b, sizeof b, pl.syn_fused ? "k_syncmer_pf<%d>" : pl.syn_long ? "k_syncmer_pkl<%d>" : "k_syncmer_pk<%d>", pl.fast_w); break;
+        case K_SYN_PK: snprintf(b, sizeof b, pl.syn_fused ? (pl.syn_long ? "k_syncmer_pfl<%d>" : "k_syncmer_pf<%d>") : pl.syn_long ? "k_syncmer_pkl<%d>" : "k_syncmer_pk<%d>", pl.fast_w); break;
         case K_SYN_SEL: snprintf(b, sizeof b, "k_syncmer_sel<%d> + k_syncmer_emit", pl.fast_w); break;
         case K_PROT_MIN_FAST: snprintf(b, sizeof b, "k_prot_minimizer_fast<%d,%d,%s>", pl.fast_w, pl.fast_k, pl.fused_dna ? "true" : "false"); break;
         case K_PROT_HASH_FAST: snprintf(b, sizeof b, "k_prot_hash_fast<%d,%s>", pl.fast_k, pl.fused_dna ? "true" : "false"); break;
@@ -2416,7 +2421,7 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         case K_PROT_MIN: hipLaunchKernelGGL(k_prot_minimizer, dim3(pl.grid), dim3(64), 0, ctx->stream, a); break;
         case K_SYN_FAST: fast_syncmer_launch(pl.fast_w, pl.grid, ctx->stream, a); break;
         case K_SYN_PK:
-            if (pl.syn_fused) pf_syncmer_launch(pl.fast_w, pl.grid, std::min(pl.grid, ctx->cus * 8), ctx->stream, a);
+            if (pl.syn_fused) pf_syncmer_launch(pl.fast_w, pl.syn_long, pl.grid, std::min(pl.grid, ctx->cus * 8), ctx->stream, a);
             else pk_syncmer_launch(pl.fast_w, pl.syn_long, pl.grid, std::min(pl.grid, ctx->cus * 8), ctx->stream, a);
             break;
 #ifndef BSK_EXPERIMENTS
@@ -3124,8 +3129,8 @@ static u32 tile_min_for(const bsk_ctx *ctx, const bsk_batch *b, const bsk_params
 // ---- class plans: the decision (host, from the batch's length histogram) ------------------------------------------------------------
 struct ClassSig {
     int which = -1, octave = 0;
-    bool syn_long = false;
-    bool operator==(const ClassSig &o) const { return which == o.which && octave == o.octave && syn_long == o.syn_long; }
+    bool syn_long = false, syn_fused = false;
+    bool operator==(const ClassSig &o) const { return which == o.which && octave == o.octave && syn_long == o.syn_long && syn_fused == o.syn_fused; }
 };
 // what the planner would run over `n` reads of `bases` bases, the longest `hi` (the pure 2-bit plan: reads with an N are the parent's side launch)
 static bool class_sig(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, u64 n, u64 bases, u32 hi, ClassSig &g) {
@@ -3141,8 +3146,9 @@ static bool class_sig(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, u64
     if (make_plan(ctx, &t, p, pl) != BSK_OK) return false;
     g.which = (int)pl.which;
     g.syn_long = pl.syn_long;
+    g.syn_fused = pl.syn_fused;
     g.octave = hi > 1024 ? 63 - __builtin_clzll((u64)hi) : 0;  // (long classes also split by octave: per-read slabs are sized by the class's longest read)
-    if (hi > tile_min_for(ctx, b, p)) g.which = -2, g.syn_long = false, g.octave = 99;  // tile work: one class, whatever its lengths
+    if (hi > tile_min_for(ctx, b, p)) g.which = -2, g.syn_long = g.syn_fused = false, g.octave = 99;  // tile work: one class, whatever its lengths
     return true;
 }
 // rough kernel rates in Tbases/s (profiles/r04/robustness.jsonl): only their ratios matter -- is splitting worth its passes?
@@ -3154,7 +3160,7 @@ static double class_rate(const ClassSig &g, double meanlen, bool tiled, int kind
         case K_MIN_DENSE: return 0.7;
         case K_MIN_PKD: return 0.78;
         case K_MIN_FAST: return 0.75;
-        case K_SYN_PK: return g.syn_long ? 0.8 : 0.93;
+        case K_SYN_PK: return g.syn_fused ? (g.syn_long ? 0.95 : 1.15) : g.syn_long ? 0.8 : 0.93;
         case K_SYN_FAST: return meanlen <= 448 ? 0.6 : 0.15;
         default: return 0.09;
     }

@@ -60,11 +60,13 @@ void pk_syncmer_launch(int w, bool lng, int grid, int fix_grid, hipStream_t stre
 
 // the same machine with the emit fused into every unit (kernels_syncmer_pf.hpp, round 6): the s-mer side alone + from-scratch hashes of
 // the selected k-mers at the end of the unit; no staging columns; k <= 64; the exact machine over its listed reads is k_syncmer_fix.hip's
-bool pf_syncmer_supported(int w);
-u32 pf_syncmer_max_bases();
-u32 pf_syncmer_mask_rows();
-int pf_syncmer_blocks_per_cu(int w);
-void pf_syncmer_launch(int w, int grid, int fix_grid, hipStream_t stream, const KArgs &a);
+// lng: k_syncmer_pfl -- 32 words of a read in registers (reads of up to 480 bases), k - s up to 24, two waves per SIMD
+bool pf_syncmer_supported(int w, bool lng);
+u32 pf_syncmer_max_bases(bool lng);
+u32 pf_syncmer_mask_rows(bool lng);
+u32 pf_syncmer_unit_tuples(bool lng);  // what a unit's emit phase takes
+int pf_syncmer_blocks_per_cu(int w, bool lng);
+void pf_syncmer_launch(int w, bool lng, int grid, int fix_grid, hipStream_t stream, const KArgs &a);
 
 // the two-pass plan (kernels_syncmer_sel.hpp): selection by the packed s-mer machine, then the selected k-mers hashed from scratch
 bool sel_syncmer_supported(int w);

@@ -19,7 +19,7 @@ struct BskOpts {
     int syn_margin = 2;
     u32 test_overflow = 0;   // BSK_TEST_OVERFLOW (tests): pretend an overflow flag once per call -- 1: in a timed re-run (BSK_RESIZE), 2: a class plan's part while sizing, 4: ... in a timed re-run (BSK_REPLAN_CLASS)
     bool no_syn_long = false;
-    u32 pf_density = 12;     // BSK_PF_DENSITY (tests): the expected selections per read up to which k_syncmer_pf is planned (its emit list holds BSK_PF_TCAP = 1 024 tuples per unit of 64 reads: beyond it the unit's last reads go to the exact machine)
+    u32 pf_density = 0;      // BSK_PF_DENSITY (tests): the expected selections per read up to which k_syncmer_pf / _pfl are planned (0: 86 % of what a unit's emit list holds per read -- 1 024 / 1 792 tuples per 64 reads; beyond the list the unit's last reads go to the exact machine)
     bool no_syn_pf = false;  // BSK_NO_SYN_PF: syncmers on k_syncmer_pk / _pkl also where the fused-emit kernel (k_syncmer_pf, round 6) is planned
     bool syn_sel = false;    // BSK_SYN_SEL (make EXPERIMENTS=1): the two-pass syncmer plan, measured and not planned (kernels_syncmer_sel.hpp)
     bool no_class = false;   // BSK_NO_CLASS: one plan per batch, keyed on the longest read (rounds 1-4)

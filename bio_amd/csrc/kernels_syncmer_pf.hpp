@@ -19,7 +19,7 @@
 // Loads and the one vmcnt as in k_syncmer_pk: the next unit's words and descriptors travel global -> LDS (WBUF / DBUF) while this unit is
 // hashed and are waited for before this unit's stores.  Reads with a 27-bit key tie go to the list of the exact machine
 // (k_syncmer_fast<W, true>) as before; so do the last reads of a unit that selects more than BSK_PF_TCAP positions.
-// LDS: 13 184 B per wavefront -- twelve waves per CU, three per SIMD (<= 168 VGPRs).
+// LDS: 13 184 B per wavefront -- twelve waves per CU, three per SIMD (<= 168 VGPRs); k_syncmer_pfl (reads of up to 480 bases): 14 208 B, two per SIMD.
 #pragma once
 #include "kernels_syncmer_pk.hpp"
 
@@ -27,27 +27,35 @@ namespace bsk {
 
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 
-#define BSK_PF_TCAP 1024u  // tuples of a unit the emit phase takes (a unit of 150-base reads at k = 31, s = 11 has ~450)
-struct SynPfLds {
+// NW_: packed words of a read a lane keeps (16: reads of up to 224 bases, the next unit's words travel global -> LDS; 32: up to 480 bases,
+// the next unit's words travel global -> registers as in k_syncmer_pkl).  MROWS_: rows of 256 bytes of the region the parked suffix
+// minima (W rows), the selection words (one row per block) and, in the emit phase, the unit's packed words share.  TCAP_: tuples of a
+// unit the emit phase takes (a unit of 150-base reads at k = 31, s = 11 has ~450).
+template <int NW_, int MROWS_, int TCAP_, bool DMA_, int LIM>
+struct SynPfLdsT {
     static constexpr int PR = 1, ROW = 33;  // (unused by the SEL machine; SynPk names them)
-    static constexpr int NW = PKNW;
-    static constexpr bool DMA = true;
+    static constexpr int NW = NW_;
+    static constexpr bool DMA = DMA_;
+    static constexpr int TCAP = TCAP_;
     static constexpr int TABK = 0, TABS = 0;  // the s-mer update table: 20 x uint4
     static constexpr int KTA = 320;           // u32x4 [64]: three bases, first half of a piece of six: (rol(F3, 3), R3)
     static constexpr int KT1 = KTA + 1024;    // u32x4 [4]: one base
-    static constexpr int MROWS = 20;          // rows of the region below: W parked suffix minima (W <= 20), then <= 20 selection words per lane, then EBUF + KTB
-    static constexpr int PARK = KT1 + 64;     // u32 [MROWS][64]
+    static constexpr bool KTB_DYN = DMA_;     // the short plan has no room for a second static table: KTB lies behind EBUF and is written at the start of every emit phase
+    static constexpr int MROWS = MROWS_;
+    static constexpr int PARK = KT1 + 64 + (KTB_DYN ? 0 : 1024);  // u32 [MROWS][64]
     static constexpr int MASK = PARK;
-    static constexpr int EST = 16;            // words from one lane's row of EBUF to the next (a window that runs over the row's end reads bits nobody uses)
+    static constexpr int EST = NW_;           // words from one lane's row of EBUF to the next (a window that runs over the row's end reads bits nobody uses)
     static constexpr int EBUF = PARK;         // u32 [64][EST]: the unit's packed words, in the emit phase
-    static constexpr int KTB = EBUF + 64 * EST * 4;  // u32x4 [64]: second half of a piece of six: (F3, rol(R3, 3)) -- written at the start of every emit phase (the hash phase parks over it)
+    static constexpr int KTB = KTB_DYN ? EBUF + 64 * EST * 4 : KT1 + 64;  // u32x4 [64]: second half of a piece of six: (F3, rol(R3, 3))
     static constexpr int SH = PARK, SP = PARK;
-    static constexpr int FLAT = PARK + MROWS * 256;   // u16 [BSK_PF_TCAP]
-    static constexpr int WBUF = FLAT + (int)BSK_PF_TCAP * 2;
+    static constexpr int FLAT = PARK + MROWS * 256;   // u16 [TCAP]: (lane << 9) | idx
+    static constexpr int WBUF = FLAT + TCAP * 2;
     static constexpr int DBUF = WBUF + NW * 64 * 4;
-    static constexpr int TOTAL = DBUF + 512;
-    static_assert(KTB + 1024 <= PARK + MROWS * 256 && WBUF % 16 == 0 && EBUF % 16 == 0 && TOTAL <= 13648, "SynPfLds: twelve waves per CU");
+    static constexpr int TOTAL = DMA ? DBUF + 512 : WBUF;
+    static_assert(64 * EST * 4 + (KTB_DYN ? 1024 : 0) <= MROWS * 256 && WBUF % 16 == 0 && EBUF % 16 == 0 && TOTAL <= LIM && NW % 4 == 0, "SynPfLds");
 };
+typedef SynPfLdsT<PKNW, 20, 1024, true, 13648> SynPfLds;    // k_syncmer_pf: 13 184 B, twelve waves per CU, three per SIMD (<= 168 VGPRs)
+typedef SynPfLdsT<32, 32, 1792, false, 20480> SynPfLdsL;     // k_syncmer_pfl: 14 208 B; two waves per SIMD (the registers of a 32-word prefetch), eight per CU
 
 __device__ __forceinline__ void pf_rol64(u32 &lo, u32 &hi, u32 rot) {  // rot wave-uniform, 0..63
     if (rot & 32u) {
@@ -79,8 +87,8 @@ __device__ __forceinline__ u32 pf_xor3(u32 a, u32 b, u32 c) {  // one full-rate 
     return r;
 }
 // (q0, q1, q2: the three words of the read from word idx / 16 on -- the caller requests them a round ahead)
+template <class LY>
 __device__ __forceinline__ PfHash pf_hash_kmer(LDSQ const char *lds, u32 o, u32 idx, u32 k, u32 q0, u32 q1, u32 q2) {
-    typedef SynPfLds LY;
     const LDSQ u32 *const row = reinterpret_cast<const LDSQ u32 *>(lds + LY::EBUF) + o * (u32)LY::EST;
     u32 fl = 0, fh = 0, al = 0, ah = 0;
     auto rows_of = [&](u32 offa, u32 offb, u32x4 &xa, u32x4 &xb) {
@@ -168,19 +176,14 @@ __device__ __forceinline__ PfHash pf_hash_kmer(LDSQ const char *lds, u32 o, u32 
     return PfHash{fl, fh, al, ah};
 }
 
-#ifndef SYNPF_LB
-#define SYNPF_LB 3
-#endif
-template <int W>
-__global__ __launch_bounds__(64, SYNPF_LB) void k_syncmer_pf(KArgs a) {
-    typedef SynPfLds LY;
+template <int W, class LY>
+__device__ __forceinline__ void synpf_body(const KArgs &a, char *lds) {
     constexpr int NQ = LY::NW / 4;
-    static_assert(W <= LY::MROWS && NQ == 4, "k_syncmer_pf");
-    __shared__ __attribute__((aligned(16))) char lds[LY::TOTAL];
+    static_assert(W <= LY::MROWS, "synpf_body");
     LDSQ char *const ldsq = (LDSQ char *)lds;
     const int lane = lane_id();
-    u32x4 ktb_row;  // this lane's row of KTB (kept in registers: the table's place is the hash phase's)
-    {  // the tables, once per wavefront (nothing overwrites them): s-mer update rows, the 64 three-base rows of KTA, the four single bases
+    u32x4 ktb_row;  // this lane's row of KTB (the short plan keeps it in registers: the table's place is the hash phase's)
+    {  // the tables, once per wavefront: s-mer update rows, the 64 three-base rows of KTA (and KTB where it has a place of its own), the four single bases
         SynPkTabs tabs;
         tabs.init(a.s, a.s, lane);
         if (lane < 20) *reinterpret_cast<LDSQ u32x4 *>(ldsq + LY::TABS + lane * 16) = tabs.row;
@@ -190,6 +193,7 @@ __global__ __launch_bounds__(64, SYNPF_LB) void k_syncmer_pf(KArgs a) {
         const u64 fa = rol64(f3, 3), rb = rol64(r3, 3);
         *reinterpret_cast<LDSQ u32x4 *>(ldsq + LY::KTA + lane * 16) = (u32x4){(u32)fa, (u32)(fa >> 32), (u32)r3, (u32)(r3 >> 32)};
         ktb_row = (u32x4){(u32)f3, (u32)(f3 >> 32), (u32)rb, (u32)(rb >> 32)};
+        if constexpr (!LY::KTB_DYN) *reinterpret_cast<LDSQ u32x4 *>(ldsq + LY::KTB + lane * 16) = ktb_row;
         if (lane < 4) {
             const u64 f1 = seed_fwd_code((unsigned)lane), r1 = seed_rev_code((unsigned)lane);
             *reinterpret_cast<LDSQ u32x4 *>(ldsq + LY::KT1 + lane * 16) = (u32x4){(u32)f1, (u32)(f1 >> 32), (u32)r1, (u32)(r1 >> 32)};
@@ -197,7 +201,10 @@ __global__ __launch_bounds__(64, SYNPF_LB) void k_syncmer_pf(KArgs a) {
         wave_sync_lds();
     }
     const u64 slab = (u64)64 * BSK_SYN_CAP;
-    u64 d_cur = 0;
+    u64 d_cur = 0, d_nx = 0;
+    SynWords<NQ == 4 || NQ == 6 || NQ == 8 ? NQ : 4> pw_cur;  // (register form of the prefetch)
+#pragma unroll
+    for (int j = 0; j < (int)(sizeof(pw_cur.q) / sizeof(pw_cur.q[0])); ++j) pw_cur.q[j] = (u32x4){0, 0, 0, 0};
     bool have = false;
     const u32 lseg = a.fixcap / a.list_grid;
     u32 lcur = 0;
@@ -214,34 +221,59 @@ __global__ __launch_bounds__(64, SYNPF_LB) void k_syncmer_pf(KArgs a) {
         const bool nxt = unit + 1 != uend && unit + 1 < a.nunits;
         const u64 rmax = a.n - 1;
         typename SynVec<LY::NW>::type wr;
-        u64 d_n1;
+        u64 d_n1, d_n2 = 0;
+        SynWords<NQ == 4 || NQ == 6 || NQ == 8 ? NQ : 4> pw_n1;
         u32 rfl;
-        if (!have) {  // first unit of a ticket: nothing was requested ahead
-            d_cur = a.desc[r < rmax ? r : rmax];
-            synpk_dma_words<NQ>(a.words + (d_cur >> 24), wbuf);
-            synpk_dma_desc(a.desc + (r + 64 < rmax ? r + 64 : rmax), dbuf);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        {
-            u32x4 wq[NQ];
-            const LDSQ u32x4 *wb = reinterpret_cast<const LDSQ u32x4 *>(ldsq + LY::WBUF) + lane;
-            const LDSQ u32 *db = reinterpret_cast<const LDSQ u32 *>(ldsq + LY::DBUF) + lane;
+        if constexpr (LY::DMA) {
+            if (!have) {  // first unit of a ticket: nothing was requested ahead
+                d_cur = a.desc[r < rmax ? r : rmax];
+                synpk_dma_words<NQ>(a.words + (d_cur >> 24), wbuf);
+                synpk_dma_desc(a.desc + (r + 64 < rmax ? r + 64 : rmax), dbuf);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            {
+                static_assert(!LY::DMA || NQ == 4, "synpf_body: the LDS-DMA plan takes 16 words");
+                u32x4 wq[NQ];
+                const LDSQ u32x4 *wb = reinterpret_cast<const LDSQ u32x4 *>(ldsq + LY::WBUF) + lane;
+                const LDSQ u32 *db = reinterpret_cast<const LDSQ u32 *>(ldsq + LY::DBUF) + lane;
 #pragma unroll
-            for (int j = 0; j < NQ; ++j) wq[j] = wb[64 * j];
-            u32 dl = db[0], dh = db[64];
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[0]), "+v"(wq[1]), "+v"(wq[2]), "+v"(wq[3]), "+v"(dl), "+v"(dh)::"memory");
+                for (int j = 0; j < NQ; ++j) wq[j] = wb[64 * j];
+                u32 dl = db[0], dh = db[64];
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[0]), "+v"(wq[1]), "+v"(wq[2]), "+v"(wq[3]), "+v"(dl), "+v"(dh)::"memory");
+#pragma unroll
+                for (int j = 0; j < NQ; ++j) {
+                    wr[4 * j] = wq[j].x;
+                    wr[4 * j + 1] = wq[j].y;
+                    wr[4 * j + 2] = wq[j].z;
+                    wr[4 * j + 3] = wq[j].w;
+                }
+                d_n1 = ((u64)dh << 32) | dl;
+            }
+            synpk_dma_words<NQ>(a.words + (d_n1 >> 24), wbuf);
+            synpk_dma_desc(a.desc + (r + 128 < rmax ? r + 128 : rmax), dbuf);
+            rfl = pk_load_u8(a.rflags ? a.rflags + (r < rmax ? r : rmax) : reinterpret_cast<const u8 *>(a.desc));
+        } else {  // register form, as k_syncmer_pkl: every load unconditional, words of unit N+1 and descriptor of unit N+2 requested here
+            if (!have) {
+                d_cur = pk_load_u64(a.desc + (r < rmax ? r : rmax));
+                d_nx = pk_load_u64(a.desc + (r + 64 < rmax ? r + 64 : rmax));
+                pk_wait_loads(d_cur, d_nx);
+                pw_cur = syn_load_words<NQ>(a.words + (d_cur >> 24));
+                u64 dz = d_cur;
+                u32 fz = 0;
+                syn_wait_loads<NQ>(pw_cur, dz, fz);
+            }
+            d_n1 = d_nx;
+            pw_n1 = syn_load_words<NQ>(a.words + (d_n1 >> 24));
+            d_n2 = pk_load_u64(a.desc + (r + 128 < rmax ? r + 128 : rmax));
+            rfl = pk_load_u8(a.rflags ? a.rflags + (r < rmax ? r : rmax) : reinterpret_cast<const u8 *>(a.desc));
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
-                wr[4 * j] = wq[j].x;
-                wr[4 * j + 1] = wq[j].y;
-                wr[4 * j + 2] = wq[j].z;
-                wr[4 * j + 3] = wq[j].w;
+                wr[4 * j] = pw_cur.q[j].x;
+                wr[4 * j + 1] = pw_cur.q[j].y;
+                wr[4 * j + 2] = pw_cur.q[j].z;
+                wr[4 * j + 3] = pw_cur.q[j].w;
             }
-            d_n1 = ((u64)dh << 32) | dl;
         }
-        synpk_dma_words<NQ>(a.words + (d_n1 >> 24), wbuf);
-        synpk_dma_desc(a.desc + (r + 128 < rmax ? r + 128 : rmax), dbuf);
-        rfl = pk_load_u8(a.rflags ? a.rflags + (r < rmax ? r : rmax) : reinterpret_cast<const u8 *>(a.desc));
         const u64 d = d_cur;
         const u64 L = desc_len(a, d);
         const u64 ro = out_index(a, r, d);
@@ -265,15 +297,21 @@ __global__ __launch_bounds__(64, SYNPF_LB) void k_syncmer_pf(KArgs a) {
             cnt = sp.nsel;
             tmin_lane = sp.tmin;
         }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(rfl)::"memory");  // the next unit's words and the descriptors after them are in LDS
+        if constexpr (LY::DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(rfl)::"memory");  // the next unit's words and the descriptors after them are in LDS
+        } else {
+            syn_wait_loads<NQ>(pw_n1, d_n2, rfl);  // the next unit's words and the descriptor after it, requested a whole hashing phase ago
+            pw_cur = pw_n1;
+            d_nx = d_n2;
+        }
         d_cur = d_n1;
         have = nxt;
         // reads the exact machine must run: two equal 27-bit keys met in one of their min operations (kernels_syncmer_pk.hpp) -- and the
-        // last reads of a unit whose tuples do not fit the emit phase's list (never on real densities: 16 per read)
+        // last reads of a unit whose tuples do not fit the emit phase's list or the unit's slab (never on planned densities)
         u64 redo = __builtin_amdgcn_ballot_w64(ok && tmin_lane < 32u);
         if ((redo >> lane) & 1) cnt = 0;
         u32 incl = wave_incl_scan_u32(cnt, lane);
-        const u64 over = __builtin_amdgcn_ballot_w64(incl > BSK_PF_TCAP);  // (a suffix of the lanes: incl never decreases)
+        const u64 over = __builtin_amdgcn_ballot_w64(incl > (u32)LY::TCAP);  // (a suffix of the lanes: incl never decreases)
         if (over) {
             redo |= over & __builtin_amdgcn_ballot_w64(cnt != 0u);
             if ((over >> lane) & 1) {
@@ -295,7 +333,7 @@ __global__ __launch_bounds__(64, SYNPF_LB) void k_syncmer_pf(KArgs a) {
             LDSQ unsigned short *const flat = reinterpret_cast<LDSQ unsigned short *>(ldsq + LY::FLAT);
             {
                 u32 at = ((u32)(size_t)flat) + excl * 2u;  // (byte address of this lane's next entry; the rows' bits are exactly its cnt selections: windows beyond a lane's end are masked in the hash phase)
-                const u32 tag = (u32)lane << 8;
+                const u32 tag = (u32)lane << 9;
                 for (u32 mm = 0; mm < nb; ++mm) {
                     u32 w = cnt ? *reinterpret_cast<const LDSQ u32 *>(ldsq + LY::MASK + mm * 256u + (u32)lane * 4u) : 0u;
                     const u32 val0 = tag + (mm * (u32)W + 1u - (u32)W);  // (+, not |: row 0 starts at idx 1 - W and only its last bit is ever set)
@@ -314,7 +352,7 @@ __global__ __launch_bounds__(64, SYNPF_LB) void k_syncmer_pf(KArgs a) {
                 LDSQ u32x4 *eb = reinterpret_cast<LDSQ u32x4 *>(ldsq + LY::EBUF + lane * (LY::EST * 4));
 #pragma unroll
                 for (int j = 0; j < NQ; ++j) eb[j] = (u32x4){wr[4 * j], wr[4 * j + 1], wr[4 * j + 2], wr[4 * j + 3]};
-                *reinterpret_cast<LDSQ u32x4 *>(ldsq + LY::KTB + lane * 16) = ktb_row;
+                if constexpr (LY::KTB_DYN) *reinterpret_cast<LDSQ u32x4 *>(ldsq + LY::KTB + lane * 16) = ktb_row;
             }
             wave_sync_lds();
             u64 *const gh = a.hash + base;
@@ -323,7 +361,7 @@ __global__ __launch_bounds__(64, SYNPF_LB) void k_syncmer_pf(KArgs a) {
             auto request = [&](u32 tb, u32 &tp, u32 &q0, u32 &q1, u32 &q2) {
                 const u32 tl = tb + (u32)lane;
                 tp = (u32)flat[tl < T ? tl : T - 1u];
-                const LDSQ u32 *const wp = reinterpret_cast<const LDSQ u32 *>(ldsq + LY::EBUF) + (tp >> 8) * (u32)LY::EST + ((tp & 0xffu) >> 4);
+                const LDSQ u32 *const wp = reinterpret_cast<const LDSQ u32 *>(ldsq + LY::EBUF) + (tp >> 9) * (u32)LY::EST + ((tp & 0x1ffu) >> 4);
                 q0 = wp[0];
                 q1 = wp[1];
                 q2 = wp[2];
@@ -337,9 +375,9 @@ __global__ __launch_bounds__(64, SYNPF_LB) void k_syncmer_pf(KArgs a) {
 #endif
                 const u32 tl = tb + (u32)lane;
                 const bool live = tl < T;
-                const u32 idx = tp & 0xffu, o = tp >> 8, c0 = q0, c1 = q1, c2 = q2;
+                const u32 idx = tp & 0x1ffu, o = tp >> 9, c0 = q0, c1 = q1, c2 = q2;
                 if (tb + 64u < T) request(tb + 64u, tp, q0, q1, q2);
-                const PfHash h = pf_hash_kmer(ldsq, o, idx, (u32)a.k, c0, c1, c2);
+                const PfHash h = pf_hash_kmer<LY>(ldsq, o, idx, (u32)a.k, c0, c1, c2);
                 const bool rev = h.rh < h.fh || (h.rh == h.fh && h.rl < h.fl);  // nthash returns rev only when strictly smaller
 #ifdef SYNPF_NOSTORE
                 asm volatile("" ::"v"(h.rh), "v"(h.rl), "v"(h.fh), "v"(h.fl), "v"(rev), "v"(gh), "v"(gp));
@@ -362,26 +400,56 @@ __global__ __launch_bounds__(64, SYNPF_LB) void k_syncmer_pf(KArgs a) {
     list_close(reinterpret_cast<u32 *>(a.fixlist), lseg, lcur, lane);
 }
 
+#ifndef SYNPF_LB
+#define SYNPF_LB 3
+#endif
+template <int W>
+__global__ __launch_bounds__(64, SYNPF_LB) void k_syncmer_pf(KArgs a) {  // three waves per SIMD: at most 168 VGPRs
+    __shared__ __attribute__((aligned(16))) char lds[SynPfLds::TOTAL];
+    synpf_body<W, SynPfLds>(a, lds);
+}
+// the same kernel for reads of up to 480 bases and k - s up to 24: 32 words of a read in registers, two waves per SIMD (k_syncmer_pkl's place)
+template <int W>
+__global__ __launch_bounds__(64, 2) void k_syncmer_pfl(KArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[SynPfLdsL::TOTAL];
+    synpf_body<W, SynPfLdsL>(a, lds);
+}
+
 #ifndef BSK_SYNPF_WS
 #define BSK_SYNPF_WS(X) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20)
 #endif
+#ifndef BSK_SYNPFL_WS
+#define BSK_SYNPFL_WS(X) BSK_SYNPF_WS(X) X(21) X(22) X(23) X(24)
+#endif
 #ifdef BSK_IMPL_SYNPF
-bool pf_syncmer_supported(int w) {
+bool pf_syncmer_supported(int w, bool lng) {
 #define X(WW) \
     if (w == WW) return true;
-    BSK_SYNPF_WS(X)
+    if (lng) {
+        BSK_SYNPFL_WS(X)
+    } else {
+        BSK_SYNPF_WS(X)
+    }
 #undef X
     return false;
 }
-u32 pf_syncmer_max_bases() { return 16u * (u32)(SynPfLds::NW - 2); }
-u32 pf_syncmer_mask_rows() { return (u32)SynPfLds::MROWS; }
-int pf_syncmer_blocks_per_cu(int w) {
+u32 pf_syncmer_max_bases(bool lng) { return 16u * (u32)((lng ? SynPfLdsL::NW : SynPfLds::NW) - 2); }
+u32 pf_syncmer_mask_rows(bool lng) { return (u32)(lng ? SynPfLdsL::MROWS : SynPfLds::MROWS); }
+u32 pf_syncmer_unit_tuples(bool lng) { return (u32)(lng ? SynPfLdsL::TCAP : SynPfLds::TCAP); }
+int pf_syncmer_blocks_per_cu(int w, bool lng) {
     int nb = 0;
     hipError_t e = hipErrorInvalidValue;
+    if (lng) {
+#define X(WW) \
+    if (w == WW) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_syncmer_pfl<WW>, 64, 0);
+        BSK_SYNPFL_WS(X)
+#undef X
+    } else {
 #define X(WW) \
     if (w == WW) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_syncmer_pf<WW>, 64, 0);
-    BSK_SYNPF_WS(X)
+        BSK_SYNPF_WS(X)
 #undef X
+    }
     if (e != hipSuccess || nb < 1) {
         (void)hipGetLastError();
         nb = 1;
@@ -389,11 +457,18 @@ int pf_syncmer_blocks_per_cu(int w) {
     return nb;
 }
 // the fused kernel, then the exact machine over the listed reads (k_syncmer_fix.hip)
-void pf_syncmer_launch(int w, int grid, int fix_grid, hipStream_t stream, const KArgs &a) {
+void pf_syncmer_launch(int w, bool lng, int grid, int fix_grid, hipStream_t stream, const KArgs &a) {
+    if (lng) {
+#define X(WW) \
+    if (w == WW) hipLaunchKernelGGL((k_syncmer_pfl<WW>), dim3(grid), dim3(64), 0, stream, a);
+        BSK_SYNPFL_WS(X)
+#undef X
+    } else {
 #define X(WW) \
     if (w == WW) hipLaunchKernelGGL((k_syncmer_pf<WW>), dim3(grid), dim3(64), 0, stream, a);
-    BSK_SYNPF_WS(X)
+        BSK_SYNPF_WS(X)
 #undef X
+    }
     pk_syncmer_fix_launch(w, fix_grid, stream, a);
 }
 #endif  // BSK_IMPL_SYNPF

@@ -129,6 +129,9 @@ def run_all(pk_ws, syn_ws, ring_ws, jobs=None):
     from concurrent.futures import ThreadPoolExecutor
     tasks = [lambda w=w: check_hidden_loads((w,)) for w in pk_ws]
     tasks += [lambda w=w: check_hidden_loads((w,), "k_syncmer_pk", "BSK_SYNPKL_WS", ("-DBSK_SYNPK_WS(X)=" + ("X(%s)" % w if int(w) <= 20 else ""),)) for w in syn_ws]
+    # the fused-emit syncmer kernels (round 6): k_syncmer_pf (k - s = 8..20, LDS-DMA: nothing to check but the build) and k_syncmer_pfl (8..24: the
+    # register form of the prefetch, hand-placed waits as k_syncmer_pkl)
+    tasks += [lambda w=w: check_hidden_loads((w,), "k_syncmer_pf", "BSK_SYNPFL_WS", ("-DBSK_SYNPF_WS(X)=" + ("X(%s)" % w if int(w) <= 20 else ""),)) for w in syn_ws if int(w) >= 8]
     tasks += [lambda w=w: check_hidden_loads((w,), "k_minimizer_ring", "BSK_RING_WS") + check_reserved((w,)) for w in ring_ws]
     with ThreadPoolExecutor(max_workers=jobs or max(2, (os.cpu_count() or 4))) as ex:
         res = list(ex.map(lambda f: f(), tasks))

@@ -151,8 +151,11 @@ def test_syncmer_packed_kernel_at_its_length_limit(engine, oracle):
 
 @pytest.mark.parametrize("k,s,lo,hi", [(31, 11, 225, 260), (31, 11, 180, 250), (120, 100, 330, 352), (35, 11, 120, 160), (31, 11, 300, 352), (150, 128, 440, 480), (33, 10, 140, 150),
                                        (35, 13, 150, 151), (45, 21, 200, 300), (31, 11, 60, 250)])
-def test_syncmer_long_packed_kernel(engine, oracle, k, s, lo, hi):
-    """k_syncmer_pkl: the packed machine with 32 words of a read in registers (reads of up to 480 bases), longer staging columns and
+@pytest.mark.parametrize("fused", [True, False])
+def test_syncmer_long_packed_kernel(engine, oracle, monkeypatch, k, s, lo, hi, fused):
+    """fused (round 6): k_syncmer_pfl, the fused-emit kernel with 32 words of a read in registers, takes these batches where k <= 64;
+    not fused (BSK_NO_SYN_PF): k_syncmer_pkl as in rounds 4-5.
+    k_syncmer_pkl: the packed machine with 32 words of a read in registers (reads of up to 480 bases), longer staging columns and
     k - s up to 24 (round 4; until then these batches ran on k_syncmer_fast).  Every read against the closed form AND the reference's
     state machine; lengths up to the word limit so that the clamped word index of the last blocks is exercised; ragged batches
     (length-binned units) included."""
@@ -160,9 +163,11 @@ def test_syncmer_long_packed_kernel(engine, oracle, k, s, lo, hi):
     seqs = [rand_seq(rng, rng.randint(lo, hi)) for _ in range(2200)]
     seqs[7] = "A" * hi                      # every s-mer the same hash: a key tie in every min operation -> the exact machine
     seqs[8] = rand_seq(rng, lo - 40) + "T" * 40  # a low-complexity tail
+    if not fused:
+        monkeypatch.setenv("BSK_NO_SYN_PF", "1")
     b = engine.batch(seqs)
     res = engine.run(b, engine.params(L.SYNCMER, k, s=s))
-    assert "k_syncmer_pkl" in res.plan()["kernel"], res.plan()
+    assert ("k_syncmer_pfl" if fused and k <= 64 else "k_syncmer_pkl") in res.plan()["kernel"], res.plan()
     for i, q in enumerate(seqs):
         st, h, p = res.read(i)
         if len(q) < 2 * k - s - 1:
@@ -187,7 +192,7 @@ def test_syncmer_mid_length_reads_run_as_tiles(engine, oracle):
     seqs[3] = "AC" * 400
     b = engine.batch(seqs)
     res = engine.run(b, engine.params(L.SYNCMER, 31, s=11))
-    assert "over tiles" in res.plan()["kernel"] and "k_syncmer_pkl" in res.plan()["kernel"], res.plan()
+    assert "over tiles" in res.plan()["kernel"] and ("k_syncmer_pkl" in res.plan()["kernel"] or "k_syncmer_pfl" in res.plan()["kernel"]), res.plan()
     for i, q in enumerate(seqs):
         st, h, p = res.read(i)
         eh, ep, es, fl = oracle.syncmer(q, 31, 11, False, closed=True)
@@ -209,7 +214,7 @@ def test_syncmer_tiles_stay_on_the_long_packed_plan(engine, oracle, k, s):
     seqs = [rand_seq(rng, rng.choice((460, 700, 1000, 2500))) for _ in range(300)] + ["A" * 900, "ACG" * 400]
     b = engine.batch(seqs)
     res = engine.run(b, engine.params(L.SYNCMER, k, s=s))
-    assert "over tiles" in res.plan()["kernel"] and "k_syncmer_pkl<%d>" % (k - s) in res.plan()["kernel"], res.plan()
+    assert "over tiles" in res.plan()["kernel"] and ("k_syncmer_pkl<%d>" % (k - s) in res.plan()["kernel"] or "k_syncmer_pfl<%d>" % (k - s) in res.plan()["kernel"]), res.plan()  # (round 6: the fused-emit long plan where the tile's density fits its list)
     for i, q in enumerate(seqs):
         st, h, p = res.read(i)
         eh, ep, es, fl = oracle.syncmer(q, k, s, False, closed=True)
@@ -261,14 +266,25 @@ def test_syncmer_wide_windows_run_on_the_staged_kernel(engine, oracle, k, s):
 
 
 def test_syncmer_long_plan_digest_equals_the_64_bit_kernels(engine):
-    """Same batch through k_syncmer_pkl and (BSK_NO_SYN_LONG) k_syncmer_fast: identical digests and flag counts."""
+    """Same batch through k_syncmer_pfl, k_syncmer_pkl (BSK_NO_SYN_PF) and (BSK_NO_SYN_LONG) k_syncmer_fast: identical digests and flag counts."""
     import os
     b = engine.synth(L.ALPHA_DNA, 300000, 250, 0x5EED0250)
     prm = engine.params(L.SYNCMER, 31, s=11)
     res = engine.run(b, prm)
-    assert "k_syncmer_pkl" in res.plan()["kernel"], res.plan()
-    d1 = res.digest()
+    assert "k_syncmer_pfl" in res.plan()["kernel"], res.plan()
+    d0 = res.digest()
     res.close()
+    os.environ["BSK_NO_SYN_PF"] = "1"
+    try:
+        engine.reload_options()
+        res = engine.run(b, prm)
+        assert "k_syncmer_pkl" in res.plan()["kernel"], res.plan()
+        d1 = res.digest()
+        res.close()
+    finally:
+        del os.environ["BSK_NO_SYN_PF"]
+        engine.reload_options()
+    assert d0 == d1, (d0, d1)
     os.environ["BSK_NO_SYN_LONG"] = "1"
     try:
         engine.reload_options()
