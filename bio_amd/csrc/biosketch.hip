@@ -245,6 +245,12 @@ __global__ void k_fold_flags(const u32 *side_ticket, u32 *parent_word) {
     const u32 f = side_ticket[1] | side_ticket[3];
     if (f) atomicOr(parent_word, f);
 }
+// sketch_tiled without a last synchronisation (a class plan's tiled part): the tile kernels' overflow flags (saved words 1 and 3) and the
+// stitch's (word 1 of the live ticket) become one word the parent folds into its own (launch_parts)
+__global__ void k_tile_flag_word(const u32 *saved, const u32 *live, u32 *out) { out[0] = saved[1] | saved[3] | live[1]; }
+__global__ void k_fold_word(const u32 *word, u32 *parent_word) {
+    if (word[0]) atomicOr(parent_word, word[0]);
+}
 __global__ void k_adopt_side(const u32 *subset, u64 nsub, const u64 *srefs, const u8 *sstatus, u64 *refs, u8 *status) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nsub; i += (u64)gridDim.x * blockDim.x) {
         const u64 r = subset[i];
@@ -548,6 +554,7 @@ extern "C" void bsk_ctx_destroy(bsk_ctx *ctx) {
     }
     if (ctx->ev_side_done) (void)hipEventDestroy(ctx->ev_side_done);
     if (ctx->ev_adopted) (void)hipEventDestroy(ctx->ev_adopted);
+    if (ctx->ev_tiled) (void)hipEventDestroy(ctx->ev_tiled);
     if (ctx->ev_mix0) (void)hipEventDestroy(ctx->ev_mix0);
     if (ctx->ev_mix1) (void)hipEventDestroy(ctx->ev_mix1);
     bsk_comm_destroy(ctx);
@@ -715,6 +722,7 @@ void BskOpts::load() {
     syn_margin = (int)env_u32("BSK_SYN_MARGIN", 2 + 64) - 64;  // dev: rows of slack the planner wants in k_syncmer_pk's columns (BSK_SYN_MARGIN = 64 + margin)
     no_tiles = on("BSK_NO_TILES");
     no_tile_cache = on("BSK_NO_TILE_CACHE");
+    no_tile_defer = on("BSK_NO_TILE_DEFER");  // dev: tiled calls with the host round trips of rounds 2-5 (tile count, sizing run, totals)
     no_group_gather = on("BSK_NO_GROUP_GATHER");  // dev: bsk_result_compact / _fetch_narrow with one (part of a) wavefront per sequence, as before round 4
     timing = on("BSK_TIMING");
     no_fused_translate = on("BSK_NO_FUSED_TRANSLATE");
@@ -746,7 +754,8 @@ static bsk_ctx *side_ctx(bsk_ctx *ctx) {
         bsk_ctx *s = nullptr;
         if (bsk_ctx_create(ctx->device, &s) != BSK_OK) return nullptr;
         if (hipEventCreateWithFlags(&ctx->ev_side_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_adopted, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ctx->ev_mix0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_mix1, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&ctx->ev_mix0, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_mix1, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_tiled, hipEventDisableTiming) != hipSuccess) {
             bsk_ctx_destroy(s);
             return nullptr;
         }
@@ -2123,6 +2132,7 @@ struct ClassPart {
     u32 lo = 0, hi = 0;
     bool tiled = false;  // longer than the kind's tile threshold: the part runs over tiles (sketch_tiled), its result is wide and copied into the tail
     bool fresh = false;  // ... and was just run by the sizing call (the parent's first launch does not run it again)
+    bool async = false;  // ... without a synchronisation of its own (sketch_tiled, tile_async): its overflow flags wait in the side context's d_ticket[24]
 };
 struct ClassSet {
     std::vector<ClassPart> parts;
@@ -2170,14 +2180,19 @@ static int launch_parts(bsk_ctx *ctx, ClassSet *cs, const bsk_params *p, bsk_res
         }
         if (pt.tiled) {  // tiles + stitch into a result of its own, then one copy into the tail
             if (!pt.fresh) {
+                side->tile_async = pt.async;  // (no synchronisation of its own: the part must not hold the bulk's launch back -- unless it was sized the round-trip way after an overflow)
+                side->tile_sync = !pt.async;
                 const int trc = sketch_tiled(side, pt.sub, p, 0, &pt.res, 0, 0, nullptr);
+                pt.async = side->tile_was_async;
+                side->tile_async = side->tile_sync = false;
                 if (trc != BSK_OK) {
                     ctx->err = side->err;
                     return trc;
                 }
             }
             pt.fresh = false;
-            const u64 T = pt.res->n_tuples;
+            if (pt.async) hipLaunchKernelGGL(k_fold_word, dim3(1), dim3(1), 0, side->stream, side->d_ticket + 24, ctx->d_ticket + 16);  // the part's overflow flags of its last run
+            const u64 T = pt.res->n_tuples;  // (the asynchronous path: an upper bound -- the result's capacity)
             if (T > pt.extent) {
                 ctx->err = "class plan: a tiled part outgrew its place in the tail";
                 return BSK_ERR_DEVICE;
@@ -2241,6 +2256,14 @@ static int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_res
         // when the bulk's persistent waves retire (they hold every CU's LDS) -- measured: 0.835 against 0.851 of the uniform rate
         const int trc = launch_parts(ctx, cs, p, res, true);
         if (trc != BSK_OK) return trc;
+        // (round 6: the tiled parts no longer wait on the host -- but their CHAIN of small kernels must be through before the bulk's persistent
+        // waves take every CU, or its later links only run when those retire: 0.855 of the uniform rate against 0.908 with the host waits)
+        bool any_tiled = false;
+        for (auto &pt : cs->parts) any_tiled |= pt.tiled && pt.n;
+        if (any_tiled) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev_tiled, ctx->side->stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_tiled, 0));
+        }
         const int prc = launch_parts(ctx, cs, p, res, false);
         if (prc != BSK_OK) return prc;
     }
@@ -2623,7 +2646,14 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
         if (rc != BSK_OK) return cleanup(rc);
         if (pl.nunits == 0) {  // empty batch: nothing was launched, the scratch counters are stale
             res->n_tuples = 0;
+            if (ctx->defer) HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket + 20, 0, 4 * sizeof(u32), ctx->stream));
             break;
+        }
+        if (ctx->defer) {  // nothing is read back: the launch's flags are parked where later passes leave them alone, the caller looks at them
+            HIPCHK(ctx, hipMemcpyAsync(ctx->d_ticket + 20, ctx->d_ticket, 4 * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+            res->n_tuples = res->cap;  // (an upper bound; the caller sizes by it)
+            plan_record(res, b, p, circ_ext, pl);
+            return cleanup(BSK_OK);
         }
         hipError_t e = hipMemcpyAsync(ctx->h_pinned, ctx->d_total, 4 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_pinned + 4, ctx->d_ticket, 4 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream);
@@ -2894,6 +2924,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
         *out = ctx->tmp[slot];
         return hipSuccess;
     };
+    bsk_result *old = nullptr;  // the caller's previous result (below)
     auto done = [&](int code) {
         if (tb) {  // the tile batch only borrowed its descriptor / flag arrays
             tb->desc = nullptr;
@@ -2902,6 +2933,10 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
             bsk_batch_destroy(tb);
         }
         if (code != BSK_OK && fin) bsk_result_release(fin);
+        if (old) {
+            bsk_result_release(old);
+            old = nullptr;
+        }
         if (ctx->opt.no_tile_cache && ctx->tile_res) {  // dev switch
             bsk_result_release(ctx->tile_res);
             ctx->tile_res = nullptr;
@@ -2923,16 +2958,29 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
         fprintf(stderr, "[tiled] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t_prev).count());
         t_prev = t;
     };
-    if (*result) {  // a tiled result is rebuilt from scratch
-        bsk_result_release(*result);
-        *result = nullptr;
-    }
+    // the caller's previous result: its arrays serve again where they fit (a timed re-run, a class plan's part on every launch, a streaming
+    // caller's next chunk: hipFree synchronises the whole device and five hipMalloc per call cost more than a small part's kernels)
+    old = *result;
+    *result = nullptr;
+    auto drop_old = [&]() {
+        if (old) bsk_result_release(old);
+        old = nullptr;
+    };
+    if (old && (old->ctx != ctx || !old->wfirst || old->n != n || old->arrays_borrowed || old->classes || !kind_has_pos(p_in->kind) || two_strand || old->kind != p_in->kind)) drop_old();
     // 1. tiles per sequence -> first tile of every sequence
     const u32 nunits = (u32)((n + 63) / 64);
     int rc = ensure_scratch(ctx, std::max<u32>(nunits, 1), 0);
     if (rc != BSK_OK) return done(rc);
     TCHK(pool(0, (n + 1) * 8, (void **)&tstart));
     TCHK(hipMemsetAsync(tstart, 0, (n + 1) * 8, ctx->stream));
+    // Without host round trips (round 6): the number of tiles is bounded on the host -- a sequence of L bases has at most L positions, so
+    // at most L / tp + 1 tiles -- every array and grid is sized by the bound, the entries beyond the true count (on the device: tstart[n])
+    // are empty tiles, the tile kernels launch ONCE into slabs sized by the plan (run_planned, ctx->defer) and the only synchronisation is
+    // the call's last one, which also brings the overflow flags: a call that finds one set runs again the old way (tile_sync).  Batches
+    // with a non-ACGT letter (per-tile flags pick the side launch's tiles), proteins and the two-strand k-mer mode keep the round trips.
+    const bool defer = !ctx->opt.no_tile_defer && !ctx->tile_sync && !prot && b->n_nonacgt == 0 && !two_strand && n > 0;
+    const bool async_final = defer && ctx->tile_async && warmup + iters == 0;
+    ctx->tile_was_async = async_final;
     u64 nt = 0;
     if (n) {
         TCHK(hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream));
@@ -2940,9 +2988,13 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
         TileArgs ta{seq, geo, nunits, tstart, ctx->d_ticket, ctx->d_lookback};
         hipLaunchKernelGGL(k_tile_count, dim3(std::min<u32>(nunits, (u32)ctx->cus * 8)), dim3(64), 0, ctx->stream, ta);
         TCHK(hipGetLastError());
-        TCHK(hipMemcpyAsync(ctx->h_pinned, tstart + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-        TCHK(hipStreamSynchronize(ctx->stream));
-        nt = ctx->h_pinned[0];
+        if (defer) {
+            nt = b->n_bases / geo.tp + n;
+        } else {
+            TCHK(hipMemcpyAsync(ctx->h_pinned, tstart + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+            TCHK(hipStreamSynchronize(ctx->stream));
+            nt = ctx->h_pinned[0];
+        }
     }
     lap("tile count");
     // 2. tile table + a batch whose "reads" are the tiles (aliases the words / bytes of b)
@@ -3000,7 +3052,9 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     lap("tile table");
     // 3. the ordinary kernels over the tiles
     // the cached tile result belongs to an earlier batch: always size (one untimed run) before any timed repetition
+    ctx->defer = defer;
     rc = run_planned(ctx, tb, &p2, 0, &tres_slot, 0, 0, nullptr);
+    ctx->defer = false;
     if (rc == BSK_OK && warmup + iters > 0) rc = run_planned_resizing(ctx, tb, &p2, 0, &tres_slot, warmup, iters, kernel_ms);
     tres = tres_slot;
     if (rc != BSK_OK) return done(rc);
@@ -3011,20 +3065,26 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     TCHK(hipMemsetAsync(sflags, 0, (n ? n : 1) * 4, ctx->stream));
     TCHK(hipMemsetAsync(sbad, 0xff, (n ? n : 1) * 8, ctx->stream));
     if (nt) {
-        hipLaunchKernelGGL(k_tile_flags, dim3(grid_for(ctx, nt, 256)), dim3(256), 0, ctx->stream, tres->status, tt.seq, tstart, nt, sflags,
+        hipLaunchKernelGGL(k_tile_flags, dim3(grid_for(ctx, nt, 256)), dim3(256), 0, ctx->stream, tres->status, tt.seq, tstart, nt, n, sflags,
                            sbad);
         TCHK(hipGetLastError());
     }
     // 5. the final, per-sequence result
-    fin = new (std::nothrow) bsk_result();
-    if (!fin) return done(BSK_ERR_NOMEM);
-    fin->ctx = ctx;
-    fin->n = n;
-    fin->kind = p_in->kind;
-    fin->has_pos = stream ? 0 : 1;
-    TCHK(hipMalloc(&fin->status, n ? n : 1));
-    TCHK(hipMalloc(&fin->wfirst, (n ? n : 1) * 8));
-    TCHK(hipMalloc(&fin->wcount, (n ? n : 1) * 8));
+    if (old && !stream && old->hash && old->pos && old->alloc_cap >= tres->n_tuples + 64) {  // (stitched kinds: the old arrays are large enough)
+        fin = old;
+        old = nullptr;
+    } else {
+        drop_old();
+        fin = new (std::nothrow) bsk_result();
+        if (!fin) return done(BSK_ERR_NOMEM);
+        fin->ctx = ctx;
+        fin->n = n;
+        fin->kind = p_in->kind;
+        fin->has_pos = stream ? 0 : 1;
+        TCHK(hipMalloc(&fin->status, n ? n : 1));
+        TCHK(hipMalloc(&fin->wfirst, (n ? n : 1) * 8));
+        TCHK(hipMalloc(&fin->wcount, (n ? n : 1) * 8));
+    }
     if (two_strand) {  // twice the room; filled after k_tile_finish (k_two_strand)
         fin->cap = fin->alloc_cap = 2 * tres->cap + 64;
         TCHK(hipMalloc(&fin->hash, fin->cap * 8));
@@ -3036,10 +3096,16 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
         tres->main_cap = 0;
         tres->ovf_cap = 0;
     } else {
-        const u64 cap = tres->n_tuples + 64;  // the stitch keeps a subset of the tile tuples
-        TCHK(hipMalloc(&fin->hash, cap * 8));
-        TCHK(hipMalloc(&fin->pos, cap * 4));
-        fin->cap = fin->alloc_cap = cap;
+        u64 cap = tres->n_tuples + 64;  // the stitch keeps a subset of the tile tuples (deferred: n_tuples is the tile result's capacity)
+        lap("flags");
+        if (fin->hash) {
+            cap = fin->alloc_cap;  // (the previous result's arrays)
+        } else {
+            TCHK(hipMalloc(&fin->hash, cap * 8));
+            TCHK(hipMalloc(&fin->pos, cap * 4));
+            fin->cap = fin->alloc_cap = cap;
+        }
+        lap("result arrays");
         TCHK(pool(9, (nt + 1) * 8, (void **)&oexcl));
         TCHK(hipMemsetAsync(oexcl, 0, (nt + 1) * 8, ctx->stream));
         if (nt) {
@@ -3081,14 +3147,31 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
                            ctx->d_total);
         TCHK(hipGetLastError());
     }
-    TCHK(hipMemcpyAsync(ctx->h_pinned, ctx->d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
-    TCHK(hipMemcpyAsync(ctx->h_pinned + 2, ctx->d_ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-    TCHK(hipStreamSynchronize(ctx->stream));
-    if (!stream && nt && ((u32 *)(ctx->h_pinned + 2))[1]) {
-        ctx->err = "tile stitch overflow";
-        return done(BSK_ERR_DEVICE);
+    if (async_final) {  // a class plan's tiled part: the totals stay on the device (k_adopt_wide reads wfirst / wcount), the flags wait in d_ticket[24]
+        hipLaunchKernelGGL(k_tile_flag_word, dim3(1), dim3(1), 0, ctx->stream, ctx->d_ticket + 20, ctx->d_ticket, ctx->d_ticket + 24);
+        TCHK(hipGetLastError());
+        fin->n_tuples = fin->cap;  // (an upper bound: what the parent reserves and copies)
+    } else {
+        TCHK(hipMemcpyAsync(ctx->h_pinned, ctx->d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+        TCHK(hipMemcpyAsync(ctx->h_pinned + 2, ctx->d_ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+        if (defer) TCHK(hipMemcpyAsync(ctx->h_pinned + 4, ctx->d_ticket + 20, 4 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+        TCHK(hipStreamSynchronize(ctx->stream));
+        const bool stitch_ovf = !stream && nt && ((u32 *)(ctx->h_pinned + 2))[1];
+        if (defer && (stitch_ovf || ((u32 *)(ctx->h_pinned + 4))[1] || ((u32 *)(ctx->h_pinned + 4))[3] || (ctx->opt.test_overflow & 8u))) {
+            // a slab, a list segment or an overflow region was too small for this batch: the old way sizes them by what the batch needs
+            if (timing) fprintf(stderr, "[tiled] deferred launch overflowed (flags %u / %u, stitch %d): again with the sizing run\n", ((u32 *)(ctx->h_pinned + 4))[1], ((u32 *)(ctx->h_pinned + 4))[3], (int)stitch_ovf);
+            (void)done(BSK_ERR_DEVICE);  // (releases `fin` and the tile batch)
+            ctx->tile_sync = true;
+            const int frc = sketch_tiled(ctx, b, p_in, circ_ext, result, warmup, iters, kernel_ms);
+            ctx->tile_sync = false;
+            return frc;
+        }
+        if (stitch_ovf) {
+            ctx->err = "tile stitch overflow";
+            return done(BSK_ERR_DEVICE);
+        }
+        fin->n_tuples = ctx->h_pinned[0];
     }
-    fin->n_tuples = ctx->h_pinned[0];
     snprintf(fin->plan, sizeof fin->plan, "%.70s (over tiles)", tres->plan);
     fin->plan_grid = tres->plan_grid;
     fin->plan_per_cu = tres->plan_per_cu;
@@ -3500,7 +3583,11 @@ static int run_classed(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
                 bsk_result_release(pt.res);
                 pt.res = nullptr;
             }
+            side->tile_async = !grow;  // (sized again after an overflow: the round-trip path, which sizes by what the batch needs)
+            side->tile_sync = grow;
             rc = sketch_tiled(side, pt.sub, p, 0, &pt.res, 0, 0, nullptr);
+            pt.async = side->tile_was_async;
+            side->tile_async = side->tile_sync = false;
             if (rc != BSK_OK) {
                 ctx->err = side->err;
                 return drop(rc);

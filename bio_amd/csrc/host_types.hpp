@@ -14,7 +14,7 @@
 // Developer switches (DESIGN.md "Switches"): read from the environment ONCE, when the context is created, or again on
 // bsk_ctx_reload_options (the test suite flips them inside one process) -- never on the bsk_sketch path.
 struct BskOpts {
-    bool force_generic = false, no_mixed = false, no_dense = false, no_pk = false, no_ring = false, no_pkd = false, no_side_early = false, no_side_dense = false, ring = false, no_bin = false, no_bin_early = false, compact = false, no_tiles = false, no_tile_cache = false, no_group_gather = false, timing = false,
+    bool force_generic = false, no_mixed = false, no_dense = false, no_pk = false, no_ring = false, no_pkd = false, no_side_early = false, no_side_dense = false, ring = false, no_bin = false, no_bin_early = false, compact = false, no_tiles = false, no_tile_cache = false, no_tile_defer = false, no_group_gather = false, timing = false,
          no_fused_translate = false, sets_no_small = false;
     int syn_margin = 2;
     u32 test_overflow = 0;   // BSK_TEST_OVERFLOW (tests): pretend an overflow flag once per call -- 1: in a timed re-run (BSK_RESIZE), 2: a class plan's part while sizing, 4: ... in a timed re-run (BSK_REPLAN_CLASS)
@@ -60,7 +60,7 @@ struct bsk_ctx {
     // class plans: the parts (the classes besides the bulk) run on a SIDE context -- a stream and scratch of their own -- so that their
     // small, latency-bound launches overlap with the bulk's kernel instead of queueing in front of it; two events order the two streams
     bsk_ctx *side = nullptr;              // created on first use, destroyed with this context
-    hipEvent_t ev_side_done = nullptr, ev_adopted = nullptr, ev_mix0 = nullptr, ev_mix1 = nullptr;
+    hipEvent_t ev_side_done = nullptr, ev_adopted = nullptr, ev_mix0 = nullptr, ev_mix1 = nullptr, ev_tiled = nullptr;
     bool adopted_recorded = false;
     struct ClassSet *cls = nullptr;       // the class plan a run_planned / launch in progress belongs to (biosketch.hip: run_classed)
     bool no_side_fast = false;            // run_planned: a staged side kernel's region overflowed, plan the general one
@@ -68,6 +68,10 @@ struct bsk_ctx {
     u64 sel_need = 0;           // two-pass syncmers: the dense region a call that is being sized again needs (run_planned)
     bool no_syn_pk = false;     // set while a call falls back from k_syncmer_pk / k_minimizer_pk (the list of reads for the exact machine filled up)
     bool no_prot_fast = false;
+    bool defer = false;         // run_planned: plan, size from the plan's own bounds, launch ONCE and read nothing back (sketch_tiled's path without host round trips: the caller looks at the flags behind its own last synchronisation)
+    bool tile_sync = false;     // sketch_tiled: the round-trip path (tile count, sizing run and totals read on the host) -- set while a call falls back after the deferred path's flags showed an overflow
+    bool tile_async = false;    // sketch_tiled on a class plan's side context: not even the last synchronisation -- totals stay on the device, the flags in d_ticket[24] (launch_parts folds them into the parent's)
+    bool tile_was_async = false;  // ... what the last sketch_tiled on this context did
     bool in_resize = false;     // a timed call that outgrew its sized regions is being sized again (once per call: run_planned_resizing)
     int cls_round = 0;          // run_classed: which sizing round of the class plan is running (tests: BSK_TEST_OVERFLOW fires in round 0 only)
     bool part_grow = false;     // ... and a class plan's parts get twice their previous overflow regions (run_classed)

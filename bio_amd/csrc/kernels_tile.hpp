@@ -103,8 +103,20 @@ struct TileTab {
     u64 *keep;    // [nt] lo | hi << 32: tile-local positions [lo, hi) belong to this tile
 };
 
+// nt may be an UPPER BOUND of the number of tiles (the path without host round trips sizes everything from n_bases / tp + n): the entries
+// from the true count tstart[n] on are empty tiles -- no bases, no owned positions -- that every later pass takes as such
 __global__ void k_tile_build(SeqTab seq, TileGeo g, const u64 *tstart, u64 nt, TileTab t, const u32 *wbits, u8 *tflags) {
+    const u64 nt_true = tstart[seq.n];
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += (u64)gridDim.x * blockDim.x) {
+        if (i >= nt_true) {
+            t.desc[i] = 0;
+            if (t.adesc) t.adesc[i] = 0;
+            t.seq[i] = 0;
+            t.shift[i] = 0;
+            t.keep[i] = 0;
+            if (tflags) tflags[i] = 0;
+            continue;
+        }
         u64 lo = 0, hi = seq.n - 1;  // largest r with tstart[r] <= i (sequences without tiles share their successor's start)
         while (lo < hi) {
             const u64 mid = (lo + hi + 1) >> 1;
@@ -144,7 +156,9 @@ __global__ void k_tile_build(SeqTab seq, TileGeo g, const u64 *tstart, u64 nt, T
 }
 
 // per-tile flags -> per-sequence accumulators: first-window tie (first tile only), first tile that met an illegal base
-__global__ void k_tile_flags(const u8 *tstatus, const u32 *tseq, const u64 *tstart, u64 nt, u32 *sflags, u64 *sbad) {
+__global__ void k_tile_flags(const u8 *tstatus, const u32 *tseq, const u64 *tstart, u64 nt, u64 nseq, u32 *sflags, u64 *sbad) {
+    const u64 nt_true = tstart[nseq];  // (nt may be an upper bound: k_tile_build)
+    if (nt > nt_true) nt = nt_true;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nt; i += (u64)gridDim.x * blockDim.x) {
         const u8 st = tstatus[i];
         const u32 r = tseq[i];

@@ -1,0 +1,14 @@
+#!/bin/bash
+cd "$(dirname "$0")/../.."
+O=gpurun_out/r6_long2
+mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_long_sequences.py tests/test_gpu_class_plans.py -x -q -m gpu > $O/pytest.txt 2>&1; tail -5 $O/pytest.txt
+TOTAL=2e9 NSEQ=400 timeout 600 python scripts/dev/perf_long2.py > $O/long.txt 2>&1
+BSK_NO_TILE_DEFER=1 TOTAL=2e9 NSEQ=400 timeout 600 python scripts/dev/perf_long2.py > $O/long_nodefer.txt 2>&1
+cat $O/long.txt $O/long_nodefer.txt
+BSK_SWEEP_OUTLIER_READS=1e8 timeout 900 python scripts/robustness_sweep.py 3e9 --only-outliers > $O/outliers.jsonl 2> $O/outliers.err
+python - <<'PY'
+import json
+for l in open("gpurun_out/r6_long2/outliers.jsonl"):
+    d = json.loads(l); print(d["case"], d["gbases_per_s"], d.get("of_uniform"), d["kernel"][:100])
+PY

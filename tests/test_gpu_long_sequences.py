@@ -414,3 +414,44 @@ def test_two_strand_kmer_codes_tile(engine, oracle, tiny_tiles):
                 continue
             assert (st & L.ST_CODE_MASK) == L.ST_OK and np.array_equal(h, e), (i, circular, len(h), len(e))
         b.close()
+
+
+@pytest.mark.parametrize("mode", ["deferred", "forced fallback", "round trips"])
+def test_tiled_path_without_host_round_trips(engine, oracle, monkeypatch, mode):
+    """Round 6: a tiled call sizes every array from a host-side bound of the tile count (n_bases / tp + n), launches the tile kernels once
+    into slabs sized by the plan and synchronises ONCE, at its end -- that synchronisation also brings the overflow flags, and a call that
+    finds one set runs again with the sizing run of rounds 2-5 (BSK_TEST_OVERFLOW=8 pretends one).  All three ways give the same result:
+    every sequence against the oracle for minimizers and syncmers, digests for the ntHash stream; sequences of very different lengths,
+    among them short ones without a tile and one below the length rule (the bound's empty tiles sit behind them)."""
+    if mode == "forced fallback":
+        monkeypatch.setenv("BSK_TEST_OVERFLOW", "8")
+    elif mode == "round trips":
+        monkeypatch.setenv("BSK_NO_TILE_DEFER", "1")
+    rng = random.Random(66)
+    seqs = [rand_seq(rng, n) for n in (5000, 31, 12000, 20, 4097, 150, 65000, 8000, 40, 300000, 9999)]
+    seqs.append("A" * 7000)
+    seqs.append("ACGTTGCA" * 900)
+    b = engine.batch(seqs)
+    for kind, pk, fn in ((L.MINIMIZER, dict(k=21, w=11), lambda q: oracle.minimizer(q, 21, 11, False, closed=True)),
+                         (L.SYNCMER, dict(k=31, s=11), lambda q: oracle.syncmer(q, 31, 11, False, closed=True))):
+        res = engine.run(b, engine.params(kind, **pk))
+        assert "over tiles" in res.plan()["kernel"], res.plan()
+        for i, q in enumerate(seqs):
+            st, h, p = res.read(i)
+            try:
+                eh, ep, es, fl = fn(q)
+            except oracle.OracleError as e:
+                assert e.name == "ErrShortSeq" and (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0, (i, len(q))
+                continue
+            assert (st & L.ST_CODE_MASK) == L.ST_OK and np.array_equal(h, eh), (mode, kind, i, len(q))
+            assert np.array_equal(p & L.POS_MASK, ep) and np.array_equal(p >> 31, es), (mode, kind, i, len(q))
+        res.close()
+    res = engine.run(b, engine.params(L.NTHASH, 21))
+    d = res.digest()
+    data = np.frombuffer("".join(seqs).encode(), np.uint8)
+    offs = np.zeros(len(seqs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(q) for q in seqs])
+    nt, ck = oracle.batch_run(2, data, offs, 21, 0, threads=1)
+    assert d["n_tuples"] == nt and d["checksum"] == ck, mode
+    res.close()
+    b.close()
