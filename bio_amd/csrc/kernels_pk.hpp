@@ -239,6 +239,12 @@ struct PkMin {
             asm volatile("v_cmp_ne_u32_e32 vcc, 0, %1\n\ts_and_saveexec_b64 %0, vcc\n\tds_write_b64 %2, %3\n\tds_write_b16 %4, %5\n\ts_mov_b64 exec, %0"
                          : "=&s"(sv) : "v"(b), "v"(a0), "v"(H[O]), "v"(a1), "v"(pv) : "vcc", "memory");
         }
+#elif defined(PK_NOPOS)  // dev (round 6, timing only): hashes-only staging -- the per-step position write and its v_add3 gone, nothing rebuilds the positions:
+        // an UPPER BOUND of what any exact form of it can gain (the review's experiment (a); PK_STRMASK adds the strand mask an exact form needs per step)
+        *reinterpret_cast<LDSQ u64 *>(lds + LY::SH + slot) = H[O];
+#ifdef PK_STRMASK
+        asm volatile("" ::"v"(pv));
+#endif
 #elif !defined(PK_NOSTAGE)  // (dev knock-outs, timing only: PK_NOSTAGE, PK_NOTIE, PK_NOTAB, PK_NOCOPY)
         *reinterpret_cast<LDSQ u64 *>(lds + LY::SH + slot) = H[O];
         *reinterpret_cast<LDSQ u16 *>(lds + LY::SP + (slot >> 2)) = (u16)pv;
