@@ -22,6 +22,7 @@
 #include "kernels_fast.hpp"
 #include "kernels_more.hpp"
 #include "fast_dispatch.hpp"
+#include "planner_table.hpp"
 #include "kernels_translate.hpp"
 #include "kernels_tile.hpp"
 #include "kernels_simhash.hpp"
@@ -687,7 +688,7 @@ static void upload_odd(bsk_ctx *ctx, bsk_batch *b) {
 static constexpr u64 kMaxPrefetchWords = 32;  // >= SynPkLdsL::NW (static_assert beside pk_syncmer_max_bases, kernels_syncmer_pk.hpp)
 // The smallest read length any kind tiles from (sketch_impl's tile_min: syncmers on the long packed plan from 448 bases, stream kinds from
 // 16 (BSK_NT_FAST_WORDS - 2) = 512): batch creation keeps the non-ACGT word bits of every batch that MAY be tiled.
-static constexpr u32 kSynTileMin = 448;
+static constexpr u32 kSynTileMin = (u32)PlannerTable::syn_tile_min_bases;
 static u32 min_tile_min(const bsk_ctx *ctx);
 static u64 pad_words(u32 maxlen) { return (u64)maxlen / 16 + kMaxPrefetchWords + 1; }
 static u32 env_u32(const char *name, u32 dflt) {
@@ -719,7 +720,7 @@ void BskOpts::load() {
     no_syn_pf = on("BSK_NO_SYN_PF");
     pf_density = env_u32("BSK_PF_DENSITY", 0);
     no_syn_long = on("BSK_NO_SYN_LONG");  // dev: reads beyond k_syncmer_pk's limits go to k_syncmer_fast as before round 4
-    syn_margin = (int)env_u32("BSK_SYN_MARGIN", 2 + 64) - 64;  // dev: rows of slack the planner wants in k_syncmer_pk's columns (BSK_SYN_MARGIN = 64 + margin)
+    syn_margin = (int)env_u32("BSK_SYN_MARGIN", (u32)PlannerTable::syn_margin_rows + 64) - 64;  // dev: rows of slack the planner wants in k_syncmer_pk's columns (BSK_SYN_MARGIN = 64 + margin)
     no_tiles = on("BSK_NO_TILES");
     no_tile_cache = on("BSK_NO_TILE_CACHE");
     no_tile_defer = on("BSK_NO_TILE_DEFER");  // dev: tiled calls with the host round trips of rounds 2-5 (tile count, sizing run, totals)
@@ -729,7 +730,7 @@ void BskOpts::load() {
     sets_no_small = on("BSK_SETS_NO_SMALL");
     wpr = env_u32("BSK_WPR", 0);
     seg = env_u32("BSK_SEG", 0);
-    dense_min = env_u32("BSK_DENSE_MIN", 21);
+    dense_min = env_u32("BSK_DENSE_MIN", (u32)PlannerTable::dense_min);
     waves_per_cu = env_u32("BSK_WAVES_PER_CU", 0);
     tile_min = env_u32("BSK_TILE_MIN", 0);
     tile_pos = env_u32("BSK_TILE_POS", 0);
@@ -1653,7 +1654,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         // fast path: 2-bit input, a window size with a compiled specialisation, positions that fit 15 bits
         // windows that select more positions per read than the slab kernel stages (32): per-read slabs + mid-read flushes
         const double nwin = (double)b->maxlen - p->k - p->w + 2;
-        const u64 dense_slab = (std::min<u64>((u64)std::max(nwin, 0.0), (u64)(std::max(nwin, 0.0) * 2.6 / (p->w + 1.0)) + 16) + 15) & ~(u64)15;
+        const u64 dense_slab = (std::min<u64>((u64)std::max(nwin, 0.0), (u64)(std::max(nwin, 0.0) * PlannerTable::slab_sel_num / (p->w + 1.0)) + PlannerTable::slab_sel_pad) + 15) & ~(u64)15;
         // k_minimizer_seg: per-read slabs of the expected count + 30 % + 4 (150 bp, w = 11: 32 tuples), rounded to 64-byte pieces
         const double exp_sel = std::max(nwin, 0.0) * 2.0 / (p->w + 1.0) + 1.0;
         [[maybe_unused]] const u64 seg_slab = (std::min<u64>((u64)std::max(nwin, 1.0), (u64)(exp_sel * 1.3) + 4) + 7) & ~(u64)7;  // (make EXPERIMENTS=1)
@@ -1665,7 +1666,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         // at w = 3 / 4 / 5 / 6 -- two or more blocks per flush round there, and the packed machine's per-block overhead weighs more on short
         // blocks --, 40 at w = 7, and 41 / 42 / 45 / 46 / 50 / 53 at w = 8 .. 13 in that sweep, 5 % of k_minimizer_pkd's rate lower since its
         // flush rounds are two blocks there: 17 + 2.5 w.  Round 4's rule, 34 + 2 w, was fitted against k_minimizer_dense.  BSK_RING_MAX overrides.)
-        const double ring_cap = ctx->opt.ring_max ? (double)ctx->opt.ring_max : p->w <= 5 ? 76.0 : p->w == 6 ? 65.0 : p->w == 7 ? 40.0 : 17.0 + 2.5 * p->w;
+        const double ring_cap = ctx->opt.ring_max ? (double)ctx->opt.ring_max : PlannerTable::ring_cap[std::min(std::max(p->w, 0), 13)];  // (planner_table.hpp: fitted per w by scripts/fit_planner.py)
         const bool ring_wins = ctx->opt.ring ? true : exp_tuples > (double)ctx->opt.dense_min && exp_tuples <= ring_cap;
 #ifdef BSK_EXPERIMENTS  // the two measured-and-rejected minimizer kernels (make EXPERIMENTS=1; NOTEBOOK round 2): never planned without their switch
         if (!use_ascii && p->w == 11 && p->k + p->w <= 65 && b->maxlen < 32768u && nwin >= 1.0 && ctx->opt.wpr && !ctx->no_dense && slab_budget_ok(b, seg_slab) &&
@@ -1689,7 +1690,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             per_cu = seg_minimizer_blocks_per_cu(p->w);
         } else
 #endif
-        if (!use_ascii && ring_minimizer_supported(p->w) && !b->alias && nwin >= 1.0 && nwin < 262144.0 && ring_wins && !ctx->opt.force_generic && !ctx->opt.no_ring &&
+        if (!use_ascii && ring_minimizer_supported(p->w) && !b->alias && nwin >= 1.0 && nwin < (double)PlannerTable::ring_nwin_max && ring_wins && !ctx->opt.force_generic && !ctx->opt.no_ring &&
             !ctx->no_syn_pk && slab_budget_ok(b, ring_rows(nwin, p->w))) {
             pl.which = K_MIN_RING;  // w <= 13: packed window machine, unit rows through a ring of staged rows (kernels_ring.hpp)
             pl.fast_w = p->w;
@@ -1716,7 +1717,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             pl.which = K_MIN_DENSE;
             pl.fast_w = p->w;
             pl.slab = true;
-            pl.slab_read = std::min<u64>((u64)nwin, (u64)(nwin * 2.6 / (p->w + 1.0)) + 16);
+            pl.slab_read = std::min<u64>((u64)nwin, (u64)(nwin * PlannerTable::slab_sel_num / (p->w + 1.0)) + PlannerTable::slab_sel_pad);
             pl.slab_read = (pl.slab_read + 15) & ~(u64)15;  // whole 128-byte lines of hashes per read
             pl.slab_unit = 64 * pl.slab_read;
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
@@ -1763,19 +1764,19 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         // (round 4, scripts/dev/perf_syn_len.py: with six, reads of 165..188 bases ran on k_syncmer_fast at 640 instead of 800-850
         // Gbases/s; with none, 195-base reads fill their columns, list a quarter of the batch and fall back after a wasted run)
         const double syn_nwin = (double)b->maxlen - 2.0 * p->k + p->s + 2.0;
-        const double syn_rows = 2.0 * (syn_nwin * 1.5 / (p->k - p->s + 1.0) + 0.5) + (double)ctx->opt.syn_margin;
+        const double syn_rows = 2.0 * (syn_nwin * PlannerTable::syn_sel_num / (p->k - p->s + 1.0) + 0.5) + (double)ctx->opt.syn_margin;
         auto syn_pk_fits = [&](bool lng) {
             // (the long plan: an eighth more than the short plan's rule, the spread of a pair's count grows with the count.  k=31 s=11,
             // scripts/dev/perf_syn_long.py: 250 / 300 / 350 / 380-base reads 818 / 750 / 759 / 680 Gbases/s -- at 380 the columns begin
             // to fill -- against 635 / 597 / 604 / 416 on k_syncmer_fast; 400-base reads want 59.3 of the 58 rows and stay there)
-            const double want = lng ? syn_rows + 0.12 * (syn_rows - (double)ctx->opt.syn_margin) : syn_rows;
+            const double want = lng ? syn_rows + PlannerTable::syn_long_spread * (syn_rows - (double)ctx->opt.syn_margin) : syn_rows;
             return pk_syncmer_supported(p->k - p->s, lng) && b->maxlen <= pk_syncmer_max_bases(lng) && want <= (double)pk_syncmer_pair_rows(lng);
         };
         const bool syn_short = syn_pk_fits(false), syn_lng = !syn_short && !ctx->opt.no_syn_long && syn_pk_fits(true);
         // small s: equal s-mers inside one 2w window are the rule (s = 7: 8 192 canonical values, half of the 150-base reads hold such a
         // pair), every such read is the exact machine's, the list (a quarter of the batch) fills up and the call falls back after a
         // wasted run.  Expected pairs per read = windows x 2w x 2 / 4^s; beyond 0.2 the packed kernels are not planned.
-        const bool syn_ties = std::max(syn_nwin, 0.0) * 4.0 * (p->k - p->s) / std::pow(4.0, (double)std::min(p->s, 24)) > 0.2;
+        const bool syn_ties = std::max(syn_nwin, 0.0) * 4.0 * (p->k - p->s) / std::pow(4.0, (double)std::min(p->s, 24)) > PlannerTable::syn_tie_pairs_max;
 #ifdef BSK_EXPERIMENTS
         // the two-pass plan (kernels_syncmer_sel.hpp): selection by the packed s-mer machine, then ONLY the selected k-mers are hashed -- no
         // staging columns, so neither the rows-per-pair rule above nor column overflows apply: any read whose words fit the registers.
@@ -1801,9 +1802,9 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
         // registers, whose blocks fit the mask rows, k <= 64 (the emit's window) and <= BSK_PF_TCAP / 64 expected selections per read
         const u32 syn_ns_max = b->maxlen >= (u32)p->s ? b->maxlen - (u32)p->s + 1u : 0u;
         auto syn_pf_fits = [&](bool lng) {  // (expected selections per read with a seventh of room below what a unit's emit phase takes)
-            const double dens = std::max(syn_nwin, 0.0) * 1.5 / (p->k - p->s + 1.0);
-            const double dmax = ctx->opt.pf_density ? (double)ctx->opt.pf_density : (double)pf_syncmer_unit_tuples(lng) / 64.0 * 0.86;
-            return !ctx->opt.no_syn_pf && pf_syncmer_supported(p->k - p->s, lng) && b->maxlen <= pf_syncmer_max_bases(lng) && p->k <= 64 &&
+            const double dens = std::max(syn_nwin, 0.0) * PlannerTable::syn_sel_num / (p->k - p->s + 1.0);
+            const double dmax = ctx->opt.pf_density ? (double)ctx->opt.pf_density : (double)pf_syncmer_unit_tuples(lng) / 64.0 * PlannerTable::pf_list_fill;
+            return !ctx->opt.no_syn_pf && pf_syncmer_supported(p->k - p->s, lng) && b->maxlen <= pf_syncmer_max_bases(lng) && p->k <= PlannerTable::pf_k_max &&
                    (syn_ns_max + (u32)(p->k - p->s) - 1u) / (u32)(p->k - p->s) <= pf_syncmer_mask_rows(lng) + 1u && dens <= dmax;
         };
         const bool syn_pf_short = syn_pf_fits(false), syn_pf_long = !syn_pf_short && !ctx->opt.no_syn_long && syn_pf_fits(true);
@@ -2822,7 +2823,7 @@ static bool syn_long_plan_ok(const bsk_ctx *ctx, const bsk_params *p) {
 static u32 tile_positions(const bsk_ctx *ctx, const bsk_params *p, u64 n_bases, u64 maxlen) {
     u32 tp;
     if (p->kind == BSK_MINIMIZER || p->kind == BSK_PROT_MINIMIZER) {
-        tp = 16u * std::max<u32>(2, (u32)(22.0 * (p->w + 1.0) / 2.0 / 16.0));
+        tp = 16u * std::max<u32>(2, (u32)((double)PlannerTable::tile_min_tuples * (p->w + 1.0) / 2.0 / 16.0));
         // windows only k_minimizer_fast takes (w >= 17): its lanes stage in PAIRS of reads sharing a 56-row column, and a tile of 22 owned
         // tuples carries 25 with its overlap -- 50 +- 5 per pair, a tenth of the pairs over, i.e. every unit run again with direct stores
         // (w = 20, 700-base reads over such tiles: 288 Gbases/s).  20 expected tuples per tile instead.
@@ -2845,14 +2846,14 @@ static u32 tile_positions(const bsk_ctx *ctx, const bsk_params *p, u64 n_bases, 
             // run_tilepos.sh: with fewer than ~300 000 the larger tile loses: 2 10^7 bases 0.45 ms on 96-position tiles, 0.7 on 512)
             if (pkd_minimizer_supported(p->w) && !ctx->opt.no_pkd && !ctx->opt.no_dense && !ctx->no_dense && !ctx->no_syn_pk)
                 for (u32 big = 1024; big >= 256; big >>= 1)
-                    if (n_bases / big >= 300000ULL) {
+                    if (n_bases / big >= (u64)PlannerTable::tile_big_tiles_min) {
                         tp = big;
                         break;
                     }
         }
     }
     else if (p->kind == BSK_SYNCMER) {
-        tp = 16u * std::max<u32>(2, (u32)(11.0 * (p->k - p->s + 1.0) / 2.0 / 16.0));
+        tp = 16u * std::max<u32>(2, (u32)((double)PlannerTable::tile_syn_tuples * (p->k - p->s + 1.0) / 2.0 / 16.0));
         // round 4: k_syncmer_pkl takes tiles three times as long at 0.9 of the rate, and a tile carries 3k + 16 bases of overlap: at k=31
         // s=11 tiles of 112 + 109 bases spend half of the kernel on overlaps, tiles of 224 + 109 a third (~21 expected selections
         // per tile: where the long plan's rate is still flat, scripts/dev/perf_syn_long.py)
@@ -3236,16 +3237,17 @@ static bool class_sig(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, u64
 }
 // rough kernel rates in Tbases/s (profiles/r04/robustness.jsonl): only their ratios matter -- is splitting worth its passes?
 static double class_rate(const ClassSig &g, double meanlen, bool tiled, int kind) {
-    if (tiled || g.which == -2) return kind == BSK_SYNCMER ? 0.25 : 0.19;
+    // (planner_table.hpp: the rates of profiles/r06/planner_sweep.jsonl)
+    if (tiled || g.which == -2) return PlannerTable::rate(kind == BSK_SYNCMER ? "TILED_SYN" : "TILED_MIN", meanlen);
     switch ((Which)g.which) {
-        case K_MIN_PK: return 1.2;
-        case K_MIN_RING: return meanlen <= 170 ? 1.06 : meanlen <= 260 ? 0.93 : 0.8;  // (150-base reads in a batch planned for its 250-base ones: 1 053 against 1 190 on k_minimizer_pk, profiles/r05)
-        case K_MIN_DENSE: return 0.7;
-        case K_MIN_PKD: return 0.78;
-        case K_MIN_FAST: return 0.75;
-        case K_SYN_PK: return g.syn_fused ? (g.syn_long ? 0.95 : 1.15) : g.syn_long ? 0.8 : 0.93;
-        case K_SYN_FAST: return meanlen <= 448 ? 0.6 : 0.15;
-        default: return 0.09;
+        case K_MIN_PK: return PlannerTable::rate("K_MIN_PK", meanlen);
+        case K_MIN_RING: return PlannerTable::rate("K_MIN_RING", meanlen);
+        case K_MIN_DENSE: return PlannerTable::rate("K_MIN_DENSE", meanlen);
+        case K_MIN_PKD: return PlannerTable::rate("K_MIN_PKD", meanlen);
+        case K_MIN_FAST: return PlannerTable::rate("K_MIN_FAST", meanlen);
+        case K_SYN_PK: return PlannerTable::rate(g.syn_fused ? (g.syn_long ? "K_SYN_PFL" : "K_SYN_PF") : g.syn_long ? "K_SYN_PKL" : "K_SYN_PK", meanlen);
+        case K_SYN_FAST: return PlannerTable::rate("K_SYN_FAST", meanlen);
+        default: return PlannerTable::rate("OTHER", meanlen);
     }
 }
 struct ClassCut {

@@ -26,7 +26,7 @@ struct BskOpts {
     u32 class_min = 16384;   // BSK_CLASS_MIN: batches below this many reads keep one plan
     bool class_view = false;   // BSK_CLASS_VIEW: class plans always cut on the device (k_class_cut + a view of the batch), also where the host's list would do
     bool class_force = false;  // BSK_CLASS_FORCE: cut wherever the planner's choice changes, whatever the cost model says (tests: small batches)
-    u32 wpr = 0, seg = 0, dense_min = 21, ring_max = 0, bin_min = 1024, waves_per_cu = 0, tile_min = 0, tile_pos = 0;  // tile_min 0: the kind's default
+    u32 wpr = 0, seg = 0, dense_min = 21 /* PlannerTable::dense_min */, ring_max = 0, bin_min = 1024, waves_per_cu = 0, tile_min = 0, tile_pos = 0;  // tile_min 0: the kind's default
     void load();  // biosketch.hip
 };
 

@@ -139,3 +139,20 @@ def test_developer_switches_are_read_once_per_context():
             a, b = text.index("static u32 env_u32("), text.index('extern "C" int bsk_ctx_reload_options')
             body = text[:a] + text[b:]
         assert "getenv" not in body, fn
+
+
+def test_planner_table_is_generated_from_the_committed_sweep():
+    """bio_amd/csrc/planner_table.hpp (every threshold of the planner, with the measurement it came from) is what scripts/fit_planner.py
+    makes of profiles/r06/planner_sweep.jsonl -- an edited header or a changed sweep file without the regeneration fails here -- and the
+    planner's sources carry no ring / slab / syncmer / tile threshold of their own any more."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "fit_planner.py"), "--check"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    src = open(os.path.join(root, "bio_amd", "csrc", "biosketch.hip")).read()
+    assert "PlannerTable::ring_cap" in src and "17.0 + 2.5 * p->w" not in src and "* 2.6 / (p->w + 1.0)" not in src
+    hdr = open(os.path.join(root, "bio_amd", "csrc", "planner_table.hpp")).read()
+    for name in ("ring_cap", "dense_min", "slab_sel_num", "syn_sel_num", "syn_long_spread", "syn_tie_pairs_max", "pf_list_fill", "tile_min_tuples", "tile_big_tiles_min", "rates"):
+        assert name in hdr, name
