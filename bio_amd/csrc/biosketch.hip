@@ -1551,7 +1551,7 @@ static int ensure_binned(bsk_ctx *ctx, const bsk_batch *b, u32 lo, u32 gran, u32
 // rows (150 bp, w = 11: 32 rows).  A read with more goes to the exact machine's list.
 static u64 ring_rows(double nwin, int w) {
     const double nw = std::max(nwin, 1.0);
-    return ((u64)std::min(nw, std::ceil(nw * 2.6 / (w + 1.0)) + 6.0) + 3) & ~(u64)3;
+    return ((u64)std::min(nw, std::ceil(nw * PlannerTable::slab_sel_num / (w + 1.0)) + 6.0) + 3) & ~(u64)3;
 }
 
 #define BSK_RESIZE (-1001)         // internal: a timed re-run outgrew the regions the result was sized with (run_planned_resizing sizes again, once)
@@ -1889,7 +1889,7 @@ static int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, 
             const u64 nwin = plen >= (u32)(p->k + p->w) ? (u64)plen - p->k - p->w + 2 : 1;
             // mean 2/(w+1) of the windows, +30 % + 16 (+ 8 until round 5: 2 10^7 sequences of 100 residues at k = 8 w = 8 -- 19 +- 3 tuples in a
             // slab of 32 -- had one sequence over, and the whole batch fell back to the general kernel: 72 instead of 530 G residues/s)
-            pl.slab_read = std::min<u64>(nwin, (u64)(nwin * 2.6 / (p->w + 1.0)) + 16);
+            pl.slab_read = std::min<u64>(nwin, (u64)(nwin * PlannerTable::slab_sel_num / (p->w + 1.0)) + PlannerTable::slab_sel_pad);
             pl.slab_read = (pl.slab_read + 15) & ~(u64)15;  // whole 128-byte lines of hashes per sequence
             pl.slab_unit = 64 * pl.slab_read;
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
@@ -2555,13 +2555,13 @@ static u64 estimate_cap_n(const bsk_params *p, u64 bases, u64 nreads) {
         case BSK_MINIMIZER:
         case BSK_PROT_MINIMIZER: {
             if (p->w <= 1) return bases + 64;
-            double d = 2.6 / (p->w + 1.0);
+            double d = PlannerTable::slab_sel_num / (p->w + 1.0);
             if (d > 1.0) d = 1.0;
             return (u64)(bases * d) + nreads + 1024;
         }
         case BSK_SYNCMER: {
             if (p->s == p->k) return bases + 64;
-            double d = 2.6 / (p->k - p->s + 1.0);
+            double d = PlannerTable::slab_sel_num / (p->k - p->s + 1.0);
             if (d > 1.0) d = 1.0;
             return (u64)(bases * d) + nreads + 1024;
         }
