@@ -13,7 +13,7 @@ import bench  # noqa: E402  (WORKLOADS table)
 
 # the sketch kernel family each workload's plan lands on (only used to pick that kernel's rows out of the CSVs; the full
 # instantiated name is read from the rows themselves)
-FAMILY = {"min": "k_minimizer_pk<", "nt": "k_nthash_fast", "syn": "k_syncmer_pk<", "pmin": "k_prot_minimizer_fast", "kmer": "k_nthash_fast",
+FAMILY = {"min": "k_minimizer_pk<", "nt": "k_nthash_fast", "syn": "k_syncmer_pf<", "pmin": "k_prot_minimizer_fast", "kmer": "k_nthash_fast",
           "phash": "k_prot_hash_fast", "sim": "k_simhash_fast"}
 
 out_dir, workloads = sys.argv[1], sys.argv[2].split()
@@ -25,7 +25,7 @@ for cand in (os.path.join(out_dir, "valu_model.json"), os.path.join(os.path.dirn
 entries = []
 for w in workloads:
     kind, n_reads = bench.WORKLOADS[w][0], bench.WORKLOADS[w][1]
-    kname = "k_minimizer_ring<" if w == "minimizer250" else "k_minimizer_pkd<" if w == "minimizer400" else "k_syncmer_pkl<" if w == "syncmer250" else FAMILY[kind]  # (reads of ~160-280 bases are planned on the unit-row kernel; syncmers of 190+ bases on the long packed plan)
+    kname = "k_minimizer_ring<" if w == "minimizer250" else "k_minimizer_pkd<" if w == "minimizer400" else "k_syncmer_pfl<" if w == "syncmer250" else FAMILY[kind]  # (reads of ~160-280 bases are planned on the unit-row kernel; syncmers of 190+ bases on the long packed plan)
     full = {"name": None}
 
     def mean_counter(path, counter):
@@ -65,7 +65,7 @@ for w in workloads:
                 "simd_cycles": simd_cycles, "frac": round(vi * vm["cycles_per_inst"] / simd_cycles, 4),
                 "issue_cycles_per_unit": round(vi * vm["cycles_per_inst"] / units, 5), "insts_per_unit": round(vi / units, 4),
                 "shader_clock_GHz": round(gui / 8 / (kms * 1e-3) / 1e9, 3) if kms else None}
-    entries.append({"workload": w, "reads_per_gpu": n_reads, "kernel": full["name"], "valu": valu,
+    entries.append({"workload": w, "reads_per_gpu": n_reads, "kernel": full["name"], "valu": valu, "commit": os.environ.get("BSK_BENCH_COMMIT"),
                     "SQ_ACTIVE_INST_VALU": va, "GRBM_GUI_ACTIVE_sum_over_xcds": gui, "FETCH_SIZE_KiB_mean": round(f), "WRITE_SIZE_KiB_mean": round(wr),
                     "fetch_bytes_corrected": int(f * 1024 * 2), "write_bytes": int(wr * 1024), "hbm_bytes_per_launch": int(f * 2048 + wr * 1024),
                     "rocprof_kernel_ms_avg": kms})

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): rocprofv3 kernel stats + HBM counter passes + the bench line of every workload.
+# BSK_BENCH_COMMIT=<git rev-parse --short HEAD> (the GPU box gets a snapshot without .git): recorded in traffic.json and in every bench line.
 # usage: scripts/profile_round.sh r01 "minimizer nthash syncmer protmin kmer prothash"
 # Results land in gpurun_out/<round>/ ; copy them into profiles/<round>/ afterwards.
 set -u
@@ -24,7 +25,7 @@ for w in $WORKLOADS; do
   tail -3 /tmp/prof_$w.log > "$OUT/bench_${w}_rocprof_tail.log"
 done
 cd "$REPO"
-cp "$(ls profiles/r*/valu_model.json | tail -1)" "$OUT/valu_model.json" 2>/dev/null  # (the VALU issue-cost model travels with the round it was last measured in)
+cp "profiles/$ROUND/valu_model.json" "$OUT/valu_model.json" 2>/dev/null || cp "$(ls profiles/r*/valu_model.json | tail -1)" "$OUT/valu_model.json" 2>/dev/null  # (the VALU issue-cost model: scripts/valu_model.py on the build container, committed with the round before the collection)
 python scripts/profile_post.py "$OUT" "$WORKLOADS" && mkdir -p profiles/$ROUND && cp "$OUT/traffic.json" profiles/$ROUND/traffic.json
 for w in $WORKLOADS; do
   python bench.py --workload $w --steps 20 --warmup 3 > "$OUT/BENCH_${w}_n1.json" 2> "$OUT/BENCH_${w}_n1.err" || true

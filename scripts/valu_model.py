@@ -29,7 +29,9 @@ WIDE = re.compile(r"^v_(mad_u64_u32|mad_i64_i32|lshl_add_u64|mul_lo_u32|mul_hi_u
 KERNELS = {
     "minimizer": ("k_minimizer_pk.hip", ["-DBSK_PK_WS(X)=X(11)"], "k_minimizer_pkILi11ELb0"),
     "minimizer400": ("k_minimizer_pkd.hip", ["-DBSK_PKD_WS(X)=X(11)"], "k_minimizer_pkdILi11"),
-    "syncmer": ("k_syncmer_pk.hip", ["-DBSK_SYNPK_WS(X)=X(20)"], "k_syncmer_pkILi20"),
+    "minimizer250": ("k_minimizer_ring.hip", ["-DBSK_RING_WS(X)=X(11)"], "k_minimizer_ringILi11ELi3ELb1"),
+    "syncmer": ("k_syncmer_pf.hip", ["-DBSK_SYNPF_WS(X)=X(20)", "-DBSK_SYNPFL_WS(X)="], "k_syncmer_pfILi20"),
+    "syncmer250": ("k_syncmer_pf.hip", ["-DBSK_SYNPF_WS(X)=", "-DBSK_SYNPFL_WS(X)=X(20)"], "k_syncmer_pflILi20"),
     "nthash": ("biosketch.hip", [], "k_nthash_fastILi1"),
     "kmer": ("biosketch.hip", [], "k_nthash_fastILi2"),
     "simhash": ("biosketch.hip", [], "k_simhash_fastILi5ELi12"),
