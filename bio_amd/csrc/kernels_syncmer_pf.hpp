@@ -117,10 +117,21 @@ __device__ __forceinline__ PfHash pf_hash_kmer(LDSQ const char *lds, u32 o, u32 
         h0 = __builtin_amdgcn_alignbit(q1, q0, sh);
         h1 = __builtin_amdgcn_alignbit(q2, q1, sh);
     }
+    auto one = [&](const u32x4 &x) {
+        const u32 nfl = __builtin_amdgcn_alignbit(fl, fh, 31) ^ x.x, nfh = __builtin_amdgcn_alignbit(fh, fl, 31) ^ x.y;  // rol(f, 1)
+        fl = nfl;
+        fh = nfh;
+        const u32 tl = al ^ x.z, th = ah ^ x.w;
+        al = __builtin_amdgcn_alignbit(th, tl, 1);
+        ah = __builtin_amdgcn_alignbit(tl, th, 1);
+    };
+    u32x4 xs0 = {0, 0, 0, 0}, xs1 = {0, 0, 0, 0};  // bases 30 and 31 of the last window: requested WITH its ten rows (k = 31 or 32, 61 or 62: no read of their own behind the chain)
     for (u32 sg = 0; sg < nseg; ++sg) {
         if (sg) window(idx + 30u * sg, h0, h1);
         const u32 mid = __builtin_amdgcn_alignbit(h1, h0, 24);  // bases 12..27
         u32x4 xa[5], xb[5];
+        xs0 = *reinterpret_cast<const LDSQ u32x4 *>(lds + LY::KT1 + ((h1 >> 24) & 0x30u));
+        xs1 = *reinterpret_cast<const LDSQ u32x4 *>(lds + LY::KT1 + ((h1 >> 26) & 0x30u));
         rows_of((h0 << 4) & 0x3f0u, (h0 >> 2) & 0x3f0u, xa[0], xb[0]);
         rows_of((h0 >> 8) & 0x3f0u, (h0 >> 14) & 0x3f0u, xa[1], xb[1]);
         rows_of((mid << 4) & 0x3f0u, (mid >> 2) & 0x3f0u, xa[2], xb[2]);
@@ -129,12 +140,12 @@ __device__ __forceinline__ PfHash pf_hash_kmer(LDSQ const char *lds, u32 o, u32 
 #pragma unroll
         for (int q = 0; q < 5; ++q) six(xa[q], xb[q]);
     }
-    if (rem) {
+    if (nseg && rem && rem <= 2u) {  // (the last window still holds them)
+        one(xs0);
+        if (rem == 2u) one(xs1);
+    } else if (rem) {
         u32 t0, t1;
-        if (nseg && rem <= 2u) {  // (the last window still holds them: bases 30, 31)
-            t0 = h1 >> 28;
-            t1 = 0;
-        } else if (nseg) {
+        if (nseg) {
             window(idx + 30u * nseg, t0, t1);
         } else {
             t0 = h0;
@@ -162,13 +173,8 @@ __device__ __forceinline__ PfHash pf_hash_kmer(LDSQ const char *lds, u32 o, u32 
             rem -= 3u;
         }
         for (; rem; --rem) {
-            const u32x4 x = *reinterpret_cast<const LDSQ u32x4 *>(lds + LY::KT1 + ((t0 << 4) & 0x30u));
-            const u32 nfl = __builtin_amdgcn_alignbit(fl, fh, 31) ^ x.x, nfh = __builtin_amdgcn_alignbit(fh, fl, 31) ^ x.y;  // rol(f, 1)
-            fl = nfl;
-            fh = nfh;
-            const u32 tl = al ^ x.z, th = ah ^ x.w;
-            al = __builtin_amdgcn_alignbit(th, tl, 1);
-            ah = __builtin_amdgcn_alignbit(tl, th, 1);
+            const u32x4 x1 = *reinterpret_cast<const LDSQ u32x4 *>(lds + LY::KT1 + ((t0 << 4) & 0x30u));
+            one(x1);
             t0 >>= 2;
         }
     }
