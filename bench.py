@@ -53,14 +53,14 @@ WORKLOADS = {
     # off the headline point (the same 1.5e10 bases): the unit-row kernel's length range (scripts/robustness_sweep.py has the rest)
     "minimizer250": ("min", 60_000_000, 250, 21, 11, "60M x 250 bp reads, minimizer sketch k=21 w=11 (the configs[2] parameters on longer reads)"),
     "minimizer400": ("min", 37_500_000, 400, 21, 11, "37.5M x 400 bp reads, minimizer sketch k=21 w=11 (the configs[2] parameters beyond the unit-row kernel's reach: k_minimizer_pkd, DESIGN.md 3.1c)"),
-    "syncmer250": ("syn", 60_000_000, 250, 31, 11, "60M x 250 bp reads, syncmer sketch k=31 s=11 (the configs[3] parameters on longer reads: k_syncmer_pkl, DESIGN.md 3.3a)"),
+    "syncmer250": ("syn", 60_000_000, 250, 31, 11, "60M x 250 bp reads, syncmer sketch k=31 s=11 (the configs[3] parameters on longer reads: k_syncmer_pfl, DESIGN.md 3.3)"),
 }
 NOTES = {
     "min": "bound by the in-order instruction issue of two waves per SIMD (eight waves per CU: LDS staging) with the board's power cap as a second ceiling 5-8 % "
            "above it -- the three-wave kernel (k_minimizer_ring) needs 8 % fewer cycles and is clocked 9 % lower; `power` holds this run's board watts and clock "
            "(every kernel of the library draws 1.26-1.38 kW of the 1.4 kW cap; DESIGN.md 3.1) -- not by HBM; the VALU pipe is ~0.6 full",
     "nt": "HBM-write bound (DESIGN.md 3.2); a plain 16 B/lane fill kernel reaches 5.2-5.9 TB/s on this part",
-    "syn": "integer-VALU bound (two rolling hashes + a 2(k-s) window per base; DESIGN.md 3.3)",
+    "syn": "integer-VALU bound: k_syncmer_pf -- the rolling s-mer hash + a 2(k-s) window per base, then the ~7 selected k-mers of a read hashed from scratch at the end of every unit (round 6; DESIGN.md 3.3)",
     "pmin": "integer-VALU bound (wyhash from scratch per residue: 8 v_mad_u64_u32; DESIGN.md 3.4)",
     "kmer": "HBM-write bound, same streaming kernel as ntHash (DESIGN.md 3.2)",
     "phash": "HBM-write bound (DESIGN.md 3.4)",
@@ -287,6 +287,18 @@ def measured_profile(workload: str, n_reads: int):
                 if e.get("workload") == workload and e.get("reads_per_gpu") == n_reads:
                     best = dict(e, profile=d)
     return best
+
+
+def same_kernel(profiled: str, planned: str) -> bool:
+    """The profiled instantiation (rocprofv3's full name, e.g. k_minimizer_ring<11,3,true>) against the plan's name (the planner prints the
+    arguments a reader needs: k_minimizer_ring<11,true>): same family, and the plan's arguments appear in order among the profiled ones."""
+    import re
+    planned = planned.split(" ")[0]
+    if profiled.split("<")[0] != planned.split("<")[0]:
+        return False
+    pa = re.findall(r"[\w-]+", profiled.partition("<")[2])
+    it = iter(pa)
+    return all(any(a == b for b in it) for a in re.findall(r"[\w-]+", planned.partition("<")[2]))
 
 
 def plumbing_counters(rank: int):
@@ -540,7 +552,7 @@ def main():
                 "valu": prof.get("valu") if prof else None,
                 "binding_ceiling": (("valu-issue" if (prof.get("valu") or {}).get("frac", 0) > achieved / HBM_PEAK_GBS else "hbm") if prof and prof.get("valu") else None),
                 "profile": ({"dir": "profiles/" + prof["profile"], "kernel": prof.get("kernel"), "commit": prof.get("commit"), "this_run_commit": git_commit(),
-                             "kernel_matches_this_run": prof.get("kernel", "").split("<")[0] == kern.split("<")[0] and (prof.get("kernel", "") in kern or kern in prof.get("kernel", ""))}
+                             "kernel_matches_this_run": same_kernel(prof.get("kernel", ""), kern)}
                             if prof else None),
                 "note": NOTES[kind] + "; frac is vs the 8 TB/s spec peak; read_only_frac = input bytes alone over the same peak "
                                       "(north_star's 'HBM-read roofline'); `bound`/`achieved`/`peak` are the HBM roofline of the contract; `valu` is the VALU-issue "
