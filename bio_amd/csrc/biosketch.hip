@@ -2650,7 +2650,13 @@ static int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, in
             if (ctx->defer) HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket + 20, 0, 4 * sizeof(u32), ctx->stream));
             break;
         }
-        if (ctx->defer) {  // nothing is read back: the launch's flags are parked where later passes leave them alone, the caller looks at them
+        // (deferred only where what the launch leaves behind is in range WHATEVER it overflowed: slab kernels -- a read's reference word names its
+        // own slab -- and the stream kinds, whose counts follow from the lengths.  The dense look-back kernels size by an estimate, and after an
+        // undershoot their reference words point past the arrays: the stitch pass would follow them -- the memory fault of fuzz seed 21002744's
+        // neighbourhood, round 6.  They take the sizing loop below; the caller's bound-sized tile table serves either way.)
+        const bool defer_now = ctx->defer && (pl.slab || !kind_has_pos(p->kind));
+        if (ctx->defer && !defer_now) HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket + 20, 0, 4 * sizeof(u32), ctx->stream));
+        if (defer_now) {  // nothing is read back: the launch's flags are parked where later passes leave them alone, the caller looks at them
             HIPCHK(ctx, hipMemcpyAsync(ctx->d_ticket + 20, ctx->d_ticket, 4 * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
             res->n_tuples = res->cap;  // (an upper bound; the caller sizes by it)
             plan_record(res, b, p, circ_ext, pl);
@@ -3119,6 +3125,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
             sa.nt = nt;
             sa.nunits = tunits;
             sa.trefs = tres->refs;
+            sa.tcap = tres->alloc_cap ? tres->alloc_cap : tres->cap;
             sa.thash = tres->hash;
             sa.tpos = tres->pos;
             sa.shift = tt.shift;

@@ -171,6 +171,7 @@ struct StitchArgs {
     u64 nt;
     u32 nunits;          // ceil(nt / 64)
     const u64 *trefs;    // tile results
+    u64 tcap;            // tuples the tile result's arrays hold: a reference word that names more (a launch that overflowed and was not sized again) counts as empty and raises the flag
     const u64 *thash;
     const u32 *tpos;
     const u64 *shift, *keep;
@@ -208,6 +209,10 @@ __global__ __launch_bounds__(64) void k_tile_stitch(StitchArgs a) {
                 first = BSK_REF_FIRST(ref);
                 cnt = (u32)(ref & 0xffffffULL);
                 stride = (u32)BSK_REF_STRIDE(ref);
+                if (cnt && first + (u64)(cnt - 1u) * stride >= a.tcap) {
+                    cnt = 0;
+                    atomicOr(&a.ticket[1], 1u);
+                }
                 lo = (u32)kp;
                 hi = (u32)(kp >> 32);
                 sh = a.shift[t];
