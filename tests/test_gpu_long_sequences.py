@@ -416,7 +416,7 @@ def test_two_strand_kmer_codes_tile(engine, oracle, tiny_tiles):
         b.close()
 
 
-@pytest.mark.parametrize("mode", ["deferred", "forced fallback", "round trips"])
+@pytest.mark.parametrize("mode", ["deferred", "forced fallback", "round trips", "general kernels"])
 def test_tiled_path_without_host_round_trips(engine, oracle, monkeypatch, mode):
     """Round 6: a tiled call sizes every array from a host-side bound of the tile count (n_bases / tp + n), launches the tile kernels once
     into slabs sized by the plan and synchronises ONCE, at its end -- that synchronisation also brings the overflow flags, and a call that
@@ -427,10 +427,17 @@ def test_tiled_path_without_host_round_trips(engine, oracle, monkeypatch, mode):
         monkeypatch.setenv("BSK_TEST_OVERFLOW", "8")
     elif mode == "round trips":
         monkeypatch.setenv("BSK_NO_TILE_DEFER", "1")
+    elif mode == "general kernels":
+        # the dense look-back kernels size their output by an ESTIMATE; the homopolymer and the repeat below select far more than it, so the first
+        # launch overflows and (before the fix) its reference words pointed past the arrays -- which the deferred path handed to the stitch pass:
+        # a memory fault (scripts/fuzz_campaign.py 21000000 12000, round 6).  Such plans keep the sizing loop now.
+        monkeypatch.setenv("BSK_FORCE_GENERIC", "1")
     rng = random.Random(66)
     seqs = [rand_seq(rng, n) for n in (5000, 31, 12000, 20, 4097, 150, 65000, 8000, 40, 300000, 9999)]
     seqs.append("A" * 7000)
     seqs.append("ACGTTGCA" * 900)
+    if mode == "general kernels":
+        seqs += ["C" * 30000, "GT" * 20000, "A" * 50000]
     b = engine.batch(seqs)
     for kind, pk, fn in ((L.MINIMIZER, dict(k=21, w=11), lambda q: oracle.minimizer(q, 21, 11, False, closed=True)),
                          (L.SYNCMER, dict(k=31, s=11), lambda q: oracle.syncmer(q, 31, 11, False, closed=True))):
