@@ -723,6 +723,7 @@ void BskOpts::load() {
     syn_margin = (int)env_u32("BSK_SYN_MARGIN", (u32)PlannerTable::syn_margin_rows + 64) - 64;  // dev: rows of slack the planner wants in k_syncmer_pk's columns (BSK_SYN_MARGIN = 64 + margin)
     no_tiles = on("BSK_NO_TILES");
     no_tile_cache = on("BSK_NO_TILE_CACHE");
+    tile_dense = on("BSK_TILE_DENSE");  // minimizers of long sequences by the dense tile kernel (k_minimizer_pft: final tuples, no stitch pass).  Exact, and measured no faster than slabs + k_tile_stitch (6.3 against 5.9 ms for 2 10^9 bases -- its from-scratch emit is VALU the stitch pass pays in HBM time): opt-in
     no_tile_defer = on("BSK_NO_TILE_DEFER");  // dev: tiled calls with the host round trips of rounds 2-5 (tile count, sizing run, totals)
     no_group_gather = on("BSK_NO_GROUP_GATHER");  // dev: bsk_result_compact / _fetch_narrow with one (part of a) wavefront per sequence, as before round 4
     timing = on("BSK_TIMING");
@@ -2907,6 +2908,17 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     geo.w = p->kind == BSK_SYNCMER ? p->k - p->s : p->w;
     geo.s = p->s;
     geo.tp = tile_positions(ctx, p, b->n_bases, b->maxlen);
+    // Dense tiles (round 6, kernels_minimizer_pf.hpp): the tile kernel writes the final tuples -- owned positions only, shifted, every unit
+    // packed behind the one before through a decoupled look-back -- and no stitch pass runs.  Its tiles are sized by its own limits: 160
+    // bases of a tile in LDS (tp + 2w + k + 16), 16 blocks of W k-mers (tp + 2w + 16 <= 16 w), 86 % of the emit list (64 tp 2 / (w + 1) <= 1 100).
+    u32 dense_tp = 0;
+    if (p->kind == BSK_MINIMIZER && !syn_all && pft_minimizer_supported(p->w) && p->k <= PlannerTable::pf_k_max && ctx->opt.tile_dense && !ctx->opt.force_generic &&
+        !ctx->opt.no_pk && !ctx->opt.tile_pos) {
+        const long long la = (long long)pft_minimizer_max_tile_bases() - 16 - 2LL * p->w - p->k, lb = ((long long)pft_minimizer_mask_rows() - 3) * p->w - 13,  // (nk <= tp + 2w + 14 k-mers in at most 16 blocks of w)
+                        lc = (long long)((double)pft_minimizer_unit_tuples() * PlannerTable::pf_list_fill / 64.0 * (p->w + 1.0) / 2.0);
+        const long long t = std::min(la, std::min(lb, lc)) & ~15LL;
+        if (t >= 32) dense_tp = (u32)t;
+    }
     geo.circ_ext = circ_ext;
     geo.syn_all = syn_all ? 1 : 0;
     const bool stream = !kind_has_pos(p->kind);
@@ -2986,6 +2998,8 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     // the call's last one, which also brings the overflow flags: a call that finds one set runs again the old way (tile_sync).  Batches
     // with a non-ACGT letter (per-tile flags pick the side launch's tiles), proteins and the two-strand k-mer mode keep the round trips.
     const bool defer = !ctx->opt.no_tile_defer && !ctx->tile_sync && !prot && b->n_nonacgt == 0 && !two_strand && n > 0;
+    const bool dense = defer && dense_tp && !ctx->tile_async && !circ_ext;
+    if (dense) geo.tp = dense_tp;
     const bool async_final = defer && ctx->tile_async && warmup + iters == 0;
     ctx->tile_was_async = async_final;
     u64 nt = 0;
@@ -3059,12 +3073,93 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     lap("tile table");
     // 3. the ordinary kernels over the tiles
     // the cached tile result belongs to an earlier batch: always size (one untimed run) before any timed repetition
+    if (dense) {
+        // 3d. dense tiles: the tile kernel writes the FINAL tuples into the sequence result's own arrays (expected 2 / (w + 1) per position + a
+        // quarter; a batch that selects more -- long low-complexity stretches -- raises the flag and the call runs again the old way)
+        const u64 need = (u64)((double)b->n_bases * 2.0 / (p->w + 1.0) * 1.25) + (1u << 20);
+        if (old && old->hash && old->pos && old->alloc_cap >= need) {
+            fin = old;
+            old = nullptr;
+        } else {
+            drop_old();
+            fin = new (std::nothrow) bsk_result();
+            if (!fin) return done(BSK_ERR_NOMEM);
+            fin->ctx = ctx;
+            fin->n = n;
+            fin->kind = p_in->kind;
+            fin->has_pos = 1;
+            TCHK(hipMalloc(&fin->status, n ? n : 1));
+            TCHK(hipMalloc(&fin->wfirst, (n ? n : 1) * 8));
+            TCHK(hipMalloc(&fin->wcount, (n ? n : 1) * 8));
+            TCHK(hipMalloc(&fin->hash, need * 8));
+            TCHK(hipMalloc(&fin->pos, need * 4));
+            fin->cap = fin->alloc_cap = need;
+        }
+        rc = result_prepare(ctx, &tres_slot, nt, p->kind, 0);  // (reference words and status bytes per tile; the tuples are the sequence result's)
+        if (rc != BSK_OK) return done(rc);
+        tres = tres_slot;
+        const u32 tunits = (u32)((nt + 63) / 64);
+        // scratch of the units' prefix (kernels_minimizer_pf.hpp): a look-back granule per chunk of 64 units, a total per unit, then the eight
+        // ticket heads (one per XCD, 128 B apart)
+        const size_t lb_entries = pft_minimizer_scratch_words(tunits);
+        rc = ensure_scratch(ctx, lb_entries, 0);
+        if (rc != BSK_OK) return done(rc);
+        const int per_cu = pft_minimizer_blocks_per_cu(p->w);
+        const int grid = (int)std::max<u64>(1, std::min<u64>((u64)ctx->cus * per_cu, tunits));
+        KArgs ka;
+        memset(&ka, 0, sizeof ka);
+        ka.words = b->words;
+        ka.desc = tt.desc;
+        ka.n = nt;
+        ka.nunits = tunits;
+        ka.kind = p->kind;
+        ka.k = p->k;
+        ka.w = p->w;
+        ka.refs = tres->refs;
+        ka.status = tres->status;
+        ka.hash = fin->hash;
+        ka.pos = fin->pos;
+        ka.cap = fin->alloc_cap;
+        ka.ticket = ctx->d_ticket;
+        ka.lookback = ctx->d_lookback;
+        ka.tkeep = tt.keep;
+        ka.tshift = tt.shift;
+        ka.len_mask = 0xffffffu;
+        std::vector<hipEvent_t> evs;
+        for (int i = 0; kernel_ms && i < 2 * iters; ++i) {
+            hipEvent_t e = nullptr;
+            (void)hipEventCreate(&e);
+            evs.push_back(e);
+        }
+        for (int it = -1; it < warmup + iters; ++it) {  // (-1: the call's own run)
+            if (it >= 0 && warmup + iters == 0) break;
+            TCHK(hipMemsetAsync(ctx->d_ticket, 0, 8 * sizeof(u32), ctx->stream));
+            TCHK(hipMemsetAsync(ctx->d_lookback, 0, lb_entries * 8, ctx->stream));
+            const bool timed = kernel_ms && it >= warmup;
+            if (timed) (void)hipEventRecord(evs[2 * (it - warmup)], ctx->stream);
+            if (nt) pft_minimizer_launch(p->w, grid, ctx->stream, ka);
+            if (timed) (void)hipEventRecord(evs[2 * (it - warmup) + 1], ctx->stream);
+        }
+        TCHK(hipGetLastError());
+        TCHK(hipMemcpyAsync(ctx->d_ticket + 20, ctx->d_ticket, 4 * sizeof(u32), hipMemcpyDeviceToDevice, ctx->stream));
+        if (kernel_ms && iters > 0) {
+            TCHK(hipStreamSynchronize(ctx->stream));
+            for (int i = 0; i < iters; ++i) (void)hipEventElapsedTime(&kernel_ms[i], evs[2 * i], evs[2 * i + 1]);
+        }
+        for (hipEvent_t e : evs)
+            if (e) (void)hipEventDestroy(e);
+        snprintf(tres->plan, sizeof tres->plan, "k_minimizer_pft<%d>", p->w);
+        tres->plan_grid = grid;
+        tres->plan_per_cu = per_cu;
+        tres->n_tuples = 0;
+    } else {
     ctx->defer = defer;
     rc = run_planned(ctx, tb, &p2, 0, &tres_slot, 0, 0, nullptr);
     ctx->defer = false;
     if (rc == BSK_OK && warmup + iters > 0) rc = run_planned_resizing(ctx, tb, &p2, 0, &tres_slot, warmup, iters, kernel_ms);
     tres = tres_slot;
     if (rc != BSK_OK) return done(rc);
+    }
     lap("kernels (+sizing)");
     // 4. per-sequence flags
     TCHK(pool(7, (n ? n : 1) * 4, (void **)&sflags));
@@ -3077,7 +3172,9 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
         TCHK(hipGetLastError());
     }
     // 5. the final, per-sequence result
-    if (old && !stream && old->hash && old->pos && old->alloc_cap >= tres->n_tuples + 64) {  // (stitched kinds: the old arrays are large enough)
+    if (dense) {
+        // (made before the tile kernel ran: it wrote into these arrays)
+    } else if (old && !stream && old->hash && old->pos && old->alloc_cap >= tres->n_tuples + 64) {  // (stitched kinds: the old arrays are large enough)
         fin = old;
         old = nullptr;
     } else {
@@ -3092,7 +3189,9 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
         TCHK(hipMalloc(&fin->wfirst, (n ? n : 1) * 8));
         TCHK(hipMalloc(&fin->wcount, (n ? n : 1) * 8));
     }
-    if (two_strand) {  // twice the room; filled after k_tile_finish (k_two_strand)
+    if (dense) {
+        // nothing to stitch: the tiles' owned tuples lie back to back in tile order
+    } else if (two_strand) {  // twice the room; filled after k_tile_finish (k_two_strand)
         fin->cap = fin->alloc_cap = 2 * tres->cap + 64;
         TCHK(hipMalloc(&fin->hash, fin->cap * 8));
     } else if (stream) {  // the tile runs are adjacent: the tile result's value array IS the sequence result
@@ -3143,8 +3242,8 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
     lap("flags + stitch");
     TCHK(hipMemsetAsync(ctx->d_total, 0, 2 * sizeof(u64), ctx->stream));
     if (n) {
-        hipLaunchKernelGGL(k_tile_finish, dim3(grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, seq, geo, tstart, stream ? nullptr : oexcl,
-                           tres->refs, prot ? nullptr : b->rflags, sflags, sbad, fin->wfirst, fin->wcount, fin->status, ctx->d_total);
+        hipLaunchKernelGGL(k_tile_finish, dim3(grid_for(ctx, n, 256)), dim3(256), 0, ctx->stream, seq, geo, tstart, (stream || dense) ? nullptr : oexcl,
+                           tres->refs, prot ? nullptr : b->rflags, sflags, sbad, fin->wfirst, fin->wcount, fin->status, ctx->d_total, dense ? 1 : 0);
         TCHK(hipGetLastError());
     }
     if (two_strand && nt) {
@@ -3164,7 +3263,7 @@ static int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in
         TCHK(hipMemcpyAsync(ctx->h_pinned + 2, ctx->d_ticket, 2 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
         if (defer) TCHK(hipMemcpyAsync(ctx->h_pinned + 4, ctx->d_ticket + 20, 4 * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
         TCHK(hipStreamSynchronize(ctx->stream));
-        const bool stitch_ovf = !stream && nt && ((u32 *)(ctx->h_pinned + 2))[1];
+        const bool stitch_ovf = !stream && !dense && nt && ((u32 *)(ctx->h_pinned + 2))[1];
         if (defer && (stitch_ovf || ((u32 *)(ctx->h_pinned + 4))[1] || ((u32 *)(ctx->h_pinned + 4))[3] || (ctx->opt.test_overflow & 8u))) {
             // a slab, a list segment or an overflow region was too small for this batch: the old way sizes them by what the batch needs
             if (timing) fprintf(stderr, "[tiled] deferred launch overflowed (flags %u / %u, stitch %d): again with the sizing run\n", ((u32 *)(ctx->h_pinned + 4))[1], ((u32 *)(ctx->h_pinned + 4))[3], (int)stitch_ovf);

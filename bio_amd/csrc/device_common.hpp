@@ -195,6 +195,36 @@ __device__ __forceinline__ u64 lookback_exclusive(u64 *st, u32 unit, u64 total, 
     return excl;
 }
 
+// The same walk by a unit that only wants to know where `unit` begins (every granule before it is somebody else's to publish).
+__device__ __forceinline__ u64 lookback_peek(u64 *st, u32 unit, int lane) {
+    u64 excl = 0;
+    long long end = (long long)unit - 1;
+    for (;;) {
+        long long idx = end - lane;
+        u64 s = idx >= 0 ? lb_load(&st[idx]) : LB_INC;
+        u32 state = (u32)(s >> 62);
+        u64 inc_mask = __ballot(state == 2);
+        u64 empty_mask = __ballot(state == 0);
+        if (inc_mask) {
+            int first = __builtin_ctzll(inc_mask);
+            u64 needed = first == 63 ? ~0ULL : ((2ULL << first) - 1);
+            if (empty_mask & needed) {
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            excl += wave_sum_u64(lane <= first ? (s & LB_VAL) : 0ULL);
+            break;
+        }
+        if (empty_mask) {
+            __builtin_amdgcn_s_sleep(2);
+            continue;
+        }
+        excl += wave_sum_u64(s & LB_VAL);
+        end -= 64;
+    }
+    return excl;
+}
+
 // splitmix64: counter-based generator for bsk_batch_synth
 __host__ __device__ __forceinline__ u64 splitmix64(u64 x) {
     x += 0x9E3779B97F4A7C15ULL;

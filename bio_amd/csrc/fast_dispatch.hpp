@@ -68,6 +68,15 @@ u32 pf_syncmer_unit_tuples(bool lng);  // what a unit's emit phase takes
 int pf_syncmer_blocks_per_cu(int w, bool lng);
 void pf_syncmer_launch(int w, bool lng, int grid, int fix_grid, hipStream_t stream, const KArgs &a);
 
+// minimizers of long sequences as DENSE tiles (kernels_minimizer_pf.hpp, round 6): the tile kernel writes final tuples, no stitch pass; w = 4..13, k <= 64
+bool pft_minimizer_supported(int w);
+u32 pft_minimizer_max_tile_bases();
+u32 pft_minimizer_mask_rows();
+u32 pft_minimizer_unit_tuples();
+size_t pft_minimizer_scratch_words(u32 nunits);
+int pft_minimizer_blocks_per_cu(int w);
+void pft_minimizer_launch(int w, int grid, hipStream_t stream, const KArgs &a);
+
 // the two-pass plan (kernels_syncmer_sel.hpp): selection by the packed s-mer machine, then the selected k-mers hashed from scratch
 bool sel_syncmer_supported(int w);
 u32 sel_syncmer_max_bases();

@@ -14,7 +14,7 @@
 // Developer switches (DESIGN.md "Switches"): read from the environment ONCE, when the context is created, or again on
 // bsk_ctx_reload_options (the test suite flips them inside one process) -- never on the bsk_sketch path.
 struct BskOpts {
-    bool force_generic = false, no_mixed = false, no_dense = false, no_pk = false, no_ring = false, no_pkd = false, no_side_early = false, no_side_dense = false, ring = false, no_bin = false, no_bin_early = false, compact = false, no_tiles = false, no_tile_cache = false, no_tile_defer = false, no_group_gather = false, timing = false,
+    bool force_generic = false, no_mixed = false, no_dense = false, no_pk = false, no_ring = false, no_pkd = false, no_side_early = false, no_side_dense = false, ring = false, no_bin = false, no_bin_early = false, compact = false, no_tiles = false, no_tile_cache = false, no_tile_defer = false, tile_dense = false, no_group_gather = false, timing = false,
          no_fused_translate = false, sets_no_small = false;
     int syn_margin = 2;
     u32 test_overflow = 0;   // BSK_TEST_OVERFLOW (tests): pretend an overflow flag once per call -- 1: in a timed re-run (BSK_RESIZE), 2: a class plan's part while sizing, 4: ... in a timed re-run (BSK_REPLAN_CLASS)

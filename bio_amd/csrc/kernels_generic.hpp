@@ -70,6 +70,10 @@ struct KArgs {
     u32 *sel_mask, *sel_cnt, *sel_utot;
     u64 *sel_ubase, *sel_lookback;
     u32 sel_nb;
+    // dense tiles (k_minimizer_pft, kernels_minimizer_pf.hpp): per tile the positions it OWNS, tile-local (lo | hi << 32: kernels_tile.hpp, TileTab::keep),
+    // and the position of its first base in its sequence (TileTab::shift); the kernel emits only owned tuples, positions shifted, units packed back
+    // to back through `lookback` -- the tile result IS the sequence result, no stitch pass
+    const u64 *tkeep, *tshift;
     u32 cls_lo, cls_hi, cls_pretend;  // class plans: see desc_len()
     u32 tk;          // units per ticket of the persistent-wave kernels (0: the kernel's own 4 or 8): a batch with fewer units than the grid has
                      // wavefronts x that number takes smaller tickets -- a pipeline chunk or a class plan's part is latency, not throughput

@@ -135,7 +135,9 @@ __device__ __forceinline__ u32 pk_load_u8(const u8 *p) {
 // RINGM (k_minimizer_pkd, kernels_pkd.hpp): the same machine over FLds staging -- the lane's CAP + 1 rows are a ring that the kernel
 // flushes to the read's own slab every few blocks (flush_groups), so a read may select any number of tuples; the words of a block are
 // requested one block ahead (in_lo .. out_hi) and there is no register copy of the read, no paired column and no guard.
-template <int W, bool LONG, class LY_ = PkLds, bool RINGM = false>
+// SELM (k_minimizer_pft, kernels_minimizer_pf.hpp, round 6): the SELECTION alone -- nothing is staged: the finished block's selection bits
+// (bit o = k-mer o of the block) go to row (block number) of LY::MASK, one word per lane, and the unit's own emit phase hashes what was selected.
+template <int W, bool LONG, class LY_ = PkLds, bool RINGM = false, bool SELM = false>
 struct PkMin {
     typedef LY_ LY;
     const u32 *__restrict__ w;
@@ -147,6 +149,7 @@ struct PkMin {
     u64 H[W];   // canonical hashes of the previous block, slot by slot replaced by the current block's
     u32 SB[W];  // strand << 15 of the same slots
     u32 P, bm, tmin;
+    u32 nsel;  // SELM: the lane's selections so far
     u32 slot, spare;
     u32 glo, gspan;  // guard(): the lane's staging pointer may start a block in [glo, glo + gspan]
     u32 c8000;
@@ -221,7 +224,7 @@ struct PkMin {
     // spare row for the rest of the unit -- its count then reads as a full column and both reads of the column go to the list.  Four
     // instructions per block instead of a clamp (v_min_u32) in every staging step.
     __device__ __forceinline__ void guard() {
-        if constexpr (RINGM) return;
+        if constexpr (RINGM || SELM) return;
         const bool in = slot - glo <= gspan;
         slot = in ? slot : spare;
         sstep = in ? sstep : 0;
@@ -229,6 +232,10 @@ struct PkMin {
     // one staging step: slot o of the block whose slot 0 is k-mer pbase (wave-uniform)
     template <int IDX, int O>
     __device__ __forceinline__ void emit(u32 pbase) {
+        if constexpr (!SELM) emit_staged<IDX, O>(pbase);
+    }
+    template <int IDX, int O>
+    __device__ __forceinline__ void emit_staged(u32 pbase) {
         const u32 b = (bm >> IDX) & 1u;  // v_bfe_u32
         u32 pv;  // strand << 15 | position: one v_add3_u32 (scalar base, inline slot number); as C it is an s_add per step and a v_or
         asm("v_add3_u32 %0, %1, %2, %3" : "=v"(pv) : "v"(SB[O]), "s"(pbase), "n"(O));
@@ -363,12 +370,25 @@ struct PkMin {
                 S[q] = S[q] < S[q + 1] ? S[q] : S[q + 1];
             }
         }
+        if constexpr (SELM) {
+            if (!FIRST) {  // the previous block (number i0 / W - 1) is final: its word leaves
+                const u32 wsel = (bm >> PB) & ((1u << W) - 1u);
+                *reinterpret_cast<LDSQ u32 *>(lds + LY::MASK + (i0 / (u32)W - 1u) * 256u + (u32)lane * 4u) = wsel;
+                nsel += (u32)__builtin_popcount(wsel);
+            }
+        }
         if (!FIRST) bm &= PAR ? 0xffff0000u : 0x0000ffffu;  // the previous block's slots are all emitted
     }
 
     // the last block's own slots
     template <int PAR>
     __device__ __forceinline__ void drain(u32 i0) {
+        if constexpr (SELM) {  // the last block's own word
+            const u32 wsel = (bm >> (PAR * 16)) & ((1u << W) - 1u);
+            *reinterpret_cast<LDSQ u32 *>(lds + LY::MASK + (i0 / (u32)W) * 256u + (u32)lane * 4u) = wsel;
+            nsel += (u32)__builtin_popcount(wsel);
+            return;
+        }
         const u32 pbase = (u32)__builtin_amdgcn_readfirstlane((int)i0);
         guard();
         pk_unroll<W>([&](auto oc) {
@@ -382,6 +402,7 @@ struct PkMin {
     __device__ __forceinline__ void begin(u32 slot0, int step, u32 col8) {
         fl = fh_ = rl = rh_ = 0;
         bm = 0;
+        nsel = 0;
         c8000 = 0x8000u;
         asm volatile("" : "+v"(c8000));  // (stays a register: as a known constant the compiler re-materialises it, or goes back to select + shift)
         tmin = 0xffffffffu;

@@ -325,15 +325,21 @@ __global__ __launch_bounds__(64) void k_tile_stitch(StitchArgs a) {
 }
 
 // per sequence: first tuple, tuple count, status.  stream = 1: the tile runs already are the sequence's run.
-__global__ void k_tile_finish(SeqTab seq, TileGeo g, const u64 *tstart, const u64 *oexcl /*stitched kinds*/, const u64 *trefs /*stream kinds*/,
-                              const u8 *rflags, const u32 *sflags, const u64 *sbad, u64 *wfirst, u64 *wcount, u8 *status, u64 *total) {
+// dense = 1 (k_minimizer_pft): the tile kernel packed its tiles' OWNED tuples back to back in tile order -- a sequence's tuples are the run from its
+// first tile's first tuple to the end of its last tile's.
+__global__ void k_tile_finish(SeqTab seq, TileGeo g, const u64 *tstart, const u64 *oexcl /*stitched kinds*/, const u64 *trefs /*stream kinds, dense tiles*/,
+                              const u8 *rflags, const u32 *sflags, const u64 *sbad, u64 *wfirst, u64 *wcount, u8 *status, u64 *total, int dense = 0) {
     u64 sum = 0;
     for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < seq.n; r += (u64)gridDim.x * blockDim.x) {
         const u64 t0 = tstart[r], t1 = tstart[r + 1];
         u64 first = 0, cnt = 0;
         u8 st = tile_short(g, seq_len(seq, r), seq_short(seq, r)) ? BSK_ST_SHORT : BSK_ST_OK;
         if (t1 > t0) {
-            if (oexcl) {
+            if (dense) {
+                const u64 last = trefs[t1 - 1];
+                first = trefs[t0] >> 24;
+                cnt = (last >> 24) + (last & 0xffffffULL) - first;
+            } else if (oexcl) {
                 first = oexcl[t0];
                 cnt = oexcl[t1] - first;
             } else {

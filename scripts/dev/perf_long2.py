@@ -8,7 +8,9 @@ rng = np.random.default_rng(1)
 data = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, total, dtype=np.uint8)]
 offs = np.linspace(0, total, nseq + 1).astype(np.uint64)
 b = eng.batch_from_arrays(data, offs)
+only = os.environ.get("ONLY", "")
 for name, p in (("minimizer k21 w11", eng.params(L.MINIMIZER, 21, w=11)), ("syncmer k31 s11", eng.params(L.SYNCMER, 31, s=11))):
+    if only and only not in name: continue
     ts = []
     for _ in range(4):
         t = time.time(); res = eng.run(b, p); ts.append(time.time() - t); nt = res.info()["n_tuples"]; pl = res.plan()["kernel"]; dg = res.digest()["checksum"]; res.close()

@@ -462,3 +462,62 @@ def test_tiled_path_without_host_round_trips(engine, oracle, monkeypatch, mode):
     assert d["n_tuples"] == nt and d["checksum"] == ck, mode
     res.close()
     b.close()
+
+
+@pytest.mark.parametrize("k,w", [(21, 11), (31, 13), (15, 4), (21, 5), (64, 8), (33, 7), (11, 9), (25, 12)])
+def test_minimizers_of_long_sequences_as_dense_tiles(engine, oracle, monkeypatch, k, w):
+    """Round 6 (kernels_minimizer_pf.hpp): the tile kernel k_minimizer_pft writes the FINAL tuples -- only the positions a tile owns, shifted
+    to the sequence, every unit packed behind the one before -- and no stitch pass runs.  Every sequence against the oracle's closed form
+    (hashes, positions, strands, first-window flag); homopolymers, short repeats and a k-mer with its reverse complement inside one window
+    are key ties of the packed machine: those tiles go through the in-kernel exact path.  Same digest as the slab + stitch path."""
+    rng = random.Random(100 * k + w)
+    seqs = [rand_seq(rng, n) for n in (5000, k + w - 2, 12000, 20, 4097, 150, 40000, 8000, k + w - 1, 90000, 9999, 333)]
+    seqs.append("A" * 3000 + rand_seq(rng, 4000))                   # a homopolymer run inside an ordinary sequence
+    seqs.append(rand_seq(rng, 2500) + "ACGTTGCA" * 200 + rand_seq(rng, 2500))
+    pal = rand_seq(rng, k)
+    rc = pal[::-1].translate(str.maketrans("ACGT", "TGCA"))
+    seqs.append(rand_seq(rng, 3000) + pal + "AC" + rc + rand_seq(rng, 3000))  # equal canonical hashes a few positions apart
+    seqs.append("AAAAA" + rand_seq(rng, 6000))                         # (first-window region with repeated k-mers when k is small)
+    monkeypatch.setenv("BSK_TILE_DENSE", "1")
+    b = engine.batch(seqs)
+    p = engine.params(L.MINIMIZER, k, w=w)
+    res = engine.run(b, p)
+    assert "k_minimizer_pft<%d>" % w in res.plan()["kernel"] and "over tiles" in res.plan()["kernel"], res.plan()
+    for i, q in enumerate(seqs):
+        st, h, pos = res.read(i)
+        try:
+            eh, ep, es, fl = oracle.minimizer(q, k, w, False, closed=True)
+        except oracle.OracleError as e:
+            assert e.name == "ErrShortSeq" and (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0, (i, len(q))
+            continue
+        assert (st & L.ST_CODE_MASK) == L.ST_OK and len(h) == len(eh), (k, w, i, len(q), len(h), len(eh))
+        assert np.array_equal(h, eh) and np.array_equal(pos & L.POS_MASK, ep) and np.array_equal(pos >> 31, es), (k, w, i, len(q))
+        assert (st & 0xF0) == fl, (k, w, i, st, fl)
+    d = res.digest()
+    res.close()
+    monkeypatch.delenv("BSK_TILE_DENSE")
+    res = engine.run(b, p)
+    assert "k_minimizer_pft" not in res.plan()["kernel"], res.plan()
+    assert res.digest() == d
+    res.close()
+    b.close()
+
+
+def test_dense_tiles_fall_back_when_the_batch_selects_more_than_expected(engine, oracle, monkeypatch):
+    """The dense path sizes the sequence result by the expected density (2 / (w + 1) per position + a quarter); a batch of homopolymers
+    selects EVERY position: the kernel raises its flag instead of writing past the arrays and the call runs again through slabs + stitch."""
+    seqs = ["A" * 2000000, "C" * 150000, "ACGT" * 3, "GT" * 60000]
+    monkeypatch.setenv("BSK_TILE_DENSE", "1")
+    b = engine.batch(seqs)
+    res = engine.run(b, engine.params(L.MINIMIZER, 21, w=11))
+    assert "over tiles" in res.plan()["kernel"] and "k_minimizer_pft" not in res.plan()["kernel"], res.plan()
+    for i, q in enumerate(seqs):
+        st, h, pos = res.read(i)
+        try:
+            eh, ep, es, fl = oracle.minimizer(q, 21, 11, False, closed=True)
+        except oracle.OracleError:
+            assert (st & L.ST_CODE_MASK) == L.ST_SHORT
+            continue
+        assert np.array_equal(h, eh) and np.array_equal(pos & L.POS_MASK, ep), i
+    res.close()
+    b.close()
