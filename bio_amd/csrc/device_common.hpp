@@ -144,6 +144,36 @@ __device__ __forceinline__ u32 next_ticket(u32 *ticket, int lane) {
     return (u32)__builtin_amdgcn_readfirstlane((int)t);
 }
 
+// ---- tickets from eight heads ---------------------------------------------------------
+// ONE word hands out ~88 tickets a microsecond however many waves pull (MI355X guide, "dequeue": a returning device-scope atomicAdd on one
+// head word saturates there).  Kernels whose units are many thousand bases long and come several to a ticket never notice; a kernel that must
+// take its units ONE by one, in order (a look-back over the units: several units to a ticket would chain the tickets), is bound by exactly
+// that: 240 000 units of 64 tiles = 2.7 ms of k_tile_stitch's 2.8.  Eight heads, one per XCD and a cache line each: head x hands out the
+// units x, x + 8, x + 16, ...; a wave pulls from its own XCD's head and, when that has run out, goes round the others (nothing says every XCD
+// holds a wave of the launch).  The units still start in (nearly) rising order, which is all a decoupled look-back asks for.
+__device__ __forceinline__ u32 xcc_id() {
+    u32 x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(x));
+    return x & 7u;
+}
+constexpr u32 HEAD_WORDS = 8 * 32;  // u32 words of the eight heads (zeroed before the launch)
+struct HeadTickets {
+    u32 *heads;
+    u32 x0, hh;
+    __device__ __forceinline__ HeadTickets(u32 *h) : heads(h), x0(xcc_id()), hh(0) {}
+    __device__ __forceinline__ u32 head() const { return (x0 + hh) & 7u; }
+    // the next unit (< nunits), or ~0u when every head has run out
+    __device__ __forceinline__ u32 next(u32 nunits, int lane) {
+        while (hh < 8u) {
+            const u32 hx = head();
+            const u32 u = next_ticket(heads + hx * 32u, lane) * 8u + hx;
+            if (u < nunits) return u;
+            ++hh;
+        }
+        return ~0u;
+    }
+};
+
 // ---- decoupled look-back: exclusive prefix of per-unit tuple totals ---------------
 // One 8-byte granule per unit: bits 63..62 state (0 empty, 1 aggregate, 2 inclusive),
 // bits 61..0 value.  Granules are written/read with relaxed agent-scope atomics

@@ -184,26 +184,34 @@ struct StitchArgs {
 };
 
 // minimizer / syncmer: keep the tuples a tile owns, shift their positions, pack them in tile order.
-// A unit is 64 tiles; its tile tuples are ENTRIES 0 .. K_in - 1 in tile order (entry j belongs to the first tile whose inclusive count
-// prefix exceeds j; positions ascend inside a tile, so the owned tuples of a tile are one run).  Two streaming passes over the entries, 64
-// per step, every lane one entry: the count pass (positions only) gives the unit's total for the look-back and, per tile, how many kept
-// entries precede it (oexcl); the write pass tests again (the positions come from the L2 now) and writes the kept entries behind a running
-// offset, coalesced.  (Round 4's version gave every LANE a tile: a serial scan of its ~21 positions -- 21 dependent loads -- and then a
-// search per output; it was latency-bound at 6.1 ms for 4 10^8 tile tuples, the larger half of the tiled minimizer path.)
+// A unit is 64 tiles.  Positions ascend inside a tile, so the tuples a tile OWNS (positions in [lo, hi): TileTab::keep) are ONE RUN of its
+// tuples: every lane finds its tile's run by two binary searches over the tile's positions (both at once: ~log2(count) dependent loads, 5
+// for a pk-sized tile, 8 for a pkd-sized one) -- that is the whole count pass; the unit's total goes through the look-back; then the runs
+// are copied behind one another, 64 consecutive output tuples per step and four steps' loads in flight, no test per tuple: entry j of the
+// unit's kept tuples belongs to the first tile whose inclusive kept-count prefix exceeds j (a table written by the tiles when the unit keeps
+// at most OWN_CAP tuples; larger units -- pkd-sized tiles -- go tile by tile, a tile's run being several steps long there).
+// (Round 4 gave every LANE a tile and scanned its ~21 positions one dependent load after the other: 6.1 ms for 4 10^8 tile tuples.  Round 5
+// streamed all entries twice -- count pass, write pass, a test per entry -- and searched the prefix per entry in units above OWN_CAP: six
+// dependent LDS round trips per entry, 2.7 ms for the pkd-sized tiles of 2 10^9 bases, 4.2 TB/s of traffic at best.)
+// scratch of a stitch over nunits units, in u64 words: the look-back granules, then the ticket heads
+__host__ __device__ constexpr size_t stitch_heads_at(u32 nunits) { return ((size_t)nunits + 15u) & ~(size_t)15u; }
+__host__ __device__ constexpr size_t stitch_scratch_words(u32 nunits) { return stitch_heads_at(nunits) + HEAD_WORDS / 2; }
 __global__ __launch_bounds__(64) void k_tile_stitch(StitchArgs a) {
-    constexpr u32 OWN_CAP = 4096;  // entries whose tile is looked up in a table (a unit of pk tiles has ~1 700; larger units search)
-    __shared__ u64 s_first[64], s_shift[64];
-    __shared__ u32 s_pre[64], s_lo[64], s_hi[64], s_stride[64];
+    constexpr u32 OWN_CAP = 4096;  // kept tuples whose tile is looked up in a table (a unit of pk tiles keeps ~1 500)
+    constexpr int SU = 4;
+    __shared__ u64 s_src[64], s_shift[64];  // first kept tuple of the tile, its offset in the sequence
+    __shared__ u32 s_pre[64], s_stride[64];
     __shared__ u8 s_own[OWN_CAP];
     const int lane = lane_id();
+    HeadTickets tickets(reinterpret_cast<u32 *>(a.lookback + stitch_heads_at(a.nunits)));  // (one unit per ticket: device_common.hpp, "tickets from eight heads")
     for (;;) {
-        const u32 unit = next_ticket(a.ticket, lane);
-        if (unit >= a.nunits) break;
+        const u32 unit = tickets.next(a.nunits, lane);
+        if (unit == ~0u) break;
         const u64 t = (u64)unit * 64 + lane;
-        u32 cnt = 0;
+        u32 kept = 0;
         {
             u64 first = 0, sh = 0;
-            u32 lo = 0, hi = 0, stride = 1;
+            u32 cnt = 0, lo = 0, hi = 0, stride = 1;
             if (t < a.nt) {
                 const u64 ref = a.trefs[t], kp = a.keep[t];
                 first = BSK_REF_FIRST(ref);
@@ -217,107 +225,97 @@ __global__ __launch_bounds__(64) void k_tile_stitch(StitchArgs a) {
                 hi = (u32)(kp >> 32);
                 sh = a.shift[t];
             }
-            s_first[lane] = first;
+            // first tuple at or beyond lo, first tuple at or beyond hi
+            u32 a0 = 0, b0 = cnt, a1 = 0, b1 = cnt;
+            while (__builtin_amdgcn_ballot_w64(a0 < b0 || a1 < b1)) {
+                const u32 m0 = (a0 + b0) >> 1, m1 = (a1 + b1) >> 1;
+                const bool g0 = a0 < b0, g1 = a1 < b1;
+                const u32 p0 = g0 ? a.tpos[first + (u64)m0 * stride] & BSK_POS_MASK : 0u;
+                const u32 p1 = g1 ? a.tpos[first + (u64)m1 * stride] & BSK_POS_MASK : 0u;
+                if (g0) {
+                    if (p0 < lo) a0 = m0 + 1u;
+                    else b0 = m0;
+                }
+                if (g1) {
+                    if (p1 < hi) a1 = m1 + 1u;
+                    else b1 = m1;
+                }
+            }
+            kept = a1 > a0 ? a1 - a0 : 0u;
+            s_src[lane] = first + (u64)a0 * stride;
             s_shift[lane] = sh;
-            s_lo[lane] = lo;
-            s_hi[lane] = hi;
             s_stride[lane] = stride;
         }
-        const u32 pre = wave_incl_scan_u32(cnt, lane);
+        const u32 pre = wave_incl_scan_u32(kept, lane);
         s_pre[lane] = pre;
-        const u32 K_in = wave_bcast_u32(pre, 63);
-        const u32 start = pre - cnt;  // this lane's TILE starts at entry `start`
-        // the table entry -> tile: every tile writes its number over its own run (no waits between the writes; a search per entry is six
-        // DEPENDENT LDS round trips, and the kernel is bound by exactly that latency)
-        const bool tabled = K_in <= OWN_CAP;
-        if (tabled)
-            for (u32 i = 0; i < cnt; ++i) s_own[start + i] = (u8)lane;
-        wave_sync_lds();
-        // entry j -> (its tile o, the index of its tuple)
-        auto locate = [&](u32 j, u32 &o, u64 &src) {
-            if (tabled) {
-                o = s_own[j];
-            } else {
-                u32 lo_ = 0, hi_ = 63;  // first tile whose inclusive prefix exceeds j
-#pragma unroll
-                for (int it = 0; it < 6; ++it) {
-                    const u32 mid = (lo_ + hi_) >> 1;
-                    const bool up = s_pre[mid] > j;
-                    hi_ = up ? mid : hi_;
-                    lo_ = up ? lo_ : mid + 1;
-                }
-                o = lo_ < 63u ? lo_ : 63u;
-            }
-            const u32 before = o ? s_pre[o - 1] : 0u;  // (s_pre is inclusive)
-            src = s_first[o] + (u64)(j - before) * s_stride[o];
-        };
-        // count pass (four steps' positions requested together: a step is one dependent load, and a unit of a small batch -- a class
-        // plan's few thousand long reads -- is alone on its SIMD with nothing to hide it behind)
-        constexpr int SU = 4;
-        u32 acc = 0, kept_total = 0;
-        for (u32 j0 = 0; j0 < K_in; j0 += 64 * SU) {
-            u32 pv[SU], ov[SU];
-#pragma unroll
-            for (int q = 0; q < SU; ++q) {
-                const u32 j = j0 + 64u * (u32)q + (u32)lane;
-                pv[q] = 0;
-                ov[q] = 0;
-                if (j < K_in) {
-                    u64 src;
-                    locate(j, ov[q], src);
-                    pv[q] = a.tpos[src];
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < SU; ++q) {
-                const u32 jq = j0 + 64u * (u32)q, j = jq + (u32)lane;
-                const u32 p = pv[q] & BSK_POS_MASK;
-                const bool keepf = j < K_in && p >= s_lo[ov[q]] && p < s_hi[ov[q]];
-                const u64 m = __builtin_amdgcn_ballot_w64(keepf);
-                kept_total += (u32)__builtin_popcountll(m);
-                const int d = (int)start - (int)jq;  // kept entries of this step that precede this lane's tile
-                const u64 below = d <= 0 ? 0ULL : d >= 64 ? ~0ULL : ((1ULL << d) - 1ULL);
-                acc += (u32)__builtin_popcountll(m & below);
-            }
-        }
-        const u64 base = lookback_exclusive(a.lookback, unit, (u64)kept_total, lane);
-        if (t < a.nt) a.oexcl[t] = base + acc;
-        if (unit == a.nunits - 1 && lane == 63) a.oexcl[a.nt] = base + kept_total;
-        if (base + kept_total > a.cap) {
+        const u32 K = wave_bcast_u32(pre, 63);
+        const u32 start = pre - kept;  // this lane's TILE starts at kept tuple `start` of the unit
+        const u64 base = lookback_exclusive(a.lookback, unit, (u64)K, lane);
+        if (t < a.nt) a.oexcl[t] = base + start;
+        if (unit == a.nunits - 1 && lane == 63) a.oexcl[a.nt] = base + K;
+        if (base + K > a.cap) {
             if (lane == 0) atomicOr(&a.ticket[1], 1u);
             wave_sync_lds();
             continue;
         }
-        // write pass
-        u64 run = base;
-        for (u32 j0 = 0; j0 < K_in; j0 += 64 * SU) {
-            u32 pv[SU], ov[SU];
-            u64 sv[SU], hv[SU];
+        if (K <= OWN_CAP) {
+            // the table tuple -> tile: every tile writes its number over its own run
+            for (u32 i = 0; i < kept; ++i) s_own[start + i] = (u8)lane;
+            wave_sync_lds();
+            for (u32 j0 = 0; j0 < K; j0 += 64 * SU) {
+                u32 pv[SU], ov[SU];
+                u64 hv[SU];
 #pragma unroll
-            for (int q = 0; q < SU; ++q) {
-                const u32 j = j0 + 64u * (u32)q + (u32)lane;
-                pv[q] = 0;
-                ov[q] = 0;
-                sv[q] = 0;
-                hv[q] = 0;
-                if (j < K_in) {
-                    locate(j, ov[q], sv[q]);
-                    pv[q] = a.tpos[sv[q]];
-                    hv[q] = a.thash[sv[q]];  // (requested with the position: most entries of a pk-sized tile are kept)
+                for (int q = 0; q < SU; ++q) {
+                    const u32 j = j0 + 64u * (u32)q + (u32)lane;
+                    pv[q] = 0;
+                    ov[q] = 0;
+                    hv[q] = 0;
+                    if (j < K) {
+                        const u32 o = s_own[j];
+                        const u64 src = s_src[o] + (u64)(j - (o ? s_pre[o - 1] : 0u)) * s_stride[o];  // (s_pre is inclusive)
+                        ov[q] = o;
+                        pv[q] = __builtin_nontemporal_load(&a.tpos[src]);
+                        hv[q] = __builtin_nontemporal_load(&a.thash[src]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < SU; ++q) {
+                    const u32 j = j0 + 64u * (u32)q + (u32)lane;
+                    if (j < K) {
+                        __builtin_nontemporal_store(hv[q], &a.ohash[base + j]);
+                        __builtin_nontemporal_store(pv[q] + (u32)s_shift[ov[q]], &a.opos[base + j]);  // (the strand bit rides along: a sequence position stays below 2^31)
+                    }
                 }
             }
+        } else {
+            wave_sync_lds();
+            for (u32 o = 0; o < 64u; ++o) {  // tile by tile (a pkd-sized tile keeps ~160 tuples: one step)
+                const u32 before = o ? s_pre[o - 1] : 0u, n_o = s_pre[o] - before;
+                const u64 src0 = s_src[o], dst0 = base + before;
+                const u32 stride = s_stride[o], sh = (u32)s_shift[o];
+                for (u32 i0 = 0; i0 < n_o; i0 += 64 * SU) {
+                    u32 pv[SU];
+                    u64 hv[SU];
 #pragma unroll
-            for (int q = 0; q < SU; ++q) {
-                const u32 j = j0 + 64u * (u32)q + (u32)lane;
-                const u32 p = pv[q] & BSK_POS_MASK;
-                const bool keepf = j < K_in && p >= s_lo[ov[q]] && p < s_hi[ov[q]];
-                const u64 m = __builtin_amdgcn_ballot_w64(keepf);
-                if (keepf) {
-                    const u64 dst = run + (u64)__builtin_popcountll(m & ((1ULL << lane) - 1ULL));
-                    a.ohash[dst] = hv[q];
-                    a.opos[dst] = (pv[q] & BSK_POS_STRAND_BIT) | (u32)(p + s_shift[ov[q]]);
+                    for (int q = 0; q < SU; ++q) {
+                        const u32 i = i0 + 64u * (u32)q + (u32)lane;
+                        pv[q] = 0;
+                        hv[q] = 0;
+                        if (i < n_o) {
+                            pv[q] = __builtin_nontemporal_load(&a.tpos[src0 + (u64)i * stride]);
+                            hv[q] = __builtin_nontemporal_load(&a.thash[src0 + (u64)i * stride]);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < SU; ++q) {
+                        const u32 i = i0 + 64u * (u32)q + (u32)lane;
+                        if (i < n_o) {
+                            __builtin_nontemporal_store(hv[q], &a.ohash[dst0 + i]);
+                            __builtin_nontemporal_store(pv[q] + sh, &a.opos[dst0 + i]);
+                        }
+                    }
                 }
-                run += (u64)__builtin_popcountll(m);
             }
         }
         wave_sync_lds();

@@ -13,5 +13,5 @@ for name, p in (("minimizer k21 w11", eng.params(L.MINIMIZER, 21, w=11)), ("sync
     if only and only not in name: continue
     ts = []
     for _ in range(4):
-        t = time.time(); res = eng.run(b, p); ts.append(time.time() - t); nt = res.info()["n_tuples"]; pl = res.plan()["kernel"]; dg = res.digest()["checksum"]; res.close()
+        t = time.time(); res = eng.run(b, p); ts.append(time.time() - t); nt = res.info()["n_tuples"]; pl = res.plan()["kernel"]; dg = 0 if os.environ.get("NODIGEST") else res.digest()["checksum"]; res.close()
     print(f"{name:20s} wall ms {[round(x*1e3,1) for x in ts]} -> {total/min(ts)/1e9:.1f} Gbases/s, tuples {nt} {pl} {dg}")
