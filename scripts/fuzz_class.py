@@ -1,4 +1,4 @@
-"""dev helper (GPU): differential fuzz of the class plans (run_classed, biosketch.hip) and of the pipeline's sink.
+"""dev helper (GPU): differential fuzz of the class plans (run_classed, classes.hip) and of the pipeline's sink.
 
 Every case: a batch of a random bulk length (fixed or ragged) with random outlier classes (counts, lengths up to 40 000 bases, reads with
 an N, low-complexity reads), random (kind, k, w | s); the class-plan run (BSK_CLASS_FORCE, host list or device pass at random) must give,

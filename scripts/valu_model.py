@@ -32,9 +32,9 @@ KERNELS = {
     "minimizer250": ("k_minimizer_ring.hip", ["-DBSK_RING_WS(X)=X(11)"], "k_minimizer_ringILi11ELi3ELb1"),
     "syncmer": ("k_syncmer_pf.hip", ["-DBSK_SYNPF_WS(X)=X(20)", "-DBSK_SYNPFL_WS(X)="], "k_syncmer_pfILi20"),
     "syncmer250": ("k_syncmer_pf.hip", ["-DBSK_SYNPF_WS(X)=", "-DBSK_SYNPFL_WS(X)=X(20)"], "k_syncmer_pflILi20"),
-    "nthash": ("biosketch.hip", [], "k_nthash_fastILi1"),
-    "kmer": ("biosketch.hip", [], "k_nthash_fastILi2"),
-    "simhash": ("biosketch.hip", [], "k_simhash_fastILi5ELi12"),
+    "nthash": ("launch.hip", [], "k_nthash_fastILi1"),
+    "kmer": ("launch.hip", [], "k_nthash_fastILi2"),
+    "simhash": ("launch.hip", [], "k_simhash_fastILi5ELi12"),
     "protmin": ("k_protein.hip", [], "k_prot_minimizer_fastILi5ELi9ELb0"),
     "prothash": ("k_protein.hip", [], "k_prot_hash_fastILi9ELb0"),
 }

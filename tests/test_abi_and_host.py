@@ -129,14 +129,14 @@ def test_hand_written_asm_is_safe():
 
 
 def test_developer_switches_are_read_once_per_context():
-    """No getenv on the bsk_sketch path: biosketch.hip / sets.hip read the BSK_* switches only in BskOpts::load (bsk_ctx_create,
-    bsk_ctx_reload_options)."""
+    """No getenv on the bsk_sketch path: the host translation units read the BSK_* switches only in BskOpts::load (bsk_ctx_create,
+    bsk_ctx_reload_options; biosketch.hip)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for fn in ("biosketch.hip", "sets.hip", "comm.cpp"):
+    for fn in ("biosketch.hip", "planner.hip", "launch.hip", "tiles.hip", "classes.hip", "sets.hip", "comm.cpp"):
         text = open(os.path.join(root, "bio_amd", "csrc", fn)).read()
         body = text
         if fn == "biosketch.hip":  # the two functions that may call getenv
-            a, b = text.index("static u32 env_u32("), text.index('extern "C" int bsk_ctx_reload_options')
+            a, b = text.index("u32 env_u32("), text.index('extern "C" int bsk_ctx_reload_options')
             body = text[:a] + text[b:]
         assert "getenv" not in body, fn
 
@@ -151,7 +151,7 @@ def test_planner_table_is_generated_from_the_committed_sweep():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "scripts", "fit_planner.py"), "--check"], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout + p.stderr
-    src = open(os.path.join(root, "bio_amd", "csrc", "biosketch.hip")).read()
+    src = "".join(open(os.path.join(root, "bio_amd", "csrc", fn)).read() for fn in ("planner.hip", "launch.hip", "tiles.hip", "classes.hip", "biosketch.hip"))
     assert "PlannerTable::ring_cap" in src and "17.0 + 2.5 * p->w" not in src and "* 2.6 / (p->w + 1.0)" not in src
     hdr = open(os.path.join(root, "bio_amd", "csrc", "planner_table.hpp")).read()
     for name in ("ring_cap", "dense_min", "slab_sel_num", "syn_sel_num", "syn_long_spread", "syn_tie_pairs_max", "pf_list_fill", "tile_min_tuples", "tile_big_tiles_min", "rates"):

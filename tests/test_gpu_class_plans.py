@@ -1,4 +1,4 @@
-"""GPU: class plans (run_classed, biosketch.hip) -- one plan per LENGTH CLASS of a batch instead of one plan keyed on the longest read.
+"""GPU: class plans (run_classed, classes.hip) -- one plan per LENGTH CLASS of a batch instead of one plan keyed on the longest read.
 
 The reference sketches one sequence at a time: a 5-kb contig costs its own 5 kb and nothing else (sketches/sketch.go:46, :85-94).  A batch
 of 150-base reads with a few longer ones must therefore (a) give every read exactly the tuples of its own iterator -- per-read parity
