@@ -988,7 +988,7 @@ static int translate_batch(bsk_ctx *ctx, const bsk_batch *b, int table, int fram
     t->device_bytes = cap_bytes + BSK_ASCII_PAD + (b->n + 1) * 8 + b->n;
     const u32 nunits = (u32)((b->n + 63) / 64);
     if (nunits) {
-        int rc = ensure_scratch(ctx, nunits, 0);
+        int rc = ensure_scratch(ctx, lb_words_with_heads(nunits), 0);  // (k_translate takes its units from eight ticket heads behind the granules)
         if (rc != BSK_OK) {
             bsk_batch_destroy(t);
             return rc;
@@ -1017,7 +1017,7 @@ static int translate_batch(bsk_ctx *ctx, const bsk_batch *b, int table, int fram
         const int grid = (int)std::max<u64>(1, std::min<u64>((u64)ctx->cus * per_cu, nunits));
         if ((e = hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream)) == hipSuccess &&
             (e = hipMemsetAsync(ctx->d_total, 0, 2 * sizeof(u64), ctx->stream)) == hipSuccess &&
-            (e = hipMemsetAsync(ctx->d_lookback, 0, (size_t)nunits * sizeof(u64), ctx->stream)) == hipSuccess) {
+            (e = hipMemsetAsync(ctx->d_lookback, 0, lb_words_with_heads(nunits) * sizeof(u64), ctx->stream)) == hipSuccess) {
             if (use_ascii) hipLaunchKernelGGL(k_translate<1>, dim3(grid), dim3(64), 0, ctx->stream, a);
             else hipLaunchKernelGGL(k_translate<0>, dim3(grid), dim3(64), 0, ctx->stream, a);
             e = hipGetLastError();

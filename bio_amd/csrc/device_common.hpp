@@ -157,6 +157,9 @@ __device__ __forceinline__ u32 xcc_id() {
     return x & 7u;
 }
 constexpr u32 HEAD_WORDS = 8 * 32;  // u32 words of the eight heads (zeroed before the launch)
+// a look-back scratch of nunits granules with the heads behind it (u64 words): where the heads start, and the whole of it
+__host__ __device__ constexpr size_t lb_heads_at(u32 nunits) { return ((size_t)nunits + 15u) & ~(size_t)15u; }
+__host__ __device__ constexpr size_t lb_words_with_heads(u32 nunits) { return lb_heads_at(nunits) + HEAD_WORDS / 2; }
 struct HeadTickets {
     u32 *heads;
     u32 x0, hh;

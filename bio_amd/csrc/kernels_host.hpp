@@ -78,9 +78,10 @@ static __global__ void k_count_flags(const u8 *rflags, u64 n, u32 *count) {
 // indices of the flagged reads, ascending (one wavefront per 64 reads + look-back: deterministic order)
 static __global__ __launch_bounds__(64) void k_compact_flags(const u8 *rflags, u64 n, u32 nunits, u32 *ticket, u64 *lookback, u32 *subset) {
     const int lane = lane_id();
+    HeadTickets tickets(reinterpret_cast<u32 *>(lookback + lb_heads_at(nunits)));  // (a unit is 64 flag bytes: one head word would BE the kernel -- 10^8 reads = 1.6 10^6 tickets = 18 ms)
     for (;;) {
-        const u32 unit = next_ticket(ticket, lane);
-        if (unit >= nunits) break;
+        const u32 unit = tickets.next(nunits, lane);
+        if (unit == ~0u) break;
         const u64 r = (u64)unit * 64 + lane;
         const bool f = r < n && rflags[r] != 0;
         const u64 m = __ballot(f);

@@ -193,9 +193,7 @@ struct StitchArgs {
 // (Round 4 gave every LANE a tile and scanned its ~21 positions one dependent load after the other: 6.1 ms for 4 10^8 tile tuples.  Round 5
 // streamed all entries twice -- count pass, write pass, a test per entry -- and searched the prefix per entry in units above OWN_CAP: six
 // dependent LDS round trips per entry, 2.7 ms for the pkd-sized tiles of 2 10^9 bases, 4.2 TB/s of traffic at best.)
-// scratch of a stitch over nunits units, in u64 words: the look-back granules, then the ticket heads
-__host__ __device__ constexpr size_t stitch_heads_at(u32 nunits) { return ((size_t)nunits + 15u) & ~(size_t)15u; }
-__host__ __device__ constexpr size_t stitch_scratch_words(u32 nunits) { return stitch_heads_at(nunits) + HEAD_WORDS / 2; }
+// (scratch of a stitch over nunits units: lb_words_with_heads -- the look-back granules, then the ticket heads)
 __global__ __launch_bounds__(64) void k_tile_stitch(StitchArgs a) {
     constexpr u32 OWN_CAP = 4096;  // kept tuples whose tile is looked up in a table (a unit of pk tiles keeps ~1 500)
     constexpr int SU = 4;
@@ -203,7 +201,7 @@ __global__ __launch_bounds__(64) void k_tile_stitch(StitchArgs a) {
     __shared__ u32 s_pre[64], s_stride[64];
     __shared__ u8 s_own[OWN_CAP];
     const int lane = lane_id();
-    HeadTickets tickets(reinterpret_cast<u32 *>(a.lookback + stitch_heads_at(a.nunits)));  // (one unit per ticket: device_common.hpp, "tickets from eight heads")
+    HeadTickets tickets(reinterpret_cast<u32 *>(a.lookback + lb_heads_at(a.nunits)));  // (one unit per ticket: device_common.hpp, "tickets from eight heads")
     for (;;) {
         const u32 unit = tickets.next(a.nunits, lane);
         if (unit == ~0u) break;

@@ -54,9 +54,10 @@ __global__ __launch_bounds__(64) void k_translate(TArgs a) {
     }
     __syncthreads();
     const int frame = a.frame;
+    HeadTickets tickets(reinterpret_cast<u32 *>(a.lookback + lb_heads_at(a.nunits)));  // (one unit per ticket and a look-back over the units: device_common.hpp, "tickets from eight heads")
     for (;;) {
-        const u32 unit = next_ticket(a.ticket, lane);
-        if (unit >= a.nunits) break;
+        const u32 unit = tickets.next(a.nunits, lane);
+        if (unit == ~0u) break;
         const u64 r = (u64)unit * 64 + lane;
         u64 src = 0, L = 0;
         if (r < a.n) {

@@ -73,11 +73,11 @@ int build_subset(bsk_ctx *ctx, bsk_batch *b) {
     b->nsub = 0;
     if (!b->n || !b->n_nonacgt || !b->rflags || b->n >= (1ULL << 32)) return BSK_OK;
     const u32 nunits = (u32)((b->n + 63) / 64);
-    int rc = ensure_scratch(ctx, nunits, 0);
+    int rc = ensure_scratch(ctx, lb_words_with_heads(nunits), 0);
     if (rc != BSK_OK) return rc;
     HIPCHK(ctx, hipMalloc(&b->subset, b->n_nonacgt * sizeof(u32)));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_ticket, 0, 4 * sizeof(u32), ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_lookback, 0, (size_t)nunits * sizeof(u64), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_lookback, 0, lb_words_with_heads(nunits) * sizeof(u64), ctx->stream));
     hipLaunchKernelGGL(k_compact_flags, dim3(std::min<u32>(nunits, (u32)ctx->cus * 8)), dim3(64), 0, ctx->stream, b->rflags, b->n, nunits,
                        ctx->d_ticket, ctx->d_lookback, b->subset);
     HIPCHK(ctx, hipGetLastError());

@@ -415,10 +415,10 @@ int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in, int c
         TCHK(hipMemsetAsync(oexcl, 0, (nt + 1) * 8, ctx->stream));
         if (nt) {
             const u32 tunits = (u32)((nt + 63) / 64);
-            rc = ensure_scratch(ctx, stitch_scratch_words(tunits), 0);
+            rc = ensure_scratch(ctx, lb_words_with_heads(tunits), 0);
             if (rc != BSK_OK) return done(rc);
             TCHK(hipMemsetAsync(ctx->d_ticket, 0, 2 * sizeof(u32), ctx->stream));
-            TCHK(hipMemsetAsync(ctx->d_lookback, 0, stitch_scratch_words(tunits) * 8, ctx->stream));
+            TCHK(hipMemsetAsync(ctx->d_lookback, 0, lb_words_with_heads(tunits) * 8, ctx->stream));
             StitchArgs sa;
             sa.nt = nt;
             sa.nunits = tunits;
