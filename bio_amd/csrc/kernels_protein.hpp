@@ -45,6 +45,9 @@ __device__ __forceinline__ u64 mum64(u32 a0, u32 a1, u32 b0, u32 b1) {  // hi64(
     return hi ^ lo;
 }
 
+#ifndef PROT_WIDE
+#define PROT_WIDE 1  // the residues of four macro blocks per request (k_prot_minimizer_fast; 0: one block per request, round 3's way)
+#endif
 template <int W, int K>
 struct FastProt {
     static_assert(K >= 4 && K <= 16, "register wyhash covers 4..16 residues");
@@ -321,7 +324,13 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
                 head = head >= (u32)LY::ROWS ? head - (u32)LY::ROWS : head;
                 done += nfl;
             };
-            for (u32 i0 = 0; i0 < nk_max; i0 += MB) {
+            // PROT_WIDE (protein-fed): the residues of FOUR macro blocks are requested together, every fourth block -- a 128-byte line is touched
+            // two or three times instead of eight, and its touches lie four blocks apart at most (the 16-byte requests of every block keep
+            // 64 lanes' partly consumed lines alive for eight blocks: at eight waves per CU they outgrow the L2 and are fetched 1.5 times).
+            constexpr int QB = PROT_WIDE ? 4 : 1, ND = MB / 4;
+            u32 wide[PROT_WIDE ? QB * ND : 1];
+            auto one_block = [&](auto qc, const u32 i0) {
+                constexpr int Q = decltype(qc)::value;
                 u64 raw[MB / 4];  // DNA: the next macro block's packed words are requested here, a whole block of hashing ahead of their use
                 u32 nextR[MB / 4];  // protein: the same for the next macro block's residues (round 3: they were requested after the
                                     // block and waited for at once -- an exposed L2 / HBM round trip every MB steps)
@@ -330,7 +339,11 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
                     for (int g = 0; g < MB / 4; ++g) raw[g] = dna_issue(dj + (u32)g);
                 } else {
 #ifndef PROT_NO_AHEAD
-                    load_dwords(nextR, MB / 4, dj);
+                    if (PROT_WIDE && !DNA) {
+                        if (Q == 0) load_dwords(wide, QB * ND, dj);
+                    } else {
+                        load_dwords(nextR, MB / 4, dj);
+                    }
 #endif
                 }
                 if (HS < MB) {
@@ -352,8 +365,17 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
                     for (int g = 0; g < MB / 4; ++g) fp.R[5 + g] = dna_finish(raw[g], dj + (u32)g);
                 } else {
 #ifndef PROT_NO_AHEAD
+                    if (PROT_WIDE && !DNA) {
+                        if (Q == 0) {
 #pragma unroll
-                    for (int g = 0; g < MB / 4; ++g) fp.R[5 + g] = nextR[g];
+                            for (int g = 0; g < QB * ND; ++g) asm volatile("" : "+v"(wide[g]));  // (all of them in before the flush's stores go out)
+                        }
+#pragma unroll
+                        for (int g = 0; g < ND; ++g) fp.R[5 + g] = wide[(Q % QB) * ND + g];
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < MB / 4; ++g) fp.R[5 + g] = nextR[g];
+                    }
 #else
                     load_dwords(fp.R + 5, MB / 4, dj);
 #endif
@@ -362,6 +384,24 @@ __global__ __launch_bounds__(64) void k_prot_minimizer_fast(KArgs a) {
 #pragma unroll
                 for (int g = 0; g < MB / 4; ++g) asm volatile("" ::"v"(fp.R[5 + g]));
                 flush(i0 + MB >= nk_max);
+            };
+            {
+                u32 i0 = 0;
+                while (i0 < nk_max) {
+                    one_block(std::integral_constant<int, 0>{}, i0);
+                    i0 += MB;
+                    if (PROT_WIDE && !DNA) {
+                        if (i0 >= nk_max) break;
+                        one_block(std::integral_constant<int, 1>{}, i0);
+                        i0 += MB;
+                        if (i0 >= nk_max) break;
+                        one_block(std::integral_constant<int, 2>{}, i0);
+                        i0 += MB;
+                        if (i0 >= nk_max) break;
+                        one_block(std::integral_constant<int, 3>{}, i0);
+                        i0 += MB;
+                    }
+                }
             }
             tie = (u32)((fp.tm >> lane) & 1);
         }
