@@ -141,7 +141,7 @@ int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_result *re
 int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, int circ_ext, bsk_result **result, int warmup, int iters, float *kernel_ms);
 int run_planned_resizing(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, int circ_ext, bsk_result **result, int warmup, int iters, float *kernel_ms);
 // workgroups per CU of the kernels only launch.hip instantiates (the planner asks by name)
-enum OccId { OCC_MIN_GEN_P, OCC_MIN_GEN_A, OCC_NT_FAST0, OCC_NT_FAST1, OCC_NT_FAST2, OCC_NT_FAST0C, OCC_NT_FAST1C, OCC_NT_FAST2C, OCC_NT_P, OCC_NT_A, OCC_SYN_P, OCC_SYN_A,
+enum OccId { OCC_MIN_GEN_P, OCC_MIN_GEN_A, OCC_NT_FAST0, OCC_NT_FAST1, OCC_NT_FAST2, OCC_NT_FAST3, OCC_NT_FAST4, OCC_NT_FAST0C, OCC_NT_FAST1C, OCC_NT_FAST2C, OCC_NT_P, OCC_NT_A, OCC_SYN_P, OCC_SYN_A,
              OCC_KMER_P, OCC_KMER_A, OCC_SIMF_5S, OCC_SIMF_6S, OCC_SIMF_5M, OCC_SIMF_6M, OCC_SIMF_5, OCC_SIMF_6, OCC_SIM_P, OCC_SIM_A, OCC_PROT_HASH, OCC_PROT_MIN };
 int occ(OccId id);
 // ---- tiles.hip ----

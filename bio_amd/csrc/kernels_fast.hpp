@@ -957,7 +957,12 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
 // output offset of every read is a closed form, otherwise it comes from the look-back.
 // ---------------------------------------------------------------------------------------
 #define BSK_NT_FAST_WORDS 34  // reads of up to 32*16 = 512 bases (+2 words of look-ahead)
-// MODE 0: ntHash forward strand, 1: canonical ntHash, 2: canonical 2-bit k-mer code (NextKmer, iterator.go:708-759, k <= 32)
+// MODE 0: ntHash forward strand, 1: canonical ntHash, 2: canonical 2-bit k-mer code (NextKmer, iterator.go:708-759, k <= 32),
+// 3 (round 6): NextKmer's TWO-STRAND mode (iterator.go:713-723: the codes of the sequence, then the codes of its reverse complement) --
+// a read's run is 2 nk values: value j < nk is the forward code at position j, value j >= nk the reverse-complement code of position
+// 2 nk - 1 - j, i.e. the lane walks forward through the read and then BACK, rolling the reverse-complement code the other way (a base
+// enters at the k-mer's front); the runs leave in whole lines exactly as in the other modes, 16 bytes per base (the general kernel this
+// replaces ran 166 Gbases/s); 4: forward codes only (the tile pass of long sequences in two-strand mode, k_two_strand after it)
 // CP ("compact runs", fixed-length batches of reads with >= 32 values; an EXPERIMENT -- measured and rejected, see stream_compact_ok in
 // biosketch.hip -- instantiated only with make EXPERIMENTS=1): no padding at all.  Read l of a unit starts at
 //   unit base + l * nk  (the unit's 64 nk values are one run; 64 nk is a multiple of 16, so units start on lines)
@@ -966,6 +971,7 @@ __global__ __launch_bounds__(64) void k_minimizer_dense(KArgs a) {
 // lines that hold the tail of one read and the head of the next (one per read) leave at the end of the unit, assembled from the
 // ring and from the heads, which every lane keeps in registers since block 0.  Padded runs cost 144 values written for 130
 // (k = 21, 150 bases): 11 % of the write traffic of a write-bound kernel.
+__host__ __device__ __forceinline__ unsigned pair_map2(int pairs);  // (kernels_more.hpp: the 2-bit code of a base's PairLetter in the batch's alphabet)
 template <int MODE, bool CP = false>
 __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
     constexpr int TL = CP ? 34 : 18;  // u64 per tile row (16 + 2 pad: 144-byte rows keep 16-byte alignment, 2-way conflicts at most; CP: a ring of 32 + 2)
@@ -1005,7 +1011,7 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
               u64 L = 0;
               if (r < a.n) L = a.desc[r] & 0xffffffULL;
               const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) >= (u64)k;
-              const u32 pk = ok ? ((u32)(L - k + 1) + 15u) & ~15u : 0u;
+              const u32 pk = ok ? ((MODE == 3 ? 2u : 1u) * (u32)(L - k + 1) + 15u) & ~15u : 0u;
               if (lane == 0) s_base[unit - u0] = run;
               run += wave_sum_u64((u64)pk);
           }
@@ -1023,8 +1029,10 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
             L = d & 0xffffffULL;
         }
         const bool ok = r < a.n && L >= (u64)a.circ_ext && (L - (u64)a.circ_ext) >= (u64)k;  // iterator.go:619
-        const u32 nk = ok ? (u32)(L - k + 1) : 0u;
-        const u32 nk_max = wave_max_u32(nk);
+        const u32 nkp = ok ? (u32)(L - k + 1) : 0u;      // k-mer positions of the read
+        const u32 nk = MODE == 3 ? 2u * nkp : nkp;       // values of its run
+        const u32 nkp_max = wave_max_u32(nkp);
+        const u32 nk_max = MODE == 3 ? 2u * nkp_max : nkp_max;
         // every read's run starts on a 128-byte line and is padded to whole lines (16 values): each 16-step flush
         // then writes full, aligned lines (measured WRITE_SIZE 1.24x -> ~1.0x of the algorithmic bytes)
         const u32 pk = CP ? nk : (nk + 15u) & ~15u;
@@ -1066,7 +1074,7 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
         // made every block wait for the previous flush to reach memory)
         const u32 *__restrict__ w = a.words + off;
         LDSQ u32 *const sw = reinterpret_cast<LDSQ u32 *>(lq + SW_OFF);
-        const u32 nw_max = ((nk_max + (u32)k - 1 + 15) >> 4) + 2;  // <= NWL (checked by the host)
+        const u32 nw_max = ((nkp_max + (u32)k - 1 + 15) >> 4) + 2;  // <= NWL (checked by the host)
         for (u32 j = 0; j < nw_max; ++j) sw[j * 64 + lane] = w[j];
         wave_sync_lds();
         u32 fl = 0, fh_ = 0, rl = 0, rh_ = 0;
@@ -1079,6 +1087,10 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
             rh_ = d ^ x.w;
         };
         u64 code = 0, rc = 0;  // MODE 2: forward / reverse-complement code, first base in the most significant pair
+        // MODE 3: rc is the code of the reverse-COMPLEMENTED LETTERS (RevComInplace, iterator.go:719: PairLetter of the sequence's alphabet --
+        // RNA leaves a T, Unlimit complements nothing), not the arithmetic complement the canonical mode compares with (iterator.go:740)
+        const u32 map2 = MODE == 3 ? pair_map2(a.pairs) : 0x1Bu;
+        auto cm = [&](u32 b) -> u32 { return MODE == 3 ? (map2 >> (2u * b)) & 3u : b ^ 3u; };
         const u64 cmask = k >= 32 ? ~0ULL : ((1ULL << (2 * k)) - 1ULL);
         const unsigned sh2 = 2u * (unsigned)(k - 1);
         for (int t0 = 0; t0 < k - 1; t0 += 16) {
@@ -1086,9 +1098,9 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
             const int nb = (k - 1 - t0) < 16 ? (k - 1 - t0) : 16;
             for (int j = 0; j < nb; ++j) {
                 const u32 b = (word >> (2 * j)) & 3;
-                if (MODE == 2) {
+                if (MODE >= 2) {
                     code = (code << 2) | b;
-                    rc = (rc >> 2) | ((u64)(b ^ 3u) << sh2);
+                    rc = (rc >> 2) | ((u64)cm(b) << sh2);
                 } else {
                     roll(*reinterpret_cast<LDSQ const u32x4 *>(lq + 256 + (b << 4)));
                 }
@@ -1099,12 +1111,21 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
         // the read's start modulo 16 (wa0 / wa1), so that the ring columns [16 PAR, 16 PAR + 16) hold exactly line b of the row
         auto blockfn = [&](auto parc, const u32 i0) {
             constexpr int PAR = decltype(parc)::value;
-            const u32 t0 = i0 + (u32)k - 1, p0 = i0 ? i0 - 1 : 0;
+            const u32 t0 = MODE == 3 ? (i0 + (u32)k - 1 < 16u * (NWL - 2) ? i0 + (u32)k - 1 : 16u * (NWL - 2)) : i0 + (u32)k - 1, p0 = MODE == 3 ? 0u : (i0 ? i0 - 1 : 0);
+            u32 cb2 = 0;  // MODE 3: the 16 bases at positions P0 - 15 .. P0, P0 = 2 nk - 1 - i0 (what enters at the front on the way back)
+            if (MODE == 3) {
+                const int P0 = 2 * (int)nkp - 1 - (int)i0;
+                const int lo = P0 - 15 > 0 ? P0 - 15 : 0;
+                const u32 wq = (u32)(lo >> 4) < (u32)(NWL - 2) ? (u32)(lo >> 4) : (u32)(NWL - 2);
+                const u64 win = ((u64)sw[(wq + 1) * 64 + lane] << 32) | sw[wq * 64 + lane];
+                const int sft = P0 - 15 - 16 * (int)wq;  // -15 .. (beyond 15: no position of this block lies inside the read)
+                cb2 = sft >= 32 ? 0u : sft >= 0 ? (u32)(win >> (2 * sft)) : (u32)(win << (-2 * sft));
+            }
             const u32 cinb = __builtin_amdgcn_alignbit(sw[((t0 >> 4) + 1) * 64 + lane], sw[(t0 >> 4) * 64 + lane], (t0 & 15) * 2);
             const u32 olo = sw[(p0 >> 4) * 64 + lane], ohi = sw[((p0 >> 4) + 1) * 64 + lane];
             const u32 coutb = i0 ? __builtin_amdgcn_alignbit(ohi, olo, (p0 & 15) * 2) : (olo << 2);
             u32x4 xs[16];
-            if (MODE != 2) {
+            if (MODE < 2) {
 #pragma unroll
                 for (int o = 0; o < 16; ++o) {
                     const u32 ia = (o >= 2 ? (cinb >> (2 * o - 4)) : (cinb << (4 - 2 * o))) & 0x30u;
@@ -1116,7 +1137,24 @@ __global__ __launch_bounds__(64) void k_nthash_fast(KArgs a) {
 #pragma unroll
             for (int o = 0; o < 16; ++o) {
                 u32 hl, hh;
-                if (MODE == 2) {
+                if (MODE == 3) {
+                    const u32 j = i0 + (u32)o;  // value j of the run
+                    const bool fwd = j < nkp, back = j > nkp;  // (j == nkp: the reverse-complement code of the last position, as the forward walk left it)
+                    const u32 b = (cinb >> (2 * o)) & 3, bb = (cb2 >> (2 * (15 - o))) & 3;
+                    const u64 ncode = ((code << 2) | b) & cmask;                  // iterator.go:736
+                    const u64 nrc_f = (rc >> 2) | ((u64)cm(b) << sh2);           // (iterator.go:740's roll, on the paired letter)
+                    const u64 nrc_b = ((rc << 2) & cmask) | (u64)cm(bb);          // the same code one position to the LEFT
+                    code = fwd ? ncode : code;
+                    rc = fwd ? nrc_f : back ? nrc_b : rc;
+                    const u64 out = fwd ? code : rc;
+                    hl = (u32)out;
+                    hh = (u32)(out >> 32);
+                } else if (MODE == 4) {
+                    const u32 b = (cinb >> (2 * o)) & 3;
+                    code = ((code << 2) | b) & cmask;
+                    hl = (u32)code;
+                    hh = (u32)(code >> 32);
+                } else if (MODE == 2) {
                     const u32 b = (cinb >> (2 * o)) & 3;
                     code = ((code << 2) | b) & cmask;                   // iterator.go:736
                     rc = (rc >> 2) | ((u64)(b ^ 3u) << sh2);            // iterator.go:740

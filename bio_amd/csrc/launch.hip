@@ -278,7 +278,9 @@ int launch(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, bsk_result *re
                 else hipLaunchKernelGGL((k_nthash_fast<0, true>), dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             } else
 #endif
-            if (a.kind == BSK_KMER) hipLaunchKernelGGL(k_nthash_fast<2>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
+            if (a.kind == BSK_KMER && a.one_strand) hipLaunchKernelGGL(k_nthash_fast<4>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
+            else if (a.kind == BSK_KMER && !a.canonical) hipLaunchKernelGGL(k_nthash_fast<3>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
+            else if (a.kind == BSK_KMER) hipLaunchKernelGGL(k_nthash_fast<2>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             else if (a.canonical) hipLaunchKernelGGL(k_nthash_fast<1>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             else hipLaunchKernelGGL(k_nthash_fast<0>, dim3(pl.grid), dim3(64), 0, ctx->stream, a);
             break;
@@ -572,6 +574,8 @@ int occ(OccId id) {
         case OCC_NT_FAST0: return blocks_per_cu(k_nthash_fast<0>);
         case OCC_NT_FAST1: return blocks_per_cu(k_nthash_fast<1>);
         case OCC_NT_FAST2: return blocks_per_cu(k_nthash_fast<2>);
+        case OCC_NT_FAST3: return blocks_per_cu(k_nthash_fast<3>);
+        case OCC_NT_FAST4: return blocks_per_cu(k_nthash_fast<4>);
 #ifdef BSK_EXPERIMENTS
         case OCC_NT_FAST0C: return blocks_per_cu(k_nthash_fast<0, true>);
         case OCC_NT_FAST1C: return blocks_per_cu(k_nthash_fast<1, true>);

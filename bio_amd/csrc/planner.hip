@@ -444,6 +444,9 @@ int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan &p
 #ifdef BSK_EXPERIMENTS
             if (pl.compact) per_cu = occ(OCC_NT_FAST2C);
 #endif
+        } else if (!use_ascii && p->canonical <= 0 && !p->circular && b->maxlen <= 16u * (BSK_NT_FAST_WORDS - 2) && !ctx->opt.force_generic) {
+            pl.which = K_NT_FAST;  // MODE 3: both strands (iterator.go:713-723), MODE 4: forward codes only (the tile pass of two-strand long sequences)
+            per_cu = occ(p->canonical < 0 ? OCC_NT_FAST4 : OCC_NT_FAST3);
         } else {
             pl.which = use_ascii ? K_KMER_A : K_KMER_P;
             per_cu = use_ascii ? occ(OCC_KMER_A) : occ(OCC_KMER_P);
@@ -528,7 +531,7 @@ void plan_name(const Plan &pl, const bsk_params *p, bool tiled, int cus, bsk_res
         case K_MIN_PKD: snprintf(b, sizeof b, "k_minimizer_pkd<%d>", pl.fast_w); break;
         case K_MIN_SEG: snprintf(b, sizeof b, "k_minimizer_seg<%d>", pl.fast_w); break;
         case K_MIN_WPR: snprintf(b, sizeof b, "k_minimizer_wpr<%d>", pl.fast_w); break;
-        case K_NT_FAST: snprintf(b, sizeof b, pl.compact ? "k_nthash_fast<%d,true>" : "k_nthash_fast<%d>", p->kind == BSK_KMER ? 2 : p->canonical ? 1 : 0); break;
+        case K_NT_FAST: snprintf(b, sizeof b, pl.compact ? "k_nthash_fast<%d,true>" : "k_nthash_fast<%d>", p->kind == BSK_KMER ? (p->canonical > 0 ? 2 : p->canonical < 0 ? 4 : 3) : p->canonical ? 1 : 0); break;
         case K_SYN_P: snprintf(b, sizeof b, "k_syncmer<0>"); break;
         case K_SYN_A: snprintf(b, sizeof b, "k_syncmer<1>"); break;
         case K_KMER_P: snprintf(b, sizeof b, "k_kmer<0>"); break;

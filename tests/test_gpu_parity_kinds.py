@@ -382,6 +382,34 @@ def test_two_strand_kmer_codes_pair_letters_with_the_sequences_own_alphabet(engi
                 os.environ[k_] = v
 
 
+@pytest.mark.parametrize("alphabet", [L.ALPHA_DNA, L.ALPHA_RNA, L.ALPHA_UNLIMIT])
+def test_two_strand_kmer_codes_on_the_stream_kernel(engine, oracle, alphabet):
+    """Round 6: NextKmer's two-strand mode (iterator.go:713-723) of pure-ACGT reads of up to 512 bases runs on k_nthash_fast<3> -- the lane
+    walks forward through the read and then back, rolling the code of the reverse-complemented letters the other way -- instead of the
+    general kernel.  Ragged and fixed-length batches, k = 1 .. 32, every value against the oracle; the second strand pairs the letters of
+    the batch's own alphabet (RNA leaves a T, Unlimit complements nothing)."""
+    rng = random.Random(977 + alphabet)
+    ragged = [rand_seq(rng, n) for n in [1, 2, 11, 12, 15, 16, 17, 31, 32, 33, 63, 64, 65, 150, 151, 255, 256, 257, 400, 511, 512]]
+    ragged += [rand_seq(rng, rng.randint(5, 512)) for _ in range(200)]
+    fixed = [rand_seq(rng, 150) for _ in range(300)]
+    for seqs in (ragged, fixed):
+        b = engine.batch(seqs, alphabet)
+        for k in (1, 2, 5, 11, 16, 17, 21, 31, 32):
+            res = engine.run(b, engine.params(L.KMER, k, canonical=False))
+            assert "k_nthash_fast<3>" in res.plan()["kernel"], res.plan()
+            for i, q in enumerate(seqs):
+                st, h, _ = res.read(i)
+                try:
+                    e = oracle.kmer_codes(q, k, False, False, alphabet)
+                except oracle.OracleError as err:
+                    assert err.name == "ErrShortSeq" and (st & L.ST_CODE_MASK) == L.ST_SHORT and len(h) == 0, (k, i)
+                    continue
+                assert (st & L.ST_CODE_MASK) == L.ST_OK and len(h) == 2 * (len(q) - k + 1), (alphabet, k, i, len(q), len(h))
+                assert np.array_equal(h, e), (alphabet, k, i, len(q))
+            res.close()
+        b.close()
+
+
 def test_kmer_k_too_large(engine):
     from bio_amd import sketches as S
     seq, _ = S.NewSeq(S.DNA, "ACGT" * 20)
