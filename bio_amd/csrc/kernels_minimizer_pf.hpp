@@ -1,25 +1,27 @@
-// kernels_minimizer_pf.hpp -- k_minimizer_pft<W>: minimizers of LONG sequences without a stitch pass (round 6).
+// kernels_minimizer_pf.hpp -- k_minimizer_pft<W>: minimizers of LONG sequences without a stitch pass (round 6; opt-in: BSK_TILE_DENSE=1).
 //
-// A long sequence runs as overlapping tiles, one per lane (kernels_tile.hpp).  Until now every tile kernel wrote its tuples -- the
-// overlap's included, positions tile-local -- into slabs, and k_tile_stitch read all of them back to drop, shift and pack them: 2.8 of the
-// 5.9 ms a call over 2 10^9 bases took, pure HBM traffic.  Here the tile kernel writes the FINAL tuples:
+// A long sequence runs as overlapping tiles, one per lane (kernels_tile.hpp).  The shipped path writes every tile's tuples -- the overlap's
+// included, positions tile-local -- into slabs, and k_tile_stitch reads them back to drop, shift and pack them.  Here the tile kernel writes
+// the FINAL tuples:
 //
 //   hash phase   PkMin<W, ..., SELM>: the packed window machine of k_minimizer_pk, selection only -- one word of selection bits per block and
 //                lane into LDS rows (nothing is staged);
-//   ownership    bits of positions outside the tile's own [lo, hi) are dropped (TileTab::keep), so the lane's count is final;
-//   packing      the unit's 64 tiles are consecutive tiles of (mostly) one sequence and their tuples are wanted in tile order: a wave scan of
-//                the counts + a decoupled look-back over the units (tickets are handed out in order) give every tile its place in ONE dense
-//                stream -- a sequence's tuples end up contiguous and in position order, which is what the stitch pass existed for;
-//   emit         as k_syncmer_pf: the lanes' packed words back to LDS, one LANE PER TUPLE hashes the k bases from scratch (pf_hash_kmer),
-//                picks the strand, adds the tile's offset in its sequence and stores 64 consecutive final tuples per round.
+//   repair       a tile in which two equal 27-bit keys met (the packed machine cannot vouch for it: kernels_pk.hpp; 1e-4 of the tiles on
+//                random sequence, low-complexity stretches on real genomes) is done again RIGHT HERE by all 64 lanes (pft_repair_tile):
+//                a dense stream has no room for a list pass afterwards;
+//   ownership    bits of positions outside the tile's own [lo, hi) are dropped (TileTab::keep); the rows move into registers and the lane's
+//                count is final: the unit's total is published (one granule per unit);
+//   -- the unit waits here, hashed and counted, while the wave hashes its NEXT unit --
+//   place        the tuples of all units before it: the totals of the units before it in its chunk of 64 + a decoupled look-back over the
+//                chunks (a unit waits for LOWER units only: the wave holds tickets it has not begun);
+//   emit         as k_syncmer_pf: the lanes' packed words back to LDS, the selection rows expanded into a list (in passes of TCAP tuples),
+//                one LANE PER TUPLE hashes the k bases from scratch (pf_hash_kmer), picks the strand, adds the tile's offset in its
+//                sequence and stores 64 consecutive final tuples per round: a sequence's tuples end up contiguous and in position order.
 //
-// Exactness.  The packed machine is exact unless two equal 27-bit keys met in a min operation (kernels_pk.hpp).  A dense stream has no room
-// for a list pass afterwards, so such a tile (1e-4 of them on random sequence; low-complexity stretches on real genomes) is done again
-// RIGHT HERE by min_exact_tile: a plain per-lane restatement of NextMinimizer's closed form (sketch.go:205-309: leftmost argmin of every
-// window of w canonical 64-bit hashes, emitted when the position changes) that reads its bases from global memory -- once to count (the
-// tile's place in the stream depends on it), once to write -- and evaluates BSK_ST_FIRST_WINDOW_TIE (oracle: tie_flag).  It is slow
-// (~3 unit-times for a unit with such a tile) and rare.  The same path takes the tiles of a unit that selects more than the emit list holds.
-// Tiles of at most 160 bases (12 packed words), k <= 64, w = 4..13; LDS 13 440 B: twelve waves per CU.
+// Tickets: one unit per ticket, from eight heads (device_common.hpp).  Measured (NOTEBOOK 6.4): exact, and NOT faster than slabs + stitch --
+// 6.2 ms against 5.4-5.9 for 2 10^9 bases: with the tickets out of the way the kernel is VALU-bound, and hashing the selected 17.7 % of all
+// positions a second time costs what the stitch pass costs in HBM time.  Tiles of at most 160 bases (12 packed words), k <= 64, w = 4..13;
+// LDS 13 440 B, 168 VGPRs: twelve waves per CU.
 #pragma once
 #include "kernels_syncmer_pf.hpp"
 
