@@ -73,6 +73,7 @@ extern "C" int bsk_ctx_create(int device, bsk_ctx **out) {
         bsk_ctx_destroy(ctx);
         return BSK_ERR_DEVICE;
     }
+    spare_register(ctx, true);
     *out = ctx;
     return BSK_OK;
 }
@@ -81,6 +82,8 @@ extern "C" void bsk_ctx_destroy(bsk_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    spare_register(ctx, false);
+    spare_flush(ctx);
     if (ctx->side) {
         bsk_ctx_destroy(ctx->side);
         ctx->side = nullptr;
@@ -239,6 +242,7 @@ void BskOpts::load() {
     compact = on("BSK_COMPACT");
     ring = on("BSK_RING");
     ring_max = env_u32("BSK_RING_MAX", 0);
+    ring_sel10 = env_u32("BSK_RING_SEL10", 0);
     bin_min = env_u32("BSK_BIN_MIN", 1024);
     no_class = on("BSK_NO_CLASS");
     syn_sel = on("BSK_SYN_SEL");
@@ -250,6 +254,7 @@ void BskOpts::load() {
     no_syn_long = on("BSK_NO_SYN_LONG");  // dev: reads beyond k_syncmer_pk's limits go to k_syncmer_fast as before round 4
     syn_margin = (int)env_u32("BSK_SYN_MARGIN", (u32)PlannerTable::syn_margin_rows + 64) - 64;  // dev: rows of slack the planner wants in k_syncmer_pk's columns (BSK_SYN_MARGIN = 64 + margin)
     no_tiles = on("BSK_NO_TILES");
+    no_spare = on("BSK_NO_SPARE");  // released results' arrays are freed, not kept for the next result (bsk_ctx::spare)
     no_tile_cache = on("BSK_NO_TILE_CACHE");
     tile_dense = on("BSK_TILE_DENSE");  // minimizers of long sequences by the dense tile kernel (k_minimizer_pft: final tuples, no stitch pass).  Exact, and measured no faster than slabs + k_tile_stitch (6.3 against 5.9 ms for 2 10^9 bases -- its from-scratch emit is VALU the stitch pass pays in HBM time): opt-in
     no_tile_defer = on("BSK_NO_TILE_DEFER");  // dev: tiled calls with the host round trips of rounds 2-5 (tile count, sizing run, totals)
@@ -687,18 +692,106 @@ extern "C" int bsk_batch_fetch_ascii(bsk_ctx *ctx, const bsk_batch *b, uint64_t 
 // ------------------------------------------------------------------------------------
 // results
 // ------------------------------------------------------------------------------------
+// ---- spare result arrays (bsk_ctx::spare) ----------------------------------------------------------------------------------------------
+static std::mutex g_spare_mu;            // (contexts are single-threaded; the out-of-memory flush walks every live context)
+static std::vector<bsk_ctx *> g_ctxs;    // live contexts
+void spare_register(bsk_ctx *ctx, bool add) {
+    std::lock_guard<std::mutex> lk(g_spare_mu);
+    if (add) g_ctxs.push_back(ctx);
+    else g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), ctx), g_ctxs.end());
+}
+static void spare_flush_locked(bsk_ctx *ctx) {
+    for (auto &s : ctx->spare) {
+        if (s.p) (void)hipFree(s.p);
+        s = bsk_ctx::Spare();
+    }
+    ctx->spare_bytes = 0;
+}
+void spare_flush(bsk_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(g_spare_mu);
+    spare_flush_locked(ctx);
+}
+// an allocation of the library failed: everything every context keeps in reserve goes back to the device (host_internal.hpp: then once more)
+bool spare_flush_all() {
+    std::lock_guard<std::mutex> lk(g_spare_mu);
+    bool any = false;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (bsk_ctx *c : g_ctxs) {
+        if (!c->spare_bytes) continue;
+        any = true;
+        (void)hipSetDevice(c->device);
+        spare_flush_locked(c);
+    }
+    (void)hipSetDevice(dev);
+    return any;
+}
+// a released result's array: kept for the next result (true) or freed
+void spare_give(bsk_ctx *ctx, void *p) {
+    if (!p) return;
+    size_t bytes = 0;
+    if (!ctx || ctx->opt.no_spare || hipMemPtrGetInfo(p, &bytes) != hipSuccess || bytes < (1u << 20)) {
+        (void)hipGetLastError();
+        (void)hipFree(p);
+        return;
+    }
+    std::lock_guard<std::mutex> lk(g_spare_mu);
+    if (!ctx->spare_limit) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) tot = (size_t)64 << 30;
+        ctx->spare_limit = tot / 5 * 2;
+    }
+    int slot = -1, smallest = 0;
+    for (int i = 0; i < bsk_ctx::SPARE_SLOTS; ++i) {
+        if (!ctx->spare[i].p && slot < 0) slot = i;
+        if (ctx->spare[i].bytes < ctx->spare[smallest].bytes) smallest = i;
+    }
+    if (slot < 0 && ctx->spare[smallest].bytes < bytes) {  // full: the smallest one makes room for a larger one
+        (void)hipFree(ctx->spare[smallest].p);
+        ctx->spare_bytes -= ctx->spare[smallest].bytes;
+        ctx->spare[smallest] = bsk_ctx::Spare();
+        slot = smallest;
+    }
+    if (slot < 0 || ctx->spare_bytes + bytes > ctx->spare_limit) {
+        (void)hipFree(p);
+        return;
+    }
+    ctx->spare[slot].p = p;
+    ctx->spare[slot].bytes = bytes;
+    ctx->spare_bytes += bytes;
+}
+// an array of at least `bytes` for a result: the best fit among the spare ones (none wastes more than half of itself), else hipMalloc
+hipError_t spare_take(bsk_ctx *ctx, void **out, size_t bytes) {
+    *out = nullptr;
+    if (ctx && !ctx->opt.no_spare) {
+        std::lock_guard<std::mutex> lk(g_spare_mu);
+        int best = -1;
+        for (int i = 0; i < bsk_ctx::SPARE_SLOTS; ++i) {
+            const auto &s = ctx->spare[i];
+            if (s.p && s.bytes >= bytes && s.bytes <= 2 * bytes + ((size_t)64 << 20) && (best < 0 || s.bytes < ctx->spare[best].bytes)) best = i;
+        }
+        if (best >= 0) {
+            *out = ctx->spare[best].p;
+            ctx->spare_bytes -= ctx->spare[best].bytes;
+            ctx->spare[best] = bsk_ctx::Spare();
+            return hipSuccess;
+        }
+    }
+    return hipMalloc(out, bytes);
+}
+
 extern "C" void bsk_result_release(bsk_result *r) {
     if (!r) return;
     if (r->ctx) (void)hipSetDevice(r->ctx->device);
     if (r->classes) class_set_free(r->classes);
     if (r->ctx && r->ctx->cls_owner == r) r->ctx->cls_owner = nullptr;
-    (void)hipFree(r->refs);
-    (void)hipFree(r->wfirst);
-    (void)hipFree(r->wcount);
-    (void)hipFree(r->status);
+    spare_give(r->ctx, r->refs);
+    spare_give(r->ctx, r->wfirst);
+    spare_give(r->ctx, r->wcount);
+    spare_give(r->ctx, r->status);
     if (!r->arrays_borrowed) {
-        (void)hipFree(r->hash);
-        (void)hipFree(r->pos);
+        spare_give(r->ctx, r->hash);
+        spare_give(r->ctx, r->pos);
     }
     delete r;
 }
@@ -721,7 +814,7 @@ int result_prepare(bsk_ctx *ctx, bsk_result **res, u64 n, int kind, u64 cap, u64
         r->ctx = ctx;
         r->n_cap = n;
         hipError_t e;
-        if ((e = hipMalloc(&r->refs, (n ? n : 1) * 8)) != hipSuccess || (e = hipMalloc(&r->status, n ? n : 1)) != hipSuccess) {
+        if ((e = spare_take(ctx, (void **)&r->refs, (n ? n : 1) * 8)) != hipSuccess || (e = spare_take(ctx, (void **)&r->status, n ? n : 1)) != hipSuccess) {
             bsk_result_release(r);
             return fail_hip(ctx, e, "result alloc");
         }
@@ -738,8 +831,8 @@ int result_prepare(bsk_ctx *ctx, bsk_result **res, u64 n, int kind, u64 cap, u64
     }
     if (r->alloc_cap < cap + tail || r->arrays_borrowed || (hp && !r->pos)) {
         if (!r->arrays_borrowed) {
-            (void)hipFree(r->hash);
-            (void)hipFree(r->pos);
+            spare_give(ctx, r->hash);
+            spare_give(ctx, r->pos);
         }
         r->arrays_borrowed = false;
         r->hash = nullptr;
@@ -747,8 +840,8 @@ int result_prepare(bsk_ctx *ctx, bsk_result **res, u64 n, int kind, u64 cap, u64
         r->cap = 0;
         r->alloc_cap = 0;
         hipError_t e;
-        if ((e = hipMalloc(&r->hash, (cap + tail + 2) * 8)) != hipSuccess) return fail_hip(ctx, e, "result hash alloc");
-        if (hp && (e = hipMalloc(&r->pos, (cap + tail + 2) * 4)) != hipSuccess) return fail_hip(ctx, e, "result pos alloc");
+        if ((e = spare_take(ctx, (void **)&r->hash, (cap + tail + 2) * 8)) != hipSuccess) return fail_hip(ctx, e, "result hash alloc");
+        if (hp && (e = spare_take(ctx, (void **)&r->pos, (cap + tail + 2) * 4)) != hipSuccess) return fail_hip(ctx, e, "result pos alloc");
         r->alloc_cap = cap + tail;
     }
     r->tail_cap = tail;

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -112,6 +113,10 @@ struct ClassCut {
 // (internal: none of these is an export of libbiosketch.so)
 #pragma GCC visibility push(hidden)
 // ---- biosketch.hip ----
+void spare_register(bsk_ctx *ctx, bool add);
+void spare_flush(bsk_ctx *ctx);
+void spare_give(bsk_ctx *ctx, void *p);
+hipError_t spare_take(bsk_ctx *ctx, void **out, size_t bytes);
 int grid_for(bsk_ctx *ctx, u64 items, int block);
 u64 pad_words(u32 maxlen);
 u32 env_u32(const char *name, u32 dflt);

@@ -14,7 +14,7 @@
 // Developer switches (DESIGN.md "Switches"): read from the environment ONCE, when the context is created, or again on
 // bsk_ctx_reload_options (the test suite flips them inside one process) -- never on the bsk_sketch path.
 struct BskOpts {
-    bool force_generic = false, no_mixed = false, no_dense = false, no_pk = false, no_ring = false, no_pkd = false, no_side_early = false, no_side_dense = false, ring = false, no_bin = false, no_bin_early = false, compact = false, no_tiles = false, no_tile_cache = false, no_tile_defer = false, tile_dense = false, no_group_gather = false, timing = false,
+    bool force_generic = false, no_mixed = false, no_dense = false, no_pk = false, no_ring = false, no_pkd = false, no_side_early = false, no_side_dense = false, ring = false, no_bin = false, no_bin_early = false, compact = false, no_spare = false, no_tiles = false, no_tile_cache = false, no_tile_defer = false, tile_dense = false, no_group_gather = false, timing = false,
          no_fused_translate = false, sets_no_small = false;
     int syn_margin = 2;
     u32 test_overflow = 0;   // BSK_TEST_OVERFLOW (tests): pretend an overflow flag once per call -- 1: in a timed re-run (BSK_RESIZE), 2: a class plan's part while sizing, 4: ... in a timed re-run (BSK_REPLAN_CLASS)
@@ -26,7 +26,7 @@ struct BskOpts {
     u32 class_min = 16384;   // BSK_CLASS_MIN: batches below this many reads keep one plan
     bool class_view = false;   // BSK_CLASS_VIEW: class plans always cut on the device (k_class_cut + a view of the batch), also where the host's list would do
     bool class_force = false;  // BSK_CLASS_FORCE: cut wherever the planner's choice changes, whatever the cost model says (tests: small batches)
-    u32 wpr = 0, seg = 0, dense_min = 21 /* PlannerTable::dense_min */, ring_max = 0, bin_min = 1024, waves_per_cu = 0, tile_min = 0, tile_pos = 0;  // tile_min 0: the kind's default
+    u32 wpr = 0, seg = 0, dense_min = 21 /* PlannerTable::dense_min */, ring_max = 0, ring_sel10 = 0 /* dev: ring_rows' selections per window x (w + 1), in tenths (0: PlannerTable::slab_sel_num) */, bin_min = 1024, waves_per_cu = 0, tile_min = 0, tile_pos = 0;  // tile_min 0: the kind's default
     void load();  // biosketch.hip
 };
 
@@ -53,6 +53,16 @@ struct bsk_ctx {
     u64 *h_refs = nullptr;   // pinned staging of bsk_result_fetch (refs down, offsets up), grow-only
     size_t h_refs_cap = 0;
     struct bsk_result *tile_res = nullptr;  // tile-level result of the previous tiled call, reused
+    // Result arrays a released result leaves behind (biosketch.hip: spare_give / spare_take).  hipFree + hipMalloc of the arrays of a bench-size
+    // result (10^8 reads: 32 GB) cost 1.2-3 s a call -- a hundred kernel times; a caller that releases every result and sketches the next
+    // batch gets the last ones back instead.  Bounded (SPARE_SLOTS buffers, 40 % of the device memory), flushed when any allocation of the
+    // library runs out of memory (host_internal.hpp: hipMalloc retries once after the flush) and with the context.
+    static constexpr int SPARE_SLOTS = 8;
+    struct Spare {
+        void *p = nullptr;
+        size_t bytes = 0;
+    } spare[SPARE_SLOTS];
+    size_t spare_bytes = 0, spare_limit = 0;
     // the one collective of the path (comm.cpp): an RCCL communicator over the GPUs that share a job
     void *comm = nullptr;  // ncclComm_t
     int comm_rank = 0, comm_world = 0;
@@ -195,3 +205,15 @@ static inline int fail_arg(bsk_ctx *ctx, const char *what) {
         if (e__ != hipSuccess) return fail_hip(ctx, e__, #call); \
     } while (0)
 
+bool spare_flush_all() __attribute__((visibility("hidden")));  // biosketch.hip
+// Every device allocation of the library's host code (this header is in all of its translation units): when the device is out of memory, what the contexts keep in reserve (released
+// results' arrays) goes back first, then the allocation is tried once more.
+static inline hipError_t bsk_malloc_retry(void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory && spare_flush_all()) {
+        (void)hipGetLastError();
+        e = hipMalloc(p, bytes);
+    }
+    return e;
+}
+#define hipMalloc(ptr, bytes) bsk_malloc_retry((void **)(ptr), (bytes))

@@ -359,7 +359,10 @@ int run_planned(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, int circ_
         // the list pass gives every listed read a slab of one tuple per window out of this region (a wavefront claims 64 of them): room
         // for 1.5 % of the reads -- low-complexity tails are per cent of real reads -- before the call has to be sized again
         const u64 nwin_max = b->maxlen + 2 > (u32)(p->k + p->w) ? (u64)b->maxlen - p->k - p->w + 2 : 1;
-        ovf_cap += (b->n / 64 + 64) * ((nwin_max + 15) & ~(u64)15);
+        // (the unit-row kernel lists the reads whose lane outran the ring as well: 1.6 / 2.6-3.1 / 3.0 % of the reads at 200 / 250 / 300 bases,
+        // w = 11 -- with room for 1.5 % every first call on such a batch ran the kernel twice; room for 4.5 % there)
+        const u64 list_units = pl.which == K_MIN_RING ? 3 * (b->n / 64) + 64 : b->n / 64 + 64;
+        ovf_cap += list_units * ((nwin_max + 15) & ~(u64)15);
     }
     if (pl.slab && *result && (*result)->ovf_cap > ovf_cap) ovf_cap = (*result)->ovf_cap;
     if (pl.slab && *result && ctx->in_resize) ovf_cap = std::max(ovf_cap, 2 * (*result)->ovf_cap + 65536);  // a timed re-run outgrew the region: twice the room

@@ -156,9 +156,9 @@ int ensure_binned(bsk_ctx *ctx, const bsk_batch *b, u32 lo, u32 gran, u32 mlo, u
 
 // rows of 64 tuples in a unit's slab (kernels_ring.hpp): a read selects 2 / (w + 1) of its windows; + 30 % + 6, in whole groups of four
 // rows (150 bp, w = 11: 32 rows).  A read with more goes to the exact machine's list.
-static u64 ring_rows(double nwin, int w) {
+static u64 ring_rows(double nwin, int w, double sel = PlannerTable::slab_sel_num) {
     const double nw = std::max(nwin, 1.0);
-    return ((u64)std::min(nw, std::ceil(nw * PlannerTable::slab_sel_num / (w + 1.0)) + 6.0) + 3) & ~(u64)3;
+    return ((u64)std::min(nw, std::ceil(nw * sel / (w + 1.0)) + 6.0) + 3) & ~(u64)3;
 }
 
 
@@ -270,6 +270,7 @@ int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan &p
         // blocks --, 40 at w = 7, and 41 / 42 / 45 / 46 / 50 / 53 at w = 8 .. 13 in that sweep, 5 % of k_minimizer_pkd's rate lower since its
         // flush rounds are two blocks there: 17 + 2.5 w.  Round 4's rule, 34 + 2 w, was fitted against k_minimizer_dense.  BSK_RING_MAX overrides.)
         const double ring_cap = ctx->opt.ring_max ? (double)ctx->opt.ring_max : PlannerTable::ring_cap[std::min(std::max(p->w, 0), 13)];  // (planner_table.hpp: fitted per w by scripts/fit_planner.py)
+        const double ring_sel = ctx->opt.ring_sel10 ? ctx->opt.ring_sel10 / 10.0 : (double)PlannerTable::slab_sel_num;  // (dev: BSK_RING_SEL10)
         const bool ring_wins = ctx->opt.ring ? true : exp_tuples > (double)ctx->opt.dense_min && exp_tuples <= ring_cap;
 #ifdef BSK_EXPERIMENTS  // the two measured-and-rejected minimizer kernels (make EXPERIMENTS=1; NOTEBOOK round 2): never planned without their switch
         if (!use_ascii && p->w == 11 && p->k + p->w <= 65 && b->maxlen < 32768u && nwin >= 1.0 && ctx->opt.wpr && !ctx->no_dense && slab_budget_ok(b, seg_slab) &&
@@ -294,12 +295,12 @@ int make_plan_enc(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p, Plan &p
         } else
 #endif
         if (!use_ascii && ring_minimizer_supported(p->w) && !b->alias && nwin >= 1.0 && nwin < (double)PlannerTable::ring_nwin_max && ring_wins && !ctx->opt.force_generic && !ctx->opt.no_ring &&
-            !ctx->no_syn_pk && slab_budget_ok(b, ring_rows(nwin, p->w))) {
+            !ctx->no_syn_pk && slab_budget_ok(b, ring_rows(nwin, p->w, ring_sel))) {
             pl.which = K_MIN_RING;  // w <= 13: packed window machine, unit rows through a ring of staged rows (kernels_ring.hpp)
             pl.fast_w = p->w;
             pl.fast_k = b->maxlen > ring_minimizer_short_bases() ? 1 : 0;  // (the kernel's LONG argument, for plan_name)
             pl.slab = true;
-            pl.slab_unit = (u64)64 * ring_rows(nwin, p->w);
+            pl.slab_unit = (u64)64 * ring_rows(nwin, p->w, ring_sel);
             pl.slab_total = (u64)pl.nunits * pl.slab_unit;
             pl.bin_gran = bin_gran_for(ctx, b, p->w);
             per_cu = ring_minimizer_blocks_per_cu(p->w);

@@ -317,6 +317,9 @@ int bsk_result_device_wide(const bsk_result *r, const uint64_t **first, const ui
  *   k in {SHORT, ILLEGAL, FIRST_WINDOW_TIE, HAS_NON_ACGT} (4 entries). */
 int bsk_result_digest(bsk_ctx *ctx, const bsk_result *r, uint64_t *checksum, uint64_t *n_tuples,
                       uint64_t status_counts[4]);
+/* Frees the result.  Its device arrays (a bench-size result reserves tens of GB) stay with the context for the next result of that context --
+ * hipMalloc + hipFree of them cost a hundred kernel times -- up to eight buffers and 40 % of the device memory; the reserve goes back to the
+ * device when any allocation of the library runs out of memory, and with bsk_ctx_destroy (BSK_NO_SPARE=1: freed at once). */
 void bsk_result_release(bsk_result *r);
 
 /* ---- streaming callers: bounded allocation and the end-to-end pipeline ------------------------

@@ -66,3 +66,27 @@ def test_distribution_keeps_its_length_weighted_uniform_rate(engine, oracle, uni
         res.close()
     print(name, report)
     b.close()
+
+
+@pytest.mark.parametrize("rl", [150, 250, 300, 400])
+def test_a_plain_call_costs_one_launch(engine, rl):
+    """bsk_sketch sizes and launches in one call; a launch that outgrows its overflow region is sized again and REPEATED.  Round 6 found the
+    unit-row kernel doing that on every call at 250-300 bases (it lists 2.6-3 % of such reads for the exact machine, the region had room
+    for 1.5 %): 12.8 ms per call where the kernel takes 3.4 -- and every call on a FRESH result paying hipMalloc + hipFree of the result
+    arrays (1.2-3 s at bench size; the context keeps a released result's arrays for the next one now, bsk_ctx::spare).  A steady-state
+    plain call on a fresh result may cost at most 1.5 kernel times + 1 ms here (3 10^9 bases: sizing synchronises, counts and sums)."""
+    import time
+    n = int(3e9 / rl)
+    b = engine.synth(L.ALPHA_DNA, n, rl, 0x5EED0F00 + rl)
+    p = engine.params(L.MINIMIZER, 21, w=11)
+    res, ms = engine.run_timed(b, p, 1, 3)
+    res.close()
+    kernel = min(ms) * 1e-3
+    walls = []
+    for _ in range(4):
+        t = time.time()
+        res = engine.run(b, p)
+        walls.append(time.time() - t)
+        res.close()
+    b.close()
+    assert min(walls[1:]) <= 1.5 * kernel + 1.0e-3, (rl, [round(w * 1e3, 2) for w in walls], round(kernel * 1e3, 2))
