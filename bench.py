@@ -571,6 +571,22 @@ def main():
         if not args.plumbing_only:
             out["first_call"] = dict(first_call, note="one-time costs of a context / a fresh result on this rank (wall ms): outside the timed region, reported so that a caller can see them")
         if world == 1 and kernel_ms and not args.plumbing_only:
+            # what a caller that releases every result and sketches the next batch pays per call: bsk_sketch's wall time on a FRESH result
+            # (plan + result arrays + one sizing launch + the totals read back) -- outside `value`, reported beside it.  The first of the
+            # three allocates its arrays (the timed result still holds its own); the next ones take over what the one before released.
+            try:
+                pc = []
+                for _ in range(3):
+                    t_pc = time.perf_counter()
+                    r2 = eng.run(batch, p)
+                    pc.append(round((time.perf_counter() - t_pc) * 1e3, 3))
+                    r2.close()
+                out["plain_call"] = {"ms": pc, "steady_ms": min(pc[1:]), "kernel_ms_avg": round(sum(kernel_ms) / len(kernel_ms), 4),
+                                     "note": "wall ms of bsk_sketch on a fresh result, three calls in a row, each result released before the next call "
+                                             "(the context keeps a released result's arrays for the next one: bsk_ctx::spare, NOTEBOOK 6.7)"}
+            except Exception as e:
+                out["plain_call"] = {"error": repr(e)}
+        if world == 1 and kernel_ms and not args.plumbing_only:
             # what a device-side consumer of the tuples pays on top of the sketch: bsk_result_compact (offsets scanned, the units'
             # slabs squeezed into dense CSR arrays left in HBM; sets.hip, k_gather_groups) -- outside `value`, reported beside it
             try:
