@@ -290,8 +290,8 @@ int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in, int c
             TCHK(hipMalloc(&fin->status, n ? n : 1));
             TCHK(hipMalloc(&fin->wfirst, (n ? n : 1) * 8));
             TCHK(hipMalloc(&fin->wcount, (n ? n : 1) * 8));
-            TCHK(hipMalloc(&fin->hash, need * 8));
-            TCHK(hipMalloc(&fin->pos, need * 4));
+            TCHK(spare_take(ctx, (void **)&fin->hash, need * 8));  // (a released result's arrays, if the context holds ones that fit: bsk_ctx::spare)
+            TCHK(spare_take(ctx, (void **)&fin->pos, need * 4));
             fin->cap = fin->alloc_cap = need;
         }
         rc = result_prepare(ctx, &tres_slot, nt, p->kind, 0);  // (reference words and status bytes per tile; the tuples are the sequence result's)
@@ -392,7 +392,7 @@ int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in, int c
         // nothing to stitch: the tiles' owned tuples lie back to back in tile order
     } else if (two_strand) {  // twice the room; filled after k_tile_finish (k_two_strand)
         fin->cap = fin->alloc_cap = 2 * tres->cap + 64;
-        TCHK(hipMalloc(&fin->hash, fin->cap * 8));
+        TCHK(spare_take(ctx, (void **)&fin->hash, fin->cap * 8));
     } else if (stream) {  // the tile runs are adjacent: the tile result's value array IS the sequence result
         fin->hash = tres->hash;
         fin->cap = fin->alloc_cap = tres->cap;
@@ -406,8 +406,8 @@ int sketch_tiled(bsk_ctx *ctx, const bsk_batch *b, const bsk_params *p_in, int c
         if (fin->hash) {
             cap = fin->alloc_cap;  // (the previous result's arrays)
         } else {
-            TCHK(hipMalloc(&fin->hash, cap * 8));
-            TCHK(hipMalloc(&fin->pos, cap * 4));
+            TCHK(spare_take(ctx, (void **)&fin->hash, cap * 8));  // (a released result's arrays, if the context holds ones that fit: bsk_ctx::spare)
+            TCHK(spare_take(ctx, (void **)&fin->pos, cap * 4));
             fin->cap = fin->alloc_cap = cap;
         }
         lap("result arrays");
