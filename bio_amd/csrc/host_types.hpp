@@ -139,7 +139,7 @@ struct bsk_batch {
     u32 *subset = nullptr; // reads with a non-ACGT letter, ascending (side launch of the ASCII kernels); nsub = n_nonacgt
     u64 nsub = 0;
     u8 *rflags = nullptr;
-    // length-binned view of desc / rflags (ensure_binned, biosketch.hip): built on the first sketch call that plans it, kept with the batch
+    // length-binned view of desc / rflags (ensure_binned, planner.hip): built on the first sketch call that plans it, kept with the batch
     mutable u64 *bdesc = nullptr;
     mutable u8 *bflags = nullptr;
     mutable u32 bin_gran = 0, bin_lo = 0;  // bases per length class (above bin_lo) the view was built with (0: not built)
@@ -175,7 +175,7 @@ struct bsk_result {
     u32 *pos = nullptr;
     char plan[320] = "";   // what ran: kernel name of the last launch into this result (bsk_result_plan)
     int plan_grid = 0, plan_per_cu = 0;
-    // The plan the arrays were SIZED for (run_planned, biosketch.hip): bsk_sketch_timed on an existing result repeats exactly this plan --
+    // The plan the arrays were SIZED for (run_planned, launch.hip): bsk_sketch_timed on an existing result repeats exactly this plan --
     // a fresh plan could want more rows per unit than `cap` holds (k_minimizer_ring after a fall-back to 32-row slabs) and write past it.
     bool plan_valid = false;
     bool unit_rows = false;  // the last launch wrote unit rows (BSK_REF_ROWS: k_minimizer_ring): what the group gathers of sets.hip dispatch on

@@ -61,7 +61,7 @@ struct KArgs {
     const u8 *lut;   // device codon tables of the context (kernels_translate.hpp layout)
     int pairs;       // KMER, canonical = 0: the alphabet whose PairLetter builds the second strand (bsk_alphabet; 0 = DNAredundant)
     int one_strand;  // KMER, canonical = 0, over tiles: forward codes only (k_two_strand appends the second strand per sequence)
-    // length-binned descriptors (bsk_batch::bdesc, k_bin_desc in biosketch.hip): the reads of every chunk of 4096 (64 units) are ordered
+    // length-binned descriptors (bsk_batch::bdesc, k_bin_desc in kernels_host.hpp): the reads of every chunk of 4096 (64 units) are ordered
     // by length class, so that the 64 reads of a unit end together; a binned descriptor carries the read's place in its chunk in bits
     // 12..23 (such batches hold reads of < 4096 bases), and the reference word / status byte of the read a lane holds belong at
     // out_index(), not at unit * 64 + lane
