@@ -90,3 +90,26 @@ def test_a_plain_call_costs_one_launch(engine, rl):
         res.close()
     b.close()
     assert min(walls[1:]) <= 1.5 * kernel + 1.0e-3, (rl, [round(w * 1e3, 2) for w in walls], round(kernel * 1e3, 2))
+
+
+def test_released_arrays_are_reused_and_results_do_not_change(engine, monkeypatch):
+    """The context hands a released result's arrays to the next result (bsk_ctx::spare): whatever the arrays held before must not show.
+    Three kinds over one batch, each sketched three times on fresh results -- after a result of ANOTHER kind was released in between --
+    and once more with the reserve switched off (BSK_NO_SPARE): equal digests, tuple counts and status counts."""
+    b = engine.synth(L.ALPHA_DNA, 300000, 200, 0x5EED0A11)
+    kinds = [engine.params(L.MINIMIZER, 21, w=11), engine.params(L.SYNCMER, 31, s=11), engine.params(L.NTHASH, 21), engine.params(L.KMER, 15, canonical=False)]
+    want = {}
+    for rep in range(3):
+        for i, p in enumerate(kinds):
+            res = engine.run(b, p)
+            d = res.digest()
+            res.close()
+            key = (d["checksum"], d["n_tuples"], d["first_window_tie"], d["has_non_acgt"])
+            assert want.setdefault(i, key) == key, (rep, i)
+    monkeypatch.setenv("BSK_NO_SPARE", "1")
+    for i, p in enumerate(kinds):
+        res = engine.run(b, p)
+        d = res.digest()
+        res.close()
+        assert want[i] == (d["checksum"], d["n_tuples"], d["first_window_tie"], d["has_non_acgt"]), i
+    b.close()
